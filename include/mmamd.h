@@ -1,0 +1,147 @@
+/*
+ * mmamd.h — C-ABI of libmmamd.so: the MI355X (gfx950) kernels behind the dual-encoder contrastive
+ * forward + loss path of facebookresearch/multimodal (TorchMultimodal).
+ *
+ * The reference has no FFI of its own (it is pure Python over ATen); the boundary it
+ * exposes is the nn.Module API.  Each entry point below therefore replaces one group of ATen calls
+ * that the reference's Python issues on this path; the citation after each prototype names the
+ * reference call site (paths relative to the reference checkout).  The host-side mirror of the
+ * nn.Module API that binds these symbols with ctypes lives in multimodal_amd/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; nothing is copied or
+ *     synchronised by the library; all work is enqueued on `stream` (a hipStream_t, 0 = null stream)
+ *   - no allocation, no host sync: every entry point is legal inside hipStreamBeginCapture
+ *   - return value: 0 on success; >0 = hipError_t of the failed launch; <0 = MMAMD_E_* argument error.
+ *     mmamd_last_error() returns a thread-local description of the last non-zero return.
+ *   - row-major everywhere; "ld*" are leading dimensions in ELEMENTS
+ *   - dtype codes: MMAMD_F32 = 0, MMAMD_BF16 = 1
+ */
+#ifndef MMAMD_H_
+#define MMAMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMAMD_ABI_VERSION 1
+
+#define MMAMD_F32 0
+#define MMAMD_BF16 1
+
+#define MMAMD_ACT_NONE 0
+#define MMAMD_ACT_QUICKGELU 1 /* x * sigmoid(1.702 x): modules/layers/activation.py:24-25 */
+#define MMAMD_ACT_GELU_ERF 2  /* nn.GELU (FLAVA: models/flava/model.py:79) */
+
+#define MMAMD_E_BADARG (-1)
+#define MMAMD_E_UNSUPPORTED (-2)
+#define MMAMD_E_ALIGN (-3)
+
+#define MMAMD_REDUCE_MEAN 0
+#define MMAMD_REDUCE_SUM 1
+
+typedef void* mmamd_stream_t; /* hipStream_t */
+
+int mmamd_abi_version(void);
+const char* mmamd_last_error(void);
+
+/* Select a GEMM kernel variant at run time (0 = default).  Test/bench hook; variants are bit-compatible
+ * in what they compute, they differ in tiling/pipelining only. */
+int mmamd_set_gemm_variant(int variant);
+int mmamd_get_gemm_variant(void);
+
+/* --- K2: row LayerNorm ----------------------------------------------------------------------
+ * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta, statistics in fp32 (biased variance).
+ * Replaces nn.LayerNorm norm1/norm2 inside torch's TransformerEncoderLayer created at
+ * models/clip/image_encoder.py:65-73 / text_encoder.py:58-65, and Fp32LayerNorm
+ * (modules/layers/normalizations.py:13-25) at image_encoder.py:106, text_encoder.py:125. */
+int mmamd_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                    int y_dtype, int rows, int d, float eps, mmamd_stream_t stream);
+
+/* --- K3/K5/K6: C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]) -------------------
+ * A, W bf16; fp32 accumulate on MFMA; bias fp32 or NULL; residual (dtype = out_dtype) or NULL, may
+ * alias C.  Requires K % 64 == 0, lda/ldw % 8 == 0, ldc/ldr % 4 == 0, 16-byte aligned bases.
+ * Replaces F.linear in-projection (torch functional `_in_projection_packed`), out_proj + residual,
+ * linear1 + SiLU, linear2 + residual of the encoder layers (call sites image_encoder.py:108,
+ * text_encoder.py:121), and the patch-embedding conv as a GEMM (image_encoder.py:91). */
+int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias,
+                    const void* residual, int ldr, void* C, int ldc, int out_dtype, int M, int N,
+                    int K, int act, mmamd_stream_t stream);
+
+/* --- K4: multi-head self-attention forward ---------------------------------------------------
+ * qkv: bf16 [B*S, 3*H*64] rows = tokens, columns = [q | k | v], each H heads of 64;  out: bf16
+ * [B*S, H*64] = softmax(q k^T * scale (+causal)) v, heads merged.  Head dim is 64 for every
+ * model on the path.  Replaces F.scaled_dot_product_attention reached from nn.MultiheadAttention
+ * (image_encoder.py:108 non-causal; text_encoder.py:121 is_causal=True). */
+int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
+                        mmamd_stream_t stream);
+
+/* --- K1 front end: non-overlapping patch extraction ("im2col" of a stride==kernel conv) -------
+ * images [B,C,HW,HW] (f32 or bf16) -> patches bf16 [B*(HW/P)^2, Kpad], column k = (c*P+py)*P+px,
+ * columns >= C*P*P zero-filled.  Replaces the gather half of nn.Conv2d at image_encoder.py:50-56,91. */
+int mmamd_patchify(const void* images, int img_dtype, void* patches, int B, int C, int HW, int P,
+                   int Kpad, mmamd_stream_t stream);
+
+/* --- K1 back end: prepend CLS, add positional embedding, ln_pre -------------------------------
+ * patch_emb [B*G2, d] (pe_dtype) ; cls [d], pos [(G2+1), d], gamma/beta [d] fp32 -> x fp32 [B*(G2+1), d].
+ * Replaces torch.cat/+/ln_pre at image_encoder.py:98-106. */
+int mmamd_vit_assemble_ln(const void* patch_emb, int pe_dtype, const float* cls, const float* pos,
+                          const float* gamma, const float* beta, float eps, float* x, int B, int G2,
+                          int d, mmamd_stream_t stream);
+
+/* --- K8: token embedding gather + positional embedding ----------------------------------------
+ * x[b,s,:] = table[ids[b,s],:] + pos[s,:]  (fp32 out).  Returns the launch status only; ids are
+ * range-clamped on device (out-of-range ids are a caller error, as with nn.Embedding).
+ * Replaces text_encoder.py:118-119. */
+int mmamd_embed_tokens(const int64_t* ids, const void* table, int table_dtype, const float* pos,
+                       float* x, int B, int S, int d, int vocab, mmamd_stream_t stream);
+
+/* --- K7/K9/K10: pooled row -> LayerNorm -> projection (-> L2 normalize) -----------------------
+ * row(b) = x[b, idx(b), :] with idx(b) = 0 when ids == NULL (CLS, image_encoder.py:111) or
+ * argmax_s ids[b,s] (first maximum; text_encoder.py:129-132).  out[b,e] = sum_k LN(row)[k] *
+ * proj[k*proj_sk + e*proj_se]  (image: projection [d,E] -> sk=E,se=1; text: Linear weight [E,d] ->
+ * sk=1,se=d).  normalize != 0 additionally applies F.normalize (models/clip/model.py:72-73). */
+int mmamd_pool_ln_proj(const float* x, int S, int d, const int64_t* ids, const float* gamma,
+                       const float* beta, float eps, const float* proj, int proj_sk, int proj_se,
+                       float* out, int B, int E, int normalize, mmamd_stream_t stream);
+
+/* F.normalize(x, p=2, dim=1, eps) on [rows,d]  (models/clip/model.py:72-73). */
+int mmamd_l2_normalize(const void* x, int x_dtype, void* y, int y_dtype, int rows, int d, float eps,
+                       mmamd_stream_t stream);
+
+/* --- K13: in-place clamp of the 0-dim logit_scale parameter ----------------------------------
+ * (modules/losses/contrastive_loss_with_temperature.py:193). */
+int mmamd_clamp_scalar(float* p, int has_min, float lo, int has_max, float hi, mmamd_stream_t stream);
+
+/* --- K11/K12: logits + cross entropy ----------------------------------------------------------
+ * a,b fp32 [B,E] local features; a_all,b_all fp32 [WB,E] gathered features (row stride ld_all
+ * elements; pass a/b and ld_all=E for the single-process case); logit_scale: device scalar (log T).
+ *   logits_a[B,WB] = (a . b_all^T) * exp(logit_scale);  logits_b[B,WB] = (b . a_all^T) * exp(..)
+ *   labels[i] = label_offset + i;  row_mask (uint8 [B], NULL = all rows) drops rows from the loss
+ *   out3 = {loss, loss_a, loss_b};  ws = scratch of at least 2*B floats.
+ * Replaces contrastive_loss_with_temperature.py:81,90-107 (matmul x2, cross_entropy x2, mean). */
+int mmamd_contrastive_fwd(const float* a, const float* b, const float* a_all, const float* b_all,
+                          int ld_all, const float* logit_scale, int B, int WB, int E,
+                          int label_offset, const uint8_t* row_mask, float label_smoothing,
+                          int reduction, float* logits_a, float* logits_b, float* out3, float* ws,
+                          mmamd_stream_t stream);
+
+/* Elementwise dtype conversion helper (fp32 <-> bf16), n elements. Used for weight packing. */
+int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
+                  mmamd_stream_t stream);
+
+/* --- timing helper for bench.py: HIP events on the SAME stream the kernels run on ------------
+ * mmamd_timer_create returns an opaque handle (two hipEvents); start/stop record on `stream`;
+ * elapsed_ms synchronises on the stop event (host-side call, not capturable). */
+void* mmamd_timer_create(void);
+void mmamd_timer_destroy(void* t);
+int mmamd_timer_start(void* t, mmamd_stream_t stream);
+int mmamd_timer_stop(void* t, mmamd_stream_t stream);
+int mmamd_timer_elapsed_ms(void* t, float* ms_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMAMD_H_ */

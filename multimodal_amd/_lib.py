@@ -1,0 +1,90 @@
+"""ctypes binding of libmmamd.so (the C-ABI declared in include/mmamd.h).
+
+The library is the product: there is NO fallback.  If the shared object is missing, cannot be loaded, or
+lacks a symbol, `lib()` raises — loudly — instead of routing anything through PyTorch eager ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("MMAMD_LIB", _PKG / "lib" / "libmmamd.so"))
+
+ABI_VERSION = 1
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
+REDUCE_MEAN, REDUCE_SUM = 0, 1
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> (restype, argtypes); must list every prototype of include/mmamd.h (tests/test_capi_symbols.py checks)
+PROTOTYPES = {
+    "mmamd_abi_version": (_i, []),
+    "mmamd_last_error": (C.c_char_p, []),
+    "mmamd_set_gemm_variant": (_i, [_i]),
+    "mmamd_get_gemm_variant": (_i, []),
+    "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "mmamd_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mmamd_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmamd_vit_assemble_ln": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
+    "mmamd_embed_tokens": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mmamd_pool_ln_proj": (_i, [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "mmamd_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "mmamd_clamp_scalar": (_i, [_vp, _i, _f, _i, _f, _vp]),
+    "mmamd_contrastive_fwd": (
+        _i,
+        [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "mmamd_convert": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+    "mmamd_timer_create": (_vp, []),
+    "mmamd_timer_destroy": (None, [_vp]),
+    "mmamd_timer_start": (_i, [_vp, _vp]),
+    "mmamd_timer_stop": (_i, [_vp, _vp]),
+    "mmamd_timer_elapsed_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+}
+
+
+class MmamdError(RuntimeError):
+    pass
+
+
+_LIB: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the bound library; raise MmamdError if it is unusable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not LIB_PATH.exists():
+        raise MmamdError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m multimodal_amd.build` "
+            "(or __graft_entry__.build()). There is no eager/CPU fallback for this path."
+        )
+    try:
+        handle = C.CDLL(str(LIB_PATH))
+    except OSError as e:  # missing libamdhip64 etc.
+        raise MmamdError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise MmamdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.mmamd_abi_version()
+    if got != ABI_VERSION:
+        raise MmamdError(f"{LIB_PATH} has ABI version {got}, host code expects {ABI_VERSION}; rebuild it")
+    _LIB = handle
+    return handle
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().mmamd_last_error()
+        raise MmamdError(f"{what} failed (status {status}): {msg.decode() if msg else '?'}")

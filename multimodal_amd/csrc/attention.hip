@@ -1,0 +1,210 @@
+// attention.hip — multi-head self-attention forward, head dim 64, S <= 288 (gfx950).
+//
+// Every sequence on the path is short (77 text, 50/197/257 ViT, 275 FLAVA fusion), so the whole K and V
+// of one (batch, head) fit in LDS (<= 2 x 41 KiB): they are staged ONCE per workgroup and every query tile
+// of that head re-reads them from LDS only.
+//
+// One workgroup (4 waves) per (batch, head).  K is staged row-major (padded rows, conflict-free
+// ds_read_b128), V is staged TRANSPOSED (V^T[d][key], row stride = 2 (mod 4) dwords -> conflict-free
+// ds_read_b64).  Each wave owns 32 query rows at a time and walks the keys in tiles of 32 with a running
+// max / running sum (flash-style), which keeps the live state at ~110 VGPRs (4 waves per SIMD) instead of
+// the ~450 a materialised [32 x S] score strip costs.  BOTH products are computed swapped:
+//     S^T = K . Q^T   (MFMA A = K rows,   B = Q rows)  -> lane owns ONE query, 16 keys of the tile:
+//                      row max / row sum are in-lane reductions + one cross-half shuffle
+//     O^T = V^T . P^T (MFMA A = V^T rows, B = P rows)  -> the P^T fragment is exactly the packed bf16 score
+//                      registers the lane already holds (no LDS round trip, no permute), and the lane ends
+//                      up with 4 consecutive output channels of its query row -> 8-byte stores.
+// The MFMA sums over its 16 k-slots; as long as slot j of lane-half h carries the SAME key for both
+// operands the order of keys inside a slot group is irrelevant, which is what makes the register reuse
+// above legal.  exp2 with log2(e)/sqrt(dh) folded into the score scale.
+// Replaces F.scaled_dot_product_attention under nn.MultiheadAttention (reference call sites:
+// models/clip/image_encoder.py:108, models/clip/text_encoder.py:121 with is_causal=True).
+#include "common.h"
+
+namespace mmamd {
+
+constexpr int kDh = 64;
+constexpr int kKStride = 72;  // bf16 elements per K row in LDS (144 B: 16-B aligned, 9 slots -> conflict-free)
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+template <int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                            int S, int H, float scale_log2e) {
+  constexpr int SP = NKT * 32;   // padded key count
+  constexpr int VS = SP + 4;     // V^T row stride (elements): (SP+4)/2 dwords = 2 (mod 4)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);                       // [SP][kKStride]
+  bf16* Vt = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);   // [64][VS]
+
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * kDh;
+  const size_t row_stride = (size_t)3 * D;
+  const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- stage K (row-major) and V (transposed); rows >= S are zero so padded keys contribute exact 0
+  for (int r = tid >> 3; r < SP; r += 32) {
+    const int c = tid & 7;
+    bf16x8 kv, vv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+    if (r < S) {
+      kv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + D + c * 8);
+      vv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + 2 * D + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VS + r] = vv[j];
+  }
+  __syncthreads();
+
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nqt = (S + 31) >> 5;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    // ---- Q fragments (B operand): row q, channels 16t + 8*half .. +7
+    const int q = qt * 32 + l31;
+    const int qc = q < S ? q : S - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * row_stride + 16 * t + 8 * half);
+
+    float m = -INFINITY, lsum = 0.f;  // running max (log2 domain) and running sum of this lane's query row
+    f32x16 ot[2];                     // ot[nt][r] = O[q][channel nt*32 + (r&3) + 8*(r>>2) + 4*half]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+
+    const int kt_end = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
+#pragma unroll 1
+    for (int kt = 0; kt < kt_end; ++kt) {
+      // ---- S^T tile: st[r] = score(query q, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * t);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], st, 0, 0, 0);
+      }
+      // ---- scale, mask (only tiles that can contain dead keys pay for it), tile max
+      const bool need_mask = (kt * 32 + 32 > S) || (CAUSAL && kt == qt);
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = st[r] * scale_log2e;
+        if (need_mask) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (key >= S || (CAUSAL && key > q)) v = -INFINITY;
+        }
+        st[r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      // key kt*32 is alive for every row of this tile pair (kt <= qt when causal; key 0 < S), so once a
+      // tile has been seen m_new is finite; alpha = exp2(-inf - finite) = 0 on the first tile
+      const float m_new = fmaxf(m, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      m = m_new;
+      // ---- P = exp2(s - m), packed to bf16 pairs: pk[2g], pk[2g+1] = the 4 keys of accumulator group g
+      uint32_t pk[8];
+      float psum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          e[j] = __builtin_amdgcn_exp2f(st[4 * g + j] - m_new);
+          psum += e[j];
+        }
+        bf16x2 p0, p1;
+        p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+        pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
+        pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+      }
+      lsum = lsum * alpha + psum;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[nt][r] *= alpha;
+      // ---- O^T += V^T . P^T over this tile's 32 keys (two MFMA k-groups of 16)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        // slots 0-3 = keys key0..key0+3, slots 4-7 = keys key0+8..key0+11 (per lane half), both operands
+        const int key0 = kt * 32 + 16 * jj + 4 * half;
+        u32x4 pw;
+        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16* vrow = Vt + (nt * 32 + l31) * VS + key0;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+          u32x4 vw;
+          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
+          ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[nt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- normalise and store: lane owns row q, channels nt*32 + 8g + 4*half + {0..3}
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;
+    if (q < S) {
+      bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = ot[nt][4 * g + j] * inv;
+          store4(orow + nt * 32 + 8 * g + 4 * half, o);
+        }
+    }
+  }
+}
+
+template <int NKT, bool CAUSAL>
+static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st) {
+  constexpr int SP = NKT * 32;
+  constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2;
+  auto kern = attention_fwd_kernel<NKT, CAUSAL>;
+  static bool attr_done = false;
+  if (!attr_done && smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), smem, st, (const bf16*)qkv, (bf16*)out, S, H,
+                     scale * 1.4426950408889634f);
+  return launch_status("attention_fwd");
+}
+
+}  // namespace mmamd
+
+using namespace mmamd;
+
+extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
+                                   mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(qkv && out && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention: bad argument");
+  MMAMD_CHECK_ARG(S <= 288, MMAMD_E_UNSUPPORTED, "attention: S=%d > 288 not supported (single-pass LDS kernel)", S);
+  MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out), MMAMD_E_ALIGN, "attention: pointers must be 16-byte aligned");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nkt = (S + 31) / 32;
+#define ATTN_CASE(N)                                                              \
+  case N:                                                                         \
+    return causal ? launch_attn<N, true>(qkv, out, B, S, H, scale, st)            \
+                  : launch_attn<N, false>(qkv, out, B, S, H, scale, st);
+  switch (nkt) {
+    ATTN_CASE(1) ATTN_CASE(2) ATTN_CASE(3) ATTN_CASE(4) ATTN_CASE(5) ATTN_CASE(6) ATTN_CASE(7) ATTN_CASE(8) ATTN_CASE(9)
+  }
+#undef ATTN_CASE
+  MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention: unsupported S=%d", S);
+}

@@ -1,0 +1,434 @@
+// rowops.hip — HBM-bound row kernels of the dual-encoder path (gfx950).
+//   layernorm, ViT assemble(+CLS,+pos)+ln_pre, token embedding, patch extraction,
+//   pooled-row LN + projection (+L2 normalize), L2 normalize, scalar clamp, dtype convert.
+// All are one-wave-per-row (64 lanes, 16-byte vector accesses) unless noted; none reshapes work
+// into a GEMM — the roofline that bounds them is HBM bandwidth.
+#include "common.h"
+
+namespace mmamd {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row cached in registers (MAXV float4 per lane), two-pass statistics
+// ---------------------------------------------------------------------------------------------
+template <typename TIN, typename TOUT, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        TOUT* __restrict__ y, int rows, int d,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int d4 = d >> 2;
+  const TIN* xr = x + (size_t)row * d;
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+      v[i] = load4(xr + 4 * c);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = v[i][j] - mean;
+        q += t * t;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+  TOUT* yr = y + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+      const f32x4 g = load4(gamma + 4 * c), b = load4(beta + 4 * c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+      store4(yr + 4 * c, o);
+    }
+  }
+}
+
+template <typename TIN, typename TOUT>
+static int launch_layernorm(const void* x, const float* g, const float* b, void* y, int rows, int d,
+                            float eps, hipStream_t st) {
+  const int d4 = d / 4;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (d4 <= 128)
+    hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 2>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
+  else if (d4 <= 256)
+    hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 4>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 8>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
+  return launch_status("layernorm");
+}
+
+// ---------------------------------------------------------------------------------------------
+// ViT assemble: x[b,0]=cls+pos[0]; x[b,1+i]=patch_emb[b,i]+pos[1+i]; then ln_pre  -> fp32
+// ---------------------------------------------------------------------------------------------
+template <typename TPE, int MAXV>
+__global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const TPE* __restrict__ pe,
+                                                              const float* __restrict__ cls,
+                                                              const float* __restrict__ pos,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              float eps, float* __restrict__ x,
+                                                              int B, int G2, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int S = G2 + 1;
+  if (row >= B * S) return;
+  const int b = row / S, s = row - b * S;
+  const int d4 = d >> 2;
+  f32x4 v[MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+      f32x4 t = (s == 0) ? load4(cls + 4 * c) : load4(pe + ((size_t)b * G2 + (s - 1)) * d + 4 * c);
+      const f32x4 p = load4(pos + (size_t)s * d + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] += p[j];
+      v[i] = t;
+      sum += (t[0] + t[1]) + (t[2] + t[3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(sum) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = v[i][j] - mean;
+        q += t * t;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+  float* xr = x + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+      const f32x4 g = load4(gamma + 4 * c), bb = load4(beta + 4 * c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+      store4(xr + 4 * c, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// token embedding gather + positional embedding  -> fp32
+// ---------------------------------------------------------------------------------------------
+template <typename TT>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __restrict__ ids,
+                                                           const TT* __restrict__ table,
+                                                           const float* __restrict__ pos,
+                                                           float* __restrict__ x, int rows, int S,
+                                                           int d, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int s = row % S;
+  long long id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const TT* tr = table + (size_t)id * d;
+  const float* pr = pos + (size_t)s * d;
+  float* xr = x + (size_t)row * d;
+  for (int c = lane; c < (d >> 2); c += 64) {
+    f32x4 t = load4(tr + 4 * c);
+    const f32x4 p = load4(pr + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] += p[j];
+    store4(xr + 4 * c, t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// patch extraction: out[(b*G+gy)*G+gx, k=(c*P+py)*P+px] = img[b,c,gy*P+py,gx*P+px]; zero pad k>=C*P*P
+// one thread per 4 consecutive k
+// ---------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ img,
+                                                       bf16* __restrict__ out, int B, int C, int HW,
+                                                       int P, int Kpad) {
+  const int G = HW / P;
+  const int K = C * P * P;
+  const int kq = Kpad >> 2;  // groups of 4 per row
+  const size_t total = (size_t)B * G * G * kq;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (size_t)gridDim.x * blockDim.x) {
+    const int k0 = (int)(t % kq) * 4;
+    const size_t prow = t / kq;
+    const int gx = (int)(prow % G);
+    const int gy = (int)((prow / G) % G);
+    const int b = (int)(prow / ((size_t)G * G));
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((P & 3) == 0 && k0 + 3 < K) {
+      const int c = k0 / (P * P), r = k0 - c * P * P, py = r / P, px = r - py * P;
+      v = load4(img + (((size_t)b * C + c) * HW + (gy * P + py)) * HW + gx * P + px);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        if (k < K) {
+          const int c = k / (P * P), r = k - c * P * P, py = r / P, px = r - py * P;
+          v[j] = to_f32(img[(((size_t)b * C + c) * HW + (gy * P + py)) * HW + gx * P + px]);
+        }
+      }
+    }
+    store4(out + prow * Kpad + k0, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooled row -> LN -> projection -> (L2 normalize).  One 256-thread block per sample.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void pool_ln_proj_kernel(
+    const float* __restrict__ x, int S, int d, const int64_t* __restrict__ ids,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const float* __restrict__ proj, int sk, int se, float* __restrict__ out, int E, int normalize) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // h[d] | o[E] | red[4] | idx
+  float* h = sm;
+  float* o = sm + d;
+  float* red = o + E;
+  int* sidx = reinterpret_cast<int*>(red + 4);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+  if (wv == 0) {
+    int best_i = 0;
+    if (ids != nullptr) {
+      long long best_v = INT64_MIN;
+      best_i = 0x7fffffff;
+      for (int s = lane; s < S; s += 64) {
+        const long long v = ids[(size_t)b * S + s];
+        if (v > best_v) { best_v = v; best_i = s; }  // ascending s: keeps the first maximum
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const long long ov = __shfl_xor(best_v, off);
+        const int oi = __shfl_xor(best_i, off);
+        if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+      }
+    }
+    if (lane == 0) *sidx = best_i;
+  }
+  __syncthreads();
+  const float* xr = x + ((size_t)b * S + *sidx) * d;
+
+  float s1 = 0.f;
+  for (int k = tid; k < d; k += 256) { const float v = xr[k]; h[k] = v; s1 += v; }
+  const float mean = block_sum_256(s1, red) / (float)d;
+  float s2 = 0.f;
+  for (int k = tid; k < d; k += 256) { const float t = h[k] - mean; s2 += t * t; }
+  const float rstd = 1.0f / sqrtf(block_sum_256(s2, red) / (float)d + eps);
+  for (int k = tid; k < d; k += 256) h[k] = (h[k] - mean) * rstd * gamma[k] + beta[k];
+  __syncthreads();
+
+  if (se == 1) {  // proj [d,E] row-major: thread per output column, coalesced across threads
+    for (int e = tid; e < E; e += 256) {
+      float acc = 0.f;
+      for (int k = 0; k < d; ++k) acc = fmaf(h[k], proj[(size_t)k * sk + e], acc);
+      o[e] = acc;
+    }
+  } else {  // proj [E,d] (Linear weight): wave per output, lanes stride over k
+    for (int e = wv; e < E; e += 4) {
+      float acc = 0.f;
+      for (int k = lane; k < d; k += 64) acc = fmaf(h[k], proj[(size_t)e * se + (size_t)k * sk], acc);
+      acc = wave_sum(acc);
+      if (lane == 0) o[e] = acc;
+    }
+  }
+  __syncthreads();
+  float scale = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+    for (int e = tid; e < E; e += 256) ss += o[e] * o[e];
+    const float n = sqrtf(block_sum_256(ss, red));
+    scale = 1.0f / fmaxf(n, 1e-12f);
+  }
+  for (int e = tid; e < E; e += 256) out[(size_t)b * E + e] = o[e] * scale;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const TI* __restrict__ x, TO* __restrict__ y,
+                                                           int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TI* xr = x + (size_t)row * d;
+  float ss = 0.f;
+  for (int k = lane; k < d; k += 64) { const float v = to_f32(xr[k]); ss += v * v; }
+  const float sc = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
+  TO* yr = y + (size_t)row * d;
+  for (int k = lane; k < d; k += 64) yr[k] = (TO)(to_f32(xr[k]) * sc);
+}
+
+__global__ void clamp_scalar_kernel(float* p, int has_min, float lo, int has_max, float hi) {
+  float v = *p;
+  if (has_min) v = fmaxf(v, lo);
+  if (has_max) v = fminf(v, hi);
+  *p = v;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert_kernel(const TI* __restrict__ s, TO* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = (TO)to_f32(s[i]);
+}
+
+}  // namespace mmamd
+
+using namespace mmamd;
+
+extern "C" int mmamd_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta,
+                               void* y, int y_dtype, int rows, int d, float eps, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && gamma && beta && y && rows >= 0 && d > 0, MMAMD_E_BADARG, "layernorm: bad argument");
+  MMAMD_CHECK_ARG(d % 4 == 0 && d <= 8192, MMAMD_E_UNSUPPORTED, "layernorm: d=%d must be a multiple of 4 and <= 8192", d);
+  MMAMD_CHECK_ARG(aligned16(x) && aligned16(gamma) && aligned16(beta) && (y_dtype == MMAMD_F32 ? aligned16(y) : ((uintptr_t)y & 7) == 0),
+                  MMAMD_E_ALIGN, "layernorm: pointers must be 16-byte aligned");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_BF16) return launch_layernorm<float, bf16>(x, gamma, beta, y, rows, d, eps, st);
+  if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_F32) return launch_layernorm<float, float>(x, gamma, beta, y, rows, d, eps, st);
+  if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_BF16) return launch_layernorm<bf16, bf16>(x, gamma, beta, y, rows, d, eps, st);
+  if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_F32) return launch_layernorm<bf16, float>(x, gamma, beta, y, rows, d, eps, st);
+  MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "layernorm: bad dtype code");
+}
+
+extern "C" int mmamd_vit_assemble_ln(const void* pe, int pe_dtype, const float* cls, const float* pos,
+                                     const float* gamma, const float* beta, float eps, float* x, int B,
+                                     int G2, int d, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(pe && cls && pos && gamma && beta && x && B >= 0 && G2 > 0 && d > 0, MMAMD_E_BADARG, "vit_assemble_ln: bad argument");
+  MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "vit_assemble_ln: d=%d must be a multiple of 4 and <= 2048", d);
+  if (B == 0) return 0;
+  const int rows = B * (G2 + 1);
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int d4 = d / 4;
+#define LAUNCH_ASM(T, MV) hipLaunchKernelGGL((vit_assemble_ln_kernel<T, MV>), grid, block, 0, st, (const T*)pe, cls, pos, gamma, beta, eps, x, B, G2, d)
+  if (pe_dtype == MMAMD_BF16) {
+    if (d4 <= 128) LAUNCH_ASM(bf16, 2); else if (d4 <= 256) LAUNCH_ASM(bf16, 4); else LAUNCH_ASM(bf16, 8);
+  } else if (pe_dtype == MMAMD_F32) {
+    if (d4 <= 128) LAUNCH_ASM(float, 2); else if (d4 <= 256) LAUNCH_ASM(float, 4); else LAUNCH_ASM(float, 8);
+  } else {
+    MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "vit_assemble_ln: bad dtype code");
+  }
+#undef LAUNCH_ASM
+  return launch_status("vit_assemble_ln");
+}
+
+extern "C" int mmamd_embed_tokens(const int64_t* ids, const void* table, int table_dtype, const float* pos,
+                                  float* x, int B, int S, int d, int vocab, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(ids && table && pos && x && B >= 0 && S > 0 && d > 0 && vocab > 0, MMAMD_E_BADARG, "embed_tokens: bad argument");
+  MMAMD_CHECK_ARG(d % 4 == 0, MMAMD_E_UNSUPPORTED, "embed_tokens: d=%d must be a multiple of 4", d);
+  if (B == 0) return 0;
+  const int rows = B * S;
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (table_dtype == MMAMD_F32)
+    hipLaunchKernelGGL((embed_tokens_kernel<float>), grid, block, 0, st, ids, (const float*)table, pos, x, rows, S, d, vocab);
+  else if (table_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((embed_tokens_kernel<bf16>), grid, block, 0, st, ids, (const bf16*)table, pos, x, rows, S, d, vocab);
+  else
+    MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "embed_tokens: bad dtype code");
+  return launch_status("embed_tokens");
+}
+
+extern "C" int mmamd_patchify(const void* images, int img_dtype, void* patches, int B, int C, int HW, int P,
+                              int Kpad, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(images && patches && B >= 0 && C > 0 && HW > 0 && P > 0 && HW % P == 0, MMAMD_E_BADARG, "patchify: bad argument");
+  MMAMD_CHECK_ARG(Kpad % 4 == 0 && Kpad >= C * P * P, MMAMD_E_BADARG, "patchify: Kpad=%d must be a multiple of 4 and >= C*P*P", Kpad);
+  if (B == 0) return 0;
+  const int G = HW / P;
+  const size_t total = (size_t)B * G * G * (Kpad / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (img_dtype == MMAMD_F32)
+    hipLaunchKernelGGL((patchify_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)images, (bf16*)patches, B, C, HW, P, Kpad);
+  else if (img_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(blocks), dim3(256), 0, st, (const bf16*)images, (bf16*)patches, B, C, HW, P, Kpad);
+  else
+    MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "patchify: bad dtype code");
+  return launch_status("patchify");
+}
+
+extern "C" int mmamd_pool_ln_proj(const float* x, int S, int d, const int64_t* ids, const float* gamma,
+                                  const float* beta, float eps, const float* proj, int proj_sk, int proj_se,
+                                  float* out, int B, int E, int normalize, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && gamma && beta && proj && out && S > 0 && d > 0 && B >= 0 && E > 0, MMAMD_E_BADARG, "pool_ln_proj: bad argument");
+  MMAMD_CHECK_ARG(proj_se == 1 || proj_sk == 1, MMAMD_E_UNSUPPORTED, "pool_ln_proj: projection must be contiguous along k or e");
+  const size_t smem = sizeof(float) * ((size_t)d + E + 4) + 16;
+  MMAMD_CHECK_ARG(smem <= 64 * 1024, MMAMD_E_UNSUPPORTED, "pool_ln_proj: d+E too large");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(pool_ln_proj_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, x, S, d, ids, gamma, beta, eps,
+                     proj, proj_sk, proj_se, out, E, normalize);
+  return launch_status("pool_ln_proj");
+}
+
+extern "C" int mmamd_l2_normalize(const void* x, int x_dtype, void* y, int y_dtype, int rows, int d, float eps,
+                                  mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && y && rows >= 0 && d > 0, MMAMD_E_BADARG, "l2_normalize: bad argument");
+  if (rows == 0) return 0;
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_F32)
+    hipLaunchKernelGGL((l2_normalize_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)y, rows, d, eps);
+  else if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((l2_normalize_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)x, (bf16*)y, rows, d, eps);
+  else if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_F32)
+    hipLaunchKernelGGL((l2_normalize_kernel<bf16, float>), grid, block, 0, st, (const bf16*)x, (float*)y, rows, d, eps);
+  else if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((l2_normalize_kernel<float, bf16>), grid, block, 0, st, (const float*)x, (bf16*)y, rows, d, eps);
+  else
+    MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "l2_normalize: bad dtype code");
+  return launch_status("l2_normalize");
+}
+
+extern "C" int mmamd_clamp_scalar(float* p, int has_min, float lo, int has_max, float hi, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(p != nullptr, MMAMD_E_BADARG, "clamp_scalar: null pointer");
+  hipLaunchKernelGGL(clamp_scalar_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p, has_min, lo, has_max, hi);
+  return launch_status("clamp_scalar");
+}
+
+extern "C" int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(src && dst && n >= 0, MMAMD_E_BADARG, "convert: bad argument");
+  if (n == 0) return 0;
+  const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == MMAMD_F32 && dst_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16*)dst, n);
+  else if (src_dtype == MMAMD_BF16 && dst_dtype == MMAMD_F32)
+    hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, (float*)dst, n);
+  else
+    MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "convert: unsupported dtype pair");
+  return launch_status("convert");
+}

@@ -1,0 +1,102 @@
+"""Parameter containers + HIP execution of the pre-norm transformer stack CLIP builds from
+torch.nn.TransformerEncoder(Layer) (reference: models/clip/image_encoder.py:65-77, text_encoder.py:58-66).
+
+The containers reproduce torch's parameter NAMES (so published checkpoints and the reference's state_dicts load
+with strict=True: `encoder.layers.N.self_attn.in_proj_weight`, `...out_proj.weight`, `linear1`, `linear2`,
+`norm1`, `norm2`) and torch's default INITIALISATION ORDER (so a seeded construction yields bit-identical
+initial weights to the reference — including nn.TransformerEncoder's deep-copy of ONE initialised layer into
+all N layers).  Their forward is not torch's: `TransformerStack.run` drives the MI355X kernels:
+
+    per layer:  LN -> QKV GEMM(+bias) -> attention -> out-proj GEMM(+bias,+residual)
+                LN -> up GEMM(+bias,QuickGELU) -> down GEMM(+bias,+residual)
+
+The residual stream x is kept in fp32 in HBM (accumulated in place by the residual epilogues); everything
+that feeds an MFMA is bf16.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+from torch import nn
+
+from ... import ops
+from ..._packing import PackedCache
+
+HEAD_DIM = 64  # every model on the path (CLIP B/32, B/16, L/14 and both text towers) has 64-wide heads
+
+
+class SelfAttentionParams(nn.Module):
+    """Parameters of nn.MultiheadAttention (packed in-projection), same names / same default init."""
+
+    def __init__(self, embed_dim: int, num_heads: int) -> None:
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)  # consumes the RNG exactly like torch's out_proj
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.in_proj_bias, 0.0)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class EncoderLayerParams(nn.Module):
+    """Parameters of nn.TransformerEncoderLayer(norm_first=True, activation=SiLU())."""
+
+    def __init__(self, d_model: int, nhead: int, dim_feedforward: int, layer_norm_eps: float = 1e-5) -> None:
+        super().__init__()
+        self.self_attn = SelfAttentionParams(d_model, nhead)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+
+
+class TransformerStack(nn.Module):
+    """`layers` = N deep copies of one initialised layer (what nn.TransformerEncoder does)."""
+
+    def __init__(self, d_model: int, nhead: int, dim_feedforward: int, num_layers: int) -> None:
+        super().__init__()
+        if d_model % nhead != 0:
+            raise ValueError(f"embed_dim {d_model} must be divisible by num_heads {nhead}")
+        proto = EncoderLayerParams(d_model, nhead, dim_feedforward)
+        self.layers = nn.ModuleList([copy.deepcopy(proto) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.d_model = d_model
+        self.nhead = nhead
+        self.dim_feedforward = dim_feedforward
+        self._packed = PackedCache()
+
+    def run(self, x: torch.Tensor, B: int, S: int, causal: bool) -> torch.Tensor:
+        """x: fp32 [B*S, d] residual stream (updated in place and returned)."""
+        d, H = self.d_model, self.nhead
+        if d // H != HEAD_DIM:
+            raise ops.MmamdError(f"the MI355X attention kernel is built for head dim 64, got {d // H}")
+        M = B * S
+        dev = x.device
+        pk = self._packed.get
+        bf, f32 = torch.bfloat16, torch.float32
+        hn = torch.empty((M, d), dtype=bf, device=dev)
+        qkv = torch.empty((M, 3 * d), dtype=bf, device=dev)
+        att = torch.empty((M, d), dtype=bf, device=dev)
+        up = torch.empty((M, self.dim_feedforward), dtype=bf, device=dev)
+        for layer in self.layers:
+            sa = layer.self_attn
+            ops.layernorm(x, pk(layer.norm1.weight, f32), pk(layer.norm1.bias, f32), layer.norm1.eps, out=hn)
+            ops.gemm_bf16(hn, pk(sa.in_proj_weight, bf), pk(sa.in_proj_bias, f32), out=qkv)
+            ops.attention_fwd(qkv, B, S, H, causal, out=att)
+            ops.gemm_bf16(att, pk(sa.out_proj.weight, bf), pk(sa.out_proj.bias, f32), residual=x, out=x)
+            ops.layernorm(x, pk(layer.norm2.weight, f32), pk(layer.norm2.bias, f32), layer.norm2.eps, out=hn)
+            ops.gemm_bf16(hn, pk(layer.linear1.weight, bf), pk(layer.linear1.bias, f32), act=ops.ACT_QUICKGELU, out=up)
+            ops.gemm_bf16(up, pk(layer.linear2.weight, bf), pk(layer.linear2.bias, f32), residual=x, out=x)
+        return x
+
+
+def forbid_training_forward(module: nn.Module) -> None:
+    """The engine is forward-only this round (SURVEY.md §8f rank 1 = backward).  Refuse, loudly, to return
+    non-differentiable outputs to a training loop instead of silently detaching them."""
+    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            f"{type(module).__name__}: backward is not implemented on the MI355X path yet; call .eval() and/or "
+            "run under torch.no_grad() for forward + loss")

@@ -1,0 +1,96 @@
+"""CLIPViTEncoder — host-side mirror of torchmultimodal/models/clip/image_encoder.py:22-113 on the MI355X kernels.
+
+Same constructor signature, same parameter names/shapes (state_dict-compatible), same
+ValueErrors; forward() = patchify -> patch-embed GEMM -> (+CLS,+pos,ln_pre) -> transformer stack ->
+(ln_post(CLS) @ projection), every step a libmmamd.so kernel.  The ResNet towers of the reference
+(image_encoder.py:116-339) are outside the hot path and are not provided.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+from ...modules.layers.normalizations import Fp32LayerNorm
+from ._transformer import TransformerStack, forbid_training_forward
+
+EXPANSION = 4
+
+
+class CLIPViTEncoder(nn.Module):
+    """
+    Vision transformer encoder for CLIP.
+
+    Args:
+        embedding_dim (int): Embedding dimension for text and image encoders projections.
+        patch_size (int): The dimension of each patch
+        image_size(int): The size (width==height) of input image
+        width (int): Dimensionality of the encoder layers and the pooler layer
+        heads (int): Number of attention heads for each attention layer in the Transformer encoder
+        layers (int): Number of hidden layers in the Transformer encoder
+
+    Inputs:
+        x (Tensor): image tensor with dimensions B x C(3) x image_size x image_size
+    """
+
+    def __init__(self, embedding_dim: int, patch_size: int, image_size: int, width: int, heads: int, layers: int):
+        super().__init__()
+        torch._C._log_api_usage_once(f"torchmultimodal.{self.__class__.__name__}")
+        # parameter creation order == reference order (image_encoder.py:50-80) so seeded inits coincide
+        self.conv = nn.Conv2d(in_channels=3, out_channels=width, kernel_size=patch_size, stride=patch_size, bias=False)
+        self.image_size = image_size
+        self.patch_size = patch_size
+        self.width = width
+        self.embedding_dim = embedding_dim
+
+        scale = width**-0.5
+        self.cls_token_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((image_size // patch_size) ** 2 + 1, width))
+        self.ln_pre = Fp32LayerNorm(width)
+        self.encoder = TransformerStack(d_model=width, nhead=heads, dim_feedforward=EXPANSION * width, num_layers=layers)
+        self.ln_post = Fp32LayerNorm(width)
+        self.projection = nn.Parameter(scale * torch.randn(width, embedding_dim))
+        self._packed = PackedCache()
+        self._conv_w_cache = None  # (ptr, version, device, packed [width, Kpad] bf16)
+
+    def _conv_weight_bf16(self, kpad: int) -> Tensor:
+        """conv.weight [w,3,p,p] viewed as the GEMM weight [w, 3*p*p] (K-contiguous), zero-padded to Kpad."""
+        w = self.conv.weight.detach()
+        K = w.shape[1] * w.shape[2] * w.shape[3]
+        if K == kpad:
+            return self._packed.get(self.conv.weight, torch.bfloat16).view(w.shape[0], K)
+        c = self._conv_w_cache
+        if c is not None and c[0] == w.data_ptr() and c[1] == self.conv.weight._version and c[2] == w.device:
+            return c[3]
+        packed = torch.zeros((w.shape[0], kpad), dtype=torch.bfloat16, device=w.device)  # one-time pack
+        packed[:, :K].copy_(self._packed.get(self.conv.weight, torch.bfloat16).view(w.shape[0], K))
+        self._conv_w_cache = (w.data_ptr(), self.conv.weight._version, w.device, packed)
+        return packed
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.size(2) != self.image_size or x.size(3) != self.image_size:
+            raise ValueError(
+                f"Expected input with width and height as {self.image_size}, found {x.size(2)} by {x.size(3)} ")
+        if x.size(1) != 3:
+            raise ValueError(f"Expected 3 channels found {x.size(1)}")
+        forbid_training_forward(self)
+        f32 = torch.float32
+        pk = self._packed.get
+        B = x.size(0)
+        g = self.image_size // self.patch_size
+        G2 = g * g
+        K = 3 * self.patch_size * self.patch_size
+        kpad = (K + 63) // 64 * 64
+        xc = x if x.is_contiguous() else x.contiguous()
+        # K1: patch embedding = GEMM over non-overlapping patches (conv has no bias in CLIP), fp32 result
+        patches = ops.patchify(xc, self.patch_size, kpad)
+        pe = ops.gemm_bf16(patches, self._conv_weight_bf16(kpad), out_dtype=f32)
+        # prepend CLS, + positional embedding, ln_pre  -> fp32 residual stream [B*S, w]
+        h = ops.vit_assemble_ln(pe, pk(self.cls_token_embedding, f32), pk(self.positional_embedding, f32),
+                                pk(self.ln_pre.weight, f32), pk(self.ln_pre.bias, f32), self.ln_pre.eps, B, G2)
+        h = self.encoder.run(h, B, G2 + 1, causal=False)
+        # K7: ln_post(CLS) @ projection
+        out = ops.pool_ln_proj(h, B, G2 + 1, None, pk(self.ln_post.weight, f32), pk(self.ln_post.bias, f32),
+                               self.ln_post.eps, pk(self.projection, f32), proj_is_linear_weight=False)
+        return out if self.projection.dtype == f32 else ops.convert(out, self.projection.dtype)

@@ -1,0 +1,79 @@
+"""CLIP two-tower wrapper + factories — host-side mirror of torchmultimodal/models/clip/model.py:19-114.
+
+`CLIP` stays tower-agnostic (any nn.Module encoders whose outputs are [B,E] HIP tensors, cf. the reference's
+tests/models/clip/test_clip.py:26-56); the L2 normalisation of model.py:72-73 is the l2_normalize kernel.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+from torch import nn
+
+from ... import ops
+from ...utils.common import load_module_from_url
+from .image_encoder import CLIPViTEncoder
+from .text_encoder import CLIPTextEncoder
+
+
+class CLIPOutput(NamedTuple):
+    embeddings_a: torch.Tensor
+    embeddings_b: torch.Tensor
+
+
+CLIP_MODEL_MAPPING = {
+    "vit_b16": "https://download.pytorch.org/models/multimodal/clip/clip_vit_b16.pt",
+    "vit_b32": "https://download.pytorch.org/models/multimodal/clip/clip_vit_b32.pt",
+    "vit_l14": "https://download.pytorch.org/models/multimodal/clip/clip_vit_l14.pt",
+}
+
+
+class CLIP(nn.Module):
+    """CLIP is a model for contrastive pretraining between two modalities.
+
+    Args:   encoder_a (nn.Module): Instantiated encoder for modality A (e.g. CLIPViTEncoder).
+            encoder_b (nn.Module): Instantiated encoder for modality B (e.g. CLIPTextEncoder).
+
+    Inputs: features_a (Tensor): Tensor containing features of modality A.
+            features_b (Tensor): Tensor containing features of modality B.
+    """
+
+    def __init__(self, encoder_a: nn.Module, encoder_b: nn.Module):
+        super().__init__()
+        torch._C._log_api_usage_once(f"torchmultimodal.{self.__class__.__name__}")
+        self.encoder_a = encoder_a
+        self.encoder_b = encoder_b
+
+    def forward(self, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
+        embeddings_a = self.encoder_a(features_a)
+        embeddings_b = self.encoder_b(features_b)
+        embeddings_a = ops.l2_normalize(embeddings_a.detach().contiguous(), eps=1e-12)
+        embeddings_b = ops.l2_normalize(embeddings_b.detach().contiguous(), eps=1e-12)
+        return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
+
+
+def clip_vit_b16(pretrained: bool = False) -> CLIP:
+    vision_encoder = CLIPViTEncoder(image_size=224, patch_size=16, layers=12, heads=12, width=768, embedding_dim=512)
+    text_encoder = CLIPTextEncoder(embedding_dim=512)
+    clip = CLIP(vision_encoder, text_encoder)
+    if pretrained:
+        load_module_from_url(clip, CLIP_MODEL_MAPPING["vit_b16"])
+    return clip
+
+
+def clip_vit_b32(pretrained: bool = False) -> CLIP:
+    vision_encoder = CLIPViTEncoder(image_size=224, patch_size=32, layers=12, heads=12, width=768, embedding_dim=512)
+    text_encoder = CLIPTextEncoder(embedding_dim=512)
+    clip = CLIP(vision_encoder, text_encoder)
+    if pretrained:
+        load_module_from_url(clip, CLIP_MODEL_MAPPING["vit_b32"])
+    return clip
+
+
+def clip_vit_l14(pretrained: bool = False) -> CLIP:
+    vision_encoder = CLIPViTEncoder(image_size=224, patch_size=14, layers=24, heads=16, width=1024, embedding_dim=768)
+    text_encoder = CLIPTextEncoder(embedding_dim=768, width=768, dim_feedforward=3072, heads=12)
+    clip = CLIP(vision_encoder, text_encoder)
+    if pretrained:
+        load_module_from_url(clip, CLIP_MODEL_MAPPING["vit_l14"])
+    return clip

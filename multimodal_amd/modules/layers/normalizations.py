@@ -1,0 +1,26 @@
+"""Host-side mirror of torchmultimodal/modules/layers/normalizations.py:13-25 (Fp32LayerNorm)."""
+from typing import Any
+
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+
+import torch
+
+
+class Fp32LayerNorm(nn.LayerNorm):
+    """LayerNorm whose statistics are computed in fp32 whatever the input dtype; result cast back to the
+    input dtype.  forward() launches the wave-per-row HIP kernel (csrc/rowops.hip: layernorm_kernel)."""
+
+    def __init__(self, *args: Any, **kwargs: Any) -> None:
+        super().__init__(*args, **kwargs)
+        self._packed = PackedCache()
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.weight is None or self.bias is None or len(self.normalized_shape) != 1:
+            raise ops.MmamdError("Fp32LayerNorm on the MI355X path needs a 1-D affine LayerNorm")
+        g = self._packed.get(self.weight, torch.float32)
+        b = self._packed.get(self.bias, torch.float32)
+        xc = x if x.is_contiguous() else x.contiguous()
+        return ops.layernorm(xc, g, b, self.eps, out_dtype=x.dtype)

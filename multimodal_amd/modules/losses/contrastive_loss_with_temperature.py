@@ -1,0 +1,132 @@
+"""ContrastiveLossWithTemperature — host-side mirror of
+torchmultimodal/modules/losses/contrastive_loss_with_temperature.py:17-201 on the MI355X kernels.
+
+Same signatures, same ContrastiveLossOutput fields, same ValueError, same in-place clamp of the logit_scale
+parameter (…:193, done by the clamp_scalar kernel so there is no host sync).  The forward is
+    one packed all-gather (RCCL over xGMI; utils/distributed.gather_packed_features)
+ -> mmamd_contrastive_fwd (fp32 logits on the exact-f32 MFMA + row cross entropy + reduction).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, OrderedDict, Union
+
+import torch
+from torch import nn, Tensor
+
+from ... import _lib, ops
+from ...utils.distributed import BackpropType, gather_packed_features
+
+
+@dataclass
+class ContrastiveLossOutput(OrderedDict):
+    loss: Tensor
+    logits_a: Tensor
+    logits_b: Tensor
+    loss_a: Tensor
+    loss_b: Tensor
+
+
+_SUPPORTED_CE_KWARGS = {"label_smoothing", "reduction"}
+
+
+def _as_f32(t: Tensor) -> Tensor:
+    t = t.detach()
+    t = t if t.is_contiguous() else t.contiguous()
+    return t if t.dtype == torch.float32 else ops.convert(t, torch.float32)
+
+
+def contrastive_loss_with_temperature(
+    embeddings_a: Tensor,
+    embeddings_b: Tensor,
+    logit_scale: nn.Parameter,
+    mask: Optional[Tensor] = None,
+    backprop_type: BackpropType = BackpropType.GLOBAL,
+    cross_entropy_kwargs: Optional[Dict[str, Any]] = None,
+) -> ContrastiveLossOutput:
+    """Functional component for the ContrastiveLossWithTemperature (reference …:50-115).
+
+    Args:
+        embeddings_a (Tensor): features from the first modality, [B, E].
+        embeddings_b (Tensor): features from the second modality, [B, E].
+        logit_scale (nn.Parameter): 0-dim parameter holding the log of the temperature.
+        mask (Optional[Tensor]): boolean [B]; rows that are False are dropped from the loss and the logits.
+        backprop_type (BackpropType): kept for API parity; the engine is forward-only, where GLOBAL, LOCAL and
+            NONE gather the same values.
+        cross_entropy_kwargs: `label_smoothing` and `reduction` ('mean' | 'sum') are supported.
+    """
+    if not isinstance(backprop_type, BackpropType):
+        raise TypeError("backprop_type must be a BackpropType")
+    if embeddings_a.shape != embeddings_b.shape or embeddings_a.dim() != 2:
+        raise ValueError("embeddings_a and embeddings_b must both be [batch, embedding_dim] of equal shape")
+    kwargs = dict(cross_entropy_kwargs or {})
+    unknown = set(kwargs) - _SUPPORTED_CE_KWARGS
+    if unknown:
+        raise NotImplementedError(f"cross_entropy_kwargs {sorted(unknown)} are not supported on the MI355X path")
+    smoothing = float(kwargs.get("label_smoothing", 0.0))
+    red = kwargs.get("reduction", "mean")
+    if red not in ("mean", "sum"):
+        raise NotImplementedError(f"cross_entropy reduction '{red}' is not supported on the MI355X path")
+
+    out_dtype = embeddings_a.dtype
+    a = _as_f32(embeddings_a)
+    b = _as_f32(embeddings_b)
+    B, E = a.shape
+    buf, rank, world = gather_packed_features(a, b)  # [W*B, 2E]; W=1 without a process group
+    a_all, b_all = buf[:, :E], buf[:, E:]
+    scale = logit_scale.detach()
+    scale32 = scale if scale.dtype == torch.float32 else ops.convert(scale.reshape(1), torch.float32)
+    row_mask = None
+    if mask is not None:
+        if mask.dtype != torch.bool or mask.shape != (B,):
+            raise ValueError("mask must be a boolean tensor of shape (batch,)")
+        row_mask = mask.contiguous().view(torch.uint8)
+    out3, logits_a, logits_b = ops.contrastive_fwd(
+        a, b, a_all, b_all, 2 * E, scale32.reshape(1), label_offset=B * rank, row_mask=row_mask,
+        label_smoothing=smoothing, reduction=_lib.REDUCE_MEAN if red == "mean" else _lib.REDUCE_SUM)
+    if mask is not None:  # reference …:97-100 returns only the kept rows (data-dependent shape)
+        logits_a, logits_b = logits_a[mask], logits_b[mask]
+    if out_dtype != torch.float32:
+        logits_a, logits_b, out3 = (ops.convert(t.contiguous(), out_dtype) for t in (logits_a, logits_b, out3))
+    return ContrastiveLossOutput(loss=out3[0], logits_a=logits_a, logits_b=logits_b, loss_a=out3[1], loss_b=out3[2])
+
+
+DEFAULT_LOGIT_SCALE = math.log(1 / 0.07)
+
+
+class ContrastiveLossWithTemperature(nn.Module):
+    """Contrastive loss with a temperature parameter, as used in CLIP and FLAVA.
+
+    Args:
+        logit_scale (Union[float, nn.Parameter]): log of the learnable temperature (default ln(1/0.07)); an
+            nn.Parameter is adopted as is.
+        logit_scale_min (Optional[float]): log of the minimum temperature (default ln 1); None = no lower clamp.
+        logit_scale_max (Optional[float]): log of the maximum temperature (default ln 100); None = no upper clamp.
+
+    Inputs: embeddings_a, embeddings_b ([B,E]), backprop_type, cross_entropy_kwargs, mask — as the functional.
+    """
+
+    def __init__(self, logit_scale: Union[float, nn.Parameter] = DEFAULT_LOGIT_SCALE,
+                 logit_scale_min: Optional[float] = math.log(1), logit_scale_max: Optional[float] = math.log(100)):
+        super().__init__()
+        torch._C._log_api_usage_once(f"torchmultimodal.{self.__class__.__name__}")
+        # same truthiness test as the reference (…:172-175): a 0.0 minimum counts as "not set" there too
+        if not logit_scale_min and not logit_scale_max:
+            raise ValueError("Only one of `logit_scale_min` and `logit_scale_max` can be None.")
+        self.logit_scale_min = logit_scale_min
+        self.logit_scale_max = logit_scale_max
+        if isinstance(logit_scale, nn.Parameter):
+            self.logit_scale = logit_scale
+        else:
+            self.logit_scale = nn.Parameter(logit_scale * torch.ones([]))
+
+    def forward(self, embeddings_a: Tensor, embeddings_b: Tensor, backprop_type: BackpropType = BackpropType.GLOBAL,
+                cross_entropy_kwargs: Optional[Dict[str, Any]] = None, mask: Optional[Tensor] = None) -> Tensor:
+        if self.logit_scale.dtype != torch.float32:
+            raise ops.MmamdError("logit_scale must be kept in float32")
+        # the one sanctioned parameter mutation of the path: in-place clamp before every forward
+        ops.clamp_scalar_(self.logit_scale.data.view(1), self.logit_scale_min, self.logit_scale_max)
+        return contrastive_loss_with_temperature(
+            embeddings_a=embeddings_a, embeddings_b=embeddings_b, logit_scale=self.logit_scale,
+            backprop_type=backprop_type, cross_entropy_kwargs=cross_entropy_kwargs, mask=mask).loss

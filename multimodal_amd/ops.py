@@ -1,0 +1,235 @@
+"""Thin tensor-level wrappers over the C-ABI (multimodal_amd/_lib.py, include/mmamd.h).
+
+PyTorch is used here for device memory and streams only: every wrapper passes raw device pointers,
+sizes and the CURRENT torch stream to libmmamd.so.  No wrapper ever computes with ATen ops; inputs
+that are not on a HIP device raise (there is no CPU path).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, BF16, F32, MmamdError, check
+
+__all__ = [
+    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
+    "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
+    "convert", "set_gemm_variant", "StreamTimer",
+]
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise MmamdError(f"unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _chk(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise MmamdError(f"{name} is on {t.device}: the MI355X path needs HIP device tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise MmamdError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise MmamdError(f"{name} must be contiguous")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def set_gemm_variant(v: int) -> None:
+    _lib.lib().mmamd_set_gemm_variant(int(v))
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+              out_dtype: torch.dtype = torch.bfloat16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x"); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(_lib.lib().mmamd_layernorm(x.data_ptr(), _dt(x), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                     _dt(out), rows, d, float(eps), _stream()), "mmamd_layernorm")
+    return out
+
+
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+              residual: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = act(a[M,K] @ w[N,K]^T + bias) (+ residual); residual may alias out."""
+    _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16)
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise MmamdError(f"gemm: inner dims differ ({K} vs {K2})")
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    _chk(out, "out")
+    if residual is not None:
+        _chk(residual, "residual", out.dtype)
+    check(_lib.lib().mmamd_gemm_bf16(a.data_ptr(), K, w.data_ptr(), K, _ptr(bias), _ptr(residual), N, out.data_ptr(),
+                                     N, _dt(out), M, N, K, int(act), _stream()), "mmamd_gemm_bf16")
+    return out
+
+
+def attention_fwd(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv bf16 [B*S, 3*H*64] -> bf16 [B*S, H*64]."""
+    _chk(qkv, "qkv", torch.bfloat16)
+    if qkv.shape != (B * S, 3 * H * 64):
+        raise MmamdError(f"attention: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * H * 64)}")
+    if out is None:
+        out = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=qkv.device)
+    check(_lib.lib().mmamd_attention_fwd(qkv.data_ptr(), out.data_ptr(), B, S, H, int(bool(causal)),
+                                         1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_fwd")
+    return out
+
+
+def patchify(images: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
+    _chk(images, "images")
+    B, Cc, Hh, Ww = images.shape
+    g = Hh // patch
+    out = torch.empty((B * g * g, kpad), dtype=torch.bfloat16, device=images.device)
+    check(_lib.lib().mmamd_patchify(images.data_ptr(), _dt(images), out.data_ptr(), B, Cc, Hh, patch, kpad, _stream()),
+          "mmamd_patchify")
+    return out
+
+
+def vit_assemble_ln(patch_emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor,
+                    beta: torch.Tensor, eps: float, B: int, G2: int) -> torch.Tensor:
+    _chk(patch_emb, "patch_emb")
+    for n, t in (("cls", cls), ("pos", pos), ("gamma", gamma), ("beta", beta)):
+        _chk(t, n, torch.float32)
+    d = patch_emb.shape[-1]
+    x = torch.empty((B * (G2 + 1), d), dtype=torch.float32, device=patch_emb.device)
+    check(_lib.lib().mmamd_vit_assemble_ln(patch_emb.data_ptr(), _dt(patch_emb), cls.data_ptr(), pos.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), float(eps), x.data_ptr(), B, G2, d,
+                                           _stream()), "mmamd_vit_assemble_ln")
+    return x
+
+
+def embed_tokens(ids: torch.Tensor, table: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    _chk(ids, "ids", torch.int64); _chk(table, "table"); _chk(pos, "pos", torch.float32)
+    B, S = ids.shape
+    vocab, d = table.shape
+    x = torch.empty((B * S, d), dtype=torch.float32, device=ids.device)
+    check(_lib.lib().mmamd_embed_tokens(ids.data_ptr(), table.data_ptr(), _dt(table), pos.data_ptr(), x.data_ptr(),
+                                        B, S, d, vocab, _stream()), "mmamd_embed_tokens")
+    return x
+
+
+def pool_ln_proj(x: torch.Tensor, B: int, S: int, ids: Optional[torch.Tensor], gamma: torch.Tensor,
+                 beta: torch.Tensor, eps: float, proj: torch.Tensor, proj_is_linear_weight: bool,
+                 normalize: bool = False) -> torch.Tensor:
+    """x fp32 [B*S, d]; proj fp32: [d,E] (x @ proj) or, if proj_is_linear_weight, [E,d] (x @ proj.T)."""
+    _chk(x, "x", torch.float32); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
+    _chk(proj, "proj", torch.float32)
+    d = x.shape[-1]
+    if proj_is_linear_weight:
+        E, sk, se = proj.shape[0], 1, d
+    else:
+        E, sk, se = proj.shape[1], proj.shape[1], 1
+    if ids is not None:
+        _chk(ids, "ids", torch.int64)
+    out = torch.empty((B, E), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmamd_pool_ln_proj(x.data_ptr(), S, d, _ptr(ids), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                        proj.data_ptr(), sk, se, out.data_ptr(), B, E, int(bool(normalize)), _stream()),
+          "mmamd_pool_ln_proj")
+    return out
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    _chk(x, "x")
+    if x.dim() != 2:
+        raise MmamdError("l2_normalize expects a [rows, d] tensor")
+    out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    check(_lib.lib().mmamd_l2_normalize(x.data_ptr(), _dt(x), out.data_ptr(), _dt(out), x.shape[0], x.shape[1],
+                                        float(eps), _stream()), "mmamd_l2_normalize")
+    return out
+
+
+def clamp_scalar_(p: torch.Tensor, lo: Optional[float], hi: Optional[float]) -> None:
+    _chk(p, "scalar", torch.float32)
+    if p.numel() != 1:
+        raise MmamdError("clamp_scalar_ expects a 1-element tensor")
+    check(_lib.lib().mmamd_clamp_scalar(p.data_ptr(), int(lo is not None), float(lo or 0.0), int(hi is not None),
+                                        float(hi or 0.0), _stream()), "mmamd_clamp_scalar")
+
+
+def contrastive_fwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all: torch.Tensor, ld_all: int,
+                    logit_scale: torch.Tensor, label_offset: int, row_mask: Optional[torch.Tensor] = None,
+                    label_smoothing: float = 0.0, reduction: int = _lib.REDUCE_MEAN
+                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Returns (out3 = [loss, loss_a, loss_b], logits_a [B,WB], logits_b [B,WB]), all fp32."""
+    _chk(a, "a", torch.float32); _chk(b, "b", torch.float32); _chk(logit_scale, "logit_scale", torch.float32)
+    for n, t in (("a_all", a_all), ("b_all", b_all)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise MmamdError(f"{n} must be an fp32 HIP tensor with unit inner stride")
+    B, E = a.shape
+    WB = a_all.shape[0]
+    if row_mask is not None:
+        _chk(row_mask, "row_mask", torch.uint8)
+    dev = a.device
+    logits_a = torch.empty((B, WB), dtype=torch.float32, device=dev)
+    logits_b = torch.empty((B, WB), dtype=torch.float32, device=dev)
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    ws = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    check(_lib.lib().mmamd_contrastive_fwd(a.data_ptr(), b.data_ptr(), a_all.data_ptr(), b_all.data_ptr(), int(ld_all),
+                                           logit_scale.data_ptr(), B, WB, E, int(label_offset), _ptr(row_mask),
+                                           float(label_smoothing), int(reduction), logits_a.data_ptr(),
+                                           logits_b.data_ptr(), out3.data_ptr(), ws.data_ptr(), _stream()),
+          "mmamd_contrastive_fwd")
+    return out3, logits_a, logits_b
+
+
+def convert(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _chk(src, "src")
+    if src.dtype == dtype:
+        return src
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.lib().mmamd_convert(src.data_ptr(), _dt(src), dst.data_ptr(), _dt(dst), src.numel(), _stream()),
+          "mmamd_convert")
+    return dst
+
+
+class StreamTimer:
+    """HIP-event timer recorded on the stream the kernels are launched on (bench.py)."""
+
+    def __init__(self) -> None:
+        self._h = _lib.lib().mmamd_timer_create()
+        if not self._h:
+            raise MmamdError("mmamd_timer_create failed")
+
+    def start(self) -> None:
+        check(_lib.lib().mmamd_timer_start(self._h, _stream()), "mmamd_timer_start")
+
+    def stop(self) -> None:
+        check(_lib.lib().mmamd_timer_stop(self._h, _stream()), "mmamd_timer_stop")
+
+    def elapsed_ms(self) -> float:
+        import ctypes
+
+        ms = ctypes.c_float(0.0)
+        check(_lib.lib().mmamd_timer_elapsed_ms(self._h, ctypes.byref(ms)), "mmamd_timer_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self) -> None:
+        try:
+            if self._h:
+                _lib.lib().mmamd_timer_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,264 @@
+"""CPU ORACLE (test infrastructure, NOT product code) for the dual-encoder contrastive hot path.
+
+This file is a plain-numpy restatement of what the reference computes on its PyTorch CPU path for
+CLIP forward + ContrastiveLossWithTemperature.  It exists only so that tests/, __graft_entry__.smoke()
+and bench.py's `cpu_baseline` leg have something to check the HIP kernels against on a box where
+/root/reference does not exist.  Nothing under multimodal_amd/ may import it.
+
+Pinned (see tests/test_oracle_golden.py and tests/golden/make_golden.py):
+  * against every eval-mode known-answer vector the reference's own tests hold for this path
+    (tests/models/clip/test_image_encoder.py:58-64, tests/models/clip/test_text_encoder.py:107-149,
+     tests/modules/losses/test_contrastive_loss_with_temperature.py:75-82,112-123,182-184),
+  * against outputs of the reference itself, imported in the build container under the 3-module shim
+    (tests/golden/_ref_shim.py) and committed as fixtures under tests/golden/*.npz.
+
+Part of the arithmetic of this path lives in a third-party dependency of the reference that is not
+vendored in /root/reference: `torch` (unpinned by the reference; CI uses pytorch-nightly,
+.github/workflows/unit_test.yaml:32; installed here: 2.10.0+rocm7.0).  The semantics restated from it:
+  nn.TransformerEncoderLayer(norm_first=True):  x = x + sa(norm1(x)); x = x + ff(norm2(x))
+      (torch/nn/modules/transformer.py:946-950), ff = linear2(act(linear1(x))) (:980-982), LN eps 1e-5
+  nn.MultiheadAttention packed in-projection  q,k,v = split(x @ in_proj_weight.T + in_proj_bias)
+      (torch/nn/functional.py `_in_projection_packed`), heads split along the channel dim, dh = d/h
+  F.scaled_dot_product_attention  softmax(q k^T / sqrt(dh) [+ causal mask]) v
+  F.layer_norm (biased variance), F.normalize (x / max(||x||_2, eps)), F.cross_entropy
+      (mean reduction, label_smoothing:  (1-s)*nll + s*mean_j(-logp_j)).
+Reference call sites for those: models/clip/image_encoder.py:65-77,108; models/clip/text_encoder.py:58-66,121;
+models/clip/model.py:72-73; modules/losses/contrastive_loss_with_temperature.py:90-107.
+
+All functions take / return numpy arrays.  `dtype` selects the arithmetic type (float32 mirrors the
+reference CPU path; float64 is used by tests that need a tighter anchor).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+
+Array = np.ndarray
+
+
+# ----------------------------------------------------------------------------------------------
+# elementary pieces
+# ----------------------------------------------------------------------------------------------
+def layer_norm(x: Array, weight: Array, bias: Array, eps: float) -> Array:
+    """F.layer_norm over the last dim, biased variance (Fp32LayerNorm: modules/layers/normalizations.py:13-25)."""
+    mean = x.mean(axis=-1, keepdims=True)
+    xc = x - mean
+    var = (xc * xc).mean(axis=-1, keepdims=True)
+    return xc / np.sqrt(var + x.dtype.type(eps)) * weight + bias
+
+
+def quick_gelu(x: Array) -> Array:
+    """SiLU of the reference = x * sigmoid(1.702 x) (modules/layers/activation.py:24-25)."""
+    return x / (1.0 + np.exp(-x.dtype.type(1.702) * x))
+
+
+def softmax_lastdim(s: Array) -> Array:
+    m = s.max(axis=-1, keepdims=True)
+    e = np.exp(s - m)
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def l2_normalize(x: Array, eps: float = 1e-12) -> Array:
+    """F.normalize(x) with p=2, dim=1 (models/clip/model.py:72-73)."""
+    n = np.sqrt((x * x).sum(axis=1, keepdims=True))
+    return x / np.maximum(n, x.dtype.type(eps))
+
+
+def multi_head_self_attention(
+    x: Array, in_w: Array, in_b: Array, out_w: Array, out_b: Array, heads: int, causal: bool
+) -> Array:
+    """nn.MultiheadAttention self-attention, batch-first [B,S,d] (see module docstring for torch sites)."""
+    B, S, d = x.shape
+    dh = d // heads
+    qkv = x @ in_w.T + in_b  # [B,S,3d]
+    q, k, v = qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :]
+
+    def split(t):  # [B,S,d] -> [B,h,S,dh]
+        return t.reshape(B, S, heads, dh).transpose(0, 2, 1, 3)
+
+    q, k, v = split(q), split(k), split(v)
+    s = (q @ k.transpose(0, 1, 3, 2)) * x.dtype.type(1.0 / math.sqrt(dh))
+    if causal:
+        # text_encoder.py:74-77 mask = full(-inf).triu(1); torch uses SDPA's causal flag for it
+        mask = np.triu(np.ones((S, S), dtype=bool), k=1)
+        s = np.where(mask, -np.inf, s).astype(x.dtype)
+    p = softmax_lastdim(s)
+    o = (p @ v).transpose(0, 2, 1, 3).reshape(B, S, d)
+    return o @ out_w.T + out_b
+
+
+def encoder_layer(x: Array, sd: Dict[str, Array], prefix: str, heads: int, causal: bool) -> Array:
+    """One pre-norm torch.nn.TransformerEncoderLayer with QuickGELU (image_encoder.py:65-73)."""
+    g = lambda k: sd[prefix + k]
+    h = layer_norm(x, g("norm1.weight"), g("norm1.bias"), 1e-5)
+    x = x + multi_head_self_attention(
+        h,
+        g("self_attn.in_proj_weight"),
+        g("self_attn.in_proj_bias"),
+        g("self_attn.out_proj.weight"),
+        g("self_attn.out_proj.bias"),
+        heads,
+        causal,
+    )
+    h = layer_norm(x, g("norm2.weight"), g("norm2.bias"), 1e-5)
+    h = quick_gelu(h @ g("linear1.weight").T + g("linear1.bias"))
+    x = x + (h @ g("linear2.weight").T + g("linear2.bias"))
+    return x
+
+
+def _num_layers(sd: Dict[str, Array], prefix: str) -> int:
+    n = 0
+    while f"{prefix}encoder.layers.{n}.norm1.weight" in sd:
+        n += 1
+    return n
+
+
+def _cast(sd: Dict[str, Array], dtype) -> Dict[str, Array]:
+    return {k: np.asarray(v).astype(dtype, copy=False) for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# towers
+# ----------------------------------------------------------------------------------------------
+def patch_embed(images: Array, conv_w: Array) -> Array:
+    """nn.Conv2d(3,w,k=p,s=p,bias=False) + flatten + permute (image_encoder.py:91-97) -> [B, g*g, w]."""
+    B, C, H, W = images.shape
+    w, _, p, _ = conv_w.shape
+    g = H // p
+    # [B,C,g,p,g,p] -> [B,g,g,C,p,p] -> [B,g*g,C*p*p]; k-order (c,py,px) == conv weight flattening
+    patches = images.reshape(B, C, g, p, g, p).transpose(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * p * p)
+    return patches @ conv_w.reshape(w, -1).T
+
+
+def clip_vit_hidden(sd: Dict[str, Array], images: Array, heads: int, prefix: str = "") -> Array:
+    """CLIPViTEncoder.forward up to and including the transformer (image_encoder.py:82-108) -> [B,S,w]."""
+    x = patch_embed(images, sd[prefix + "conv.weight"])
+    B = x.shape[0]
+    cls = np.broadcast_to(sd[prefix + "cls_token_embedding"], (B, 1, x.shape[2]))
+    x = np.concatenate([cls, x], axis=1) + sd[prefix + "positional_embedding"]
+    x = layer_norm(x, sd[prefix + "ln_pre.weight"], sd[prefix + "ln_pre.bias"], 1e-5)
+    for i in range(_num_layers(sd, prefix)):
+        x = encoder_layer(x, sd, f"{prefix}encoder.layers.{i}.", heads, causal=False)
+    return x
+
+
+def clip_vit_forward(sd: Dict[str, Array], images: Array, heads: int, prefix: str = "", dtype=np.float32) -> Array:
+    """CLIPViTEncoder.forward (models/clip/image_encoder.py:82-113) -> [B,E] (not normalized)."""
+    sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
+    x = clip_vit_hidden(sd, np.asarray(images).astype(dtype), heads, prefix)
+    x = layer_norm(x[:, 0, :], sd[prefix + "ln_post.weight"], sd[prefix + "ln_post.bias"], 1e-5)
+    return x @ sd[prefix + "projection"]
+
+
+def clip_text_forward(
+    sd: Dict[str, Array],
+    text: Array,
+    heads: int,
+    prefix: str = "",
+    return_hidden_state: bool = False,
+    dtype=np.float32,
+) -> Array:
+    """CLIPTextEncoder.forward (models/clip/text_encoder.py:113-134)."""
+    sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
+    text = np.asarray(text)
+    x = sd[prefix + "token_embedding.weight"][text] + sd[prefix + "positional_embedding"]
+    for i in range(_num_layers(sd, prefix)):
+        x = encoder_layer(x, sd, f"{prefix}encoder.layers.{i}.", heads, causal=True)
+    hidden = layer_norm(x, sd[prefix + "ln_final.weight"], sd[prefix + "ln_final.bias"], 1e-5)
+    if return_hidden_state:
+        return hidden
+    eot = text.argmax(axis=-1)  # first index of the max id, as torch.argmax
+    pooled = hidden[np.arange(hidden.shape[0]), eot]
+    return pooled @ sd[prefix + "projection.weight"].T
+
+
+def clip_forward(sd, images, text, vision_heads: int, text_heads: int, dtype=np.float32):
+    """CLIP.forward (models/clip/model.py:65-74): both towers + L2 normalize."""
+    a = clip_vit_forward(sd, images, vision_heads, "encoder_a.", dtype)
+    b = clip_text_forward(sd, text, text_heads, "encoder_b.", False, dtype)
+    return l2_normalize(a), l2_normalize(b)
+
+
+# ----------------------------------------------------------------------------------------------
+# loss
+# ----------------------------------------------------------------------------------------------
+def cross_entropy(logits: Array, labels: Array, label_smoothing: float = 0.0, reduction: str = "mean"):
+    """F.cross_entropy over rows (contrastive_loss_with_temperature.py:105-106)."""
+    m = logits.max(axis=1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(logits - m).sum(axis=1))
+    logp = logits - lse[:, None]
+    nll = -logp[np.arange(logits.shape[0]), labels]
+    if label_smoothing:
+        s = logits.dtype.type(label_smoothing)
+        nll = (1 - s) * nll + s * (-logp.mean(axis=1))
+    if reduction == "mean":
+        return nll.mean() if nll.size else np.asarray(np.nan, dtype=logits.dtype)
+    if reduction == "sum":
+        return nll.sum()
+    return nll
+
+
+def contrastive_loss_with_temperature(
+    embeddings_a: Array,
+    embeddings_b: Array,
+    logit_scale: float,
+    embeddings_a_all: Optional[Array] = None,
+    embeddings_b_all: Optional[Array] = None,
+    rank: int = 0,
+    mask: Optional[Array] = None,
+    label_smoothing: float = 0.0,
+    dtype=np.float32,
+):
+    """contrastive_loss_with_temperature (modules/losses/contrastive_loss_with_temperature.py:50-115).
+
+    `embeddings_*_all` are the concatenated all-gathered features ([W*B,E], :35-47); None = single process.
+    Returns a dict with the fields of ContrastiveLossOutput (:17-23).
+    """
+    a = np.asarray(embeddings_a).astype(dtype)
+    b = np.asarray(embeddings_b).astype(dtype)
+    a_all = a if embeddings_a_all is None else np.asarray(embeddings_a_all).astype(dtype)
+    b_all = b if embeddings_b_all is None else np.asarray(embeddings_b_all).astype(dtype)
+    temperature = np.exp(np.asarray(logit_scale, dtype=dtype))  # :81
+    B = a.shape[0]
+    labels = B * rank + np.arange(B)  # :38-41
+    logits_a = (a @ b_all.T) * temperature  # :90-92
+    logits_b = (b @ a_all.T) * temperature  # :93-95
+    if mask is not None:  # :97-100
+        mask = np.asarray(mask).astype(bool)
+        logits_a, logits_b, labels = logits_a[mask], logits_b[mask], labels[mask]
+    loss_a = cross_entropy(logits_a, labels, label_smoothing)
+    loss_b = cross_entropy(logits_b, labels, label_smoothing)
+    return {
+        "loss": (loss_a + loss_b) / 2,
+        "logits_a": logits_a,
+        "logits_b": logits_b,
+        "loss_a": loss_a,
+        "loss_b": loss_b,
+    }
+
+
+def clamp_logit_scale(value: float, lo: Optional[float], hi: Optional[float]) -> float:
+    """ContrastiveLossWithTemperature.forward's in-place clamp (…:193)."""
+    if lo is not None:
+        value = max(value, lo)
+    if hi is not None:
+        value = min(value, hi)
+    return value
+
+
+# ----------------------------------------------------------------------------------------------
+# algorithmic work, used by bench.py for the roofline figure (BASELINE.md §3 formula)
+# ----------------------------------------------------------------------------------------------
+def tower_flops(S: int, d: int, ff: int, layers: int) -> float:
+    return layers * (2 * S * d * 3 * d + 4 * S * S * d + 2 * S * d * d + 4 * S * d * ff)
+
+
+def clip_flops_per_pair(
+    image_size=224, patch=16, vw=768, vl=12, tw=512, tff=2048, tl=12, ctx=77, E=512
+) -> float:
+    S = (image_size // patch) ** 2 + 1
+    vision = tower_flops(S, vw, 4 * vw, vl) + 2 * (S - 1) * 3 * patch * patch * vw + 2 * vw * E
+    text = tower_flops(ctx, tw, tff, tl) + 2 * tw * E
+    return float(vision + text)
