@@ -81,8 +81,14 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     _chk(out, "out")
     if residual is not None:
         _chk(residual, "residual", out.dtype)
+    probe = _GEMM_PROBE
+    timer = probe._timer_for(M, N, K) if probe is not None else None
+    if timer is not None:
+        timer.start()
     check(_lib.lib().mmamd_gemm_bf16(a.data_ptr(), K, w.data_ptr(), K, _ptr(bias), _ptr(residual), N, out.data_ptr(),
                                      N, _dt(out), M, N, K, int(act), _stream()), "mmamd_gemm_bf16")
+    if timer is not None:
+        timer.stop()
     return out
 
 
@@ -233,3 +239,38 @@ class StreamTimer:
                 _lib.lib().mmamd_timer_destroy(self._h)
         except Exception:
             pass
+
+
+_GEMM_PROBE = None
+
+
+class GemmProbe:
+    """Measurement hook for bench.py: brackets every gemm_bf16 launch of ONE problem shape with a pair of HIP
+    events on the launch stream, so the dominant kernel's duration is measured live inside the timed region."""
+
+    def __init__(self, M: int, N: int, K: int, max_samples: int = 4096) -> None:
+        self.shape = (M, N, K)
+        self.max_samples = max_samples
+        self._timers = []
+
+    def _timer_for(self, M: int, N: int, K: int):
+        if (M, N, K) != self.shape or len(self._timers) >= self.max_samples:
+            return None
+        t = StreamTimer()
+        self._timers.append(t)
+        return t
+
+    def __enter__(self):
+        global _GEMM_PROBE
+        _GEMM_PROBE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _GEMM_PROBE
+        _GEMM_PROBE = None
+
+    def durations_ms(self):
+        return [t.elapsed_ms() for t in self._timers]
+
+    def reset(self):
+        self._timers = []

@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Per-kernel microbenchmarks on one MI355X (HIP-event timed on the launch stream): every GEMM problem of the
+cfg-2 step x every tiling variant, both attention problems, LayerNorm.  Prints one line per (kernel, shape, variant).
+
+    python tools/kernel_bench.py [--iters 20] [--variants 1,2,3,4,5,6]
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def timeit(fn, iters):
+    from multimodal_amd import ops
+
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t = ops.StreamTimer()
+    t.start()
+    for _ in range(iters):
+        fn()
+    t.stop()
+    return t.elapsed_ms() / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--variants", default="1,2,3,4,5,6")
+    ap.add_argument("--batch", type=int, default=256)
+    args = ap.parse_args()
+    from multimodal_amd import build, ops
+
+    build.build()
+    dev = torch.device("cuda", 0)
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(0)
+
+    def rnd(*shape, dtype=torch.bfloat16, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(dev).to(dtype)
+
+    Mv, Mt = B * 197, B * 77
+    gemms = [("v.qkv", Mv, 2304, 768, 0, False), ("v.out+res", Mv, 768, 768, 0, True), ("v.up+gelu", Mv, 3072, 768, 1, False),
+             ("v.down+res", Mv, 768, 3072, 0, True), ("t.qkv", Mt, 1536, 512, 0, False), ("t.out+res", Mt, 512, 512, 0, True),
+             ("t.up+gelu", Mt, 2048, 512, 1, False), ("t.down+res", Mt, 512, 2048, 0, True), ("patch", B * 196, 768, 768, 0, False)]
+    variants = [int(v) for v in args.variants.split(",")]
+    print(f"{'gemm':12s} {'M':>6s} {'N':>5s} {'K':>5s} " + " ".join(f"v{v}:TF/s".rjust(10) for v in variants))
+    for name, M, N, K, act, res in gemms:
+        a, w, bias = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, dtype=torch.float32)
+        out = torch.zeros((M, N), dtype=torch.float32 if res else torch.bfloat16, device=dev)
+        row = []
+        for v in variants:
+            ops.set_gemm_variant(v)
+            ms = timeit(lambda: ops.gemm_bf16(a, w, bias, act=act, residual=out if res else None, out=out), args.iters)
+            row.append(2.0 * M * N * K / ms / 1e9)
+        ops.set_gemm_variant(0)
+        print(f"{name:12s} {M:6d} {N:5d} {K:5d} " + " ".join(f"{x:10.1f}" for x in row), flush=True)
+
+    for name, S, H, causal in (("attn.vision", 197, 12, False), ("attn.text", 77, 8, True)):
+        qkv = rnd(B * S, 3 * H * 64)
+        o = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=dev)
+        ms = timeit(lambda: ops.attention_fwd(qkv, B, S, H, causal, out=o), args.iters)
+        fl = 4.0 * B * H * S * S * 64 * (0.5 if causal else 1.0)
+        print(f"{name:12s} S={S} H={H} causal={causal}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:8.1f} TF/s (algorithmic)", flush=True)
+
+    for d, rows in ((768, Mv), (512, Mt)):
+        x = rnd(rows, d, dtype=torch.float32)
+        gm, bt = rnd(d, dtype=torch.float32), rnd(d, dtype=torch.float32)
+        y = torch.empty((rows, d), dtype=torch.bfloat16, device=dev)
+        ms = timeit(lambda: ops.layernorm(x, gm, bt, 1e-5, out=y), args.iters)
+        print(f"layernorm    rows={rows} d={d}: {ms * 1e3:8.1f} us  {rows * d * 6 / ms / 1e6:8.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
