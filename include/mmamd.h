@@ -51,6 +51,8 @@ const char* mmamd_last_error(void);
  * in what they compute, they differ in tiling/pipelining only. */
 int mmamd_set_gemm_variant(int variant);
 int mmamd_get_gemm_variant(void);
+/* Diagnostic: device buffer of 64*2*256 uint64 that GEMM variant 14 fills with s_memtime stamps (NULL = off). */
+int mmamd_debug_set_gemm_trace(void* buf);
 
 /* --- K2: row LayerNorm ----------------------------------------------------------------------
  * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta, statistics in fp32 (biased variance).

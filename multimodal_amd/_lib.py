@@ -27,6 +27,7 @@ PROTOTYPES = {
     "mmamd_last_error": (C.c_char_p, []),
     "mmamd_set_gemm_variant": (_i, [_i]),
     "mmamd_get_gemm_variant": (_i, []),
+    "mmamd_debug_set_gemm_trace": (_i, [_vp]),
     "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -22,6 +22,8 @@
 //     compute phase later.
 //   * XCD-aware bijective block remap: consecutive tile ids land on ONE XCD so the blocks sharing an
 //     activation row-panel / the weight matrix hit the same 4 MiB L2.
+#include <type_traits>
+
 #include "common.h"
 
 namespace mmamd {
@@ -41,13 +43,224 @@ struct GemmArgs {
   int tiles_n;
 };
 
+// x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
+// `/` compiles to the ~10-instruction IEEE division sequence: measured at 29 % of the MLP-up GEMM's time.
+__device__ __forceinline__ float quick_gelu(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == MMAMD_ACT_QUICKGELU) return v / (1.0f + __expf(-1.702f * v));
+  if (act == MMAMD_ACT_QUICKGELU) return quick_gelu(v);
   if (act == MMAMD_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
   return v;
 }
 
 static int g_gemm_variant = 0;
+
+// Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
+// n = .. + 8g + 4*(lane>>5) + {0..3}.
+template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn,
+                                              int lane) {
+  const int l31 = lane & 31, half = lane >> 5;
+  // pass 1: bias (depends on n only).  pass 2: activation behind ONE uniform branch.  pass 3: residual + store.
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) bv = load4(p.bias + n);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
+      }
+  }
+  if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[ni][mi][r];
+          acc[ni][mi][r] = quick_gelu(v);
+        }
+  } else if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[ni][mi][r];
+          acc[ni][mi][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        }
+  }
+  const bool has_res = p.R != nullptr;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + wm * TM + mi * 32 + l31;
+    const bool mok = m < p.M;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nb = n0 + wn * TN + ni * 32 + 4 * half;
+      f32x4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nb + 8 * g;
+        const bool ok = mok && (n + 3 < p.N);
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = acc[ni][mi][4 * g + j];
+        if (has_res && ok) {
+          f32x4 rv;
+          if constexpr (OUT_F32) rv = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+          else rv = load4(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] += rv[j];
+        }
+        if constexpr (OUT_F32) {
+          if (ok) store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, t);
+        }
+        v[g] = t;
+      }
+      if constexpr (!OUT_F32) {
+        // pack to bf16 and widen the stores: groups (g, g+1) -> one 16-byte store per lane (T21)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          bf16x4 pa, pb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pa[j] = (bf16)v[g][j]; pb[j] = (bf16)v[g + 1][j]; }
+          uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+          // lanes 32-63 of `ua` <-> lanes 0-31 of `ub`
+          auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+          const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          // lower half now holds columns 8g..8g+7 of its row, upper half columns 8(g+1)..8(g+1)+7
+          const int n = n0 + wn * TN + ni * 32 + 8 * (g + half);
+          if (mok && n + 7 < p.N)
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+        }
+      }
+    }
+  }
+}
+
+// LDS-staged epilogue (used by the pipelined kernels).  The MFMA layout gives every lane 4 consecutive columns of
+// ONE row, so a direct store instruction touches 32 different rows with 32 bytes each — measured (ablation: no epilogue)
+// at 30-50 % of the kernel time.  Here every wave transposes its sub-tile through a private LDS strip, 32 rows at a
+// time, and then stores/loads FULL rows: one wave-instruction covers 8 rows x 128 B (bf16) or 4 rows x 256 B (fp32),
+// i.e. whole cache lines; the fp32 residual is read with the same row-contiguous pattern.
+template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT, int ABL = 0>
+__device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm,
+                                                  int wn, int lane, int wave, char* smem) {
+  static_assert(TN == 64, "row strip below is laid out for 64-column wave tiles");
+  const int l31 = lane & 31, half = lane >> 5;
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) bv = load4(p.bias + n);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
+      }
+  }
+  if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[ni][mi][r];
+          acc[ni][mi][r] = quick_gelu(v);
+        }
+  } else if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[ni][mi][r];
+          acc[ni][mi][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        }
+  }
+  constexpr int ROWB = OUT_F32 ? (TN * 4 + 16) : (TN * 2 + 16);  // padded strip row: 272 B / 144 B (conflict-free b128)
+  __syncthreads();  // every wave is done reading the operand stages: LDS can be reused
+  char* strip = smem + wave * (32 * ROWB);
+  const int nw0 = n0 + wn * TN;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int mrow0 = m0 + wm * TM + mi * 32;
+    if constexpr (OUT_F32) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 t;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] = acc[ni][mi][4 * g + j];
+          *reinterpret_cast<f32x4*>(strip + l31 * ROWB + (ni * 32 + 8 * g + 4 * half) * 4) = t;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {  // 4 rows x 256 B per wave-instruction
+        const int row = it * 4 + (lane >> 4), c = lane & 15;
+        f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * ROWB + c * 16);
+        const int m = mrow0 + row, n = nw0 + c * 4;
+        if (m < p.M && n + 3 < p.N && ((ABL & 16) == 0 || v[0] == 1.2345678e33f)) {
+          if (p.R != nullptr) {
+            const f32x4 rv = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rv[j];
+          }
+          store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          bf16x4 pa, pb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pa[j] = (bf16)acc[ni][mi][4 * g + j]; pb[j] = (bf16)acc[ni][mi][4 * (g + 1) + j]; }
+          uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+          auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+          // lower half: columns 8g..8g+7 of its row; upper half: columns 8(g+1)..8(g+1)+7
+          *reinterpret_cast<uint4*>(strip + l31 * ROWB + (ni * 32 + 8 * (g + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        uint4 v = *reinterpret_cast<const uint4*>(strip + row * ROWB + c * 16);
+        const int m = mrow0 + row, n = nw0 + c * 8;
+        if (m < p.M && n + 7 < p.N && ((ABL & 16) == 0 || v.x == 0x12345678u)) {
+          if (p.R != nullptr) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+            bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
+            v = __builtin_bit_cast(uint4, a8);
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = v;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip reads done before the next 32 rows overwrite it
+  }
+}
 
 // BM x BN block tile, WM x WN waves, BK = 64
 template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB>
@@ -174,90 +387,588 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
     }
   }
 
-  // ---- epilogue: lane owns row m = .. + l31; acc regs 4g..4g+3 are columns n = .. + 8g + 4*half + {0..3}
-  // pass 1: bias (depends on n only).  pass 2: activation behind ONE uniform branch.  pass 3: residual + store.
-  if (p.bias != nullptr) {
+  gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Pipelined kernel ("P"): same tile geometry / LDS image / epilogue as above, different schedule.
+//   * the K loop is ROTATED across the barrier: the 4th k-step's MFMAs of tile k are issued AFTER the barrier
+//     that publishes tile k+1, so they cover the barrier release, the LDS-DMA issue for tile k+2 and the
+//     latency of the first fragment reads of tile k+1 (in the plain loop the matrix pipe idles through all
+//     three on every K-tile: SQ_WAIT_ANY was 35 % of wave cycles there);
+//   * the 8 DMA pieces of the next tile are interleaved one-per-MFMA instead of issued as a burst;
+//   * block -> tile order is grouped (GM row-panels x all column tiles per group) inside each XCD's contiguous
+//     id range, so the ~32 blocks an XCD runs concurrently share GM activation panels and ~32/GM weight tiles
+//     in its 4 MiB L2 (the row-major order re-fetched the whole weight matrix every 32 blocks: FETCH_SIZE was
+//     3-6x the algorithmic bytes).
+// ABL (ablation bit mask, perf experiments only — results are WRONG for ABL != 0): 1 = no DMA in the loop,
+// 2 = no MFMA, 4 = no epilogue, 8 = no fragment reads, 16 = no global accesses in the epilogue
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+  constexpr int NF = NI + MI, NM = NI * MI, NDMA = A_INSTR + B_INSTR;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 4 == 0, "tile/wave geometry");
+  static_assert(NM >= NF && NM >= NDMA, "interleave below needs one MFMA per fragment read / DMA piece");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * p.tiles_n;
+    const int grp = bid / per_group, within = bid - grp * per_group;
+    const int gm0 = grp * GM;
+    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tn = within / rows;
+    tm = gm0 + (within - tn * rows);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+
+  const int sw = (4 * (wave & 3) + (lane >> 4)) & 15;
+  const int slot = (lane & 15) ^ sw;
+  const int row8 = 2 * (lane >> 4) + (slot >> 3);
+  const int chunk = slot & 7;
+  uint32_t a_off[A_INSTR], b_off[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    int r = m0 + 8 * (wave + NW * j) + row8;
+    r = r < p.M ? r : p.M - 1;
+    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+  }
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    int r = n0 + 8 * (wave + NW * j) + row8;
+    r = r < p.N ? r : p.N - 1;
+    b_off[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  auto issue_stage = [&](int buf, int kt) {
+    char* sbase = smem + buf * STAGE;
+    const uint32_t kbytes = (uint32_t)kt * 128u;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j)
+      __builtin_amdgcn_global_load_lds((glb_u32p)(Ab + a_off[j] + kbytes),
+                                       (lds_u32p)(sbase + (wave + NW * j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j)
+      __builtin_amdgcn_global_load_lds((glb_u32p)(Wb + b_off[j] + kbytes),
+                                       (lds_u32p)(sbase + A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
+  };
+
+  const int l31 = lane & 31, half = lane >> 5;
+  const int hsw = l31 >> 1;
+  int roff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) roff[t] = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  bf16x8 xa0[MI], wb0[NI], xa1[MI], wb1[NI];  // two fragment sets, statically named (no runtime indexing)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa1[mi][j] = (bf16)0.f;  // first rotated MFMA group multiplies zeros
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
+
+  auto load_frags = [&](const char* sa, const char* sb, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+    if constexpr ((ABL & 8) != 0) return;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 32 * 128 + roff[t]);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 32 * 128 + roff[t]);
+  };
+  auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+    if constexpr ((ABL & 2) != 0) {  // keep the fragment reads alive without the matrix work
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wb[ni]));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xa[mi]));
+      return;
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) bv = load4(p.bias + n);
+      for (int mi = 0; mi < MI; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+  };
+  // one K-tile between two barriers.  On entry: tile kt is visible in LDS, (xa1, wb1) hold the LAST k-step of
+  // tile kt-1 (or zeros).  On exit: (xa1, wb1) hold the last k-step of tile kt, everything else is consumed.
+  auto tile_body = [&](int kt, auto has_next) {
+    const char* sa = smem + (kt & 1) * STAGE + (wm * TM) * 128;
+    const char* sb = smem + (kt & 1) * STAGE + A_BYTES + (wn * TN) * 128;
+    load_frags(sa, sb, 0, xa0, wb0);
+    if constexpr (decltype(has_next)::value && (ABL & 1) == 0) issue_stage((kt + 1) & 1, kt + 1);
+    mma(xa1, wb1);  // k-step 3 of the previous tile: covers the barrier release, the DMA issue and the reads above
+    load_frags(sa, sb, 1, xa1, wb1);
+    mma(xa0, wb0);
+    load_frags(sa, sb, 2, xa0, wb0);
+    mma(xa1, wb1);
+    load_frags(sa, sb, 3, xa1, wb1);
+    mma(xa0, wb0);
+    // pin the order (masks: MFMA 0x008, VMEM 0x010, DS read 0x100)
+    if constexpr (ABL != 0) return;  // ablations: leave the order to the compiler
+    __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+    if constexpr (decltype(has_next)::value) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
+      for (int i = 0; i < NDMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       }
+      if constexpr (NM > NDMA) __builtin_amdgcn_sched_group_barrier(0x008, NM - NDMA, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+    }
+  };
+
+  const int KT = p.K >> 6;
+  issue_stage(0, 0);
+  for (int kt = 0; kt < KT - 1; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tile_body(kt, std::true_type{});
   }
-  if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  tile_body(KT - 1, std::false_type{});
+  mma(xa1, wb1);
+
+  if constexpr ((ABL & 4) != 0) {
+    float ssum = 0.f;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[ni][mi][r];
-          acc[ni][mi][r] = v / (1.0f + __expf(-1.702f * v));
-        }
-  } else if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
+        for (int r = 0; r < 16; ++r) ssum += acc[ni][mi][r];
+    if (ssum == 1.2345678e33f) reinterpret_cast<float*>(p.C)[0] = ssum;
+    return;
+  }
+  if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, p, m0, n0, wm, wn, lane, wave, smem);
+  else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Deep-ring kernel ("Q"): 256 x 256 tile, BK = 32, FOUR-stage LDS ring (4 x 32 KiB), 8 waves.
+// Why: with a 2-stage ring the DMA for K-tile k+1 is issued at the barrier of tile k and drained (vmcnt(0)) at the
+// barrier of tile k+1, so at most one tile is in flight and the L2->LDS stream stops between tiles; measured, the
+// load skeleton alone (no MFMA) ran at ~24 B/clk/CU and barely overlapped the matrix work.  Here three 32-wide
+// stages (96 KiB per CU) are ALWAYS in flight: stage s+3 is issued right after the barrier that retires stage s-1,
+// and the wait before the next barrier is a COUNTED vmcnt (8 = the pieces of the two younger stages), never 0.
+// One raw s_barrier per stage; fragment reads are software-pipelined one k16-step deep ACROSS the barrier.
+// Stage image: tile row = 64 B (4 chunks of 16 B), 4 rows per 256-B bank row, slot' = slot ^ (bankrow & 3)
+// (conflict-free for ds_read_b128 lane groups; applied on the DMA source address, undone on the read).
+// LDS-DMA piece through inline asm: 1 KiB (64 lanes x 16 B) from per-lane global addresses to the wave-uniform LDS
+// byte address `lds_dst`.  hipcc does not model it (no LDS-alias drain of lgkmcnt before it, no vmcnt bookkeeping):
+// completion is counted by hand with s_waitcnt vmcnt(N).  M0 is saved/restored inside the statement (guide 5.7).
+__device__ __forceinline__ void dma_piece(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <bool OUT_F32, int ACT, int GM, int SCHED = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_q(const GemmArgs p, const int tiles_m) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;  // 128 x 64 per wave: MI 4, NI 2
+  constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;               // 16 KiB + 16 KiB
+  constexpr int NF = NI + MI, NM = NI * MI;                              // 6 fragment reads, 8 MFMAs per k16-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];            // 4 * STAGE = 128 KiB
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * p.tiles_n;
+    const int grp = bid / per_group, within = bid - grp * per_group;
+    const int gm0 = grp * GM;
+    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tn = within / rows;
+    tm = gm0 + (within - tn * rows);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+
+  // DMA: a 1-KiB piece = 16 tile rows; piece i of the A (or W) half covers rows 16i..16i+15; wave w moves pieces
+  // w and w+8 of each half.  LDS position of lane: bank row 4i + (lane>>4), slot' = lane&15.
+  const int slot = (lane & 15) ^ (lane >> 4);          // (bank row & 3) == lane>>4
+  const int row16 = 4 * (lane >> 4) + (slot >> 2);     // row inside the 16-row piece
+  const int chunk = slot & 3;                          // 16-byte chunk inside the 64-byte row
+  uint32_t a_off[2], b_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int r = m0 + 16 * (wave + NW * j) + row16;
+    r = r < p.M ? r : p.M - 1;
+    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+    int rn = n0 + 16 * (wave + NW * j) + row16;
+    rn = rn < p.N ? rn : p.N - 1;
+    b_off[j] = ((uint32_t)rn * (uint32_t)p.ldw + chunk * 8) * 2u;
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  auto issue_stage = [&](int st) {
+    char* sbase = smem + (st & 3) * STAGE;
+    const uint32_t kbytes = (uint32_t)st * 64u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((glb_u32p)(Ab + a_off[j] + kbytes), (lds_u32p)(sbase + (wave + NW * j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((glb_u32p)(Wb + b_off[j] + kbytes),
+                                       (lds_u32p)(sbase + A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
+  };
+
+  // fragment read: row l31 of a 32-row block (8 bank rows), chunk 2t + half; bank row & 3 == (l31 >> 2) & 3
+  const int l31 = lane & 31, half = lane >> 5;
+  int roff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    roff[t] = (l31 >> 2) * 256 + (((((l31 & 3) << 2) | (2 * t + half)) ^ ((l31 >> 2) & 3)) << 4);
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+  bf16x8 xa0[MI], wb0[NI], xa1[MI], wb1[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xa1[mi][j] = (bf16)0.f;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
+
+  auto load_frags = [&](const char* sa, const char* sb, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 32 * 64 + roff[t]);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 32 * 64 + roff[t]);
+  };
+  auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+  };
+  // one 32-wide stage between two barriers.  On entry (xa1, wb1) = 2nd k16-step of the previous stage (or zeros).
+  auto mma_range = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI], int i0, int i1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[ni][mi][r];
-          acc[ni][mi][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        }
+    for (int i = 0; i < NM; ++i)
+      if (i >= i0 && i < i1)
+        acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
+  auto stage_body = [&](int st, auto issue_next) {
+    const char* sa = smem + (st & 3) * STAGE + (wm * TM) * 64;
+    const char* sb = smem + (st & 3) * STAGE + A_BYTES + (wn * TN) * 64;
+    if constexpr (SCHED == 1) {
+      // k16-step = [1 MFMA | all 6 fragment reads of the NEXT step (front-loaded: 7 MFMAs of cover) | MFMA | DMA piece |
+      // 3 MFMA | DMA piece | 3 MFMA]; the 4 DMA pieces of stage st+3 are spread over the whole stage instead of bursting
+      constexpr bool ISS = decltype(issue_next)::value;
+      const uint32_t dst = lds0 + ((st + 3) & 3) * STAGE + wave * 1024;
+      const uint32_t kb = (uint32_t)(st + 3) * 64u;
+      mma_range(xa1, wb1, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);  // the wait for THIS step's fragments stays in front of the new reads
+      load_frags(sa, sb, 0, xa0, wb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_range(xa1, wb1, 1, 2);
+      if constexpr (ISS) dma_piece(Ab + a_off[0] + kb, dst);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_range(xa1, wb1, 2, 5);
+      if constexpr (ISS) dma_piece(Ab + a_off[1] + kb, dst + NW * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_range(xa1, wb1, 5, 8);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_range(xa0, wb0, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(sa, sb, 1, xa1, wb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_range(xa0, wb0, 1, 2);
+      if constexpr (ISS) dma_piece(Wb + b_off[0] + kb, dst + A_BYTES);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_range(xa0, wb0, 2, 5);
+      if constexpr (ISS) dma_piece(Wb + b_off[1] + kb, dst + A_BYTES + NW * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_range(xa0, wb0, 5, 8);
+      return;
+    }
+    // program order: DMA pieces BEFORE the fragment reads (an LDS-DMA issued behind pending ds_reads makes hipcc
+    // drain lgkmcnt first), then everything is re-interleaved behind the previous stage's last MFMA group
+    if constexpr (decltype(issue_next)::value) issue_stage(st + 3);
+    load_frags(sa, sb, 0, xa0, wb0);
+    mma(xa1, wb1);
+    load_frags(sa, sb, 1, xa1, wb1);
+    mma(xa0, wb0);
+    if constexpr (decltype(issue_next)::value) {
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM - 3, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+  };
+
+  const int NS = p.K >> 5;  // stages (>= 2 since K % 64 == 0)
+#pragma unroll 1
+  for (int st = 0; st < 3 && st < NS; ++st) issue_stage(st);
+  // steady state: two younger stages (8 pieces of this wave) stay in flight across the barrier
+  int st = 0;
+#pragma unroll 1
+  for (; st + 3 < NS; ++st) {
+    __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8) lgkmcnt(0) (gfx9 encoding: vm[3:0] | exp<<4 | lgkm<<8 | vm[5:4]<<14)
+    __builtin_amdgcn_s_barrier();
+    stage_body(st, std::true_type{});
   }
-  const bool has_res = p.R != nullptr;
+  // drain: the last three stages, nothing left to issue
+#pragma unroll 1
+  for (; st < NS; ++st) {
+    const int younger = NS - 1 - st;
+    if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0078);       // vmcnt(8) lgkmcnt(0)
+    else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    stage_body(st, std::false_type{});
+  }
+  mma(xa1, wb1);
+  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Staggered kernel ("S"): the Q kernel's geometry (256 x 256 tile, BK = 32, 4-stage 128 KiB ring, 8 waves = 2 per
+// SIMD) with the two wave halves running HALF A PERIOD APART.  Ablations of the lock-step kernels showed the MFMA
+// loop alone sustains 77 % of peak but drops to 40 % as soon as fragment reads + DMA are added: both waves of a SIMD
+// hit their LDS waits at the same time (matrix pipe idle) and then fight for the pipe at the same time.  Here every
+// stage is split into a LOAD section (4 DMA pieces of stage s+3, the 12 fragment reads of stage s, counted vmcnt +
+// lgkmcnt drain) and a MATRIX section (16 MFMAs under s_setprio 1), separated by raw s_barriers; waves 4-7 execute
+// one extra barrier up front, so on each SIMD one wave is always in its matrix section while its partner loads:
+//        interval:   0      1      2      3      4
+//        waves 0-3:  L(0)   M(0)   L(1)   M(1)   L(2) ...
+//        waves 4-7:  -      L(0)   M(0)   L(1)   M(1) ...
+// Hazards (s = stage, buffer = s & 3, all barriers are whole-workgroup):
+//   RAW  stage x is first read in L(x); its pieces were issued in L(x-3) and are waited for (vmcnt(8) = the two
+//        younger stages may stay in flight) in L(x-1), which ends with a barrier BEFORE any L(x) starts.
+//   WAR  the DMA for stage x (issued in L(x-3)) overwrites stage x-4, whose last reads (other half's L(x-4)) were
+//        drained (lgkmcnt(0)) before the barrier that ends that interval, i.e. before L(x-3) of either half starts.
+// TRACE: waves 0 and 4 of the first 64 blocks stamp s_memtime at every section boundary into `trace`
+// ([block][2 waves][256] u64) — diagnostic variant 14, see tools/gemm_trace.py
+template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, const int tiles_m, unsigned long long* trace = nullptr) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * p.tiles_n;
+    const int grp = bid / per_group, within = bid - grp * per_group;
+    const int gm0 = grp * GM;
+    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tn = within / rows;
+    tm = gm0 + (within - tn * rows);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+
+  const int slot = (lane & 15) ^ (lane >> 4);
+  const int row16 = 4 * (lane >> 4) + (slot >> 2);
+  const int chunk = slot & 3;
+  uint32_t a_off[2], b_off[2];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm * TM + mi * 32 + l31;
-    const bool mok = m < p.M;
+  for (int j = 0; j < 2; ++j) {
+    int r = m0 + 16 * (wave + NW * j) + row16;
+    r = r < p.M ? r : p.M - 1;
+    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+    int rn = n0 + 16 * (wave + NW * j) + row16;
+    rn = rn < p.N ? rn : p.N - 1;
+    b_off[j] = ((uint32_t)rn * (uint32_t)p.ldw + chunk * 8) * 2u;
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  auto issue_stage = [&](int st) {
+    char* sbase = smem + (st & 3) * STAGE;
+    const uint32_t kbytes = (uint32_t)st * 64u;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int nb = n0 + wn * TN + ni * 32 + 4 * half;
-      f32x4 v[4];
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((glb_u32p)(Ab + a_off[j] + kbytes), (lds_u32p)(sbase + (wave + NW * j) * 1024), 16, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = nb + 8 * g;
-        const bool ok = mok && (n + 3 < p.N);
-        f32x4 t;
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((glb_u32p)(Wb + b_off[j] + kbytes),
+                                       (lds_u32p)(sbase + A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
+  };
+
+  const int l31 = lane & 31, half = lane >> 5;
+  int roff[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = acc[ni][mi][4 * g + j];
-        if (has_res && ok) {
-          f32x4 rv;
-          if constexpr (OUT_F32) rv = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
-          else rv = load4(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+  for (int t = 0; t < 2; ++t)
+    roff[t] = (l31 >> 2) * 256 + (((((l31 & 3) << 2) | (2 * t + half)) ^ ((l31 >> 2) & 3)) << 4);
+
+  f32x16 acc[NI][MI];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] += rv[j];
-        }
-        if constexpr (OUT_F32) {
-          if (ok) store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, t);
-        }
-        v[g] = t;
-      }
-      if constexpr (!OUT_F32) {
-        // pack to bf16 and widen the stores: groups (g, g+1) -> one 16-byte store per lane (T21)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          bf16x4 pa, pb;
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { pa[j] = (bf16)v[g][j]; pb[j] = (bf16)v[g + 1][j]; }
-          uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
-          // lanes 32-63 of `ua` <-> lanes 0-31 of `ub`
-          auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
-          auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
-          const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-          // lower half now holds columns 8g..8g+7 of its row, upper half columns 8(g+1)..8(g+1)+7
-          const int n = n0 + wn * TN + ni * 32 + 8 * (g + half);
-          if (mok && n + 7 < p.N)
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
-        }
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+  bf16x8 xa[2][MI], wb[2][NI];  // both k16-steps of one stage
+  int tix = 0;
+  unsigned long long* tr = nullptr;
+  if constexpr (TRACE) {
+    if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
+  }
+  auto stamp = [&]() {
+    if constexpr (TRACE) {
+      if (tr != nullptr && tix < 255) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) tr[1 + tix] = t;
+        ++tix;
       }
     }
+  };
+
+  // LOAD section of stage st: DMA of stage st+3 first (an LDS-DMA behind pending ds_reads would make hipcc drain them)
+  auto load_section = [&](int st, auto issue_next, auto waitcode) {
+    if constexpr (decltype(issue_next)::value && (ABL & 1) == 0) issue_stage(st + 3);
+    if constexpr (TRACE) { __builtin_amdgcn_sched_barrier(0); stamp(); }
+    const char* sa = smem + (st & 3) * STAGE + (wm * TM) * 64;
+    const char* sb = smem + (st & 3) * STAGE + A_BYTES + (wn * TN) * 64;
+    if constexpr ((ABL & 8) == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wb[t][ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 32 * 64 + roff[t]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xa[t][mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 32 * 64 + roff[t]);
+      }
+    }
+    if constexpr (TRACE) {
+      __builtin_amdgcn_sched_barrier(0); stamp();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+      __builtin_amdgcn_sched_barrier(0); stamp();
+    }
+    __builtin_amdgcn_s_waitcnt(decltype(waitcode)::value);  // fragments in registers; next stage's own pieces landed
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto matrix_section = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[t][ni], xa[t][mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using W8 = std::integral_constant<int, 0x0078>;  // vmcnt(8) lgkmcnt(0)
+  using W4 = std::integral_constant<int, 0x0074>;  // vmcnt(4) lgkmcnt(0)
+  using W0 = std::integral_constant<int, 0x0070>;  // vmcnt(0) lgkmcnt(0)
+
+  stamp();
+  const int NS = p.K >> 5;
+#pragma unroll 1
+  for (int st = 0; st < 3 && st < NS; ++st) issue_stage(st);
+  // stage 0 visible to everyone before the first load section
+  if (NS >= 3) __builtin_amdgcn_s_waitcnt(0x0078); else if (NS == 2) __builtin_amdgcn_s_waitcnt(0x0074); else __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger: waves 4-7 run one interval behind
+  stamp();
+
+  int st = 0;
+#pragma unroll 1
+  for (; st + 3 < NS; ++st) {
+    load_section(st, std::true_type{}, W8{});
+    stamp();
+    __builtin_amdgcn_s_barrier();
+    stamp();
+    matrix_section();
+    stamp();
+    __builtin_amdgcn_s_barrier();
+    stamp();
+  }
+#pragma unroll 1
+  for (; st < NS; ++st) {
+    const int younger = NS - 2 - st;  // issued stages younger than st+1
+    if (younger >= 2) load_section(st, std::false_type{}, W8{});
+    else if (younger == 1) load_section(st, std::false_type{}, W4{});
+    else load_section(st, std::false_type{}, W0{});
+    __builtin_amdgcn_s_barrier();
+    matrix_section();
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
+  stamp();
+  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
+  stamp();
+  if constexpr (TRACE) {
+    if (tr != nullptr && lane == 0) tr[0] = (unsigned long long)tix;
   }
 }
 
@@ -296,13 +1007,64 @@ static int launch_tiled(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16");
 }
 
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true>
+static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto kern = gemm_bf16_nt_kernel_p<BM, BN, WM, WN, OUT_F32, ACT, GM, ABL, LDSEPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, st, p, tiles_m);
+  return launch_status("gemm_bf16_p");
+}
+
+template <bool OUT_F32, int ACT, int GM, int SCHED = 0>
+static int launch_tiled_q(GemmArgs& p, hipStream_t st) {
+  constexpr int smem = 4 * 512 * 64;
+  auto kern = gemm_bf16_nt_kernel_q<OUT_F32, ACT, GM, SCHED>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m);
+  return launch_status("gemm_bf16_q");
+}
+
+static unsigned long long* g_gemm_trace = nullptr;
+
+template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
+static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
+  constexpr int smem = 4 * 512 * 64;
+  auto kern = gemm_bf16_nt_kernel_s<OUT_F32, ACT, GM, TRACE, ABL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m, TRACE ? g_gemm_trace : nullptr);
+  return launch_status("gemm_bf16_s");
+}
+
 template <bool OUT_F32, int ACT>
 static int dispatch_variant(GemmArgs& p, hipStream_t st) {
   int v = g_gemm_variant;
   if (v == 0) {
-    // default policy: big tile when the grid still fills the chip, else the 128x128 tile
+    // default policy: the pipelined 256x256 kernel whenever its grid reaches a good fraction of the 256 CUs,
+    // else the 128x128 tile (4x the blocks).  Measured per shape with tools/kernel_bench.py.
     const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    v = (t256 >= 256) ? 1 : 2;
+    v = (t256 >= 96) ? 7 : 6;
   }
   switch (v) {
     case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);
@@ -311,6 +1073,26 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     case 4: return launch_tiled<128, 256, 2, 4, OUT_F32, ACT, false>(p, st);
     case 5: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
     case 6: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(p, st);
+    case 7: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(p, st);
+    case 9: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, false>(p, st);  // direct-store epilogue
+    case 10: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 1>(p, st);
+    case 11: return launch_tiled_q<OUT_F32, ACT, 8>(p, st);
+    case 12: return launch_tiled_q<OUT_F32, ACT, 8, 1>(p, st);
+    case 13: return launch_tiled_s<OUT_F32, ACT, 8>(p, st);
+    case 14: return launch_tiled_s<OUT_F32, ACT, 8, true>(p, st);  // + section timestamps
+    case 15: return launch_tiled_s<OUT_F32, ACT, 8, true, 1>(p, st);  // trace, no DMA in the loop (wrong results)
+    case 16: return launch_tiled_s<OUT_F32, ACT, 8, true, 8>(p, st);  // trace, no fragment reads (wrong results)
+    // ablations of the pipelined kernel (WRONG results, timing only): variant = 100 + mask
+    case 101: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 1>(p, st);
+    case 102: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 2>(p, st);
+    case 104: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 4>(p, st);
+    case 105: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 5>(p, st);
+    case 108: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 8>(p, st);
+    case 112: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 12>(p, st);
+    case 113: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 13>(p, st);
+    case 116: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 16>(p, st);
+    case 114: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 14>(p, st);  // DMA + barriers only
+    case 106: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 6>(p, st);   // DMA + reads, no MFMA, no epilogue
     default: set_error("gemm: unknown variant %d", v); return MMAMD_E_BADARG;
   }
 }
@@ -337,6 +1119,11 @@ extern "C" int mmamd_set_gemm_variant(int variant) {
   return 0;
 }
 extern "C" int mmamd_get_gemm_variant(void) { return g_gemm_variant; }
+
+extern "C" int mmamd_debug_set_gemm_trace(void* buf) {
+  g_gemm_trace = reinterpret_cast<unsigned long long*>(buf);
+  return 0;
+}
 
 extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
                                int ldr, void* C, int ldc, int out_dtype, int M, int N, int K, int act,

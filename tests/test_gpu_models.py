@@ -189,7 +189,9 @@ def test_loss_module_semantics_on_device(golden):
     assert lo.logits_a.shape == tuple(z["logits_a_masked"].shape)
     np.testing.assert_allclose(host(lo.logits_a), z["logits_a_masked"], atol=1e-4)
     assert abs(float(lo.loss) - float(z["loss_masked"])) < 1e-4
-    assert list(lo.keys()) == ["loss", "logits_a", "logits_b", "loss_a", "loss_b"]
+    import dataclasses
+
+    assert [f.name for f in dataclasses.fields(lo)] == ["loss", "logits_a", "logits_b", "loss_a", "loss_b"]
 
 
 def test_global_loss_over_rccl_single_rank(golden, tmp_path):

@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""Run ONE GEMM problem a few times (for rocprofv3 --pmc passes):  python tools/one_gemm.py M N K act res variant [iters]"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from multimodal_amd import ops  # noqa: E402
+
+M, N, K, act, res, variant = (int(x) for x in sys.argv[1:7])
+iters = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(0)
+a = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+bias = torch.randn(N, generator=g).to(dev)
+out = torch.zeros((M, N), dtype=torch.float32 if res else torch.bfloat16, device=dev)
+ops.set_gemm_variant(variant)
+for _ in range(iters):
+    ops.gemm_bf16(a, w, bias, act=act, residual=out if res else None, out=out)
+torch.cuda.synchronize()
