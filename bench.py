@@ -35,6 +35,19 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md "Chip-l
 GF_PER_PAIR = 41.09             # BASELINE.md §3, CLIP ViT-B/16 + text, full S^2 attention counted
 
 
+def _blas_threads() -> int:
+    """Threads the numpy BLAS actually uses (OpenBLAS caps at its build-time MAX_THREADS, not os.cpu_count())."""
+    try:
+        from threadpoolctl import threadpool_info
+
+        n = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        if n:
+            return int(max(n))
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +166,7 @@ def main() -> None:
         a, b = oc.clip_forward(sd_host, im_s, id_s, 12, 8)
         o = oc.contrastive_loss_with_temperature(a, b, math.log(1 / 0.07))
         tcpu = time.perf_counter() - tc
-        cpu_baseline = {"value": round(n / tcpu, 3), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+        cpu_baseline = {"value": round(n / tcpu, 3), "unit": "pairs/s", "cores": _blas_threads(), "kind": "port",
                         "sample": f"first {n} pairs of the same synthetic ViT-B/16 batch, fp32 numpy+OpenBLAS oracle, "
                                   f"1 pass, {tcpu:.1f} s", "loss_on_sample": round(float(o["loss"]), 5)}
 

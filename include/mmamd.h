@@ -53,6 +53,8 @@ int mmamd_set_gemm_variant(int variant);
 int mmamd_get_gemm_variant(void);
 /* Diagnostic: device buffer of 64*2*256 uint64 that GEMM variant 14 fills with s_memtime stamps (NULL = off). */
 int mmamd_debug_set_gemm_trace(void* buf);
+/* Diagnostic: attention ablation variant (timing experiments; non-zero values compute WRONG results). */
+int mmamd_debug_set_attn_variant(int v);
 
 /* --- K2: row LayerNorm ----------------------------------------------------------------------
  * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta, statistics in fp32 (biased variance).
@@ -104,10 +106,11 @@ int mmamd_embed_tokens(const int64_t* ids, const void* table, int table_dtype, c
  * row(b) = x[b, idx(b), :] with idx(b) = 0 when ids == NULL (CLS, image_encoder.py:111) or
  * argmax_s ids[b,s] (first maximum; text_encoder.py:129-132).  out[b,e] = sum_k LN(row)[k] *
  * proj[k*proj_sk + e*proj_se]  (image: projection [d,E] -> sk=E,se=1; text: Linear weight [E,d] ->
- * sk=1,se=d).  normalize != 0 additionally applies F.normalize (models/clip/model.py:72-73). */
+ * sk=1,se=d).  normalize != 0 additionally applies F.normalize (models/clip/model.py:72-73).
+ * ws: scratch of B*d floats (the normalised pooled rows). */
 int mmamd_pool_ln_proj(const float* x, int S, int d, const int64_t* ids, const float* gamma,
                        const float* beta, float eps, const float* proj, int proj_sk, int proj_se,
-                       float* out, int B, int E, int normalize, mmamd_stream_t stream);
+                       float* out, int B, int E, int normalize, float* ws, mmamd_stream_t stream);
 
 /* F.normalize(x, p=2, dim=1, eps) on [rows,d]  (models/clip/model.py:72-73). */
 int mmamd_l2_normalize(const void* x, int x_dtype, void* y, int y_dtype, int rows, int d, float eps,

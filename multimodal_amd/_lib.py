@@ -28,13 +28,14 @@ PROTOTYPES = {
     "mmamd_set_gemm_variant": (_i, [_i]),
     "mmamd_get_gemm_variant": (_i, []),
     "mmamd_debug_set_gemm_trace": (_i, [_vp]),
+    "mmamd_debug_set_attn_variant": (_i, [_i]),
     "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_patchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmamd_vit_assemble_ln": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mmamd_embed_tokens": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mmamd_pool_ln_proj": (_i, [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "mmamd_pool_ln_proj": (_i, [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mmamd_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_clamp_scalar": (_i, [_vp, _i, _f, _i, _f, _vp]),
     "mmamd_contrastive_fwd": (

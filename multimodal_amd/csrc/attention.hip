@@ -19,6 +19,8 @@
 // above legal.  exp2 with log2(e)/sqrt(dh) folded into the score scale.
 // Replaces F.scaled_dot_product_attention under nn.MultiheadAttention (reference call sites:
 // models/clip/image_encoder.py:108, models/clip/text_encoder.py:121 with is_causal=True).
+#include <type_traits>
+
 #include "common.h"
 
 namespace mmamd {
@@ -28,160 +30,213 @@ constexpr int kKStride = 72;  // bf16 elements per K row in LDS (144 B: 16-B ali
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-template <int NKT, bool CAUSAL>
+// Persistent kernel: gridDim.x workgroups (2 per CU) walk the (batch, head) items.  While item i is being computed out
+// of LDS, the K/V rows of item i + grid are already in flight into registers (issue-early / write-late staging: the
+// r01 ablation showed ~50 of 150 us were the exposed K/V load latency at the head of every workgroup), and each wave's
+// next Q tile is prefetched the same way.
+// Softmax VALU diet (the first version spent ~270 instructions per 32-key tile for 8 MFMAs): the score scale is folded
+// into the exp2 argument (one FMA), masking code exists only in the peeled tail / diagonal tile, and the O / l rescale
+// runs only when some row's maximum grows by more than 2^8 (deferred max: P stays <= 256, exact in the normalisation).
+// ABL (timing experiments only, results WRONG): 1 = V staged row-major, 2 = no exp, 4 = no K/V global loads
+template <int NKT, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                            int S, int H, float scale_log2e) {
+                                                            int S, int H, int BH, float scale_log2e) {
   constexpr int SP = NKT * 32;   // padded key count
   constexpr int VS = SP + 4;     // V^T row stride (elements): (SP+4)/2 dwords = 2 (mod 4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Ks = reinterpret_cast<bf16*>(smem);                       // [SP][kKStride]
   bf16* Vt = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);   // [64][VS]
 
-  const int bh = blockIdx.x;
-  const int b = bh / H, h = bh - b * H;
   const int D = H * kDh;
   const size_t row_stride = (size_t)3 * D;
-  const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  // ---- stage K (row-major) and V (transposed); rows >= S are zero so padded keys contribute exact 0
-  for (int r = tid >> 3; r < SP; r += 32) {
-    const int c = tid & 7;
-    bf16x8 kv, vv;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
-    if (r < S) {
-      kv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + D + c * 8);
-      vv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + 2 * D + c * 8);
-    }
-    *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VS + r] = vv[j];
-  }
-  __syncthreads();
-
   const int l31 = lane & 31, half = lane >> 5;
   const int nqt = (S + 31) >> 5;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    // ---- Q fragments (B operand): row q, channels 16t + 8*half .. +7
+  const int srow = tid >> 3, schunk = tid & 7;
+
+  auto item_base = [&](int item) { return qkv + (size_t)(item / H) * S * row_stride + (item % H) * kDh; };
+
+  bf16x8 kreg[NKT], vreg[NKT];
+  auto load_item = [&](const bf16* base) {
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+      const int r = srow + 32 * i;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kreg[i][j] = (bf16)0.f; vreg[i][j] = (bf16)0.f; }
+      if (r < S && (ABL & 4) == 0) {
+        kreg[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + D + schunk * 8);
+        vreg[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + 2 * D + schunk * 8);
+      }
+    }
+  };
+  auto store_item = [&]() {  // rows >= S are zero so padded keys contribute exact 0
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+      const int r = srow + 32 * i;
+      *reinterpret_cast<bf16x8*>(Ks + r * kKStride + schunk * 8) = kreg[i];
+      if constexpr ((ABL & 1) != 0) {
+        *reinterpret_cast<bf16x8*>(Vt + r * 64 + schunk * 8) = vreg[i];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(schunk * 8 + j) * VS + r] = vreg[i][j];
+      }
+    }
+  };
+  auto load_q = [&](const bf16* base, int qt, bf16x8 (&qf)[4]) {
     const int q = qt * 32 + l31;
     const int qc = q < S ? q : S - 1;
-    bf16x8 qf[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * row_stride + 16 * t + 8 * half);
+    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * row_stride + 16 * t + 8 * half);
+  };
 
-    float m = -INFINITY, lsum = 0.f;  // running max (log2 domain) and running sum of this lane's query row
-    f32x16 ot[2];                     // ot[nt][r] = O[q][channel nt*32 + (r&3) + 8*(r>>2) + 4*half]
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+  int item = blockIdx.x;
+  if (item >= BH) return;
+  load_item(item_base(item));
+  bf16x8 qcur[4], qnext[4];
+  load_q(item_base(item), wave, qcur);
 
-    const int kt_end = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
-#pragma unroll 1
-    for (int kt = 0; kt < kt_end; ++kt) {
-      // ---- S^T tile: st[r] = score(query q, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
-      f32x16 st;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = 0.f;
-      const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * t);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], st, 0, 0, 0);
-      }
-      // ---- scale, mask (only tiles that can contain dead keys pay for it), tile max
-      const bool need_mask = (kt * 32 + 32 > S) || (CAUSAL && kt == qt);
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = st[r] * scale_log2e;
-        if (need_mask) {
-          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (key >= S || (CAUSAL && key > q)) v = -INFINITY;
-        }
-        st[r] = v;
-        tmax = fmaxf(tmax, v);
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      // key kt*32 is alive for every row of this tile pair (kt <= qt when causal; key 0 < S), so once a
-      // tile has been seen m_new is finite; alpha = exp2(-inf - finite) = 0 on the first tile
-      const float m_new = fmaxf(m, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-      m = m_new;
-      // ---- P = exp2(s - m), packed to bf16 pairs: pk[2g], pk[2g+1] = the 4 keys of accumulator group g
-      uint32_t pk[8];
-      float psum = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float e[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          e[j] = __builtin_amdgcn_exp2f(st[4 * g + j] - m_new);
-          psum += e[j];
-        }
-        bf16x2 p0, p1;
-        p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
-        pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
-        pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
-      }
-      lsum = lsum * alpha + psum;
+  for (; item < BH; item += gridDim.x) {
+    const bf16* base = item_base(item);
+    const int b = item / H, h = item - b * H;
+    store_item();
+    __syncthreads();
+    const int nitem = item + gridDim.x;
+    if (nitem < BH) load_item(item_base(nitem));  // in flight during the whole compute phase below
+
+    for (int qt = wave; qt < nqt; qt += 4) {
+      // prefetch the Q fragments this wave needs next: its next tile of this item, else its first tile of the next item
+      if (qt + 4 < nqt) load_q(base, qt + 4, qnext);
+      else if (nitem < BH && wave < nqt) load_q(item_base(nitem), wave, qnext);
+      const int q = qt * 32 + l31;
+
+      float m = -INFINITY, lsum = 0.f;  // running reference (scaled log2 domain) and running sum of this lane's row
+      f32x16 ot[2];                     // ot[nt][r] = O[q][channel nt*32 + (r&3) + 8*(r>>2) + 4*half]
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[nt][r] *= alpha;
-      // ---- O^T += V^T . P^T over this tile's 32 keys (two MFMA k-groups of 16)
+        for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+
+      auto tile = [&](int kt, auto masked) {
+        // ---- S^T tile: st[r] = score(query q, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
+        f32x16 st;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        // slots 0-3 = keys key0..key0+3, slots 4-7 = keys key0+8..key0+11 (per lane half), both operands
-        const int key0 = kt * 32 + 16 * jj + 4 * half;
-        u32x4 pw;
-        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const bf16* vrow = Vt + (nt * 32 + l31) * VS + key0;
-          const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
-          const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
-          u32x4 vw;
-          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
-          ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[nt], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * t);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qcur[t], st, 0, 0, 0);
         }
-      }
-    }
-    // ---- normalise and store: lane owns row q, channels nt*32 + 8g + 4*half + {0..3}
-    lsum += __shfl_xor(lsum, 32);
-    const float inv = 1.0f / lsum;
-    if (q < S) {
-      bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
+        if constexpr (decltype(masked)::value) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key >= S || (CAUSAL && key > q)) st[r] = -INFINITY;
+          }
+        }
+        float tmax = st[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float ts = tmax * scale_log2e;
+        // deferred max: move the reference only when a row grew by more than 2^8 (first tile: m = -inf -> always)
+        if (__any(ts > m + 8.0f)) {
+          const float m_new = fmaxf(m, ts);
+          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+          m = m_new;
+          lsum *= alpha;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[nt][r] *= alpha;
+        }
+        // ---- P = exp2(s*c - m), packed to bf16 pairs: pk[2g], pk[2g+1] = the 4 keys of accumulator group g
+        uint32_t pk[8];
+        float psum = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f32x4 o;
+          float e[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = ot[nt][4 * g + j] * inv;
-          store4(orow + nt * 32 + 8 * g + 4 * half, o);
+          for (int j = 0; j < 4; ++j) {
+            if constexpr ((ABL & 2) != 0) e[j] = st[4 * g + j];
+            else e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[4 * g + j], scale_log2e, -m));
+            psum += e[j];
+          }
+          bf16x2 p0, p1;
+          p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+          pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
+          pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
         }
+        lsum += psum;
+        // ---- O^T += V^T . P^T over this tile's 32 keys (two MFMA k-groups of 16)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          // slots 0-3 = keys key0..key0+3, slots 4-7 = keys key0+8..key0+11 (per lane half), both operands
+          const int key0 = kt * 32 + 16 * jj + 4 * half;
+          u32x4 pw;
+          pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const bf16* vrow = Vt + (nt * 32 + l31) * VS + key0;
+            const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+            const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+            u32x4 vw;
+            vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
+            ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[nt], 0, 0, 0);
+          }
+        }
+      };
+
+      // tiles that cannot contain a dead key run the mask-free body; the (at most one) partial / diagonal tile is peeled
+      const int kt_end = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
+      const int kt_last = kt_end - 1;
+      const bool last_masked = ((kt_last + 1) * 32 > S) || CAUSAL;
+      const int kt_plain = last_masked ? kt_last : kt_end;
+#pragma unroll 1
+      for (int kt = 0; kt < kt_plain; ++kt) tile(kt, std::false_type{});
+      if (last_masked) tile(kt_last, std::true_type{});
+
+      // ---- normalise and store: lane owns row q, channels nt*32 + 8g + 4*half + {0..3}
+      lsum += __shfl_xor(lsum, 32);
+      const float inv = 1.0f / lsum;
+      if (q < S) {
+        bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = ot[nt][4 * g + j] * inv;
+            store4(orow + nt * 32 + 8 * g + 4 * half, o);
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) qcur[t] = qnext[t];
     }
+    __syncthreads();  // every wave is done with this item's K/V before the next item overwrites LDS
   }
 }
 
-template <int NKT, bool CAUSAL>
+static int g_attn_variant = 0;
+
+template <int NKT, bool CAUSAL, int ABL = 0>
 static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st) {
   constexpr int SP = NKT * 32;
   constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2;
-  auto kern = attention_fwd_kernel<NKT, CAUSAL>;
+  auto kern = attention_fwd_kernel<NKT, CAUSAL, ABL>;
   static bool attr_done = false;
   if (!attr_done && smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) { set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), smem, st, (const bf16*)qkv, (bf16*)out, S, H,
+  const int BH = B * H;
+  const int grid = BH < 512 ? BH : 512;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,
                      scale * 1.4426950408889634f);
   return launch_status("attention_fwd");
 }
@@ -189,6 +244,11 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
 }  // namespace mmamd
 
 using namespace mmamd;
+
+extern "C" int mmamd_debug_set_attn_variant(int v) {
+  g_attn_variant = v;
+  return 0;
+}
 
 extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                                    mmamd_stream_t stream) {
@@ -198,6 +258,15 @@ extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int nkt = (S + 31) / 32;
+  if (g_attn_variant != 0 && nkt == 7 && !causal) {  // ablations, vision shape only
+    switch (g_attn_variant) {
+      case 1: return launch_attn<7, false, 1>(qkv, out, B, S, H, scale, st);
+      case 2: return launch_attn<7, false, 2>(qkv, out, B, S, H, scale, st);
+      case 3: return launch_attn<7, false, 3>(qkv, out, B, S, H, scale, st);
+      case 4: return launch_attn<7, false, 4>(qkv, out, B, S, H, scale, st);
+      case 7: return launch_attn<7, false, 7>(qkv, out, B, S, H, scale, st);
+    }
+  }
 #define ATTN_CASE(N)                                                              \
   case N:                                                                         \
     return causal ? launch_attn<N, true>(qkv, out, B, S, H, scale, st)            \

@@ -30,6 +30,25 @@ namespace mmamd {
 
 typedef uint32_t __attribute__((address_space(3))) * lds_u32p;
 typedef const uint32_t __attribute__((address_space(1))) * glb_u32p;
+typedef __attribute__((ext_vector_type(4))) int int32x4;
+
+// LDS-DMA through a buffer descriptor: per-lane 32-bit byte offset (constant over the K loop) + a SCALAR K offset.
+// The 64-bit-vaddr form (global_load_lds v[a:a+1], off) needs one v_lshl_add_u64 per piece; measured
+// (tools/microbench/mfma_dma_mix.hip) that VALU traffic beside a busy matrix pipe cuts the DMA stream of a CU from
+// 57 to 21 B/clk and was the reason every schedule of this kernel stalled at ~40 % MFMA utilisation.  The SRD /
+// saddr forms need no VALU at all and run at the full 57 B/clk next to full-rate MFMAs.
+__device__ void llvm_amdgcn_raw_buffer_load_lds(int32x4 rsrc, lds_u32p lds_ptr, int size, int voffset, int soffset,
+                                                int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+
+__device__ __forceinline__ int32x4 make_srd(const void* base, uint32_t bytes) {
+  const uint64_t p = reinterpret_cast<uint64_t>(base);
+  int32x4 r;
+  r[0] = (int)(uint32_t)(p & 0xffffffffu);
+  r[1] = (int)(uint32_t)((p >> 32) & 0xffffu);  // stride 0 (raw buffer)
+  r[2] = (int)bytes;                              // num_records in bytes: reads past the end return 0
+  r[3] = 0x00020000;
+  return r;
+}
 
 struct GemmArgs {
   const bf16* A;
@@ -391,6 +410,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 }
 
 
+// LDS-DMA piece through inline asm: 1 KiB (64 lanes x 16 B) from per-lane global addresses to the wave-uniform LDS
+// byte address `lds_dst`.  hipcc does not model it (no LDS-alias drain of lgkmcnt before it, no vmcnt bookkeeping):
+// completion is counted by hand with s_waitcnt vmcnt(N).  M0 is saved/restored inside the statement (guide 5.7).
+__device__ __forceinline__ void dma_piece(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// Same piece with the address split as SCALAR base (SGPR pair) + per-lane 32-bit byte offset: no VALU per piece.
+__device__ __forceinline__ void dma_piece_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Pipelined kernel ("P"): same tile geometry / LDS image / epilogue as above, different schedule.
 //   * the K loop is ROTATED across the barrier: the 4th k-step's MFMAs of tile k are issued AFTER the barrier
@@ -455,24 +494,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   }
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
+  // piece i of a stage (i < A_INSTR: activation rows, else weight rows): scalar base + K offset, per-lane 32-bit offset
+  auto issue_piece = [&](int buf, int kt, int i) {
+    const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
+    if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
+    else dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
+  };
   auto issue_stage = [&](int buf, int kt) {
-    char* sbase = smem + buf * STAGE;
-    const uint32_t kbytes = (uint32_t)kt * 128u;
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Ab + a_off[j] + kbytes),
-                                       (lds_u32p)(sbase + (wave + NW * j) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Wb + b_off[j] + kbytes),
-                                       (lds_u32p)(sbase + A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
+    for (int i = 0; i < NDMA; ++i) issue_piece(buf, kt, i);
   };
 
   const int l31 = lane & 31, half = lane >> 5;
   const int hsw = l31 >> 1;
-  int roff[4];
+  // per-lane LDS byte addresses of the fragment reads, fully precomputed per (buffer, k-step): the K loop is unrolled by
+  // two so the buffer is a compile-time constant and NO address VALU is left inside the loop (every VALU instruction
+  // beside the MFMA stream waits for an issue gap of the matrix pipe; the 8 v_add per K-tile cost ~25 % of the loop)
+  uint32_t ra[2][4], rb[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) roff[t] = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
+  for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
+      ra[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + (wm * TM) * 128 + ro;
+      rb[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
+    }
+  typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
 
   f32x16 acc[NI][MI];
 #pragma unroll
@@ -492,12 +540,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 #pragma unroll
     for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
 
-  auto load_frags = [&](const char* sa, const char* sb, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+  auto load_frags = [&](auto bufc, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
     if constexpr ((ABL & 8) != 0) return;
+    constexpr int BF = decltype(bufc)::value;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 32 * 128 + roff[t]);
+    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + ni * 32 * 128));
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 32 * 128 + roff[t]);
+    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + mi * 32 * 128));
   };
   auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
     if constexpr ((ABL & 2) != 0) {  // keep the fragment reads alive without the matrix work
@@ -515,31 +564,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   };
   // one K-tile between two barriers.  On entry: tile kt is visible in LDS, (xa1, wb1) hold the LAST k-step of
   // tile kt-1 (or zeros).  On exit: (xa1, wb1) hold the last k-step of tile kt, everything else is consumed.
-  auto tile_body = [&](int kt, auto has_next) {
-    const char* sa = smem + (kt & 1) * STAGE + (wm * TM) * 128;
-    const char* sb = smem + (kt & 1) * STAGE + A_BYTES + (wn * TN) * 128;
-    load_frags(sa, sb, 0, xa0, wb0);
-    if constexpr (decltype(has_next)::value && (ABL & 1) == 0) issue_stage((kt + 1) & 1, kt + 1);
-    mma(xa1, wb1);  // k-step 3 of the previous tile: covers the barrier release, the DMA issue and the reads above
-    load_frags(sa, sb, 1, xa1, wb1);
-    mma(xa0, wb0);
-    load_frags(sa, sb, 2, xa0, wb0);
-    mma(xa1, wb1);
-    load_frags(sa, sb, 3, xa1, wb1);
-    mma(xa0, wb0);
-    // pin the order (masks: MFMA 0x008, VMEM 0x010, DS read 0x100)
-    if constexpr (ABL != 0) return;  // ablations: leave the order to the compiler
-    __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
-    if constexpr (decltype(has_next)::value) {
+  auto mma_one = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI], int i) {
+    acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
+  };
+  auto tile_body = [&](int kt, auto bufc, const bool has_next) {
+    constexpr int BF = decltype(bufc)::value;
+    const bool NEXT = has_next && (ABL & 1) == 0;
+    // segment 1 (hand-ordered; the asm DMA is invisible to sched_group_barrier): this tile's first fragments, then the
+    // previous tile's last k-step with one DMA piece of tile kt+1 behind every MFMA
+    load_frags(bufc, 0, xa0, wb0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < NDMA; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      }
-      if constexpr (NM > NDMA) __builtin_amdgcn_sched_group_barrier(0x008, NM - NDMA, 0);
-    } else {
-      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    for (int i = 0; i < NM; ++i) {
+      mma_one(xa1, wb1, i);
+      if (NEXT && i < NDMA) issue_piece(BF ^ 1, kt + 1, i);  // wave-uniform scalar branch
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // segment 2 (compiler-scheduled under the pattern below): k-steps 0..2 with the next step's reads interleaved
+    load_frags(bufc, 1, xa1, wb1);
+    mma(xa0, wb0);
+    load_frags(bufc, 2, xa0, wb0);
+    mma(xa1, wb1);
+    load_frags(bufc, 3, xa1, wb1);
+    mma(xa0, wb0);
+    if constexpr (ABL != 0) return;  // ablations: leave the order to the compiler
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
@@ -550,17 +598,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
       if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
     }
   };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  auto sync_tile = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the tile have landed
+    __syncthreads();                                   // ... everyone's; and the previous tile's reads are done
+  };
 
-  const int KT = p.K >> 6;
-  issue_stage(0, 0);
-  for (int kt = 0; kt < KT - 1; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    tile_body(kt, std::true_type{});
+  if constexpr ((ABL & 32) != 0) {
+    // experiment: break the lock-step of the first wave of blocks (all CUs otherwise hit their store bursts together)
+    if (blockIdx.x < 256) {
+      const int phase = (blockIdx.x >> 3) & 3;  // 4 phases inside every XCD
+      for (int i = 0; i < phase * 2; ++i) __builtin_amdgcn_s_sleep(127);  // 127*64 cycles ~ 3.4 us each -> ~T/4 per phase
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  tile_body(KT - 1, std::false_type{});
+  const int KT = p.K >> 6;  // even (checked by the launcher): two tiles per trip, the buffer index is a compile-time constant
+  issue_stage(0, 0);
+#pragma unroll 1
+  for (int kt = 0; kt < KT; kt += 2) {
+    sync_tile();
+    tile_body(kt, B0{}, true);
+    sync_tile();
+    tile_body(kt + 1, B1{}, kt + 2 < KT);
+  }
   mma(xa1, wb1);
 
   if constexpr ((ABL & 4) != 0) {
@@ -589,17 +649,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 // One raw s_barrier per stage; fragment reads are software-pipelined one k16-step deep ACROSS the barrier.
 // Stage image: tile row = 64 B (4 chunks of 16 B), 4 rows per 256-B bank row, slot' = slot ^ (bankrow & 3)
 // (conflict-free for ds_read_b128 lane groups; applied on the DMA source address, undone on the read).
-// LDS-DMA piece through inline asm: 1 KiB (64 lanes x 16 B) from per-lane global addresses to the wave-uniform LDS
-// byte address `lds_dst`.  hipcc does not model it (no LDS-alias drain of lgkmcnt before it, no vmcnt bookkeeping):
-// completion is counted by hand with s_waitcnt vmcnt(N).  M0 is saved/restored inside the statement (guide 5.7).
-__device__ __forceinline__ void dma_piece(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
 template <bool OUT_F32, int ACT, int GM, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_q(const GemmArgs p, const int tiles_m) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
@@ -1009,6 +1058,8 @@ static int launch_tiled(GemmArgs& p, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true>
 static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
+  // the pipelined kernel walks the K-tiles in pairs (compile-time buffer index): odd tile counts take the plain kernel
+  if (((p.K >> 6) & 1) != 0) return launch_tiled<BM, BN, WM, WN, OUT_F32, ACT, true>(p, st);
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = gemm_bf16_nt_kernel_p<BM, BN, WM, WN, OUT_F32, ACT, GM, ABL, LDSEPI>;
   static bool attr_done = false;
@@ -1091,6 +1142,7 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     case 112: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 12>(p, st);
     case 113: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 13>(p, st);
     case 116: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 16>(p, st);
+    case 132: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 32>(p, st);  // start-stagger experiment (correct)
     case 114: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 14>(p, st);  // DMA + barriers only
     case 106: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 6>(p, st);   // DMA + reads, no MFMA, no epilogue
     default: set_error("gemm: unknown variant %d", v); return MMAMD_E_BADARG;

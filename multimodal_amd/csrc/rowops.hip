@@ -201,81 +201,94 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ im
 }
 
 // ---------------------------------------------------------------------------------------------
-// pooled row -> LN -> projection -> (L2 normalize).  One 256-thread block per sample.
+// pooled row -> LN -> projection (-> L2 normalize)
+//   pool_ln_kernel : one wave per sample: EOT index = first argmax of the ids (or 0), LayerNorm of that row -> h[B,d] fp32
+//   proj_f32_kernel: out[B,E] = h[B,d] . P on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), one wave per 32x32 tile;
+//                    P element (k,e) at proj[k*sk + e*se]: [d,E] parameter (sk=E,se=1) or Linear weight [E,d] (sk=1,se=d)
+//   (the first version did the projection as a block-per-sample mat-vec that re-read the whole matrix per sample:
+//    276 us per call in the r01 rocprof trace)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
-  v = wave_sum(v);
-  const int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[w] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+__global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ x, int S, int d,
+                                                      const int64_t* __restrict__ ids, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, float* __restrict__ h, int B) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int best_i = 0;
+  if (ids != nullptr) {
+    long long best_v = INT64_MIN;
+    best_i = 0x7fffffff;
+    for (int s = lane; s < S; s += 64) {
+      const long long v = ids[(size_t)b * S + s];
+      if (v > best_v) { best_v = v; best_i = s; }  // ascending s: keeps the first maximum
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const long long ov = __shfl_xor(best_v, off);
+      const int oi = __shfl_xor(best_i, off);
+      if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+    }
+  }
+  const float* xr = x + ((size_t)b * S + best_i) * d;
+  float s1 = 0.f;
+  for (int k = lane; k < d; k += 64) s1 += xr[k];
+  const float mean = wave_sum(s1) / (float)d;
+  float s2 = 0.f;
+  for (int k = lane; k < d; k += 64) { const float t = xr[k] - mean; s2 += t * t; }
+  const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + eps);
+  float* hr = h + (size_t)b * d;
+  for (int k = lane; k < d; k += 64) hr[k] = (xr[k] - mean) * rstd * gamma[k] + beta[k];
 }
 
-__global__ __launch_bounds__(256) void pool_ln_proj_kernel(
-    const float* __restrict__ x, int S, int d, const int64_t* __restrict__ ids,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    const float* __restrict__ proj, int sk, int se, float* __restrict__ out, int E, int normalize) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // h[d] | o[E] | red[4] | idx
-  float* h = sm;
-  float* o = sm + d;
-  float* red = o + E;
-  int* sidx = reinterpret_cast<int*>(red + 4);
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-  if (wv == 0) {
-    int best_i = 0;
-    if (ids != nullptr) {
-      long long best_v = INT64_MIN;
-      best_i = 0x7fffffff;
-      for (int s = lane; s < S; s += 64) {
-        const long long v = ids[(size_t)b * S + s];
-        if (v > best_v) { best_v = v; best_i = s; }  // ascending s: keeps the first maximum
-      }
+__global__ __launch_bounds__(256) void proj_f32_kernel(const float* __restrict__ h, const float* __restrict__ proj, int sk,
+                                                       int se, float* __restrict__ out, int B, int d, int E) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 32;
+  const int j0 = (blockIdx.x * 4 + wv) * 32;
+  if (j0 >= E) return;  // wave-uniform
+  const int half = lane >> 5;
+  int ri = i0 + (lane & 31); ri = ri < B ? ri : B - 1;
+  int rj = j0 + (lane & 31); rj = rj < E ? rj : E - 1;
+  const float* lp = h + (size_t)ri * d;
+  const float* rp = proj + (size_t)rj * se;
+  const bool vec = (sk == 1) && ((d & 3) == 0) && ((se & 3) == 0) && ((reinterpret_cast<uintptr_t>(proj) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(h) & 15) == 0);
+  f32x16 acc;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const long long ov = __shfl_xor(best_v, off);
-        const int oi = __shfl_xor(best_i, off);
-        if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
-      }
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < d; k0 += 8) {
+    const int k = k0 + 4 * half;
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
+    if (vec && k + 3 < d) {
+      xv = load4(lp + k);
+      yv = load4(rp + k);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + u < d) { xv[u] = lp[k + u]; yv[u] = rp[(size_t)(k + u) * sk]; }
     }
-    if (lane == 0) *sidx = best_i;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u], yv[u], acc, 0, 0, 0);
   }
-  __syncthreads();
-  const float* xr = x + ((size_t)b * S + *sidx) * d;
+  const int j = j0 + (lane & 31);
+  if (j < E) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (i < B) out[(size_t)i * E + j] = acc[r];
+    }
+  }
+}
 
-  float s1 = 0.f;
-  for (int k = tid; k < d; k += 256) { const float v = xr[k]; h[k] = v; s1 += v; }
-  const float mean = block_sum_256(s1, red) / (float)d;
-  float s2 = 0.f;
-  for (int k = tid; k < d; k += 256) { const float t = h[k] - mean; s2 += t * t; }
-  const float rstd = 1.0f / sqrtf(block_sum_256(s2, red) / (float)d + eps);
-  for (int k = tid; k < d; k += 256) h[k] = (h[k] - mean) * rstd * gamma[k] + beta[k];
-  __syncthreads();
-
-  if (se == 1) {  // proj [d,E] row-major: thread per output column, coalesced across threads
-    for (int e = tid; e < E; e += 256) {
-      float acc = 0.f;
-      for (int k = 0; k < d; ++k) acc = fmaf(h[k], proj[(size_t)k * sk + e], acc);
-      o[e] = acc;
-    }
-  } else {  // proj [E,d] (Linear weight): wave per output, lanes stride over k
-    for (int e = wv; e < E; e += 4) {
-      float acc = 0.f;
-      for (int k = lane; k < d; k += 64) acc = fmaf(h[k], proj[(size_t)e * se + (size_t)k * sk], acc);
-      acc = wave_sum(acc);
-      if (lane == 0) o[e] = acc;
-    }
-  }
-  __syncthreads();
-  float scale = 1.f;
-  if (normalize) {
-    float ss = 0.f;
-    for (int e = tid; e < E; e += 256) ss += o[e] * o[e];
-    const float n = sqrtf(block_sum_256(ss, red));
-    scale = 1.0f / fmaxf(n, 1e-12f);
-  }
-  for (int e = tid; e < E; e += 256) out[(size_t)b * E + e] = o[e] * scale;
+__global__ __launch_bounds__(256) void l2_normalize_inplace_f32_kernel(float* __restrict__ x, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* xr = x + (size_t)row * d;
+  float ss = 0.f;
+  for (int k = lane; k < d; k += 64) { const float v = xr[k]; ss += v * v; }
+  const float sc = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
+  for (int k = lane; k < d; k += 64) xr[k] *= sc;
 }
 
 template <typename TI, typename TO>
@@ -383,14 +396,15 @@ extern "C" int mmamd_patchify(const void* images, int img_dtype, void* patches, 
 
 extern "C" int mmamd_pool_ln_proj(const float* x, int S, int d, const int64_t* ids, const float* gamma,
                                   const float* beta, float eps, const float* proj, int proj_sk, int proj_se,
-                                  float* out, int B, int E, int normalize, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(x && gamma && beta && proj && out && S > 0 && d > 0 && B >= 0 && E > 0, MMAMD_E_BADARG, "pool_ln_proj: bad argument");
+                                  float* out, int B, int E, int normalize, float* ws, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && gamma && beta && proj && out && ws && S > 0 && d > 0 && B >= 0 && E > 0, MMAMD_E_BADARG, "pool_ln_proj: bad argument");
   MMAMD_CHECK_ARG(proj_se == 1 || proj_sk == 1, MMAMD_E_UNSUPPORTED, "pool_ln_proj: projection must be contiguous along k or e");
-  const size_t smem = sizeof(float) * ((size_t)d + E + 4) + 16;
-  MMAMD_CHECK_ARG(smem <= 64 * 1024, MMAMD_E_UNSUPPORTED, "pool_ln_proj: d+E too large");
   if (B == 0) return 0;
-  hipLaunchKernelGGL(pool_ln_proj_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, x, S, d, ids, gamma, beta, eps,
-                     proj, proj_sk, proj_se, out, E, normalize);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pool_ln_kernel, dim3((B + 3) / 4), dim3(256), 0, st, x, S, d, ids, gamma, beta, eps, ws, B);
+  hipLaunchKernelGGL(proj_f32_kernel, dim3((E + 127) / 128, (B + 31) / 32), dim3(256), 0, st, ws, proj, proj_sk, proj_se, out, B, d, E);
+  if (normalize)
+    hipLaunchKernelGGL(l2_normalize_inplace_f32_kernel, dim3((B + 3) / 4), dim3(256), 0, st, out, B, E, 1e-12f);
   return launch_status("pool_ln_proj");
 }
 

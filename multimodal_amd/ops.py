@@ -152,9 +152,10 @@ def pool_ln_proj(x: torch.Tensor, B: int, S: int, ids: Optional[torch.Tensor], g
     if ids is not None:
         _chk(ids, "ids", torch.int64)
     out = torch.empty((B, E), dtype=torch.float32, device=x.device)
+    ws = torch.empty((B, d), dtype=torch.float32, device=x.device)
     check(_lib.lib().mmamd_pool_ln_proj(x.data_ptr(), S, d, _ptr(ids), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                                        proj.data_ptr(), sk, se, out.data_ptr(), B, E, int(bool(normalize)), _stream()),
-          "mmamd_pool_ln_proj")
+                                        proj.data_ptr(), sk, se, out.data_ptr(), B, E, int(bool(normalize)), ws.data_ptr(),
+                                        _stream()), "mmamd_pool_ln_proj")
     return out
 
 
