@@ -281,6 +281,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
   }
 }
 
+// LDS-DMA piece through inline asm: 1 KiB (64 lanes x 16 B) from per-lane global addresses to the wave-uniform LDS
+// byte address `lds_dst`.  hipcc does not model it (no LDS-alias drain of lgkmcnt before it, no vmcnt bookkeeping):
+// completion is counted by hand with s_waitcnt vmcnt(N).  M0 is saved/restored inside the statement (guide 5.7).
+__device__ __forceinline__ void dma_piece(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// Same piece with the address split as SCALAR base (SGPR pair) + per-lane 32-bit byte offset: no VALU per piece.
+__device__ __forceinline__ void dma_piece_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
 // BM x BN block tile, WM x WN waves, BK = 64
 template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArgs p) {
@@ -328,17 +348,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
 
-  auto issue_stage = [&](int buf, int kt) {
-    char* sbase = smem + buf * STAGE;
-    const uint32_t kbytes = (uint32_t)kt * 128u;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
+  auto issue_stage = [&](int buf, int kt) {  // scalar base + K offset, per-lane 32-bit offset: no VALU per piece
+    const uint32_t dst = lds0 + buf * STAGE + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Ab + a_off[j] + kbytes),
-                                       (lds_u32p)(sbase + (wave + NW * j) * 1024), 16, 0, 0);
+    for (int j = 0; j < A_INSTR; ++j) dma_piece_s(Ab + (size_t)kt * 128, a_off[j], dst + NW * j * 1024);
 #pragma unroll
-    for (int j = 0; j < B_INSTR; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Wb + b_off[j] + kbytes),
-                                       (lds_u32p)(sbase + A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
+    for (int j = 0; j < B_INSTR; ++j) dma_piece_s(Wb + (size_t)kt * 128, b_off[j], dst + A_BYTES + NW * j * 1024);
   };
 
   // ---- fragment read offsets: lane reads row (lane&31) of a 32-row block, 16-byte chunk 2t + (lane>>5)
@@ -409,26 +425,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
   gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane);
 }
 
-
-// LDS-DMA piece through inline asm: 1 KiB (64 lanes x 16 B) from per-lane global addresses to the wave-uniform LDS
-// byte address `lds_dst`.  hipcc does not model it (no LDS-alias drain of lgkmcnt before it, no vmcnt bookkeeping):
-// completion is counted by hand with s_waitcnt vmcnt(N).  M0 is saved/restored inside the statement (guide 5.7).
-__device__ __forceinline__ void dma_piece(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
-
-// Same piece with the address split as SCALAR base (SGPR pair) + per-lane 32-bit byte offset: no VALU per piece.
-__device__ __forceinline__ void dma_piece_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Pipelined kernel ("P"): same tile geometry / LDS image / epilogue as above, different schedule.
@@ -1112,10 +1108,36 @@ template <bool OUT_F32, int ACT>
 static int dispatch_variant(GemmArgs& p, hipStream_t st) {
   int v = g_gemm_variant;
   if (v == 0) {
-    // default policy: the pipelined 256x256 kernel whenever its grid reaches a good fraction of the 256 CUs,
-    // else the 128x128 tile (4x the blocks).  Measured per shape with tools/kernel_bench.py.
-    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    v = (t256 >= 96) ? 7 : 6;
+    // Default policy (measured per shape with tools/kernel_bench.py):
+    //  * the pipelined 256x256 kernel whenever its grid reaches a good fraction of the 256 CUs, else 128x128 tiles;
+    //  * wave quantisation: one workgroup per CU, so a grid of r = tiles/256 rounds with a small fractional part pays a
+    //    whole extra round (N = 768 GEMMs at B = 256: 591 tiles = 2.31 rounds -> 3).  Then the row range is split: the
+    //    first floor(r) full rounds run on 256x256 tiles, the remaining rows on 128x128 tiles (4x the workgroups, ~1/4
+    //    the time each), as a second launch on the same stream.
+    const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+    const long t256 = (long)tiles_m * tiles_n;
+    if (t256 < 96) {
+      v = 6;
+    } else {
+      v = 7;
+      const long full = t256 / 256, rem = t256 - full * 256;
+      if (full >= 1 && full <= 4 && rem > 0 && rem <= 128) {
+        const int m_tiles_big = (int)((full * 256) / tiles_n);  // whole row-panels that fit in the full rounds
+        if (m_tiles_big >= 1 && m_tiles_big < tiles_m) {
+          GemmArgs a = p, b = p;
+          const size_t rows = (size_t)m_tiles_big * 256;
+          a.M = (int)rows;
+          b.M = p.M - (int)rows;
+          b.A = p.A + rows * p.lda;
+          const size_t esz = OUT_F32 ? 4 : 2;
+          b.C = reinterpret_cast<char*>(p.C) + rows * p.ldc * esz;
+          if (p.R != nullptr) b.R = reinterpret_cast<const char*>(p.R) + rows * p.ldr * esz;
+          const int rc = launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
+          if (rc != 0) return rc;
+          return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
+        }
+      }
+    }
   }
   switch (v) {
     case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);

@@ -16,6 +16,9 @@ from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
 
 
+_SIDE_STREAMS = {}
+
+
 class CLIPOutput(NamedTuple):
     embeddings_a: torch.Tensor
     embeddings_b: torch.Tensor
@@ -45,11 +48,38 @@ class CLIP(nn.Module):
         self.encoder_b = encoder_b
 
     def forward(self, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
-        embeddings_a = self.encoder_a(features_a)
-        embeddings_b = self.encoder_b(features_b)
+        # The two towers are independent until the normalised features meet in the loss: run tower B on a side HIP
+        # stream so its small-grid kernels (77-token sequences: 150-600 workgroups per GEMM) fill the CUs that tower
+        # A's kernels leave idle in their last, partial wave of workgroups.  Pure stream plumbing: same kernels,
+        # same results.  MMAMD_SINGLE_STREAM=1 disables it.
+        side = self._side_stream(features_a)
+        if side is None:
+            embeddings_a = self.encoder_a(features_a)
+            embeddings_b = self.encoder_b(features_b)
+        else:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                embeddings_b = self.encoder_b(features_b)
+            embeddings_a = self.encoder_a(features_a)
+            main.wait_stream(side)
+            embeddings_b.record_stream(main)
         embeddings_a = ops.l2_normalize(embeddings_a.detach().contiguous(), eps=1e-12)
         embeddings_b = ops.l2_normalize(embeddings_b.detach().contiguous(), eps=1e-12)
         return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
+
+    def _side_stream(self, ref):
+        import os
+
+        if os.environ.get("MMAMD_SINGLE_STREAM") == "1" or not isinstance(ref, torch.Tensor) or not ref.is_cuda:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        s = _SIDE_STREAMS.get(ref.device)  # process-wide, not a module attribute (modules stay deep-copyable/picklable)
+        if s is None:
+            s = torch.cuda.Stream(device=ref.device)
+            _SIDE_STREAMS[ref.device] = s
+        return s
 
 
 def clip_vit_b16(pretrained: bool = False) -> CLIP:
