@@ -75,6 +75,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 static int g_gemm_variant = 0;
+static unsigned long long* g_gemm_trace = nullptr;
 
 // Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
 // n = .. + 8g + 4*(lane>>5) + {0..3}.
@@ -214,9 +215,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
         }
   }
   constexpr int ROWB = OUT_F32 ? (TN * 4 + 16) : (TN * 2 + 16);  // padded strip row: 272 B / 144 B (conflict-free b128)
+  const int nw0 = n0 + wn * TN;
+  const bool has_res = OUT_F32 && p.R != nullptr;
+  f32x4 rr[8], rn[8];
+  auto res_load = [&](int mi, f32x4 (&dst)[8]) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = m0 + wm * TM + mi * 32 + it * 4 + (lane >> 4), n = nw0 + (lane & 15) * 4;
+      dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+    }
+  };
+  if constexpr (OUT_F32) {
+    if (has_res) res_load(0, rr);  // in flight across the barrier and the first transpose
+  }
   __syncthreads();  // every wave is done reading the operand stages: LDS can be reused
   char* strip = smem + wave * (32 * ROWB);
-  const int nw0 = n0 + wn * TN;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int mrow0 = m0 + wm * TM + mi * 32;
@@ -231,20 +245,27 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
           *reinterpret_cast<f32x4*>(strip + l31 * ROWB + (ni * 32 + 8 * g + 4 * half) * 4) = t;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4 vv[8];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {  // 4 rows x 256 B per wave-instruction
-        const int row = it * 4 + (lane >> 4), c = lane & 15;
-        f32x4 v = *reinterpret_cast<const f32x4*>(strip + row * ROWB + c * 16);
-        const int m = mrow0 + row, n = nw0 + c * 4;
-        if (m < p.M && n + 3 < p.N && ((ABL & 16) == 0 || v[0] == 1.2345678e33f)) {
-          if (p.R != nullptr) {
-            const f32x4 rv = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+      for (int it = 0; it < 8; ++it)  // 4 rows x 256 B per wave-instruction
+        vv[it] = *reinterpret_cast<const f32x4*>(strip + (it * 4 + (lane >> 4)) * ROWB + (lane & 15) * 16);
+      // residual of the NEXT 32-row slab is requested before this slab is consumed: the (otherwise fully exposed)
+      // HBM/L2 round trip of every slab overlaps the previous slab's adds and stores (r01 trace: 39k of 72k ticks)
+      if (has_res && mi + 1 < MI) res_load(mi + 1, rn);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += rv[j];
+      for (int it = 0; it < 8; ++it) {
+        const int m = mrow0 + it * 4 + (lane >> 4), n = nw0 + (lane & 15) * 4;
+        if (m < p.M && n + 3 < p.N && ((ABL & 16) == 0 || vv[it][0] == 1.2345678e33f)) {
+          f32x4 v = vv[it];
+          if (has_res) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rr[it][j];
           }
           store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
         }
       }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) rr[it] = rn[it];
     } else {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -440,7 +461,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 // ABL (ablation bit mask, perf experiments only — results are WRONG for ABL != 0): 1 = no DMA in the loop,
 // 2 = no MFMA, 4 = no epilogue, 8 = no fragment reads, 16 = no global accesses in the epilogue
 template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m,
+                                                                        unsigned long long* trace = nullptr) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
@@ -594,6 +616,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
       if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
     }
   };
+  int tix = 0;
+  unsigned long long* tr = nullptr;
+  if constexpr ((ABL & 64) != 0) {
+    if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
+  }
+  auto stamp = [&]() {
+    if constexpr ((ABL & 64) != 0) {
+      if (tr != nullptr && tix < 255) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) tr[1 + tix] = t;
+        ++tix;
+      }
+    }
+  };
+  stamp();
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   auto sync_tile = [&]() {
@@ -613,10 +650,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 #pragma unroll 1
   for (int kt = 0; kt < KT; kt += 2) {
     sync_tile();
+    stamp();
     tile_body(kt, B0{}, true);
     sync_tile();
+    stamp();
     tile_body(kt + 1, B1{}, kt + 2 < KT);
   }
+  stamp();
   mma(xa1, wb1);
 
   if constexpr ((ABL & 4) != 0) {
@@ -632,6 +672,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   }
   if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, p, m0, n0, wm, wn, lane, wave, smem);
   else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane);
+  if constexpr ((ABL & 64) != 0) {
+    stamp();                                           // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores retired
+    stamp();
+    if (tr != nullptr && lane == 0) tr[0] = (unsigned long long)tix;
+  }
 }
 
 
@@ -1017,6 +1063,307 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent pipelined kernel ("PP", the production kernel): the P schedule, but ONE workgroup per CU walks the tiles
+// vb = blockIdx.x, + gridDim.x, ...  The r01 section trace of P showed 6 % of every tile in the exposed first-stage
+// load and 22-55 % in the epilogue; here the first K-tile of the NEXT output tile is DMA'd (into ring buffer 0, free
+// during the last K-tile) behind the last K-tile's MFMAs, so it lands while the epilogue runs out of ring buffer 1.
+//   * epilogue strips live in ring buffer 1 only (32 rows x 128 B per wave and pass, fp32 tiles in two column halves)
+//   * the fp32 residual of pass i+1 is requested before pass i is consumed
+//   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
+template <bool OUT_F32, int ACT, int GM>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int A_INSTR = 4, B_INSTR = 4, NDMA = 8, NF = NI + MI, NM = NI * MI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  auto tile_of = [&](int vb, int& tm, int& tn) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, loc = vb >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int per_group = GM * p.tiles_n;
+    const int grp = id / per_group, within = id - grp * per_group;
+    const int gm0 = grp * GM;
+    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tn = within / rows;
+    tm = gm0 + (within - tn * rows);
+  };
+
+  // DMA source offsets of this lane (see kernel above for the swizzle): depend on the tile, not on K
+  const int sw = (4 * (wave & 3) + (lane >> 4)) & 15;
+  const int slot = (lane & 15) ^ sw;
+  const int row8 = 2 * (lane >> 4) + (slot >> 3);
+  const int chunk = slot & 7;
+  auto tile_offsets = [&](int tm, int tn, uint32_t (&ao)[A_INSTR], uint32_t (&bo)[B_INSTR]) {
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      int r = tm * BM + 8 * (wave + NW * j) + row8;
+      r = r < p.M ? r : p.M - 1;
+      ao[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      int r = tn * BN + 8 * (wave + NW * j) + row8;
+      r = r < p.N ? r : p.N - 1;
+      bo[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
+    }
+  };
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
+  uint32_t a_off[A_INSTR], b_off[B_INSTR], a_nxt[A_INSTR], b_nxt[B_INSTR];
+  auto issue_piece = [&](int buf, int kt, int i) {
+    const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
+    if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
+    else dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
+  };
+
+  const int hsw = l31 >> 1;
+  uint32_t ra[2][4], rb[2][4];
+#pragma unroll
+  for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
+      ra[bf][t] = lds0 + bf * STAGE + (wm * TM) * 128 + ro;
+      rb[bf][t] = lds0 + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
+    }
+  typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
+
+  f32x16 acc[NI][MI];
+  bf16x8 xa0[MI], wb0[NI], xa1[MI], wb1[NI];
+  auto load_frags = [&](auto bufc, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+    constexpr int BF = decltype(bufc)::value;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + ni * 32 * 128));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + mi * 32 * 128));
+  };
+  auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+  };
+  auto mma_one = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI], int i) {
+    acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
+  };
+  // one K-tile out of ring buffer BF; behind the first MFMA group one DMA piece each of (ktsrc -> buffer BF^1)
+  auto tile_body = [&](auto bufc, int ktsrc, const bool issue) {
+    constexpr int BF = decltype(bufc)::value;
+    load_frags(bufc, 0, xa0, wb0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      mma_one(xa1, wb1, i);
+      if (issue && i < NDMA) issue_piece(BF ^ 1, ktsrc, i);  // wave-uniform scalar branch
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_frags(bufc, 1, xa1, wb1);
+    mma(xa0, wb0);
+    load_frags(bufc, 2, xa0, wb0);
+    mma(xa1, wb1);
+    load_frags(bufc, 3, xa1, wb1);
+    mma(xa0, wb0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+    }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  auto sync_tile = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  const int KT = p.K >> 6;  // even (launcher)
+  int vb = blockIdx.x;
+  int tm, tn;
+  tile_of(vb, tm, tn);
+  tile_offsets(tm, tn, a_off, b_off);
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) issue_piece(0, 0, i);
+
+  while (true) {
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nvb = vb + gridDim.x;
+    const bool more = nvb < ntiles;
+    int ntm = 0, ntn = 0;
+    if (more) {
+      tile_of(nvb, ntm, ntn);
+      tile_offsets(ntm, ntn, a_nxt, b_nxt);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xa1[mi][j] = (bf16)0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
+
+#pragma unroll 1
+    for (int kt = 0; kt < KT; kt += 2) {
+      sync_tile();
+      tile_body(B0{}, kt + 1, true);
+      const bool last = kt + 2 >= KT;
+      if (last && more) {  // this tile's loads are all issued: switch the DMA source to the next tile's first K-tile
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) a_off[j] = a_nxt[j];
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j) b_off[j] = b_nxt[j];
+      }
+      sync_tile();
+      tile_body(B1{}, last ? 0 : kt + 2, !last || more);
+    }
+    mma(xa1, wb1);  // flush the rotated last k-step
+
+    // ---------------- epilogue (LDS strips in ring buffer 1; buffer 0 is receiving the next tile) ----------------
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (n + 3 < p.N) bv = load4(p.bias + n);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
+        }
+    }
+    if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ni][mi][r] = quick_gelu(acc[ni][mi][r]);
+    } else if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[ni][mi][r];
+            acc[ni][mi][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+          }
+    }
+    constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
+    char* strip = smem + STAGE + wave * (32 * ROWB);
+    const int nw0 = n0 + wn * TN;
+    __syncthreads();  // every wave has finished reading the last K-tile out of ring buffer 1
+    if constexpr (OUT_F32) {
+      const bool has_res = p.R != nullptr;
+      const int rrow = lane >> 3, rc = (lane & 7) * 4;  // read-back: 8 rows x 128 B per wave-instruction
+      f32x4 rr[4], rn[4];
+      auto res_load = [&](int pass, f32x4 (&dst)[4]) {  // pass = mi * NI + ni
+        const int mi = pass / NI, ni = pass - mi * NI;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
+          dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+        }
+      };
+      if (has_res) res_load(0, rr);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int pass = mi * NI + ni;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = acc[ni][mi][4 * g + j];
+            *reinterpret_cast<f32x4*>(strip + l31 * ROWB + (8 * g + 4 * half) * 4) = t;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          f32x4 vv[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) vv[it] = *reinterpret_cast<const f32x4*>(strip + (it * 8 + rrow) * ROWB + rc * 4);
+          if (has_res && pass + 1 < MI * NI) res_load(pass + 1, rn);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
+            if (m < p.M && n + 3 < p.N) {
+              f32x4 v = vv[it];
+              if (has_res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rr[it][j];
+              }
+              store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
+            }
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) rr[it] = rn[it];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            bf16x4 pa, pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pa[j] = (bf16)acc[ni][mi][4 * g + j]; pb[j] = (bf16)acc[ni][mi][4 * (g + 1) + j]; }
+            uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+            auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+            *reinterpret_cast<uint4*>(strip + l31 * ROWB + (ni * 32 + 8 * (g + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
+          const int row = it * 8 + (lane >> 3), c = lane & 7;
+          uint4 v = *reinterpret_cast<const uint4*>(strip + row * ROWB + c * 16);
+          const int m = m0 + wm * TM + mi * 32 + row, n = nw0 + c * 8;
+          if (m < p.M && n + 7 < p.N) {
+            if (p.R != nullptr) {
+              const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+              bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
+              v = __builtin_bit_cast(uint4, a8);
+            }
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = v;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    if (!more) break;
+    vb = nvb;
+    tm = ntm;
+    tn = ntn;
+  }
+}
+
 // plain one-thread-per-output kernel: on-device cross-check for the MFMA kernels (tests / debugging)
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmArgs p) {
@@ -1066,7 +1413,8 @@ static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
   }
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, st, p, tiles_m);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, st, p, tiles_m,
+                     (ABL & 64) != 0 ? g_gemm_trace : nullptr);
   return launch_status("gemm_bf16_p");
 }
 
@@ -1086,8 +1434,6 @@ static int launch_tiled_q(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_q");
 }
 
-static unsigned long long* g_gemm_trace = nullptr;
-
 template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
 static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
   constexpr int smem = 4 * 512 * 64;
@@ -1104,6 +1450,25 @@ static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_s");
 }
 
+template <bool OUT_F32, int ACT, int GM>
+static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
+  if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
+  constexpr int smem = 2 * 512 * 128;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int ntiles = tiles_m * p.tiles_n;
+  const int grid = ntiles < 256 ? ntiles : 256;  // one persistent workgroup per CU (multiple of 8 when it matters)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, p, tiles_m, ntiles);
+  return launch_status("gemm_bf16_pp");
+}
+
 template <bool OUT_F32, int ACT>
 static int dispatch_variant(GemmArgs& p, hipStream_t st) {
   int v = g_gemm_variant;
@@ -1118,6 +1483,8 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     const long t256 = (long)tiles_m * tiles_n;
     if (t256 < 96) {
       v = 6;
+    } else if ((p.K & 127) == 0 && (t256 >= 1024 || (t256 >= 512 && p.K >= 2048))) {
+      v = 18;  // many tiles per CU: the persistent kernel hides each tile's first-stage load behind the previous epilogue
     } else {
       v = 7;
       const long full = t256 / 256, rem = t256 - full * 256;
@@ -1152,6 +1519,7 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     case 11: return launch_tiled_q<OUT_F32, ACT, 8>(p, st);
     case 12: return launch_tiled_q<OUT_F32, ACT, 8, 1>(p, st);
     case 13: return launch_tiled_s<OUT_F32, ACT, 8>(p, st);
+    case 18: return launch_tiled_pp<OUT_F32, ACT, 8>(p, st);
     case 14: return launch_tiled_s<OUT_F32, ACT, 8, true>(p, st);  // + section timestamps
     case 15: return launch_tiled_s<OUT_F32, ACT, 8, true, 1>(p, st);  // trace, no DMA in the loop (wrong results)
     case 16: return launch_tiled_s<OUT_F32, ACT, 8, true, 8>(p, st);  // trace, no fragment reads (wrong results)
@@ -1165,6 +1533,7 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     case 113: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 13>(p, st);
     case 116: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 16>(p, st);
     case 132: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 32>(p, st);  // start-stagger experiment (correct)
+    case 164: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 64>(p, st);  // section timestamps (correct)
     case 114: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 14>(p, st);  // DMA + barriers only
     case 106: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 6>(p, st);   // DMA + reads, no MFMA, no epilogue
     default: set_error("gemm: unknown variant %d", v); return MMAMD_E_BADARG;

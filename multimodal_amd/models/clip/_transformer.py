@@ -16,6 +16,7 @@ that feeds an MFMA is bf16.
 from __future__ import annotations
 
 import copy
+import os
 
 import torch
 from torch import nn
@@ -81,6 +82,10 @@ class TransformerStack(nn.Module):
         qkv = torch.empty((M, 3 * d), dtype=bf, device=dev)
         att = torch.empty((M, d), dtype=bf, device=dev)
         up = torch.empty((M, self.dim_feedforward), dtype=bf, device=dev)
+        bf16_stream = os.environ.get("MMAMD_RESIDUAL", "fp32") == "bf16"  # experiment knob: residual stream dtype
+        x_f32 = x
+        if bf16_stream:
+            x = ops.convert(x, bf)
         for layer in self.layers:
             sa = layer.self_attn
             ops.layernorm(x, pk(layer.norm1.weight, f32), pk(layer.norm1.bias, f32), layer.norm1.eps, out=hn)
@@ -90,6 +95,8 @@ class TransformerStack(nn.Module):
             ops.layernorm(x, pk(layer.norm2.weight, f32), pk(layer.norm2.bias, f32), layer.norm2.eps, out=hn)
             ops.gemm_bf16(hn, pk(layer.linear1.weight, bf), pk(layer.linear1.bias, f32), act=ops.ACT_QUICKGELU, out=up)
             ops.gemm_bf16(up, pk(layer.linear2.weight, bf), pk(layer.linear2.bias, f32), residual=x, out=x)
+        if bf16_stream:
+            x = ops.convert(x, f32)
         return x
 
 

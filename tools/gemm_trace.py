@@ -43,3 +43,4 @@ for grp in (0, 1):
     print("  stage total:", round(sec.sum(1).mean()), "cycles; x", len(sec), "stages")
     print("  tail (drain stages, epilogue):", np.round(body[k:]).tolist(), round(mean[n - 1]))
     print("  whole block:", round(d.sum(1).mean()), "cycles")
+

@@ -3,4 +3,4 @@
 set +e
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "gemm" --maxfail=10 -p no:cacheprovider 2>&1 | tail -15
-timeout 300 python tools/kernel_bench.py --variants ${VARIANTS:-0,7} 2>&1 | tee gpurun_out/kernel_bench.log
+timeout 300 python tools/kernel_bench.py --variants ${VARIANTS:-7,18} 2>&1 | tee gpurun_out/kernel_bench.log

@@ -32,9 +32,10 @@ def timeit(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--variants", default="1,2,3,4,5,6")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--rounds", type=int, default=5)
     args = ap.parse_args()
     from multimodal_amd import build, ops
 
@@ -55,11 +56,14 @@ def main():
     for name, M, N, K, act, res in gemms:
         a, w, bias = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, dtype=torch.float32)
         out = torch.zeros((M, N), dtype=torch.float32 if res else torch.bfloat16, device=dev)
-        row = []
-        for v in variants:
-            ops.set_gemm_variant(v)
-            ms = timeit(lambda: ops.gemm_bf16(a, w, bias, act=act, residual=out if res else None, out=out), args.iters)
-            row.append(2.0 * M * N * K / ms / 1e9)
+        # interleaved rounds, median per variant (single runs move +-10 % with clocks / neighbours on this pool)
+        samples = {v: [] for v in variants}
+        for _ in range(args.rounds):
+            for v in variants:
+                ops.set_gemm_variant(v)
+                ms = timeit(lambda: ops.gemm_bf16(a, w, bias, act=act, residual=out if res else None, out=out), args.iters)
+                samples[v].append(2.0 * M * N * K / ms / 1e9)
+        row = [sorted(samples[v])[len(samples[v]) // 2] for v in variants]
         ops.set_gemm_variant(0)
         print(f"{name:12s} {M:6d} {N:5d} {K:5d} " + " ".join(f"{x:10.1f}" for x in row), flush=True)
 
