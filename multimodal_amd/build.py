@@ -24,6 +24,8 @@ INCLUDE = PKG.parent / "include"
 
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-return-type"]
+if os.environ.get("MMAMD_EXPERIMENTS") == "1":  # also build the schedule experiments / ablations / traces of gemm.hip
+    CXXFLAGS.append("-DMMAMD_EXPERIMENTS")
 
 
 def _hipcc() -> str:

@@ -315,11 +315,21 @@ __device__ __forceinline__ void dma_piece(const void* gsrc, uint32_t lds_dst) {
 
 // Same piece with the address split as SCALAR base (SGPR pair) + per-lane 32-bit byte offset: no VALU per piece.
 __device__ __forceinline__ void dma_piece_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_dst)
-               : "memory");
+  // M0 is written and consumed inside the statement and NOT restored: nothing else in these kernels uses M0 (no LDS-DMA
+  // builtin, no s_movrel, no GWS), so the guide's save/restore pair (2 of 5 scalar instructions per piece) is dropped.
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// 16-byte global store with an explicit cache policy.  POLICY 0: plain (line stays in the XCD's L2); 1: sc1 (written
+// through and dropped from L2 - the C tile is never re-read by this kernel, so it should not evict operand panels);
+// 2: nt.  The trailing s_nop covers the data-register hazard of an asm store (guide 5.7).
+template <int POLICY>
+__device__ __forceinline__ void store16(void* ptr, uint4 v) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+  const u32x4_t w = __builtin_bit_cast(u32x4_t, v);
+  if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(ptr), "v"(w) : "memory");
+  else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(ptr), "v"(w) : "memory");
+  else *reinterpret_cast<uint4*>(ptr) = v;
 }
 
 // BM x BN block tile, WM x WN waves, BK = 64
@@ -1072,12 +1082,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
 //   * epilogue strips live in ring buffer 1 only (32 rows x 128 B per wave and pass, fp32 tiles in two column halves)
 //   * the fp32 residual of pass i+1 is requested before pass i is consumed
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
-template <bool OUT_F32, int ACT, int GM>
-__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+// WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
+// SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
+  constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-  constexpr int A_INSTR = 4, B_INSTR = 4, NDMA = 8, NF = NI + MI, NM = NI * MI;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW, NDMA = A_INSTR + B_INSTR, NF = NI + MI, NM = NI * MI;
+  static_assert(NM >= NDMA && NM >= NF && NW % 4 == 0, "interleave needs one MFMA per DMA piece / fragment read");
+  constexpr int CH = TN / 64;  // 128-byte column chunks of a wave tile row in bf16
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -1180,7 +1194,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_pp(const GemmArgs p, 
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+      if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
     }
   };
   using B0 = std::integral_constant<int, 0>;
@@ -1315,7 +1329,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_pp(const GemmArgs p, 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += rr[it][j];
               }
-              store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
+              store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
             }
           }
 #pragma unroll
@@ -1324,38 +1338,41 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_pp(const GemmArgs p, 
         }
     } else {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int ch = 0; ch < CH; ++ch) {  // 64 columns (128 B of bf16) per pass
 #pragma unroll
-          for (int g = 0; g < 4; g += 2) {
-            bf16x4 pa, pb;
+          for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { pa[j] = (bf16)acc[ni][mi][4 * g + j]; pb[j] = (bf16)acc[ni][mi][4 * (g + 1) + j]; }
-            uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
-            auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
-            *reinterpret_cast<uint4*>(strip + l31 * ROWB + (ni * 32 + 8 * (g + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int g = 0; g < 4; g += 2) {
+              const int ni = 2 * ch + nn;
+              bf16x4 pa, pb;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
-          const int row = it * 8 + (lane >> 3), c = lane & 7;
-          uint4 v = *reinterpret_cast<const uint4*>(strip + row * ROWB + c * 16);
-          const int m = m0 + wm * TM + mi * 32 + row, n = nw0 + c * 8;
-          if (m < p.M && n + 7 < p.N) {
-            if (p.R != nullptr) {
-              const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
-              bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
-              v = __builtin_bit_cast(uint4, a8);
+              for (int j = 0; j < 4; ++j) { pa[j] = (bf16)acc[ni][mi][4 * g + j]; pb[j] = (bf16)acc[ni][mi][4 * (g + 1) + j]; }
+              uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+              auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+              auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+              *reinterpret_cast<uint4*>(strip + l31 * ROWB + (nn * 32 + 8 * (g + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = v;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
+            const int row = it * 8 + (lane >> 3), c = lane & 7;
+            uint4 v = *reinterpret_cast<const uint4*>(strip + row * ROWB + c * 16);
+            const int m = m0 + wm * TM + mi * 32 + row, n = nw0 + ch * 64 + c * 8;
+            if (m < p.M && n + 7 < p.N) {
+              if (p.R != nullptr) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+                bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
+                v = __builtin_bit_cast(uint4, a8);
+              }
+              store16<STP>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v);
+            }
           }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
     }
     if (!more) break;
     vb = nvb;
@@ -1450,11 +1467,11 @@ static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_s");
 }
 
-template <bool OUT_F32, int ACT, int GM>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM>;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1465,7 +1482,7 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   p.tiles_n = (p.N + 255) / 256;
   const int ntiles = tiles_m * p.tiles_n;
   const int grid = ntiles < 256 ? ntiles : 256;  // one persistent workgroup per CU (multiple of 8 when it matters)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, p, tiles_m, ntiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, st, p, tiles_m, ntiles);
   return launch_status("gemm_bf16_pp");
 }
 
@@ -1499,44 +1516,59 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
           const size_t esz = OUT_F32 ? 4 : 2;
           b.C = reinterpret_cast<char*>(p.C) + rows * p.ldc * esz;
           if (p.R != nullptr) b.R = reinterpret_cast<const char*>(p.R) + rows * p.ldr * esz;
-          const int rc = launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
-          if (rc != 0) return rc;
-          return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
+          if constexpr (ACT != MMAMD_ACT_GELU_ERF) {
+            const int rc = launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
+            if (rc != 0) return rc;
+            return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
+          }
         }
       }
     }
   }
-  switch (v) {
-    case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);
-    case 2: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, false>(p, st);
-    case 3: return launch_tiled<256, 128, 4, 2, OUT_F32, ACT, false>(p, st);
-    case 4: return launch_tiled<128, 256, 2, 4, OUT_F32, ACT, false>(p, st);
-    case 5: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
-    case 6: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(p, st);
-    case 7: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(p, st);
-    case 9: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, false>(p, st);  // direct-store epilogue
-    case 10: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 1>(p, st);
-    case 11: return launch_tiled_q<OUT_F32, ACT, 8>(p, st);
-    case 12: return launch_tiled_q<OUT_F32, ACT, 8, 1>(p, st);
-    case 13: return launch_tiled_s<OUT_F32, ACT, 8>(p, st);
-    case 18: return launch_tiled_pp<OUT_F32, ACT, 8>(p, st);
-    case 14: return launch_tiled_s<OUT_F32, ACT, 8, true>(p, st);  // + section timestamps
-    case 15: return launch_tiled_s<OUT_F32, ACT, 8, true, 1>(p, st);  // trace, no DMA in the loop (wrong results)
-    case 16: return launch_tiled_s<OUT_F32, ACT, 8, true, 8>(p, st);  // trace, no fragment reads (wrong results)
-    // ablations of the pipelined kernel (WRONG results, timing only): variant = 100 + mask
-    case 101: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 1>(p, st);
-    case 102: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 2>(p, st);
-    case 104: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 4>(p, st);
-    case 105: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 5>(p, st);
-    case 108: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 8>(p, st);
-    case 112: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 12>(p, st);
-    case 113: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 13>(p, st);
-    case 116: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 16>(p, st);
-    case 132: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 32>(p, st);  // start-stagger experiment (correct)
-    case 164: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 64>(p, st);  // section timestamps (correct)
-    case 114: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 14>(p, st);  // DMA + barriers only
-    case 106: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 6>(p, st);   // DMA + reads, no MFMA, no epilogue
-    default: set_error("gemm: unknown variant %d", v); return MMAMD_E_BADARG;
+  // erf-GELU (FLAVA) costs ~2x the registers in the epilogue: it is only instantiated for the 128x128 kernel
+  if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
+    return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(p, st);
+  } else {
+    switch (v) {
+      case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);
+      case 2: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, false>(p, st);
+      case 5: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
+      case 6: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(p, st);
+      case 7: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(p, st);
+      // bf16 C tiles are stored non-temporal (measured +6-7 % on the qkv / MLP-up GEMMs: the 128 KiB a block writes per
+      // tile no longer competes with the operand panels for the XCD's L2); the in-place fp32 residual update stays plain
+      case 18: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(p, st);
+#ifdef MMAMD_EXPERIMENTS
+      case 20: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 1>(p, st);  // C stores sc1 (write-through, not kept in L2)
+      case 21: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 2>(p, st);  // C stores nt
+      case 22: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 0>(p, st);  // C stores plain
+#endif
+#ifdef MMAMD_EXPERIMENTS  // schedule experiments, ablations (WRONG results for 1xx except 132/164) and traces: see DESIGN.md 4.1
+      case 3: return launch_tiled<256, 128, 4, 2, OUT_F32, ACT, false>(p, st);
+      case 4: return launch_tiled<128, 256, 2, 4, OUT_F32, ACT, false>(p, st);
+      case 9: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, false>(p, st);  // direct-store epilogue
+      case 10: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 1>(p, st);
+      case 11: return launch_tiled_q<OUT_F32, ACT, 8>(p, st);
+      case 12: return launch_tiled_q<OUT_F32, ACT, 8, 1>(p, st);
+      case 13: return launch_tiled_s<OUT_F32, ACT, 8>(p, st);
+      case 14: return launch_tiled_s<OUT_F32, ACT, 8, true>(p, st);
+      case 15: return launch_tiled_s<OUT_F32, ACT, 8, true, 1>(p, st);
+      case 16: return launch_tiled_s<OUT_F32, ACT, 8, true, 8>(p, st);
+      case 101: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 1>(p, st);
+      case 102: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 2>(p, st);
+      case 104: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 4>(p, st);
+      case 105: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 5>(p, st);
+      case 106: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 6>(p, st);
+      case 108: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 8>(p, st);
+      case 112: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 12>(p, st);
+      case 113: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 13>(p, st);
+      case 114: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 14>(p, st);
+      case 116: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 16>(p, st);
+      case 132: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 32>(p, st);
+      case 164: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 64>(p, st);
+#endif
+      default: set_error("gemm: unknown variant %d (experimental variants need -DMMAMD_EXPERIMENTS)", v); return MMAMD_E_BADARG;
+    }
   }
 }
 

@@ -59,7 +59,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 18])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6, 7, 18])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_f32_out_exactness(variant, M, N, K):
     """fp32 output: bf16 inputs are exact in fp32, so the only error is fp32 accumulation order."""
@@ -81,7 +81,7 @@ def test_gemm_f32_out_exactness(variant, M, N, K):
     np.testing.assert_allclose(host(c), ref, atol=2e-3 * math.sqrt(K / 64), rtol=1e-5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 5, 7, 11, 12, 13, 18, 99])
+@pytest.mark.parametrize("variant", [0, 2, 5, 7, 18, 99])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_bf16_out_epilogues(variant, act):
     from multimodal_amd import ops
