@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
 // WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
 // SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
   constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -1189,12 +1189,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     mma(xa0, wb0);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
+      if constexpr (RDP == 0) {         // one read of the next k-step behind each of the first NF MFMAs
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
+        for (int i = 0; i < NF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+      } else if constexpr (RDP == 1) {  // all NF reads in one burst behind the first MFMA (maximum cover)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
+      } else {                          // two reads behind each of the first NF/2 MFMAs
+#pragma unroll
+        for (int i = 0; i < NF / 2; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NF / 2, 0);
       }
-      if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
     }
   };
   using B0 = std::integral_constant<int, 0>;
@@ -1467,11 +1480,11 @@ static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_s");
 }
 
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP>;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1542,6 +1555,8 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       case 20: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 1>(p, st);  // C stores sc1 (write-through, not kept in L2)
       case 21: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 2>(p, st);  // C stores nt
       case 22: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 0>(p, st);  // C stores plain
+      case 23: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 1>(p, st);  // fragment reads in one burst
+      case 24: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 2>(p, st);  // fragment reads 2 per MFMA
 #endif
 #ifdef MMAMD_EXPERIMENTS  // schedule experiments, ablations (WRONG results for 1xx except 132/164) and traces: see DESIGN.md 4.1
       case 3: return launch_tiled<256, 128, 4, 2, OUT_F32, ACT, false>(p, st);

@@ -133,6 +133,24 @@ def test_headline_config_properties_b256():
     np.testing.assert_allclose(b[:4], ob, atol=EMB_TOL)
 
 
+def test_clip_vit_l14_vs_oracle():
+    """cfg-3 model (ViT-L/14: width 1024, 16 heads, S=257, patch 14 -> K padded 588->640, E=768) at B=2 vs the oracle."""
+    import multimodal_amd.models.clip as mc
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    set_rng_seed(0)
+    model = mc.clip_vit_l14()
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    images, ids = clip_batch(2)
+    with torch.no_grad():
+        out = model(images.cuda(), ids.cuda())
+    a, b = oc.clip_forward(sd, images.numpy(), ids.numpy(), 16, 12)
+    assert out.embeddings_a.shape == (2, 768)
+    np.testing.assert_allclose(host(out.embeddings_a), a, atol=EMB_TOL)
+    np.testing.assert_allclose(host(out.embeddings_b), b, atol=EMB_TOL)
+
+
 def test_bf16_parameters_and_generic_towers():
     """model.to(bfloat16) keeps working (outputs follow the parameter dtype) and CLIP stays tower-agnostic
     (reference tests/models/clip/test_clip.py:26-56 uses arbitrary towers)."""
