@@ -262,3 +262,148 @@ def clip_flops_per_pair(
     vision = tower_flops(S, vw, 4 * vw, vl) + 2 * (S - 1) * 3 * patch * patch * vw + 2 * vw * E
     text = tower_flops(ctx, tw, tff, tl) + 2 * tw * E
     return float(vision + text)
+
+
+# ==============================================================================================
+# FLAVA dual encoder (+ multimodal encoder) and its global contrastive loss
+#   restated from models/flava/{model,image_encoder,text_encoder,transformer}.py,
+#   modules/layers/{attention,mlp,text_embedding}.py, modules/encoders/bert_text_encoder.py,
+#   modules/losses/flava.py  — all arithmetic of this part is explicit in the reference (no torch fused ops)
+# ==============================================================================================
+def gelu_erf(x: Array) -> Array:
+    """nn.GELU() (exact erf form; models/flava/model.py:79,435,447,459 pass nn.GELU as activation)."""
+    from scipy.special import erf
+
+    return (0.5 * x * (1.0 + erf(x / math.sqrt(2.0)))).astype(x.dtype)
+
+
+def flava_attention(x: Array, sd, prefix: str, heads: int, key_mask: Optional[Array]):
+    """MultiHeadAttention + SelfAttention (modules/layers/attention.py:120-241). key_mask [B,S]: 1 = attend."""
+    B, S, d = x.shape
+    dh = d // heads
+    g = lambda k: sd[prefix + k]
+
+    def proj(name):
+        return (x @ g(name + ".weight").T + g(name + ".bias")).reshape(B, S, heads, dh).transpose(0, 2, 1, 3)
+
+    q, k, v = proj("query"), proj("key"), proj("value")
+    attn = (q @ k.transpose(0, 1, 3, 2)) / np.sqrt(x.dtype.type(dh))  # :220-221
+    if key_mask is not None:  # :227-228 masked_fill(attention_mask == 0, -inf); mask broadcast [B,1,1,S]
+        attn = np.where(np.asarray(key_mask)[:, None, None, :] == 0, -np.inf, attn).astype(x.dtype)
+    probs = softmax_lastdim(attn)  # :230
+    a = (probs @ v).transpose(0, 2, 1, 3).reshape(B, S, d)  # :239 + merge_multihead
+    return a @ g("output.weight").T + g("output.bias"), probs
+
+
+def flava_encoder_layer(x: Array, sd, prefix: str, heads: int, eps: float, key_mask: Optional[Array], activation=None):
+    """TransformerEncoderLayer._forward_prenorm (models/flava/transformer.py:155-176); activation defaults to the erf GELU
+    every FLAVA factory passes (the class default is nn.ReLU, used by the reference's layer KAT)."""
+    act = gelu_erf if activation is None else activation
+    g = lambda k: sd[prefix + k]
+    h = layer_norm(x, g("attention_layernorm.weight"), g("attention_layernorm.bias"), eps)
+    a, probs = flava_attention(h, sd, prefix + "attention.", heads, key_mask)
+    x1 = a + x
+    h2 = layer_norm(x1, g("feedforward_layernorm.weight"), g("feedforward_layernorm.bias"), eps)
+    ff = act(h2 @ g("feedforward.model.0.weight").T + g("feedforward.model.0.bias"))
+    ff = ff @ g("feedforward.model.2.weight").T + g("feedforward.model.2.bias")
+    return x1 + ff, probs
+
+
+def flava_transformer_encoder(x: Array, sd, prefix: str, heads: int, eps: float, key_mask: Optional[Array] = None):
+    """TransformerEncoder.forward (models/flava/transformer.py:255-293) with both return flags on."""
+    hidden, attns = [], []
+    n = 0
+    while f"{prefix}layer.{n}.attention.query.weight" in sd:
+        hidden.append(x)
+        x, p = flava_encoder_layer(x, sd, f"{prefix}layer.{n}.", heads, eps, key_mask)
+        attns.append(p)
+        n += 1
+    hidden.append(x)
+    return x, hidden, attns
+
+
+def flava_pooler(hidden: Array, sd, prefix: str) -> Array:
+    """Pooler: tanh(Linear(hidden[:, 0])) (modules/losses/flava.py:84-97)."""
+    return np.tanh(hidden[:, 0] @ sd[prefix + "dense.weight"].T + sd[prefix + "dense.bias"])
+
+
+def flava_image_encoder(sd, prefix: str, pixel_values: Array, heads: int, image_patches_mask: Optional[Array] = None,
+                        eps: float = 1e-12, dtype=np.float32):
+    """ImageTransformer.forward (models/flava/image_encoder.py:204-234) incl. ImageEmbeddings (:139-177)."""
+    sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
+    x = np.asarray(pixel_values).astype(dtype)
+    w = sd[prefix + "embeddings.patch_embeddings.projection.weight"]
+    emb = patch_embed(x, w) + sd[prefix + "embeddings.patch_embeddings.projection.bias"]
+    B = emb.shape[0]
+    if image_patches_mask is not None:  # :151-156
+        m = np.asarray(image_patches_mask).astype(dtype)[..., None]
+        emb = emb * (1 - m) + sd[prefix + "embeddings.mask_token"].reshape(1, 1, -1) * m
+    cls = np.broadcast_to(sd[prefix + "embeddings.cls_token"].reshape(1, 1, -1), (B, 1, emb.shape[2]))
+    emb = np.concatenate([cls, emb], axis=1) + sd[prefix + "embeddings.position_embeddings"].reshape(1, -1, emb.shape[2])
+    last, hidden, attns = flava_transformer_encoder(emb, sd, prefix + "encoder.", heads, eps)
+    seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps)
+    return {"last_hidden_state": seq, "pooler_output": flava_pooler(seq, sd, prefix + "pooler."), "hidden_states": hidden,
+            "attentions": attns}
+
+
+def flava_text_encoder(sd, prefix: str, input_ids: Array, heads: int, pad_token_id: int = 0, eps: float = 1e-12,
+                       attention_mask: Optional[Array] = None, dtype=np.float32):
+    """BERTTextEncoder.forward (modules/encoders/bert_text_encoder.py:67-120) + BERTTextEmbeddings (text_embedding.py:74-104)."""
+    sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
+    ids = np.asarray(input_ids)
+    B, S = ids.shape
+    if attention_mask is None:  # :86-89
+        attention_mask = (ids != pad_token_id).astype(np.int64)
+    e = (sd[prefix + "embeddings.word_embeddings.weight"][ids] + sd[prefix + "embeddings.position_embeddings.weight"][np.arange(S)][None]
+         + sd[prefix + "embeddings.token_type_embeddings.weight"][0][None, None])
+    e = layer_norm(e, sd[prefix + "embeddings.layer_norm.weight"], sd[prefix + "embeddings.layer_norm.bias"], eps)
+    last, hidden, attns = flava_transformer_encoder(e, sd, prefix + "encoder.", heads, eps, key_mask=attention_mask)
+    seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps)
+    return {"last_hidden_state": seq, "pooler_output": flava_pooler(seq, sd, prefix + "pooler."), "hidden_states": hidden,
+            "attentions": attns}
+
+
+def flava_mm_encoder(sd, prefix: str, hidden_states: Array, heads: int, eps: float = 1e-12, dtype=np.float32):
+    """FLAVATransformerWithoutEmbeddings.forward (models/flava/transformer.py:47-77)."""
+    sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
+    x = np.asarray(hidden_states).astype(dtype)
+    cls = np.broadcast_to(sd[prefix + "cls_token"].reshape(1, 1, -1), (x.shape[0], 1, x.shape[2]))
+    x = np.concatenate([cls, x], axis=1)
+    last, hidden, attns = flava_transformer_encoder(x, sd, prefix + "encoder.", heads, eps)
+    seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps)
+    return {"last_hidden_state": seq, "pooler_output": flava_pooler(seq, sd, prefix + "pooler."), "hidden_states": hidden,
+            "attentions": attns}
+
+
+def flava_model_forward(sd, image: Array, text: Array, heads: int, mm_heads: int, image_patches_mask=None, text_masked=None,
+                        dtype=np.float32):
+    """FLAVAModel.forward with required_embedding='mm', skip_unmasked_mm_encoder=True (models/flava/model.py:127-231)."""
+    sdc = _cast(sd, dtype)
+    lin = lambda name, x: x @ sdc[name + ".weight"].T + sdc[name + ".bias"]
+    img = flava_image_encoder(sd, "image_encoder.", image, heads, dtype=dtype)
+    txt = flava_text_encoder(sd, "text_encoder.", text, heads, dtype=dtype)
+    out = {"image": img, "text": txt,
+           "projected_image_embeddings": lin("image_projection", img["last_hidden_state"][:, 0]),
+           "projected_text_embeddings": lin("text_projection", txt["last_hidden_state"][:, 0])}
+    img_m = flava_image_encoder(sd, "image_encoder.", image, heads, image_patches_mask, dtype=dtype)
+    out["image_masked"] = img_m
+    if text_masked is not None:
+        txt_m = flava_text_encoder(sd, "text_encoder.", text_masked, heads, dtype=dtype)
+        out["text_masked"] = txt_m
+        fused = np.concatenate([lin("image_to_mm_projection", img_m["hidden_states"][-1]),
+                                lin("text_to_mm_projection", txt_m["hidden_states"][-1])], axis=1)  # :294-297
+        out["multimodal_masked"] = flava_mm_encoder(sd, "mm_encoder.", fused, mm_heads, dtype=dtype)
+    return out
+
+
+def flava_global_contrastive_loss(image_sequence: Array, text_sequence: Array, logit_scale: float, mask: Optional[Array] = None,
+                                  image_all: Optional[Array] = None, text_all: Optional[Array] = None, rank: int = 0,
+                                  dtype=np.float32):
+    """FLAVAGlobalContrastiveLoss.forward (modules/losses/flava.py:261-293): normalise (dim=-1), clamp logit_scale to
+    [0, 4.6052], contrastive_loss_with_temperature(image, text, mask)."""
+    img = l2_normalize(np.asarray(image_sequence).astype(dtype))
+    txt = l2_normalize(np.asarray(text_sequence).astype(dtype))
+    scale = clamp_logit_scale(float(logit_scale), 0.0, 4.6052)
+    o = contrastive_loss_with_temperature(img, txt, scale, image_all, text_all, rank, mask, dtype=dtype)
+    return {"loss": o["loss"], "image_logits": o["logits_a"], "text_logits": o["logits_b"], "image_loss": o["loss_a"],
+            "text_loss": o["loss_b"], "image_embedding": img, "text_embedding": txt, "logit_scale": scale}

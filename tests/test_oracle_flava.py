@@ -1,0 +1,37 @@
+"""Pin the FLAVA part of the numpy oracle to the reference (fixtures from tests/golden/make_golden_flava.py). CPU-only."""
+import numpy as np
+
+from oracle import clip_oracle as oc
+from tests._util import fixture_sd
+
+
+def test_flava_layer_kat(golden):
+    """reference tests/models/flava/test_transformer.py:36-52 (pre-norm layer, hard-coded expectation)."""
+    z = golden("flava_layer_kat.npz")
+    x = z["x"].reshape(1, 8, 2)  # MultiHeadAttention flattens the latent dims (1,2,2,2,2) -> sequence of 8
+    y, _ = oc.flava_encoder_layer(x, fixture_sd(z), "", heads=1, eps=1e-12, key_mask=None, activation=lambda v: np.maximum(v, 0))
+    y = y.reshape(1, 2, 2, 2, 2)
+    assert abs(float(y[0, 0, 0, 0, 0]) - (-1.5605)) < 1e-4 and abs(float(y[0, 1, 1, 1, 1]) - (-1.1081)) < 1e-4
+    np.testing.assert_allclose(y, z["y"], atol=2e-5)
+
+
+def test_flava_small_model_all_outputs(golden):
+    z = golden("flava_small.npz")
+    sd = fixture_sd(z)
+    out = oc.flava_model_forward(sd, z["image"], z["text"], heads=2, mm_heads=2, image_patches_mask=z["patches_mask"],
+                                 text_masked=z["text_masked"])
+    np.testing.assert_allclose(out["projected_image_embeddings"], z["proj_image"], atol=2e-5)
+    np.testing.assert_allclose(out["projected_text_embeddings"], z["proj_text"], atol=2e-5)
+    for name in ("image", "text", "image_masked", "text_masked", "multimodal_masked"):
+        o = out[name]
+        np.testing.assert_allclose(o["last_hidden_state"], z[name + ".last_hidden_state"], atol=5e-5, err_msg=name)
+        np.testing.assert_allclose(o["pooler_output"], z[name + ".pooler_output"], atol=2e-5, err_msg=name)
+        np.testing.assert_allclose(np.stack(o["hidden_states"]), z[name + ".hidden_states"], atol=5e-5, err_msg=name)
+        np.testing.assert_allclose(np.stack(o["attentions"]), z[name + ".attentions"], atol=2e-6, err_msg=name)
+    # padded keys get exactly zero probability (row 0 is padded from position 10)
+    assert np.all(np.stack(out["text"]["attentions"])[:, 0, :, :, 10:] == 0)
+    lo = oc.flava_global_contrastive_loss(out["projected_image_embeddings"], out["projected_text_embeddings"], np.log(1 / 0.07),
+                                          mask=z["loss_mask"])
+    np.testing.assert_allclose(lo["loss"], z["itc_loss"], atol=2e-5)
+    np.testing.assert_allclose(lo["image_logits"], z["itc_image_logits"], atol=1e-4)
+    np.testing.assert_allclose(lo["text_embedding"], z["itc_text_embedding"], atol=2e-6)
