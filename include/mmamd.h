@@ -82,6 +82,13 @@ int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float*
 int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                         mmamd_stream_t stream);
 
+/* Same, additionally returning the attention probabilities (normalised, [B,H,S,S], probs_dtype F32 or BF16) and honouring a
+ * key-padding mask (uint8 [B,S], 0 = masked key, NULL = none).  Non-causal.  Replaces scaled_dot_product_attention of
+ * modules/layers/attention.py:185-241 as FLAVA's encoders call it (models/flava/transformer.py:155-176 with
+ * return_attn_weights; padding mask from modules/encoders/bert_text_encoder.py:86-91).  probs may be NULL (mask only). */
+int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int probs_dtype, int B,
+                              int S, int H, float scale, mmamd_stream_t stream);
+
 /* --- K1 front end: non-overlapping patch extraction ("im2col" of a stride==kernel conv) -------
  * images [B,C,HW,HW] (f32 or bf16) -> patches bf16 [B*(HW/P)^2, Kpad], column k = (c*P+py)*P+px,
  * columns >= C*P*P zero-filled.  Replaces the gather half of nn.Conv2d at image_encoder.py:50-56,91. */
@@ -101,6 +108,27 @@ int mmamd_vit_assemble_ln(const void* patch_emb, int pe_dtype, const float* cls,
  * Replaces text_encoder.py:118-119. */
 int mmamd_embed_tokens(const int64_t* ids, const void* table, int table_dtype, const float* pos,
                        float* x, int B, int S, int d, int vocab, mmamd_stream_t stream);
+
+/* out[i] = 1 where key i may be attended, 0 where it is padding.  kind 0: src = int64 token ids, keep = (id != pad_id);
+ * kind 1/2/3: src = float32 / int64 / uint8-bool mask, keep = (value != 0).  Replaces the mask construction of
+ * modules/encoders/bert_text_encoder.py:84-91 (+ utils/attention.py:13-52). */
+int mmamd_key_mask(const void* src, int kind, int64_t pad_id, uint8_t* out, int64_t n, mmamd_stream_t stream);
+
+/* BERT embeddings: x[b,s,:] = LayerNorm(word[ids] + position[pos_ids or s] + token_type[type_ids or 0]) (fp32 out).
+ * Replaces modules/layers/text_embedding.py:74-104 (three gathers, add, nn.LayerNorm). */
+int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                        const float* pos, const float* type, const float* gamma, const float* beta, float eps, float* x,
+                        int B, int S, int d, int vocab, int max_pos, int n_types, mmamd_stream_t stream);
+
+/* FLAVA image embeddings: x[b,0] = cls + pos[0]; x[b,1+i] = blend(patch_emb[b,i], mask_token, patches_mask[b,i]) + pos[1+i]
+ * (fp32, no LayerNorm; patches_mask int64 [B,G2] / mask_token may be NULL).  Replaces models/flava/image_encoder.py:139-177. */
+int mmamd_flava_image_embed(const float* patch_emb, const float* cls, const float* pos, const int64_t* patches_mask,
+                            const float* mask_token, float* x, int B, int G2, int d, mmamd_stream_t stream);
+
+/* out[B,E] = act(rows . W^T + bias), rows i at h + i*ldh (fp32, exact-f32 MFMA); act 0 none, 1 tanh.  Replaces Pooler
+ * (modules/losses/flava.py:84-97) and the CLS projections (models/flava/model.py:243-247,260-264). */
+int mmamd_rows_linear_f32(const float* h, int64_t ldh, const float* W, const float* bias, int act, float* out, int B, int d,
+                          int E, mmamd_stream_t stream);
 
 /* --- K7/K9/K10: pooled row -> LayerNorm -> projection (-> L2 normalize) -----------------------
  * row(b) = x[b, idx(b), :] with idx(b) = 0 when ids == NULL (CLS, image_encoder.py:111) or

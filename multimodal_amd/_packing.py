@@ -8,7 +8,7 @@ optimizer.step, .to(...)).  Parameters that already have the wanted dtype are us
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Sequence, Tuple
 
 import torch
 
@@ -18,6 +18,7 @@ from . import ops
 class PackedCache:
     def __init__(self) -> None:
         self._store: Dict[Tuple[int, torch.dtype], Tuple[int, int, torch.device, torch.Tensor]] = {}
+        self._cat: Dict[tuple, tuple] = {}
 
     def get(self, p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         t = p.detach()
@@ -35,5 +36,29 @@ class PackedCache:
         self._store[key] = (t.data_ptr(), p._version, t.device, conv)
         return conv
 
+    def get_cat(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+        """One contiguous kernel-ready buffer holding `params` stacked along dim 0 (e.g. FLAVA's separate query / key /
+        value Linear weights as ONE [3d, d] in-projection, so q, k and v come out of a single GEMM)."""
+        ts = [p.detach() for p in params]
+        for t in ts:
+            if not t.is_cuda:
+                raise ops.MmamdError(
+                    f"parameter lives on {t.device}: move the module to a HIP device (.to('cuda')); there is no CPU path")
+        key = (tuple(id(p) for p in params), dtype)
+        sig = tuple((t.data_ptr(), p._version) for t, p in zip(ts, params))
+        hit = self._cat.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        rows = sum(t.shape[0] for t in ts)
+        buf = torch.empty((rows, *ts[0].shape[1:]), dtype=dtype, device=ts[0].device)
+        r0 = 0
+        for t in ts:
+            src = t if t.is_contiguous() else t.contiguous()
+            ops.convert(src, dtype, out=buf[r0:r0 + t.shape[0]])
+            r0 += t.shape[0]
+        self._cat[key] = (sig, buf)
+        return buf
+
     def clear(self) -> None:
+        self._cat.clear()
         self._store.clear()

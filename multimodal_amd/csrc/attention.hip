@@ -221,6 +221,171 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention variant that ALSO returns the probabilities and honours a key-padding mask — what FLAVA's encoders need
+// (modules/layers/attention.py:185-241 returns `attn`, models/flava/image_encoder.py:217-222 always asks for it;
+// BERTTextEncoder masks padded keys, modules/encoders/bert_text_encoder.py:86-91).  Two passes over the key tiles per
+// 32-query tile: pass 1 = row max / row sum (QK^T only), pass 2 = recompute QK^T, emit NORMALISED probabilities
+// (fp32 or bf16, [B,H,S,S]) and accumulate P.V.  Same swapped-operand register layout as the kernel above.
+// key_mask: uint8 [B,S], 0 = masked key (NULL = no mask).  HBM-bound by the S^2 probability write.
+template <int NKT, typename TP>
+__global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
+                                                              bf16* __restrict__ out, TP* __restrict__ probs, int S, int H,
+                                                              float scale_log2e) {
+  constexpr int SP = NKT * 32;
+  constexpr int VS = SP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vt = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);
+  float* Mk = reinterpret_cast<float*>(smem + SP * kKStride * 2 + 64 * VS * 2);  // additive key mask: 0 or -inf, [SP]
+
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * kDh;
+  const size_t row_stride = (size_t)3 * D;
+  const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int r = tid >> 3; r < SP; r += 32) {
+    const int c = tid & 7;
+    bf16x8 kv, vv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+    if (r < S) {
+      kv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + D + c * 8);
+      vv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + 2 * D + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VS + r] = vv[j];
+  }
+  for (int k = tid; k < SP; k += 256)
+    Mk[k] = (k < S && (key_mask == nullptr || key_mask[(size_t)b * S + k] != 0)) ? 0.f : -INFINITY;
+  __syncthreads();
+
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nqt = (S + 31) >> 5;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 32 + l31;
+    const int qc = q < S ? q : S - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * row_stride + 16 * t + 8 * half);
+
+    auto scores = [&](int kt, f32x16& st) {  // masked, scaled scores (log2 domain) of this lane's 16 keys of tile kt
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * t);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], st, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = st[r] * scale_log2e + Mk[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    };
+
+    // ---- pass 1: running max and sum
+    float m = -INFINITY, lsum = 0.f;
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 st;
+      scores(kt, st);
+      float tmax = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m, tmax);
+      // a fully masked prefix keeps m = -inf: exp2(-inf - (-inf)) would be NaN, so guard the rescale factor
+      const float alpha = (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ps += (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[r] - m_new);
+      lsum = lsum * alpha + ps;
+      m = m_new;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;  // all keys masked -> 0 * inf = NaN, as the reference's softmax of an all -inf row
+
+    // ---- pass 2: normalised probabilities out, P.V accumulated
+    f32x16 ot[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+    TP* prow = probs + (((size_t)b * H + h) * S + (size_t)qc) * S;
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 st;
+      scores(kt, st);
+      uint32_t pk[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(st[4 * g + j] - m) * inv;
+        if (probs != nullptr && q < S) {
+          const int key = kt * 32 + 8 * g + 4 * half;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (key + j < S) prow[key + j] = (TP)e[j];
+        }
+        bf16x2 p0, p1;
+        p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+        pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
+        pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int key0 = kt * 32 + 16 * jj + 4 * half;
+        u32x4 pw;
+        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16* vrow = Vt + (nt * 32 + l31) * VS + key0;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+          u32x4 vw;
+          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+          ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, ot[nt], 0, 0, 0);
+        }
+      }
+    }
+    if (q < S) {
+      bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = ot[nt][4 * g + j];
+          store4(orow + nt * 32 + 8 * g + 4 * half, o);
+        }
+    }
+  }
+}
+
+template <int NKT, typename TP>
+static int launch_attn_probs(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int B, int S, int H, float scale,
+                             hipStream_t st) {
+  constexpr int SP = NKT * 32;
+  constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2 + SP * 4;
+  auto kern = attention_probs_kernel<NKT, TP>;
+  static bool attr_done = false;
+  if (!attr_done && smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("attention_probs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), smem, st, (const bf16*)qkv, key_mask, (bf16*)out, (TP*)probs, S, H,
+                     scale * 1.4426950408889634f);
+  return launch_status("attention_probs_fwd");
+}
+
 static int g_attn_variant = 0;
 
 template <int NKT, bool CAUSAL, int ABL = 0>
@@ -276,4 +441,23 @@ extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int
   }
 #undef ATTN_CASE
   MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention: unsupported S=%d", S);
+}
+
+extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int probs_dtype,
+                                         int B, int S, int H, float scale, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(qkv && out && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention_probs: bad argument");
+  MMAMD_CHECK_ARG(S <= 288, MMAMD_E_UNSUPPORTED, "attention_probs: S=%d > 288 not supported", S);
+  MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out), MMAMD_E_ALIGN, "attention_probs: pointers must be 16-byte aligned");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nkt = (S + 31) / 32;
+#define ATTNP_CASE(N)                                                                                              \
+  case N:                                                                                                          \
+    return probs_dtype == MMAMD_F32 ? launch_attn_probs<N, float>(qkv, key_mask, out, probs, B, S, H, scale, st)   \
+                                    : launch_attn_probs<N, bf16>(qkv, key_mask, out, probs, B, S, H, scale, st);
+  switch (nkt) {
+    ATTNP_CASE(1) ATTNP_CASE(2) ATTNP_CASE(3) ATTNP_CASE(4) ATTNP_CASE(5) ATTNP_CASE(6) ATTNP_CASE(7) ATTNP_CASE(8) ATTNP_CASE(9)
+  }
+#undef ATTNP_CASE
+  MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention_probs: unsupported S=%d", S);
 }

@@ -68,9 +68,23 @@ __device__ __forceinline__ float quick_gelu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
 }
 
+// nn.GELU() = 0.5 v (1 + erf(v / sqrt 2)).  libm's erff is ~60 instructions with branches (it doubled the epilogue's register
+// use); this is the Abramowitz-Stegun 7.1.26 rational form on the hardware rcp / exp2: |erf error| <= 1.5e-7, i.e. the result
+// differs from the exact GELU by < 1e-7 |v| -- far below the bf16 rounding of the value that is stored.  Branch-free.
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float x = fabsf(v) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float h = 0.5f * v * (poly * t) * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);  // 0.5 v (1 - erf|x|)
+  return v >= 0.f ? v - h : h;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == MMAMD_ACT_QUICKGELU) return quick_gelu(v);
-  if (act == MMAMD_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  if (act == MMAMD_ACT_GELU_ERF) return gelu_erf(v);
   return v;
 }
 
@@ -116,7 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = acc[ni][mi][r];
-          acc[ni][mi][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+          acc[ni][mi][r] = gelu_erf(v);
         }
   }
   const bool has_res = p.R != nullptr;
@@ -203,17 +217,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
           const float v = acc[ni][mi][r];
           acc[ni][mi][r] = quick_gelu(v);
         }
-  } else if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[ni][mi][r];
-          acc[ni][mi][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-        }
   }
+  // erf-GELU is applied where the values are packed for the strip (32x32 at a time): as one pass over all 256
+  // accumulators its temporaries spilled (282 VGPRs)
   constexpr int ROWB = OUT_F32 ? (TN * 4 + 16) : (TN * 2 + 16);  // padded strip row: 272 B / 144 B (conflict-free b128)
   const int nw0 = n0 + wn * TN;
   const bool has_res = OUT_F32 && p.R != nullptr;
@@ -241,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
         for (int g = 0; g < 4; ++g) {
           f32x4 t;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = acc[ni][mi][4 * g + j];
+          for (int j = 0; j < 4; ++j) t[j] = ACT == MMAMD_ACT_GELU_ERF ? gelu_erf(acc[ni][mi][4 * g + j]) : acc[ni][mi][4 * g + j];
           *reinterpret_cast<f32x4*>(strip + l31 * ROWB + (ni * 32 + 8 * g + 4 * half) * 4) = t;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -273,7 +279,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
         for (int g = 0; g < 4; g += 2) {
           bf16x4 pa, pb;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { pa[j] = (bf16)acc[ni][mi][4 * g + j]; pb[j] = (bf16)acc[ni][mi][4 * (g + 1) + j]; }
+          for (int j = 0; j < 4; ++j) {
+            float va = acc[ni][mi][4 * g + j], vb = acc[ni][mi][4 * (g + 1) + j];
+            if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb = gelu_erf(vb); }
+            pa[j] = (bf16)va; pb[j] = (bf16)vb;
+          }
           uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
           auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
           auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
@@ -1287,16 +1297,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[ni][mi][r] = quick_gelu(acc[ni][mi][r]);
-    } else if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[ni][mi][r];
-            acc[ni][mi][r] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-          }
     }
     constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
     char* strip = smem + STAGE + wave * (32 * ROWB);
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
           for (int g = 0; g < 4; ++g) {
             f32x4 t;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = acc[ni][mi][4 * g + j];
+            for (int j = 0; j < 4; ++j) t[j] = ACT == MMAMD_ACT_GELU_ERF ? gelu_erf(acc[ni][mi][4 * g + j]) : acc[ni][mi][4 * g + j];
             *reinterpret_cast<f32x4*>(strip + l31 * ROWB + (8 * g + 4 * half) * 4) = t;
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1361,7 +1361,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
               const int ni = 2 * ch + nn;
               bf16x4 pa, pb;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) { pa[j] = (bf16)acc[ni][mi][4 * g + j]; pb[j] = (bf16)acc[ni][mi][4 * (g + 1) + j]; }
+              for (int j = 0; j < 4; ++j) {
+                float va = acc[ni][mi][4 * g + j], vb = acc[ni][mi][4 * (g + 1) + j];
+                if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb = gelu_erf(vb); }
+                pa[j] = (bf16)va; pb[j] = (bf16)vb;
+              }
               uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
               auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
               auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
@@ -1529,19 +1533,14 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
           const size_t esz = OUT_F32 ? 4 : 2;
           b.C = reinterpret_cast<char*>(p.C) + rows * p.ldc * esz;
           if (p.R != nullptr) b.R = reinterpret_cast<const char*>(p.R) + rows * p.ldr * esz;
-          if constexpr (ACT != MMAMD_ACT_GELU_ERF) {
-            const int rc = launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
-            if (rc != 0) return rc;
-            return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
-          }
+          const int rc = launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
+          if (rc != 0) return rc;
+          return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
         }
       }
     }
   }
-  // erf-GELU (FLAVA) costs ~2x the registers in the epilogue: it is only instantiated for the 128x128 kernel
-  if constexpr (ACT == MMAMD_ACT_GELU_ERF) {
-    return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(p, st);
-  } else {
+  {
     switch (v) {
       case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);
       case 2: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, false>(p, st);

@@ -291,6 +291,163 @@ __global__ __launch_bounds__(256) void l2_normalize_inplace_f32_kernel(float* __
   for (int k = lane; k < d; k += 64) xr[k] *= sc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// BERT embeddings: word[id] + position[pos] + token_type[type], then LayerNorm  -> fp32   (wave per token)
+// (modules/layers/text_embedding.py:74-104; position ids default to 0..S-1, token types to 0)
+// ---------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
+                                                            const int64_t* __restrict__ pos_ids, const float* __restrict__ word,
+                                                            const float* __restrict__ pos, const float* __restrict__ type,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, float* __restrict__ x, int rows, int S, int d, int vocab,
+                                                            int max_pos, int n_types) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long long id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  long long pi = pos_ids ? pos_ids[row] : (row % S);
+  pi = pi < 0 ? 0 : (pi >= max_pos ? max_pos - 1 : pi);
+  long long ti = type_ids ? type_ids[row] : 0;
+  ti = ti < 0 ? 0 : (ti >= n_types ? n_types - 1 : ti);
+  const int d4 = d >> 2;
+  f32x4 v[MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d4) {
+      const f32x4 a = load4(word + (size_t)id * d + 4 * c), b = load4(pos + (size_t)pi * d + 4 * c),
+                  t = load4(type + (size_t)ti * d + 4 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = (a[j] + b[j]) + t[j];
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float u = v[i][j] - mean; q += u * u; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+      const f32x4 g = load4(gamma + 4 * c), bb = load4(beta + 4 * c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+      store4(x + (size_t)row * d + 4 * c, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FLAVA image embeddings: patch embeddings (optionally blended with the mask token), CLS, + position  -> fp32, no LN
+// (models/flava/image_encoder.py:139-177)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flava_image_embed_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                                                const float* __restrict__ pos, const int64_t* __restrict__ pmask,
+                                                                const float* __restrict__ mask_token, float* __restrict__ x,
+                                                                int B, int G2, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int S = G2 + 1;
+  if (row >= B * S) return;
+  const int b = row / S, s = row - b * S;
+  float w = 0.f;
+  if (s > 0 && pmask != nullptr && mask_token != nullptr) w = (float)pmask[(size_t)b * G2 + (s - 1)];
+  for (int c = lane; c < (d >> 2); c += 64) {
+    f32x4 t;
+    if (s == 0) {
+      t = load4(cls + 4 * c);
+    } else {
+      t = load4(pe + ((size_t)b * G2 + (s - 1)) * d + 4 * c);
+      if (w != 0.f) {
+        const f32x4 mt = load4(mask_token + 4 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = t[j] * (1.f - w) + mt[j] * w;
+      }
+    }
+    const f32x4 pp = load4(pos + (size_t)s * d + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] += pp[j];
+    store4(x + (size_t)row * d + 4 * c, t);
+  }
+}
+
+// out[B,E] = act(rows . W^T + bias): rows i at h + i*ldh (e.g. the CLS row of every sample), W [E,d] fp32 (Linear weight),
+// fp32 MFMA; act 0 = none, 1 = tanh  (Pooler: modules/losses/flava.py:84-97; image/text projections: models/flava/model.py:243-264)
+__global__ __launch_bounds__(256) void rows_linear_f32_kernel(const float* __restrict__ h, size_t ldh, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, int act, float* __restrict__ out,
+                                                              int B, int d, int E) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 32;
+  const int j0 = (blockIdx.x * 4 + wv) * 32;
+  if (j0 >= E) return;
+  const int half = lane >> 5;
+  int ri = i0 + (lane & 31); ri = ri < B ? ri : B - 1;
+  int rj = j0 + (lane & 31); rj = rj < E ? rj : E - 1;
+  const float* lp = h + (size_t)ri * ldh;
+  const float* rp = W + (size_t)rj * d;
+  const bool vec = ((d & 3) == 0) && ((ldh & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(h) & 15) == 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < d; k0 += 8) {
+    const int k = k0 + 4 * half;
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
+    if (vec && k + 3 < d) {
+      xv = load4(lp + k);
+      yv = load4(rp + k);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k + u < d) { xv[u] = lp[k + u]; yv[u] = rp[k + u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u], yv[u], acc, 0, 0, 0);
+  }
+  const int j = j0 + (lane & 31);
+  if (j < E) {
+    const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (i < B) {
+        float v = acc[r] + bj;
+        if (act == 1) v = tanhf(v);
+        out[(size_t)i * E + j] = v;
+      }
+    }
+  }
+}
+
+
+// key-padding mask as the attention kernel wants it (uint8, 0 = masked key) from ids (!= pad) or from a 0/1 mask of any of
+// the dtypes callers hold (modules/encoders/bert_text_encoder.py:86-91; utils/attention.py:13-52 keeps "0 = ignore")
+__global__ __launch_bounds__(256) void key_mask_kernel(const void* __restrict__ src, int kind, long long pad, uint8_t* __restrict__ out,
+                                                       long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  bool keep;
+  if (kind == 0) keep = reinterpret_cast<const int64_t*>(src)[i] != pad;
+  else if (kind == 1) keep = reinterpret_cast<const float*>(src)[i] != 0.f;
+  else if (kind == 2) keep = reinterpret_cast<const int64_t*>(src)[i] != 0;
+  else keep = reinterpret_cast<const uint8_t*>(src)[i] != 0;
+  out[i] = keep ? 1 : 0;
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void l2_normalize_kernel(const TI* __restrict__ x, TO* __restrict__ y,
                                                            int rows, int d, float eps) {
@@ -442,7 +599,55 @@ extern "C" int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_
     hipLaunchKernelGGL((convert_kernel<float, bf16>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16*)dst, n);
   else if (src_dtype == MMAMD_BF16 && dst_dtype == MMAMD_F32)
     hipLaunchKernelGGL((convert_kernel<bf16, float>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, (float*)dst, n);
+  else if (src_dtype == MMAMD_F32 && dst_dtype == MMAMD_F32)  // same-type copy: packing several parameters into one buffer
+    hipLaunchKernelGGL((convert_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else if (src_dtype == MMAMD_BF16 && dst_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((convert_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, n);
   else
     MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "convert: unsupported dtype pair");
   return launch_status("convert");
+}
+
+extern "C" int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
+                                   const float* pos, const float* type, const float* gamma, const float* beta, float eps, float* x,
+                                   int B, int S, int d, int vocab, int max_pos, int n_types, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(ids && word && pos && type && gamma && beta && x && B >= 0 && S > 0 && d > 0, MMAMD_E_BADARG, "bert_embed_ln: bad argument");
+  MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "bert_embed_ln: d=%d must be a multiple of 4 and <= 2048", d);
+  MMAMD_CHECK_ARG(pos_ids != nullptr || S <= max_pos, MMAMD_E_BADARG, "bert_embed_ln: sequence longer than the position table");
+  if (B == 0) return 0;
+  const int rows = B * S;
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int d4 = d / 4;
+#define LAUNCH_BE(MV) hipLaunchKernelGGL((bert_embed_ln_kernel<MV>), grid, block, 0, st, ids, type_ids, pos_ids, word, pos, type, gamma, beta, eps, x, rows, S, d, vocab, max_pos, n_types)
+  if (d4 <= 128) LAUNCH_BE(2); else if (d4 <= 256) LAUNCH_BE(4); else LAUNCH_BE(8);
+#undef LAUNCH_BE
+  return launch_status("bert_embed_ln");
+}
+
+extern "C" int mmamd_flava_image_embed(const float* patch_emb, const float* cls, const float* pos, const int64_t* patches_mask,
+                                       const float* mask_token, float* x, int B, int G2, int d, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(patch_emb && cls && pos && x && B >= 0 && G2 > 0 && d > 0 && d % 4 == 0, MMAMD_E_BADARG, "flava_image_embed: bad argument");
+  if (B == 0) return 0;
+  const int rows = B * (G2 + 1);
+  hipLaunchKernelGGL(flava_image_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patch_emb, cls, pos,
+                     patches_mask, mask_token, x, B, G2, d);
+  return launch_status("flava_image_embed");
+}
+
+extern "C" int mmamd_rows_linear_f32(const float* h, int64_t ldh, const float* W, const float* bias, int act, float* out, int B,
+                                     int d, int E, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(h && W && out && B >= 0 && d > 0 && E > 0 && ldh >= d && (act == 0 || act == 1), MMAMD_E_BADARG, "rows_linear_f32: bad argument");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(rows_linear_f32_kernel, dim3((E + 127) / 128, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream, h, (size_t)ldh,
+                     W, bias, act, out, B, d, E);
+  return launch_status("rows_linear_f32");
+}
+
+extern "C" int mmamd_key_mask(const void* src, int kind, int64_t pad_id, uint8_t* out, int64_t n, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(src && out && n >= 0 && kind >= 0 && kind <= 3, MMAMD_E_BADARG, "key_mask: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(key_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, kind, (long long)pad_id,
+                     out, (long long)n);
+  return launch_status("key_mask");
 }

@@ -1,0 +1,327 @@
+"""Host-side mirror of the dual-encoder / multimodal part of torchmultimodal/models/flava/model.py: FLAVAOutput (:38-59),
+flava_multimodal_encoder (:73-98), FLAVAModel (:107-333) and the flava_model factory (:429-523).
+
+Constructor arguments, attribute names, state_dict keys and initialisation order match the reference, so
+`flava_model_unified_text_encoder.pt` loads with strict=True.  FLAVAForPreTraining / FLAVAForClassification (MLM, MIM, ITM,
+DALL-E codebook) are outside the contrastive path and are not provided.
+
+MI355X-specific: the image and text towers are issued on two HIP streams (as in models/clip/model.py); when
+`image_patches_mask` is None the reference encodes the same image twice with identical results (:146-160 vs :175-181) —
+here the second pass reuses the first pass's outputs.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from functools import partial
+from typing import Any, Callable, List, Optional, Tuple, Union
+
+import torch
+from torch import nn, Tensor
+from typing_extensions import Literal
+
+from ... import ops
+from ..._packing import PackedCache
+from ...modules.layers.normalizations import Fp32LayerNorm
+from ...modules.layers.transformer import TransformerOutput
+from ...modules.losses.flava import cls_linear, Pooler
+from ...utils.common import load_module_from_url
+from ..clip._transformer import forbid_training_forward
+from .image_encoder import flava_image_encoder
+from .text_encoder import flava_text_encoder
+from .transformer import FLAVATransformerWithoutEmbeddings, TransformerEncoder
+
+EMBEDDING_OPTIONS = Literal["image", "text", "mm"]
+
+FLAVAOutput = namedtuple(
+    "FLAVAOutput",
+    ["image", "image_masked", "text", "text_masked", "multimodal", "multimodal_masked", "projected_image_embeddings",
+     "projected_text_embeddings"],
+    defaults=(None, None, None, None, None, None, None, None),
+)
+FLAVAOutput.__annotations__ = {
+    "image": TransformerOutput,
+    "image_masked": TransformerOutput,
+    "text": TransformerOutput,
+    "text_masked": TransformerOutput,
+    "multimodal": TransformerOutput,
+    "multimodal_masked": TransformerOutput,
+}
+
+CKPT_KEY = "flava_full"
+FLAVA_MODEL_MAPPING = {
+    CKPT_KEY: "https://download.pytorch.org/models/multimodal/flava/flava_model_unified_text_encoder.pt",
+}
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device: torch.device) -> torch.cuda.Stream:
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def flava_multimodal_encoder(
+    hidden_size: int = 768,
+    num_attention_heads: int = 12,
+    num_hidden_layers: int = 12,
+    dropout: float = 0.0,
+    intermediate_size: int = 3072,
+    intermediate_activation: Callable[..., nn.Module] = nn.GELU,
+    layer_norm_eps: float = 1e-12,
+) -> FLAVATransformerWithoutEmbeddings:
+    encoder = TransformerEncoder(n_layer=num_hidden_layers, d_model=hidden_size, n_head=num_attention_heads,
+                                 dim_feedforward=intermediate_size, activation=intermediate_activation,
+                                 layer_norm_eps=layer_norm_eps, dropout=dropout, norm_first=True)
+    layernorm = Fp32LayerNorm(hidden_size, eps=layer_norm_eps)
+    pooler = Pooler(hidden_size=hidden_size)
+    return FLAVATransformerWithoutEmbeddings(encoder=encoder, layernorm=layernorm, pooler=pooler, hidden_size=hidden_size)
+
+
+class FLAVAModel(nn.Module):
+    def __init__(
+        self,
+        image_encoder: nn.Module,
+        text_encoder: nn.Module,
+        mm_encoder: nn.Module,
+        image_to_mm_projection: nn.Module,
+        text_to_mm_projection: nn.Module,
+        text_projection: nn.Module,
+        image_projection: nn.Module,
+        **kwargs: Any,
+    ) -> None:
+        super().__init__()
+        self.image_encoder = image_encoder
+        self.text_encoder = text_encoder
+        self.mm_encoder = mm_encoder
+        self.image_to_mm_projection = image_to_mm_projection
+        self.text_to_mm_projection = text_to_mm_projection
+        self.text_projection = text_projection
+        self.image_projection = image_projection
+        self._packed = PackedCache()
+
+    def forward(
+        self,
+        image: Optional[Tensor] = None,
+        text: Optional[Tensor] = None,
+        image_patches_mask: Optional[Tensor] = None,
+        text_masked: Optional[Tensor] = None,
+        required_embedding: Optional[EMBEDDING_OPTIONS] = None,
+        skip_unmasked_mm_encoder: bool = True,
+    ) -> FLAVAOutput:
+        forbid_training_forward(self)
+        if required_embedding is None:
+            if image is not None and text is not None:
+                required_embedding = "mm"
+            elif image is not None:
+                required_embedding = "image"
+            else:
+                required_embedding = "text"
+
+        want_image = image is not None and required_embedding in ("image", "mm")
+        want_text = text is not None and required_embedding in ("text", "mm")
+        want_text_masked = text_masked is not None and required_embedding in ("text", "mm")
+
+        image_outputs: TransformerOutput = TransformerOutput()
+        image_masked_outputs: TransformerOutput = TransformerOutput()
+        text_outputs: TransformerOutput = TransformerOutput()
+        text_masked_outputs: TransformerOutput = TransformerOutput()
+        projected_image_embeddings = projected_text_embeddings = None
+
+        # text tower(s) on the side stream, image tower(s) on the caller's stream
+        side = None
+        dev = (image if image is not None else text).device
+        if want_image and (want_text or want_text_masked) and dev.type == "cuda":
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(main)
+        ctx = torch.cuda.stream(side) if side is not None else _Null()
+        with ctx:
+            if want_text:
+                text_outputs, projected_text_embeddings = self.encode_text(text, projection=True)
+            if want_text_masked:
+                text_masked_outputs = self.encode_text(text_masked)
+        if want_image:
+            image_outputs, projected_image_embeddings = self.encode_image(image, projection=True)
+            if image_patches_mask is None:
+                image_masked_outputs = image_outputs  # identical inputs, deterministic kernels: same values
+            else:
+                image_masked_outputs = self.encode_image(image, image_patches_mask=image_patches_mask)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            for o in (text_outputs, text_masked_outputs):
+                _record(o, torch.cuda.current_stream(dev))
+            if projected_text_embeddings is not None:
+                projected_text_embeddings.record_stream(torch.cuda.current_stream(dev))
+
+        multimodal_outputs = TransformerOutput()
+        multimodal_masked_outputs = TransformerOutput()
+        if required_embedding == "mm":
+            # hidden_states[-1], not last_hidden_state: FLAVA feeds the state WITHOUT the final layernorm (:187-188)
+            if not skip_unmasked_mm_encoder:
+                multimodal_outputs = self.encode_mm(
+                    image_outputs.hidden_states[-1] if image_outputs.hidden_states else None,
+                    text_outputs.hidden_states[-1] if text_outputs.hidden_states else None,
+                )
+            multimodal_masked_outputs = self.encode_mm(
+                image_masked_outputs.hidden_states[-1] if image_masked_outputs.hidden_states else None,
+                text_masked_outputs.hidden_states[-1] if text_masked_outputs.hidden_states else None,
+            )
+
+        return FLAVAOutput(
+            image=image_outputs,
+            image_masked=image_masked_outputs,
+            text=text_outputs,
+            text_masked=text_masked_outputs,
+            multimodal=multimodal_outputs,
+            multimodal_masked=multimodal_masked_outputs,
+            projected_image_embeddings=projected_image_embeddings,
+            projected_text_embeddings=projected_text_embeddings,
+        )
+
+    def encode_image(self, image: Tensor, image_patches_mask: Optional[Tensor] = None, projection: bool = False
+                     ) -> Union[Tuple[TransformerOutput, Tensor], Optional[TransformerOutput]]:
+        if image_patches_mask is not None:
+            encoded_image = self.image_encoder(image, image_patches_mask)
+        else:
+            encoded_image = self.image_encoder(image)
+        if projection:
+            projected_embeddings = cls_linear(encoded_image.last_hidden_state, self.image_projection, self._packed)
+            return encoded_image, projected_embeddings
+        return encoded_image
+
+    def encode_text(self, text: Tensor, text_mask: Optional[Tensor] = None, projection: bool = False
+                    ) -> Union[Tuple[TransformerOutput, Tensor], Optional[TransformerOutput]]:
+        encoded_text = self.text_encoder(input_ids=text, attention_mask=text_mask, return_attn_weights=True,
+                                         return_hidden_states=True)
+        if projection:
+            projected_embeddings = cls_linear(encoded_text.last_hidden_state, self.text_projection, self._packed)
+            return encoded_text, projected_embeddings
+        return encoded_text
+
+    def _token_linear(self, x: Tensor, lin: nn.Linear, out: Tensor) -> None:
+        """out[B, S, dm] (a strided slice of the fused sequence) = lin(x[B, S, d]) — bf16 MFMA GEMM per sample block."""
+        B, S, d = x.shape
+        h = ops.convert((x if x.is_contiguous() else x.contiguous()).view(B * S, d), torch.bfloat16)
+        y = ops.gemm_bf16(h, self._packed.get(lin.weight, torch.bfloat16),
+                          self._packed.get(lin.bias, torch.float32) if lin.bias is not None else None,
+                          out_dtype=torch.float32)
+        out.copy_(y.view(B, S, -1))  # placement into the fused [image | text] sequence: a strided device copy
+
+    def encode_mm(self, image_embedding: Tensor, text_embedding: Tensor) -> TransformerOutput:
+        if image_embedding is None or text_embedding is None:
+            # nothing passed: e.g. no masked data
+            return TransformerOutput()
+        B, Si, _ = image_embedding.shape
+        St = text_embedding.shape[1]
+        dm = self.image_to_mm_projection.out_features
+        fused_state = torch.empty((B, Si + St, dm), dtype=torch.float32, device=image_embedding.device)
+        self._token_linear(image_embedding, self.image_to_mm_projection, fused_state[:, :Si])
+        self._token_linear(text_embedding, self.text_to_mm_projection, fused_state[:, Si:])
+        return self.mm_encoder(fused_state)
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _record(o: TransformerOutput, stream) -> None:
+    for t in (o.last_hidden_state, o.pooler_output, *(o.hidden_states or ()), *(o.attentions or ())):
+        if t is not None:
+            t.record_stream(stream)
+
+
+def flava_model(
+    # Image encoder specific parameters
+    image_hidden_size: int = 768,
+    image_num_attention_heads: int = 12,
+    image_num_hidden_layers: int = 12,
+    image_dropout: float = 0.0,
+    image_intermediate_size: int = 3072,
+    image_intermediate_activation: Callable[..., nn.Module] = nn.GELU,
+    image_layer_norm_eps: float = 1e-12,
+    use_image_masking: bool = True,
+    image_size: int = 224,
+    patch_size: int = 16,
+    num_channels: int = 3,
+    # Text encoder specific parameters
+    text_hidden_size: int = 768,
+    text_num_attention_heads: int = 12,
+    text_num_hidden_layers: int = 12,
+    text_dropout: float = 0.0,
+    text_intermediate_size: int = 3072,
+    text_intermediate_activation: Callable[..., nn.Module] = nn.GELU,
+    text_layer_norm_eps: float = 1e-12,
+    vocab_size: int = 30522,
+    pad_token_id: int = 0,
+    type_vocab_size: int = 2,
+    max_position_embeddings: int = 512,
+    # Multimodal encoder specific parameters
+    multimodal_hidden_size: int = 768,
+    multimodal_num_attention_heads: int = 12,
+    multimodal_num_hidden_layers: int = 6,
+    multimodal_dropout: float = 0.0,
+    multimodal_intermediate_size: int = 3072,
+    multimodal_intermediate_activation: Callable[..., nn.Module] = nn.GELU,
+    multimodal_layer_norm_eps: float = 1e-12,
+    # projection
+    text_and_image_proj_size: int = 768,
+    pretrained: bool = False,
+    **kwargs: Any,
+) -> FLAVAModel:
+    image_encoder = flava_image_encoder(
+        hidden_size=image_hidden_size,
+        num_attention_heads=image_num_attention_heads,
+        num_hidden_layers=image_num_hidden_layers,
+        use_image_masking=use_image_masking,
+        dropout=image_dropout,
+        intermediate_size=image_intermediate_size,
+        intermediate_activation=image_intermediate_activation,
+        layer_norm_eps=image_layer_norm_eps,
+        image_size=image_size,
+        patch_size=patch_size,
+        num_channels=num_channels,
+    )
+    text_encoder = flava_text_encoder(
+        hidden_size=text_hidden_size,
+        num_attention_heads=text_num_attention_heads,
+        num_hidden_layers=text_num_hidden_layers,
+        dropout=text_dropout,
+        intermediate_size=text_intermediate_size,
+        intermediate_activation=text_intermediate_activation,
+        layer_norm_eps=text_layer_norm_eps,
+        vocab_size=vocab_size,
+        pad_token_id=pad_token_id,
+        type_vocab_size=type_vocab_size,
+        max_position_embeddings=max_position_embeddings,
+    )
+    mm_encoder = flava_multimodal_encoder(
+        hidden_size=multimodal_hidden_size,
+        num_attention_heads=multimodal_num_attention_heads,
+        num_hidden_layers=multimodal_num_hidden_layers,
+        dropout=multimodal_dropout,
+        intermediate_size=multimodal_intermediate_size,
+        intermediate_activation=multimodal_intermediate_activation,
+        layer_norm_eps=multimodal_layer_norm_eps,
+    )
+    image_to_mm_projection = nn.Linear(image_hidden_size, multimodal_hidden_size)
+    text_to_mm_projection = nn.Linear(text_hidden_size, multimodal_hidden_size)
+    image_projection = nn.Linear(image_hidden_size, text_and_image_proj_size)
+    text_projection = nn.Linear(text_hidden_size, text_and_image_proj_size)
+    flava = FLAVAModel(
+        image_encoder=image_encoder,
+        text_encoder=text_encoder,
+        mm_encoder=mm_encoder,
+        image_to_mm_projection=image_to_mm_projection,
+        text_to_mm_projection=text_to_mm_projection,
+        text_projection=text_projection,
+        image_projection=image_projection,
+    )
+    if pretrained:
+        load_module_from_url(flava, FLAVA_MODEL_MAPPING[CKPT_KEY])
+    return flava

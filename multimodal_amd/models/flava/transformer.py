@@ -1,0 +1,193 @@
+"""Host-side mirror of torchmultimodal/models/flava/transformer.py (TransformerEncoderLayer :77-221, TransformerEncoder
+:224-293, FLAVATransformerWithoutEmbeddings :18-74, init_transformer_weights :296-310).
+
+Same constructors, attribute names and construction order (state_dict keys `layer.N.attention.{query,key,value,output}`,
+`layer.N.feedforward.model.{0,2}`, `layer.N.{attention,feedforward}_layernorm`; a seeded construction gives the
+reference's initial weights).  One encoder layer on the MI355X is
+
+    LN(fp32 -> bf16) -> in-proj GEMM [3d,d] -> attention (+mask, +probabilities) -> output GEMM (+bias, +residual, fp32)
+    LN(fp32 -> bf16) -> up GEMM (+bias, GELU epilogue, bf16) -> down GEMM (+bias, +residual, fp32)
+
+with the residual stream in fp32.  Every layer writes its output into a NEW buffer (residual read from the previous one),
+so `hidden_states` — which FLAVA always asks for — are the live buffers, not copies.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Any, Callable, List, Optional, Tuple, Union
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+from ...modules.layers.attention import key_mask_from_attention_mask, MultiHeadAttention, SelfAttention
+from ...modules.layers.mlp import MLP
+from ...modules.layers.normalizations import Fp32LayerNorm
+from ...modules.layers.transformer import TransformerOutput
+from ..clip._transformer import forbid_training_forward
+
+
+class FLAVATransformerWithoutEmbeddings(nn.Module):
+    def __init__(
+        self,
+        encoder: nn.Module,
+        layernorm: nn.Module,
+        pooler: nn.Module,
+        hidden_size: int = 768,
+        weight_init_fn: Optional[Callable] = None,
+        initializer_range: float = 0.02,
+        use_cls_token: bool = True,
+        **kwargs: Any,
+    ):
+        super().__init__()
+        self.encoder = encoder
+        self.layernorm = layernorm
+        self.pooler = pooler
+        if use_cls_token:
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, hidden_size))
+        else:
+            self.cls_token = None
+        if weight_init_fn is None:
+            weight_init_fn = partial(init_transformer_weights, initializer_range=initializer_range)
+        self.apply(weight_init_fn)
+
+    def forward(self, hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None) -> TransformerOutput:
+        if hidden_states is None:
+            raise ValueError("You have to specify hidden_states")
+        if self.cls_token is not None:
+            # [cls | tokens]: a strided device copy into one buffer (layout plumbing, no arithmetic)
+            B, S, d = hidden_states.shape
+            fused = torch.empty((B, S + 1, d), dtype=hidden_states.dtype, device=hidden_states.device)
+            fused[:, 0:1].copy_(self.cls_token.detach().to(hidden_states.dtype).expand(B, -1, -1))
+            fused[:, 1:].copy_(hidden_states)
+            hidden_states = fused
+        encoder_output = self.encoder(hidden_states, attention_mask=attention_mask, return_hidden_states=True,
+                                      return_attn_weights=True)
+        sequence_output = self.layernorm(encoder_output.last_hidden_state)
+        pooled_output = self.pooler(sequence_output) if self.pooler is not None else None
+        return TransformerOutput(last_hidden_state=sequence_output, pooler_output=pooled_output,
+                                 hidden_states=encoder_output.hidden_states, attentions=encoder_output.attentions)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(
+        self,
+        d_model: int,
+        n_head: int,
+        dim_feedforward: int,
+        dropout: float = 0.0,
+        activation: Callable[..., nn.Module] = nn.ReLU,
+        layer_norm_eps: float = 1e-12,
+        norm_first: bool = False,
+    ) -> None:
+        super().__init__()
+        self.attention = MultiHeadAttention(dim_q=d_model, dim_kv=d_model, n_head=n_head, attn_module=SelfAttention(dropout))
+        self.attention_dropout = nn.Dropout(dropout)
+        self.feedforward = MLP(d_model, d_model, dim_feedforward, dropout=dropout, activation=activation)
+        self.feedforward_dropout = nn.Dropout(dropout)
+        self.attention_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
+        self.feedforward_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm_first = norm_first
+        self._packed = PackedCache()
+
+    def _ln(self, ln: nn.LayerNorm, x: Tensor, out_dtype: torch.dtype) -> Tensor:
+        pk = self._packed.get
+        return ops.layernorm(x, pk(ln.weight, torch.float32), pk(ln.bias, torch.float32), ln.eps, out_dtype=out_dtype)
+
+    def run(self, x: Tensor, B: int, S: int, key_mask: Optional[Tensor], want_probs: bool) -> Tuple[Tensor, Optional[Tensor]]:
+        """x: fp32 [B*S, d] (left untouched).  Returns (new fp32 [B*S, d], probabilities [B,H,S,S] or None)."""
+        if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
+            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
+        bf, f32 = torch.bfloat16, torch.float32
+        if self.norm_first:  # reference :155-176
+            hn = self._ln(self.attention_layernorm, x, bf)
+            x1, probs = self.attention.run(hn, B, S, key_mask, want_probs, residual=x)
+            hn = self._ln(self.feedforward_layernorm, x1, bf)
+            y = self.feedforward.run(hn, residual=x1, out=x1)  # x1 is private to this layer: updated in place
+            return y, probs
+        # post-norm, reference :178-198
+        a, probs = self.attention.run(ops.convert(x, bf), B, S, key_mask, want_probs, residual=x)
+        x1 = self._ln(self.attention_layernorm, a, f32)
+        ff = self.feedforward.run(ops.convert(x1, bf), residual=x1, out=a)
+        return self._ln(self.feedforward_layernorm, ff, f32), probs
+
+    def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None,
+                return_attn_weights: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        if head_mask is not None:
+            raise ops.MmamdError("head_mask is not implemented on the MI355X path")
+        forbid_training_forward(self)
+        shape = hidden_states.shape
+        d = shape[-1]
+        B = shape[0]
+        S = hidden_states.numel() // (B * d)  # n-dimensional inputs [b, d1..dn, c] attend over the flattened positions
+        xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+        if xc.dtype != torch.float32:
+            raise ops.MmamdError("encoder layers on the MI355X path take fp32 hidden states")
+        km = key_mask_from_attention_mask(attention_mask, B, S)
+        y, probs = self.run(xc.view(B * S, d), B, S, km, return_attn_weights)
+        y = y.view(shape)
+        return (y, probs) if return_attn_weights else y
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(
+        self,
+        n_layer: int,
+        d_model: int,
+        n_head: int,
+        dim_feedforward: int,
+        dropout: float = 0.0,
+        activation: Callable[..., nn.Module] = nn.ReLU,
+        layer_norm_eps: float = 1e-12,
+        norm_first: bool = False,
+        final_layer_norm_eps: Optional[float] = None,
+    ):
+        super().__init__()
+        self.layer = nn.ModuleList([
+            TransformerEncoderLayer(d_model, n_head, dim_feedforward, dropout, activation, layer_norm_eps, norm_first)
+            for _ in range(n_layer)
+        ])
+        self.final_layer_norm = None
+        if final_layer_norm_eps:
+            self.final_layer_norm = Fp32LayerNorm(d_model, eps=final_layer_norm_eps)
+
+    def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None,
+                return_attn_weights: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
+        if head_mask is not None:
+            raise ops.MmamdError("head_mask is not implemented on the MI355X path")
+        forbid_training_forward(self)
+        if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
+            raise ops.MmamdError("TransformerEncoder on the MI355X path takes fp32 [b, seq, c] hidden states")
+        B, S, d = hidden_states.shape
+        x = (hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()).view(B * S, d)
+        km = key_mask_from_attention_mask(attention_mask, B, S)
+        all_hidden_states: Optional[List[Tensor]] = [] if return_hidden_states else None
+        all_self_attentions: Optional[List[Tensor]] = [] if return_attn_weights else None
+        for layer_module in self.layer:
+            if return_hidden_states:
+                all_hidden_states.append(x.view(B, S, d))
+            x, probs = layer_module.run(x, B, S, km, return_attn_weights)
+            if return_attn_weights:
+                all_self_attentions.append(probs)
+        x = x.view(B, S, d)
+        if return_hidden_states:
+            all_hidden_states.append(x)
+        if self.final_layer_norm is not None:
+            x = self.final_layer_norm(x)
+        return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, attentions=all_self_attentions)
+
+
+def init_transformer_weights(module: nn.Module, initializer_range: float) -> None:
+    """Initialize the weights (reference :296-310)."""
+    if isinstance(module, (nn.Linear, nn.Conv2d)):
+        module.weight.data.normal_(mean=0.0, std=initializer_range)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    elif isinstance(module, nn.Embedding):
+        module.weight.data.normal_(mean=0.0, std=initializer_range)
+        if module.padding_idx is not None:
+            module.weight.data[module.padding_idx].zero_()
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)

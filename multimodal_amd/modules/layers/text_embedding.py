@@ -1,0 +1,61 @@
+"""Host-side mirror of torchmultimodal/modules/layers/text_embedding.py:13-104 (BERTTextEmbeddings).  Three gathers, the
+sum and the LayerNorm are ONE kernel (csrc/rowops.hip: bert_embed_ln_kernel, wave per token)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+
+
+class BERTTextEmbeddings(nn.Module):
+    def __init__(
+        self,
+        hidden_size: int = 768,
+        vocab_size: int = 30522,
+        pad_token_id: int = 0,
+        max_position_embeddings: int = 512,
+        type_vocab_size: int = 2,
+        layer_norm_eps: float = 1e-12,
+        dropout: float = 0.0,
+        offset_pos_ids: bool = False,
+    ) -> None:
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab_size, hidden_size, pad_token_id)
+        self.position_embeddings = nn.Embedding(max_position_embeddings, hidden_size)
+        self.token_type_embeddings = nn.Embedding(type_vocab_size, hidden_size)
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=layer_norm_eps)
+        self.dropout = nn.Dropout(dropout)
+        self.pad_token_id = pad_token_id
+        self.offset_pos_ids = offset_pos_ids
+        self._packed = PackedCache()
+
+    def forward(
+        self,
+        input_ids: Optional[Tensor] = None,
+        token_type_ids: Optional[Tensor] = None,
+        position_ids: Optional[Tensor] = None,
+        inputs_embeds: Optional[Tensor] = None,
+    ) -> Tensor:
+        if input_ids is None:
+            if inputs_embeds is None:
+                raise ValueError("input_ids or inputs_embeds must not be None")
+            raise ops.MmamdError("inputs_embeds is not implemented on the MI355X path (pass input_ids)")
+        if inputs_embeds is not None:
+            raise ops.MmamdError("inputs_embeds is not implemented on the MI355X path (pass input_ids)")
+        if self.offset_pos_ids and position_ids is None:
+            raise ops.MmamdError("offset_pos_ids (RoBERTa position ids) is not implemented on the MI355X path; pass position_ids")
+        if self.training and self.dropout.p > 0:
+            raise ops.MmamdError("embedding dropout > 0 in training mode is not implemented on the MI355X path")
+        B, S = input_ids.shape
+        if position_ids is not None and position_ids.shape != input_ids.shape:
+            position_ids = position_ids.expand(B, S).contiguous()
+        pk, f32 = self._packed.get, torch.float32
+        x = ops.bert_embed_ln(input_ids if input_ids.is_contiguous() else input_ids.contiguous(),
+                              pk(self.word_embeddings.weight, f32), pk(self.position_embeddings.weight, f32),
+                              pk(self.token_type_embeddings.weight, f32), pk(self.layer_norm.weight, f32),
+                              pk(self.layer_norm.bias, f32), self.layer_norm.eps, token_type_ids, position_ids)
+        return x.view(B, S, -1)

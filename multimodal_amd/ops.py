@@ -17,7 +17,8 @@ from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, BF16, F32, MmamdError, 
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "StreamTimer",
+    "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "rows_linear_f32",
 ]
 
 
@@ -102,6 +103,102 @@ def attention_fwd(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool,
         out = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=qkv.device)
     check(_lib.lib().mmamd_attention_fwd(qkv.data_ptr(), out.data_ptr(), B, S, H, int(bool(causal)),
                                          1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_fwd")
+    return out
+
+
+def attention_probs_fwd(qkv: torch.Tensor, B: int, S: int, H: int, key_mask: Optional[torch.Tensor] = None,
+                        want_probs: bool = True, probs_dtype: torch.dtype = torch.float32,
+                        out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Bidirectional attention that also returns the normalised probabilities [B,H,S,S] and honours a key-padding mask
+    (uint8 [B,S], 0 = masked).  qkv bf16 [B*S, 3*H*64] -> (bf16 [B*S, H*64], probs or None)."""
+    _chk(qkv, "qkv", torch.bfloat16)
+    if qkv.shape != (B * S, 3 * H * 64):
+        raise MmamdError(f"attention: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * H * 64)}")
+    if key_mask is not None:
+        _chk(key_mask, "key_mask", torch.uint8)
+        if key_mask.shape != (B, S):
+            raise MmamdError(f"attention: key_mask shape {tuple(key_mask.shape)} != {(B, S)}")
+    if out is None:
+        out = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=qkv.device)
+    probs = torch.empty((B, H, S, S), dtype=probs_dtype, device=qkv.device) if want_probs else None
+    check(_lib.lib().mmamd_attention_probs_fwd(qkv.data_ptr(), _ptr(key_mask), out.data_ptr(), _ptr(probs),
+                                               _dt(probs) if probs is not None else F32, B, S, H,
+                                               1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_probs_fwd")
+    return out, probs
+
+
+def key_mask(src: torch.Tensor, pad_id: Optional[int] = None) -> torch.Tensor:
+    """uint8 keep-mask (same shape as src): ids != pad_id when pad_id is given, else src != 0."""
+    _chk(src, "mask source")
+    if pad_id is not None:
+        if src.dtype != torch.int64:
+            raise MmamdError("key_mask: token ids must be int64")
+        kind = 0
+    else:
+        kind = {torch.float32: 1, torch.int64: 2, torch.uint8: 3, torch.bool: 3}.get(src.dtype)
+        if kind is None:
+            raise MmamdError(f"key_mask: unsupported mask dtype {src.dtype}")
+    out = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+    check(_lib.lib().mmamd_key_mask(src.data_ptr(), kind, int(pad_id or 0), out.data_ptr(), src.numel(), _stream()),
+          "mmamd_key_mask")
+    return out
+
+
+def bert_embed_ln(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, typ: torch.Tensor, gamma: torch.Tensor,
+                  beta: torch.Tensor, eps: float, token_type_ids: Optional[torch.Tensor] = None,
+                  position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(word[ids] + pos[position] + type[token_type]) -> fp32 [B*S, d]."""
+    _chk(ids, "input_ids", torch.int64)
+    for n, t in (("word_embeddings", word), ("position_embeddings", pos), ("token_type_embeddings", typ),
+                 ("gamma", gamma), ("beta", beta)):
+        _chk(t, n, torch.float32)
+    for n, t in (("token_type_ids", token_type_ids), ("position_ids", position_ids)):
+        if t is not None:
+            _chk(t, n, torch.int64)
+            if t.shape != ids.shape:
+                raise MmamdError(f"{n} shape {tuple(t.shape)} != input_ids shape {tuple(ids.shape)}")
+    B, S = ids.shape
+    d = word.shape[1]
+    x = torch.empty((B * S, d), dtype=torch.float32, device=ids.device)
+    check(_lib.lib().mmamd_bert_embed_ln(ids.data_ptr(), _ptr(token_type_ids), _ptr(position_ids), word.data_ptr(),
+                                         pos.data_ptr(), typ.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                         x.data_ptr(), B, S, d, word.shape[0], pos.shape[0], typ.shape[0], _stream()),
+          "mmamd_bert_embed_ln")
+    return x
+
+
+def flava_image_embed(patch_emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int, G2: int,
+                      patches_mask: Optional[torch.Tensor] = None,
+                      mask_token: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """patch embeddings fp32 [B*G2, d] (+ optional mask-token blend), CLS, + positions -> fp32 [B*(G2+1), d]."""
+    _chk(patch_emb, "patch_emb", torch.float32); _chk(cls, "cls_token", torch.float32); _chk(pos, "pos", torch.float32)
+    if patches_mask is not None:
+        _chk(patches_mask, "image_patches_mask", torch.int64)
+        if patches_mask.numel() != B * G2:
+            raise MmamdError(f"image_patches_mask has {patches_mask.numel()} entries, expected {B * G2}")
+    if mask_token is not None:
+        _chk(mask_token, "mask_token", torch.float32)
+    d = patch_emb.shape[-1]
+    x = torch.empty((B * (G2 + 1), d), dtype=torch.float32, device=patch_emb.device)
+    check(_lib.lib().mmamd_flava_image_embed(patch_emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), _ptr(patches_mask),
+                                             _ptr(mask_token), x.data_ptr(), B, G2, d, _stream()),
+          "mmamd_flava_image_embed")
+    return x
+
+
+def rows_linear_f32(h: torch.Tensor, row_stride: int, B: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                    tanh: bool = False) -> torch.Tensor:
+    """act(rows @ weight.T + bias) in exact fp32: row i starts at h.data_ptr() + i*row_stride floats (e.g. every
+    sample's CLS row of a [B,S,d] tensor: row_stride = S*d)."""
+    _chk(h, "h", torch.float32); _chk(weight, "weight", torch.float32)
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+    E, d = weight.shape
+    if B > 0 and (B - 1) * row_stride + d > h.numel():
+        raise MmamdError("rows_linear_f32: rows run past the end of h")
+    out = torch.empty((B, E), dtype=torch.float32, device=h.device)
+    check(_lib.lib().mmamd_rows_linear_f32(h.data_ptr(), int(row_stride), weight.data_ptr(), _ptr(bias), int(bool(tanh)),
+                                           out.data_ptr(), B, d, E, _stream()), "mmamd_rows_linear_f32")
     return out
 
 
@@ -203,11 +300,17 @@ def contrastive_fwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
     return out3, logits_a, logits_b
 
 
-def convert(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+def convert(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(src, "src")
-    if src.dtype == dtype:
+    if out is not None:
+        _chk(out, "out", dtype)
+        if out.numel() != src.numel():
+            raise MmamdError("convert: out has a different number of elements")
+        dst = out
+    elif src.dtype == dtype:
         return src
-    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    else:
+        dst = torch.empty(src.shape, dtype=dtype, device=src.device)
     check(_lib.lib().mmamd_convert(src.data_ptr(), _dt(src), dst.data_ptr(), _dt(dst), src.numel(), _stream()),
           "mmamd_convert")
     return dst

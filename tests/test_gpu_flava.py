@@ -1,0 +1,327 @@
+"""FLAVA dual encoder + multimodal encoder + global contrastive loss on an MI355X: the HIP
+kernels and the drop-in nn.Modules against (a) outputs of the reference itself (tests/golden/make_golden_flava.py) and
+(b) the numpy oracle.
+
+Tolerances: the HIP path computes GEMMs / attention from bf16 operands with fp32 accumulation and keeps the residual
+stream, LayerNorm, softmax statistics, poolers, projections and the loss in fp32; the reference is fp32 end to end.
+Attention probabilities |d| <= 2e-3, hidden states |d| <= 3e-2 (values are O(1)), pooled / projected rows |d| <= 2e-2,
+L2-normalised embeddings |d| <= 4e-3, logits |d| <= 0.06, loss |d| <= 5e-3 (same protocol as CLIP).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as oc
+from tests._util import assert_checksums, fixture_sd
+from tests.conftest import set_rng_seed
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL, HID_TOL, ROW_TOL, EMB_TOL, LOGIT_TOL, LOSS_TOL = 2e-3, 3e-2, 2e-2, 4e-3, 0.06, 5e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from multimodal_amd import build
+
+    build.build()
+
+
+def host(t):
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("B,S,H,masked,pdt", [(3, 16, 2, True, torch.float32), (2, 22, 2, False, torch.float32),
+                                               (2, 77, 12, True, torch.float32), (2, 197, 12, False, torch.float32),
+                                               (1, 197, 3, True, torch.bfloat16), (2, 275, 2, True, torch.float32),
+                                               (1, 1, 1, False, torch.float32), (1, 33, 1, True, torch.float32)])
+def test_attention_probs_kernel(B, S, H, masked, pdt):
+    from multimodal_amd import ops
+
+    set_rng_seed(B * 1000 + S)
+    D = H * 64
+    qkv = (torch.randn(B * S, 3 * D) * 1.5).to(torch.bfloat16)
+    km = None
+    if masked:
+        km = (torch.rand(B, S) > 0.3).to(torch.uint8)
+        km[:, 0] = 1  # at least one key stays (an all-masked row is NaN in the reference too; covered below)
+    out, probs = ops.attention_probs_fwd(qkv.cuda(), B, S, H, km.cuda() if km is not None else None, probs_dtype=pdt)
+    x = qkv.float().numpy().astype(np.float64).reshape(B, S, 3, H, 64)
+    q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(0, 1, 3, 2) / 8.0
+    if km is not None:
+        s = np.where(km.numpy()[:, None, None, :] == 0, -np.inf, s)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    o = (p @ v).transpose(0, 2, 1, 3).reshape(B * S, D)
+    dp = np.abs(host(probs) - p).max()
+    do = np.abs(host(out) - o).max()
+    assert dp <= (2e-6 if pdt == torch.float32 else 4e-3), dp
+    assert do <= 2e-2 * max(1.0, np.abs(o).max()), do
+    assert np.abs(host(probs).sum(-1) - 1).max() <= (1e-5 if pdt == torch.float32 else 2e-2)
+    # mask only, no probabilities: same attention output
+    out2, none = ops.attention_probs_fwd(qkv.cuda(), B, S, H, km.cuda() if km is not None else None, want_probs=False)
+    assert none is None and torch.equal(out2, out)
+    if km is None:  # and the same values as the fast (no-probabilities) kernel to bf16 rounding
+        fast = ops.attention_fwd(qkv.cuda(), B, S, H, causal=False)
+        assert np.abs(host(fast) - host(out)).max() <= 2e-2 * max(1.0, np.abs(o).max())
+
+
+def test_attention_all_keys_masked_row_is_nan_like_reference():
+    from multimodal_amd import ops
+
+    set_rng_seed(3)
+    qkv = torch.randn(2 * 16, 3 * 64).to(torch.bfloat16).cuda()
+    km = torch.ones(2, 16, dtype=torch.uint8)
+    km[1] = 0
+    out, probs = ops.attention_probs_fwd(qkv, 2, 16, 1, km.cuda())
+    assert torch.isfinite(probs[0]).all() and torch.isnan(probs[1]).all()  # softmax over an all -inf row (attention.py:227-230)
+
+
+@pytest.mark.parametrize("B,S,d", [(3, 16, 128), (2, 77, 768), (1, 512, 768)])
+def test_bert_embed_ln_kernel(B, S, d):
+    from multimodal_amd import ops
+
+    set_rng_seed(S)
+    vocab, maxpos = 300, 512
+    word, pos, typ = torch.randn(vocab, d), torch.randn(maxpos, d), torch.randn(2, d)
+    g, b = torch.rand(d) + 0.5, torch.randn(d)
+    ids = torch.randint(0, vocab, (B, S))
+    tt = torch.randint(0, 2, (B, S))
+    for use_tt, use_pos in ((False, False), (True, True)):
+        pid = torch.randint(0, maxpos, (B, S)) if use_pos else None
+        x = ops.bert_embed_ln(ids.cuda(), word.cuda(), pos.cuda(), typ.cuda(), g.cuda(), b.cuda(), 1e-12,
+                              tt.cuda() if use_tt else None, pid.cuda() if use_pos else None)
+        e = word[ids] + pos[pid if use_pos else torch.arange(S).expand(B, S)] + typ[tt if use_tt else torch.zeros_like(tt)]
+        ref = oc.layer_norm(e.numpy().astype(np.float64), g.numpy(), b.numpy(), 1e-12).reshape(B * S, d)
+        assert np.abs(host(x) - ref).max() <= 2e-5
+
+
+def test_flava_image_embed_and_key_mask_and_rows_linear():
+    from multimodal_amd import ops
+
+    set_rng_seed(11)
+    B, G2, d = 3, 196, 768
+    pe, cls, pos, mt = torch.randn(B * G2, d), torch.randn(1, 1, d), torch.randn(1, G2 + 1, d), torch.randn(1, 1, d)
+    mask = torch.randint(0, 2, (B, G2))
+    for m in (None, mask):
+        x = ops.flava_image_embed(pe.cuda(), cls.cuda(), pos.cuda(), B, G2, m.cuda() if m is not None else None,
+                                  mt.cuda() if m is not None else None)
+        e = pe.view(B, G2, d)
+        if m is not None:
+            w = m.unsqueeze(-1).float()
+            e = e * (1 - w) + mt * w
+        ref = torch.cat([cls.expand(B, -1, -1), e], 1) + pos
+        assert torch.equal(x.cpu().view(B, G2 + 1, d), ref)  # pure fp32 adds in the reference's order: bit-exact
+    ids = torch.randint(0, 4, (5, 33))
+    assert torch.equal(ops.key_mask(ids.cuda(), pad_id=0).cpu(), (ids != 0).to(torch.uint8))
+    for t in (torch.rand(5, 33).round(), torch.randint(0, 2, (5, 33)), torch.rand(5, 33) > 0.5):
+        assert torch.equal(ops.key_mask(t.cuda()).cpu(), (t != 0).to(torch.uint8))
+    for (Bn, S, dd, E, tanh) in ((5, 6, 128, 64, False), (130, 3, 768, 768, True), (1, 1, 36, 10, True)):
+        h, W, bias = torch.randn(Bn, S, dd), torch.randn(E, dd) * 0.05, torch.randn(E)
+        y = ops.rows_linear_f32(h.cuda(), S * dd, Bn, W.cuda(), bias.cuda(), tanh=tanh)
+        ref = h[:, 0].double() @ W.double().T + bias.double()
+        ref = torch.tanh(ref) if tanh else ref
+        assert np.abs(host(y) - ref.numpy()).max() <= 5e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_gelu_erf_epilogue_matches_exact_gelu():
+    from multimodal_amd import ops
+
+    set_rng_seed(5)
+    for (M, N, K) in ((300, 256, 128), (2048, 3072, 768)):
+        a, w, bias = torch.randn(M, K).to(torch.bfloat16), (torch.randn(N, K) * 0.05).to(torch.bfloat16), torch.randn(N)
+        y = ops.gemm_bf16(a.cuda(), w.cuda(), bias.cuda(), act=ops.ACT_GELU_ERF)
+        ref = oc.gelu_erf(a.double().numpy() @ w.double().numpy().T + bias.double().numpy())
+        assert np.abs(host(y) - bf16_round(ref)).max() <= 2 ** -7 * max(1.0, np.abs(ref).max())  # one bf16 ulp of the largest value
+        y32 = ops.gemm_bf16(a.cuda(), w.cuda(), bias.cuda(), act=ops.ACT_GELU_ERF, out_dtype=torch.float32)
+        assert np.abs(host(y32) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+# ----------------------------------------------------------------------------------------------------------------- models
+SMALL_KW = dict(image_hidden_size=128, image_num_attention_heads=2, image_num_hidden_layers=2, image_intermediate_size=256,
+                image_size=32, patch_size=16, text_hidden_size=128, text_num_attention_heads=2, text_num_hidden_layers=2,
+                text_intermediate_size=256, vocab_size=200, max_position_embeddings=32, multimodal_hidden_size=128,
+                multimodal_num_attention_heads=2, multimodal_num_hidden_layers=2, multimodal_intermediate_size=256,
+                text_and_image_proj_size=64)
+
+
+def _small_model(z):
+    from multimodal_amd.models.flava.model import flava_model
+
+    model = flava_model(**SMALL_KW)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fixture_sd(z).items()}, strict=True)
+    return model.cuda().eval()
+
+
+def _cmp_output(name, o, z, report):
+    for field, tol in (("last_hidden_state", HID_TOL), ("pooler_output", ROW_TOL)):
+        d = np.abs(host(getattr(o, field)) - z[f"{name}.{field}"]).max()
+        report[f"{name}.{field}"] = d
+        assert d <= tol, (name, field, d)
+    hs = np.stack([host(h) for h in o.hidden_states])
+    d = np.abs(hs - z[f"{name}.hidden_states"]).max()
+    report[f"{name}.hidden_states"] = d
+    assert hs.shape == z[f"{name}.hidden_states"].shape and d <= HID_TOL, (name, d)
+    at = np.stack([host(a) for a in o.attentions])
+    d = np.abs(at - z[f"{name}.attentions"]).max()
+    report[f"{name}.attentions"] = d
+    assert at.shape == z[f"{name}.attentions"].shape and d <= PROB_TOL, (name, d)
+
+
+def test_small_flava_model_vs_reference_fixture(golden):
+    from multimodal_amd.models.flava.model import FLAVAOutput
+    from multimodal_amd.modules.layers.transformer import TransformerOutput
+    from multimodal_amd.modules.losses.flava import FLAVAGlobalContrastiveLoss
+
+    z = golden("flava_small.npz")
+    model = _small_model(z)
+    image, text = torch.from_numpy(z["image"]).cuda(), torch.from_numpy(z["text"]).cuda()
+    with torch.no_grad():
+        out = model(image, text, image_patches_mask=torch.from_numpy(z["patches_mask"]).cuda(),
+                    text_masked=torch.from_numpy(z["text_masked"]).cuda(), skip_unmasked_mm_encoder=True)
+    assert isinstance(out, FLAVAOutput) and isinstance(out.image, TransformerOutput)
+    assert out.multimodal == TransformerOutput()  # skipped, like the reference
+    report = {}
+    for name in ("image", "text", "image_masked", "text_masked", "multimodal_masked"):
+        _cmp_output(name, getattr(out, name), z, report)
+    for k, t in (("proj_image", out.projected_image_embeddings), ("proj_text", out.projected_text_embeddings)):
+        report[k] = np.abs(host(t) - z[k]).max()
+        assert report[k] <= ROW_TOL, (k, report[k])
+    # padded text rows really are masked: their attention columns are exactly 0
+    txt = z["text"]
+    att = host(out.text.attentions[-1])
+    assert (att[0][:, :, txt[0] == 0] == 0).all() and (att[3][:, :, txt[3] == 0] == 0).all()
+
+    loss_mod = FLAVAGlobalContrastiveLoss().cuda().eval()
+    mask = torch.from_numpy(z["loss_mask"]).cuda()
+    lo = loss_mod(out.projected_image_embeddings, out.projected_text_embeddings, mask)
+    report["itc_loss"] = abs(float(lo.loss) - float(z["itc_loss"]))
+    assert report["itc_loss"] <= LOSS_TOL
+    for k, t in (("itc_image_logits", lo.image_logits), ("itc_text_logits", lo.text_logits)):
+        report[k] = np.abs(host(t) - z[k]).max()
+        assert host(t).shape == z[k].shape and report[k] <= LOGIT_TOL
+    for k, t in (("itc_image_embedding", lo.image_embedding), ("itc_text_embedding", lo.text_embedding)):
+        report[k] = np.abs(host(t) - z[k]).max()
+        assert report[k] <= EMB_TOL
+    # loss on the REFERENCE's projections isolates the loss kernels: fp32 end to end
+    lo2 = loss_mod(torch.from_numpy(z["proj_image"]).cuda(), torch.from_numpy(z["proj_text"]).cuda(), mask)
+    assert abs(float(lo2.loss) - float(z["itc_loss"])) <= 2e-5
+    assert np.abs(host(lo2.image_logits) - z["itc_image_logits"]).max() <= 2e-4
+    print("flava small-model parity |d|:", {k: float(f"{v:.2e}") for k, v in report.items()})
+
+
+def test_small_flava_unmasked_paths_and_required_embedding(golden):
+    z = golden("flava_small.npz")
+    model = _small_model(z)
+    image, text = torch.from_numpy(z["image"]).cuda(), torch.from_numpy(z["text"]).cuda()
+    with torch.no_grad():
+        full = model(image, text, text_masked=text, skip_unmasked_mm_encoder=False)
+        only_i = model(image=image)
+        only_t = model(text=text)
+        as_text = model(image, text, required_embedding="text")
+    # no patch mask: the "masked" image pass equals the plain one (the reference recomputes it; values identical)
+    assert full.image_masked.last_hidden_state is full.image.last_hidden_state
+    sd = fixture_sd(z)
+    mm = oc.flava_mm_encoder(sd, "mm_encoder.", np.concatenate([
+        host(full.image.hidden_states[-1]).astype(np.float32) @ sd["image_to_mm_projection.weight"].T + sd["image_to_mm_projection.bias"],
+        host(full.text.hidden_states[-1]).astype(np.float32) @ sd["text_to_mm_projection.weight"].T + sd["text_to_mm_projection.bias"]], 1), 2)
+    assert np.abs(host(full.multimodal.last_hidden_state) - mm["last_hidden_state"]).max() <= HID_TOL
+    assert torch.equal(full.multimodal.last_hidden_state, full.multimodal_masked.last_hidden_state)  # same inputs, deterministic
+    assert only_i.text.last_hidden_state is None and only_i.projected_text_embeddings is None
+    assert only_t.image.last_hidden_state is None and only_t.multimodal_masked.last_hidden_state is None
+    assert torch.equal(only_i.projected_image_embeddings, full.projected_image_embeddings)
+    assert torch.equal(only_t.projected_text_embeddings, full.projected_text_embeddings)
+    assert as_text.image.last_hidden_state is None and torch.equal(as_text.text.pooler_output, full.text.pooler_output)
+
+
+def test_small_flava_vs_oracle_other_batch(golden):
+    """Fresh inputs (not the fixture's): HIP model vs the numpy oracle through the same weights."""
+    z = golden("flava_small.npz")
+    model = _small_model(z)
+    sd = fixture_sd(z)
+    set_rng_seed(99)
+    B = 9
+    image = torch.randn(B, 3, 32, 32)
+    text = torch.randint(1, 200, (B, 16))
+    text[2, 3:] = 0
+    text[7, 15:] = 0
+    pm = torch.randint(0, 2, (B, 4))
+    with torch.no_grad():
+        out = model(image.cuda(), text.cuda(), image_patches_mask=pm.cuda(), text_masked=text.cuda())
+    ref = oc.flava_model_forward(sd, image.numpy(), text.numpy(), 2, 2, image_patches_mask=pm.numpy(), text_masked=text.numpy())
+    assert np.abs(host(out.projected_image_embeddings) - ref["projected_image_embeddings"]).max() <= ROW_TOL
+    assert np.abs(host(out.projected_text_embeddings) - ref["projected_text_embeddings"]).max() <= ROW_TOL
+    assert np.abs(host(out.image_masked.last_hidden_state) - ref["image_masked"]["last_hidden_state"]).max() <= HID_TOL
+    assert np.abs(host(out.multimodal_masked.pooler_output) - ref["multimodal_masked"]["pooler_output"]).max() <= ROW_TOL
+    assert np.abs(host(out.multimodal_masked.attentions[-1]) - ref["multimodal_masked"]["attentions"][-1]).max() <= PROB_TOL
+
+
+def test_full_size_flava_b2_vs_reference_fixture(golden):
+    from multimodal_amd.models.flava.model import flava_model
+
+    z = golden("flava_full_b2.npz")
+    set_rng_seed(0)
+    model = flava_model()
+    assert_checksums(model, z)  # seeded construction == the reference's weights
+    model = model.cuda().eval()
+    g = torch.Generator().manual_seed(77)
+    image = torch.randn(2, 3, 224, 224, generator=g)
+    text = torch.randint(1, 30500, (2, 77), generator=g)
+    text[1, 40:] = 0
+    assert abs(float(image.double().sum()) - float(z["image_sum"])) < 1e-6 and int(text.sum()) == int(z["text_sum"])
+    with torch.no_grad():
+        img, pi = model.encode_image(image.cuda(), projection=True)
+        txt, pt = model.encode_text(text.cuda(), projection=True)
+    rep = {
+        "proj_image": np.abs(host(pi) - z["proj_image"]).max(), "proj_text": np.abs(host(pt) - z["proj_text"]).max(),
+        "image_cls": np.abs(host(img.last_hidden_state[:, 0]) - z["image_cls"]).max(),
+        "text_cls": np.abs(host(txt.last_hidden_state[:, 0]) - z["text_cls"]).max(),
+        "image_pooler": np.abs(host(img.pooler_output) - z["image_pooler"]).max(),
+        "text_pooler": np.abs(host(txt.pooler_output) - z["text_pooler"]).max(),
+        "text_attn_row": np.abs(host(txt.attentions[-1][1, 0, 0]) - z["text_attn_row"]).max(),
+    }
+    print("flava full-size parity |d|:", {k: float(f"{v:.2e}") for k, v in rep.items()})
+    assert len(img.hidden_states) == 13 and len(img.attentions) == 12 and img.attentions[0].shape == (2, 12, 197, 197)
+    assert max(rep["proj_image"], rep["proj_text"], rep["image_pooler"], rep["text_pooler"]) <= ROW_TOL
+    assert max(rep["image_cls"], rep["text_cls"]) <= HID_TOL and rep["text_attn_row"] <= PROB_TOL
+    assert abs(float(img.attentions[-1].double().sum()) - float(z["image_attn_last_sum"])) <= 1e-2  # 2*12*197 rows summing to 1
+    assert abs(float(img.hidden_states[-1].double().mean()) - float(z["image_hidden_last_mean"])) <= 1e-3
+
+
+def test_flava_layer_and_encoder_module_api(golden):
+    """TransformerEncoderLayer / TransformerEncoder / MLP / MultiHeadAttention called directly, like the reference's unit tests."""
+    from multimodal_amd.models.flava.transformer import TransformerEncoder, TransformerEncoderLayer
+    from multimodal_amd import ops
+
+    set_rng_seed(4)
+    layer = TransformerEncoderLayer(128, 2, 256, activation=torch.nn.GELU, norm_first=True).cuda().eval()
+    post = TransformerEncoderLayer(128, 2, 256, activation=torch.nn.GELU, norm_first=False).cuda().eval()
+    x = torch.randn(2, 3, 4, 128)  # n-dimensional positions, like the reference KAT's [1,2,2,2,2]
+    for mod, name in ((layer, "pre"), (post, "post")):
+        sd = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+        with torch.no_grad():
+            y, p = mod(x.cuda(), return_attn_weights=True)
+        xf = x.numpy().reshape(2, 12, 128)
+        if name == "pre":
+            ref, rp = oc.flava_encoder_layer(xf, sd, "", 2, 1e-12, None)
+        else:
+            a, rp = oc.flava_attention(xf, sd, "attention.", 2, None)
+            x1 = oc.layer_norm(a + xf, sd["attention_layernorm.weight"], sd["attention_layernorm.bias"], 1e-12)
+            ff = oc.gelu_erf(x1 @ sd["feedforward.model.0.weight"].T + sd["feedforward.model.0.bias"]) @ sd["feedforward.model.2.weight"].T + sd["feedforward.model.2.bias"]
+            ref = oc.layer_norm(x1 + ff, sd["feedforward_layernorm.weight"], sd["feedforward_layernorm.bias"], 1e-12)
+        assert y.shape == x.shape and np.abs(host(y).reshape(2, 12, 128) - ref).max() <= HID_TOL, name
+        assert np.abs(host(p) - rp).max() <= PROB_TOL
+    enc = TransformerEncoder(2, 128, 2, 256, activation=torch.nn.GELU, norm_first=True, final_layer_norm_eps=1e-5).cuda().eval()
+    with torch.no_grad():
+        o = enc(torch.randn(3, 10, 128).cuda(), attention_mask=torch.ones(3, 1, 1, 10).cuda())
+    assert o.hidden_states is None and o.attentions is None and o.last_hidden_state.shape == (3, 10, 128)
+    with pytest.raises(ops.MmamdError):
+        enc(torch.randn(3, 10, 128).cuda(), attention_mask=torch.ones(3, 1, 10, 10).cuda())  # query-dependent mask
+    with pytest.raises(ops.MmamdError):
+        TransformerEncoderLayer(128, 2, 256).cuda().eval()(torch.randn(1, 4, 128).cuda())  # default nn.ReLU: no fused epilogue
