@@ -161,6 +161,23 @@ int mmamd_contrastive_fwd(const float* a, const float* b, const float* a_all, co
                           int reduction, float* logits_a, float* logits_b, float* out3, float* ws,
                           mmamd_stream_t stream);
 
+/* --- FLAVA pre-training heads (modules/losses/flava.py:110-238, 391-469)
+ * Compaction of the labelled positions (replaces the boolean indexing `hidden_states[masked_tokens, :]`,
+ * `masked_labels[masked_tokens]` :212-215 and the ITM row filter `sequence[pos_mask]` :433-437): for labels [B,L], in
+ * row-major order, every (b,l) with labels != ignore_index (and row_keep[b] != 0 when row_keep is given) appends
+ * idx_out = b*seq_S + tok_offset + l and label_out = labels[b,l] (label_out may be NULL); count_out[0] = number kept. */
+int mmamd_select_tokens(const int64_t* labels, const uint8_t* row_keep, int64_t ignore_index, int B, int L, int seq_S,
+                        int tok_offset, int32_t* idx_out, int64_t* label_out, int32_t* count_out, mmamd_stream_t stream);
+
+/* dst[i,:] = src[idx[i]*row_stride : +d] (fp32 source rows; dst fp32 or bf16, dense [n,d]). */
+int mmamd_gather_rows(const float* src, int64_t row_stride, const int32_t* idx, int n, int d, void* dst, int dst_dtype,
+                      mmamd_stream_t stream);
+
+/* nn.CrossEntropyLoss(ignore_index=...) with mean reduction: out_loss[0] = mean over kept rows of lse(logits[i]) -
+ * logits[i, labels[i]] (NaN when no row is kept, like torch).  ws: 2*N floats.  Replaces :137-140, :225-228. */
+int mmamd_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int N, int V, int64_t ignore_index,
+                        float* out_loss, float* ws, mmamd_stream_t stream);
+
 /* Elementwise dtype conversion helper (fp32 <-> bf16), n elements. Used for weight packing. */
 int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
                   mmamd_stream_t stream);

@@ -59,6 +59,27 @@ class PackedCache:
         self._cat[key] = (sig, buf)
         return buf
 
+    def get_padded_rows(self, p: torch.Tensor, dtype: torch.dtype, multiple: int) -> torch.Tensor:
+        """`p` ([rows, ...]) with its row count rounded up to `multiple` (zero rows appended) — e.g. a [30522, d] vocabulary
+        projection padded to the GEMM's N % 8 == 0."""
+        t = p.detach()
+        if not t.is_cuda:
+            raise ops.MmamdError(
+                f"parameter lives on {t.device}: move the module to a HIP device (.to('cuda')); there is no CPU path")
+        rows = t.shape[0]
+        padded = (rows + multiple - 1) // multiple * multiple
+        if padded == rows:
+            return self.get(p, dtype)
+        key = (("pad", id(p), multiple), dtype)
+        sig = ((t.data_ptr(), p._version),)
+        hit = self._cat.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        buf = torch.zeros((padded, *t.shape[1:]), dtype=dtype, device=t.device)  # zero fill = memset, not arithmetic
+        ops.convert(t if t.is_contiguous() else t.contiguous(), dtype, out=buf[:rows])
+        self._cat[key] = (sig, buf)
+        return buf
+
     def clear(self) -> None:
         self._cat.clear()
         self._store.clear()

@@ -120,6 +120,104 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
 
 using namespace mmamd;
 
+
+// ---------------------------------------------------------------------------------------------------------
+// FLAVA masked-prediction / ITM heads (modules/losses/flava.py:110-238)
+// ---------------------------------------------------------------------------------------------------------
+// Order-preserving compaction of the labelled positions: for labels [B, L] (and an optional per-sample keep flag) emit, for
+// every kept (b, l) in row-major order, the source row b*seq_S + tok_offset + l and its label.  This is what the reference
+// does with boolean indexing (`hidden_states[masked_tokens, :]`, `labels[masked_tokens]`, `sequence[pos_mask]`): one block,
+// ballot + popcount prefix per 1024-element chunk (B*L is at most a few 10^4).
+__global__ __launch_bounds__(1024) void select_tokens_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ row_keep,
+                                                             long long ignore, int B, int L, int seq_S, int tok_offset,
+                                                             int* __restrict__ idx_out, int64_t* __restrict__ label_out,
+                                                             int* __restrict__ count_out) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = B * L;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int start = 0; start < total; start += 1024) {
+    const int i = start + tid;
+    bool flag = false;
+    int b = 0, l = 0;
+    long long lab = 0;
+    if (i < total) {
+      b = i / L; l = i - b * L;
+      lab = labels[i];
+      flag = (row_keep == nullptr || row_keep[b] != 0) && lab != ignore;
+    }
+    const unsigned long long ballot = __ballot(flag);
+    const int lanepos = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(ballot);
+    __syncthreads();
+    int prefix = 0, chunk = 0;
+    for (int w = 0; w < 16; ++w) { const int c = wave_cnt[w]; if (w < wave) prefix += c; chunk += c; }
+    if (flag) {
+      const int pos = base + prefix + lanepos;
+      idx_out[pos] = b * seq_S + tok_offset + l;
+      if (label_out) label_out[pos] = lab;
+    }
+    __syncthreads();
+    if (tid == 0) base += chunk;
+    __syncthreads();
+  }
+  if (tid == 0) count_out[0] = base;
+}
+
+// dst[i, :] = src[idx[i], :] (fp32 rows `row_stride` floats apart) as fp32 or bf16 — wave per row
+template <typename TO>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, size_t row_stride, const int* __restrict__ idx,
+                                                          int n, int d, TO* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* s = src + (size_t)idx[row] * row_stride;
+  for (int c = lane; c < (d >> 2); c += 64) store4(dst + (size_t)row * d + 4 * c, load4(s + 4 * c));
+}
+
+// nn.CrossEntropyLoss(ignore_index) rows: ws[row] = lse - logit[label] (0 for ignored rows), ws[N + row] = 1 / 0 kept flag
+__global__ __launch_bounds__(256) void ce_generic_rows_kernel(const float* __restrict__ logits, size_t ld, const int64_t* __restrict__ labels,
+                                                              int N, int V, long long ignore, float* __restrict__ ws) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long lab = labels[row];
+  if (lab == ignore || lab < 0 || lab >= V) {  // out-of-range labels are an error in torch; they are dropped here
+    if (tid == 0) { ws[row] = 0.f; ws[N + row] = 0.f; }
+    return;
+  }
+  const float* x = logits + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int j = tid; j < V; j += 256) m = fmaxf(m, x[j]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int j = tid; j < V; j += 256) se += expf(x[j] - m);
+  se = wave_sum(se);
+  if (lane == 0) red[wave] = se;
+  __syncthreads();
+  if (tid == 0) {
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    ws[row] = (m + logf(tot)) - x[lab];
+    ws[N + row] = 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_generic_reduce_kernel(const float* __restrict__ ws, int N, float* __restrict__ out) {
+  __shared__ float rs[4], rc[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f, c = 0.f;
+  for (int i = tid; i < N; i += 256) { s += ws[i]; c += ws[N + i]; }
+  s = wave_sum(s); c = wave_sum(c);
+  if (lane == 0) { rs[wave] = s; rc[wave] = c; }
+  __syncthreads();
+  if (tid == 0) out[0] = ((rs[0] + rs[1]) + (rs[2] + rs[3])) / ((rc[0] + rc[1]) + (rc[2] + rc[3]));  // 0/0 = NaN, like torch
+}
+
 extern "C" int mmamd_contrastive_fwd(const float* a, const float* b, const float* a_all, const float* b_all,
                                      int ld_all, const float* logit_scale, int B, int WB, int E, int label_offset,
                                      const uint8_t* row_mask, float label_smoothing, int reduction, float* logits_a,
@@ -139,4 +237,42 @@ extern "C" int mmamd_contrastive_fwd(const float* a, const float* b, const float
                      row_mask, label_smoothing, ws);
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, st, ws, B, row_mask, reduction, out3);
   return launch_status("contrastive_fwd");
+}
+
+extern "C" int mmamd_select_tokens(const int64_t* labels, const uint8_t* row_keep, int64_t ignore_index, int B, int L, int seq_S,
+                                   int tok_offset, int32_t* idx_out, int64_t* label_out, int32_t* count_out, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(labels && idx_out && count_out && B >= 0 && L > 0 && seq_S > 0 && tok_offset >= 0 && tok_offset + L <= seq_S,
+                  MMAMD_E_BADARG, "select_tokens: bad argument");
+  MMAMD_CHECK_ARG((int64_t)B * seq_S < (1ll << 31), MMAMD_E_UNSUPPORTED, "select_tokens: more than 2^31 source rows");
+  hipLaunchKernelGGL(select_tokens_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, row_keep, (long long)ignore_index, B, L,
+                     seq_S, tok_offset, idx_out, label_out, count_out);
+  return launch_status("select_tokens");
+}
+
+extern "C" int mmamd_gather_rows(const float* src, int64_t row_stride, const int32_t* idx, int n, int d, void* dst, int dst_dtype,
+                                 mmamd_stream_t stream) {
+  if (n == 0) return 0;
+  MMAMD_CHECK_ARG(src && idx && dst && n > 0 && d > 0 && d % 4 == 0 && row_stride >= d && row_stride % 4 == 0, MMAMD_E_BADARG,
+                  "gather_rows: bad argument");
+  MMAMD_CHECK_ARG(aligned16(src) && aligned16(dst), MMAMD_E_ALIGN, "gather_rows: pointers must be 16-byte aligned");
+  if (n == 0) return 0;
+  const dim3 grid((n + 3) / 4), block(256);
+  if (dst_dtype == MMAMD_F32)
+    hipLaunchKernelGGL((gather_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, src, (size_t)row_stride, idx, n, d, (float*)dst);
+  else if (dst_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((gather_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, src, (size_t)row_stride, idx, n, d, (bf16*)dst);
+  else
+    MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "gather_rows: bad dst_dtype %d", dst_dtype);
+  return launch_status("gather_rows");
+}
+
+extern "C" int mmamd_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int N, int V, int64_t ignore_index,
+                                   float* out_loss, float* ws, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(out_loss && N >= 0 && V > 0 && ld >= V && (N == 0 || (logits && labels && ws)), MMAMD_E_BADARG,
+                  "cross_entropy: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 0)
+    hipLaunchKernelGGL(ce_generic_rows_kernel, dim3(N), dim3(256), 0, st, logits, (size_t)ld, labels, N, V, (long long)ignore_index, ws);
+  hipLaunchKernelGGL(ce_generic_reduce_kernel, dim3(1), dim3(256), 0, st, ws, N, out_loss);
+  return launch_status("cross_entropy");
 }

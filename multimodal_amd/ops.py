@@ -18,7 +18,7 @@ __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
-    "rows_linear_f32",
+    "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy",
 ]
 
 
@@ -200,6 +200,53 @@ def rows_linear_f32(h: torch.Tensor, row_stride: int, B: int, weight: torch.Tens
     check(_lib.lib().mmamd_rows_linear_f32(h.data_ptr(), int(row_stride), weight.data_ptr(), _ptr(bias), int(bool(tanh)),
                                            out.data_ptr(), B, d, E, _stream()), "mmamd_rows_linear_f32")
     return out
+
+
+def select_tokens(labels: torch.Tensor, ignore_index: int, seq_S: int, tok_offset: int,
+                  row_keep: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Compaction of the labelled positions of labels [B, L] (see mmamd_select_tokens).  Returns (source-row indices int32
+    [n], labels int64 [n]); reading n back is the one host sync (the reference's boolean indexing has the same one)."""
+    _chk(labels, "labels", torch.int64)
+    if labels.dim() == 1:
+        labels = labels.view(-1, 1)
+    B, L = labels.shape
+    if row_keep is not None:
+        _chk(row_keep, "row_keep", torch.uint8)
+        if row_keep.numel() != B:
+            raise MmamdError("select_tokens: row_keep must have one flag per sample")
+    dev = labels.device
+    idx = torch.empty(B * L, dtype=torch.int32, device=dev)
+    lab = torch.empty(B * L, dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    check(_lib.lib().mmamd_select_tokens(labels.data_ptr(), _ptr(row_keep), int(ignore_index), B, L, int(seq_S), int(tok_offset),
+                                         idx.data_ptr(), lab.data_ptr(), cnt.data_ptr(), _stream()), "mmamd_select_tokens")
+    n = int(cnt.item())
+    return idx[:n], lab[:n]
+
+
+def gather_rows(src: torch.Tensor, row_stride: int, idx: torch.Tensor, d: int, dtype: torch.dtype) -> torch.Tensor:
+    """dst[i] = the d floats at src + idx[i]*row_stride, as fp32 or bf16 [n, d]."""
+    _chk(src, "src", torch.float32); _chk(idx, "idx", torch.int32)
+    n = idx.numel()
+    dst = torch.empty((n, d), dtype=dtype, device=src.device)
+    check(_lib.lib().mmamd_gather_rows(src.data_ptr(), int(row_stride), idx.data_ptr(), n, d, dst.data_ptr(), _dt(dst), _stream()),
+          "mmamd_gather_rows")
+    return dst
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """Mean cross entropy over the rows whose label != ignore_index; logits fp32 [N, V] (row stride may exceed V)."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1):
+        raise MmamdError("cross_entropy: logits must be an fp32 [N, V] HIP tensor with unit inner stride")
+    _chk(labels, "labels", torch.int64)
+    N, V = logits.shape
+    if labels.numel() != N:
+        raise MmamdError("cross_entropy: one label per row expected")
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ws = torch.empty(max(2 * N, 1), dtype=torch.float32, device=logits.device)
+    check(_lib.lib().mmamd_cross_entropy(logits.data_ptr(), logits.stride(0) if N > 0 else V, labels.data_ptr(), N, V,
+                                         int(ignore_index), out.data_ptr(), ws.data_ptr(), _stream()), "mmamd_cross_entropy")
+    return out[0]
 
 
 def patchify(images: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:

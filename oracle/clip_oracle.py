@@ -407,3 +407,88 @@ def flava_global_contrastive_loss(image_sequence: Array, text_sequence: Array, l
     o = contrastive_loss_with_temperature(img, txt, scale, image_all, text_all, rank, mask, dtype=dtype)
     return {"loss": o["loss"], "image_logits": o["logits_a"], "text_logits": o["logits_b"], "image_loss": o["loss_a"],
             "text_loss": o["loss_b"], "image_embedding": img, "text_embedding": txt, "logit_scale": scale}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# FLAVA pre-training heads and loss (modules/losses/flava.py:100-484)
+# ------------------------------------------------------------------------------------------------------------------------
+def cross_entropy_ignore(logits: Array, labels: Array, ignore_index: int = -1):
+    """nn.CrossEntropyLoss(ignore_index=...) with mean reduction over the kept rows (NaN when none is kept, like torch)."""
+    logits = np.asarray(logits)
+    labels = np.asarray(labels).reshape(-1)
+    keep = labels != ignore_index
+    lg = logits.reshape(-1, logits.shape[-1])[keep]
+    lb = labels[keep]
+    if lg.shape[0] == 0:
+        return lg.dtype.type(np.nan)
+    m = lg.max(axis=1, keepdims=True)
+    lse = (m + np.log(np.exp(lg - m).sum(axis=1, keepdims=True)))[:, 0]
+    return (lse - lg[np.arange(lg.shape[0]), lb]).mean(dtype=lg.dtype)
+
+
+def masked_prediction_head(h: Array, sd, prefix: str, eps: float = 1e-5) -> Array:
+    """MaskedPredictionHead.forward (:174-179): dense -> erf GELU -> Fp32LayerNorm -> decoder (+ the tied output bias)."""
+    x = gelu_erf(h @ sd[prefix + "dense.weight"].T + sd[prefix + "dense.bias"])
+    x = layer_norm(x, sd[prefix + "layer_norm.weight"], sd[prefix + "layer_norm.bias"], eps)
+    return x @ sd[prefix + "decoder.weight"].T + sd[prefix + "bias"]
+
+
+def masked_prediction_loss(hidden: Array, labels: Optional[Array], sd, prefix: str, ignore_index: int = -1):
+    """MaskedPredictionLoss.forward (:206-238): only the labelled positions go through the head."""
+    hidden = np.asarray(hidden)
+    if labels is not None:
+        labels = np.asarray(labels)
+        keep = labels != ignore_index
+        seq, lab = hidden[keep], labels[keep]
+    else:
+        seq, lab = hidden, None
+    logits = masked_prediction_head(seq, sd, prefix + "cls.")
+    if lab is None:
+        return {"logits": logits, "loss": logits.dtype.type(0)}
+    return {"logits": logits, "loss": cross_entropy_ignore(logits, lab, ignore_index)}
+
+
+def itm_loss(hidden: Array, labels: Optional[Array], sd, prefix: str, ignore_index: int = -1):
+    """ITMLoss.forward (:122-140): Pooler -> Linear(hidden, 2) -> CE."""
+    pooled = flava_pooler(np.asarray(hidden), sd, prefix + "pooler.")
+    scores = pooled @ sd[prefix + "cls.seq_relationship.weight"].T + sd[prefix + "cls.seq_relationship.bias"]
+    if labels is None:
+        return {"logits": scores, "loss": scores.dtype.type(0)}
+    return {"logits": scores, "loss": cross_entropy_ignore(scores, labels, ignore_index)}
+
+
+def flava_pretraining_loss(sd, image_masked_sequence=None, text_masked_sequence=None, multimodal_masked_sequence=None,
+                           itm_labels=None, mim_labels=None, mlm_labels=None, projected_image_embeddings=None,
+                           projected_text_embeddings=None, dtype=np.float32):
+    """FLAVAPretrainingLoss.forward with all weights 1 (:370-484).  `sd` = the loss module's state_dict."""
+    sd = _cast(sd, dtype)
+    f = lambda a: None if a is None else np.asarray(a).astype(dtype)
+    ims, tms, mms = f(image_masked_sequence), f(text_masked_sequence), f(multimodal_masked_sequence)
+    out = {}
+    pos_mask = None
+    if ims is not None and mms is None:  # unimodal MIM (:391-402)
+        start = -mim_labels.shape[1] if mim_labels is not None else 1
+        out["mim"] = masked_prediction_loss(ims[:, start:, :], mim_labels, sd, "mim_loss.")
+    if tms is not None and mms is None:  # unimodal MLM (:405-416)
+        start = -mlm_labels.shape[1] if mlm_labels is not None else 1
+        out["mlm"] = masked_prediction_loss(tms[:, start:, :], mlm_labels, sd, "mlm_loss.")
+    if mms is not None:  # ITM + row filter (:418-437)
+        if itm_labels is not None:
+            pos = np.asarray(itm_labels) != 0
+            pos_mask = pos if pos.any() else np.ones_like(pos)
+        else:
+            pos_mask = np.ones(mms.shape[0], dtype=bool)
+        out["itm"] = itm_loss(mms, itm_labels, sd, "itm_loss.")
+        mms = mms[pos_mask]
+        if mlm_labels is not None:
+            mlm_labels = np.asarray(mlm_labels)[pos_mask]
+        if mim_labels is not None:
+            mim_labels = np.asarray(mim_labels)[pos_mask]
+        start = -mlm_labels.shape[1] if mlm_labels is not None else -(tms.shape[1] - 1)  # :439-452
+        out["mmm_text"] = masked_prediction_loss(mms[:, start:, :], mlm_labels, sd, "mmm_loss.mlm.")
+        total = mim_labels.shape[1] if mlm_labels is not None else ims.shape[1] - 1  # :454-469 (2 CLS rows skipped)
+        out["mmm_image"] = masked_prediction_loss(mms[:, 2:2 + total, :], mim_labels, sd, "mmm_loss.mim.")
+    if projected_image_embeddings is not None and projected_text_embeddings is not None:  # :471-482
+        out["global_contrastive"] = flava_global_contrastive_loss(
+            projected_image_embeddings, projected_text_embeddings, float(sd["contrastive_loss.logit_scale"]), pos_mask, dtype=dtype)
+    return out

@@ -325,3 +325,103 @@ def test_flava_layer_and_encoder_module_api(golden):
         enc(torch.randn(3, 10, 128).cuda(), attention_mask=torch.ones(3, 1, 10, 10).cuda())  # query-dependent mask
     with pytest.raises(ops.MmamdError):
         TransformerEncoderLayer(128, 2, 256).cuda().eval()(torch.randn(1, 4, 128).cuda())  # default nn.ReLU: no fused epilogue
+
+
+# ------------------------------------------------------------------------------------------------- pre-training heads / loss
+def test_select_gather_cross_entropy_kernels():
+    from multimodal_amd import ops
+
+    set_rng_seed(17)
+    B, L, S, off, d = 37, 61, 80, 19, 128
+    labels = torch.randint(0, 50, (B, L))
+    labels[torch.rand(B, L) < 0.8] = -1
+    keep = (torch.rand(B) < 0.6).to(torch.uint8)
+    src = torch.randn(B, S, d)
+    for rk in (None, keep):
+        idx, lab = ops.select_tokens(labels.cuda(), -1, S, off, rk.cuda() if rk is not None else None)
+        m = labels != -1
+        if rk is not None:
+            m = m & rk.bool()[:, None]
+        bb, ll = torch.nonzero(m, as_tuple=True)
+        assert torch.equal(idx.cpu().long(), bb * S + off + ll) and torch.equal(lab.cpu(), labels[m])
+        rows = ops.gather_rows(src.cuda(), d, idx, d, torch.float32)
+        assert torch.equal(rows.cpu(), src[bb, off + ll])
+        assert torch.equal(ops.gather_rows(src.cuda(), d, idx, d, torch.bfloat16).cpu(), src[bb, off + ll].to(torch.bfloat16))
+    none, _ = ops.select_tokens(torch.full((4, 3), -1).cuda(), -1, 3, 0)
+    assert none.numel() == 0
+    for (N, V, pad) in ((300, 30522, 6), (5, 2, 0), (64, 8192, 0)):
+        logits = torch.randn(N, V + pad) * 3
+        lab = torch.randint(0, V, (N,))
+        lab[torch.rand(N) < 0.3] = -1
+        got = ops.cross_entropy(logits.cuda()[:, :V], lab.cuda(), -1)
+        ref = torch.nn.functional.cross_entropy(logits[:, :V].double(), lab, ignore_index=-1)
+        assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert torch.isnan(ops.cross_entropy(torch.randn(3, 5).cuda(), torch.full((3,), -1).cuda(), -1))
+
+
+def test_flava_pretraining_loss_vs_reference_fixture(golden):
+    from multimodal_amd.modules.losses.flava import FLAVAPretrainingLoss, FLAVAPretrainingLossOutput
+
+    z, s = golden("flava_pretrain_small.npz"), golden("flava_small.npz")
+    loss = FLAVAPretrainingLoss(hidden_size=128, text_vocab_size=200, image_vocab_size=64)
+    loss.load_state_dict({k: torch.from_numpy(v) for k, v in fixture_sd(z).items()}, strict=True)
+    loss = loss.cuda().eval()
+    T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    seqs = dict(image_masked_sequence=T(s["image_masked.last_hidden_state"]), text_masked_sequence=T(s["text_masked.last_hidden_state"]))
+    LOGIT, LOSS = 3e-2, 1e-2  # bf16 GEMM operands through dense -> LN -> vocabulary projection
+    with torch.no_grad():
+        mm = loss(multimodal_masked_sequence=T(s["multimodal_masked.last_hidden_state"]), itm_labels=T(z["itm_labels"]),
+                  mim_labels=T(z["mim_labels"]), mlm_labels=T(z["mlm_labels"]), projected_image_embeddings=T(s["proj_image"]),
+                  projected_text_embeddings=T(s["proj_text"]), **seqs)
+        uni = loss(mim_labels=T(z["mim_labels"]), mlm_labels=T(z["mlm_labels"]), **seqs)
+        neg = loss(multimodal_masked_sequence=T(s["multimodal_masked.last_hidden_state"]), itm_labels=torch.zeros(5, dtype=torch.long).cuda(),
+                   mim_labels=T(z["mim_labels"]), mlm_labels=T(z["mlm_labels"]), **seqs)
+    assert isinstance(mm, FLAVAPretrainingLossOutput) and mm.losses.mim_loss is None and mm.mlm_output is None
+    rep = {}
+    for out, key in ((mm.mmm_text_output, "mm.mmm_text"), (mm.mmm_image_output, "mm.mmm_image"), (mm.itm_output, "mm.itm"),
+                     (uni.mim_output, "uni.mim"), (uni.mlm_output, "uni.mlm"), (neg.mmm_text_output, "allneg.mmm_text")):
+        assert tuple(out.logits.shape) == z[key + "_logits"].shape, key
+        rep[key + "_logits"] = np.abs(host(out.logits) - z[key + "_logits"]).max()
+        rep[key + "_loss"] = abs(float(out.loss) - float(z[key + "_loss"]))
+        assert rep[key + "_logits"] <= LOGIT and rep[key + "_loss"] <= LOSS, (key, rep)
+    assert abs(float(neg.losses.itm_loss) - float(z["allneg.itm_loss"])) <= 1e-4
+    assert abs(float(mm.losses.itm_loss) - float(z["mm.itm_loss"])) <= 1e-4  # pooler + 2-way head are fp32 end to end
+    assert abs(float(mm.losses.global_contrastive_loss) - float(z["mm.global_contrastive_loss"])) <= 2e-5
+    assert np.abs(host(mm.global_contrastive_output.image_logits) - z["mm.itc_image_logits"]).max() <= 2e-4
+    assert mm.losses.mmm_text_loss is mm.mmm_text_output.loss
+    print("flava pretraining-loss parity |d|:", {k: float(f"{v:.2e}") for k, v in rep.items()})
+
+
+def test_masked_prediction_head_full_vocab_and_module_api():
+    """Vocabulary 30522 is not a multiple of 8: the decoder is padded internally and the logits come back as a [N, 30522] view."""
+    from multimodal_amd.modules.losses.flava import ITMLoss, MaskedPredictionHead, MaskedPredictionLoss
+
+    set_rng_seed(12)
+    head = MaskedPredictionHead(hidden_size=128, vocab_size=30522).cuda().eval()
+    torch.nn.init.normal_(head.bias, std=0.1)
+    x = torch.randn(3, 7, 128)
+    sd = {k: v.detach().cpu().numpy() for k, v in head.state_dict().items()}
+    assert sorted(sd) == ["bias", "decoder.bias", "decoder.weight", "dense.bias", "dense.weight", "layer_norm.bias", "layer_norm.weight"]
+    with torch.no_grad():
+        y = head(x.cuda())
+    ref = oc.masked_prediction_head(x.numpy(), sd, "")
+    assert y.shape == (3, 7, 30522) and np.abs(host(y) - ref).max() <= 3e-2
+    mp = MaskedPredictionLoss(hidden_size=128, vocab_size=64).cuda().eval()
+    lab = torch.full((3, 7), -1)
+    lab[0, 2], lab[2, 6] = 5, 63
+    sdl = {k: v.detach().cpu().numpy() for k, v in mp.state_dict().items()}
+    with torch.no_grad():
+        o = mp(x.cuda(), lab.cuda())
+        o_none = mp(x.cuda())
+        o_empty = mp(x.cuda(), torch.full((3, 7), -1).cuda())
+    r = oc.masked_prediction_loss(x.numpy(), lab.numpy(), sdl, "")
+    assert o.logits.shape == (2, 64) and abs(float(o.loss) - float(r["loss"])) <= 1e-2
+    assert o_none.logits.shape == (3, 7, 64) and float(o_none.loss) == 0.0
+    assert o_empty.logits.shape == (0, 64) and torch.isnan(o_empty.loss)
+    itm = ITMLoss(hidden_size=128).cuda().eval()
+    with torch.no_grad():
+        oi = itm(x.cuda(), torch.tensor([1, -1, 0]).cuda())
+        oi_none = itm(x.cuda(), None)
+    ri = oc.itm_loss(x.numpy(), np.array([1, -1, 0]), {k: v.detach().cpu().numpy() for k, v in itm.state_dict().items()}, "")
+    assert np.abs(host(oi.logits) - ri["logits"]).max() <= 1e-5 and abs(float(oi.loss) - float(ri["loss"])) <= 1e-5
+    assert float(oi_none.loss) == 0.0

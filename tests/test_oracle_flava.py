@@ -35,3 +35,31 @@ def test_flava_small_model_all_outputs(golden):
     np.testing.assert_allclose(lo["loss"], z["itc_loss"], atol=2e-5)
     np.testing.assert_allclose(lo["image_logits"], z["itc_image_logits"], atol=1e-4)
     np.testing.assert_allclose(lo["text_embedding"], z["itc_text_embedding"], atol=2e-6)
+
+
+def test_pretraining_loss_oracle_vs_reference_fixture(golden):
+    """FLAVAPretrainingLoss restated in numpy == the reference's own outputs (multimodal, unimodal, and the all-negative
+    ITM batch where the row filter falls back to "keep everything")."""
+    z = golden("flava_pretrain_small.npz")
+    s = golden("flava_small.npz")
+    sd = fixture_sd(z)
+    seqs = dict(image_masked_sequence=s["image_masked.last_hidden_state"], text_masked_sequence=s["text_masked.last_hidden_state"])
+    mm = oc.flava_pretraining_loss(sd, multimodal_masked_sequence=s["multimodal_masked.last_hidden_state"], itm_labels=z["itm_labels"],
+                                   mim_labels=z["mim_labels"], mlm_labels=z["mlm_labels"], projected_image_embeddings=s["proj_image"],
+                                   projected_text_embeddings=s["proj_text"], **seqs)
+    assert "mim" not in mm and "mlm" not in mm
+    for k, name in (("mmm_text", "mm.mmm_text"), ("mmm_image", "mm.mmm_image"), ("itm", "mm.itm")):
+        assert abs(float(mm[k]["loss"]) - float(z[name + "_loss"])) <= 2e-5, k
+        assert mm[k]["logits"].shape == z[name + "_logits"].shape
+        assert np.abs(mm[k]["logits"] - z[name + "_logits"]).max() <= 2e-5, k
+    assert abs(float(mm["global_contrastive"]["loss"]) - float(z["mm.global_contrastive_loss"])) <= 2e-5
+    assert np.abs(mm["global_contrastive"]["image_logits"] - z["mm.itc_image_logits"]).max() <= 1e-4
+    uni = oc.flava_pretraining_loss(sd, mim_labels=z["mim_labels"], mlm_labels=z["mlm_labels"], **seqs)
+    for k in ("mim", "mlm"):
+        assert abs(float(uni[k]["loss"]) - float(z[f"uni.{k}_loss"])) <= 2e-5
+        assert np.abs(uni[k]["logits"] - z[f"uni.{k}_logits"]).max() <= 2e-5
+    neg = oc.flava_pretraining_loss(sd, multimodal_masked_sequence=s["multimodal_masked.last_hidden_state"],
+                                    itm_labels=np.zeros(5, dtype=np.int64), mim_labels=z["mim_labels"], mlm_labels=z["mlm_labels"], **seqs)
+    assert abs(float(neg["itm"]["loss"]) - float(z["allneg.itm_loss"])) <= 2e-5
+    assert abs(float(neg["mmm_text"]["loss"]) - float(z["allneg.mmm_text_loss"])) <= 2e-5
+    assert np.abs(neg["mmm_text"]["logits"] - z["allneg.mmm_text_logits"]).max() <= 2e-5
