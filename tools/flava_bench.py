@@ -1,0 +1,77 @@
+"""FLAVA forward (+ pre-training loss) timing on one MI355X — SURVEY.md section 8 cfg 4 (B = 128), WITHOUT the DALL-E
+codebook stage (out of scope, section 8f rank 2):  python tools/flava_bench.py [--batch 128] [--steps 10]
+
+Algorithmic FLOPs per sample: image 35.13 GF and text 13.30 GF per pass, fusion 24.75 GF, heads ~1.8 GF.
+The reference runs 2 image + 2 text passes; so does this path when an image_patches_mask is given.
+Prints one JSON line."""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-loss", action="store_true")
+    a = ap.parse_args()
+    from multimodal_amd.models.flava.model import flava_model
+    from multimodal_amd.modules.losses.flava import FLAVAPretrainingLoss
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    model = flava_model().to(dev).eval()
+    loss = FLAVAPretrainingLoss().to(dev).eval()
+    B = a.batch
+    g = torch.Generator().manual_seed(1)
+    image = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    text = torch.randint(1, 30522, (B, 77), generator=g)
+    text[:, 60:] = 0
+    text_masked = text.clone()
+    mlm = torch.full((B, 77), -1, dtype=torch.long)
+    sel = torch.rand(B, 77, generator=g) < 0.15
+    sel[:, 60:] = False
+    mlm[sel] = text[sel]
+    text_masked[sel] = 103
+    pmask = (torch.rand(B, 196, generator=g) < 0.4).long()
+    mim = torch.randint(0, 8192, (B, 196), generator=g)
+    mim[pmask == 0] = -1
+    itm = torch.ones(B, dtype=torch.long)
+    text, text_masked, mlm, pmask, mim, itm = (t.to(dev) for t in (text, text_masked, mlm, pmask, mim, itm))
+
+    def step():
+        with torch.no_grad():
+            o = model(image, text, image_patches_mask=pmask, text_masked=text_masked)
+            if a.no_loss:
+                return o.projected_image_embeddings
+            lo = loss(image_sequence=o.image.last_hidden_state, text_sequence=o.text.last_hidden_state,
+                      image_masked_sequence=o.image_masked.last_hidden_state, text_masked_sequence=o.text_masked.last_hidden_state,
+                      multimodal_masked_sequence=o.multimodal_masked.last_hidden_state, itm_labels=itm, mim_labels=mim, mlm_labels=mlm,
+                      projected_image_embeddings=o.projected_image_embeddings, projected_text_embeddings=o.projected_text_embeddings)
+            return lo.losses.global_contrastive_loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(a.steps):
+        r = step()
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / a.steps
+    gf = 2 * 35.13 + 2 * 13.30 + 24.75 + (0.0 if a.no_loss else 1.8)
+    print(json.dumps({"workload": "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + " (no codebook)",
+                      "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_sample": gf,
+                      "tflops": round(B * gf / ms, 1), "mfma_frac": round(B * gf / ms / 2500.0, 4),
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "last": float(r.flatten()[0])}))
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,8 @@ timeout 300 python tools/kernel_bench.py --variants 0,7 > gpurun_out/kernel_benc
 cat gpurun_out/kernel_bench.log
 timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1
 cat gpurun_out/bench.log
+timeout 300 python tools/flava_bench.py > gpurun_out/flava_bench.log 2>&1
+cat gpurun_out/flava_bench.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 cat gpurun_out/smoke.log
 rm -rf gpurun_out/prof
