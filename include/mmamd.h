@@ -89,6 +89,18 @@ int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int cau
 int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int probs_dtype, int B,
                               int S, int H, float scale, mmamd_stream_t stream);
 
+/* General attention: separate strided q / k / v (bf16), Sq != Sk, head_dim 64 or 96, optional causal / key-padding /
+ * full [B or 1, Sq, Sk] uint8 masks (0 = masked), optional probabilities.  q row (b,i) at q + b*q_batch_stride + i*ldq
+ * (q_batch_stride = 0: queries shared by every sample), k/v row (b,j) at k/v + b*kv_batch_stride + j*ldk/ldv; out bf16
+ * [B*Sq, ldo].  Replaces F.scaled_dot_product_attention in MultiHeadAttentionWithCache / MultiHeadSelfAttention
+ * (modules/layers/multi_head_attention.py:69-71,165-167) as CoCa calls them: decoder self-attention with the
+ * padding-aware causal mask (models/coca/text_decoder.py:178-194), cross-attention of the multimodal decoder
+ * (modules/layers/transformer.py:367-385), AttentionPooler (modules/layers/attention_pooler.py:58-70). */
+int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                          int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                          int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
+                          int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream);
+
 /* --- K1 front end: non-overlapping patch extraction ("im2col" of a stride==kernel conv) -------
  * images [B,C,HW,HW] (f32 or bf16) -> patches bf16 [B*(HW/P)^2, Kpad], column k = (c*P+py)*P+px,
  * columns >= C*P*P zero-filled.  Replaces the gather half of nn.Conv2d at image_encoder.py:50-56,91. */
@@ -114,6 +126,15 @@ int mmamd_embed_tokens(const int64_t* ids, const void* table, int table_dtype, c
  * modules/encoders/bert_text_encoder.py:84-91 (+ utils/attention.py:13-52). */
 int mmamd_key_mask(const void* src, int kind, int64_t pad_id, uint8_t* out, int64_t n, mmamd_stream_t stream);
 
+/* CoCa text embeddings: x[b,s] = table[ids[b,s]] + pos[s] (s < S_ids); x[b,S_ids] = cls + pos[S_ids] when cls != NULL.
+ * fp32 [B, S_ids(+1), d].  Replaces CoCaTextEmbeddings.forward, models/coca/text_decoder.py:67-88. */
+int mmamd_coca_text_embed(const int64_t* ids, const float* table, const float* pos, const float* cls, float* x, int B,
+                          int S_ids, int d, int vocab, mmamd_stream_t stream);
+
+/* CoCaTextDecoder.build_mask (models/coca/text_decoder.py:178-194) as uint8 [B, S+1, S+1] (1 = attend): causal, and the CLS
+ * query row masks padded tokens (shifted by one column, like the reference's F.pad).  src/kind/pad_id as mmamd_key_mask. */
+int mmamd_coca_text_mask(const void* src, int kind, int64_t pad_id, uint8_t* out, int B, int S, mmamd_stream_t stream);
+
 /* BERT embeddings: x[b,s,:] = LayerNorm(word[ids] + position[pos_ids or s] + token_type[type_ids or 0]) (fp32 out).
  * Replaces modules/layers/text_embedding.py:74-104 (three gathers, add, nn.LayerNorm). */
 int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
@@ -121,7 +142,8 @@ int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64
                         int B, int S, int d, int vocab, int max_pos, int n_types, mmamd_stream_t stream);
 
 /* FLAVA image embeddings: x[b,0] = cls + pos[0]; x[b,1+i] = blend(patch_emb[b,i], mask_token, patches_mask[b,i]) + pos[1+i]
- * (fp32, no LayerNorm; patches_mask int64 [B,G2] / mask_token may be NULL).  Replaces models/flava/image_encoder.py:139-177. */
+ * (fp32, no LayerNorm; patches_mask int64 [B,G2] / mask_token may be NULL; cls NULL = no CLS row, x is [B,G2,d]).  Replaces
+ * models/flava/image_encoder.py:139-177 and modules/layers/patch_embedding.py:98-152 (CoCa's ViT). */
 int mmamd_flava_image_embed(const float* patch_emb, const float* cls, const float* pos, const int64_t* patches_mask,
                             const float* mask_token, float* x, int B, int G2, int d, mmamd_stream_t stream);
 

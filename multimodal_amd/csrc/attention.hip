@@ -386,6 +386,213 @@ static int launch_attn_probs(const void* qkv, const uint8_t* key_mask, void* out
   return launch_status("attention_probs_fwd");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// General attention (CoCa: cross-attention with Sq != Sk, the attention pooler's 96-wide heads and batch-shared learned
+// queries, causal decoders with a padding-aware mask).  Same two-pass structure and register layout as the kernel above,
+// templated on the head dimension; q / k / v are separate strided bf16 matrices:
+//   q row (b, i) at q + b*q_bs + i*ldq (+ h*DH)     q_bs = 0: the same queries for every sample (AttentionPooler)
+//   k/v row (b, j) at k/v + b*kv_bs + j*ldk/ldv (+ h*DH)
+// Masks (all optional, combined): causal (key j <= query i), key_mask uint8 [B,Sk], full_mask uint8 [B or 1, Sq, Sk]
+// (0 = masked; fm_bs = 0 broadcasts one [Sq,Sk] mask over the batch).
+struct AttnX {
+  const bf16 *q, *k, *v;
+  bf16* out;
+  void* probs;
+  const uint8_t *key_mask, *full_mask;
+  long long q_bs, kv_bs, fm_bs;
+  int ldq, ldk, ldv, ldo, Sq, Sk, H, causal;
+  float scale_log2e;
+};
+
+template <int NKT, int DH, typename TP>
+__global__ __launch_bounds__(256) void attention_x_kernel(const AttnX p) {
+  constexpr int SP = NKT * 32;
+  constexpr int KS = DH + 8;   // bf16 per K row in LDS: (DH+8)*2 B = an odd number of 16-B slots -> conflict-free b128 reads
+  constexpr int VS = SP + 4;
+  constexpr int CPR = DH / 8;  // 16-byte chunks per row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vt = reinterpret_cast<bf16*>(smem + SP * KS * 2);
+  float* Mk = reinterpret_cast<float*>(smem + SP * KS * 2 + DH * VS * 2);
+
+  const int bh = blockIdx.x;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Sq = p.Sq, Sk = p.Sk;
+  const bf16* kb = p.k + (size_t)b * p.kv_bs + h * DH;
+  const bf16* vb = p.v + (size_t)b * p.kv_bs + h * DH;
+  const bf16* qb = p.q + (size_t)b * p.q_bs + h * DH;
+
+  for (int i = tid; i < SP * CPR; i += 256) {
+    const int r = i / CPR, c = i - r * CPR;
+    bf16x8 kv, vv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+    if (r < Sk) {
+      kv = *reinterpret_cast<const bf16x8*>(kb + (size_t)r * p.ldk + c * 8);
+      vv = *reinterpret_cast<const bf16x8*>(vb + (size_t)r * p.ldv + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Ks + r * KS + c * 8) = kv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VS + r] = vv[j];
+  }
+  for (int k = tid; k < SP; k += 256)
+    Mk[k] = (k < Sk && (p.key_mask == nullptr || p.key_mask[(size_t)b * Sk + k] != 0)) ? 0.f : -INFINITY;
+  __syncthreads();
+
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nqt = (Sq + 31) >> 5;
+  const uint8_t* fm = p.full_mask ? p.full_mask + (size_t)b * p.fm_bs : nullptr;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 32 + l31;
+    const int qc = q < Sq ? q : Sq - 1;
+    bf16x8 qf[DH / 16];
+#pragma unroll
+    for (int t = 0; t < DH / 16; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qc * p.ldq + 16 * t + 8 * half);
+    const int kt_hi = p.causal ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;  // tiles above the diagonal are fully masked
+
+    auto scores = [&](int kt, f32x16& st) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      const bf16* krow = Ks + (kt * 32 + l31) * KS + 8 * half;
+#pragma unroll
+      for (int t = 0; t < DH / 16; ++t) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + 16 * t);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], st, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float add = Mk[key];
+        if (p.causal && key > qc) add = -INFINITY;
+        if (fm != nullptr && key < Sk && fm[(size_t)qc * Sk + key] == 0) add = -INFINITY;
+        st[r] = st[r] * p.scale_log2e + add;
+      }
+    };
+
+    float m = -INFINITY, lsum = 0.f;
+#pragma unroll 1
+    for (int kt = 0; kt < kt_hi; ++kt) {
+      f32x16 st;
+      scores(kt, st);
+      float tmax = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m, tmax);
+      const float alpha = (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ps += (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[r] - m_new);
+      lsum = lsum * alpha + ps;
+      m = m_new;
+    }
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;
+
+    f32x16 ot[DH / 32];
+#pragma unroll
+    for (int nt = 0; nt < DH / 32; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+    TP* prow = p.probs ? reinterpret_cast<TP*>(p.probs) + (((size_t)b * p.H + h) * Sq + (size_t)qc) * Sk : nullptr;
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt >= kt_hi) {  // causal tail: probabilities are exactly 0, nothing to accumulate
+        if (prow != nullptr && q < Sq) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (key < Sk) prow[key] = (TP)0.f;
+          }
+        }
+        continue;
+      }
+      f32x16 st;
+      scores(kt, st);
+      uint32_t pk[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(st[4 * g + j] - m) * inv;
+        if (prow != nullptr && q < Sq) {
+          const int key = kt * 32 + 8 * g + 4 * half;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (key + j < Sk) prow[key + j] = (TP)e[j];
+        }
+        bf16x2 p0, p1;
+        p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+        pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
+        pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int key0 = kt * 32 + 16 * jj + 4 * half;
+        u32x4 pw;
+        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int nt = 0; nt < DH / 32; ++nt) {
+          const bf16* vrow = Vt + (nt * 32 + l31) * VS + key0;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+          u32x4 vw;
+          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+          ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, ot[nt], 0, 0, 0);
+        }
+      }
+    }
+    if (q < Sq) {
+      bf16* orow = p.out + ((size_t)b * Sq + q) * p.ldo + h * DH;
+#pragma unroll
+      for (int nt = 0; nt < DH / 32; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = ot[nt][4 * g + j];
+          store4(orow + nt * 32 + 8 * g + 4 * half, o);
+        }
+    }
+  }
+}
+
+template <int NKT, int DH, typename TP>
+static int launch_attn_x(const AttnX& p, int B, hipStream_t st) {
+  constexpr int SP = NKT * 32;
+  constexpr int smem = SP * (DH + 8) * 2 + DH * (SP + 4) * 2 + SP * 4;
+  auto kern = attention_x_kernel<NKT, DH, TP>;
+  static bool attr_done = false;
+  if (!attr_done && smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("attention_x: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * p.H), dim3(256), smem, st, p);
+  return launch_status("attention_x_fwd");
+}
+
+template <int DH, typename TP>
+static int dispatch_attn_x(const AttnX& p, int B, hipStream_t st) {
+  switch ((p.Sk + 31) / 32) {
+    case 1: return launch_attn_x<1, DH, TP>(p, B, st);
+    case 2: return launch_attn_x<2, DH, TP>(p, B, st);
+    case 3: return launch_attn_x<3, DH, TP>(p, B, st);
+    case 4: return launch_attn_x<4, DH, TP>(p, B, st);
+    case 5: return launch_attn_x<5, DH, TP>(p, B, st);
+    case 6: return launch_attn_x<6, DH, TP>(p, B, st);
+    case 7: return launch_attn_x<7, DH, TP>(p, B, st);
+    case 8: return launch_attn_x<8, DH, TP>(p, B, st);
+    case 9: return launch_attn_x<9, DH, TP>(p, B, st);
+  }
+  set_error("attention_x: Sk=%d > 288 not supported", p.Sk);
+  return MMAMD_E_UNSUPPORTED;
+}
+
 static int g_attn_variant = 0;
 
 template <int NKT, bool CAUSAL, int ABL = 0>
@@ -460,4 +667,30 @@ extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mas
   }
 #undef ATTNP_CASE
   MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention_probs: unsupported S=%d", S);
+}
+
+extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                     int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                     int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
+                                     int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(q && k && v && out && B >= 0 && Sq > 0 && Sk > 0 && H > 0, MMAMD_E_BADARG, "attention_x: bad argument");
+  MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x: head_dim=%d (64 and 96 are built)", head_dim);
+  MMAMD_CHECK_ARG(Sk <= 288, MMAMD_E_UNSUPPORTED, "attention_x: Sk=%d > 288 not supported", Sk);
+  MMAMD_CHECK_ARG(!causal || Sq == Sk, MMAMD_E_BADARG, "attention_x: causal needs Sq == Sk");
+  MMAMD_CHECK_ARG(ldq >= H * head_dim && ldk >= H * head_dim && ldv >= H * head_dim && ldo >= H * head_dim, MMAMD_E_BADARG,
+                  "attention_x: leading dimension smaller than H*head_dim");
+  MMAMD_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && q_batch_stride % 8 == 0 && kv_batch_stride % 8 == 0 &&
+                      aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out),
+                  MMAMD_E_ALIGN, "attention_x: rows must be 16-byte aligned");
+  if (B == 0) return 0;
+  AttnX p;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)out; p.probs = probs;
+  p.key_mask = key_mask; p.full_mask = full_mask;
+  p.q_bs = q_batch_stride; p.kv_bs = kv_batch_stride; p.fm_bs = full_mask_batch_stride;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal ? 1 : 0;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  const bool pf32 = probs == nullptr || probs_dtype == MMAMD_F32;
+  if (head_dim == 64) return pf32 ? dispatch_attn_x<64, float>(p, B, st) : dispatch_attn_x<64, bf16>(p, B, st);
+  return pf32 ? dispatch_attn_x<96, float>(p, B, st) : dispatch_attn_x<96, bf16>(p, B, st);
 }

@@ -361,17 +361,19 @@ __global__ __launch_bounds__(256) void flava_image_embed_kernel(const float* __r
                                                                 int B, int G2, int d) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int S = G2 + 1;
+  const int hc = cls != nullptr ? 1 : 0;  // no CLS row: CoCa's ViT (layers/patch_embedding.py, include_cls_embed=False)
+  const int S = G2 + hc;
   if (row >= B * S) return;
   const int b = row / S, s = row - b * S;
+  const int pi = s - hc;
   float w = 0.f;
-  if (s > 0 && pmask != nullptr && mask_token != nullptr) w = (float)pmask[(size_t)b * G2 + (s - 1)];
+  if (pi >= 0 && pmask != nullptr && mask_token != nullptr) w = (float)pmask[(size_t)b * G2 + pi];
   for (int c = lane; c < (d >> 2); c += 64) {
     f32x4 t;
-    if (s == 0) {
+    if (pi < 0) {
       t = load4(cls + 4 * c);
     } else {
-      t = load4(pe + ((size_t)b * G2 + (s - 1)) * d + 4 * c);
+      t = load4(pe + ((size_t)b * G2 + pi) * d + 4 * c);
       if (w != 0.f) {
         const f32x4 mt = load4(mask_token + 4 * c);
 #pragma unroll
@@ -445,6 +447,56 @@ __global__ __launch_bounds__(256) void key_mask_kernel(const void* __restrict__ 
   else if (kind == 1) keep = reinterpret_cast<const float*>(src)[i] != 0.f;
   else if (kind == 2) keep = reinterpret_cast<const int64_t*>(src)[i] != 0;
   else keep = reinterpret_cast<const uint8_t*>(src)[i] != 0;
+  out[i] = keep ? 1 : 0;
+}
+
+
+// CoCa text embeddings: x[b, s] = token[ids[b, s]] + pos[s] for s < S_ids, x[b, S_ids] = cls + pos[S_ids] (cls optional)
+// (models/coca/text_decoder.py:67-88)
+__global__ __launch_bounds__(256) void coca_text_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                              const float* __restrict__ pos, const float* __restrict__ cls,
+                                                              float* __restrict__ x, int B, int S_ids, int d, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int S = S_ids + (cls != nullptr ? 1 : 0);
+  if (row >= B * S) return;
+  const int b = row / S, s = row - b * S;
+  const float* src;
+  if (s < S_ids) {
+    long long id = ids[(size_t)b * S_ids + s];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    src = table + (size_t)id * d;
+  } else {
+    src = cls;
+  }
+  for (int c = lane; c < (d >> 2); c += 64) {
+    const f32x4 a = load4(src + 4 * c), pp = load4(pos + (size_t)s * d + 4 * c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = a[j] + pp[j];
+    store4(x + (size_t)row * d + 4 * c, o);
+  }
+}
+
+// CoCaTextDecoder.build_mask (models/coca/text_decoder.py:178-194) as a uint8 [B, S+1, S+1] attend-mask: causal everywhere;
+// the CLS query (last row) additionally sees key 0 always and key j >= 1 only if token j-1 is not padding (the reference's
+// F.pad(..., (1, 0, S, 0)) shifts the padding mask by one column).  kind as in key_mask (0: ids != pad, 1/2/3: mask != 0).
+__global__ __launch_bounds__(256) void coca_text_mask_kernel(const void* __restrict__ src, int kind, long long pad, uint8_t* __restrict__ out,
+                                                             int B, int S) {
+  const int T = S + 1;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * T * T) return;
+  const int b = (int)(i / (T * T));
+  const int rem = (int)(i - (long long)b * T * T);
+  const int qi = rem / T, kj = rem - qi * T;
+  bool keep = kj <= qi;
+  if (keep && qi == S && kj >= 1) {
+    const size_t o = (size_t)b * S + (kj - 1);
+    if (kind == 0) keep = reinterpret_cast<const int64_t*>(src)[o] != pad;
+    else if (kind == 1) keep = reinterpret_cast<const float*>(src)[o] != 0.f;
+    else if (kind == 2) keep = reinterpret_cast<const int64_t*>(src)[o] != 0;
+    else keep = reinterpret_cast<const uint8_t*>(src)[o] != 0;
+  }
   out[i] = keep ? 1 : 0;
 }
 
@@ -627,9 +679,9 @@ extern "C" int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, 
 
 extern "C" int mmamd_flava_image_embed(const float* patch_emb, const float* cls, const float* pos, const int64_t* patches_mask,
                                        const float* mask_token, float* x, int B, int G2, int d, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(patch_emb && cls && pos && x && B >= 0 && G2 > 0 && d > 0 && d % 4 == 0, MMAMD_E_BADARG, "flava_image_embed: bad argument");
+  MMAMD_CHECK_ARG(patch_emb && pos && x && B >= 0 && G2 > 0 && d > 0 && d % 4 == 0, MMAMD_E_BADARG, "flava_image_embed: bad argument");
   if (B == 0) return 0;
-  const int rows = B * (G2 + 1);
+  const int rows = B * (G2 + (cls ? 1 : 0));
   hipLaunchKernelGGL(flava_image_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, patch_emb, cls, pos,
                      patches_mask, mask_token, x, B, G2, d);
   return launch_status("flava_image_embed");
@@ -650,4 +702,21 @@ extern "C" int mmamd_key_mask(const void* src, int kind, int64_t pad_id, uint8_t
   hipLaunchKernelGGL(key_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, kind, (long long)pad_id,
                      out, (long long)n);
   return launch_status("key_mask");
+}
+
+extern "C" int mmamd_coca_text_embed(const int64_t* ids, const float* table, const float* pos, const float* cls, float* x, int B,
+                                     int S_ids, int d, int vocab, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(ids && table && pos && x && B >= 0 && S_ids > 0 && d > 0 && d % 4 == 0 && vocab > 0, MMAMD_E_BADARG, "coca_text_embed: bad argument");
+  if (B == 0) return 0;
+  const int rows = B * (S_ids + (cls ? 1 : 0));
+  hipLaunchKernelGGL(coca_text_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, table, pos, cls, x, B, S_ids, d, vocab);
+  return launch_status("coca_text_embed");
+}
+
+extern "C" int mmamd_coca_text_mask(const void* src, int kind, int64_t pad_id, uint8_t* out, int B, int S, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(src && out && B >= 0 && S > 0 && kind >= 0 && kind <= 3, MMAMD_E_BADARG, "coca_text_mask: bad argument");
+  if (B == 0) return 0;
+  const long long n = (long long)B * (S + 1) * (S + 1);
+  hipLaunchKernelGGL(coca_text_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, kind, (long long)pad_id, out, B, S);
+  return launch_status("coca_text_mask");
 }

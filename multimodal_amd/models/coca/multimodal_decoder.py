@@ -1,0 +1,50 @@
+"""Host-side mirror of torchmultimodal/models/coca/multimodal_decoder.py:14-108 (CoCaMultimodalDecoder): causal transformer
+decoder over the text tokens that cross-attends to the captioning image embeddings, then the (vocabulary) output projection —
+one bf16 MFMA GEMM with fp32 logits."""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+from ...modules.layers.transformer import TransformerDecoder
+from ...utils.attention import get_causal_attention_mask
+
+
+class CoCaMultimodalDecoder(nn.Module):
+    def __init__(self, input_seq_len: int, text_embedding_dim: int, n_layer: int, n_head: int, dim_feedforward: int,
+                 output_dim: Optional[int] = None, dropout: float = 0.0, activation: Callable[..., nn.Module] = nn.GELU,
+                 layer_norm_eps: float = 1e-5, norm_first: bool = True, final_layer_norm_eps: Optional[float] = 1e-5,
+                 visual_embedding_dim: Optional[int] = None):
+        super().__init__()
+        self.transformer_decoder = TransformerDecoder(
+            n_layer=n_layer, d_model=text_embedding_dim, n_head=n_head, dim_feedforward=dim_feedforward, dropout=dropout,
+            activation=activation, layer_norm_eps=layer_norm_eps, norm_first=norm_first, use_cross_attention=True,
+            final_layer_norm_eps=final_layer_norm_eps, dim_kv=visual_embedding_dim)
+        if output_dim is not None:
+            self.output_projection = nn.Linear(text_embedding_dim, output_dim, bias=False)
+        else:
+            self.output_projection = None
+        self.register_buffer("causal_mask", get_causal_attention_mask(input_seq_len).to(dtype=torch.bool), persistent=False)
+        self._packed = PackedCache()
+
+    def forward(self, texts: Tensor, images: Tensor) -> Tensor:
+        seq_len = texts.shape[1]
+        assert self.causal_mask.shape == (seq_len, seq_len)
+        # the registered causal_mask buffer IS lower-triangular: the kernel's causal flag skips the key tiles above the diagonal
+        decoder_outputs = self.transformer_decoder(hidden_states=texts, encoder_hidden_states=images,
+                                                   attention_mask=ops.AttnMask(causal=True))
+        hidden_states = decoder_outputs.last_hidden_state
+        assert hidden_states is not None, "hidden states must not be None"
+        if self.output_projection is None:
+            return hidden_states
+        B, S, d = hidden_states.shape
+        h = ops.convert(hidden_states.view(B * S, d), torch.bfloat16)
+        V = self.output_projection.out_features
+        w = self._packed.get_padded_rows(self.output_projection.weight, torch.bfloat16, 8)
+        out = ops.gemm_bf16(h, w, None, out_dtype=torch.float32)
+        out = out if out.shape[1] == V else out[:, :V]
+        return out.unflatten(0, (B, S))

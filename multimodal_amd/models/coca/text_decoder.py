@@ -1,0 +1,128 @@
+"""Host-side mirror of torchmultimodal/models/coca/text_decoder.py:17-252 (CoCaTextEmbeddings, CoCaTextDecoder).
+
+Token gather + CLS row + position add is one kernel (coca_text_embed_kernel); the padding-aware causal mask of
+`build_mask` is produced directly as the uint8 [B, S, S] mask the attention kernel reads (coca_text_mask_kernel)."""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+from ...modules.layers.transformer import TransformerDecoder
+from ...utils.attention import get_causal_attention_mask
+
+
+class CoCaTextEmbeddings(nn.Module):
+    def __init__(self, vocab_size: int, num_positions: int, embedding_dim: int, pad_idx: Optional[int] = 0, embed_cls: bool = True):
+        super().__init__()
+        self.num_positions = num_positions
+        if embed_cls:
+            self.cls_embedding = nn.Parameter(torch.empty(embedding_dim))
+        else:
+            self.cls_embedding = None
+        self.token_embeddings = nn.Embedding(vocab_size, embedding_dim, pad_idx)
+        self.position_embeddings = nn.Parameter(torch.empty(num_positions, embedding_dim))
+        self.init_parameters()
+        self._packed = PackedCache()
+
+    def init_parameters(self) -> None:
+        nn.init.normal_(self.token_embeddings.weight, std=0.02)
+        nn.init.normal_(self.position_embeddings, std=0.01)
+        if self.cls_embedding is not None:
+            nn.init.constant_(self.cls_embedding, 0.01)
+
+    def forward(self, input_ids: Tensor) -> Tensor:
+        assert input_ids.shape[1] == (self.num_positions if self.cls_embedding is None else self.num_positions - 1)
+        pk, f32 = self._packed.get, torch.float32
+        ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        x = ops.coca_text_embed(ids, pk(self.token_embeddings.weight, f32), pk(self.position_embeddings, f32),
+                                pk(self.cls_embedding, f32) if self.cls_embedding is not None else None)
+        return x.view(ids.shape[0], -1, x.shape[-1])
+
+
+class CoCaTextDecoder(nn.Module):
+    def __init__(self, vocab_size: int, num_positions: int, embedding_dim: int, n_layer: int, n_head: int, dim_feedforward: int,
+                 output_dim: int, pad_idx: Optional[int] = 0, embed_cls: bool = True, dropout: float = 0.0,
+                 activation: Callable[..., nn.Module] = nn.GELU, layer_norm_eps: float = 1e-5, norm_first: bool = True,
+                 final_layer_norm_eps: Optional[float] = 1e-5):
+        super().__init__()
+        self.pad_idx = pad_idx
+        self.embed_cls = embed_cls
+        self.num_positions = num_positions
+        self.embeddings = CoCaTextEmbeddings(vocab_size=vocab_size, num_positions=num_positions, embedding_dim=embedding_dim,
+                                             pad_idx=pad_idx, embed_cls=embed_cls)
+        self.transformer_decoder = TransformerDecoder(n_layer=n_layer, d_model=embedding_dim, n_head=n_head,
+                                                      dim_feedforward=dim_feedforward, dropout=dropout, activation=activation,
+                                                      layer_norm_eps=layer_norm_eps, norm_first=norm_first, use_cross_attention=False)
+        if final_layer_norm_eps is not None:
+            self.ln_final = nn.LayerNorm(normalized_shape=embedding_dim, eps=final_layer_norm_eps)
+        self.text_projection = nn.Linear(embedding_dim, output_dim, bias=False)
+        self.register_buffer("causal_mask", get_causal_attention_mask(num_positions).to(dtype=torch.bool), persistent=False)
+        self.init_parameters(embedding_dim, n_layer)
+        self._packed = PackedCache()
+
+    def init_parameters(self, embedding_dim: int, n_layer: int) -> None:
+        attn_std = embedding_dim**-0.5
+        proj_std = (2 * embedding_dim * n_layer) ** -0.5
+        fc_std = (2 * embedding_dim) ** -0.5
+        for layer in self.transformer_decoder.layer:
+            nn.init.normal_(layer.attention.q_proj.weight, std=attn_std)
+            nn.init.normal_(layer.attention.k_proj.weight, std=attn_std)
+            nn.init.normal_(layer.attention.v_proj.weight, std=attn_std)
+            nn.init.normal_(layer.attention.output_proj.weight, std=proj_std)
+            nn.init.normal_(layer.feedforward.model[0].weight, std=fc_std)
+            nn.init.normal_(layer.feedforward.model[2].weight, std=proj_std)
+        nn.init.normal_(self.text_projection.weight, std=embedding_dim**0.5)
+
+    def build_mask(self, input_ids: Tensor, padding_mask: Optional[Tensor] = None):
+        """Kernel-format mask: plain causal when there is no CLS / pad handling, else the uint8 [B, S+1, S+1] mask whose CLS
+        row hides padded tokens (reference :178-194)."""
+        if not self.embed_cls or self.pad_idx is None:
+            return ops.AttnMask(causal=True)
+        if padding_mask is None:
+            full = ops.coca_text_mask(input_ids if input_ids.is_contiguous() else input_ids.contiguous(), pad_id=self.pad_idx)
+        else:
+            pm = padding_mask if padding_mask.is_contiguous() else padding_mask.contiguous()
+            full = ops.coca_text_mask(pm)
+        return ops.AttnMask(full=full)
+
+    def forward(self, input_ids: Tensor, padding_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if self.embed_cls:
+            if input_ids.shape[1] == self.num_positions:
+                input_ids = input_ids[:, :-1]
+            if padding_mask is not None and padding_mask.shape[1] == self.num_positions:
+                padding_mask = padding_mask[:, :-1]
+        target_shape = self.num_positions - 1 if self.embed_cls else self.num_positions
+        assert input_ids.shape[1] == target_shape, f"{input_ids.shape} doesn't match ({target_shape},*)"
+        input_ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        embeddings = self.embeddings(input_ids)
+        mask = self.build_mask(input_ids, padding_mask)
+        hidden_states = self.transformer_decoder(embeddings, attention_mask=mask).last_hidden_state
+        assert hidden_states is not None, "hidden states must not be None"
+        pk, f32 = self._packed.get, torch.float32
+        B, S, d = hidden_states.shape
+        if self.embed_cls:
+            tokens = hidden_states[:, :-1]
+            # pooled = text_projection(ln_final(hidden[:, -1])): gather the B CLS rows, LN, exact-fp32 MFMA projection
+            pooled = ops.gather_rows(hidden_states.view(B * S, d), d, _last_row_index(B, S, hidden_states.device), d, f32)
+            if getattr(self, "ln_final", None) is not None:
+                pooled = ops.layernorm(pooled, pk(self.ln_final.weight, f32), pk(self.ln_final.bias, f32), self.ln_final.eps, out_dtype=f32)
+            if self.text_projection is not None:
+                pooled = ops.rows_linear_f32(pooled, d, B, pk(self.text_projection.weight, f32), None)
+        else:
+            raise ops.MmamdError("CoCaTextDecoder(embed_cls=False) is not implemented on the MI355X path")
+        return pooled, tokens
+
+
+_LAST_ROWS = {}
+
+
+def _last_row_index(B: int, S: int, device: torch.device) -> Tensor:
+    """Row numbers of every sample's last position in a [B*S, d] matrix (index bookkeeping, cached)."""
+    key = (B, S, device)
+    if key not in _LAST_ROWS:
+        _LAST_ROWS[key] = torch.arange(S - 1, B * S, S, dtype=torch.int32, device=device)
+    return _LAST_ROWS[key]

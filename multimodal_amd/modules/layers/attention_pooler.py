@@ -1,0 +1,56 @@
+"""Host-side mirror of torchmultimodal/modules/layers/attention_pooler.py:16-101 (AttentionPooler, CascadedAttentionPooler).
+
+The learned queries are the same for every sample: LayerNorm and the q projection run ONCE on [n_queries, d] and the attention
+kernel reads them with batch stride 0 (the reference materialises `query.repeat(batch, 1, 1)` and projects B copies)."""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+from .multi_head_attention import MultiHeadAttentionWithCache
+
+
+class AttentionPooler(nn.Module):
+    def __init__(self, input_embed_dim: int, output_embed_dim: int, n_head: int, n_queries: int = 256, layer_norm_eps: float = 1e-5):
+        super().__init__()
+        self.query = nn.Parameter(torch.randn(n_queries, output_embed_dim))
+        self.attn = MultiHeadAttentionWithCache(dim_q=output_embed_dim, dim_kv=input_embed_dim, num_heads=n_head)
+        self.ln_q = nn.LayerNorm(output_embed_dim, layer_norm_eps)
+        self.ln_k = nn.LayerNorm(input_embed_dim, layer_norm_eps)
+        self.ln_post = nn.LayerNorm(output_embed_dim, layer_norm_eps)
+        self._packed = PackedCache()
+
+    def forward(self, x: Tensor) -> Tensor:
+        if x.dim() != 3 or x.dtype != torch.float32:
+            raise ops.MmamdError("AttentionPooler on the MI355X path takes fp32 [batch, seq_len, input_embed_dim] tensors")
+        B, S, din = x.shape
+        pk, bf, f32 = self._packed.get, torch.bfloat16, torch.float32
+        xc = (x if x.is_contiguous() else x.contiguous()).view(B * S, din)
+        k = ops.layernorm(xc, pk(self.ln_k.weight, f32), pk(self.ln_k.bias, f32), self.ln_k.eps, out_dtype=bf)
+        q = ops.layernorm(pk(self.query, f32), pk(self.ln_q.weight, f32), pk(self.ln_q.bias, f32), self.ln_q.eps, out_dtype=bf)
+        nq, dout = self.query.shape
+        out = self.attn.run(q, k, B, nq, S, ops.AttnMask(), None, shared_q=True)
+        out = ops.layernorm(out, pk(self.ln_post.weight, f32), pk(self.ln_post.bias, f32), self.ln_post.eps, out_dtype=f32)
+        return out.view(B, nq, dout)
+
+    def _repeat(self, query: Tensor, n: int) -> Tensor:
+        return query.unsqueeze(0).repeat(n, 1, 1)
+
+
+class CascadedAttentionPooler(nn.Module):
+    """Cascaded pooling: each pooler runs on the previous pooler's output (CoCa: captioning pooler, then contrastive pooler)."""
+
+    def __init__(self, poolers: List[AttentionPooler]):
+        super().__init__()
+        self.poolers = nn.ModuleList(poolers)
+
+    def forward(self, x: Tensor) -> List[Tensor]:
+        pooler_outs = []
+        for pooler in self.poolers:
+            x = pooler(x)
+            pooler_outs.append(x)
+        return pooler_outs

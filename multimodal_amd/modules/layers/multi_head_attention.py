@@ -1,0 +1,148 @@
+"""Host-side mirror of torchmultimodal/modules/layers/multi_head_attention.py:19-180 (MultiHeadSelfAttention,
+MultiHeadAttentionWithCache, MHAWithCacheOutput) — the attention blocks of CoCa's ViT, decoders and attention pooler.
+
+Same constructors and parameter names (`input_proj` / `output_proj`; `q_proj`, `k_proj`, `v_proj`, `output_proj`).  Forward on
+the MI355X: one GEMM for the stacked projections (q|k|v for self-attention, k|v of the encoder states for cross-attention),
+the general MFMA attention kernel (csrc/attention.hip: attention_x_kernel — Sq != Sk, 64- or 96-wide heads, causal / padding /
+full boolean masks, batch-shared queries), one GEMM for the output projection with the residual add in its epilogue.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional, Tuple, Union
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+from ...ops import AttnMask
+
+
+class MHAWithCacheOutput(NamedTuple):
+    attn_output: Tensor
+    past_key_value: Tuple[Tensor, Tensor]
+
+
+def to_attn_mask(attn_mask: Optional[Tensor], is_causal: bool, B: int, Sq: int, Sk: int) -> AttnMask:
+    """Reference-style masks -> kernel masks.  Boolean masks (True = take part) of shape [Sq,Sk], [B,Sq,Sk], [B,1,Sq,Sk] or
+    [1,1,Sq,Sk] become a uint8 full mask; additive float masks and per-head masks are not implemented."""
+    if isinstance(attn_mask, AttnMask):
+        return attn_mask
+    if attn_mask is None:
+        return AttnMask(causal=is_causal)
+    if is_causal:
+        raise ops.MmamdError("attn_mask must be None when is_causal=True")
+    m = attn_mask
+    if m.dtype not in (torch.bool, torch.uint8):
+        raise ops.MmamdError(f"attention masks on the MI355X path are boolean (True = attend); got {m.dtype} (additive float "
+                             "masks are not implemented)")
+    if m.dim() == 4:
+        if m.shape[1] != 1:
+            raise ops.MmamdError("per-head attention masks are not implemented on the MI355X path")
+        m = m[:, 0]
+    if m.dim() == 2:
+        m = m[None]
+    if m.dim() != 3 or tuple(m.shape[-2:]) != (Sq, Sk) or m.shape[0] not in (1, B):
+        raise ops.MmamdError(f"attention mask of shape {tuple(attn_mask.shape)} does not broadcast to [{B}, 1, {Sq}, {Sk}]")
+    m = m if m.is_contiguous() else m.contiguous()
+    return AttnMask(full=ops.key_mask(m))
+
+
+def _check_heads(embed_dim: int, num_heads: int) -> int:
+    hd = embed_dim // num_heads
+    if hd * num_heads != embed_dim or hd not in (64, 96):
+        raise ops.MmamdError(f"the MI355X attention kernels are built for 64- and 96-wide heads, got {embed_dim}/{num_heads}")
+    return hd
+
+
+class MultiHeadSelfAttention(nn.Module):
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0):
+        super().__init__()
+        self.input_proj = nn.Linear(embed_dim, 3 * embed_dim)
+        self.output_proj = nn.Linear(embed_dim, embed_dim)
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self._packed = PackedCache()
+
+    def run(self, hn: Tensor, B: int, S: int, mask: AttnMask, residual: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+        """hn: bf16 [B*S, d] -> fp32 [B*S, d] = output_proj(attention) (+ residual)."""
+        if self.training and self.dropout > 0:
+            raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
+        d = self.output_proj.in_features
+        hd = _check_heads(d, self.num_heads)
+        pk, bf, f32 = self._packed.get, torch.bfloat16, torch.float32
+        qkv = ops.gemm_bf16(hn, pk(self.input_proj.weight, bf), pk(self.input_proj.bias, f32))
+        if mask.empty and hd == 64:
+            att = ops.attention_fwd(qkv, B, S, self.num_heads, causal=False)
+        elif mask.causal and mask.key_mask is None and mask.full is None and hd == 64:
+            att = ops.attention_fwd(qkv, B, S, self.num_heads, causal=True)
+        else:
+            att, _ = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, self.num_heads, hd, mask)
+        return ops.gemm_bf16(att, pk(self.output_proj.weight, bf), pk(self.output_proj.bias, f32), residual=residual,
+                             out_dtype=f32, out=out)
+
+    def forward(self, query: Tensor, attn_mask: Optional[Tensor] = None, is_causal: bool = False) -> Tensor:
+        if query.dim() != 3:
+            raise ops.MmamdError("MultiHeadSelfAttention takes bsz x seq_len x embed_dim inputs")
+        B, S, d = query.shape
+        qc = query if query.is_contiguous() else query.contiguous()
+        mask = to_attn_mask(attn_mask, is_causal, B, S, S)
+        return self.run(ops.convert(qc.view(B * S, d), torch.bfloat16), B, S, mask, None).view(B, S, d)
+
+
+class MultiHeadAttentionWithCache(nn.Module):
+    def __init__(self, dim_q: int, dim_kv: int, num_heads: int, dropout: float = 0.0, add_bias: bool = True) -> None:
+        super().__init__()
+        self.num_heads = num_heads
+        self.q_proj = nn.Linear(dim_q, dim_q, bias=add_bias)
+        self.k_proj = nn.Linear(dim_kv, dim_q, bias=add_bias)
+        self.v_proj = nn.Linear(dim_kv, dim_q, bias=add_bias)
+        self.output_proj = nn.Linear(dim_q, dim_q)
+        self.dropout = dropout
+        self._packed = PackedCache()
+
+    def run(self, q_in: Tensor, kv_in: Optional[Tensor], B: int, Sq: int, Sk: int, mask: AttnMask, residual: Optional[Tensor],
+            shared_q: bool = False, out: Optional[Tensor] = None) -> Tensor:
+        """q_in: bf16 [B*Sq, dq] (or [Sq, dq] when shared_q); kv_in: bf16 [B*Sk, dkv], None = self-attention over q_in.
+        Returns fp32 [B*Sq, dq] = output_proj(attention) (+ residual)."""
+        if self.training and self.dropout > 0:
+            raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
+        dq = self.q_proj.out_features
+        hd = _check_heads(dq, self.num_heads)
+        pc, bf, f32 = self._packed, torch.bfloat16, torch.float32
+        has_b = self.q_proj.bias is not None
+        if kv_in is None:  # q, k, v from the same rows: one [3dq, dq] GEMM
+            w = pc.get_cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], bf)
+            b = pc.get_cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], f32) if has_b else None
+            qkv = ops.gemm_bf16(q_in, w, b)
+            q, k, v = qkv[:, :dq], qkv[:, dq:2 * dq], qkv[:, 2 * dq:]
+        else:
+            q = ops.gemm_bf16(q_in, pc.get(self.q_proj.weight, bf), pc.get(self.q_proj.bias, f32) if has_b else None)
+            wkv = pc.get_cat([self.k_proj.weight, self.v_proj.weight], bf)
+            bkv = pc.get_cat([self.k_proj.bias, self.v_proj.bias], f32) if has_b else None
+            kv = ops.gemm_bf16(kv_in, wkv, bkv)
+            k, v = kv[:, :dq], kv[:, dq:]
+        att, _ = ops.attention_x_fwd(q, k, v, B, Sq, Sk, self.num_heads, hd, mask, shared_q=shared_q)
+        return ops.gemm_bf16(att, pc.get(self.output_proj.weight, bf), pc.get(self.output_proj.bias, f32), residual=residual,
+                             out_dtype=f32, out=out)
+
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor] = None,
+                past_key_value: Optional[Tuple[Tensor, Tensor]] = None, is_causal: bool = False, use_cache: bool = False
+                ) -> Union[Tensor, MHAWithCacheOutput]:
+        if past_key_value is not None or use_cache:
+            raise ops.MmamdError("key/value caching (incremental decoding) is not implemented on the MI355X path")
+        if key is not value:
+            raise ops.MmamdError("key and value must be the same tensor on the MI355X path (self- or cross-attention)")
+        if key.size(0) != query.size(0):
+            raise ValueError("key and value should have the same bsz as query.")
+        B, Sq, dq = query.shape
+        Sk = key.shape[1]
+        bf = torch.bfloat16
+        qc = query if query.is_contiguous() else query.contiguous()
+        q_in = ops.convert(qc.view(B * Sq, dq), bf)
+        kv_in = None
+        if key is not query:
+            kc = key if key.is_contiguous() else key.contiguous()
+            kv_in = ops.convert(kc.view(B * Sk, kc.shape[-1]), bf)
+        mask = to_attn_mask(attn_mask, is_causal, B, Sq, Sk)
+        return self.run(q_in, kv_in, B, Sq, Sk, mask, None).view(B, Sq, dq)

@@ -11,3 +11,211 @@ class TransformerOutput(NamedTuple):
     attentions: Optional[List[Tensor]] = None
     image_labels: Optional[Tensor] = None
     current_key_values: Optional[List[Tuple[Tensor, Tensor]]] = None
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# TransformerEncoder(Layer) / TransformerDecoder(Layer) of torchmultimodal/modules/layers/transformer.py:31-657 — the blocks
+# CoCa's ViT (encoders/vision_transformer.py), text decoder and multimodal decoder are built from.  Same constructors,
+# attribute names and state_dict keys.  Per layer on the MI355X (pre-norm):
+#     LN -> [3d,d] GEMM -> attention -> output GEMM(+residual)   [-> LN -> q GEMM, [2d,dkv] GEMM -> cross-attention -> GEMM(+res)]
+#     LN -> up GEMM(+bias, GELU) -> down GEMM(+bias, +residual)
+# residual stream fp32, MFMA operands bf16.
+# ------------------------------------------------------------------------------------------------------------------------
+from typing import Callable  # noqa: E402
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+from ... import ops  # noqa: E402
+from ..._packing import PackedCache  # noqa: E402
+from .mlp import MLP  # noqa: E402
+from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask  # noqa: E402
+from .normalizations import Fp32LayerNorm  # noqa: E402
+
+
+def _forbid_training(module: nn.Module) -> None:
+    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(f"{type(module).__name__}: backward is not implemented on the MI355X path yet; call .eval() "
+                                  "and/or run under torch.no_grad()")
+
+
+def _ln(packed: PackedCache, ln: nn.LayerNorm, x: Tensor, out_dtype: torch.dtype) -> Tensor:
+    return ops.layernorm(x, packed.get(ln.weight, torch.float32), packed.get(ln.bias, torch.float32), ln.eps, out_dtype=out_dtype)
+
+
+def _f32_rows(t: Tensor, what: str) -> Tensor:
+    if t.dim() != 3 or t.dtype != torch.float32:
+        raise ops.MmamdError(f"{what} on the MI355X path takes fp32 [bsz, seq_len, d_model] tensors")
+    return (t if t.is_contiguous() else t.contiguous()).view(-1, t.shape[-1])
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model: int, n_head: int, dim_feedforward: int, dropout: float = 0.0,
+                 activation: Callable[..., nn.Module] = nn.ReLU, layer_norm_eps: float = 1e-12, norm_first: bool = False,
+                 drop_path_rate: Optional[float] = None) -> None:
+        super().__init__()
+        if drop_path_rate is not None:
+            raise ops.MmamdError("stochastic depth (drop_path_rate) is a training-time feature not implemented on the MI355X path")
+        self.attention = MultiHeadSelfAttention(embed_dim=d_model, num_heads=n_head)
+        self.attention_dropout = nn.Dropout(dropout)
+        self.feedforward_dropout = nn.Dropout(dropout)
+        self.feedforward = MLP(d_model, d_model, dim_feedforward, dropout=dropout, activation=activation)
+        self.attention_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
+        self.feedforward_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm_first = norm_first
+        self._packed = PackedCache()
+
+    def run(self, x: Tensor, B: int, S: int, mask: ops.AttnMask) -> Tensor:
+        """x: fp32 [B*S, d] (left untouched) -> new fp32 [B*S, d]."""
+        if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
+            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
+        bf, f32, pc = torch.bfloat16, torch.float32, self._packed
+        if self.norm_first:  # reference :96-116
+            x1 = self.attention.run(_ln(pc, self.attention_layernorm, x, bf), B, S, mask, residual=x)
+            return self.feedforward.run(_ln(pc, self.feedforward_layernorm, x1, bf), residual=x1, out=x1)
+        a = self.attention.run(ops.convert(x, bf), B, S, mask, residual=x)  # post-norm, :118-132
+        x1 = _ln(pc, self.attention_layernorm, a, f32)
+        ff = self.feedforward.run(ops.convert(x1, bf), residual=x1, out=a)
+        return _ln(pc, self.feedforward_layernorm, ff, f32)
+
+    def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
+        _forbid_training(self)
+        B, S, d = hidden_states.shape
+        y = self.run(_f32_rows(hidden_states, "TransformerEncoderLayer"), B, S, to_attn_mask(attention_mask, False, B, S, S))
+        return y.view(B, S, d)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, n_layer: int, d_model: int, n_head: int, dim_feedforward: int, dropout: float = 0.0,
+                 activation: Callable[..., nn.Module] = nn.ReLU, layer_norm_eps: float = 1e-12, norm_first: bool = False,
+                 final_layer_norm_eps: Optional[float] = None, drop_path_rate: Optional[float] = None):
+        super().__init__()
+        if drop_path_rate is not None:
+            raise ops.MmamdError("stochastic depth (drop_path_rate) is a training-time feature not implemented on the MI355X path")
+        self.layer = nn.ModuleList([
+            TransformerEncoderLayer(d_model, n_head, dim_feedforward, dropout, activation, layer_norm_eps, norm_first, None)
+            for _ in range(n_layer)
+        ])
+        self.final_layer_norm = None
+        if final_layer_norm_eps:
+            self.final_layer_norm = Fp32LayerNorm(d_model, eps=final_layer_norm_eps)
+
+    def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, return_hidden_states: bool = False
+                ) -> TransformerOutput:
+        _forbid_training(self)
+        B, S, d = hidden_states.shape
+        x = _f32_rows(hidden_states, "TransformerEncoder")
+        mask = to_attn_mask(attention_mask, False, B, S, S)
+        all_hidden_states = []
+        for layer_module in self.layer:
+            if return_hidden_states:
+                all_hidden_states.append(x.view(B, S, d))
+            x = layer_module.run(x, B, S, mask)
+        x = x.view(B, S, d)
+        if return_hidden_states:
+            all_hidden_states.append(x)
+        if self.final_layer_norm is not None:
+            x = self.final_layer_norm(x)
+        return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states if return_hidden_states else None)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model: int, n_head: int, dim_feedforward: int, dropout: float = 0.0,
+                 activation: Callable[..., nn.Module] = nn.ReLU, layer_norm_eps: float = 1e-12, norm_first: bool = False,
+                 use_cross_attention: bool = True, dim_kv: Optional[int] = None) -> None:
+        super().__init__()
+        dim_kv = dim_kv if dim_kv is not None else d_model
+        self.attention = MultiHeadAttentionWithCache(dim_q=d_model, dim_kv=d_model, num_heads=n_head, dropout=dropout)
+        self.attention_dropout = nn.Dropout(dropout)
+        self.cross_attention: Optional[MultiHeadAttentionWithCache] = None
+        self.use_cross_attention = use_cross_attention
+        if self.use_cross_attention:
+            self.cross_attention = MultiHeadAttentionWithCache(dim_q=d_model, dim_kv=dim_kv, num_heads=n_head, dropout=dropout)
+            self.cross_attention_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
+            self.cross_attention_dropout = nn.Dropout(dropout)
+        self.feedforward = MLP(d_model, d_model, dim_feedforward, dropout=dropout, activation=activation)
+        self.feedforward_dropout = nn.Dropout(dropout)
+        self.attention_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
+        self.feedforward_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm_first = norm_first
+        self._packed = PackedCache()
+
+    def run(self, x: Tensor, B: int, S: int, mask: ops.AttnMask, enc: Optional[Tensor] = None, Sk: int = 0,
+            cross_mask: Optional[ops.AttnMask] = None) -> Tensor:
+        """x: fp32 [B*S, d]; enc: bf16 [B*Sk, dim_kv] encoder states (already converted once per decoder) or None."""
+        if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
+            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
+        bf, f32, pc = torch.bfloat16, torch.float32, self._packed
+        cross_mask = cross_mask or ops.AttnMask()
+        if self.norm_first:  # reference :398-433
+            a = self.attention.run(_ln(pc, self.attention_layernorm, x, bf), None, B, S, S, mask, residual=x)
+            if self.use_cross_attention and enc is not None:
+                a = self.cross_attention.run(_ln(pc, self.cross_attention_layernorm, a, bf), enc, B, S, Sk, cross_mask, residual=a, out=a)
+            return self.feedforward.run(_ln(pc, self.feedforward_layernorm, a, bf), residual=a, out=a)
+        # post-norm, :435-472
+        a = self.attention.run(ops.convert(x, bf), None, B, S, S, mask, residual=x)
+        a = _ln(pc, self.attention_layernorm, a, f32)
+        if self.use_cross_attention:
+            if enc is None:
+                raise ValueError("encoder_hidden_states must be provided for cross attention")
+            c = self.cross_attention.run(ops.convert(a, bf), enc, B, S, Sk, cross_mask, residual=a)
+            a = _ln(pc, self.cross_attention_layernorm, c, f32)
+        ff = self.feedforward.run(ops.convert(a, bf), residual=a)
+        return _ln(pc, self.feedforward_layernorm, ff, f32)
+
+    def forward(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
+                cross_attention_mask: Optional[Tensor] = None, past_key_value: Optional[Tuple[Tensor, Tensor]] = None,
+                use_cache: bool = False) -> Tuple[Tensor, Optional[Tuple[Tensor, Tensor]]]:
+        if past_key_value is not None or use_cache:
+            raise ops.MmamdError("key/value caching (incremental decoding) is not implemented on the MI355X path")
+        _forbid_training(self)
+        B, S, d = hidden_states.shape
+        enc, Sk = None, 0
+        if encoder_hidden_states is not None:
+            Sk = encoder_hidden_states.shape[1]
+            enc = ops.convert(_f32_rows(encoder_hidden_states, "TransformerDecoderLayer"), torch.bfloat16)
+        y = self.run(_f32_rows(hidden_states, "TransformerDecoderLayer"), B, S, to_attn_mask(attention_mask, False, B, S, S), enc, Sk,
+                     to_attn_mask(cross_attention_mask, False, B, S, Sk) if enc is not None else None)
+        return y.view(B, S, d), None
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, n_layer: int, d_model: int, n_head: int, dim_feedforward: int, dropout: float = 0.0,
+                 activation: Callable[..., nn.Module] = nn.ReLU, layer_norm_eps: float = 1e-12, norm_first: bool = False,
+                 use_cross_attention: bool = True, dim_kv: Optional[int] = None, final_layer_norm_eps: Optional[float] = None,
+                 cross_attention_interval: int = 1):
+        super().__init__()
+        self.layer = nn.ModuleList([
+            TransformerDecoderLayer(d_model, n_head, dim_feedforward, dropout, activation, layer_norm_eps, norm_first,
+                                    use_cross_attention and (i % cross_attention_interval == 0), dim_kv)
+            for i in range(n_layer)
+        ])
+        self.final_layer_norm = None
+        if final_layer_norm_eps:
+            self.final_layer_norm = Fp32LayerNorm(d_model, eps=final_layer_norm_eps)
+
+    def forward(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
+                cross_attention_mask: Optional[Tensor] = None, past_key_values: Optional[List[Tuple[Tensor, Tensor]]] = None,
+                use_cache: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
+        if past_key_values is not None or use_cache:
+            raise ops.MmamdError("key/value caching (incremental decoding) is not implemented on the MI355X path")
+        _forbid_training(self)
+        B, S, d = hidden_states.shape
+        x = _f32_rows(hidden_states, "TransformerDecoder")
+        mask = to_attn_mask(attention_mask, False, B, S, S)
+        enc, Sk = None, 0
+        if encoder_hidden_states is not None:
+            Sk = encoder_hidden_states.shape[1]
+            enc = ops.convert(_f32_rows(encoder_hidden_states, "TransformerDecoder"), torch.bfloat16)  # once for all layers
+        all_hidden_states = []
+        for layer_module in self.layer:
+            if return_hidden_states:
+                all_hidden_states.append(x.view(B, S, d))
+            # (the reference does not forward cross_attention_mask to its layers either: transformer.py:630-636)
+            x = layer_module.run(x, B, S, mask, enc, Sk)
+        x = x.view(B, S, d)
+        if return_hidden_states:
+            all_hidden_states.append(x)
+        if self.final_layer_norm is not None:
+            x = self.final_layer_norm(x)
+        return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, current_key_values=[])

@@ -18,7 +18,8 @@ __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
-    "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy",
+    "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
+    "AttnMask",
 ]
 
 
@@ -127,6 +128,92 @@ def attention_probs_fwd(qkv: torch.Tensor, B: int, S: int, H: int, key_mask: Opt
     return out, probs
 
 
+class AttnMask:
+    """Mask description the attention kernels take: causal flag, key-padding mask uint8 [B,Sk], full mask uint8
+    [B or 1, Sq, Sk] (0 = masked everywhere)."""
+
+    __slots__ = ("causal", "key_mask", "full")
+
+    def __init__(self, causal: bool = False, key_mask: Optional[torch.Tensor] = None, full: Optional[torch.Tensor] = None):
+        self.causal, self.key_mask, self.full = bool(causal), key_mask, full
+
+    @property
+    def empty(self) -> bool:
+        return not self.causal and self.key_mask is None and self.full is None
+
+
+def _mat_view(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+        raise MmamdError(f"{name} must be a bf16 HIP matrix (view) with unit inner stride")
+    return t
+
+
+def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Sk: int, H: int, head_dim: int,
+                    mask: Optional[AttnMask] = None, shared_q: bool = False, want_probs: bool = False,
+                    out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """General attention (mmamd_attention_x_fwd).  q: bf16 [B*Sq, >=H*hd] (or [Sq, ...] when shared_q: the same queries for
+    every sample), k / v: bf16 [B*Sk, >=H*hd]; all may be column-slice views of wider matrices (stride(0) is the row
+    pitch).  Returns (bf16 [B*Sq, H*hd], probabilities fp32 [B,H,Sq,Sk] or None)."""
+    _mat_view(q, "q"); _mat_view(k, "k"); _mat_view(v, "v")
+    D = H * head_dim
+    if q.shape[1] != D or k.shape[1] != D or v.shape[1] != D:
+        raise MmamdError(f"attention_x: q/k/v must have {D} columns, got {q.shape[1]}/{k.shape[1]}/{v.shape[1]}")
+    if q.shape[0] != (Sq if shared_q else B * Sq) or k.shape[0] != B * Sk or v.shape[0] != B * Sk:
+        raise MmamdError("attention_x: row counts do not match B, Sq, Sk")
+    mask = mask or AttnMask()
+    km, fm, fm_bs = mask.key_mask, mask.full, 0
+    if km is not None:
+        _chk(km, "key_mask", torch.uint8)
+        if km.shape != (B, Sk):
+            raise MmamdError(f"attention_x: key_mask shape {tuple(km.shape)} != {(B, Sk)}")
+    if fm is not None:
+        _chk(fm, "full mask", torch.uint8)
+        if fm.shape[-2:] != (Sq, Sk) or fm.numel() not in (Sq * Sk, B * Sq * Sk):
+            raise MmamdError(f"attention_x: full mask shape {tuple(fm.shape)} does not match [{B} or 1, {Sq}, {Sk}]")
+        fm_bs = Sq * Sk if fm.numel() == B * Sq * Sk and B > 1 else 0
+    if out is None:
+        out = torch.empty((B * Sq, D), dtype=torch.bfloat16, device=q.device)
+    probs = torch.empty((B, H, Sq, Sk), dtype=torch.float32, device=q.device) if want_probs else None
+    check(_lib.lib().mmamd_attention_x_fwd(q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(),
+                                           k.stride(0), v.stride(0), Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal),
+                                           out.data_ptr(), out.stride(0), _ptr(probs), F32, B, Sq, Sk, H, head_dim,
+                                           1.0 / math.sqrt(float(head_dim)), _stream()), "mmamd_attention_x_fwd")
+    return out, probs
+
+
+def coca_text_embed(ids: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, cls: Optional[torch.Tensor]) -> torch.Tensor:
+    """token[ids] + pos, CLS row appended (CoCaTextEmbeddings) -> fp32 [B*(S+1 or S), d]."""
+    _chk(ids, "input_ids", torch.int64); _chk(table, "token_embeddings", torch.float32); _chk(pos, "position_embeddings", torch.float32)
+    if cls is not None:
+        _chk(cls, "cls_embedding", torch.float32)
+    B, S = ids.shape
+    vocab, d = table.shape
+    T = S + (1 if cls is not None else 0)
+    if pos.shape[0] < T:
+        raise MmamdError("coca_text_embed: position table shorter than the sequence")
+    x = torch.empty((B * T, d), dtype=torch.float32, device=ids.device)
+    check(_lib.lib().mmamd_coca_text_embed(ids.data_ptr(), table.data_ptr(), pos.data_ptr(), _ptr(cls), x.data_ptr(), B, S, d, vocab,
+                                           _stream()), "mmamd_coca_text_embed")
+    return x
+
+
+def coca_text_mask(src: torch.Tensor, pad_id: Optional[int] = None) -> torch.Tensor:
+    """CoCaTextDecoder.build_mask as uint8 [B, S+1, S+1]; src = token ids (with pad_id) or a [B,S] padding mask."""
+    _chk(src, "mask source")
+    if pad_id is not None:
+        if src.dtype != torch.int64:
+            raise MmamdError("coca_text_mask: token ids must be int64")
+        kind = 0
+    else:
+        kind = {torch.float32: 1, torch.int64: 2, torch.uint8: 3, torch.bool: 3}.get(src.dtype)
+        if kind is None:
+            raise MmamdError(f"coca_text_mask: unsupported mask dtype {src.dtype}")
+    B, S = src.shape
+    out = torch.empty((B, S + 1, S + 1), dtype=torch.uint8, device=src.device)
+    check(_lib.lib().mmamd_coca_text_mask(src.data_ptr(), kind, int(pad_id or 0), out.data_ptr(), B, S, _stream()), "mmamd_coca_text_mask")
+    return out
+
+
 def key_mask(src: torch.Tensor, pad_id: Optional[int] = None) -> torch.Tensor:
     """uint8 keep-mask (same shape as src): ids != pad_id when pad_id is given, else src != 0."""
     _chk(src, "mask source")
@@ -167,11 +254,13 @@ def bert_embed_ln(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, typ:
     return x
 
 
-def flava_image_embed(patch_emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, B: int, G2: int,
+def flava_image_embed(patch_emb: torch.Tensor, cls: Optional[torch.Tensor], pos: torch.Tensor, B: int, G2: int,
                       patches_mask: Optional[torch.Tensor] = None,
                       mask_token: Optional[torch.Tensor] = None) -> torch.Tensor:
     """patch embeddings fp32 [B*G2, d] (+ optional mask-token blend), CLS, + positions -> fp32 [B*(G2+1), d]."""
-    _chk(patch_emb, "patch_emb", torch.float32); _chk(cls, "cls_token", torch.float32); _chk(pos, "pos", torch.float32)
+    _chk(patch_emb, "patch_emb", torch.float32); _chk(pos, "pos", torch.float32)
+    if cls is not None:
+        _chk(cls, "cls_token", torch.float32)
     if patches_mask is not None:
         _chk(patches_mask, "image_patches_mask", torch.int64)
         if patches_mask.numel() != B * G2:
@@ -179,8 +268,8 @@ def flava_image_embed(patch_emb: torch.Tensor, cls: torch.Tensor, pos: torch.Ten
     if mask_token is not None:
         _chk(mask_token, "mask_token", torch.float32)
     d = patch_emb.shape[-1]
-    x = torch.empty((B * (G2 + 1), d), dtype=torch.float32, device=patch_emb.device)
-    check(_lib.lib().mmamd_flava_image_embed(patch_emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), _ptr(patches_mask),
+    x = torch.empty((B * (G2 + (1 if cls is not None else 0)), d), dtype=torch.float32, device=patch_emb.device)
+    check(_lib.lib().mmamd_flava_image_embed(patch_emb.data_ptr(), _ptr(cls), pos.data_ptr(), _ptr(patches_mask),
                                              _ptr(mask_token), x.data_ptr(), B, G2, d, _stream()),
           "mmamd_flava_image_embed")
     return x

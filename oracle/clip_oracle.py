@@ -492,3 +492,178 @@ def flava_pretraining_loss(sd, image_masked_sequence=None, text_masked_sequence=
         out["global_contrastive"] = flava_global_contrastive_loss(
             projected_image_embeddings, projected_text_embeddings, float(sd["contrastive_loss.logit_scale"]), pos_mask, dtype=dtype)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# CoCa: models/coca/*.py, modules/encoders/vision_transformer.py, modules/layers/{transformer,
+# multi_head_attention,attention_pooler,patch_embedding}.py
+# ------------------------------------------------------------------------------------------------------------------------
+def sdpa(q: Array, k: Array, v: Array, attend: Optional[Array] = None, causal: bool = False) -> Array:
+    """F.scaled_dot_product_attention on [B,H,S,dh] arrays; `attend` is a boolean mask broadcastable to [B,H,Sq,Sk]
+    (True = take part), `causal` the top-left aligned lower-triangular mask."""
+    s = (q @ k.transpose(0, 1, 3, 2)) / np.sqrt(q.dtype.type(q.shape[-1]))
+    Sq, Sk = s.shape[-2:]
+    if causal:
+        s = np.where(np.tril(np.ones((Sq, Sk), dtype=bool)), s, -np.inf)
+    if attend is not None:
+        s = np.where(np.asarray(attend).astype(bool), s, -np.inf)
+    return softmax_lastdim(s.astype(q.dtype)) @ v
+
+
+def _heads(x: Array, h: int) -> Array:
+    B, S, d = x.shape
+    return x.reshape(B, S, h, d // h).transpose(0, 2, 1, 3)
+
+
+def _merge(x: Array) -> Array:
+    B, h, S, dh = x.shape
+    return x.transpose(0, 2, 1, 3).reshape(B, S, h * dh)
+
+
+def mh_self_attention(x: Array, sd, prefix: str, heads: int, attend=None, causal=False) -> Array:
+    """MultiHeadSelfAttention.forward (modules/layers/multi_head_attention.py:38-76): packed input_proj, SDPA, output_proj."""
+    qkv = x @ sd[prefix + "input_proj.weight"].T + sd[prefix + "input_proj.bias"]
+    q, k, v = np.split(qkv, 3, axis=-1)
+    a = _merge(sdpa(_heads(q, heads), _heads(k, heads), _heads(v, heads), attend, causal))
+    return a @ sd[prefix + "output_proj.weight"].T + sd[prefix + "output_proj.bias"]
+
+
+def mha_with_cache(q_in: Array, kv_in: Array, sd, prefix: str, heads: int, attend=None, causal=False) -> Array:
+    """MultiHeadAttentionWithCache.forward without cache (…:115-180): separate q/k/v projections (k, v from kv_in)."""
+    lin = lambda name, x: x @ sd[prefix + name + ".weight"].T + (sd[prefix + name + ".bias"] if prefix + name + ".bias" in sd else 0)
+    q, k, v = lin("q_proj", q_in), lin("k_proj", kv_in), lin("v_proj", kv_in)
+    a = _merge(sdpa(_heads(q, heads), _heads(k, heads), _heads(v, heads), attend, causal))
+    return lin("output_proj", a)
+
+
+def _ffn(x: Array, sd, prefix: str) -> Array:
+    h = gelu_erf(x @ sd[prefix + "model.0.weight"].T + sd[prefix + "model.0.bias"])
+    return h @ sd[prefix + "model.2.weight"].T + sd[prefix + "model.2.bias"]
+
+
+def layers_encoder_layer(x: Array, sd, prefix: str, heads: int, eps: float, norm_first: bool = True, attend=None) -> Array:
+    """layers.transformer.TransformerEncoderLayer (modules/layers/transformer.py:96-156), GELU feed-forward."""
+    ln = lambda name, t: layer_norm(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], eps)
+    if norm_first:
+        a = mh_self_attention(ln("attention_layernorm", x), sd, prefix + "attention.", heads, attend) + x
+        return a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.")
+    a = ln("attention_layernorm", mh_self_attention(x, sd, prefix + "attention.", heads, attend) + x)
+    return ln("feedforward_layernorm", a + _ffn(a, sd, prefix + "feedforward."))
+
+
+def layers_encoder(x: Array, sd, prefix: str, heads: int, eps: float, norm_first: bool = True, final_eps: Optional[float] = None):
+    """layers.transformer.TransformerEncoder.forward (:222-262) with return_hidden_states=True."""
+    hidden, n = [], 0
+    while f"{prefix}layer.{n}.attention.input_proj.weight" in sd:
+        hidden.append(x)
+        x = layers_encoder_layer(x, sd, f"{prefix}layer.{n}.", heads, eps, norm_first)
+        n += 1
+    hidden.append(x)
+    if final_eps:
+        x = layer_norm(x, sd[prefix + "final_layer_norm.weight"], sd[prefix + "final_layer_norm.bias"], final_eps)
+    return x, hidden
+
+
+def layers_decoder_layer(x: Array, enc: Optional[Array], sd, prefix: str, heads: int, eps: float, attend=None) -> Array:
+    """TransformerDecoderLayer._forward_prenorm (:398-433): self-attention, optional cross-attention, feed-forward."""
+    ln = lambda name, t: layer_norm(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], eps)
+    h = ln("attention_layernorm", x)
+    a = mha_with_cache(h, h, sd, prefix + "attention.", heads, attend) + x
+    if enc is not None and prefix + "cross_attention.q_proj.weight" in sd:
+        a = mha_with_cache(ln("cross_attention_layernorm", a), enc, sd, prefix + "cross_attention.", heads) + a
+    return a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.")
+
+
+def layers_decoder(x: Array, enc: Optional[Array], sd, prefix: str, heads: int, eps: float, attend=None, final_eps=None) -> Array:
+    n = 0
+    while f"{prefix}layer.{n}.attention.q_proj.weight" in sd:
+        x = layers_decoder_layer(x, enc, sd, f"{prefix}layer.{n}.", heads, eps, attend)
+        n += 1
+    if final_eps:
+        x = layer_norm(x, sd[prefix + "final_layer_norm.weight"], sd[prefix + "final_layer_norm.bias"], final_eps)
+    return x
+
+
+def attention_pooler(x: Array, sd, prefix: str, heads: int, eps: float = 1e-5) -> Array:
+    """AttentionPooler.forward (modules/layers/attention_pooler.py:49-70)."""
+    k = layer_norm(x, sd[prefix + "ln_k.weight"], sd[prefix + "ln_k.bias"], eps)
+    q = layer_norm(sd[prefix + "query"], sd[prefix + "ln_q.weight"], sd[prefix + "ln_q.bias"], eps)
+    q = np.broadcast_to(q[None], (x.shape[0], *q.shape)).astype(x.dtype)
+    out = mha_with_cache(q, k, sd, prefix + "attn.", heads)
+    return layer_norm(out, sd[prefix + "ln_post.weight"], sd[prefix + "ln_post.bias"], eps)
+
+
+def layers_patch_embeddings(pixel_values: Array, sd, prefix: str) -> Array:
+    """layers.patch_embedding.PatchEmbeddings.forward (modules/layers/patch_embedding.py:98-152), eval mode, no masking."""
+    emb = patch_embed(pixel_values, sd[prefix + "conv_projection.weight"]) + sd[prefix + "conv_projection.bias"]
+    pos = sd[prefix + "position_embeddings"]
+    if prefix + "cls_token" in sd:
+        emb = emb + pos[:, 1:, :]
+        cls = np.broadcast_to(sd[prefix + "cls_token"] + pos[:, :1, :], (emb.shape[0], 1, emb.shape[2]))
+        return np.concatenate([cls, emb], axis=1)
+    return emb + pos
+
+
+def coca_text_mask(input_ids: Array, pad_idx: int = 0, padding_mask: Optional[Array] = None) -> Array:
+    """CoCaTextDecoder.build_mask (models/coca/text_decoder.py:178-194) -> bool [B,1,S+1,S+1]."""
+    ids = np.asarray(input_ids)
+    B, S = ids.shape
+    pm = (ids != pad_idx) if padding_mask is None else np.asarray(padding_mask).astype(bool)
+    full = np.ones((B, S + 1, S + 1), dtype=bool)
+    full[:, S, 1:] = pm  # F.pad(mask[:, None], (1, 0, S, 0), value=1): one new column on the LEFT, S new rows on top
+    return (full & np.tril(np.ones((S + 1, S + 1), dtype=bool)))[:, None]
+
+
+def coca_text_decoder(sd, prefix: str, input_ids: Array, heads: int, pad_idx: int = 0, eps: float = 1e-5, padding_mask=None,
+                      dtype=np.float32):
+    """CoCaTextDecoder.forward with embed_cls=True (…:196-252) -> (pooled [B,out], tokens [B,S,d])."""
+    sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
+    ids = np.asarray(input_ids)
+    npos = sd[prefix + "embeddings.position_embeddings"].shape[0]
+    if ids.shape[1] == npos:
+        ids = ids[:, :-1]
+        if padding_mask is not None and np.asarray(padding_mask).shape[1] == npos:
+            padding_mask = np.asarray(padding_mask)[:, :-1]
+    emb = sd[prefix + "embeddings.token_embeddings.weight"][ids]
+    cls = np.broadcast_to(sd[prefix + "embeddings.cls_embedding"].reshape(1, 1, -1), (ids.shape[0], 1, emb.shape[2]))
+    x = np.concatenate([emb, cls], axis=1) + sd[prefix + "embeddings.position_embeddings"]
+    mask = coca_text_mask(ids, pad_idx, padding_mask)
+    h = layers_decoder(x, None, sd, prefix + "transformer_decoder.", heads, eps, attend=mask)
+    pooled, tokens = h[:, -1], h[:, :-1]
+    pooled = layer_norm(pooled, sd[prefix + "ln_final.weight"], sd[prefix + "ln_final.bias"], eps)
+    return pooled @ sd[prefix + "text_projection.weight"].T, tokens
+
+
+def coca_model_forward(sd, images: Array, texts: Array, vision_heads: int, text_heads: int, fusion_heads: int, pooler_heads: int,
+                       cascaded: bool, pad_idx: int = 0, dtype=np.float32):
+    """CoCaModel.forward (models/coca/coca_model.py:76-135) for coca_vit(...) models."""
+    sdc = _cast(sd, dtype)
+    x = layers_patch_embeddings(np.asarray(images).astype(dtype), sdc, "vision_encoder.embeddings.")
+    img, _ = layers_encoder(x, sdc, "vision_encoder.encoder.", vision_heads, 1e-5, True, None)
+    if cascaded:
+        cap = attention_pooler(img, sdc, "vision_pooler.poolers.0.", pooler_heads)
+        con = attention_pooler(cap, sdc, "vision_pooler.poolers.1.", pooler_heads)  # [B,1,D]: the reference keeps dim 1
+    else:
+        pooled = attention_pooler(img, sdc, "vision_pooler.", pooler_heads)
+        con, cap = pooled[:, 0], pooled[:, 1:]
+    con = con @ sdc["vision_proj.weight"].T
+    con = con / np.maximum(np.linalg.norm(con, axis=-1, keepdims=True), 1e-12)
+    tp, tokens = coca_text_decoder(sdc, "text_decoder.", texts, text_heads, pad_idx, dtype=dtype)
+    tp = tp / np.maximum(np.linalg.norm(tp, axis=-1, keepdims=True), 1e-12)
+    S = tokens.shape[1]
+    mm = layers_decoder(tokens, cap, sdc, "multimodal_decoder.transformer_decoder.", fusion_heads, 1e-5,
+                        attend=np.tril(np.ones((S, S), dtype=bool)), final_eps=1e-5)
+    if "multimodal_decoder.output_projection.weight" in sdc:
+        mm = mm @ sdc["multimodal_decoder.output_projection.weight"].T
+    return {"image_pooled_output": con.astype(dtype), "text_pooled_output": tp.astype(dtype), "multimodal_embeddings": mm}
+
+
+def coca_pretraining_losses(out, texts: Array, logit_scale: float, pad_idx: int = 0, dtype=np.float32):
+    """CoCaForPretraining.forward (…:441-466): contrastive loss on the pooled outputs + captioning CE (ignore_index = pad)."""
+    texts = np.asarray(texts)
+    labels = texts[:, 1:]
+    con = contrastive_loss_with_temperature(out["image_pooled_output"], out["text_pooled_output"],
+                                            clamp_logit_scale(float(logit_scale), np.log(1.0), np.log(100.0)), dtype=dtype)["loss"]
+    V = out["multimodal_embeddings"].shape[-1]
+    cap = cross_entropy_ignore(out["multimodal_embeddings"].reshape(-1, V), labels.reshape(-1), pad_idx)
+    return {"contrastive": con, "captioning": cap}
