@@ -229,6 +229,16 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
 // 32-query tile: pass 1 = row max / row sum (QK^T only), pass 2 = recompute QK^T, emit NORMALISED probabilities
 // (fp32 or bf16, [B,H,S,S]) and accumulate P.V.  Same swapped-operand register layout as the kernel above.
 // key_mask: uint8 [B,S], 0 = masked key (NULL = no mask).  HBM-bound by the S^2 probability write.
+
+// 4 consecutive probabilities to a row that is only element-aligned (S = 197: 788-byte rows).  gfx950 global stores take any
+// dword-aligned address for dwordx4 (unaligned access mode), so the fp32 case is one 16-byte store.
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void store_probs4(float* dst, f32x4 v) { *reinterpret_cast<f32x4_a4*>(dst) = v; }
+__device__ __forceinline__ void store_probs4(bf16* dst, f32x4 v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dst[j] = (bf16)v[j];
+}
+
 template <int NKT, typename TP>
 __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
                                                               bf16* __restrict__ out, TP* __restrict__ probs, int S, int H,
@@ -239,6 +249,10 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
   bf16* Ks = reinterpret_cast<bf16*>(smem);
   bf16* Vt = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);
   float* Mk = reinterpret_cast<float*>(smem + SP * kKStride * 2 + 64 * VS * 2);  // additive key mask: 0 or -inf, [SP]
+  // per-wave 32x32 fp32 strip (row pitch 36 floats: conflict-free b128 both ways): the probability tile is transposed through
+  // it so that one wave-instruction stores 8 rows x 128 contiguous bytes instead of 32 rows x 2 x 4 bytes
+  constexpr int PSTR = 36;
+  float* Ps = reinterpret_cast<float*>(smem + SP * kKStride * 2 + 64 * VS * 2 + SP * 4) + (threadIdx.x >> 6) * (32 * PSTR);
 
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh - b * H;
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
-    TP* prow = probs + (((size_t)b * H + h) * S + (size_t)qc) * S;
+    TP* pbase = probs + ((size_t)b * H + h) * S * S;
 #pragma unroll 1
     for (int kt = 0; kt < NKT; ++kt) {
       f32x16 st;
@@ -326,16 +340,31 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
         float e[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(st[4 * g + j] - m) * inv;
-        if (probs != nullptr && q < S) {
-          const int key = kt * 32 + 8 * g + 4 * half;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (key + j < S) prow[key + j] = (TP)e[j];
-        }
+        if (probs != nullptr) *reinterpret_cast<f32x4*>(Ps + l31 * PSTR + 8 * g + 4 * half) = f32x4{e[0], e[1], e[2], e[3]};
         bf16x2 p0, p1;
         p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
         pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
         pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+      }
+      if (probs != nullptr) {  // strip -> global: lane = (row lane>>3 of 8, 4 keys at (lane&7)*4); rows are only 4-byte aligned
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(Ps + row * PSTR + c4);
+          const int qq = qt * 32 + row, key = kt * 32 + c4;
+          if (qq < S) {
+            TP* dst = pbase + (size_t)qq * S + key;
+            if (key + 3 < S) {
+              store_probs4(dst, pv);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (key + j < S) dst[j] = (TP)pv[j];
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip is rewritten by the next key tile
       }
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -373,7 +402,7 @@ template <int NKT, typename TP>
 static int launch_attn_probs(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int B, int S, int H, float scale,
                              hipStream_t st) {
   constexpr int SP = NKT * 32;
-  constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2 + SP * 4;
+  constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2 + SP * 4 + 4 * 32 * 36 * 4;
   auto kern = attention_probs_kernel<NKT, TP>;
   static bool attr_done = false;
   if (!attr_done && smem > 64 * 1024) {

@@ -11,6 +11,8 @@ cat gpurun_out/kernel_bench.log
 timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1
 cat gpurun_out/bench.log
 timeout 300 python tools/flava_bench.py > gpurun_out/flava_bench.log 2>&1
+timeout 300 python tools/coca_bench.py > gpurun_out/coca_bench.log 2>&1
+cat gpurun_out/coca_bench.log
 cat gpurun_out/flava_bench.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 cat gpurun_out/smoke.log
