@@ -701,6 +701,254 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 }
 
 
+
+#ifdef MMAMD_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------
+// Ping-pong kernel ("G"): 256 x 256 tile, BK = 64, 2-stage LDS ring, 8 waves (2 x 4), 128 x 64 per wave — same tile, LDS image,
+// DMA pieces and epilogue as "P", different time structure.
+//
+// Why: in "P" every wave interleaves its fragment reads and DMA issue 1:1 with its own MFMAs, and the two waves of a SIMD
+// do the same thing at the same time: the ablations put MFMA + DMA at 1613 TF/s-equivalent and MFMA + DMA + ds_read at 1190 —
+// the reads steal issue slots from the matrix pipe.  Here the two waves of a SIMD (wave w and w + 4, i.e. wm = 0 / wm = 1) run
+// ONE BARRIER APART: while one group issues an uninterrupted burst of 8 MFMAs at raised priority, the other one issues its
+// ds_reads and DMA pieces, then they swap.  Each K-tile is four phases (one 64 x 32 quadrant of the wave tile x all of K = 64):
+//
+//     phase : LOAD  { fragment reads of this phase; 2 DMA pieces }  s_barrier  MFMA { 8 x mfma_32x32x16 }  s_barrier
+//     quadrants (m-half, n-block): (0,0) (0,1) (1,1) (1,0)  ->  A fragments are read in phases 0 and 2, W fragments in 0 and 1
+//                                                               (both W sets stay in registers; phase 3 reads nothing)
+//
+// Because the W units of a stage are dead after phase 1 and the A units after phase 2, the DMA stream runs a whole K-tile
+// ahead inside a 2-stage ring.  Units (2 pieces per wave each): W-lo/W-hi = weight rows 0-127 / 128-255 of the tile,
+// A-lo/A-hi = activation rows 0-127 (read only by group 0) / 128-255 (only by group 1).  Issue schedule, tile t in stage t&1:
+//     phase 0(t): W-hi(t+1)   phase 1(t): A-lo(t+1)   phase 2(t): A-hi(t+1)   phase 3(t): W-lo(t+2)
+// Slots (= barrier intervals): group 0 reads tile t in slots 8t, 8t+2, 8t+4 and group 1 in 8t+1, 8t+3, 8t+5; a read issued in
+// slot L is retired by its wave's lgkmcnt(0) at the start of slot L+1, i.e. before the barrier that ends L+1: a unit may be
+// restaged from slot L+2 on.  W (last read 8t+3) -> restaged in slots 8t+6.. (phase 3) ok; A-lo (8t+4) -> 8t+10..; A-hi (8t+5)
+// -> 8t+12.. ok.
+// MEASURED (MI355X, qkv shape, TF/s-equivalent): full 1007 (P 1043, PP 1088); without epilogue 1197 (P 1320); MFMA + barriers 1758;
+// MFMA + reads 1345; MFMA + DMA 1625; loads only 1932.  The fragment reads cost the same ~25 % as in P even though another wave
+// issues them: not an issue-slot effect.  Kept as an experiment (variants 30/31/34-38).
+// RAW: every wave waits `vmcnt(2)` (its two youngest pieces = W-lo(t+2) may stay in flight) at the end of
+// slot 8t+7 — the end of the MFMA section of phase 3 for group 0, of the LOAD section of phase 3 for group 1 — and tile t+1 is
+// first read in slot 8t+8, behind the barrier.  Never vmcnt(0) in the loop except at the tail where phase 3 issues nothing.
+template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_g(const GemmArgs p, const int tiles_m, unsigned long long* trace) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;  // 128 x 64 per wave: MI 4, NI 2
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;             // 32 KiB + 32 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * p.tiles_n;
+    const int grp = bid / per_group, within = bid - grp * per_group;
+    const int gm0 = grp * GM;
+    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tn = within / rows;
+    tm = gm0 + (within - tn * rows);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm is also the ping-pong group: waves w and w+4 share a SIMD
+
+  // DMA source offsets (same image as "P": bank swizzle applied on the source side)
+  const int sw = (4 * (wave & 3) + (lane >> 4)) & 15;
+  const int slot = (lane & 15) ^ sw;
+  const int row8 = 2 * (lane >> 4) + (slot >> 3);
+  const int chunk = slot & 7;
+  uint32_t a_off[4], b_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int r = m0 + 8 * (wave + NW * j) + row8;
+    r = r < p.M ? r : p.M - 1;
+    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+    int c = n0 + 8 * (wave + NW * j) + row8;
+    c = c < p.N ? c : p.N - 1;
+    b_off[j] = ((uint32_t)c * (uint32_t)p.ldw + chunk * 8) * 2u;
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
+  // unit u of K-tile kt into stage buf: 0 = A-lo, 1 = A-hi, 2 = W-lo, 3 = W-hi (pieces j = 2(u&1), 2(u&1)+1 of the operand)
+  auto issue_unit = [&](int buf, int kt, int u) {
+    if constexpr ((ABL & 1) != 0) { if (kt > 0) return; }  // ablation: no DMA after the prologue
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = 2 * (u & 1) + e;
+      if (u < 2) dma_piece_s(Ab + (size_t)kt * 128, a_off[j], lds0 + buf * STAGE + (wave + NW * j) * 1024);
+      else dma_piece_s(Wb + (size_t)kt * 128, b_off[j], lds0 + buf * STAGE + A_BYTES + (wave + NW * j) * 1024);
+    }
+  };
+
+  const int l31 = lane & 31, half = lane >> 5;
+  const int hsw = l31 >> 1;
+  uint32_t ra[2][4], rb[2][4];
+#pragma unroll
+  for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
+      ra[bf][t] = lds0 + bf * STAGE + (wm * TM) * 128 + ro;
+      rb[bf][t] = lds0 + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
+    }
+  typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+  bf16x8 xa[2][4], w0[4], w1[4];  // A fragments of the current m-half (2 row blocks x 4 k-steps); both W column blocks
+
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int KT = p.K >> 6;  // even (checked by the launcher)
+  int tix = 0;
+  unsigned long long* tr = nullptr;
+  if constexpr (TRACE) {
+    if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
+  }
+  auto stamp = [&]() {
+    if constexpr (TRACE) {
+      if (tr != nullptr && tix < 255) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) tr[1 + tix] = t;
+        ++tix;
+      }
+    }
+  };
+
+  // one phase.  BF: stage of the current K-tile (compile-time), PH: phase 0..3, kt: current K-tile
+  auto phase = [&](auto bufc, auto phc, int kt) {
+    constexpr int BF = decltype(bufc)::value, PH = decltype(phc)::value;
+    constexpr int MH = (PH >= 2) ? 1 : 0;             // m-half of the wave tile
+    constexpr int NB = (PH == 1 || PH == 2) ? 1 : 0;  // n-block
+    // ---- LOAD section
+    if constexpr (PH == 0 && (ABL & 8) == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) w0[t] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t]));
+    }
+    if constexpr (PH == 1 && (ABL & 8) == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) w1[t] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + 32 * 128));
+    }
+    if constexpr ((PH == 0 || PH == 2) && (ABL & 8) == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) xa[mi][t] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + (2 * MH + mi) * 32 * 128));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bool issued_ahead = true;
+    if constexpr (PH == 0) { if (kt + 1 < KT) issue_unit(BF ^ 1, kt + 1, 3); }
+    if constexpr (PH == 1) { if (kt + 1 < KT) issue_unit(BF ^ 1, kt + 1, 0); }
+    if constexpr (PH == 2) { if (kt + 1 < KT) issue_unit(BF ^ 1, kt + 1, 1); }
+    if constexpr (PH == 3) {
+      issued_ahead = kt + 2 < KT;
+      if (issued_ahead) issue_unit(BF, kt + 2, 2);
+      if (wm == 1) {  // group 1: this LOAD section is slot 8t+7
+        if (issued_ahead) __builtin_amdgcn_s_waitcnt(0x0F72 | 0x0000);  // vmcnt(2)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+      }
+    }
+    stamp();
+    bar();
+    stamp();
+    // ---- MFMA section
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this phase's (and older) fragment reads
+    stamp();
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr ((ABL & 2) == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[NB][2 * MH + mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NB ? w1[t] : w0[t], xa[mi][t], acc[NB][2 * MH + mi], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { asm volatile("" ::"v"(NB ? w1[t] : w0[t])); asm volatile("" ::"v"(xa[0][t])); asm volatile("" ::"v"(xa[1][t])); }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (PH == 3) {
+      if (wm == 0) {  // group 0: this MFMA section is slot 8t+7
+        if (issued_ahead) __builtin_amdgcn_s_waitcnt(0x0F72);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+      }
+    }
+    stamp();
+    bar();
+    stamp();
+  };
+
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+
+  stamp();
+  // prologue: all of tile 0, W-lo of tile 1
+  issue_unit(0, 0, 2);
+  issue_unit(0, 0, 3);
+  issue_unit(0, 0, 0);
+  issue_unit(0, 0, 1);
+  if (KT > 1) {
+    issue_unit(1, 1, 2);
+    __builtin_amdgcn_s_waitcnt(0x0F72);
+  } else {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+  bar();
+  if (wm == 1) bar();  // group 1 runs one slot behind
+#pragma unroll 1
+  for (int kt = 0; kt < KT; kt += 2) {
+    phase(B0{}, P0{}, kt);
+    phase(B0{}, P1{}, kt);
+    phase(B0{}, P2{}, kt);
+    phase(B0{}, P3{}, kt);
+    phase(B1{}, P0{}, kt + 1);
+    phase(B1{}, P1{}, kt + 1);
+    phase(B1{}, P2{}, kt + 1);
+    phase(B1{}, P3{}, kt + 1);
+  }
+  if (wm == 0) bar();  // barrier counts of the two groups match again
+  stamp();
+  if constexpr ((ABL & 4) != 0) {
+    float ssum = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssum += acc[ni][mi][r];
+    if (ssum == 1.2345678e33f) reinterpret_cast<float*>(p.C)[0] = ssum;
+    return;
+  }
+  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
+  if constexpr (TRACE) {
+    stamp();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();
+    if (tr != nullptr && lane == 0) tr[0] = (unsigned long long)tix;
+  }
+}
+
+#endif  // MMAMD_EXPERIMENTS
+
 // ---------------------------------------------------------------------------------------------------------
 // Deep-ring kernel ("Q"): 256 x 256 tile, BK = 32, FOUR-stage LDS ring (4 x 32 KiB), 8 waves.
 // Why: with a 2-stage ring the DMA for K-tile k+1 is issued at the barrier of tile k and drained (vmcnt(0)) at the
@@ -1484,6 +1732,26 @@ static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_s");
 }
 
+#ifdef MMAMD_EXPERIMENTS
+template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
+static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
+  if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
+  constexpr int smem = 2 * 512 * 128;
+  auto kern = gemm_bf16_nt_kernel_g<OUT_F32, ACT, GM, TRACE, ABL>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m, TRACE ? g_gemm_trace : nullptr);
+  return launch_status("gemm_bf16_g");
+}
+
+#endif  // MMAMD_EXPERIMENTS
+
 template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
@@ -1558,6 +1826,13 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       case 24: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 2>(p, st);  // fragment reads 2 per MFMA
 #endif
 #ifdef MMAMD_EXPERIMENTS  // schedule experiments, ablations (WRONG results for 1xx except 132/164) and traces: see DESIGN.md 4.1
+      case 30: return launch_tiled_g<OUT_F32, ACT, 8>(p, st);        // ping-pong kernel "G" (measured: not faster than P/PP)
+      case 31: return launch_tiled_g<OUT_F32, ACT, 8, true>(p, st);  // ping-pong kernel with s_memtime stamps
+      case 34: return launch_tiled_g<OUT_F32, ACT, 8, false, 4>(p, st);   // G ablations: no epilogue
+      case 35: return launch_tiled_g<OUT_F32, ACT, 8, false, 5>(p, st);   //   no epilogue, no DMA
+      case 36: return launch_tiled_g<OUT_F32, ACT, 8, false, 12>(p, st);  //   no epilogue, no fragment reads
+      case 37: return launch_tiled_g<OUT_F32, ACT, 8, false, 6>(p, st);   //   no epilogue, no MFMA
+      case 38: return launch_tiled_g<OUT_F32, ACT, 8, false, 13>(p, st);  //   MFMA + barriers only
       case 3: return launch_tiled<256, 128, 4, 2, OUT_F32, ACT, false>(p, st);
       case 4: return launch_tiled<128, 256, 2, 4, OUT_F32, ACT, false>(p, st);
       case 9: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, false>(p, st);  // direct-store epilogue
