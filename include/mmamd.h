@@ -183,6 +183,25 @@ int mmamd_contrastive_fwd(const float* a, const float* b, const float* a_all, co
                           int reduction, float* logits_a, float* logits_b, float* out3, float* ws,
                           mmamd_stream_t stream);
 
+/* --- backward of the contrastive loss (autograd of modules/losses/contrastive_loss_with_temperature.py:81-107; the
+ * reference relies on torch autograd through matmul / cross_entropy / exp and, for BackpropType.GLOBAL, on the all-gather's
+ * backward = reduce-scatter, utils/distributed.py:47-48).  Inputs as mmamd_contrastive_fwd plus its logits outputs and
+ * grad_out3 = d(out3) (loss, loss_a, loss_b) on the device.  Outputs:
+ *   G_a, G_b [B,WB]        d logits (workspace the caller may keep)
+ *   grad_a, grad_b [B,E]   T G_a b_all (+ add_a),  T G_b a_all (+ add_b); add_* (row stride ld_add) may be NULL — the caller
+ *                          passes its reduce-scattered share of the gathered gradients there (GLOBAL, world > 1), or points them
+ *                          into grad_a_all / grad_b_all (computed first) when only its own block counts (LOCAL, or world = 1)
+ *   grad_a_all / grad_b_all  rows [all_row0, all_row0 + all_rows) of d a_all = T G_b^T b and d b_all = T G_a^T a, written at
+ *                          row 0.. of the given buffers (row stride ld_grad_all); both NULL = not wanted (BackpropType.NONE)
+ *   grad_logit_scale [1]   sum(G_a * logits_a) + sum(G_b * logits_b)
+ * ws: 2*B floats. */
+int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, const float* b_all, int ld_all,
+                          const float* logit_scale, const float* logits_a, const float* logits_b, int B, int WB, int E,
+                          int label_offset, const uint8_t* row_mask, float label_smoothing, int reduction,
+                          const float* grad_out3, float* G_a, float* G_b, float* grad_a, float* grad_b, const float* add_a,
+                          const float* add_b, int ld_add, float* grad_a_all, float* grad_b_all, int ld_grad_all,
+                          int all_row0, int all_rows, float* grad_logit_scale, float* ws, mmamd_stream_t stream);
+
 /* --- FLAVA pre-training heads (modules/losses/flava.py:110-238, 391-469)
  * Compaction of the labelled positions (replaces the boolean indexing `hidden_states[masked_tokens, :]`,
  * `masked_labels[masked_tokens]` :212-215 and the ITM row filter `sequence[pos_mask]` :433-437): for labels [B,L], in

@@ -33,6 +33,8 @@ PROTOTYPES = {
     "mmamd_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_attention_probs_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mmamd_contrastive_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_select_tokens": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mmamd_gather_rows": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _vp]),
     "mmamd_cross_entropy": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp]),

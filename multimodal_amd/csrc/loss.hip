@@ -116,6 +116,111 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward of the contrastive loss (first slice): gradient of
+//   loss = 0.5 (CE(logits_a, y) + CE(logits_b, y)),  logits_a = T a b_all^T,  logits_b = T b a_all^T,  T = exp(s)
+// (modules/losses/contrastive_loss_with_temperature.py:81-107) with respect to a, b, the gathered a_all / b_all and s.
+// ---------------------------------------------------------------------------------------------------------
+// G[dir][row, j] = w_dir * (softmax(logits)[j] - (1 - eps) [j == label] - eps / WB) for kept rows, 0 for masked rows;
+// w_a = (0.5 g[0] + g[1]) / n, w_b = (0.5 g[0] + g[2]) / n (mean; n = kept rows) where g = d(out3) from upstream.
+// ws[gw] = sum_j G * logits (this row's share of d logit_scale).  One wave per (dir, row).
+__global__ __launch_bounds__(256) void ce_grad_rows_kernel(const float* __restrict__ logits_a, const float* __restrict__ logits_b,
+                                                           int B, int WB, int label_offset, const uint8_t* __restrict__ row_mask,
+                                                           float smoothing, int reduction, const float* __restrict__ gout3,
+                                                           float* __restrict__ G_a, float* __restrict__ G_b,
+                                                           float* __restrict__ ws) {
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= 2 * B) return;
+  const int dir = gw / B, row = gw - dir * B;
+  float* g = (dir == 0 ? G_a : G_b) + (size_t)row * WB;
+  if (row_mask != nullptr && row_mask[row] == 0) {
+    for (int j = lane; j < WB; j += 64) g[j] = 0.f;
+    if (lane == 0) ws[gw] = 0.f;
+    return;
+  }
+  float n = (float)B;
+  if (row_mask != nullptr) {
+    float c = 0.f;
+    for (int i = lane; i < B; i += 64) c += row_mask[i] != 0 ? 1.f : 0.f;
+    n = wave_sum(c);
+  }
+  const float up = 0.5f * gout3[0] + gout3[1 + dir];
+  const float w = reduction == MMAMD_REDUCE_MEAN ? up / n : up;
+  const float* lr = (dir == 0 ? logits_a : logits_b) + (size_t)row * WB;
+  float m = -INFINITY;
+  for (int j = lane; j < WB; j += 64) m = fmaxf(m, lr[j]);
+  m = wave_max(m);
+  float se = 0.f;
+  for (int j = lane; j < WB; j += 64) se += expf(lr[j] - m);
+  se = wave_sum(se);
+  const float inv = 1.0f / se;
+  const int label = label_offset + row;
+  const float unif = smoothing / (float)WB;
+  float ds = 0.f;
+  for (int j = lane; j < WB; j += 64) {
+    const float v = lr[j];
+    const float gj = w * (expf(v - m) * inv - (j == label ? 1.f - smoothing : 0.f) - unif);
+    g[j] = gj;
+    ds += gj * v;
+  }
+  ds = wave_sum(ds);
+  if (lane == 0) ws[gw] = ds;
+}
+
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ ws, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += ws[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// C[m, n] = exp(*log_alpha) * sum_k X(m, k) Y(n, k) (+ R[m, n]) on the exact-f32 MFMA, operands addressed by element strides:
+// X(m, k) = X[m*sxm + k*sxk], Y(n, k) = Y[n*syn + k*syk] — so that G.b_all, G^T.a etc. need no transposed copies.
+__global__ __launch_bounds__(256) void f32_gemm_strided_kernel(const float* __restrict__ X, long long sxm, long long sxk,
+                                                               const float* __restrict__ Y, long long syn, long long syk,
+                                                               const float* __restrict__ log_alpha, const float* __restrict__ R,
+                                                               int ldr, float* __restrict__ C, int ldc, int M, int N, int K) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 32;
+  const int n0 = (blockIdx.x * 4 + wv) * 32;
+  if (n0 >= N) return;
+  const int half = lane >> 5;
+  int rm = m0 + (lane & 31); rm = rm < M ? rm : M - 1;
+  int rn = n0 + (lane & 31); rn = rn < N ? rn : N - 1;
+  const float* xp = X + (size_t)rm * sxm;
+  const float* yp = Y + (size_t)rn * syn;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 8) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 4 * half + u;
+      const float x = k < K ? xp[(size_t)k * sxk] : 0.f;
+      const float y = k < K ? yp[(size_t)k * syk] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
+    }
+  }
+  const float alpha = log_alpha ? expf(*log_alpha) : 1.f;
+  const int n = n0 + (lane & 31);
+  if (n < N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < M) {
+        float v = acc[r] * alpha;
+        if (R != nullptr) v += R[(size_t)m * ldr + n];
+        C[(size_t)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
 }  // namespace mmamd
 
 using namespace mmamd;
@@ -275,4 +380,45 @@ extern "C" int mmamd_cross_entropy(const float* logits, int64_t ld, const int64_
     hipLaunchKernelGGL(ce_generic_rows_kernel, dim3(N), dim3(256), 0, st, logits, (size_t)ld, labels, N, V, (long long)ignore_index, ws);
   hipLaunchKernelGGL(ce_generic_reduce_kernel, dim3(1), dim3(256), 0, st, ws, N, out_loss);
   return launch_status("cross_entropy");
+}
+
+static int launch_f32_gemm(const float* X, long long sxm, long long sxk, const float* Y, long long syn, long long syk,
+                           const float* log_alpha, const float* R, int ldr, float* C, int ldc, int M, int N, int K, hipStream_t st) {
+  hipLaunchKernelGGL(f32_gemm_strided_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, st, X, sxm, sxk, Y, syn, syk, log_alpha,
+                     R, ldr, C, ldc, M, N, K);
+  return launch_status("contrastive_bwd gemm");
+}
+
+extern "C" int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, const float* b_all, int ld_all,
+                                     const float* logit_scale, const float* logits_a, const float* logits_b, int B, int WB, int E,
+                                     int label_offset, const uint8_t* row_mask, float label_smoothing, int reduction,
+                                     const float* grad_out3, float* G_a, float* G_b, float* grad_a, float* grad_b,
+                                     const float* add_a, const float* add_b, int ld_add, float* grad_a_all, float* grad_b_all,
+                                     int ld_grad_all, int all_row0, int all_rows, float* grad_logit_scale, float* ws,
+                                     mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(a && b && a_all && b_all && logit_scale && logits_a && logits_b && grad_out3 && G_a && G_b && grad_a && grad_b &&
+                      grad_logit_scale && ws && B > 0 && WB >= B && E > 0 && ld_all >= E,
+                  MMAMD_E_BADARG, "contrastive_bwd: bad argument");
+  MMAMD_CHECK_ARG(label_offset >= 0 && label_offset + B <= WB, MMAMD_E_BADARG, "contrastive_bwd: labels out of range");
+  MMAMD_CHECK_ARG((grad_a_all == nullptr) == (grad_b_all == nullptr) && all_row0 >= 0 && all_rows >= 0 && all_row0 + all_rows <= WB,
+                  MMAMD_E_BADARG, "contrastive_bwd: bad gathered-gradient range");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_grad_rows_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, st, logits_a, logits_b, B, WB, label_offset, row_mask,
+                     label_smoothing, reduction, grad_out3, G_a, G_b, ws);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, st, ws, 2 * B, grad_logit_scale);
+  int rc;
+  if (grad_a_all != nullptr && all_rows > 0) {
+    // d b_all[j] = T sum_i G_a[i, j] a[i],  d a_all[j] = T sum_i G_b[i, j] b[i]  for gathered rows j in [all_row0, all_row0 + all_rows).
+    // These run FIRST so that add_a / add_b may point into grad_a_all / grad_b_all (own block joining the direct terms).
+    rc = launch_f32_gemm(G_a + all_row0, 1, WB, a, 1, E, logit_scale, nullptr, 0, grad_b_all, ld_grad_all, all_rows, E, B, st);
+    if (rc) return rc;
+    rc = launch_f32_gemm(G_b + all_row0, 1, WB, b, 1, E, logit_scale, nullptr, 0, grad_a_all, ld_grad_all, all_rows, E, B, st);
+    if (rc) return rc;
+  }
+  // d a = T G_a b_all (+ add_a),  d b = T G_b a_all (+ add_b):  X(m,k) = G[m*WB + k], Y(n,k) = all[k*ld_all + n]
+  rc = launch_f32_gemm(G_a, WB, 1, b_all, 1, ld_all, logit_scale, add_a, ld_add, grad_a, E, B, E, WB, st);
+  if (rc) return rc;
+  rc = launch_f32_gemm(G_b, WB, 1, a_all, 1, ld_all, logit_scale, add_b, ld_add, grad_b, E, B, E, WB, st);
+  if (rc) return rc;
+  return 0;
 }

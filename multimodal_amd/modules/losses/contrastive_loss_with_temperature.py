@@ -52,8 +52,8 @@ def contrastive_loss_with_temperature(
         embeddings_b (Tensor): features from the second modality, [B, E].
         logit_scale (nn.Parameter): 0-dim parameter holding the log of the temperature.
         mask (Optional[Tensor]): boolean [B]; rows that are False are dropped from the loss and the logits.
-        backprop_type (BackpropType): kept for API parity; the engine is forward-only, where GLOBAL, LOCAL and
-            NONE gather the same values.
+        backprop_type (BackpropType): how gradients flow through the all-gather when the inputs require grad — GLOBAL:
+            reduce-scatter of every rank's gathered-feature gradients; LOCAL: this rank's own block only; NONE: none.
         cross_entropy_kwargs: `label_smoothing` and `reduction` ('mean' | 'sum') are supported.
     """
     if not isinstance(backprop_type, BackpropType):
@@ -69,27 +69,83 @@ def contrastive_loss_with_temperature(
     if red not in ("mean", "sum"):
         raise NotImplementedError(f"cross_entropy reduction '{red}' is not supported on the MI355X path")
 
+    needs_grad = torch.is_grad_enabled() and (embeddings_a.requires_grad or embeddings_b.requires_grad or logit_scale.requires_grad)
+    if mask is not None and (mask.dtype != torch.bool or mask.shape != (embeddings_a.shape[0],)):
+        raise ValueError("mask must be a boolean tensor of shape (batch,)")
+    red_code = _lib.REDUCE_MEAN if red == "mean" else _lib.REDUCE_SUM
+    if needs_grad:
+        out3, logits_a, logits_b = _ContrastiveFn.apply(embeddings_a, embeddings_b, logit_scale, mask, backprop_type, smoothing, red_code)
+    else:
+        out3, logits_a, logits_b, _ = _contrastive_forward(embeddings_a, embeddings_b, logit_scale, mask, smoothing, red_code)
+    if mask is not None:  # reference …:97-100 returns only the kept rows (data-dependent shape)
+        logits_a, logits_b = logits_a[mask], logits_b[mask]
     out_dtype = embeddings_a.dtype
+    if out_dtype != torch.float32:
+        logits_a, logits_b = (ops.convert(t.contiguous(), out_dtype) for t in (logits_a, logits_b))
+        out3 = out3.to(out_dtype) if needs_grad else ops.convert(out3, out_dtype)
+    return ContrastiveLossOutput(loss=out3[0], logits_a=logits_a, logits_b=logits_b, loss_a=out3[1], loss_b=out3[2])
+
+
+def _contrastive_forward(embeddings_a: Tensor, embeddings_b: Tensor, logit_scale: Tensor, mask: Optional[Tensor], smoothing: float,
+                         red_code: int):
+    """gather + logits + cross entropy.  Returns (out3, logits_a, logits_b, saved-for-backward tuple)."""
     a = _as_f32(embeddings_a)
     b = _as_f32(embeddings_b)
     B, E = a.shape
     buf, rank, world = gather_packed_features(a, b)  # [W*B, 2E]; W=1 without a process group
     a_all, b_all = buf[:, :E], buf[:, E:]
     scale = logit_scale.detach()
-    scale32 = scale if scale.dtype == torch.float32 else ops.convert(scale.reshape(1), torch.float32)
-    row_mask = None
-    if mask is not None:
-        if mask.dtype != torch.bool or mask.shape != (B,):
-            raise ValueError("mask must be a boolean tensor of shape (batch,)")
-        row_mask = mask.contiguous().view(torch.uint8)
-    out3, logits_a, logits_b = ops.contrastive_fwd(
-        a, b, a_all, b_all, 2 * E, scale32.reshape(1), label_offset=B * rank, row_mask=row_mask,
-        label_smoothing=smoothing, reduction=_lib.REDUCE_MEAN if red == "mean" else _lib.REDUCE_SUM)
-    if mask is not None:  # reference …:97-100 returns only the kept rows (data-dependent shape)
-        logits_a, logits_b = logits_a[mask], logits_b[mask]
-    if out_dtype != torch.float32:
-        logits_a, logits_b, out3 = (ops.convert(t.contiguous(), out_dtype) for t in (logits_a, logits_b, out3))
-    return ContrastiveLossOutput(loss=out3[0], logits_a=logits_a, logits_b=logits_b, loss_a=out3[1], loss_b=out3[2])
+    scale32 = (scale if scale.dtype == torch.float32 else ops.convert(scale.reshape(1), torch.float32)).reshape(1)
+    row_mask = mask.contiguous().view(torch.uint8) if mask is not None else None
+    out3, logits_a, logits_b = ops.contrastive_fwd(a, b, a_all, b_all, 2 * E, scale32, label_offset=B * rank, row_mask=row_mask,
+                                                   label_smoothing=smoothing, reduction=red_code)
+    return out3, logits_a, logits_b, (a, b, buf, scale32, row_mask, rank, world)
+
+
+class _ContrastiveFn(torch.autograd.Function):
+    """Autograd node of the contrastive loss on the MI355X kernels (first slice).
+
+    forward = one packed all-gather + mmamd_contrastive_fwd; backward = mmamd_contrastive_bwd and, for BackpropType.GLOBAL with
+    world > 1, ONE reduce-scatter of the packed [W*B, 2E] gathered-feature gradients (the reference: two autograd all-gathers whose
+    backward are two reduce-scatters, utils/distributed.py:47-48).  LOCAL keeps only this rank's block of the gathered gradients
+    (no communication), NONE drops them.  The logits outputs are not differentiable through this node."""
+
+    @staticmethod
+    def forward(ctx, embeddings_a, embeddings_b, logit_scale, mask, backprop_type, smoothing, red_code):
+        out3, logits_a, logits_b, saved = _contrastive_forward(embeddings_a, embeddings_b, logit_scale, mask, smoothing, red_code)
+        a, b, buf, scale32, row_mask, rank, world = saved
+        ctx.save_for_backward(a, b, buf, scale32, logits_a, logits_b, row_mask if row_mask is not None else torch.empty(0, device=a.device))
+        ctx.meta = (rank, world, backprop_type, smoothing, red_code, row_mask is not None, embeddings_a.dtype, embeddings_b.dtype,
+                    logit_scale.dtype, tuple(logit_scale.shape))
+        ctx.mark_non_differentiable(logits_a, logits_b)
+        return out3, logits_a, logits_b
+
+    @staticmethod
+    def backward(ctx, g_out3, _g_la, _g_lb):
+        a, b, buf, scale32, logits_a, logits_b, row_mask = ctx.saved_tensors
+        rank, world, backprop_type, smoothing, red_code, has_mask, dt_a, dt_b, dt_s, s_shape = ctx.meta
+        B, E = a.shape
+        g3 = g_out3.detach()
+        g3 = (g3 if g3.is_contiguous() else g3.contiguous())
+        g3 = g3 if g3.dtype == torch.float32 else ops.convert(g3, torch.float32)
+        rm = row_mask if has_mask else None
+        a_all, b_all = buf[:, :E], buf[:, E:]
+        add, all_rows, add_all = None, None, False
+        if backprop_type == BackpropType.GLOBAL and world > 1:
+            # gradients of every rank's gathered features, then ONE reduce-scatter; this rank's share is added to grad_a / grad_b
+            _, _, g_all, _ = ops.contrastive_bwd(a, b, a_all, b_all, 2 * E, scale32, logits_a, logits_b, B * rank, rm, smoothing,
+                                                 red_code, g3, None, (0, world * B))
+            add = torch.empty((B, 2 * E), dtype=torch.float32, device=a.device)
+            torch.distributed.reduce_scatter_tensor(add, g_all)
+        elif backprop_type in (BackpropType.GLOBAL, BackpropType.LOCAL):
+            all_rows, add_all = (B * rank, B), True  # own block only (world == 1: that is everything), no communication
+        ga, gb, _, gs = ops.contrastive_bwd(a, b, a_all, b_all, 2 * E, scale32, logits_a, logits_b, B * rank, rm, smoothing,
+                                            red_code, g3, add, all_rows, add_all)
+        ga = ga if dt_a == torch.float32 else ops.convert(ga, dt_a)
+        gb = gb if dt_b == torch.float32 else ops.convert(gb, dt_b)
+        gs = gs.reshape(s_shape)
+        gs = gs if dt_s == torch.float32 else ops.convert(gs.reshape(1), dt_s).reshape(s_shape)
+        return ga, gb, gs, None, None, None, None
 
 
 DEFAULT_LOGIT_SCALE = math.log(1 / 0.07)

@@ -19,7 +19,7 @@ __all__ = [
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
-    "AttnMask",
+    "AttnMask", "contrastive_bwd",
 ]
 
 
@@ -434,6 +434,42 @@ def contrastive_fwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
                                            logits_b.data_ptr(), out3.data_ptr(), ws.data_ptr(), _stream()),
           "mmamd_contrastive_fwd")
     return out3, logits_a, logits_b
+
+
+def contrastive_bwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all: torch.Tensor, ld_all: int, logit_scale: torch.Tensor,
+                    logits_a: torch.Tensor, logits_b: torch.Tensor, label_offset: int, row_mask: Optional[torch.Tensor],
+                    label_smoothing: float, reduction: int, grad_out3: torch.Tensor, add: Optional[torch.Tensor] = None,
+                    all_rows: Optional[Tuple[int, int]] = None, add_all: bool = False):
+    """Backward of contrastive_fwd.  Returns (grad_a [B,E], grad_b [B,E], grad_all [rows, 2E] = [d a_all | d b_all] or None,
+    grad_logit_scale [1]).  `add` ([B, 2E] = [add_a | add_b]) is added to grad_a / grad_b; `all_rows` = (row0, rows) selects
+    the gathered rows whose gradient is wanted (None: none); add_all=True (needs rows == B) adds that block itself to
+    grad_a / grad_b — the own-block case of BackpropType.LOCAL / single-rank GLOBAL."""
+    for n, t in (("a", a), ("b", b), ("logits_a", logits_a), ("logits_b", logits_b), ("grad_out3", grad_out3)):
+        _chk(t, n, torch.float32)
+    B, E = a.shape
+    WB = logits_a.shape[1]
+    dev = a.device
+    f32 = torch.float32
+    G_a, G_b = torch.empty((B, WB), dtype=f32, device=dev), torch.empty((B, WB), dtype=f32, device=dev)
+    ga, gb = torch.empty((B, E), dtype=f32, device=dev), torch.empty((B, E), dtype=f32, device=dev)
+    gs, ws = torch.empty(1, dtype=f32, device=dev), torch.empty(2 * B, dtype=f32, device=dev)
+    g_all, row0, rows = None, 0, 0
+    if all_rows is not None:
+        row0, rows = all_rows
+        g_all = torch.empty((rows, 2 * E), dtype=f32, device=dev)
+    if add_all:
+        if g_all is None or rows != B or add is not None:
+            raise MmamdError("contrastive_bwd: add_all needs all_rows = (row0, B) and no separate add")
+        add = g_all
+    if add is not None:
+        _chk(add, "add", f32)
+    check(_lib.lib().mmamd_contrastive_bwd(
+        a.data_ptr(), b.data_ptr(), a_all.data_ptr(), b_all.data_ptr(), int(ld_all), logit_scale.data_ptr(), logits_a.data_ptr(),
+        logits_b.data_ptr(), B, WB, E, int(label_offset), _ptr(row_mask), float(label_smoothing), int(reduction), grad_out3.data_ptr(),
+        G_a.data_ptr(), G_b.data_ptr(), ga.data_ptr(), gb.data_ptr(), _ptr(add), (add.data_ptr() + 4 * E) if add is not None else None,
+        2 * E, _ptr(g_all), (g_all.data_ptr() + 4 * E) if g_all is not None else None, 2 * E, int(row0), int(rows), gs.data_ptr(),
+        ws.data_ptr(), _stream()), "mmamd_contrastive_bwd")
+    return ga, gb, g_all, gs
 
 
 def convert(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -667,3 +667,37 @@ def coca_pretraining_losses(out, texts: Array, logit_scale: float, pad_idx: int 
     V = out["multimodal_embeddings"].shape[-1]
     cap = cross_entropy_ignore(out["multimodal_embeddings"].reshape(-1, V), labels.reshape(-1), pad_idx)
     return {"contrastive": con, "captioning": cap}
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Backward of the contrastive loss (what torch autograd computes for modules/losses/contrastive_loss_with_temperature.py:81-107
+# and, through the all-gather, utils/distributed.py:28-58)
+# ------------------------------------------------------------------------------------------------------------------------
+def contrastive_loss_backward(a: Array, b: Array, logit_scale: float, a_all: Optional[Array] = None, b_all: Optional[Array] = None,
+                              rank: int = 0, mask: Optional[Array] = None, label_smoothing: float = 0.0, reduction: str = "mean",
+                              grad_out3=(1.0, 0.0, 0.0), dtype=np.float64):
+    """Returns d a, d b (direct terms only), d a_all, d b_all (this rank's logits' gradient w.r.t. EVERY gathered row) and
+    d logit_scale, for upstream gradients grad_out3 = d(loss, loss_a, loss_b).  The caller combines them per BackpropType:
+    GLOBAL -> d a += sum over ranks of d a_all[own block]; LOCAL -> own rank's d a_all[own block]; NONE -> nothing."""
+    a, b = np.asarray(a, dtype=dtype), np.asarray(b, dtype=dtype)
+    a_all = a if a_all is None else np.asarray(a_all, dtype=dtype)
+    b_all = b if b_all is None else np.asarray(b_all, dtype=dtype)
+    B, WB = a.shape[0], a_all.shape[0]
+    T = np.exp(dtype(logit_scale))
+    keep = np.ones(B, dtype=bool) if mask is None else np.asarray(mask).astype(bool)
+    n = keep.sum() if reduction == "mean" else 1.0
+    labels = rank * B + np.arange(B)
+
+    def dlogits(logits, w):
+        p = softmax_lastdim(logits)
+        g = p - label_smoothing / WB
+        g[np.arange(B), labels] -= 1.0 - label_smoothing
+        g = g * (w / n)
+        g[~keep] = 0.0
+        return g
+
+    la, lb = T * (a @ b_all.T), T * (b @ a_all.T)
+    Ga = dlogits(la, 0.5 * grad_out3[0] + grad_out3[1])
+    Gb = dlogits(lb, 0.5 * grad_out3[0] + grad_out3[2])
+    return {"grad_a": T * (Ga @ b_all), "grad_b": T * (Gb @ a_all), "grad_a_all": T * (Gb.T @ b), "grad_b_all": T * (Ga.T @ a),
+            "grad_logit_scale": (Ga * la).sum() + (Gb * lb).sum()}
