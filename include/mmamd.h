@@ -95,11 +95,19 @@ int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* ou
  * [B*Sq, ldo].  Replaces F.scaled_dot_product_attention in MultiHeadAttentionWithCache / MultiHeadSelfAttention
  * (modules/layers/multi_head_attention.py:69-71,165-167) as CoCa calls them: decoder self-attention with the
  * padding-aware causal mask (models/coca/text_decoder.py:178-194), cross-attention of the multimodal decoder
- * (modules/layers/transformer.py:367-385), AttentionPooler (modules/layers/attention_pooler.py:58-70). */
+ * (modules/layers/transformer.py:367-385), AttentionPooler (modules/layers/attention_pooler.py:58-70).
+ * lse (optional, [B,H,Sq] fp32): log2-domain log-sum-exp of the scaled masked scores, saved for mmamd_attention_bwd. */
 int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                           int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
                           int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
-                          int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream);
+                          float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream);
+
+/* Backward of self-attention over a packed qkv (head dim 64): given the forward's out [B*S, D] (bf16), d(out), and the
+ * log2-domain log-sum-exp `lse` [B,H,S] that mmamd_attention_x_fwd saved, writes dqkv [B*S, 3D] = [dQ | dK | dV] (bf16).
+ * Two kernels (dQ; dK+dV), no atomics.  This is what torch autograd computes for F.scaled_dot_product_attention under
+ * nn.MultiheadAttention (call sites models/clip/image_encoder.py:108, text_encoder.py:121). */
+int mmamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
+                        int causal, float scale, mmamd_stream_t stream);
 
 /* --- K1 front end: non-overlapping patch extraction ("im2col" of a stride==kernel conv) -------
  * images [B,C,HW,HW] (f32 or bf16) -> patches bf16 [B*(HW/P)^2, Kpad], column k = (c*P+py)*P+px,

@@ -429,6 +429,7 @@ struct AttnX {
   bf16* out;
   void* probs;
   const uint8_t *key_mask, *full_mask;
+  float* lse;  // optional [B,H,Sq]: log2-domain log-sum-exp of the scaled scores (saved for the backward kernels)
   long long q_bs, kv_bs, fm_bs;
   int ldq, ldk, ldv, ldo, Sq, Sk, H, causal;
   float scale_log2e;
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(256) void attention_x_kernel(const AttnX p) {
     }
     lsum += __shfl_xor(lsum, 32);
     const float inv = 1.0f / lsum;
+    if (p.lse != nullptr && half == 0 && q < Sq) p.lse[((size_t)b * p.H + h) * Sq + q] = m + __builtin_amdgcn_logf(lsum);
 
     f32x16 ot[DH / 32];
 #pragma unroll
@@ -622,6 +624,301 @@ static int dispatch_attn_x(const AttnX& p, int B, hipStream_t st) {
   return MMAMD_E_UNSUPPORTED;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention backward: head dim 64, packed qkv like the forward, no atomics — two kernels, each
+// with the forward's structure (one workgroup per (batch, head), whole head in LDS, 32-row tiles per wave, every product on
+// v_mfma_f32_32x32x16_bf16 with the "lane owns one row" layouts):
+//   P = exp2(s2 - L2[q])            s2 = scale*log2e * q.k (+ mask), L2 = the forward's saved log2-sum-exp
+//   Dq[q] = sum_d dO[q,d] O[q,d];   dP = dO V^T;   dS = P (dP - Dq)
+//   dQ = scale dS K  (kernel 1: lane = query, loop over key tiles; needs K rows, K^T, V rows in LDS)
+//   dV = P^T dO,  dK = scale dS^T Q  (kernel 2: lane = key, loop over query tiles; needs Q rows, Q^T, dO rows, dO^T in LDS)
+// ---------------------------------------------------------------------------------------------------------
+template <int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+                                                               const bf16* __restrict__ dO, const float* __restrict__ lse,
+                                                               bf16* __restrict__ dqkv, int S, int H, float scale) {
+  constexpr int SP = NKT * 32;
+  constexpr int VS = SP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);                                  // [SP][72]
+  bf16* Vs = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);              // [SP][72]
+  bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * SP * kKStride * 2);          // [64][VS]
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * kDh;
+  const size_t row_stride = (size_t)3 * D;
+  const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int r = tid >> 3; r < SP; r += 32) {
+    const int c = tid & 7;
+    bf16x8 kv, vv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+    if (r < S) {
+      kv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + D + c * 8);
+      vv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + 2 * D + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
+    *reinterpret_cast<bf16x8*>(Vs + r * kKStride + c * 8) = vv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VS + r] = kv[j];
+  }
+  __syncthreads();
+  const int l31 = lane & 31, half = lane >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const int nqt = (S + 31) >> 5;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 32 + l31;
+    const int qc = q < S ? q : S - 1;
+    bf16x8 qf[4], dof[4];
+    float dq_part = 0.f;
+    const bf16* orow = O + ((size_t)b * S + qc) * D + h * kDh + 8 * half;
+    const bf16* dorow = dO + ((size_t)b * S + qc) * D + h * kDh + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * row_stride + 16 * t + 8 * half);
+      dof[t] = *reinterpret_cast<const bf16x8*>(dorow + 16 * t);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(orow + 16 * t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dq_part += (float)dof[t][j] * (float)of[j];
+    }
+    const float Dq = dq_part + __shfl_xor(dq_part, 32);
+    const float L2 = lse[((size_t)b * H + h) * S + qc];
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const int kt_hi = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
+#pragma unroll 1
+    for (int kt = 0; kt < kt_hi; ++kt) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+      const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
+      const bf16* vrow = Vs + (kt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow + 16 * t), qf[t], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(vrow + 16 * t), dof[t], dp, 0, 0, 0);
+      }
+      uint32_t pk[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const int key = kt * 32 + 8 * g + 4 * half + j;
+          const bool ok = key < S && (!CAUSAL || key <= qc);
+          const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2) : 0.f;
+          e[j] = pr * (dp[r] - Dq);
+        }
+        bf16x2 p0, p1;
+        p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+        pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
+        pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int key0 = kt * 32 + 16 * jj + 4 * half;
+        u32x4 pw;
+        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+        const bf16x8 dsf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16* ktrow = Kt + (nt * 32 + l31) * VS + key0;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(ktrow);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(ktrow + 8);
+          u32x4 vw;
+          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), dsf, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    if (q < S) {
+      bf16* dst = dqkv + ((size_t)b * S + q) * row_stride + h * kDh;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = acc[nt][4 * g + j] * scale;
+          store4(dst + nt * 32 + 8 * g + 4 * half, o);
+        }
+    }
+  }
+}
+
+template <int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+                                                                const bf16* __restrict__ dO, const float* __restrict__ lse,
+                                                                bf16* __restrict__ dqkv, int S, int H, float scale) {
+  constexpr int SP = NKT * 32;
+  constexpr int VS = SP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qs = reinterpret_cast<bf16*>(smem);                                           // [SP][72]
+  bf16* dOs = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);                      // [SP][72]
+  bf16* Qt = reinterpret_cast<bf16*>(smem + 2 * SP * kKStride * 2);                   // [64][VS]
+  bf16* dOt = reinterpret_cast<bf16*>(smem + 2 * SP * kKStride * 2 + 64 * VS * 2);    // [64][VS]
+  float* L2s = reinterpret_cast<float*>(smem + 2 * SP * kKStride * 2 + 2 * 64 * VS * 2);  // [SP]
+  float* Dqs = L2s + SP;                                                                   // [SP]
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * kDh;
+  const size_t row_stride = (size_t)3 * D;
+  const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int k = tid; k < SP; k += 256) { L2s[k] = INFINITY; Dqs[k] = 0.f; }
+  __syncthreads();
+  for (int r = tid >> 3; r < SP; r += 32) {
+    const int c = tid & 7;
+    bf16x8 qv, dv, ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qv[j] = (bf16)0.f; dv[j] = (bf16)0.f; ov[j] = (bf16)0.f; }
+    if (r < S) {
+      qv = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + c * 8);
+      dv = *reinterpret_cast<const bf16x8*>(dO + ((size_t)b * S + r) * D + h * kDh + c * 8);
+      ov = *reinterpret_cast<const bf16x8*>(O + ((size_t)b * S + r) * D + h * kDh + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Qs + r * kKStride + c * 8) = qv;
+    *reinterpret_cast<bf16x8*>(dOs + r * kKStride + c * 8) = dv;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      Qt[(c * 8 + j) * VS + r] = qv[j];
+      dOt[(c * 8 + j) * VS + r] = dv[j];
+      part += (float)dv[j] * (float)ov[j];
+    }
+    // the 8 threads of a row are 8 consecutive lanes: sum their partial dot products
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    if (c == 0 && r < S) { Dqs[r] = part; L2s[r] = lse[((size_t)b * H + h) * S + r]; }
+  }
+  __syncthreads();
+  const int l31 = lane & 31, half = lane >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const int nkt = (S + 31) >> 5;
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int key = kt * 32 + l31;
+    const int kc = key < S ? key : S - 1;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      kf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)kc * row_stride + D + 16 * t + 8 * half);
+      vf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)kc * row_stride + 2 * D + 16 * t + 8 * half);
+    }
+    f32x16 dv_acc[2], dk_acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dv_acc[nt][r] = 0.f; dk_acc[nt][r] = 0.f; }
+    const int qt_lo = CAUSAL ? kt : 0;  // queries before the key tile never see it
+#pragma unroll 1
+    for (int qt = qt_lo; qt < NKT; ++qt) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+      const bf16* qrow = Qs + (qt * 32 + l31) * kKStride + 8 * half;
+      const bf16* drow = dOs + (qt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qrow + 16 * t), kf[t], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(drow + 16 * t), vf[t], dp, 0, 0, 0);
+      }
+      uint32_t pk[8], dk[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float e[4], f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const int q = qt * 32 + 8 * g + 4 * half + j;
+          const bool ok = key < S && (!CAUSAL || key <= q);
+          const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;  // L2 = +inf for padded queries -> 0
+          e[j] = pr;
+          f[j] = pr * (dp[r] - Dqs[q]);
+        }
+        bf16x2 p0, p1, d0, d1;
+        p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+        d0[0] = (bf16)f[0]; d0[1] = (bf16)f[1]; d1[0] = (bf16)f[2]; d1[1] = (bf16)f[3];
+        pk[2 * g] = __builtin_bit_cast(uint32_t, p0); pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+        dk[2 * g] = __builtin_bit_cast(uint32_t, d0); dk[2 * g + 1] = __builtin_bit_cast(uint32_t, d1);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int q0 = qt * 32 + 16 * jj + 4 * half;
+        u32x4 pw, dw;
+        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+        dw[0] = dk[4 * jj + 0]; dw[1] = dk[4 * jj + 1]; dw[2] = dk[4 * jj + 2]; dw[3] = dk[4 * jj + 3];
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dw);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16* dorow = dOt + (nt * 32 + l31) * VS + q0;
+          const bf16* qtrow = Qt + (nt * 32 + l31) * VS + q0;
+          const uint2 a0 = *reinterpret_cast<const uint2*>(dorow), a1 = *reinterpret_cast<const uint2*>(dorow + 8);
+          const uint2 b0 = *reinterpret_cast<const uint2*>(qtrow), b1 = *reinterpret_cast<const uint2*>(qtrow + 8);
+          u32x4 aw, bw;
+          aw[0] = a0.x; aw[1] = a0.y; aw[2] = a1.x; aw[3] = a1.y;
+          bw[0] = b0.x; bw[1] = b0.y; bw[2] = b1.x; bw[3] = b1.y;
+          dv_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), pf, dv_acc[nt], 0, 0, 0);
+          dk_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), dsf, dk_acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    if (key < S) {
+      bf16* dst = dqkv + ((size_t)b * S + key) * row_stride + h * kDh;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 ok_, ov_;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ok_[j] = dk_acc[nt][4 * g + j] * scale; ov_[j] = dv_acc[nt][4 * g + j]; }
+          store4(dst + D + nt * 32 + 8 * g + 4 * half, ok_);
+          store4(dst + 2 * D + nt * 32 + 8 * g + 4 * half, ov_);
+        }
+    }
+  }
+}
+
+template <int NKT>
+static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
+                           float scale, hipStream_t st) {
+  constexpr int SP = NKT * 32;
+  constexpr int smem1 = 2 * SP * kKStride * 2 + 64 * (SP + 4) * 2;
+  constexpr int smem2 = 2 * SP * kKStride * 2 + 2 * 64 * (SP + 4) * 2 + 2 * SP * 4;
+  auto k1c = attention_bwd_dq_kernel<NKT, true>;
+  auto k1n = attention_bwd_dq_kernel<NKT, false>;
+  auto k2c = attention_bwd_dkv_kernel<NKT, true>;
+  auto k2n = attention_bwd_dkv_kernel<NKT, false>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (const void* f : {(const void*)k1c, (const void*)k1n})
+      if (smem1 > 64 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess) {
+        set_error("attention_bwd: hipFuncSetAttribute failed"); return MMAMD_E_UNSUPPORTED;
+      }
+    for (const void* f : {(const void*)k2c, (const void*)k2n})
+      if (smem2 > 64 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem2) != hipSuccess) {
+        set_error("attention_bwd: hipFuncSetAttribute failed"); return MMAMD_E_UNSUPPORTED;
+      }
+    attr_done = true;
+  }
+  if (causal) {
+    hipLaunchKernelGGL(k1c, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
+    hipLaunchKernelGGL(k2c, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
+  } else {
+    hipLaunchKernelGGL(k1n, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
+    hipLaunchKernelGGL(k2n, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
+  }
+  return launch_status("attention_bwd");
+}
+
 static int g_attn_variant = 0;
 
 template <int NKT, bool CAUSAL, int ABL = 0>
@@ -701,7 +998,7 @@ extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mas
 extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                      int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
                                      int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
-                                     int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream) {
+                                     float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(q && k && v && out && B >= 0 && Sq > 0 && Sk > 0 && H > 0, MMAMD_E_BADARG, "attention_x: bad argument");
   MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x: head_dim=%d (64 and 96 are built)", head_dim);
   MMAMD_CHECK_ARG(Sk <= 288, MMAMD_E_UNSUPPORTED, "attention_x: Sk=%d > 288 not supported", Sk);
@@ -714,7 +1011,7 @@ extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_str
   if (B == 0) return 0;
   AttnX p;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)out; p.probs = probs;
-  p.key_mask = key_mask; p.full_mask = full_mask;
+  p.key_mask = key_mask; p.full_mask = full_mask; p.lse = lse;
   p.q_bs = q_batch_stride; p.kv_bs = kv_batch_stride; p.fm_bs = full_mask_batch_stride;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal ? 1 : 0;
   p.scale_log2e = scale * 1.4426950408889634f;
@@ -722,4 +1019,25 @@ extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_str
   const bool pf32 = probs == nullptr || probs_dtype == MMAMD_F32;
   if (head_dim == 64) return pf32 ? dispatch_attn_x<64, float>(p, B, st) : dispatch_attn_x<64, bf16>(p, B, st);
   return pf32 ? dispatch_attn_x<96, float>(p, B, st) : dispatch_attn_x<96, bf16>(p, B, st);
+}
+
+extern "C" int mmamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
+                                   int causal, float scale, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(qkv && out && dout && lse && dqkv && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention_bwd: bad argument");
+  MMAMD_CHECK_ARG(S <= 288, MMAMD_E_UNSUPPORTED, "attention_bwd: S=%d > 288 not supported", S);
+  MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), MMAMD_E_ALIGN, "attention_bwd: pointers must be 16-byte aligned");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch ((S + 31) / 32) {
+    case 1: return launch_attn_bwd<1>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 2: return launch_attn_bwd<2>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 3: return launch_attn_bwd<3>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 4: return launch_attn_bwd<4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 5: return launch_attn_bwd<5>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 6: return launch_attn_bwd<6>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 7: return launch_attn_bwd<7>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 8: return launch_attn_bwd<8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 9: return launch_attn_bwd<9>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+  }
+  MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention_bwd: unsupported S=%d", S);
 }

@@ -19,7 +19,7 @@ __all__ = [
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
-    "AttnMask", "contrastive_bwd",
+    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd",
 ]
 
 
@@ -150,7 +150,7 @@ def _mat_view(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Sk: int, H: int, head_dim: int,
                     mask: Optional[AttnMask] = None, shared_q: bool = False, want_probs: bool = False,
-                    out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                    out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """General attention (mmamd_attention_x_fwd).  q: bf16 [B*Sq, >=H*hd] (or [Sq, ...] when shared_q: the same queries for
     every sample), k / v: bf16 [B*Sk, >=H*hd]; all may be column-slice views of wider matrices (stride(0) is the row
     pitch).  Returns (bf16 [B*Sq, H*hd], probabilities fp32 [B,H,Sq,Sk] or None)."""
@@ -176,9 +176,35 @@ def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, S
     probs = torch.empty((B, H, Sq, Sk), dtype=torch.float32, device=q.device) if want_probs else None
     check(_lib.lib().mmamd_attention_x_fwd(q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(),
                                            k.stride(0), v.stride(0), Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal),
-                                           out.data_ptr(), out.stride(0), _ptr(probs), F32, B, Sq, Sk, H, head_dim,
+                                           out.data_ptr(), out.stride(0), _ptr(probs), F32, _ptr(lse), B, Sq, Sk, H, head_dim,
                                            1.0 / math.sqrt(float(head_dim)), _stream()), "mmamd_attention_x_fwd")
     return out, probs
+
+
+def attention_fwd_train(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Self-attention forward that also saves the log2-domain log-sum-exp [B,H,S] for attention_bwd."""
+    _chk(qkv, "qkv", torch.bfloat16)
+    D = H * 64
+    if qkv.shape != (B * S, 3 * D):
+        raise MmamdError(f"attention: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * D)}")
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    out, _ = attention_x_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, S, H, 64, AttnMask(causal=causal), lse=lse)
+    return out, lse
+
+
+def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, S: int, H: int,
+                  causal: bool) -> torch.Tensor:
+    """dqkv bf16 [B*S, 3*H*64] = [dQ | dK | dV] from the saved forward tensors."""
+    for n, x in (("qkv", qkv), ("out", out), ("dout", dout)):
+        _chk(x, n, torch.bfloat16)
+    _chk(lse, "lse", torch.float32)
+    D = H * 64
+    if qkv.shape != (B * S, 3 * D) or out.shape != (B * S, D) or dout.shape != (B * S, D) or lse.shape != (B, H, S):
+        raise MmamdError("attention_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    check(_lib.lib().mmamd_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, S, H,
+                                         int(bool(causal)), 1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_bwd")
+    return dqkv
 
 
 def coca_text_embed(ids: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, cls: Optional[torch.Tensor]) -> torch.Tensor:
