@@ -210,6 +210,31 @@ int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, co
                           const float* add_b, int ld_add, float* grad_a_all, float* grad_b_all, int ld_grad_all,
                           int all_row0, int all_rows, float* grad_logit_scale, float* ws, mmamd_stream_t stream);
 
+/* --- row / elementwise kernels of the backward pass (torch autograd of the modules named in the forward entries above)
+ * LayerNorm backward: dx[rows,d] (fp32) = LN'(x; gamma)(dy) (+ add), dgamma[d], dbeta[d].  dy fp32 or bf16.
+ * ws: (min(512, ceil(rows/4)) * 2 + 2) * d floats. */
+int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
+                        float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream);
+/* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(256, rows) * n floats. */
+int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
+/* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */
+int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream);
+int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n, int act, mmamd_stream_t stream);
+/* dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) for r < rows, 0 for rows <= r < ld_dst: operands of the weight-gradient GEMM
+ * dW[N,K] = dY^T X computed by mmamd_gemm_bf16 as (dY^T)[N,M] . (X^T)[K,M]^T with the token index M as contraction. */
+int mmamd_transpose_to_bf16(const void* src, int src_dtype, int64_t ld_src, void* dst, int rows, int cols, int ld_dst,
+                            mmamd_stream_t stream);
+/* F.normalize backward (fp32): dx = (dy - y (y.dy)) / max(|x|, eps). */
+int mmamd_l2_normalize_bwd(const float* x, const float* dy, float* dx, int rows, int d, float eps, mmamd_stream_t stream);
+/* dst[idx[i], :] += src[i, :] with fp32 atomics (embedding-table gradient; pooled-row gradient into the sequence). */
+int mmamd_scatter_add_rows(const float* src, const int64_t* idx, int n, int d, float* dst, int64_t dst_rows, mmamd_stream_t stream);
+
+/* Small exact-fp32 GEMM with element strides: C[m,n] = sum_k X[m*sxm + k*sxk] * Y[n*syn + k*syk] (+ R[m*ldr + n]).  Used for
+ * the pooled projections and their gradients in the training step (x @ projection, n^T de, de P^T: image_encoder.py:111-112,
+ * text_encoder.py:130-132 and their autograd). */
+int mmamd_f32_gemm_strided(const float* X, int64_t sxm, int64_t sxk, const float* Y, int64_t syn, int64_t syk, const float* R, int ldr,
+                           float* C, int ldc, int M, int N, int K, mmamd_stream_t stream);
+
 /* --- FLAVA pre-training heads (modules/losses/flava.py:110-238, 391-469)
  * Compaction of the labelled positions (replaces the boolean indexing `hidden_states[masked_tokens, :]`,
  * `masked_labels[masked_tokens]` :212-215 and the ITM row filter `sequence[pos_mask]` :433-437): for labels [B,L], in

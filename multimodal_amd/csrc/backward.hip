@@ -1,0 +1,271 @@
+// backward.hip — row / elementwise kernels of the training step: what torch autograd runs for
+// LayerNorm, QuickGELU / GELU, bias adds, F.normalize and the embedding lookups of the CLIP towers, plus the bf16 transpose that
+// lets the NT MFMA GEMM compute weight gradients (dW = dY^T X: both operands are needed with the token index contiguous).
+// All HBM-bound: wave per row, float4 / bf16x4 accesses, fp32 accumulation; column reductions are two-stage (no atomics),
+// the embedding-table gradient uses fp32 atomics (rows collide by construction).
+#include "common.h"
+
+namespace mmamd {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward.  y = (x - mu) rstd * gamma + beta.  dx = rstd (g - mean(g) - xh mean(g xh)), g = dy * gamma, xh = (x - mu) rstd
+// dx (+= add) in fp32;  per-block partial column sums of dy*xh (dgamma) and dy (dbeta) -> part[block][2][d]
+// ---------------------------------------------------------------------------------------------
+template <typename TD, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const TD* __restrict__ dy, const float* __restrict__ add,
+                                                            float* __restrict__ dx, float* __restrict__ part, int rows, int d, float eps) {
+  __shared__ float red[4][2][MAXV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d4 = d >> 2;
+  f32x4 gacc[MAXV], bacc[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) { gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * d;
+    const TD* dr = dy + (size_t)row * d;
+    f32x4 xv[MAXV], gv[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d4) { xv[i] = load4(xr + 4 * c); sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]); }
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float u = xv[i][j] - mean; q += u * u; }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d4) {
+        const f32x4 dyv = load4(dr + 4 * c), gm = load4(gamma + 4 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[i][j] - mean) * rstd;
+          xv[i][j] = xh;
+          gv[i][j] = dyv[j] * gm[j];
+          sg += gv[i][j];
+          sgx += gv[i][j] * xh;
+          gacc[i][j] += dyv[j] * xh;
+          bacc[i][j] += dyv[j];
+        }
+      }
+    }
+    const float mg = wave_sum(sg) / (float)d, mgx = wave_sum(sgx) / (float)d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[i][j] - mg - xv[i][j] * mgx);
+        if (add != nullptr) {
+          const f32x4 a = load4(add + (size_t)row * d + 4 * c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += a[j];
+        }
+        store4(dx + (size_t)row * d + 4 * c, o);
+      }
+    }
+  }
+  // block partials: 4 waves -> LDS -> wave 0 sums and writes part[blockIdx][{gamma, beta}][d]
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[wave][0][4 * c + j] = gacc[i][j]; red[wave][1][4 * c + j] = bacc[i][j]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    part[((size_t)blockIdx.x * 2 + 0) * d + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+    part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+  }
+}
+
+// out[c] = sum_g part[g][c]  (second stage of every column reduction)
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += part[(size_t)g * n + c];
+  out[c] = s;
+}
+
+// column sums of x [rows, n] (bias gradients): stage 1 — thread per column, block per (column strip, row group)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict__ x, int rows, int n, float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) s += to_f32(x[(size_t)r * n + c]);
+  part[(size_t)blockIdx.y * n + c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations: g = act(u) (training forward keeps u) and du = dg * act'(u)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_value(float u, int act) {
+  if (act == MMAMD_ACT_QUICKGELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * u));
+  return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
+}
+__device__ __forceinline__ float act_grad(float u, int act) {
+  if (act == MMAMD_ACT_QUICKGELU) {  // d/du [u s(1.702 u)] = s + 1.702 u s (1 - s)
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * u));
+    return sg * (1.0f + 1.702f * u * (1.0f - sg));
+  }
+  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));  // d/du [u Phi(u)] = Phi + u phi
+  return cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+}
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ u, bf16* __restrict__ g, int64_t n4, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = load4(u + 4 * i);
+    store4(g + 4 * i, f32x4{act_value(v[0], act), act_value(v[1], act), act_value(v[2], act), act_value(v[3], act)});
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ u, const bf16* __restrict__ dg, bf16* __restrict__ du,
+                                                      int64_t n4, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = load4(u + 4 * i), d = load4(dg + 4 * i);
+    store4(du + 4 * i, f32x4{d[0] * act_grad(v[0], act), d[1] * act_grad(v[1], act), d[2] * act_grad(v[2], act), d[3] * act_grad(v[3], act)});
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 transpose with zero padding: dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < ld_dst   (64 x 64 tiles through LDS)
+// ---------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const TS* __restrict__ src, int64_t ld_src, bf16* __restrict__ dst,
+                                                                int rows, int cols, int ld_dst) {
+  __shared__ bf16 tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? (bf16)to_f32(src[(size_t)r * ld_src + c]) : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize backward: y = x / max(|x|, eps);  dx = (dy - y (y . dy)) / max(|x|, eps)      (wave per row, fp32)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_normalize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * d;
+  const float* gr = dy + (size_t)row * d;
+  float ss = 0.f, sd = 0.f;
+  for (int c = lane; c < d; c += 64) { ss += xr[c] * xr[c]; sd += xr[c] * gr[c]; }
+  ss = wave_sum(ss); sd = wave_sum(sd);
+  const float nrm = sqrtf(ss);
+  const float den = fmaxf(nrm, eps);
+  // below eps the forward divides by the constant eps: plain scaling
+  const float k = nrm > eps ? sd / (den * den * den) : 0.f;
+  for (int c = lane; c < d; c += 64) dx[(size_t)row * d + c] = gr[c] / den - xr[c] * k;
+}
+
+// dst[idx[i], :] += src[i, :]  (fp32 atomics: token-embedding gradient; pooled-row gradient scattered into the sequence)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int n, int d,
+                                                               float* __restrict__ dst, int64_t dst_rows) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t r = idx[i];
+  if (r < 0 || r >= dst_rows) return;
+  for (int c = lane; c < d; c += 64) atomicAdd(dst + (size_t)r * d + c, src[(size_t)i * d + c]);
+}
+
+}  // namespace mmamd
+
+using namespace mmamd;
+
+extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
+                                   float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && ws && rows > 0 && d > 0, MMAMD_E_BADARG, "layernorm_bwd: bad argument");
+  MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "layernorm_bwd: d=%d must be a multiple of 4 and <= 2048", d);
+  hipStream_t st = (hipStream_t)stream;
+  const int G = rows < 4 * 512 ? (rows + 3) / 4 : 512;  // ws: G * 2 * d floats
+  const int d4 = d / 4;
+#define LNB(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(G), dim3(256), 0, st, x, gamma, (const T*)dy, add, dx, ws, rows, d, eps)
+  if (dy_dtype == MMAMD_F32) { if (d4 <= 128) LNB(float, 2); else if (d4 <= 256) LNB(float, 4); else LNB(float, 8); }
+  else if (dy_dtype == MMAMD_BF16) { if (d4 <= 128) LNB(bf16, 2); else if (d4 <= 256) LNB(bf16, 4); else LNB(bf16, 8); }
+  else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "layernorm_bwd: bad dy dtype");
+#undef LNB
+  // part layout [G][2][d]: columns 0..d-1 = dgamma partials, d..2d-1 = dbeta partials of one "row" of width 2d
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, ws, G, 2 * d, ws + (size_t)G * 2 * d);
+  hipMemcpyAsync(dgamma, ws + (size_t)G * 2 * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(dbeta, ws + (size_t)G * 2 * d + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+  return launch_status("layernorm_bwd");
+}
+
+extern "C" int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && out && ws && rows > 0 && n > 0, MMAMD_E_BADARG, "colsum: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int G = rows < 256 ? rows : 256;  // ws: G * n floats
+  const dim3 grid((n + 255) / 256, G);
+  if (dtype == MMAMD_F32) hipLaunchKernelGGL((colsum_stage1_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, n, ws);
+  else if (dtype == MMAMD_BF16) hipLaunchKernelGGL((colsum_stage1_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, rows, n, ws);
+  else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "colsum: bad dtype");
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, G, n, out);
+  return launch_status("colsum");
+}
+
+extern "C" int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(u && g && n >= 0 && n % 4 == 0 && (act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF), MMAMD_E_BADARG, "act_fwd: bad argument");
+  if (n == 0) return 0;
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)g, n4, act);
+  return launch_status("act_fwd");
+}
+
+extern "C" int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n, int act, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(u && dg && du && n >= 0 && n % 4 == 0 && (act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF), MMAMD_E_BADARG, "act_bwd: bad argument");
+  if (n == 0) return 0;
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (const bf16*)dg, (bf16*)du, n4, act);
+  return launch_status("act_bwd");
+}
+
+extern "C" int mmamd_transpose_to_bf16(const void* src, int src_dtype, int64_t ld_src, void* dst, int rows, int cols, int ld_dst,
+                                       mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, MMAMD_E_BADARG, "transpose: bad argument");
+  const dim3 grid((cols + 63) / 64, (ld_dst + 63) / 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == MMAMD_BF16) hipLaunchKernelGGL((transpose_to_bf16_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, ld_src, (bf16*)dst, rows, cols, ld_dst);
+  else if (src_dtype == MMAMD_F32) hipLaunchKernelGGL((transpose_to_bf16_kernel<float>), grid, dim3(256), 0, st, (const float*)src, ld_src, (bf16*)dst, rows, cols, ld_dst);
+  else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "transpose: bad dtype");
+  return launch_status("transpose_to_bf16");
+}
+
+extern "C" int mmamd_l2_normalize_bwd(const float* x, const float* dy, float* dx, int rows, int d, float eps, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && dy && dx && rows >= 0 && d > 0, MMAMD_E_BADARG, "l2_normalize_bwd: bad argument");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(l2_normalize_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, dx, rows, d, eps);
+  return launch_status("l2_normalize_bwd");
+}
+
+extern "C" int mmamd_scatter_add_rows(const float* src, const int64_t* idx, int n, int d, float* dst, int64_t dst_rows, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(src && idx && dst && n >= 0 && d > 0 && dst_rows > 0, MMAMD_E_BADARG, "scatter_add_rows: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, n, d, dst, dst_rows);
+  return launch_status("scatter_add_rows");
+}

@@ -422,3 +422,9 @@ extern "C" int mmamd_contrastive_bwd(const float* a, const float* b, const float
   if (rc) return rc;
   return 0;
 }
+
+extern "C" int mmamd_f32_gemm_strided(const float* X, int64_t sxm, int64_t sxk, const float* Y, int64_t syn, int64_t syk, const float* R,
+                                      int ldr, float* C, int ldc, int M, int N, int K, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(X && Y && C && M > 0 && N > 0 && K > 0 && ldc >= N && (!R || ldr >= N), MMAMD_E_BADARG, "f32_gemm_strided: bad argument");
+  return launch_f32_gemm(X, sxm, sxk, Y, syn, syk, nullptr, R, ldr, C, ldc, M, N, K, (hipStream_t)stream);
+}

@@ -13,6 +13,7 @@ from torch import nn, Tensor
 from ... import ops
 from ..._packing import PackedCache
 from ...modules.layers.normalizations import Fp32LayerNorm
+from . import _train
 from ._transformer import TransformerStack, forbid_training_forward
 
 EXPANSION = 4
@@ -74,7 +75,8 @@ class CLIPViTEncoder(nn.Module):
                 f"Expected input with width and height as {self.image_size}, found {x.size(2)} by {x.size(3)} ")
         if x.size(1) != 3:
             raise ValueError(f"Expected 3 channels found {x.size(1)}")
-        forbid_training_forward(self)
+        if _train.wants_grad(self):
+            return self._forward_train(x)
         f32 = torch.float32
         pk = self._packed.get
         B = x.size(0)
@@ -94,3 +96,14 @@ class CLIPViTEncoder(nn.Module):
         out = ops.pool_ln_proj(h, B, G2 + 1, None, pk(self.ln_post.weight, f32), pk(self.ln_post.bias, f32),
                                self.ln_post.eps, pk(self.projection, f32), proj_is_linear_weight=False)
         return out if self.projection.dtype == f32 else ops.convert(out, self.projection.dtype)
+
+    def _forward_train(self, x: Tensor) -> Tensor:
+        """Differentiable forward (train mode, grad enabled): the autograd nodes of models/clip/_train.py."""
+        B = x.size(0)
+        g = self.image_size // self.patch_size
+        S = g * g + 1
+        x0 = _train.VisionEmbedFn.apply(x, self.conv.weight, self.cls_token_embedding, self.positional_embedding, self.ln_pre.weight,
+                                        self.ln_pre.bias, self.patch_size, self.ln_pre.eps)
+        h = _train.run_stack(self.encoder, x0, B, S, False)
+        cls_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=x.device)
+        return _train.PooledHeadFn.apply(h, cls_rows, self.ln_post.weight, self.ln_post.bias, self.projection, self.ln_post.eps, False)

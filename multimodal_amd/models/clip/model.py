@@ -12,6 +12,7 @@ from torch import nn
 
 from ... import ops
 from ...utils.common import load_module_from_url
+from . import _train
 from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
 
@@ -52,6 +53,11 @@ class CLIP(nn.Module):
         # stream so its small-grid kernels (77-token sequences: 150-600 workgroups per GEMM) fill the CUs that tower
         # A's kernels leave idle in their last, partial wave of workgroups.  Pure stream plumbing: same kernels,
         # same results.  MMAMD_SINGLE_STREAM=1 disables it.
+        if _train.wants_grad(self):
+            # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward, one stream
+            embeddings_a = _train.L2NormalizeFn.apply(self.encoder_a(features_a))
+            embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))
+            return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
         side = self._side_stream(features_a)
         if side is None:
             embeddings_a = self.encoder_a(features_a)

@@ -14,6 +14,7 @@ from torch import nn, Tensor
 from ... import ops
 from ..._packing import PackedCache
 from ...modules.layers.normalizations import Fp32LayerNorm
+from . import _train
 from ._transformer import TransformerStack, forbid_training_forward
 
 
@@ -76,11 +77,18 @@ class CLIPTextEncoder(nn.Module):
     def forward(self, text: Tensor, return_hidden_state: bool = False) -> Tensor:
         if text.size(1) != self.context_length:
             raise ValueError(f"length of input should be {self.context_length} but found {text.size(1)}")
-        forbid_training_forward(self)
         f32 = torch.float32
         pk = self._packed.get
         B, S = text.shape
         ids = text if (text.dtype == torch.int64 and text.is_contiguous()) else text.to(torch.int64).contiguous()
+        if _train.wants_grad(self):
+            if return_hidden_state:
+                raise ops.MmamdError("return_hidden_state is not implemented for the differentiable (training) forward")
+            x0 = _train.TextEmbedFn.apply(ids, self.token_embedding.weight, self.positional_embedding)
+            h = _train.run_stack(self.encoder, x0, B, S, True)
+            eot_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=ids.device) + ids.argmax(dim=-1)  # index bookkeeping
+            return _train.PooledHeadFn.apply(h, eot_rows, self.ln_final.weight, self.ln_final.bias, self.projection.weight,
+                                             self.ln_final.eps, True)
         table = self.token_embedding.weight.detach()
         if table.dtype not in (torch.float32, torch.bfloat16):
             raise ops.MmamdError(f"token_embedding dtype {table.dtype} unsupported")

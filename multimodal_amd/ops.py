@@ -19,7 +19,8 @@ __all__ = [
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
-    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd",
+    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided",
 ]
 
 
@@ -496,6 +497,88 @@ def contrastive_bwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
         2 * E, _ptr(g_all), (g_all.data_ptr() + 4 * E) if g_all is not None else None, 2 * E, int(row0), int(rows), gs.data_ptr(),
         ws.data_ptr(), _stream()), "mmamd_contrastive_bwd")
     return ga, gb, g_all, gs
+
+
+def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float,
+                  add: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(dx fp32 [rows,d] (+ add), dgamma [d], dbeta [d]) for y = LayerNorm(x) * gamma + beta; dy fp32 or bf16."""
+    _chk(x, "x", torch.float32); _chk(gamma, "gamma", torch.float32); _chk(dy, "dy")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if dy.numel() != x.numel():
+        raise MmamdError("layernorm_bwd: dy has a different number of elements")
+    if add is not None:
+        _chk(add, "add", torch.float32)
+    dev = x.device
+    dx = torch.empty((rows, d), dtype=torch.float32, device=dev)
+    dg, db = torch.empty(d, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)
+    G = min(512, (rows + 3) // 4)
+    ws = torch.empty((G * 2 + 2) * d, dtype=torch.float32, device=dev)
+    check(_lib.lib().mmamd_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy), _ptr(add), dx.data_ptr(), dg.data_ptr(),
+                                         db.data_ptr(), ws.data_ptr(), rows, d, float(eps), _stream()), "mmamd_layernorm_bwd")
+    return dx, dg, db
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a [rows, n] fp32 / bf16 matrix (bias gradients)."""
+    _chk(x, "x")
+    rows, n = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = torch.empty(min(256, rows) * n, dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmamd_colsum(x.data_ptr(), _dt(x), rows, n, out.data_ptr(), ws.data_ptr(), _stream()), "mmamd_colsum")
+    return out
+
+
+def act_fwd(u: torch.Tensor, act: int) -> torch.Tensor:
+    _chk(u, "u", torch.bfloat16)
+    g = torch.empty_like(u)
+    check(_lib.lib().mmamd_act_fwd(u.data_ptr(), g.data_ptr(), u.numel(), int(act), _stream()), "mmamd_act_fwd")
+    return g
+
+
+def act_bwd(u: torch.Tensor, dg: torch.Tensor, act: int) -> torch.Tensor:
+    _chk(u, "u", torch.bfloat16); _chk(dg, "dg", torch.bfloat16)
+    du = torch.empty_like(u)
+    check(_lib.lib().mmamd_act_bwd(u.data_ptr(), dg.data_ptr(), du.data_ptr(), u.numel(), int(act), _stream()), "mmamd_act_bwd")
+    return du
+
+
+def transpose_to_bf16(src: torch.Tensor, pad_to: int = 64) -> torch.Tensor:
+    """[rows, cols] fp32/bf16 (row pitch = stride(0)) -> bf16 [cols, rows rounded up to pad_to] with a zero tail."""
+    if not (src.is_cuda and src.dim() == 2 and src.stride(1) == 1 and src.dtype in (torch.float32, torch.bfloat16)):
+        raise MmamdError("transpose_to_bf16: need a 2-D fp32/bf16 HIP matrix with unit inner stride")
+    rows, cols = src.shape
+    ld = (rows + pad_to - 1) // pad_to * pad_to
+    dst = torch.empty((cols, ld), dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().mmamd_transpose_to_bf16(src.data_ptr(), _dt(src), src.stride(0), dst.data_ptr(), rows, cols, ld, _stream()),
+          "mmamd_transpose_to_bf16")
+    return dst
+
+
+def l2_normalize_bwd(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    _chk(x, "x", torch.float32); _chk(dy, "dy", torch.float32)
+    dx = torch.empty_like(x)
+    check(_lib.lib().mmamd_l2_normalize_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1], float(eps), _stream()),
+          "mmamd_l2_normalize_bwd")
+    return dx
+
+
+def scatter_add_rows_(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> None:
+    """dst[idx[i]] += src[i] (fp32 atomics)."""
+    _chk(dst, "dst", torch.float32); _chk(src, "src", torch.float32); _chk(idx, "idx", torch.int64)
+    check(_lib.lib().mmamd_scatter_add_rows(src.data_ptr(), idx.data_ptr(), idx.numel(), src.shape[-1], dst.data_ptr(), dst.shape[0],
+                                            _stream()), "mmamd_scatter_add_rows")
+
+
+def f32_gemm_strided(X: torch.Tensor, sxm: int, sxk: int, Y: torch.Tensor, syn: int, syk: int, M: int, N: int, K: int) -> torch.Tensor:
+    """C[M,N] = sum_k X[m*sxm + k*sxk] * Y[n*syn + k*syk] in exact fp32 (element strides into the two fp32 buffers)."""
+    _chk(X, "X", torch.float32); _chk(Y, "Y", torch.float32)
+    if (M - 1) * sxm + (K - 1) * sxk >= X.numel() or (N - 1) * syn + (K - 1) * syk >= Y.numel():
+        raise MmamdError("f32_gemm_strided: strides run past the end of an operand")
+    C = torch.empty((M, N), dtype=torch.float32, device=X.device)
+    check(_lib.lib().mmamd_f32_gemm_strided(X.data_ptr(), sxm, sxk, Y.data_ptr(), syn, syk, None, 0, C.data_ptr(), N, M, N, K, _stream()),
+          "mmamd_f32_gemm_strided")
+    return C
 
 
 def convert(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

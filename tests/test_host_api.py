@@ -60,12 +60,18 @@ def test_no_cpu_fallback():
         ContrastiveLossWithTemperature()(torch.zeros(2, 4), torch.zeros(2, 4))
 
 
-def test_training_forward_is_refused():
+def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
+    """CLIP has a differentiable (training) forward on the HIP kernels; like everything else it has no CPU path.  FLAVA / CoCa
+    are forward-only: a training-mode forward with grad enabled is refused instead of silently returning detached outputs."""
+    from multimodal_amd import ops
     from multimodal_amd.models.clip import CLIPViTEncoder
+    from multimodal_amd.models.flava.transformer import TransformerEncoder
 
     vit = CLIPViTEncoder(embedding_dim=8, heads=1, layers=1, patch_size=16, image_size=32, width=64).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ops.MmamdError, match="no CPU"):
         vit(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(NotImplementedError, match="backward"):
+        TransformerEncoder(1, 128, 2, 256).train()(torch.zeros(1, 4, 128))
 
 
 def test_input_guards_match_reference():
