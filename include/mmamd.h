@@ -82,6 +82,12 @@ int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float*
 int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                         mmamd_stream_t stream);
 
+/* Split-K form of the same GEMM for weight gradients: C[M,N] (fp32, ldc = N) = A[M,K] . W[N,K]^T with a long contraction
+ * (K = tokens, a multiple of 128) and few output tiles: the K range is cut into `splits` chunks (one grid row each), partial
+ * outputs go to ws (splits * M * N floats) and are summed by a second kernel.  dW = dY^T X of every nn.Linear on the path. */
+int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
+                           mmamd_stream_t stream);
+
 /* Same, additionally returning the attention probabilities (normalised, [B,H,S,S], probs_dtype F32 or BF16) and honouring a
  * key-padding mask (uint8 [B,S], 0 = masked key, NULL = none).  Non-causal.  Replaces scaled_dot_product_attention of
  * modules/layers/attention.py:185-241 as FLAVA's encoders call it (models/flava/transformer.py:155-176 with

@@ -60,6 +60,8 @@ struct GemmArgs {
   int lda, ldw, ldr, ldc;
   int act;
   int tiles_n;
+  int kt_chunk;             // split-K (weight gradients): K-tiles (of 64) per split, blockIdx.y = split; 0 = no split
+  long long c_split_stride; // elements between the partial outputs of consecutive splits
 };
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
@@ -530,8 +532,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     r = r < p.N ? r : p.N - 1;
     b_off[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
   }
-  const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W);
+  // split-K: this block owns K-tiles [kt0, kt0 + KT) and writes its own partial output (no bias / residual / activation)
+  const int kt0 = p.kt_chunk > 0 ? (int)blockIdx.y * p.kt_chunk : 0;
+  const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * 128;
+  const char* Wb = reinterpret_cast<const char*>(p.W) + (size_t)kt0 * 128;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
   // piece i of a stage (i < A_INSTR: activation rows, else weight rows): scalar base + K offset, per-lane 32-bit offset
   auto issue_piece = [&](int buf, int kt, int i) {
@@ -665,7 +669,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
       for (int i = 0; i < phase * 2; ++i) __builtin_amdgcn_s_sleep(127);  // 127*64 cycles ~ 3.4 us each -> ~T/4 per phase
     }
   }
-  const int KT = p.K >> 6;  // even (checked by the launcher): two tiles per trip, the buffer index is a compile-time constant
+  // even (checked by the launcher): two tiles per trip, the buffer index is a compile-time constant
+  const int KT = p.kt_chunk > 0 ? ((p.K >> 6) - kt0 < p.kt_chunk ? (p.K >> 6) - kt0 : p.kt_chunk) : (p.K >> 6);
   issue_stage(0, 0);
 #pragma unroll 1
   for (int kt = 0; kt < KT; kt += 2) {
@@ -690,8 +695,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     if (ssum == 1.2345678e33f) reinterpret_cast<float*>(p.C)[0] = ssum;
     return;
   }
-  if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, p, m0, n0, wm, wn, lane, wave, smem);
-  else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane);
+  GemmArgs pe = p;
+  if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * (size_t)p.c_split_stride;
+  if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, pe, m0, n0, wm, wn, lane, wave, smem);
+  else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, pe, m0, n0, wm, wn, lane);
   if constexpr ((ABL & 64) != 0) {
     stamp();                                           // stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores retired
@@ -1908,8 +1915,60 @@ extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, c
   GemmArgs p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.R = residual; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.act = act; p.tiles_n = 0;
+  p.kt_chunk = 0; p.c_split_stride = 0;
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == MMAMD_F32) return dispatch<true>(p, st);
   if (out_dtype == MMAMD_BF16) return dispatch<false>(p, st);
   MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "gemm: bad out_dtype %d", out_dtype);
+}
+
+// column-wise sum of `splits` partial outputs (second stage of the split-K weight-gradient GEMM)
+namespace mmamd {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, float* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 acc = load4(part + i);
+  for (int s = 1; s < splits; ++s) {
+    const f32x4 v = load4(part + (size_t)s * n + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += v[j];
+  }
+  store4(out + i, acc);
+}
+}  // namespace mmamd
+
+extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K,
+                                      int splits, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(A && W && C && ws && M > 0 && N > 0 && K > 0 && splits >= 1, MMAMD_E_BADARG, "gemm_splitk: bad argument");
+  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_splitk: K=%d must be a multiple of 128 (pad the operands)", K);
+  MMAMD_CHECK_ARG(N % 8 == 0 && (M * (long long)N) % 4 == 0, MMAMD_E_UNSUPPORTED, "gemm_splitk: N=%d must be a multiple of 8", N);
+  MMAMD_CHECK_ARG(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "gemm_splitk: bad leading dimension");
+  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws), MMAMD_E_ALIGN, "gemm_splitk: base pointers must be 16-byte aligned");
+  MMAMD_CHECK_ARG((uint64_t)M * (uint64_t)lda * 2u < (1ull << 32) && (uint64_t)N * (uint64_t)ldw * 2u < (1ull << 32),
+                  MMAMD_E_UNSUPPORTED, "gemm_splitk: operand exceeds the 4 GiB 32-bit DMA offset range");
+  const int KT = K / 64;
+  int chunk = (KT + splits - 1) / splits;
+  chunk += chunk & 1;  // even number of K-tiles per split (the K loop is unrolled by two); KT is even, so is the remainder
+  const int nsplit = (KT + chunk - 1) / chunk;
+  GemmArgs p;
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = nullptr; p.R = nullptr; p.C = nsplit == 1 ? C : ws;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = N; p.act = MMAMD_ACT_NONE;
+  p.kt_chunk = chunk; p.c_split_stride = (long long)M * N;
+  constexpr int smem = 2 * 512 * 128;
+  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("gemm_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tiles_m = (M + 255) / 256;
+  p.tiles_n = (N + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, nsplit), dim3(512), smem, st, p, tiles_m, nullptr);
+  if (nsplit > 1) {
+    const long long n = (long long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit, n, C);
+  }
+  return launch_status("gemm_bf16_splitk");
 }

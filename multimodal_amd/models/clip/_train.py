@@ -44,15 +44,15 @@ def _dgrad(dy: Tensor, w: Tensor, out_dtype) -> Tensor:
     N = w.shape[0]
     if N % 64 != 0:
         raise ops.MmamdError(f"backward GEMM: output width {N} of a Linear must be a multiple of 64")
-    wT = ops.transpose_to_bf16(w)  # bf16 [K, N]
+    wT = ops.transpose_to_bf16(w, pad_to=64)  # bf16 [K, N]
     return ops.gemm_bf16(dy, wT, None, out_dtype=out_dtype)
 
 
 def _wgrad(dy: Tensor, x: Tensor) -> Tensor:
     """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens, zero-padded to 64."""
-    dyT = ops.transpose_to_bf16(dy)  # [N, Mp]
+    dyT = ops.transpose_to_bf16(dy)  # [N, Mp]   (Mp = tokens rounded up to 128, zero tail)
     xT = ops.transpose_to_bf16(x)    # [K, Mp]
-    return ops.gemm_bf16(dyT, xT, None, out_dtype=f32)
+    return ops.gemm_bf16_splitk(dyT, xT)
 
 
 class StackFn(torch.autograd.Function):

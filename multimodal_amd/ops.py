@@ -20,7 +20,7 @@ __all__ = [
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd",
-    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk",
 ]
 
 
@@ -92,6 +92,23 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
                                      N, _dt(out), M, N, K, int(act), _stream()), "mmamd_gemm_bf16")
     if timer is not None:
         timer.stop()
+    return out
+
+
+def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 1024) -> torch.Tensor:
+    """fp32 [M,N] = a[M,K] @ w[N,K]^T for a LONG contraction (K % 128 == 0) and few output tiles (weight gradients): the K range
+    is split over grid rows so that about `target_blocks` workgroups run, partials summed by a second kernel."""
+    _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise MmamdError(f"gemm_splitk: inner dims differ ({K} vs {w.shape[1]})")
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    splits = max(1, min(K // 128, (target_blocks + tiles - 1) // tiles))
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ws = torch.empty((splits + 1) * M * N if splits > 1 else 4, dtype=torch.float32, device=a.device)
+    check(_lib.lib().mmamd_gemm_bf16_splitk(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), ws.data_ptr(), M, N, K, splits, _stream()),
+          "mmamd_gemm_bf16_splitk")
     return out
 
 
@@ -543,7 +560,7 @@ def act_bwd(u: torch.Tensor, dg: torch.Tensor, act: int) -> torch.Tensor:
     return du
 
 
-def transpose_to_bf16(src: torch.Tensor, pad_to: int = 64) -> torch.Tensor:
+def transpose_to_bf16(src: torch.Tensor, pad_to: int = 128) -> torch.Tensor:
     """[rows, cols] fp32/bf16 (row pitch = stride(0)) -> bf16 [cols, rows rounded up to pad_to] with a zero tail."""
     if not (src.is_cuda and src.dim() == 2 and src.stride(1) == 1 and src.dtype in (torch.float32, torch.bfloat16)):
         raise MmamdError("transpose_to_bf16: need a 2-D fp32/bf16 HIP matrix with unit inner stride")

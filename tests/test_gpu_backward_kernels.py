@@ -95,7 +95,7 @@ def test_activation_transpose_normalize_scatter_kernels():
         assert np.abs(host(ops.act_bwd(u.cuda(), dg.cuda(), act)) - ud.grad.numpy()).max() <= 2 ** -6 * max(1.0, float(ud.grad.abs().max()))
     for rows, cols, dt in ((197, 128, torch.float32), (1000, 768, torch.bfloat16), (5, 3, torch.float32)):
         src = torch.randn(rows, cols + 8).to(dt)
-        t = ops.transpose_to_bf16(src.cuda()[:, :cols])
+        t = ops.transpose_to_bf16(src.cuda()[:, :cols], pad_to=64)
         ld = (rows + 63) // 64 * 64
         assert t.shape == (cols, ld)
         assert torch.equal(t[:, :rows].cpu(), src[:, :cols].to(torch.bfloat16).t()) and not t[:, rows:].any()
@@ -115,6 +115,13 @@ def test_activation_transpose_normalize_scatter_kernels():
     assert np.abs(host(C) - (X.double() @ Y.double().t()).numpy()).max() <= 1e-5
     C2 = ops.f32_gemm_strided(X.cuda(), 1, 33, Y.cuda(), 1, 33, 33, 33, 5)  # X^T Y over the first 5 rows
     assert np.abs(host(C2) - (X[:5].double().t() @ Y.double()).numpy()).max() <= 1e-5
+    # split-K weight-gradient GEMM: long contraction, few output tiles
+    for (M, N, K) in ((768, 3072, 50432), (128, 256, 512), (2304, 768, 6400)):
+        a = torch.randn(M, K).to(torch.bfloat16)
+        w = (torch.randn(N, K) * 0.1).to(torch.bfloat16)
+        got = host(ops.gemm_bf16_splitk(a.cuda(), w.cuda()))
+        ref = host(a.cuda().float() @ w.cuda().float().t())  # fp32 reference of the same bf16 operands (ATen, test only)
+        assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), (M, N, K)
 
 
 def test_clip_training_step_gradients_vs_reference_autograd(golden):

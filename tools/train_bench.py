@@ -1,0 +1,61 @@
+"""CLIP ViT-B/16 TRAINING step on one MI355X (forward + loss + backward + SGD step), B = 256 synthetic pairs:
+    python tools/train_bench.py [--batch 256] [--steps 5]
+Algorithmic FLOPs = 3 x the forward's 41.09 GF/pair (backward = dgrad + wgrad of every GEMM + attention backward at 2.5x).
+Prints one JSON line."""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    from multimodal_amd.models.clip import clip_vit_b16
+    from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    model = clip_vit_b16().to(dev).train()
+    loss_fn = ContrastiveLossWithTemperature().to(dev)
+    opt = torch.optim.SGD(list(model.parameters()) + list(loss_fn.parameters()), lr=1e-4)
+    images, ids = clip_batch(a.batch)
+    images, ids = images.to(dev), ids.to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(images, ids)
+        loss = loss_fn(out.embeddings_a, out.embeddings_b)
+        loss.backward()
+        opt.step()
+        return loss
+
+    losses = []
+    for _ in range(a.warmup):
+        losses.append(float(step()))
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(a.steps):
+        loss = step()
+    t1.record()
+    torch.cuda.synchronize()
+    losses.append(float(loss))
+    ms = t0.elapsed_time(t1) / a.steps
+    gf = 3 * 41.09
+    print(json.dumps({"workload": "CLIP ViT-B/16 training step (fwd + contrastive loss + bwd + SGD), synthetic", "batch": a.batch,
+                      "ms_per_step": round(ms, 3), "pairs_per_s": round(a.batch / ms * 1e3, 1), "gflop_per_pair": gf,
+                      "tflops": round(a.batch * gf / ms, 1), "mfma_frac": round(a.batch * gf / ms / 2500.0, 4),
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "losses": [round(x, 4) for x in losses]}))
+
+
+if __name__ == "__main__":
+    main()
