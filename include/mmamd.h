@@ -227,9 +227,11 @@ int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* w
 int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream);
 int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n, int act, mmamd_stream_t stream);
 /* dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) for r < rows, 0 for rows <= r < ld_dst: operands of the weight-gradient GEMM
- * dW[N,K] = dY^T X computed by mmamd_gemm_bf16 as (dY^T)[N,M] . (X^T)[K,M]^T with the token index M as contraction. */
+ * dW[N,K] = dY^T X computed by mmamd_gemm_bf16 as (dY^T)[N,M] . (X^T)[K,M]^T with the token index M as contraction.
+ * colsum (optional, [cols] fp32) = column sums of the bf16-rounded source = the bias gradient of the same dY, produced in the same
+ * pass; ws: ceil(ld_dst/64) * cols floats when colsum is given. */
 int mmamd_transpose_to_bf16(const void* src, int src_dtype, int64_t ld_src, void* dst, int rows, int cols, int ld_dst,
-                            mmamd_stream_t stream);
+                            float* colsum, float* ws, mmamd_stream_t stream);
 /* F.normalize backward (fp32): dx = (dy - y (y.dy)) / max(|x|, eps). */
 int mmamd_l2_normalize_bwd(const float* x, const float* dy, float* dx, int rows, int d, float eps, mmamd_stream_t stream);
 /* dst[idx[i], :] += src[i, :] with fp32 atomics (embedding-table gradient; pooled-row gradient into the sequence). */

@@ -40,7 +40,7 @@ PROTOTYPES = {
     "mmamd_colsum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
-    "mmamd_transpose_to_bf16": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _vp]),
+    "mmamd_transpose_to_bf16": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_l2_normalize_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "mmamd_scatter_add_rows": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "mmamd_f32_gemm_strided": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

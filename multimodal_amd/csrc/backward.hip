@@ -158,20 +158,62 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ u
 // ---------------------------------------------------------------------------------------------
 // bf16 transpose with zero padding: dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < ld_dst   (64 x 64 tiles through LDS)
 // ---------------------------------------------------------------------------------------------
+// 64 x 64 tiles through LDS, 8-byte global accesses on both sides (bf16 source) — and, optionally, the column sums of the
+// source on the way (colpart[blockIdx.y][c] = sum of this tile's 64 rows of column c): every dY that is transposed for a
+// weight-gradient GEMM is also the operand of a bias gradient, so the separate column-sum pass over it disappears.
 template <typename TS>
 __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const TS* __restrict__ src, int64_t ld_src, bf16* __restrict__ dst,
-                                                                int rows, int cols, int ld_dst) {
-  __shared__ bf16 tile[64][66];
+                                                                int rows, int cols, int ld_dst, float* __restrict__ colpart) {
+  __shared__ bf16 tile[64][68];  // row pitch 136 B: 8-byte aligned rows
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int i = ty; i < 64; i += 4) {
-    const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < rows && c < cols) ? (bf16)to_f32(src[(size_t)r * ld_src + c]) : (bf16)0.f;
+  const int t = threadIdx.x;
+  const int lr = t >> 4, lc = (t & 15) * 4;  // load: 16 threads x 4 columns per row, 16 rows per pass
+  const bool vec = ((ld_src & 3) == 0) && (c0 + 64 <= cols) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int r = r0 + ps * 16 + lr;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      if (vec) v = load4(src + (size_t)r * ld_src + c0 + lc);
+      else
+        for (int j = 0; j < 4; ++j)
+          if (c0 + lc + j < cols) v[j] = to_f32(src[(size_t)r * ld_src + c0 + lc + j]);
+    }
+    bf16x4 b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b[j] = (bf16)v[j]; csum[j] += (float)b[j]; }
+    *reinterpret_cast<bf16x4*>(&tile[ps * 16 + lr][lc]) = b;
   }
   __syncthreads();
-  for (int i = ty; i < 64; i += 4) {
-    const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+  // store: thread = (dst row = source column sc, 4 consecutive dst columns = source rows sr..sr+3)
+  const int sc = t >> 4, sr = (t & 15) * 4;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int c = c0 + ps * 16 + sc;
+    const int r = r0 + sr;
+    if (c < cols && r < ld_dst) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = tile[sr + j][ps * 16 + sc];
+      if (r + 3 < ld_dst) *reinterpret_cast<bf16x4*>(dst + (size_t)c * ld_dst + r) = o;
+      else
+        for (int j = 0; j < 4 && r + j < ld_dst; ++j) dst[(size_t)c * ld_dst + r + j] = o[j];
+    }
+  }
+  if (colpart != nullptr) {
+    // the 16 threads with the same (t & 15) hold partial sums of the same 4 columns over different rows: reduce through LDS
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&tile[0][0]);  // 16 x 64 floats = 4 KiB <= 8.7 KiB
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[lr * 64 + lc + j] = csum[j];
+    __syncthreads();
+    if (t < 64) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += red[i * 64 + t];
+      if (c0 + t < cols) colpart[(size_t)blockIdx.y * cols + c0 + t] = sum;
+    }
   }
 }
 
@@ -260,13 +302,17 @@ extern "C" int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n,
 }
 
 extern "C" int mmamd_transpose_to_bf16(const void* src, int src_dtype, int64_t ld_src, void* dst, int rows, int cols, int ld_dst,
-                                       mmamd_stream_t stream) {
+                                       float* colsum, float* ws, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, MMAMD_E_BADARG, "transpose: bad argument");
+  MMAMD_CHECK_ARG(ld_dst % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, MMAMD_E_ALIGN, "transpose: dst rows must be 8-byte aligned");
+  MMAMD_CHECK_ARG(colsum == nullptr || ws != nullptr, MMAMD_E_BADARG, "transpose: colsum needs a workspace");
   const dim3 grid((cols + 63) / 64, (ld_dst + 63) / 64);
   hipStream_t st = (hipStream_t)stream;
-  if (src_dtype == MMAMD_BF16) hipLaunchKernelGGL((transpose_to_bf16_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, ld_src, (bf16*)dst, rows, cols, ld_dst);
-  else if (src_dtype == MMAMD_F32) hipLaunchKernelGGL((transpose_to_bf16_kernel<float>), grid, dim3(256), 0, st, (const float*)src, ld_src, (bf16*)dst, rows, cols, ld_dst);
+  float* part = colsum ? ws : nullptr;  // [grid.y][cols]
+  if (src_dtype == MMAMD_BF16) hipLaunchKernelGGL((transpose_to_bf16_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)src, ld_src, (bf16*)dst, rows, cols, ld_dst, part);
+  else if (src_dtype == MMAMD_F32) hipLaunchKernelGGL((transpose_to_bf16_kernel<float>), grid, dim3(256), 0, st, (const float*)src, ld_src, (bf16*)dst, rows, cols, ld_dst, part);
   else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "transpose: bad dtype");
+  if (colsum != nullptr) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, ws, (int)grid.y, cols, colsum);
   return launch_status("transpose_to_bf16");
 }
 

@@ -48,11 +48,16 @@ def _dgrad(dy: Tensor, w: Tensor, out_dtype) -> Tensor:
     return ops.gemm_bf16(dy, wT, None, out_dtype=out_dtype)
 
 
-def _wgrad(dy: Tensor, x: Tensor) -> Tensor:
-    """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens, zero-padded to 64."""
-    dyT = ops.transpose_to_bf16(dy)  # [N, Mp]   (Mp = tokens rounded up to 128, zero tail)
+def _wgrad(dy: Tensor, x: Tensor, bias: bool = False):
+    """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens (zero-padded to 128).
+    bias=True also returns db[N] = column sums of dY, produced by the same transpose pass over dY."""
+    if bias:
+        dyT, db = ops.transpose_to_bf16(dy, with_colsum=True)  # [N, Mp]
+    else:
+        dyT, db = ops.transpose_to_bf16(dy), None
     xT = ops.transpose_to_bf16(x)    # [K, Mp]
-    return ops.gemm_bf16_splitk(dyT, xT)
+    dW = ops.gemm_bf16_splitk(dyT, xT)
+    return (dW, db) if bias else dW
 
 
 class StackFn(torch.autograd.Function):
@@ -96,24 +101,20 @@ class StackFn(torch.autograd.Function):
             dXb = ops.convert(dX, bf)
             # x_out = x_mid + g W2^T + b2
             dg = _dgrad(dXb, W2, bf)
-            dW2 = _wgrad(dXb, g)
-            db2 = ops.colsum(dX)
+            dW2, db2 = _wgrad(dXb, g, bias=True)
             du = ops.act_bwd(u, dg, ops.ACT_QUICKGELU)
             # u = h2 W1^T + b1
             dh2 = _dgrad(du, W1, f32)
-            dW1 = _wgrad(du, h2)
-            db1 = ops.colsum(du)
+            dW1, db1 = _wgrad(du, h2, bias=True)
             dx_mid, dg2, dbe2 = ops.layernorm_bwd(x_mid, g2, dh2, layer.norm2.eps, add=dX)
             # x_mid = x + att Wo^T + bo
             dxmb = ops.convert(dx_mid, bf)
             datt = _dgrad(dxmb, Wo, bf)
-            dWo = _wgrad(dxmb, att)
-            dbo = ops.colsum(dx_mid)
+            dWo, dbo = _wgrad(dxmb, att, bias=True)
             dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal)
             # qkv = h1 Wqkv^T + bqkv
             dh1 = _dgrad(dqkv, Wqkv, f32)
-            dWqkv = _wgrad(dqkv, h1)
-            dbqkv = ops.colsum(dqkv)
+            dWqkv, dbqkv = _wgrad(dqkv, h1, bias=True)
             dX, dg1, dbe1 = ops.layernorm_bwd(x, g1, dh1, layer.norm1.eps, add=dx_mid)
             grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
         return (dX, None, None, None, None, *grads)

@@ -95,7 +95,7 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out
 
 
-def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 1024) -> torch.Tensor:
+def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 512) -> torch.Tensor:
     """fp32 [M,N] = a[M,K] @ w[N,K]^T for a LONG contraction (K % 128 == 0) and few output tiles (weight gradients): the K range
     is split over grid rows so that about `target_blocks` workgroups run, partials summed by a second kernel."""
     _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16)
@@ -560,16 +560,21 @@ def act_bwd(u: torch.Tensor, dg: torch.Tensor, act: int) -> torch.Tensor:
     return du
 
 
-def transpose_to_bf16(src: torch.Tensor, pad_to: int = 128) -> torch.Tensor:
-    """[rows, cols] fp32/bf16 (row pitch = stride(0)) -> bf16 [cols, rows rounded up to pad_to] with a zero tail."""
+def transpose_to_bf16(src: torch.Tensor, pad_to: int = 128, with_colsum: bool = False):
+    """[rows, cols] fp32/bf16 (row pitch = stride(0)) -> bf16 [cols, rows rounded up to pad_to] with a zero tail.  With
+    with_colsum=True also returns the fp32 column sums of the (bf16-rounded) source, computed in the same pass."""
     if not (src.is_cuda and src.dim() == 2 and src.stride(1) == 1 and src.dtype in (torch.float32, torch.bfloat16)):
         raise MmamdError("transpose_to_bf16: need a 2-D fp32/bf16 HIP matrix with unit inner stride")
     rows, cols = src.shape
     ld = (rows + pad_to - 1) // pad_to * pad_to
     dst = torch.empty((cols, ld), dtype=torch.bfloat16, device=src.device)
-    check(_lib.lib().mmamd_transpose_to_bf16(src.data_ptr(), _dt(src), src.stride(0), dst.data_ptr(), rows, cols, ld, _stream()),
-          "mmamd_transpose_to_bf16")
-    return dst
+    cs = ws = None
+    if with_colsum:
+        cs = torch.empty(cols, dtype=torch.float32, device=src.device)
+        ws = torch.empty(((ld + 63) // 64) * cols, dtype=torch.float32, device=src.device)
+    check(_lib.lib().mmamd_transpose_to_bf16(src.data_ptr(), _dt(src), src.stride(0), dst.data_ptr(), rows, cols, ld, _ptr(cs), _ptr(ws),
+                                             _stream()), "mmamd_transpose_to_bf16")
+    return (dst, cs) if with_colsum else dst
 
 
 def l2_normalize_bwd(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:

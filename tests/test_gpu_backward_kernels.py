@@ -95,10 +95,13 @@ def test_activation_transpose_normalize_scatter_kernels():
         assert np.abs(host(ops.act_bwd(u.cuda(), dg.cuda(), act)) - ud.grad.numpy()).max() <= 2 ** -6 * max(1.0, float(ud.grad.abs().max()))
     for rows, cols, dt in ((197, 128, torch.float32), (1000, 768, torch.bfloat16), (5, 3, torch.float32)):
         src = torch.randn(rows, cols + 8).to(dt)
-        t = ops.transpose_to_bf16(src.cuda()[:, :cols], pad_to=64)
+        t, cs = ops.transpose_to_bf16(src.cuda()[:, :cols], pad_to=64, with_colsum=True)
         ld = (rows + 63) // 64 * 64
         assert t.shape == (cols, ld)
         assert torch.equal(t[:, :rows].cpu(), src[:, :cols].to(torch.bfloat16).t()) and not t[:, rows:].any()
+        want = src[:, :cols].to(torch.bfloat16).double().sum(0).numpy()
+        assert np.abs(host(cs) - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+        assert torch.equal(ops.transpose_to_bf16(src.cuda()[:, :cols], pad_to=128)[:, :rows], t[:, :rows])
     x = torch.randn(50, 64, dtype=torch.float64, requires_grad=True)
     dy = torch.randn(50, 64, dtype=torch.float64)
     torch.nn.functional.normalize(x, dim=1).backward(dy)
