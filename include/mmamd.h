@@ -82,6 +82,10 @@ int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float*
 int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                         mmamd_stream_t stream);
 
+/* mmamd_attention_fwd that also saves the log2-domain log-sum-exp [B,H,S] (fp32) of the scaled scores for mmamd_attention_bwd. */
+int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale,
+                            mmamd_stream_t stream);
+
 /* Split-K form of the same GEMM for weight gradients: C[M,N] (fp32, ldc = N) = A[M,K] . W[N,K]^T with a long contraction
  * (K = tokens, a multiple of 128) and few output tiles: the K range is cut into `splits` chunks (one grid row each), partial
  * outputs go to ws (splits * M * N floats) and are summed by a second kernel.  dW = dY^T X of every nn.Linear on the path. */

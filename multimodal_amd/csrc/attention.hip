@@ -40,7 +40,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // ABL (timing experiments only, results WRONG): 1 = V staged row-major, 2 = no exp, 4 = no K/V global loads
 template <int NKT, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                            int S, int H, int BH, float scale_log2e) {
+                                                            int S, int H, int BH, float scale_log2e, float* __restrict__ lse) {
   constexpr int SP = NKT * 32;   // padded key count
   constexpr int VS = SP + 4;     // V^T row stride (elements): (SP+4)/2 dwords = 2 (mod 4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -202,6 +202,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
       // ---- normalise and store: lane owns row q, channels nt*32 + 8g + 4*half + {0..3}
       lsum += __shfl_xor(lsum, 32);
       const float inv = 1.0f / lsum;
+      // training: log2-domain log-sum-exp for the backward kernels (m is the running REFERENCE, not necessarily the max: m + log2(sum) is exact either way)
+      if (lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __builtin_amdgcn_logf(lsum);
       if (q < S) {
         bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
 #pragma unroll
@@ -922,7 +924,7 @@ static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const
 static int g_attn_variant = 0;
 
 template <int NKT, bool CAUSAL, int ABL = 0>
-static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st) {
+static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st, float* lse = nullptr) {
   constexpr int SP = NKT * 32;
   constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2;
   auto kern = attention_fwd_kernel<NKT, CAUSAL, ABL>;
@@ -935,7 +937,7 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
   const int BH = B * H;
   const int grid = BH < 512 ? BH : 512;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,
-                     scale * 1.4426950408889634f);
+                     scale * 1.4426950408889634f, lse);
   return launch_status("attention_fwd");
 }
 
@@ -948,8 +950,20 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
   return 0;
 }
 
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream);
+
 extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                                    mmamd_stream_t stream) {
+  return attention_fwd_impl(qkv, out, nullptr, B, S, H, causal, scale, stream);
+}
+
+extern "C" int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale,
+                                       mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(lse != nullptr, MMAMD_E_BADARG, "attention_fwd_lse: lse is NULL");
+  return attention_fwd_impl(qkv, out, lse, B, S, H, causal, scale, stream);
+}
+
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(qkv && out && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention: bad argument");
   MMAMD_CHECK_ARG(S <= 288, MMAMD_E_UNSUPPORTED, "attention: S=%d > 288 not supported (single-pass LDS kernel)", S);
   MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out), MMAMD_E_ALIGN, "attention: pointers must be 16-byte aligned");
@@ -967,8 +981,8 @@ extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int
   }
 #define ATTN_CASE(N)                                                              \
   case N:                                                                         \
-    return causal ? launch_attn<N, true>(qkv, out, B, S, H, scale, st)            \
-                  : launch_attn<N, false>(qkv, out, B, S, H, scale, st);
+    return causal ? launch_attn<N, true>(qkv, out, B, S, H, scale, st, lse)       \
+                  : launch_attn<N, false>(qkv, out, B, S, H, scale, st, lse);
   switch (nkt) {
     ATTN_CASE(1) ATTN_CASE(2) ATTN_CASE(3) ATTN_CASE(4) ATTN_CASE(5) ATTN_CASE(6) ATTN_CASE(7) ATTN_CASE(8) ATTN_CASE(9)
   }

@@ -206,7 +206,9 @@ def attention_fwd_train(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool)
     if qkv.shape != (B * S, 3 * D):
         raise MmamdError(f"attention: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * D)}")
     lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
-    out, _ = attention_x_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, S, H, 64, AttnMask(causal=causal), lse=lse)
+    out = torch.empty((B * S, D), dtype=torch.bfloat16, device=qkv.device)
+    check(_lib.lib().mmamd_attention_fwd_lse(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, int(bool(causal)),
+                                             1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_fwd_lse")
     return out, lse
 
 
