@@ -174,3 +174,48 @@ def test_clip_training_step_gradients_vs_reference_autograd(golden):
         clip.eval()
         out2 = clip(torch.from_numpy(z["images"]).cuda(), torch.from_numpy(z["ids"]).cuda())
     assert out2.embeddings_a.grad_fn is None
+
+
+def test_training_step_under_ddp_single_rank_rccl():
+    """DistributedDataParallel over RCCL wraps the drop-in CLIP (parameters are ordinary nn.Parameters, gradients ordinary tensors):
+    same gradients as without DDP; the loss's GLOBAL backprop goes through its reduce-scatter-free single-rank path."""
+    import os
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
+    from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        set_rng_seed(5)
+        vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=1, patch_size=16, image_size=32, width=128)
+        txt = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=300, width=128, dim_feedforward=256, heads=2, layers=1)
+        clip = CLIP(vit, txt).cuda().train()
+        loss_fn = ContrastiveLossWithTemperature().cuda()
+        images, ids = clip_batch(8, image_size=32, vocab_size=300)
+        images, ids = images.cuda(), ids.cuda()
+
+        def grads(model):
+            for p in list(model.parameters()) + list(loss_fn.parameters()):
+                p.grad = None
+            out = model(images, ids)
+            loss_fn(out.embeddings_a, out.embeddings_b).backward()
+            return {k: p.grad.detach().clone() for k, p in clip.named_parameters()}, loss_fn.logit_scale.grad.clone()
+
+        g_plain, s_plain = grads(clip)
+        ddp = DDP(clip, device_ids=[0])
+        g_ddp, s_ddp = grads(ddp)
+        for k in g_plain:  # all-reduce over one rank = identity; the embedding-table gradient uses fp32 atomics (order varies)
+            assert torch.allclose(g_plain[k], g_ddp[k], rtol=1e-4, atol=1e-6 * float(g_plain[k].abs().max() + 1e-12)), k
+        assert torch.allclose(s_plain, s_ddp, rtol=1e-5)
+    finally:
+        if created:
+            dist.destroy_process_group()
