@@ -79,8 +79,7 @@ class CLIP(nn.Module):
 
         if os.environ.get("MMAMD_SINGLE_STREAM") == "1" or not isinstance(ref, torch.Tensor) or not ref.is_cuda:
             return None
-        if torch.cuda.is_current_stream_capturing():
-            return None
+        # (during graph capture the fork / join below is captured too: the side stream joins the capture through wait_stream)
         s = _SIDE_STREAMS.get(ref.device)  # process-wide, not a module attribute (modules stay deep-copyable/picklable)
         if s is None:
             s = torch.cuda.Stream(device=ref.device)

@@ -231,3 +231,41 @@ def test_global_loss_over_rccl_single_rank(golden, tmp_path):
                 np.testing.assert_allclose(host(lo.logits_a), z[f"w1.{bp.name}.r0.logits_a"], atol=1e-4)
     finally:
         dist.destroy_process_group()
+
+
+def test_forward_is_graph_capturable_and_replays_bit_identically():
+    """The C-ABI neither allocates nor synchronises: the two-tower forward + loss can be captured into one HIP graph
+    (torch.cuda.CUDAGraph) and replayed on new inputs copied into the captured buffers."""
+    from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
+    from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    set_rng_seed(7)
+    vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=2, patch_size=16, image_size=64, width=128)
+    txt = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=1000, width=128, dim_feedforward=256, heads=2, layers=2)
+    clip = CLIP(vit, txt).cuda().eval()
+    loss_fn = ContrastiveLossWithTemperature().cuda()
+    im1, id1 = clip_batch(6, image_size=64, vocab_size=1000, rank=1)
+    im2, id2 = clip_batch(6, image_size=64, vocab_size=1000, rank=2)
+    s_im, s_id = im1.cuda().clone(), id1.cuda().clone()
+    with torch.no_grad():
+        for _ in range(2):  # warm-up: parameter packing, lazy handles
+            o = clip(s_im, s_id)
+            loss_fn(o.embeddings_a, o.embeddings_b)
+        eager = []
+        for im, idt in ((im1, id1), (im2, id2)):
+            o = clip(im.cuda(), idt.cuda())
+            eager.append((o.embeddings_a.clone(), o.embeddings_b.clone(), loss_fn(o.embeddings_a, o.embeddings_b).clone()))
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                o = clip(s_im, s_id)
+                l = loss_fn(o.embeddings_a, o.embeddings_b)
+        torch.cuda.current_stream().wait_stream(side)
+        for (im, idt), (ea, eb, el) in zip(((im1, id1), (im2, id2)), eager):
+            s_im.copy_(im.cuda()); s_id.copy_(idt.cuda())
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(o.embeddings_a, ea) and torch.equal(o.embeddings_b, eb) and torch.equal(l, el)
