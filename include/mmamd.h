@@ -34,6 +34,9 @@ extern "C" {
 #define MMAMD_ACT_NONE 0
 #define MMAMD_ACT_QUICKGELU 1 /* x * sigmoid(1.702 x): modules/layers/activation.py:24-25 */
 #define MMAMD_ACT_GELU_ERF 2  /* nn.GELU (FLAVA: models/flava/model.py:79) */
+/* backward of the MLP: C = (A.W^T) * act'(residual) with `residual` = the saved bf16 pre-activation (bf16 output only) */
+#define MMAMD_ACT_MUL_QUICKGELU_GRAD 3
+#define MMAMD_ACT_MUL_GELU_GRAD 4
 
 #define MMAMD_E_BADARG (-1)
 #define MMAMD_E_UNSUPPORTED (-2)
@@ -221,10 +224,11 @@ int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, co
                           int all_row0, int all_rows, float* grad_logit_scale, float* ws, mmamd_stream_t stream);
 
 /* --- row / elementwise kernels of the backward pass (torch autograd of the modules named in the forward entries above)
- * LayerNorm backward: dx[rows,d] (fp32) = LN'(x; gamma)(dy) (+ add), dgamma[d], dbeta[d].  dy fp32 or bf16.
+ * LayerNorm backward: dx[rows,d] (fp32) = LN'(x; gamma)(dy) (+ add), dgamma[d], dbeta[d].  dy fp32 or bf16.  dx_bf16 (optional):
+ * the same dx rounded to bf16 (operand of the following gradient GEMMs).
  * ws: (min(512, ceil(rows/4)) * 2 + 2) * d floats. */
 int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
-                        float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream);
+                        void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream);
 /* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(256, rows) * n floats. */
 int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */

@@ -17,6 +17,7 @@ ABI_VERSION = 1
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
+ACT_MUL_QUICKGELU_GRAD, ACT_MUL_GELU_GRAD = 3, 4  # backward of the MLP: (A.W^T) * act'(residual)
 REDUCE_MEAN, REDUCE_SUM = 0, 1
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -37,7 +38,7 @@ PROTOTYPES = {
     "mmamd_attention_probs_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_contrastive_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "mmamd_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "mmamd_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "mmamd_colsum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),

@@ -14,7 +14,8 @@ namespace mmamd {
 template <typename TD, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const TD* __restrict__ dy, const float* __restrict__ add,
-                                                            float* __restrict__ dx, float* __restrict__ part, int rows, int d, float eps) {
+                                                            float* __restrict__ dx, bf16* __restrict__ dx_bf16, float* __restrict__ part,
+                                                            int rows, int d, float eps) {
   __shared__ float red[4][2][MAXV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d4 = d >> 2;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           for (int j = 0; j < 4; ++j) o[j] += a[j];
         }
         store4(dx + (size_t)row * d + 4 * c, o);
+        if (dx_bf16 != nullptr) store4(dx_bf16 + (size_t)row * d + 4 * c, o);  // MFMA operand of the next dgrad / wgrad
       }
     }
   }
@@ -253,13 +255,14 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 using namespace mmamd;
 
 extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
-                                   float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream) {
+                                   void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int d, float eps,
+                                   mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && ws && rows > 0 && d > 0, MMAMD_E_BADARG, "layernorm_bwd: bad argument");
   MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "layernorm_bwd: d=%d must be a multiple of 4 and <= 2048", d);
   hipStream_t st = (hipStream_t)stream;
   const int G = rows < 4 * 512 ? (rows + 3) / 4 : 512;  // ws: G * 2 * d floats
   const int d4 = d / 4;
-#define LNB(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(G), dim3(256), 0, st, x, gamma, (const T*)dy, add, dx, ws, rows, d, eps)
+#define LNB(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(G), dim3(256), 0, st, x, gamma, (const T*)dy, add, dx, (bf16*)dx_bf16, ws, rows, d, eps)
   if (dy_dtype == MMAMD_F32) { if (d4 <= 128) LNB(float, 2); else if (d4 <= 256) LNB(float, 4); else LNB(float, 8); }
   else if (dy_dtype == MMAMD_BF16) { if (d4 <= 128) LNB(bf16, 2); else if (d4 <= 256) LNB(bf16, 4); else LNB(bf16, 8); }
   else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "layernorm_bwd: bad dy dtype");

@@ -60,6 +60,7 @@ struct GemmArgs {
   int lda, ldw, ldr, ldc;
   int act;
   int tiles_n;
+  int res_mode;             // 0: C += R;  1 / 2: C *= QuickGELU'(R) / GELU'(R) (backward of the MLP: R = saved pre-activation, bf16)
   int kt_chunk;             // split-K (weight gradients): K-tiles (of 64) per split, blockIdx.y = split; 0 = no split
   long long c_split_stride; // elements between the partial outputs of consecutive splits
 };
@@ -83,6 +84,25 @@ __device__ __forceinline__ float gelu_erf(float v) {
   const float h = 0.5f * v * (poly * t) * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);  // 0.5 v (1 - erf|x|)
   return v >= 0.f ? v - h : h;
 }
+
+// d/du [u sigmoid(1.702 u)] and d/du [u Phi(u)]: the factor the MLP's backward multiplies the incoming gradient with
+__device__ __forceinline__ float act_grad(float u, int mode) {
+  if (mode == 1) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * u));
+    return sg * (1.0f + 1.702f * u * (1.0f - sg));
+  }
+  const float x = fabsf(u) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);  // exp(-u^2/2)
+  const float tail = 0.5f * (poly * t) * ex;                               // 0.5 (1 - erf|x|)
+  const float cdf = u >= 0.f ? 1.0f - tail : tail;
+  return cdf + u * 0.3989422804014327f * ex;
+}
+__device__ __forceinline__ float combine_res(float v, float r, int mode) { return mode == 0 ? v + r : v * act_grad(r, mode); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == MMAMD_ACT_QUICKGELU) return quick_gelu(v);
@@ -156,7 +176,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
           if constexpr (OUT_F32) rv = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
           else rv = load4(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] += rv[j];
+          for (int j = 0; j < 4; ++j) t[j] = OUT_F32 ? t[j] + rv[j] : combine_res(t[j], rv[j], p.res_mode);
         }
         if constexpr (OUT_F32) {
           if (ok) store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, t);
@@ -303,7 +323,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
             const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
             bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
+            for (int j = 0; j < 8; ++j) a8[j] = (bf16)combine_res((float)a8[j], (float)r8[j], p.res_mode);
             v = __builtin_bit_cast(uint4, a8);
           }
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = v;
@@ -1637,7 +1657,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
                 const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
                 bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
+                for (int j = 0; j < 8; ++j) a8[j] = (bf16)combine_res((float)a8[j], (float)r8[j], p.res_mode);
                 v = __builtin_bit_cast(uint4, a8);
               }
               store16<STP>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v);
@@ -1910,12 +1930,18 @@ extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, c
                   "gemm: base pointers must be 16-byte aligned");
   MMAMD_CHECK_ARG((uint64_t)M * (uint64_t)lda * 2u < (1ull << 32) && (uint64_t)N * (uint64_t)ldw * 2u < (1ull << 32),
                   MMAMD_E_UNSUPPORTED, "gemm: operand exceeds the 4 GiB 32-bit DMA offset range");
-  MMAMD_CHECK_ARG(act >= MMAMD_ACT_NONE && act <= MMAMD_ACT_GELU_ERF, MMAMD_E_BADARG, "gemm: bad activation code %d", act);
+  MMAMD_CHECK_ARG(act >= MMAMD_ACT_NONE && act <= MMAMD_ACT_MUL_GELU_GRAD, MMAMD_E_BADARG, "gemm: bad activation code %d", act);
   if (M == 0) return 0;
   GemmArgs p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.R = residual; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.act = act; p.tiles_n = 0;
-  p.kt_chunk = 0; p.c_split_stride = 0;
+  p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0;
+  if (act == MMAMD_ACT_MUL_QUICKGELU_GRAD || act == MMAMD_ACT_MUL_GELU_GRAD) {
+    MMAMD_CHECK_ARG(out_dtype == MMAMD_BF16 && residual != nullptr, MMAMD_E_BADARG,
+                    "gemm: the activation-gradient epilogue needs bf16 output and the saved pre-activation as `residual`");
+    p.res_mode = act == MMAMD_ACT_MUL_QUICKGELU_GRAD ? 1 : 2;
+    p.act = MMAMD_ACT_NONE;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == MMAMD_F32) return dispatch<true>(p, st);
   if (out_dtype == MMAMD_BF16) return dispatch<false>(p, st);
@@ -1953,7 +1979,7 @@ extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int
   GemmArgs p;
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = nullptr; p.R = nullptr; p.C = nsplit == 1 ? C : ws;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = N; p.act = MMAMD_ACT_NONE;
-  p.kt_chunk = chunk; p.c_split_stride = (long long)M * N;
+  p.kt_chunk = chunk; p.c_split_stride = (long long)M * N; p.res_mode = 0;
   constexpr int smem = 2 * 512 * 128;
   auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true>;
   static bool attr_done = false;

@@ -39,13 +39,14 @@ def _c32(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _dgrad(dy: Tensor, w: Tensor, out_dtype) -> Tensor:
-    """dX[M,K] = dY[M,N] . W[N,K]  (W fp32 [N,K], N % 64 == 0)."""
+def _dgrad(dy: Tensor, w: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act: Tensor = None) -> Tensor:
+    """dX[M,K] = dY[M,N] . W[N,K]  (W fp32 [N,K], N % 64 == 0); with act = ACT_MUL_*_GRAD the epilogue multiplies by
+    act'(pre_act): the activation's backward without a pass of its own."""
     N = w.shape[0]
     if N % 64 != 0:
         raise ops.MmamdError(f"backward GEMM: output width {N} of a Linear must be a multiple of 64")
     wT = ops.transpose_to_bf16(w, pad_to=64)  # bf16 [K, N]
-    return ops.gemm_bf16(dy, wT, None, out_dtype=out_dtype)
+    return ops.gemm_bf16(dy, wT, None, act=act, residual=pre_act, out_dtype=out_dtype)
 
 
 def _wgrad(dy: Tensor, x: Tensor, bias: bool = False):
@@ -94,28 +95,28 @@ class StackFn(torch.autograd.Function):
         dX = dx_out.detach()
         dX = dX if dX.is_contiguous() else dX.contiguous()
         grads: List[Tensor] = [None] * nparam
+        dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
         for li in reversed(range(len(stack.layers))):
             layer = stack.layers[li]
             x, h1, qkv, att, lse, x_mid, h2, u, g = saved[9 * li:9 * li + 9]
             Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = (_c32(p) for p in params[12 * li:12 * li + 12])
-            dXb = ops.convert(dX, bf)
-            # x_out = x_mid + g W2^T + b2
-            dg = _dgrad(dXb, W2, bf)
+            if dXb is None:
+                dXb = ops.convert(dX, bf)
+            # x_out = x_mid + g W2^T + b2;  g = QuickGELU(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
+            du = _dgrad(dXb, W2, bf, ops.ACT_MUL_QUICKGELU_GRAD, u)
             dW2, db2 = _wgrad(dXb, g, bias=True)
-            du = ops.act_bwd(u, dg, ops.ACT_QUICKGELU)
             # u = h2 W1^T + b1
             dh2 = _dgrad(du, W1, f32)
             dW1, db1 = _wgrad(du, h2, bias=True)
-            dx_mid, dg2, dbe2 = ops.layernorm_bwd(x_mid, g2, dh2, layer.norm2.eps, add=dX)
+            dx_mid, dg2, dbe2, dxmb = ops.layernorm_bwd(x_mid, g2, dh2, layer.norm2.eps, add=dX, want_bf16=True)
             # x_mid = x + att Wo^T + bo
-            dxmb = ops.convert(dx_mid, bf)
             datt = _dgrad(dxmb, Wo, bf)
             dWo, dbo = _wgrad(dxmb, att, bias=True)
             dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal)
             # qkv = h1 Wqkv^T + bqkv
             dh1 = _dgrad(dqkv, Wqkv, f32)
             dWqkv, dbqkv = _wgrad(dqkv, h1, bias=True)
-            dX, dg1, dbe1 = ops.layernorm_bwd(x, g1, dh1, layer.norm1.eps, add=dx_mid)
+            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, layer.norm1.eps, add=dx_mid, want_bf16=True)
             grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
         return (dX, None, None, None, None, *grads)
 

@@ -12,10 +12,11 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU_ERF, ACT_NONE, ACT_QUICKGELU, BF16, F32, MmamdError, check
+from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_NONE, ACT_QUICKGELU, BF16, F32, MmamdError,
+                   check)
 
 __all__ = [
-    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
+    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
@@ -519,8 +520,9 @@ def contrastive_bwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
 
 
 def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float,
-                  add: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(dx fp32 [rows,d] (+ add), dgamma [d], dbeta [d]) for y = LayerNorm(x) * gamma + beta; dy fp32 or bf16."""
+                  add: Optional[torch.Tensor] = None, want_bf16: bool = False):
+    """(dx fp32 [rows,d] (+ add), dgamma [d], dbeta [d]) for y = LayerNorm(x) * gamma + beta; dy fp32 or bf16.  With
+    want_bf16=True a bf16 copy of dx (written by the same kernel) is appended to the result."""
     _chk(x, "x", torch.float32); _chk(gamma, "gamma", torch.float32); _chk(dy, "dy")
     d = x.shape[-1]
     rows = x.numel() // d
@@ -533,9 +535,10 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: f
     dg, db = torch.empty(d, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)
     G = min(512, (rows + 3) // 4)
     ws = torch.empty((G * 2 + 2) * d, dtype=torch.float32, device=dev)
-    check(_lib.lib().mmamd_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy), _ptr(add), dx.data_ptr(), dg.data_ptr(),
-                                         db.data_ptr(), ws.data_ptr(), rows, d, float(eps), _stream()), "mmamd_layernorm_bwd")
-    return dx, dg, db
+    dxb = torch.empty((rows, d), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    check(_lib.lib().mmamd_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy), _ptr(add), dx.data_ptr(), _ptr(dxb),
+                                         dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, d, float(eps), _stream()), "mmamd_layernorm_bwd")
+    return (dx, dg, db, dxb) if want_bf16 else (dx, dg, db)
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:

@@ -73,7 +73,8 @@ def test_layernorm_backward_and_colsum():
         add = torch.randn(rows, d)
         y = torch.nn.functional.layer_norm(x.double(), (d,), gamma.double(), beta.double(), 1e-5)
         y.backward(dy.double())
-        dx, dg, db = ops.layernorm_bwd(x.detach().cuda(), gamma.detach().cuda(), dy.cuda(), 1e-5, add=add.cuda())
+        dx, dg, db, dxb = ops.layernorm_bwd(x.detach().cuda(), gamma.detach().cuda(), dy.cuda(), 1e-5, add=add.cuda(), want_bf16=True)
+        assert torch.equal(dxb, dx.to(torch.bfloat16))
         assert np.abs(host(dx) - (x.grad.double() + add.double()).numpy()).max() <= 2e-5 * max(1.0, float(x.grad.abs().max()))
         assert np.abs(host(dg) - gamma.grad.double().numpy()).max() <= 1e-4 * max(1.0, float(gamma.grad.abs().max()))
         assert np.abs(host(db) - beta.grad.double().numpy()).max() <= 1e-4 * max(1.0, float(beta.grad.abs().max()))
@@ -125,6 +126,26 @@ def test_activation_transpose_normalize_scatter_kernels():
         got = host(ops.gemm_bf16_splitk(a.cuda(), w.cuda()))
         ref = host(a.cuda().float() @ w.cuda().float().t())  # fp32 reference of the same bf16 operands (ATen, test only)
         assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), (M, N, K)
+
+
+def test_gemm_epilogue_multiplies_by_activation_gradient():
+    """dgrad of the MLP with the activation's backward in the epilogue: (dY W) * act'(u) for QuickGELU and erf-GELU, every kernel path."""
+    from multimodal_amd import ops
+
+    set_rng_seed(9)
+    for (M, N, K) in ((300, 256, 128), (50432, 3072, 768), (5000, 768, 256)):
+        a = torch.randn(M, K).to(torch.bfloat16)
+        w = (torch.randn(N, K) * 0.05).to(torch.bfloat16)
+        u = (torch.randn(M, N) * 2).to(torch.bfloat16)
+        base = (a.cuda().float() @ w.cuda().float().t()).double().cpu()  # fp32 reference of the same bf16 operands (test only)
+        for code, fn in ((ops.ACT_MUL_QUICKGELU_GRAD, lambda t: t * torch.sigmoid(1.702 * t)), (ops.ACT_MUL_GELU_GRAD, torch.nn.functional.gelu)):
+            ud = u.double().requires_grad_(True)
+            fn(ud).sum().backward()
+            ref = (base * ud.grad).numpy()
+            got = host(ops.gemm_bf16(a.cuda(), w.cuda(), None, act=code, residual=u.cuda()))
+            assert np.abs(got - ref).max() <= 2 ** -6 * max(1.0, np.abs(ref).max()), (M, N, K, code)
+    with pytest.raises(ops.MmamdError):
+        ops.gemm_bf16(a.cuda(), w.cuda(), None, act=ops.ACT_MUL_GELU_GRAD)  # needs the saved pre-activation
 
 
 def test_clip_training_step_gradients_vs_reference_autograd(golden):
