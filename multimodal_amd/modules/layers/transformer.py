@@ -1,7 +1,22 @@
-"""Host-side mirror of torchmultimodal/modules/layers/transformer.py:21-27 (the output record every encoder returns)."""
-from typing import List, NamedTuple, Optional, Tuple
+"""Host-side mirror of torchmultimodal/modules/layers/transformer.py: the output record every encoder returns (:21-27) and the
+TransformerEncoder(Layer) / TransformerDecoder(Layer) blocks (:31-657) CoCa's ViT (encoders/vision_transformer.py), text decoder and
+multimodal decoder are built from.  Same constructors, attribute names and state_dict keys.  Per layer on the MI355X (pre-norm):
 
-from torch import Tensor
+    LN -> [3d,d] GEMM -> attention -> output GEMM(+residual)   [-> LN -> q GEMM, [2d,dkv] GEMM -> cross-attention -> GEMM(+res)]
+    LN -> up GEMM(+bias, GELU) -> down GEMM(+bias, +residual)
+
+residual stream fp32, MFMA operands bf16.
+"""
+from typing import Callable, List, NamedTuple, Optional, Tuple
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._packing import PackedCache
+from .mlp import MLP
+from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask
+from .normalizations import Fp32LayerNorm
 
 
 class TransformerOutput(NamedTuple):
@@ -11,26 +26,6 @@ class TransformerOutput(NamedTuple):
     attentions: Optional[List[Tensor]] = None
     image_labels: Optional[Tensor] = None
     current_key_values: Optional[List[Tuple[Tensor, Tensor]]] = None
-
-
-# ------------------------------------------------------------------------------------------------------------------------
-# TransformerEncoder(Layer) / TransformerDecoder(Layer) of torchmultimodal/modules/layers/transformer.py:31-657 — the blocks
-# CoCa's ViT (encoders/vision_transformer.py), text decoder and multimodal decoder are built from.  Same constructors,
-# attribute names and state_dict keys.  Per layer on the MI355X (pre-norm):
-#     LN -> [3d,d] GEMM -> attention -> output GEMM(+residual)   [-> LN -> q GEMM, [2d,dkv] GEMM -> cross-attention -> GEMM(+res)]
-#     LN -> up GEMM(+bias, GELU) -> down GEMM(+bias, +residual)
-# residual stream fp32, MFMA operands bf16.
-# ------------------------------------------------------------------------------------------------------------------------
-from typing import Callable  # noqa: E402
-
-import torch  # noqa: E402
-from torch import nn  # noqa: E402
-
-from ... import ops  # noqa: E402
-from ..._packing import PackedCache  # noqa: E402
-from .mlp import MLP  # noqa: E402
-from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask  # noqa: E402
-from .normalizations import Fp32LayerNorm  # noqa: E402
 
 
 def _forbid_training(module: nn.Module) -> None:
