@@ -117,10 +117,10 @@ int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const 
 
 /* Backward of self-attention over a packed qkv (head dim 64): given the forward's out [B*S, D] (bf16), d(out), and the
  * log2-domain log-sum-exp `lse` [B,H,S] that mmamd_attention_x_fwd saved, writes dqkv [B*S, 3D] = [dQ | dK | dV] (bf16).
- * Two kernels (dQ; dK+dV), no atomics.  This is what torch autograd computes for F.scaled_dot_product_attention under
+ * key_mask (optional, uint8 [B,S], 0 = masked key) as in the forward.  Two kernels (dQ; dK+dV), no atomics.  This is what torch autograd computes for F.scaled_dot_product_attention under
  * nn.MultiheadAttention (call sites models/clip/image_encoder.py:108, text_encoder.py:121). */
-int mmamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
-                        int causal, float scale, mmamd_stream_t stream);
+int mmamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const uint8_t* key_mask, void* dqkv,
+                        int B, int S, int H, int causal, float scale, mmamd_stream_t stream);
 
 /* --- K1 front end: non-overlapping patch extraction ("im2col" of a stride==kernel conv) -------
  * images [B,C,HW,HW] (f32 or bf16) -> patches bf16 [B*(HW/P)^2, Kpad], column k = (c*P+py)*P+px,
@@ -157,6 +157,7 @@ int mmamd_coca_text_embed(const int64_t* ids, const float* table, const float* p
 int mmamd_coca_text_mask(const void* src, int kind, int64_t pad_id, uint8_t* out, int B, int S, mmamd_stream_t stream);
 
 /* BERT embeddings: x[b,s,:] = LayerNorm(word[ids] + position[pos_ids or s] + token_type[type_ids or 0]) (fp32 out).
+ * gamma = beta = NULL: the un-normalised sum (the training forward keeps it for the LayerNorm backward).
  * Replaces modules/layers/text_embedding.py:74-104 (three gathers, add, nn.LayerNorm). */
 int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                         const float* pos, const float* type, const float* gamma, const float* beta, float eps, float* x,

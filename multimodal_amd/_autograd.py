@@ -1,0 +1,202 @@
+"""Autograd nodes shared by the trainable model families: forward AND backward are HIP kernels behind
+the C-ABI; torch.autograd only sequences them.
+
+    EncoderStackFn   N pre-norm transformer layers (CLIP's torch-style layers, FLAVA's query/key/value layers via an adapter)
+    LayerNormFn      LayerNorm over all rows of a [.., d] tensor
+    RowsLinearFn     Linear (+bias) applied to one selected row per sample (CLS projections)
+    L2NormalizeFn    F.normalize(dim=-1)
+
+GEMM gradients: dgrad dX = dY W = gemm_bf16(dY, W^T) with the activation's backward fused into the epilogue where there is one;
+wgrad dW = dY^T X = split-K gemm_bf16(dY^T, X^T) over the token index (operands transposed by a kernel that also yields the bias
+gradient).  The residual-stream gradient stays fp32; MFMA operands are bf16.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+bf, f32 = torch.bfloat16, torch.float32
+
+
+def c32(t: Tensor) -> Tensor:
+    t = t.detach()
+    if t.dtype != f32:
+        raise ops.MmamdError("training on the MI355X path keeps parameters in float32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def dgrad(dy: Tensor, w: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act: Optional[Tensor] = None) -> Tensor:
+    """dX[M,K] = dY[M,N] . W[N,K]  (W fp32 [N,K], N % 64 == 0); with act = ACT_MUL_*_GRAD the epilogue multiplies by
+    act'(pre_act): the activation's backward without a pass of its own."""
+    if w.shape[0] % 64 != 0:
+        raise ops.MmamdError(f"backward GEMM: output width {w.shape[0]} of a Linear must be a multiple of 64")
+    wT = ops.transpose_to_bf16(w, pad_to=64)  # bf16 [K, N]
+    return ops.gemm_bf16(dy, wT, None, act=act, residual=pre_act, out_dtype=out_dtype)
+
+
+def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
+    """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens (zero-padded to 128).
+    bias=True also returns db[N] = column sums of dY, produced by the same transpose pass over dY."""
+    if bias:
+        dyT, db = ops.transpose_to_bf16(dy, with_colsum=True)
+    else:
+        dyT, db = ops.transpose_to_bf16(dy), None
+    dW = ops.gemm_bf16_splitk(dyT, ops.transpose_to_bf16(x))
+    return (dW, db) if bias else dW
+
+
+class StackConfig:
+    """Static description of a layer stack for EncoderStackFn.  to_canonical(layer params) -> the 12 canonical tensors
+    (Wqkv [3d,d], bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2); from_canonical(12 grads) -> grads in the layer's parameter order."""
+
+    def __init__(self, n_layers: int, n_head: int, B: int, S: int, causal: bool, act: int, eps1: Sequence[float], eps2: Sequence[float],
+                 params_per_layer: int, to_canonical: Callable, from_canonical: Callable, key_mask: Optional[Tensor] = None,
+                 keep_hidden: bool = False):
+        self.n_layers, self.n_head, self.B, self.S, self.causal, self.act = n_layers, n_head, B, S, causal, act
+        self.eps1, self.eps2, self.ppl = list(eps1), list(eps2), params_per_layer
+        self.to_canonical, self.from_canonical, self.key_mask = to_canonical, from_canonical, key_mask
+        self.keep_hidden = keep_hidden
+        self.hidden: List[Tensor] = []  # inputs of every layer (detached), filled by the forward when keep_hidden
+
+
+_ACT_GRAD = {ops.ACT_QUICKGELU: ops.ACT_MUL_QUICKGELU_GRAD, ops.ACT_GELU_ERF: ops.ACT_MUL_GELU_GRAD}
+
+
+class EncoderStackFn(torch.autograd.Function):
+    """x0 fp32 [B*S, d] -> x_L.  Per layer (tensors kept for backward in brackets):
+        [x] -LN-> [h1] -GEMM-> [qkv] -attention-> [att, lse] -GEMM(+x)-> [x_mid] -LN-> [h2] -GEMM-> [u] -act-> [g] -GEMM(+x_mid)-> x'"""
+
+    @staticmethod
+    def forward(ctx, x0: Tensor, cfg: StackConfig, *params: Tensor):
+        B, S, H = cfg.B, cfg.S, cfg.n_head
+        saved: List[Tensor] = []
+        x = x0.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        for li in range(cfg.n_layers):
+            Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]])
+            if cfg.keep_hidden:
+                cfg.hidden.append(x)
+            h1 = ops.layernorm(x, g1, be1, cfg.eps1[li], out_dtype=bf)
+            qkv = ops.gemm_bf16(h1, ops.convert(Wqkv, bf), bqkv)
+            att, lse = ops.attention_fwd_train(qkv, B, S, H, cfg.causal, cfg.key_mask)
+            x_mid = ops.gemm_bf16(att, ops.convert(Wo, bf), bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
+            h2 = ops.layernorm(x_mid, g2, be2, cfg.eps2[li], out_dtype=bf)
+            u = ops.gemm_bf16(h2, ops.convert(W1, bf), b1)
+            g = ops.act_fwd(u, cfg.act)
+            x_out = ops.gemm_bf16(g, ops.convert(W2, bf), b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
+            saved += [x, h1, qkv, att, lse, x_mid, h2, u, g]
+            x = x_out
+        if cfg.keep_hidden:
+            cfg.hidden.append(x)
+        ctx.save_for_backward(*saved, *params)
+        ctx.cfg, ctx.nparam = cfg, len(params)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx_out: Tensor):
+        cfg, nparam = ctx.cfg, ctx.nparam
+        tensors = ctx.saved_tensors
+        saved, params = tensors[:len(tensors) - nparam], tensors[len(tensors) - nparam:]
+        B, S, H = cfg.B, cfg.S, cfg.n_head
+        dX = dx_out.detach()
+        dX = dX if dX.is_contiguous() else dX.contiguous()
+        grads: List[Optional[Tensor]] = [None] * nparam
+        dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
+        for li in reversed(range(cfg.n_layers)):
+            x, h1, qkv, att, lse, x_mid, h2, u, g = saved[9 * li:9 * li + 9]
+            Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]])
+            if dXb is None:
+                dXb = ops.convert(dX, bf)
+            # x_out = x_mid + g W2^T + b2;  g = act(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
+            du = dgrad(dXb, W2, bf, _ACT_GRAD[cfg.act], u)
+            dW2, db2 = wgrad(dXb, g, bias=True)
+            # u = h2 W1^T + b1
+            dh2 = dgrad(du, W1, f32)
+            dW1, db1 = wgrad(du, h2, bias=True)
+            dx_mid, dg2, dbe2, dxmb = ops.layernorm_bwd(x_mid, g2, dh2, cfg.eps2[li], add=dX, want_bf16=True)
+            # x_mid = x + att Wo^T + bo
+            datt = dgrad(dxmb, Wo, bf)
+            dWo, dbo = wgrad(dxmb, att, bias=True)
+            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, cfg.causal, cfg.key_mask)
+            # qkv = h1 Wqkv^T + bqkv
+            dh1 = dgrad(dqkv, Wqkv, f32)
+            dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
+            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, cfg.eps1[li], add=dx_mid, want_bf16=True)
+            grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical([dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2])
+        return (dX, None, *grads)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x) over the last dimension of a contiguous fp32 tensor (affine)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float):
+        xc = x.detach()
+        xc = xc if xc.is_contiguous() else xc.contiguous()
+        if xc.dtype != f32:
+            raise ops.MmamdError("differentiable LayerNorm on the MI355X path takes fp32 activations")
+        y = ops.layernorm(xc, c32(weight), c32(bias), eps, out_dtype=f32)
+        ctx.save_for_backward(xc, weight)
+        ctx.eps = eps
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dyc = dy.detach()
+        dyc = dyc if dyc.is_contiguous() else dyc.contiguous()
+        dx, dg, db = ops.layernorm_bwd(x, c32(weight), dyc, ctx.eps)
+        return dx.view(x.shape), dg, db, None
+
+
+class RowsLinearFn(torch.autograd.Function):
+    """out[b] = x2d[rows[b]] . W^T (+ bias): a Linear applied to one selected row per sample (exact-fp32 MFMA both ways)."""
+
+    @staticmethod
+    def forward(ctx, x2d, rows64, weight, bias):
+        d = x2d.shape[1]
+        xc = x2d.detach()
+        xc = xc if xc.is_contiguous() else xc.contiguous()
+        sel = ops.gather_rows(xc, d, rows64.to(torch.int32), d, f32)
+        W = c32(weight)
+        E = W.shape[0]
+        out = ops.rows_linear_f32(sel, d, sel.shape[0], W, c32(bias) if bias is not None else None)
+        ctx.save_for_backward(sel, rows64, weight)
+        ctx.meta = (tuple(x2d.shape), E, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, de):
+        sel, rows64, weight = ctx.saved_tensors
+        xshape, E, has_bias = ctx.meta
+        B, d = sel.shape
+        de = de.detach()
+        de = de if de.is_contiguous() else de.contiguous()
+        W = c32(weight)
+        dW = ops.f32_gemm_strided(de, 1, E, sel, 1, d, E, d, B)   # dW[j,k] = sum_b de[b,j] sel[b,k]
+        dsel = ops.f32_gemm_strided(de, E, 1, W, 1, d, B, d, E)   # dsel[b,k] = sum_j de[b,j] W[j,k]
+        db = ops.colsum(de) if has_bias else None
+        dx = torch.zeros(xshape, dtype=f32, device=de.device)      # memset: only the selected rows receive gradient
+        ops.scatter_add_rows_(dx, rows64, dsel)
+        return dx, None, dW, db
+
+
+class L2NormalizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = c32(x)
+        ctx.save_for_backward(xc)
+        return ops.l2_normalize(xc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.l2_normalize_bwd(x, dy.contiguous())
+
+
+def wants_grad(module) -> bool:
+    return module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())

@@ -639,7 +639,8 @@ static int dispatch_attn_x(const AttnX& p, int B, hipStream_t st) {
 template <int NKT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                                const bf16* __restrict__ dO, const float* __restrict__ lse,
-                                                               bf16* __restrict__ dqkv, int S, int H, float scale) {
+                                                               bf16* __restrict__ dqkv, int S, int H, float scale,
+                                                               const uint8_t* __restrict__ key_mask) {
   constexpr int SP = NKT * 32;
   constexpr int VS = SP + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const int key = kt * 32 + 8 * g + 4 * half + j;
-          const bool ok = key < S && (!CAUSAL || key <= qc);
+          const bool ok = key < S && (!CAUSAL || key <= qc) && (key_mask == nullptr || key_mask[(size_t)b * S + key] != 0);
           const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2) : 0.f;
           e[j] = pr * (dp[r] - Dq);
         }
@@ -758,7 +759,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
 template <int NKT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                                 const bf16* __restrict__ dO, const float* __restrict__ lse,
-                                                                bf16* __restrict__ dqkv, int S, int H, float scale) {
+                                                                bf16* __restrict__ dqkv, int S, int H, float scale,
+                                                                const uint8_t* __restrict__ key_mask) {
   constexpr int SP = NKT * 32;
   constexpr int VS = SP + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -809,6 +811,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
   for (int kt = wave; kt < nkt; kt += 4) {
     const int key = kt * 32 + l31;
     const int kc = key < S ? key : S - 1;
+    const bool key_live = key < S && (key_mask == nullptr || key_mask[(size_t)b * S + kc] != 0);  // a masked key has P = 0: dK = dV = 0
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const int q = qt * 32 + 8 * g + 4 * half + j;
-          const bool ok = key < S && (!CAUSAL || key <= q);
+          const bool ok = key_live && (!CAUSAL || key <= q);
           const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;  // L2 = +inf for padded queries -> 0
           e[j] = pr;
           f[j] = pr * (dp[r] - Dqs[q]);
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
 
 template <int NKT>
 static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
-                           float scale, hipStream_t st) {
+                           float scale, hipStream_t st, const uint8_t* key_mask) {
   constexpr int SP = NKT * 32;
   constexpr int smem1 = 2 * SP * kKStride * 2 + 64 * (SP + 4) * 2;
   constexpr int smem2 = 2 * SP * kKStride * 2 + 2 * 64 * (SP + 4) * 2 + 2 * SP * 4;
@@ -912,11 +915,11 @@ static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const
     attr_done = true;
   }
   if (causal) {
-    hipLaunchKernelGGL(k1c, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
-    hipLaunchKernelGGL(k2c, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
+    hipLaunchKernelGGL(k1c, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
+    hipLaunchKernelGGL(k2c, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
   } else {
-    hipLaunchKernelGGL(k1n, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
-    hipLaunchKernelGGL(k2n, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale);
+    hipLaunchKernelGGL(k1n, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
+    hipLaunchKernelGGL(k2n, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
   }
   return launch_status("attention_bwd");
 }
@@ -1035,23 +1038,23 @@ extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_str
   return pf32 ? dispatch_attn_x<96, float>(p, B, st) : dispatch_attn_x<96, bf16>(p, B, st);
 }
 
-extern "C" int mmamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S, int H,
-                                   int causal, float scale, mmamd_stream_t stream) {
+extern "C" int mmamd_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const uint8_t* key_mask, void* dqkv,
+                                   int B, int S, int H, int causal, float scale, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(qkv && out && dout && lse && dqkv && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention_bwd: bad argument");
   MMAMD_CHECK_ARG(S <= 288, MMAMD_E_UNSUPPORTED, "attention_bwd: S=%d > 288 not supported", S);
   MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), MMAMD_E_ALIGN, "attention_bwd: pointers must be 16-byte aligned");
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   switch ((S + 31) / 32) {
-    case 1: return launch_attn_bwd<1>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 2: return launch_attn_bwd<2>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 3: return launch_attn_bwd<3>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 4: return launch_attn_bwd<4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 5: return launch_attn_bwd<5>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 6: return launch_attn_bwd<6>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 7: return launch_attn_bwd<7>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 8: return launch_attn_bwd<8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
-    case 9: return launch_attn_bwd<9>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st);
+    case 1: return launch_attn_bwd<1>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 2: return launch_attn_bwd<2>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 3: return launch_attn_bwd<3>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 4: return launch_attn_bwd<4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 5: return launch_attn_bwd<5>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 6: return launch_attn_bwd<6>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 7: return launch_attn_bwd<7>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 8: return launch_attn_bwd<8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    case 9: return launch_attn_bwd<9>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
   }
   MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention_bwd: unsupported S=%d", S);
 }

@@ -327,6 +327,14 @@ __global__ __launch_bounds__(256) void bert_embed_ln_kernel(const int64_t* __res
       sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
   }
+  if (gamma == nullptr) {  // training forward keeps the pre-LayerNorm sum (its backward needs it): no normalisation here
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) store4(x + (size_t)row * d + 4 * c, v[i]);
+    }
+    return;
+  }
   const float mean = wave_sum(sum) / (float)d;
   float q = 0.f;
 #pragma unroll
@@ -663,7 +671,7 @@ extern "C" int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_
 extern "C" int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                    const float* pos, const float* type, const float* gamma, const float* beta, float eps, float* x,
                                    int B, int S, int d, int vocab, int max_pos, int n_types, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(ids && word && pos && type && gamma && beta && x && B >= 0 && S > 0 && d > 0, MMAMD_E_BADARG, "bert_embed_ln: bad argument");
+  MMAMD_CHECK_ARG(ids && word && pos && type && x && (gamma == nullptr) == (beta == nullptr) && B >= 0 && S > 0 && d > 0, MMAMD_E_BADARG, "bert_embed_ln: bad argument");
   MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "bert_embed_ln: d=%d must be a multiple of 4 and <= 2048", d);
   MMAMD_CHECK_ARG(pos_ids != nullptr || S <= max_pos, MMAMD_E_BADARG, "bert_embed_ln: sequence longer than the position table");
   if (B == 0) return 0;

@@ -18,6 +18,7 @@ import torch
 from torch import Tensor
 
 from ... import ops
+from ..._autograd import EncoderStackFn, L2NormalizeFn, StackConfig, c32 as _c32, wants_grad, wgrad as _wgrad  # noqa: F401
 
 bf, f32 = torch.bfloat16, torch.float32
 
@@ -32,98 +33,13 @@ def _get(mod, dotted):
     return mod
 
 
-def _c32(t: Tensor) -> Tensor:
-    t = t.detach()
-    if t.dtype != f32:
-        raise ops.MmamdError("training on the MI355X path keeps parameters in float32")
-    return t if t.is_contiguous() else t.contiguous()
-
-
-def _dgrad(dy: Tensor, w: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act: Tensor = None) -> Tensor:
-    """dX[M,K] = dY[M,N] . W[N,K]  (W fp32 [N,K], N % 64 == 0); with act = ACT_MUL_*_GRAD the epilogue multiplies by
-    act'(pre_act): the activation's backward without a pass of its own."""
-    N = w.shape[0]
-    if N % 64 != 0:
-        raise ops.MmamdError(f"backward GEMM: output width {N} of a Linear must be a multiple of 64")
-    wT = ops.transpose_to_bf16(w, pad_to=64)  # bf16 [K, N]
-    return ops.gemm_bf16(dy, wT, None, act=act, residual=pre_act, out_dtype=out_dtype)
-
-
-def _wgrad(dy: Tensor, x: Tensor, bias: bool = False):
-    """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens (zero-padded to 128).
-    bias=True also returns db[N] = column sums of dY, produced by the same transpose pass over dY."""
-    if bias:
-        dyT, db = ops.transpose_to_bf16(dy, with_colsum=True)  # [N, Mp]
-    else:
-        dyT, db = ops.transpose_to_bf16(dy), None
-    xT = ops.transpose_to_bf16(x)    # [K, Mp]
-    dW = ops.gemm_bf16_splitk(dyT, xT)
-    return (dW, db) if bias else dW
-
-
-class StackFn(torch.autograd.Function):
-    """x0 fp32 [B*S, d] -> x_L through the pre-norm layers of a TransformerStack (models/clip/_transformer.py)."""
-
-    @staticmethod
-    def forward(ctx, x0: Tensor, stack, B: int, S: int, causal: bool, *params: Tensor):
-        H, d = stack.nhead, stack.d_model
-        saved: List[Tensor] = []
-        x = x0.detach()
-        for li, layer in enumerate(stack.layers):
-            Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = (_c32(p) for p in params[12 * li:12 * li + 12])
-            h1 = ops.layernorm(x, g1, be1, layer.norm1.eps, out_dtype=bf)
-            qkv = ops.gemm_bf16(h1, ops.convert(Wqkv, bf), bqkv)
-            att, lse = ops.attention_fwd_train(qkv, B, S, H, causal)
-            x_mid = ops.gemm_bf16(att, ops.convert(Wo, bf), bo, residual=x, out_dtype=f32,
-                                  out=torch.empty_like(x))
-            h2 = ops.layernorm(x_mid, g2, be2, layer.norm2.eps, out_dtype=bf)
-            u = ops.gemm_bf16(h2, ops.convert(W1, bf), b1)
-            g = ops.act_fwd(u, ops.ACT_QUICKGELU)
-            x_out = ops.gemm_bf16(g, ops.convert(W2, bf), b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
-            saved += [x, h1, qkv, att, lse, x_mid, h2, u, g]
-            x = x_out
-        ctx.save_for_backward(*saved, *[p for p in params])
-        ctx.meta = (stack, B, S, causal, len(params))
-        return x
-
-    @staticmethod
-    def backward(ctx, dx_out: Tensor):
-        stack, B, S, causal, nparam = ctx.meta
-        tensors = ctx.saved_tensors
-        saved, params = tensors[:len(tensors) - nparam], tensors[len(tensors) - nparam:]
-        H = stack.nhead
-        dX = dx_out.detach()
-        dX = dX if dX.is_contiguous() else dX.contiguous()
-        grads: List[Tensor] = [None] * nparam
-        dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
-        for li in reversed(range(len(stack.layers))):
-            layer = stack.layers[li]
-            x, h1, qkv, att, lse, x_mid, h2, u, g = saved[9 * li:9 * li + 9]
-            Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = (_c32(p) for p in params[12 * li:12 * li + 12])
-            if dXb is None:
-                dXb = ops.convert(dX, bf)
-            # x_out = x_mid + g W2^T + b2;  g = QuickGELU(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
-            du = _dgrad(dXb, W2, bf, ops.ACT_MUL_QUICKGELU_GRAD, u)
-            dW2, db2 = _wgrad(dXb, g, bias=True)
-            # u = h2 W1^T + b1
-            dh2 = _dgrad(du, W1, f32)
-            dW1, db1 = _wgrad(du, h2, bias=True)
-            dx_mid, dg2, dbe2, dxmb = ops.layernorm_bwd(x_mid, g2, dh2, layer.norm2.eps, add=dX, want_bf16=True)
-            # x_mid = x + att Wo^T + bo
-            datt = _dgrad(dxmb, Wo, bf)
-            dWo, dbo = _wgrad(dxmb, att, bias=True)
-            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal)
-            # qkv = h1 Wqkv^T + bqkv
-            dh1 = _dgrad(dqkv, Wqkv, f32)
-            dWqkv, dbqkv = _wgrad(dqkv, h1, bias=True)
-            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, layer.norm1.eps, add=dx_mid, want_bf16=True)
-            grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
-        return (dX, None, None, None, None, *grads)
-
-
 def run_stack(stack, x0: Tensor, B: int, S: int, causal: bool) -> Tensor:
+    """The pre-norm layers of a TransformerStack (models/clip/_transformer.py): torch's parameter layout IS the canonical one."""
     params = [_get(layer, n) for layer in stack.layers for n in _LAYER_PARAMS]
-    return StackFn.apply(x0, stack, B, S, causal, *params)
+    ident = lambda t: t
+    cfg = StackConfig(len(stack.layers), stack.nhead, B, S, causal, ops.ACT_QUICKGELU, [l.norm1.eps for l in stack.layers],
+                      [l.norm2.eps for l in stack.layers], 12, ident, ident)
+    return EncoderStackFn.apply(x0, cfg, *params)
 
 
 class VisionEmbedFn(torch.autograd.Function):
@@ -218,20 +134,3 @@ class PooledHeadFn(torch.autograd.Function):
         dx = torch.zeros(xshape, dtype=f32, device=de.device)  # memset: only the pooled rows receive gradient
         ops.scatter_add_rows_(dx, idx64, drows)
         return dx, None, dg, db, dP, None, None
-
-
-class L2NormalizeFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        xc = _c32(x)
-        ctx.save_for_backward(xc)
-        return ops.l2_normalize(xc)
-
-    @staticmethod
-    def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        return ops.l2_normalize_bwd(x, dy.contiguous())
-
-
-def wants_grad(module) -> bool:
-    return module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())

@@ -1,0 +1,164 @@
+"""Training (differentiable) forward of the FLAVA encoders on the MI355X kernels: the autograd nodes that are specific to FLAVA;
+the layer stack, LayerNorm, CLS projections and normalisation nodes are the shared ones of multimodal_amd/_autograd.py.
+
+Differentiable: ImageEmbeddings, BERTTextEmbeddings, flava.TransformerEncoder (pre-norm, GELU / QuickGELU, key-padding masks),
+Fp32LayerNorm, the CLS projections, the token-wise mm projections, FLAVAGlobalContrastiveLoss.  Not differentiable (forward-only
+outputs, returned detached): attention probabilities (not produced in training mode), Pooler outputs, the MLM / MIM / ITM heads.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn, Tensor
+
+from ... import ops
+from ..._autograd import EncoderStackFn, StackConfig, c32, dgrad, wgrad
+
+bf, f32 = torch.bfloat16, torch.float32
+
+
+class FlavaImageEmbedFn(torch.autograd.Function):
+    """pixel_values -> fp32 [B, G2+1, d]: conv patch embedding (+bias), CLS, + position embeddings (models/flava/image_encoder.py:139-177,
+    without patch masking)."""
+
+    @staticmethod
+    def forward(ctx, images, conv_w, conv_b, cls, pos, patch: int):
+        B = images.shape[0]
+        w = conv_w.shape[0]
+        K = conv_w.shape[1] * patch * patch
+        if K % 64 != 0:
+            raise ops.MmamdError(f"patch embedding: C*P*P = {K} must be a multiple of 64 on the MI355X path")
+        cols = ops.patchify(images if images.is_contiguous() else images.contiguous(), patch, K)
+        pe = ops.gemm_bf16(cols, ops.convert(c32(conv_w).view(w, K), bf), c32(conv_b), out_dtype=f32)
+        G2 = cols.shape[0] // B
+        x = ops.flava_image_embed(pe, c32(cls).view(-1), c32(pos).view(G2 + 1, w), B, G2)
+        ctx.save_for_backward(cols)
+        ctx.meta = (B, G2, w, tuple(conv_w.shape), tuple(cls.shape), tuple(pos.shape))
+        return x.view(B, G2 + 1, w)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (cols,) = ctx.saved_tensors
+        B, G2, w, conv_shape, cls_shape, pos_shape = ctx.meta
+        S = G2 + 1
+        d_asm = dx.detach().contiguous().view(B * S, w)
+        dpos = ops.colsum(d_asm.view(B, S * w)).view(S, w)
+        dcls = dpos[0].clone()
+        idx = (torch.arange(B * S, device=dx.device, dtype=torch.int32).view(B, S)[:, 1:]).reshape(-1).contiguous()
+        d_pe = ops.gather_rows(d_asm, w, idx, w, bf)
+        dW, db = wgrad(d_pe, cols, bias=True)
+        return None, dW.view(conv_shape), db, dcls.view(cls_shape), dpos.view(pos_shape), None
+
+
+class BertEmbedFn(torch.autograd.Function):
+    """LayerNorm(word[ids] + position[pos] + token_type[type]) (modules/layers/text_embedding.py:74-104)."""
+
+    @staticmethod
+    def forward(ctx, ids, word, pos, typ, ln_w, ln_b, eps: float, token_type_ids, position_ids, padding_idx):
+        B, S = ids.shape
+        e = ops.bert_embed_ln(ids, c32(word), c32(pos), c32(typ), None, None, eps, token_type_ids, position_ids)  # un-normalised sum
+        x = ops.layernorm(e, c32(ln_w), c32(ln_b), eps, out_dtype=f32)
+        ctx.save_for_backward(e, ids, ln_w, token_type_ids if token_type_ids is not None else torch.empty(0, device=ids.device),
+                              position_ids if position_ids is not None else torch.empty(0, device=ids.device))
+        ctx.meta = (eps, tuple(word.shape), tuple(pos.shape), tuple(typ.shape), token_type_ids is not None, position_ids is not None, padding_idx)
+        return x.view(B, S, -1)
+
+    @staticmethod
+    def backward(ctx, dx):
+        e, ids, ln_w, tt, pid = ctx.saved_tensors
+        eps, wshape, pshape, tshape, has_tt, has_pid, padding_idx = ctx.meta
+        B, S = ids.shape
+        d = wshape[1]
+        de, dg, db = ops.layernorm_bwd(e, c32(ln_w), dx.detach().contiguous().view(B * S, d), eps)
+        dev = de.device
+        dword = torch.zeros(wshape, dtype=f32, device=dev)  # memset; rows collide -> fp32 atomics
+        ops.scatter_add_rows_(dword, ids.reshape(-1).contiguous(), de)
+        if padding_idx is not None:
+            dword[padding_idx].zero_()  # nn.Embedding(padding_idx=...): the pad row receives no gradient
+        dpos = torch.zeros(pshape, dtype=f32, device=dev)
+        if has_pid:
+            ops.scatter_add_rows_(dpos, pid.reshape(-1).contiguous(), de)
+        else:
+            dpos[:S].copy_(ops.colsum(de.view(B, S * d)).view(S, d))  # position s is shared by the B samples
+        dtyp = torch.zeros(tshape, dtype=f32, device=dev)
+        if has_tt:
+            ops.scatter_add_rows_(dtyp, tt.reshape(-1).contiguous(), de)
+        else:
+            dtyp[0].copy_(ops.colsum(de))                              # every token has type 0
+        return None, dword, dpos, dtyp, dg, db, None, None, None, None
+
+
+class TokenLinearFn(torch.autograd.Function):
+    """y = x W^T + b over every token of a [B, S, d] fp32 tensor (image_to_mm / text_to_mm projections, models/flava/model.py:294-295)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, S, d = x.shape
+        xb = ops.convert((x.detach() if x.is_contiguous() else x.detach().contiguous()).view(B * S, d), bf)
+        y = ops.gemm_bf16(xb, ops.convert(c32(weight), bf), c32(bias) if bias is not None else None, out_dtype=f32)
+        ctx.save_for_backward(xb, weight)
+        ctx.meta = (B, S, bias is not None)
+        return y.view(B, S, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, weight = ctx.saved_tensors
+        B, S, has_bias = ctx.meta
+        dyb = ops.convert(dy.detach().contiguous().view(B * S, -1), bf)
+        dx = dgrad(dyb, c32(weight), f32)
+        if has_bias:
+            dW, db = wgrad(dyb, xb, bias=True)
+        else:
+            dW, db = wgrad(dyb, xb), None
+        return dx.view(B, S, -1), dW, db
+
+
+_FLAVA_LAYER_PARAMS = ("attention.query.weight", "attention.query.bias", "attention.key.weight", "attention.key.bias",
+                       "attention.value.weight", "attention.value.bias", "attention.output.weight", "attention.output.bias",
+                       "ff0.weight", "ff0.bias", "ff1.weight", "ff1.bias", "attention_layernorm.weight", "attention_layernorm.bias",
+                       "feedforward_layernorm.weight", "feedforward_layernorm.bias")
+
+
+def _to_canonical(p: List[Tensor]):
+    qw, qb, kw, kb, vw, vb, ow, ob, w1, b1, w2, b2, g1, be1, g2, be2 = p
+    return [torch.cat([qw, kw, vw], 0), torch.cat([qb, kb, vb], 0), ow, ob, w1, b1, w2, b2, g1, be1, g2, be2]  # stacking: copies
+
+
+def _from_canonical(g: List[Tensor]):
+    dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2 = g
+    d = dWqkv.shape[1]
+    return [dWqkv[:d], dbqkv[:d], dWqkv[d:2 * d], dbqkv[d:2 * d], dWqkv[2 * d:], dbqkv[2 * d:], dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1,
+            dg2, dbe2]
+
+
+def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool):
+    """Differentiable pass through a flava.TransformerEncoder.  Returns (x_L [B,S,d], hidden states (detached) or None)."""
+    from ...modules.layers.mlp import fused_activation_code
+
+    B, S, d = x.shape
+    params, eps1, eps2, act = [], [], [], None
+    for layer in encoder.layer:
+        if not layer.norm_first:
+            raise ops.MmamdError("training on the MI355X path implements pre-norm (norm_first=True) encoder layers")
+        if layer.attention_dropout.p > 0 or layer.feedforward_dropout.p > 0:
+            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
+        steps = layer.feedforward.plan()
+        if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
+            raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
+        act = steps[0][1] if act is None else act
+        if act != steps[0][1]:
+            raise ops.MmamdError("training: all layers of a stack must use the same activation")
+        at = layer.attention
+        params += [at.query.weight, at.query.bias, at.key.weight, at.key.bias, at.value.weight, at.value.bias, at.output.weight,
+                   at.output.bias, steps[0][0].weight, steps[0][0].bias, steps[1][0].weight, steps[1][0].bias,
+                   layer.attention_layernorm.weight, layer.attention_layernorm.bias, layer.feedforward_layernorm.weight,
+                   layer.feedforward_layernorm.bias]
+        eps1.append(layer.attention_layernorm.eps)
+        eps2.append(layer.feedforward_layernorm.eps)
+    cfg = StackConfig(len(encoder.layer), encoder.layer[0].attention.n_head, B, S, False, act, eps1, eps2, 16, _to_canonical,
+                      _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden)
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)
+    hidden = [h.view(B, S, d) for h in cfg.hidden] if keep_hidden else None
+    return y.view(B, S, d), hidden

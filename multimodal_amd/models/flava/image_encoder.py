@@ -18,6 +18,7 @@ from ... import ops
 from ..._packing import PackedCache
 from ...modules.layers.normalizations import Fp32LayerNorm
 from ...modules.layers.transformer import TransformerOutput
+from ..._autograd import wants_grad
 from ...modules.losses.flava import Pooler
 from .transformer import init_transformer_weights, TransformerEncoder
 
@@ -86,6 +87,17 @@ class ImageEmbeddings(nn.Module):
         if self.training and self.dropout.p > 0:
             raise ops.MmamdError("embedding dropout > 0 in training mode is not implemented on the MI355X path")
         B = pixel_values.shape[0]
+        if wants_grad(self):
+            if image_patches_mask is not None or interpolate_pos_encoding:
+                raise ops.MmamdError("training on the MI355X path: image_patches_mask / interpolate_pos_encoding are not implemented")
+            pe_mod = self.patch_embeddings
+            if pixel_values.shape[2] != pe_mod.image_size[0] or pixel_values.shape[3] != pe_mod.image_size[1]:
+                raise ValueError(f"Input image size ({pixel_values.shape[2]}*{pixel_values.shape[3]}) doesn't match model "
+                                 f"({pe_mod.image_size[0]}*{pe_mod.image_size[1]}).")
+            from ._train import FlavaImageEmbedFn
+
+            return FlavaImageEmbedFn.apply(pixel_values, pe_mod.projection.weight, pe_mod.projection.bias, self.cls_token,
+                                           self.position_embeddings, pe_mod.patch_size[0])
         pe = self.patch_embeddings(pixel_values, interpolate_pos_encoding=interpolate_pos_encoding)
         G2 = pe.shape[1]
         pk, f32 = self._packed.get, torch.float32

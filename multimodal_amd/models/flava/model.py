@@ -25,7 +25,7 @@ from ...modules.layers.normalizations import Fp32LayerNorm
 from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.flava import cls_linear, Pooler
 from ...utils.common import load_module_from_url
-from ..clip._transformer import forbid_training_forward
+from ..._autograd import wants_grad
 from .image_encoder import flava_image_encoder
 from .text_encoder import flava_text_encoder
 from .transformer import FLAVATransformerWithoutEmbeddings, TransformerEncoder
@@ -110,7 +110,7 @@ class FLAVAModel(nn.Module):
         required_embedding: Optional[EMBEDDING_OPTIONS] = None,
         skip_unmasked_mm_encoder: bool = True,
     ) -> FLAVAOutput:
-        forbid_training_forward(self)
+        training = wants_grad(self)
         if required_embedding is None:
             if image is not None and text is not None:
                 required_embedding = "mm"
@@ -132,7 +132,7 @@ class FLAVAModel(nn.Module):
         # text tower(s) on the side stream, image tower(s) on the caller's stream
         side = None
         dev = (image if image is not None else text).device
-        if want_image and (want_text or want_text_masked) and dev.type == "cuda":
+        if want_image and (want_text or want_text_masked) and dev.type == "cuda" and not training:
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
             side.wait_stream(main)
@@ -202,6 +202,11 @@ class FLAVAModel(nn.Module):
 
     def _token_linear(self, x: Tensor, lin: nn.Linear, out: Tensor) -> None:
         """out[B, S, dm] (a strided slice of the fused sequence) = lin(x[B, S, d]) — bf16 MFMA GEMM per sample block."""
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and lin.weight.requires_grad)):
+            from ._train import TokenLinearFn
+
+            out.copy_(TokenLinearFn.apply(x, lin.weight, lin.bias))  # the placement copy is recorded by autograd (CopySlices)
+            return
         B, S, d = x.shape
         h = ops.convert((x if x.is_contiguous() else x.contiguous()).view(B * S, d), torch.bfloat16)
         y = ops.gemm_bf16(h, self._packed.get(lin.weight, torch.bfloat16),

@@ -25,6 +25,7 @@ from ...modules.layers.attention import key_mask_from_attention_mask, MultiHeadA
 from ...modules.layers.mlp import MLP
 from ...modules.layers.normalizations import Fp32LayerNorm
 from ...modules.layers.transformer import TransformerOutput
+from ..._autograd import wants_grad
 from ..clip._transformer import forbid_training_forward
 
 
@@ -59,7 +60,8 @@ class FLAVATransformerWithoutEmbeddings(nn.Module):
             # [cls | tokens]: a strided device copy into one buffer (layout plumbing, no arithmetic)
             B, S, d = hidden_states.shape
             fused = torch.empty((B, S + 1, d), dtype=hidden_states.dtype, device=hidden_states.device)
-            fused[:, 0:1].copy_(self.cls_token.detach().to(hidden_states.dtype).expand(B, -1, -1))
+            cls = self.cls_token if (torch.is_grad_enabled() and self.training) else self.cls_token.detach()
+            fused[:, 0:1].copy_(cls.to(hidden_states.dtype).expand(B, -1, -1))  # differentiable w.r.t. cls_token in training
             fused[:, 1:].copy_(hidden_states)
             hidden_states = fused
         encoder_output = self.encoder(hidden_states, attention_mask=attention_mask, return_hidden_states=True,
@@ -156,10 +158,20 @@ class TransformerEncoder(nn.Module):
                 return_attn_weights: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
         if head_mask is not None:
             raise ops.MmamdError("head_mask is not implemented on the MI355X path")
-        forbid_training_forward(self)
         if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
             raise ops.MmamdError("TransformerEncoder on the MI355X path takes fp32 [b, seq, c] hidden states")
         B, S, d = hidden_states.shape
+        if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
+            # differentiable forward (models/flava/_train.py): attention probabilities are not produced in this mode
+            from ._train import run_encoder
+
+            km = key_mask_from_attention_mask(attention_mask, B, S)
+            x, hidden = run_encoder(self, hidden_states, km, return_hidden_states)
+            if hidden is not None:
+                hidden[-1] = x  # the last entry feeds FLAVA's multimodal encoder: keep it attached to the graph
+            if self.final_layer_norm is not None:
+                x = self.final_layer_norm(x)
+            return TransformerOutput(last_hidden_state=x, hidden_states=hidden, attentions=None)
         x = (hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()).view(B * S, d)
         km = key_mask_from_attention_mask(attention_mask, B, S)
         all_hidden_states: Optional[List[Tensor]] = [] if return_hidden_states else None

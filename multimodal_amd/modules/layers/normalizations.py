@@ -20,6 +20,10 @@ class Fp32LayerNorm(nn.LayerNorm):
     def forward(self, x: Tensor) -> Tensor:
         if self.weight is None or self.bias is None or len(self.normalized_shape) != 1:
             raise ops.MmamdError("Fp32LayerNorm on the MI355X path needs a 1-D affine LayerNorm")
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and self.weight.requires_grad)):
+            from ..._autograd import LayerNormFn  # differentiable path: forward and backward HIP kernels
+
+            return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         g = self._packed.get(self.weight, torch.float32)
         b = self._packed.get(self.bias, torch.float32)
         xc = x if x.is_contiguous() else x.contiguous()

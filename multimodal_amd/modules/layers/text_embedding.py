@@ -53,6 +53,13 @@ class BERTTextEmbeddings(nn.Module):
         B, S = input_ids.shape
         if position_ids is not None and position_ids.shape != input_ids.shape:
             position_ids = position_ids.expand(B, S).contiguous()
+        ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        if self.training and torch.is_grad_enabled() and self.word_embeddings.weight.requires_grad:
+            from ...models.flava._train import BertEmbedFn  # differentiable path
+
+            return BertEmbedFn.apply(ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
+                                     self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, token_type_ids, position_ids,
+                                     self.word_embeddings.padding_idx)
         pk, f32 = self._packed.get, torch.float32
         x = ops.bert_embed_ln(input_ids if input_ids.is_contiguous() else input_ids.contiguous(),
                               pk(self.word_embeddings.weight, f32), pk(self.position_embeddings.weight, f32),

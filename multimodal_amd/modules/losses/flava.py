@@ -91,13 +91,25 @@ class Pooler(nn.Module):
         self._packed = PackedCache()
 
     def forward(self, hidden_states: Tensor) -> Tensor:
-        return cls_linear(hidden_states, self.dense, self._packed, tanh=True)
+        # forward-only on the MI355X path (the contrastive objectives do not use the pooled output): computed on detached states
+        return cls_linear(hidden_states.detach(), self.dense, self._packed, tanh=True)
 
 
 def cls_linear(hidden_states: Tensor, dense: nn.Linear, packed: PackedCache, tanh: bool = False) -> Tensor:
     """dense(hidden_states[:, 0]) for a contiguous fp32 [B, S, d] tensor (or a [B, d] one), without materialising the slice."""
     if hidden_states.dtype != torch.float32:
         raise ops.MmamdError("pooled projections on the MI355X path take fp32 hidden states")
+    if not tanh and torch.is_grad_enabled() and (hidden_states.requires_grad or dense.weight.requires_grad and dense.training):
+        from ..._autograd import RowsLinearFn  # differentiable path: gather the first row of every sample, Linear, both on HIP
+
+        if hidden_states.dim() == 3:
+            B, S, d = hidden_states.shape
+            x2d = hidden_states.reshape(B * S, d)
+            rows = torch.arange(0, B * S, S, dtype=torch.int64, device=hidden_states.device)
+        else:
+            x2d = hidden_states
+            rows = torch.arange(hidden_states.shape[0], dtype=torch.int64, device=hidden_states.device)
+        return RowsLinearFn.apply(x2d, rows, dense.weight, dense.bias)
     if hidden_states.dim() == 3:
         base = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
         B, S, d = base.shape
@@ -135,8 +147,14 @@ class FLAVAGlobalContrastiveLoss(nn.Module):
     def forward(self, image_sequence: Tensor, text_sequence: Tensor, mask: Tensor) -> FLAVAGlobalContrastiveLossOutput:
         if image_sequence.dim() != 2 or text_sequence.dim() != 2:
             raise ops.MmamdError("FLAVAGlobalContrastiveLoss on the MI355X path takes the projected [B, E] embeddings")
-        text_embedding = ops.l2_normalize(_f32c(text_sequence))
-        image_embedding = ops.l2_normalize(_f32c(image_sequence))
+        if torch.is_grad_enabled() and (image_sequence.requires_grad or text_sequence.requires_grad):
+            from ..._autograd import L2NormalizeFn  # differentiable: normalise and loss nodes with HIP forward + backward
+
+            text_embedding = L2NormalizeFn.apply(text_sequence)
+            image_embedding = L2NormalizeFn.apply(image_sequence)
+        else:
+            text_embedding = ops.l2_normalize(_f32c(text_sequence))
+            image_embedding = ops.l2_normalize(_f32c(image_sequence))
         ops.clamp_scalar_(self.logit_scale.data.view(1), 0.0, 4.6052)  # reference :276
         output = contrastive_loss_with_temperature(
             embeddings_a=image_embedding,
@@ -348,6 +366,12 @@ class FLAVAPretrainingLoss(nn.Module):
         outputs = FLAVAPretrainingLossOutput()
         pos_mask = None
         row_keep = None
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
+                image_masked_sequence, text_masked_sequence, multimodal_masked_sequence)):
+            # the masked-prediction / ITM heads are forward-only kernels: refuse instead of returning losses without a graph
+            raise NotImplementedError(
+                "FLAVAPretrainingLoss: the MLM / MIM / ITM heads have no backward on the MI355X path yet; train the contrastive "
+                "objective with FLAVAGlobalContrastiveLoss (differentiable), or evaluate this loss under torch.no_grad()")
 
         # unimodal MIM / MLM: only when there is no multimodal sequence (reference :391-416)
         if image_masked_sequence is not None and self.mim_weight > 0 and multimodal_masked_sequence is None:

@@ -200,13 +200,17 @@ def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, S
     return out, probs
 
 
-def attention_fwd_train(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+def attention_fwd_train(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool,
+                        key_mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Self-attention forward that also saves the log2-domain log-sum-exp [B,H,S] for attention_bwd."""
     _chk(qkv, "qkv", torch.bfloat16)
     D = H * 64
     if qkv.shape != (B * S, 3 * D):
         raise MmamdError(f"attention: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * D)}")
     lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    if key_mask is not None:  # padded keys: the general kernel (two-pass) takes the mask
+        out, _ = attention_x_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, S, H, 64, AttnMask(causal=causal, key_mask=key_mask), lse=lse)
+        return out, lse
     out = torch.empty((B * S, D), dtype=torch.bfloat16, device=qkv.device)
     check(_lib.lib().mmamd_attention_fwd_lse(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, S, H, int(bool(causal)),
                                              1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_fwd_lse")
@@ -214,7 +218,7 @@ def attention_fwd_train(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool)
 
 
 def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, S: int, H: int,
-                  causal: bool) -> torch.Tensor:
+                  causal: bool, key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dqkv bf16 [B*S, 3*H*64] = [dQ | dK | dV] from the saved forward tensors."""
     for n, x in (("qkv", qkv), ("out", out), ("dout", dout)):
         _chk(x, n, torch.bfloat16)
@@ -222,8 +226,12 @@ def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse:
     D = H * 64
     if qkv.shape != (B * S, 3 * D) or out.shape != (B * S, D) or dout.shape != (B * S, D) or lse.shape != (B, H, S):
         raise MmamdError("attention_bwd: shape mismatch")
+    if key_mask is not None:
+        _chk(key_mask, "key_mask", torch.uint8)
+        if key_mask.shape != (B, S):
+            raise MmamdError("attention_bwd: key_mask must be [B, S]")
     dqkv = torch.empty_like(qkv)
-    check(_lib.lib().mmamd_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, S, H,
+    check(_lib.lib().mmamd_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), _ptr(key_mask), dqkv.data_ptr(), B, S, H,
                                          int(bool(causal)), 1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_bwd")
     return dqkv
 
@@ -278,14 +286,15 @@ def key_mask(src: torch.Tensor, pad_id: Optional[int] = None) -> torch.Tensor:
     return out
 
 
-def bert_embed_ln(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, typ: torch.Tensor, gamma: torch.Tensor,
-                  beta: torch.Tensor, eps: float, token_type_ids: Optional[torch.Tensor] = None,
+def bert_embed_ln(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, typ: torch.Tensor, gamma: Optional[torch.Tensor],
+                  beta: Optional[torch.Tensor], eps: float, token_type_ids: Optional[torch.Tensor] = None,
                   position_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """LayerNorm(word[ids] + pos[position] + type[token_type]) -> fp32 [B*S, d]."""
     _chk(ids, "input_ids", torch.int64)
-    for n, t in (("word_embeddings", word), ("position_embeddings", pos), ("token_type_embeddings", typ),
-                 ("gamma", gamma), ("beta", beta)):
+    for n, t in (("word_embeddings", word), ("position_embeddings", pos), ("token_type_embeddings", typ)):
         _chk(t, n, torch.float32)
+    if gamma is not None:  # None: the un-normalised sum
+        _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
     for n, t in (("token_type_ids", token_type_ids), ("position_ids", position_ids)):
         if t is not None:
             _chk(t, n, torch.int64)
@@ -295,7 +304,7 @@ def bert_embed_ln(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, typ:
     d = word.shape[1]
     x = torch.empty((B * S, d), dtype=torch.float32, device=ids.device)
     check(_lib.lib().mmamd_bert_embed_ln(ids.data_ptr(), _ptr(token_type_ids), _ptr(position_ids), word.data_ptr(),
-                                         pos.data_ptr(), typ.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                         pos.data_ptr(), typ.data_ptr(), _ptr(gamma), _ptr(beta), float(eps),
                                          x.data_ptr(), B, S, d, word.shape[0], pos.shape[0], typ.shape[0], _stream()),
           "mmamd_bert_embed_ln")
     return x

@@ -240,3 +240,54 @@ def test_training_step_under_ddp_single_rank_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_flava_training_step_gradients_vs_reference_autograd(golden):
+    """FLAVA dual encoder + multimodal encoder + global contrastive loss in train mode: every reached parameter's gradient against
+    the reference's torch autograd (padded text -> key masks in the attention backward; shared encoders used twice)."""
+    from multimodal_amd.models.flava.model import flava_model
+    from multimodal_amd.modules.losses.flava import FLAVAGlobalContrastiveLoss
+    from tests._util import fixture_sd
+    from tests.golden.make_golden_flava_grad import SMALL_KW
+
+    z, zg = golden("flava_small.npz"), golden("flava_grad.npz")
+    model = flava_model(**SMALL_KW)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fixture_sd(z).items()}, strict=True)
+    model = model.cuda().train()
+    loss_mod = FLAVAGlobalContrastiveLoss().cuda()
+    image, text, text_masked = (torch.from_numpy(z[k]).cuda() for k in ("image", "text", "text_masked"))
+    out = model(image, text, text_masked=text_masked)
+    assert out.image.attentions is None and len(out.image.hidden_states) == 3  # training mode: no probabilities
+    itc = loss_mod(out.projected_image_embeddings, out.projected_text_embeddings, torch.ones(image.shape[0], dtype=torch.bool, device="cuda")).loss
+    probe = torch.linspace(-1.0, 1.0, 128, device="cuda")
+    mm_term = (out.multimodal_masked.last_hidden_state[:, 0] * probe).sum(-1).mean()
+    (itc + mm_term).backward()
+    assert abs(float(itc) - float(zg["itc"])) <= 1e-2 and abs(float(mm_term) - float(zg["mm_term"])) <= 6e-2  # a 128-term sum of LN outputs
+    no_grad = {str(k) for k in zg["no_grad_keys"]}
+    report, worst = {}, ("", 0.0)
+    for k, p in list(model.named_parameters()) + [("logit_scale", loss_mod.logit_scale)]:
+        if k in no_grad:
+            assert p.grad is None or not p.grad.any(), k
+            continue
+        assert p.grad is not None, k
+        ref = zg["g." + k].astype(np.float64)
+        got = host(p.grad)
+        assert got.shape == ref.shape, k
+        if np.abs(ref).max() < 1e-6:
+            # mathematically zero gradients (a key bias shifts every score of a query by the same amount: softmax-invariant): the
+            # reference holds fp32 round-off there, this path bf16 round-off of the dK rows it sums — both must be ~0
+            assert k.endswith("attention.key.bias") and np.abs(got).max() <= 2e-3, (k, np.abs(got).max())
+            continue
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        rms = np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-12)
+        report[k] = (rel, rms)
+        if rel > worst[1]:
+            worst = (k, rel)
+    print("flava grad parity: worst max-rel", worst, " median max-rel", float(np.median([v[0] for v in report.values()])),
+          " median rms-rel", float(np.median([v[1] for v in report.values()])), " tensors", len(report))
+    for k, (rel, rms) in report.items():
+        assert rel <= 8e-2 and rms <= 4e-2, (k, rel, rms)
+    from multimodal_amd import ops
+
+    with pytest.raises(ops.MmamdError):  # patch masking in training mode is not implemented (forward-only feature)
+        model(image, text, image_patches_mask=torch.zeros(image.shape[0], 4, dtype=torch.long, device="cuda"))

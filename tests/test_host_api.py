@@ -61,17 +61,27 @@ def test_no_cpu_fallback():
 
 
 def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
-    """CLIP has a differentiable (training) forward on the HIP kernels; like everything else it has no CPU path.  FLAVA / CoCa
-    are forward-only: a training-mode forward with grad enabled is refused instead of silently returning detached outputs."""
+    """CLIP and FLAVA have a differentiable (training) forward on the HIP kernels; like everything else it has no CPU path.  CoCa
+    and the FLAVA pre-training heads are forward-only: a training-mode forward with grad enabled is refused instead of silently
+    returning detached outputs."""
     from multimodal_amd import ops
     from multimodal_amd.models.clip import CLIPViTEncoder
-    from multimodal_amd.models.flava.transformer import TransformerEncoder
+    from multimodal_amd.models.flava.transformer import TransformerEncoder as FlavaEncoder
+    from multimodal_amd.modules.layers.transformer import TransformerEncoder as LayersEncoder
+    from multimodal_amd.modules.losses.flava import FLAVAPretrainingLoss
 
     vit = CLIPViTEncoder(embedding_dim=8, heads=1, layers=1, patch_size=16, image_size=32, width=64).train()
     with pytest.raises(ops.MmamdError, match="no CPU"):
         vit(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(ops.MmamdError, match="no CPU"):
+        FlavaEncoder(1, 128, 2, 256, activation=torch.nn.GELU, norm_first=True).train()(torch.zeros(1, 4, 128))
+    with pytest.raises(ops.MmamdError, match="pre-norm"):
+        FlavaEncoder(1, 128, 2, 256, activation=torch.nn.GELU).train()(torch.zeros(1, 4, 128))
     with pytest.raises(NotImplementedError, match="backward"):
-        TransformerEncoder(1, 128, 2, 256).train()(torch.zeros(1, 4, 128))
+        LayersEncoder(1, 128, 2, 256, activation=torch.nn.GELU, norm_first=True).train()(torch.zeros(1, 4, 128))
+    with pytest.raises(NotImplementedError, match="MLM / MIM / ITM"):
+        FLAVAPretrainingLoss(hidden_size=128, text_vocab_size=64, image_vocab_size=64)(
+            image_masked_sequence=torch.zeros(1, 5, 128, requires_grad=True), mim_labels=torch.zeros(1, 4, dtype=torch.long))
 
 
 def test_input_guards_match_reference():
