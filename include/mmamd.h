@@ -260,14 +260,20 @@ int mmamd_f32_gemm_strided(const float* X, int64_t sxm, int64_t sxk, const float
 int mmamd_select_tokens(const int64_t* labels, const uint8_t* row_keep, int64_t ignore_index, int B, int L, int seq_S,
                         int tok_offset, int32_t* idx_out, int64_t* label_out, int32_t* count_out, mmamd_stream_t stream);
 
-/* dst[i,:] = src[idx[i]*row_stride : +d] (fp32 source rows; dst fp32 or bf16, dense [n,d]). */
+/* dst[i,:] = src[idx[i]*row_stride : +d] (fp32 source rows; dst fp32 or bf16, dense [n,d]); zero_rows (optional, int64 [n]):
+ * output rows with a non-zero flag are written as zeros (masked patches in the image-embedding backward). */
 int mmamd_gather_rows(const float* src, int64_t row_stride, const int32_t* idx, int n, int d, void* dst, int dst_dtype,
-                      mmamd_stream_t stream);
+                      const int64_t* zero_rows, mmamd_stream_t stream);
 
 /* nn.CrossEntropyLoss(ignore_index=...) with mean reduction: out_loss[0] = mean over kept rows of lse(logits[i]) -
  * logits[i, labels[i]] (NaN when no row is kept, like torch).  ws: 2*N floats.  Replaces :137-140, :225-228. */
 int mmamd_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int N, int V, int64_t ignore_index,
                         float* out_loss, float* ws, mmamd_stream_t stream);
+
+/* Backward of mmamd_cross_entropy (mean over kept rows): dlogits[N, ldd] (bf16 or fp32; columns [V, ldd) zeroed) =
+ * grad_out[0] / n_kept * (softmax - onehot) on kept rows, 0 on ignored rows.  ws: 2*N + 1 floats. */
+int mmamd_cross_entropy_bwd(const float* logits, int64_t ld, const int64_t* labels, int N, int V, int64_t ignore_index,
+                            const float* grad_out, void* dlogits, int dlogits_dtype, int64_t ldd, float* ws, mmamd_stream_t stream);
 
 /* Elementwise dtype conversion helper (fp32 <-> bf16), n elements. Used for weight packing. */
 int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,

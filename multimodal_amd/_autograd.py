@@ -200,3 +200,95 @@ class L2NormalizeFn(torch.autograd.Function):
 
 def wants_grad(module) -> bool:
     return module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Mean cross entropy with ignore_index over a small fp32 [N, V] logits matrix (ITM's [B, 2]); gradient in fp32."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index: int):
+        lg = logits.detach()
+        lg = lg if lg.is_contiguous() else lg.contiguous()
+        ctx.save_for_backward(lg, labels)
+        ctx.ignore = ignore_index
+        return ops.cross_entropy(lg, labels, ignore_index)
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, labels = ctx.saved_tensors
+        return ops.cross_entropy_bwd(lg, labels, ctx.ignore, g.detach().reshape(1).to(f32).contiguous()), None, None
+
+
+class TanhRowsLinearFn(torch.autograd.Function):
+    """Pooler: tanh(x2d[rows] . W^T + b) (modules/losses/flava.py:84-97), differentiable."""
+
+    @staticmethod
+    def forward(ctx, x2d, rows64, weight, bias):
+        d = x2d.shape[1]
+        xc = x2d.detach()
+        xc = xc if xc.is_contiguous() else xc.contiguous()
+        sel = ops.gather_rows(xc, d, rows64.to(torch.int32), d, f32)
+        y = ops.rows_linear_f32(sel, d, sel.shape[0], c32(weight), c32(bias), tanh=True)
+        ctx.save_for_backward(sel, rows64, weight, y)
+        ctx.xshape = tuple(x2d.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sel, rows64, weight, y = ctx.saved_tensors
+        B, d = sel.shape
+        E = y.shape[1]
+        # dz = dy * (1 - y^2): a [B, E] elementwise product — host-level glue on the pooled rows (B x 768 values)
+        dz = (dy.detach() * (1.0 - y * y)).contiguous()
+        W = c32(weight)
+        dW = ops.f32_gemm_strided(dz, 1, E, sel, 1, d, E, d, B)
+        dsel = ops.f32_gemm_strided(dz, E, 1, W, 1, d, B, d, E)
+        db = ops.colsum(dz)
+        dx = torch.zeros(ctx.xshape, dtype=f32, device=dz.device)
+        ops.scatter_add_rows_(dx, rows64, dsel)
+        return dx, None, dW, db
+
+
+class MaskedHeadLossFn(torch.autograd.Function):
+    """MaskedPredictionLoss on the labelled positions (modules/losses/flava.py:174-238): rows -> dense -> GELU -> LayerNorm ->
+    vocabulary projection (+tied bias) -> mean cross entropy.  Returns (loss, logits [Nm, V]); the logits are an output, not
+    differentiable through this node."""
+
+    @staticmethod
+    def forward(ctx, base, idx32, labels, dense_w, dense_b, ln_w, ln_b, dec_w, dec_b, eps: float, ignore_index: int):
+        B, S, d = base.shape
+        V = dec_w.shape[0]
+        b2d = base.detach()
+        b2d = (b2d if b2d.is_contiguous() else b2d.contiguous()).view(B * S, d)
+        rows = ops.gather_rows(b2d, d, idx32, d, bf)
+        u = ops.gemm_bf16(rows, ops.convert(c32(dense_w), bf), c32(dense_b))           # pre-activation, bf16
+        g = ops.convert(ops.act_fwd(u, ops.ACT_GELU_ERF), f32)                          # LayerNorm input (fp32 for its backward)
+        n = ops.layernorm(g, c32(ln_w), c32(ln_b), eps, out_dtype=bf)
+        Vp = (V + 63) // 64 * 64
+        wp = torch.zeros((Vp, d), dtype=bf, device=base.device)                          # vocabulary padded to the GEMM granule
+        ops.convert(c32(dec_w), bf, out=wp[:V])
+        bp = torch.zeros(Vp, dtype=f32, device=base.device)
+        bp[:V].copy_(c32(dec_b))
+        logits = ops.gemm_bf16(n, wp, bp, out_dtype=f32)[:, :V]
+        loss = ops.cross_entropy(logits, labels, ignore_index)
+        ctx.save_for_backward(rows, u, g, n, logits, labels, idx32, dense_w, ln_w, wp)
+        ctx.meta = (tuple(base.shape), eps, ignore_index, V, Vp)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_logits):
+        rows, u, g, n, logits, labels, idx32, dense_w, ln_w, wp = ctx.saved_tensors
+        (B, S, d), eps, ignore_index, V, Vp = ctx.meta
+        dlog = ops.cross_entropy_bwd(logits, labels, ignore_index, g_loss.detach().reshape(1).to(f32).contiguous(), out_dtype=bf,
+                                     pad_cols_to=64)                                    # bf16 [Nm, Vp]
+        # logits = n Wdec^T + bias
+        dn = ops.gemm_bf16(dlog, ops.transpose_to_bf16(wp, pad_to=64), None, out_dtype=f32)  # [Nm, d] = dlog . Wdec
+        dWp, dbp = wgrad(dlog, n, bias=True)                                             # [Vp, d], [Vp]
+        dg_, dlnw, dlnb = ops.layernorm_bwd(g, c32(ln_w), dn, eps)
+        du = ops.act_bwd(u, ops.convert(dg_, bf), ops.ACT_GELU_ERF)
+        drows = dgrad(du, c32(dense_w), f32)
+        dWd, dbd = wgrad(du, rows, bias=True)
+        dbase = torch.zeros((B * S, d), dtype=f32, device=drows.device)                  # memset; only labelled rows get gradient
+        ops.scatter_add_rows_(dbase, idx32.to(torch.int64), drows)
+        return dbase.view(B, S, d), None, None, dWd, dbd, dlnw, dlnb, dWp[:V], dbp[:V], None, None

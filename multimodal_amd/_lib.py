@@ -47,7 +47,8 @@ PROTOTYPES = {
     "mmamd_scatter_add_rows": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),
     "mmamd_f32_gemm_strided": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_select_tokens": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "mmamd_gather_rows": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _vp]),
+    "mmamd_gather_rows": (_i, [_vp, _i64, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "mmamd_cross_entropy_bwd": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _i, _i64, _vp, _vp]),
     "mmamd_cross_entropy": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp]),
     "mmamd_attention_x_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mmamd_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -221,6 +221,43 @@ __global__ __launch_bounds__(256) void f32_gemm_strided_kernel(const float* __re
   }
 }
 
+
+// backward of mmamd_cross_entropy: dlogits[row, j] = g / n_kept * (softmax(logits[row])[j] - [j == label]) for kept rows, 0 for
+// ignored rows and for the padding columns [V, ldd).  g = *gout (upstream gradient of the mean loss), n_kept = *cnt.
+template <typename TD>
+__global__ __launch_bounds__(256) void ce_generic_bwd_kernel(const float* __restrict__ logits, size_t ld, const int64_t* __restrict__ labels,
+                                                             int N, int V, long long ignore, const float* __restrict__ gout,
+                                                             const float* __restrict__ cnt, TD* __restrict__ dlogits, size_t ldd) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TD* out = dlogits + (size_t)row * ldd;
+  const long long lab = labels[row];
+  if (lab == ignore || lab < 0 || lab >= V) {
+    for (int j = tid; j < (int)ldd; j += 256) out[j] = (TD)0.f;
+    return;
+  }
+  const float* x = logits + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int j = tid; j < V; j += 256) m = fmaxf(m, x[j]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int j = tid; j < V; j += 256) se += expf(x[j] - m);
+  se = wave_sum(se);
+  if (lane == 0) red[wave] = se;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  const float w = gout[0] / cnt[0];
+  for (int j = tid; j < (int)ldd; j += 256) {
+    float g = 0.f;
+    if (j < V) g = w * (expf(x[j] - m) * inv - (j == lab ? 1.f : 0.f));
+    out[j] = (TD)g;
+  }
+}
+
 }  // namespace mmamd
 
 using namespace mmamd;
@@ -274,12 +311,13 @@ __global__ __launch_bounds__(1024) void select_tokens_kernel(const int64_t* __re
 // dst[i, :] = src[idx[i], :] (fp32 rows `row_stride` floats apart) as fp32 or bf16 — wave per row
 template <typename TO>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, size_t row_stride, const int* __restrict__ idx,
-                                                          int n, int d, TO* __restrict__ dst) {
+                                                          int n, int d, TO* __restrict__ dst, const int64_t* __restrict__ zero_rows) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const float* s = src + (size_t)idx[row] * row_stride;
-  for (int c = lane; c < (d >> 2); c += 64) store4(dst + (size_t)row * d + 4 * c, load4(s + 4 * c));
+  const bool zero = zero_rows != nullptr && zero_rows[row] != 0;  // e.g. masked patches: their embedding gets no gradient
+  for (int c = lane; c < (d >> 2); c += 64) store4(dst + (size_t)row * d + 4 * c, zero ? f32x4{0.f, 0.f, 0.f, 0.f} : load4(s + 4 * c));
 }
 
 // nn.CrossEntropyLoss(ignore_index) rows: ws[row] = lse - logit[label] (0 for ignored rows), ws[N + row] = 1 / 0 kept flag
@@ -355,7 +393,7 @@ extern "C" int mmamd_select_tokens(const int64_t* labels, const uint8_t* row_kee
 }
 
 extern "C" int mmamd_gather_rows(const float* src, int64_t row_stride, const int32_t* idx, int n, int d, void* dst, int dst_dtype,
-                                 mmamd_stream_t stream) {
+                                 const int64_t* zero_rows, mmamd_stream_t stream) {
   if (n == 0) return 0;
   MMAMD_CHECK_ARG(src && idx && dst && n > 0 && d > 0 && d % 4 == 0 && row_stride >= d && row_stride % 4 == 0, MMAMD_E_BADARG,
                   "gather_rows: bad argument");
@@ -363,9 +401,9 @@ extern "C" int mmamd_gather_rows(const float* src, int64_t row_stride, const int
   if (n == 0) return 0;
   const dim3 grid((n + 3) / 4), block(256);
   if (dst_dtype == MMAMD_F32)
-    hipLaunchKernelGGL((gather_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, src, (size_t)row_stride, idx, n, d, (float*)dst);
+    hipLaunchKernelGGL((gather_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, src, (size_t)row_stride, idx, n, d, (float*)dst, zero_rows);
   else if (dst_dtype == MMAMD_BF16)
-    hipLaunchKernelGGL((gather_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, src, (size_t)row_stride, idx, n, d, (bf16*)dst);
+    hipLaunchKernelGGL((gather_rows_kernel<bf16>), grid, block, 0, (hipStream_t)stream, src, (size_t)row_stride, idx, n, d, (bf16*)dst, zero_rows);
   else
     MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "gather_rows: bad dst_dtype %d", dst_dtype);
   return launch_status("gather_rows");
@@ -427,4 +465,24 @@ extern "C" int mmamd_f32_gemm_strided(const float* X, int64_t sxm, int64_t sxk, 
                                       int ldr, float* C, int ldc, int M, int N, int K, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(X && Y && C && M > 0 && N > 0 && K > 0 && ldc >= N && (!R || ldr >= N), MMAMD_E_BADARG, "f32_gemm_strided: bad argument");
   return launch_f32_gemm(X, sxm, sxk, Y, syn, syk, nullptr, R, ldr, C, ldc, M, N, K, (hipStream_t)stream);
+}
+
+extern "C" int mmamd_cross_entropy_bwd(const float* logits, int64_t ld, const int64_t* labels, int N, int V, int64_t ignore_index,
+                                       const float* grad_out, void* dlogits, int dlogits_dtype, int64_t ldd, float* ws,
+                                       mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(logits && labels && grad_out && dlogits && ws && N > 0 && V > 0 && ld >= V && ldd >= V, MMAMD_E_BADARG,
+                  "cross_entropy_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  // kept-row count: the forward's row pass again (cheap next to the softmax below) then a one-block sum of the flags
+  hipLaunchKernelGGL(ce_generic_rows_kernel, dim3(N), dim3(256), 0, st, logits, (size_t)ld, labels, N, V, (long long)ignore_index, ws);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, st, ws + N, N, ws + 2 * (size_t)N);
+  if (dlogits_dtype == MMAMD_BF16)
+    hipLaunchKernelGGL((ce_generic_bwd_kernel<bf16>), dim3(N), dim3(256), 0, st, logits, (size_t)ld, labels, N, V, (long long)ignore_index,
+                       grad_out, ws + 2 * (size_t)N, (bf16*)dlogits, (size_t)ldd);
+  else if (dlogits_dtype == MMAMD_F32)
+    hipLaunchKernelGGL((ce_generic_bwd_kernel<float>), dim3(N), dim3(256), 0, st, logits, (size_t)ld, labels, N, V, (long long)ignore_index,
+                       grad_out, ws + 2 * (size_t)N, (float*)dlogits, (size_t)ldd);
+  else
+    MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "cross_entropy_bwd: bad dlogits dtype");
+  return launch_status("cross_entropy_bwd");
 }

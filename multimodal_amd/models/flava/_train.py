@@ -19,11 +19,11 @@ bf, f32 = torch.bfloat16, torch.float32
 
 
 class FlavaImageEmbedFn(torch.autograd.Function):
-    """pixel_values -> fp32 [B, G2+1, d]: conv patch embedding (+bias), CLS, + position embeddings (models/flava/image_encoder.py:139-177,
-    without patch masking)."""
+    """pixel_values -> fp32 [B, G2+1, d]: conv patch embedding (+bias), optional mask-token blend (binary patch mask), CLS,
+    + position embeddings (models/flava/image_encoder.py:139-177)."""
 
     @staticmethod
-    def forward(ctx, images, conv_w, conv_b, cls, pos, patch: int):
+    def forward(ctx, images, conv_w, conv_b, cls, pos, patch: int, patches_mask, mask_token):
         B = images.shape[0]
         w = conv_w.shape[0]
         K = conv_w.shape[1] * patch * patch
@@ -32,23 +32,35 @@ class FlavaImageEmbedFn(torch.autograd.Function):
         cols = ops.patchify(images if images.is_contiguous() else images.contiguous(), patch, K)
         pe = ops.gemm_bf16(cols, ops.convert(c32(conv_w).view(w, K), bf), c32(conv_b), out_dtype=f32)
         G2 = cols.shape[0] // B
-        x = ops.flava_image_embed(pe, c32(cls).view(-1), c32(pos).view(G2 + 1, w), B, G2)
-        ctx.save_for_backward(cols)
-        ctx.meta = (B, G2, w, tuple(conv_w.shape), tuple(cls.shape), tuple(pos.shape))
+        pm = None
+        if patches_mask is not None and mask_token is not None:
+            pm = patches_mask.reshape(B, G2)
+            pm = (pm if pm.dtype == torch.int64 else pm.to(torch.int64)).contiguous()
+        x = ops.flava_image_embed(pe, c32(cls).view(-1), c32(pos).view(G2 + 1, w), B, G2, pm,
+                                  c32(mask_token).view(-1) if pm is not None else None)
+        ctx.save_for_backward(cols, pm if pm is not None else torch.empty(0, device=images.device))
+        ctx.meta = (B, G2, w, tuple(conv_w.shape), tuple(cls.shape), tuple(pos.shape), pm is not None,
+                    tuple(mask_token.shape) if mask_token is not None else None)
         return x.view(B, G2 + 1, w)
 
     @staticmethod
     def backward(ctx, dx):
-        (cols,) = ctx.saved_tensors
-        B, G2, w, conv_shape, cls_shape, pos_shape = ctx.meta
+        cols, pm = ctx.saved_tensors
+        B, G2, w, conv_shape, cls_shape, pos_shape, masked, mt_shape = ctx.meta
         S = G2 + 1
         d_asm = dx.detach().contiguous().view(B * S, w)
         dpos = ops.colsum(d_asm.view(B, S * w)).view(S, w)
         dcls = dpos[0].clone()
         idx = (torch.arange(B * S, device=dx.device, dtype=torch.int32).view(B, S)[:, 1:]).reshape(-1).contiguous()
-        d_pe = ops.gather_rows(d_asm, w, idx, w, bf)
+        # masked patches (w = 1) take the mask token instead of their embedding: zero gradient for the embedding there
+        d_pe = ops.gather_rows(d_asm, w, idx, w, bf, zero_rows=pm.view(-1) if masked else None)
         dW, db = wgrad(d_pe, cols, bias=True)
-        return None, dW.view(conv_shape), db, dcls.view(cls_shape), dpos.view(pos_shape), None
+        dmt = None
+        if masked:  # sum over the masked patch rows = (sum over all patch rows) - (sum over the unmasked ones = the conv-bias gradient)
+            dmt = (dpos[1:].sum(0) - db).view(mt_shape)
+        elif mt_shape is not None:
+            dmt = torch.zeros(mt_shape, dtype=f32, device=dx.device)
+        return None, dW.view(conv_shape), db, dcls.view(cls_shape), dpos.view(pos_shape), None, None, dmt
 
 
 class BertEmbedFn(torch.autograd.Function):

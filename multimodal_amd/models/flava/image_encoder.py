@@ -88,8 +88,11 @@ class ImageEmbeddings(nn.Module):
             raise ops.MmamdError("embedding dropout > 0 in training mode is not implemented on the MI355X path")
         B = pixel_values.shape[0]
         if wants_grad(self):
-            if image_patches_mask is not None or interpolate_pos_encoding:
-                raise ops.MmamdError("training on the MI355X path: image_patches_mask / interpolate_pos_encoding are not implemented")
+            if interpolate_pos_encoding:
+                raise ops.MmamdError("training on the MI355X path: interpolate_pos_encoding is not implemented")
+            if image_patches_mask is not None and self.mask_token is None:
+                warnings.warn("image_patches_mask passed but use_image_masking in init was false. Ignoring.")
+                image_patches_mask = None
             pe_mod = self.patch_embeddings
             if pixel_values.shape[2] != pe_mod.image_size[0] or pixel_values.shape[3] != pe_mod.image_size[1]:
                 raise ValueError(f"Input image size ({pixel_values.shape[2]}*{pixel_values.shape[3]}) doesn't match model "
@@ -97,7 +100,8 @@ class ImageEmbeddings(nn.Module):
             from ._train import FlavaImageEmbedFn
 
             return FlavaImageEmbedFn.apply(pixel_values, pe_mod.projection.weight, pe_mod.projection.bias, self.cls_token,
-                                           self.position_embeddings, pe_mod.patch_size[0])
+                                           self.position_embeddings, pe_mod.patch_size[0], image_patches_mask,
+                                           self.mask_token if image_patches_mask is not None else None)
         pe = self.patch_embeddings(pixel_values, interpolate_pos_encoding=interpolate_pos_encoding)
         G2 = pe.shape[1]
         pk, f32 = self._packed.get, torch.float32

@@ -91,7 +91,12 @@ class Pooler(nn.Module):
         self._packed = PackedCache()
 
     def forward(self, hidden_states: Tensor) -> Tensor:
-        # forward-only on the MI355X path (the contrastive objectives do not use the pooled output): computed on detached states
+        if torch.is_grad_enabled() and hidden_states.requires_grad and hidden_states.dim() == 3:
+            from ..._autograd import TanhRowsLinearFn  # differentiable pooler (ITM head)
+
+            B, S, d = hidden_states.shape
+            rows = torch.arange(0, B * S, S, dtype=torch.int64, device=hidden_states.device)
+            return TanhRowsLinearFn.apply(hidden_states.reshape(B * S, d), rows, self.dense.weight, self.dense.bias)
         return cls_linear(hidden_states.detach(), self.dense, self._packed, tanh=True)
 
 
@@ -207,8 +212,13 @@ class ITMLoss(nn.Module):
             loss = torch.zeros((), dtype=torch.float32, device=scores.device)
         else:
             lab = labels.reshape(-1)
-            loss = ops.cross_entropy(scores.view(-1, 2), lab if lab.is_contiguous() else lab.contiguous(),
-                                     self.ce_loss.ignore_index)
+            lab = lab if lab.is_contiguous() else lab.contiguous()
+            if torch.is_grad_enabled() and scores.requires_grad:
+                from ..._autograd import CrossEntropyFn
+
+                loss = CrossEntropyFn.apply(scores.view(-1, 2), lab, self.ce_loss.ignore_index)
+            else:
+                loss = ops.cross_entropy(scores.view(-1, 2), lab, self.ce_loss.ignore_index)
         return ITMLossOutput(logits=scores, loss=loss)
 
 
@@ -270,7 +280,7 @@ class MaskedPredictionLoss(nn.Module):
             row_keep: Optional[Tensor] = None) -> MaskedPredictionLossOutput:
         """Loss over base[:, tok_offset:tok_offset+L, :] (base: contiguous fp32 [B, S, d]) without slicing it: only the
         labelled positions of the samples kept by `row_keep` (uint8 [B]) are gathered and pushed through the head."""
-        if base.dtype != torch.float32 or not base.is_contiguous() or base.dim() != 3:
+        if base.dtype != torch.float32 or base.dim() != 3 or (not base.is_contiguous() and not base.requires_grad):
             raise ops.MmamdError("MaskedPredictionLoss on the MI355X path takes contiguous fp32 [B, S, d] sequences")
         B, S, d = base.shape
         if masked_labels is None:
@@ -287,7 +297,16 @@ class MaskedPredictionLoss(nn.Module):
         lab2d = masked_labels.reshape(B, L)
         idx, lab = ops.select_tokens(lab2d if lab2d.is_contiguous() else lab2d.contiguous(), self.ignore_index, S, tok_offset,
                                      row_keep)
-        prediction = self.cls.run(ops.gather_rows(base, d, idx, d, torch.bfloat16))
+        if torch.is_grad_enabled() and (base.requires_grad or (self.training and self.cls.dense.weight.requires_grad)) and idx.numel() > 0:
+            from ..._autograd import MaskedHeadLossFn  # differentiable head: forward and backward on the HIP kernels
+
+            if self.cls.transform_act_fn is not nn.functional.gelu:
+                raise ops.MmamdError("MaskedPredictionHead on the MI355X path: transform_act_fn must be nn.functional.gelu")
+            c = self.cls
+            masked_loss, prediction = MaskedHeadLossFn.apply(base, idx, lab, c.dense.weight, c.dense.bias, c.layer_norm.weight,
+                                                             c.layer_norm.bias, c.decoder.weight, c.bias, c.layer_norm.eps, self.ignore_index)
+            return MaskedPredictionLossOutput(logits=prediction, loss=masked_loss)
+        prediction = self.cls.run(ops.gather_rows(base.detach(), d, idx, d, torch.bfloat16))
         masked_loss = ops.cross_entropy(prediction, lab, self.ignore_index)
         if self.ignore_nan and idx.numel() == 0:  # the only way this mean is NaN: no labelled position (:232-235)
             warnings.warn("NaN detected in masked_loss. Replacing it with 0.")
@@ -304,7 +323,8 @@ class MaskedPredictionLoss(nn.Module):
 
 
 def _base3(t: Tensor) -> Tensor:
-    t = t.detach()
+    if not (torch.is_grad_enabled() and t.requires_grad):
+        t = t.detach()
     if t.dtype != torch.float32:
         raise ops.MmamdError("FLAVAPretrainingLoss on the MI355X path takes fp32 sequences")
     return t if t.is_contiguous() else t.contiguous()
@@ -366,13 +386,6 @@ class FLAVAPretrainingLoss(nn.Module):
         outputs = FLAVAPretrainingLossOutput()
         pos_mask = None
         row_keep = None
-        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (
-                image_masked_sequence, text_masked_sequence, multimodal_masked_sequence)):
-            # the masked-prediction / ITM heads are forward-only kernels: refuse instead of returning losses without a graph
-            raise NotImplementedError(
-                "FLAVAPretrainingLoss: the MLM / MIM / ITM heads have no backward on the MI355X path yet; train the contrastive "
-                "objective with FLAVAGlobalContrastiveLoss (differentiable), or evaluate this loss under torch.no_grad()")
-
         # unimodal MIM / MLM: only when there is no multimodal sequence (reference :391-416)
         if image_masked_sequence is not None and self.mim_weight > 0 and multimodal_masked_sequence is None:
             seq = _base3(image_masked_sequence)

@@ -21,7 +21,7 @@ __all__ = [
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd",
-    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "cross_entropy_bwd",
 ]
 
 
@@ -369,13 +369,18 @@ def select_tokens(labels: torch.Tensor, ignore_index: int, seq_S: int, tok_offse
     return idx[:n], lab[:n]
 
 
-def gather_rows(src: torch.Tensor, row_stride: int, idx: torch.Tensor, d: int, dtype: torch.dtype) -> torch.Tensor:
-    """dst[i] = the d floats at src + idx[i]*row_stride, as fp32 or bf16 [n, d]."""
+def gather_rows(src: torch.Tensor, row_stride: int, idx: torch.Tensor, d: int, dtype: torch.dtype,
+                zero_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dst[i] = the d floats at src + idx[i]*row_stride, as fp32 or bf16 [n, d]; rows whose zero_rows flag (int64 [n]) is set are zeros."""
     _chk(src, "src", torch.float32); _chk(idx, "idx", torch.int32)
     n = idx.numel()
+    if zero_rows is not None:
+        _chk(zero_rows, "zero_rows", torch.int64)
+        if zero_rows.numel() != n:
+            raise MmamdError("gather_rows: one zero_rows flag per gathered row expected")
     dst = torch.empty((n, d), dtype=dtype, device=src.device)
-    check(_lib.lib().mmamd_gather_rows(src.data_ptr(), int(row_stride), idx.data_ptr(), n, d, dst.data_ptr(), _dt(dst), _stream()),
-          "mmamd_gather_rows")
+    check(_lib.lib().mmamd_gather_rows(src.data_ptr(), int(row_stride), idx.data_ptr(), n, d, dst.data_ptr(), _dt(dst), _ptr(zero_rows),
+                                       _stream()), "mmamd_gather_rows")
     return dst
 
 
@@ -392,6 +397,22 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int 
     check(_lib.lib().mmamd_cross_entropy(logits.data_ptr(), logits.stride(0) if N > 0 else V, labels.data_ptr(), N, V,
                                          int(ignore_index), out.data_ptr(), ws.data_ptr(), _stream()), "mmamd_cross_entropy")
     return out[0]
+
+
+def cross_entropy_bwd(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int, grad_out: torch.Tensor,
+                      out_dtype: torch.dtype = torch.float32, pad_cols_to: int = 1) -> torch.Tensor:
+    """d(mean CE)/d(logits) * grad_out as [N, V rounded up to pad_cols_to] (extra columns zero), fp32 or bf16."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1):
+        raise MmamdError("cross_entropy_bwd: logits must be an fp32 [N, V] HIP tensor with unit inner stride")
+    _chk(labels, "labels", torch.int64); _chk(grad_out, "grad_out", torch.float32)
+    N, V = logits.shape
+    ldd = (V + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    d = torch.empty((N, ldd), dtype=out_dtype, device=logits.device)
+    ws = torch.empty(2 * N + 1, dtype=torch.float32, device=logits.device)
+    check(_lib.lib().mmamd_cross_entropy_bwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), N, V, int(ignore_index),
+                                             grad_out.data_ptr(), d.data_ptr(), _dt(d), ldd, ws.data_ptr(), _stream()),
+          "mmamd_cross_entropy_bwd")
+    return d
 
 
 def patchify(images: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:

@@ -287,7 +287,72 @@ def test_flava_training_step_gradients_vs_reference_autograd(golden):
           " median rms-rel", float(np.median([v[1] for v in report.values()])), " tensors", len(report))
     for k, (rel, rms) in report.items():
         assert rel <= 8e-2 and rms <= 4e-2, (k, rel, rms)
+
+
+def test_cross_entropy_backward_kernel():
     from multimodal_amd import ops
 
-    with pytest.raises(ops.MmamdError):  # patch masking in training mode is not implemented (forward-only feature)
-        model(image, text, image_patches_mask=torch.zeros(image.shape[0], 4, dtype=torch.long, device="cuda"))
+    set_rng_seed(21)
+    for (N, V, pad, dt) in ((300, 30522, 64, torch.bfloat16), (5, 2, 1, torch.float32), (64, 200, 64, torch.bfloat16)):
+        logits = (torch.randn(N, V) * 3).requires_grad_(True)
+        lab = torch.randint(0, V, (N,))
+        lab[torch.rand(N) < 0.3] = -1
+        lab[0] = 1
+        loss = torch.nn.functional.cross_entropy(logits.double(), lab, ignore_index=-1)
+        (loss * 1.7).backward()
+        g = ops.cross_entropy_bwd(logits.detach().cuda(), lab.cuda(), -1, torch.tensor([1.7], device="cuda"), out_dtype=dt, pad_cols_to=pad)
+        assert g.shape == (N, (V + pad - 1) // pad * pad) and not g[:, V:].any()
+        ref = logits.grad.double().numpy()
+        tol = 1e-6 if dt == torch.float32 else 2 ** -8 * np.abs(ref).max()
+        assert np.abs(host(g[:, :V]) - ref).max() <= tol + 1e-7
+
+
+def test_flava_full_pretraining_step_gradients_vs_reference_autograd(golden):
+    """The whole FLAVA pre-training objective (ITM + MMM text/image heads + global contrastive; patch mask, padded text, ITM row
+    filter) in train mode: every parameter gradient of the model AND of the loss heads against the reference's torch autograd."""
+    from multimodal_amd.models.flava.model import flava_model
+    from multimodal_amd.modules.losses.flava import FLAVAPretrainingLoss
+    from tests._util import fixture_sd
+    from tests.golden.make_golden_flava_grad import SMALL_KW
+
+    z, zl, zg = golden("flava_small.npz"), golden("flava_pretrain_small.npz"), golden("flava_pretrain_grad.npz")
+    model = flava_model(**SMALL_KW)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fixture_sd(z).items()}, strict=True)
+    loss = FLAVAPretrainingLoss(hidden_size=128, text_vocab_size=200, image_vocab_size=64)
+    loss.load_state_dict({k: torch.from_numpy(v) for k, v in fixture_sd(zl).items()}, strict=True)
+    model, loss = model.cuda().train(), loss.cuda().train()
+    T = lambda a: torch.from_numpy(np.asarray(a)).cuda()
+    out = model(T(z["image"]), T(z["text"]), image_patches_mask=T(z["patches_mask"]), text_masked=T(z["text_masked"]))
+    lo = loss(image_sequence=out.image.last_hidden_state, text_sequence=out.text.last_hidden_state,
+              image_masked_sequence=out.image_masked.last_hidden_state, text_masked_sequence=out.text_masked.last_hidden_state,
+              multimodal_masked_sequence=out.multimodal_masked.last_hidden_state, itm_labels=T(zl["itm_labels"]),
+              mim_labels=T(zl["mim_labels"]), mlm_labels=T(zl["mlm_labels"]),
+              projected_image_embeddings=out.projected_image_embeddings, projected_text_embeddings=out.projected_text_embeddings)
+    names = ("itm_loss", "mmm_text_loss", "mmm_image_loss", "global_contrastive_loss")
+    total = sum(getattr(lo.losses, n) for n in names)
+    total.backward()
+    for n in names:
+        assert abs(float(getattr(lo.losses, n)) - float(zg[n])) <= 2e-2, (n, float(getattr(lo.losses, n)), float(zg[n]))
+    no_grad = {str(k) for k in zg["no_grad_keys"]}
+    report, worst = {}, ("", 0.0)
+    params = [("model." + k, p) for k, p in model.named_parameters()] + [("loss." + k, p) for k, p in loss.named_parameters()]
+    for k, p in params:
+        if k in no_grad:
+            assert p.grad is None or not p.grad.any(), k
+            continue
+        assert p.grad is not None, k
+        ref = zg["g." + k].astype(np.float64)
+        got = host(p.grad)
+        assert got.shape == ref.shape, k
+        if np.abs(ref).max() < 1e-6:
+            assert np.abs(got).max() <= 2e-3, (k, np.abs(got).max())  # mathematically zero (key biases), round-off on both sides
+            continue
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        rms = np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-12)
+        report[k] = (rel, rms)
+        if rel > worst[1]:
+            worst = (k, rel)
+    print("flava pre-training grad parity: worst max-rel", worst, " median max-rel", float(np.median([v[0] for v in report.values()])),
+          " median rms-rel", float(np.median([v[1] for v in report.values()])), " tensors", len(report))
+    for k, (rel, rms) in report.items():
+        assert rel <= 8e-2 and rms <= 4e-2, (k, rel, rms)
