@@ -20,14 +20,17 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-loss", action="store_true")
+    ap.add_argument("--train", action="store_true", help="training step: forward + pre-training loss + backward + SGD")
     a = ap.parse_args()
     from multimodal_amd.models.flava.model import flava_model
     from multimodal_amd.modules.losses.flava import FLAVAPretrainingLoss
 
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
-    model = flava_model().to(dev).eval()
-    loss = FLAVAPretrainingLoss().to(dev).eval()
+    model = flava_model().to(dev)
+    loss = FLAVAPretrainingLoss().to(dev)
+    model, loss = (model.train(), loss.train()) if a.train else (model.eval(), loss.eval())
+    opt = torch.optim.SGD(list(model.parameters()) + list(loss.parameters()), lr=1e-4) if a.train else None
     B = a.batch
     g = torch.Generator().manual_seed(1)
     image = torch.randn(B, 3, 224, 224, generator=g).to(dev)
@@ -45,7 +48,21 @@ def main():
     itm = torch.ones(B, dtype=torch.long)
     text, text_masked, mlm, pmask, mim, itm = (t.to(dev) for t in (text, text_masked, mlm, pmask, mim, itm))
 
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        o = model(image, text, image_patches_mask=pmask, text_masked=text_masked)
+        lo = loss(image_sequence=o.image.last_hidden_state, text_sequence=o.text.last_hidden_state,
+                  image_masked_sequence=o.image_masked.last_hidden_state, text_masked_sequence=o.text_masked.last_hidden_state,
+                  multimodal_masked_sequence=o.multimodal_masked.last_hidden_state, itm_labels=itm, mim_labels=mim, mlm_labels=mlm,
+                  projected_image_embeddings=o.projected_image_embeddings, projected_text_embeddings=o.projected_text_embeddings)
+        total = lo.losses.itm_loss + lo.losses.mmm_text_loss + lo.losses.mmm_image_loss + lo.losses.global_contrastive_loss
+        total.backward()
+        opt.step()
+        return total.detach()
+
     def step():
+        if a.train:
+            return train_step()
         with torch.no_grad():
             o = model(image, text, image_patches_mask=pmask, text_masked=text_masked)
             if a.no_loss:
@@ -66,8 +83,8 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.steps
-    gf = 2 * 35.13 + 2 * 13.30 + 24.75 + (0.0 if a.no_loss else 1.8)
-    print(json.dumps({"workload": "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + " (no codebook)",
+    gf = (2 * 35.13 + 2 * 13.30 + 24.75 + (0.0 if a.no_loss else 1.8)) * (3 if a.train else 1)
+    print(json.dumps({"workload": ("TRAINING step: " if a.train else "") + "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + (" + bwd + SGD" if a.train else "") + " (no codebook)",
                       "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_sample": gf,
                       "tflops": round(B * gf / ms, 1), "mfma_frac": round(B * gf / ms / 2500.0, 4),
                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "last": float(r.flatten()[0])}))
