@@ -85,6 +85,15 @@ int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float*
 int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                         mmamd_stream_t stream);
 
+/* Backward of mmamd_attention_x_fwd (same operand description; out / dout bf16 [B*Sq, ldo], lse from the forward): writes
+ * dq [B, Sq, lddq] (ALWAYS per sample — with batch-shared queries the caller sums over the batch), dk / dv [B*Sk, lddk = lddv]
+ * (bf16; they may be column slices of one buffer).  head_dim 96 needs Sk <= 256 (LDS). */
+int mmamd_attention_x_bwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                          int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                          int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo, const float* lse,
+                          void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim,
+                          float scale, mmamd_stream_t stream);
+
 /* mmamd_attention_fwd that also saves the log2-domain log-sum-exp [B,H,S] (fp32) of the scaled scores for mmamd_attention_bwd. */
 int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale,
                             mmamd_stream_t stream);

@@ -51,6 +51,8 @@ PROTOTYPES = {
     "mmamd_cross_entropy_bwd": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _i, _i64, _vp, _vp]),
     "mmamd_cross_entropy": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp]),
     "mmamd_attention_x_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "mmamd_attention_x_bwd": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
+                                    _i, _i, _i, _f, _vp]),
     "mmamd_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_coca_text_embed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_coca_text_mask": (_i, [_vp, _i, _i64, _vp, _i, _i, _vp]),

@@ -22,6 +22,7 @@ __all__ = [
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "cross_entropy_bwd",
+    "attention_x_bwd",
 ]
 
 
@@ -234,6 +235,29 @@ def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse:
     check(_lib.lib().mmamd_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), _ptr(key_mask), dqkv.data_ptr(), B, S, H,
                                          int(bool(causal)), 1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_bwd")
     return dqkv
+
+
+def attention_x_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int,
+                    Sq: int, Sk: int, H: int, head_dim: int, mask: Optional[AttnMask] = None, shared_q: bool = False):
+    """Backward of attention_x_fwd.  Returns (dq bf16 [B*Sq, D] — per sample even when the queries are shared —, dkv bf16 [B*Sk, 2D]
+    = [dK | dV])."""
+    _mat_view(q, "q"); _mat_view(k, "k"); _mat_view(v, "v"); _mat_view(out, "out"); _mat_view(dout, "dout")
+    _chk(lse, "lse", torch.float32)
+    D = H * head_dim
+    mask = mask or AttnMask()
+    km, fm, fm_bs = mask.key_mask, mask.full, 0
+    if fm is not None:
+        fm_bs = Sq * Sk if fm.numel() == B * Sq * Sk and B > 1 else 0
+    if out.stride(0) != dout.stride(0):
+        raise MmamdError("attention_x_bwd: out and dout must share their row pitch")
+    dq = torch.empty((B * Sq, D), dtype=torch.bfloat16, device=q.device)
+    dkv = torch.empty((B * Sk, 2 * D), dtype=torch.bfloat16, device=q.device)
+    check(_lib.lib().mmamd_attention_x_bwd(q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(),
+                                           k.stride(0), v.stride(0), Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal),
+                                           out.data_ptr(), dout.data_ptr(), out.stride(0), lse.data_ptr(), dq.data_ptr(), D,
+                                           dkv.data_ptr(), dkv.data_ptr() + 2 * D, 2 * D, 2 * D, B, Sq, Sk, H, head_dim,
+                                           1.0 / math.sqrt(float(head_dim)), _stream()), "mmamd_attention_x_bwd")
+    return dq, dkv
 
 
 def coca_text_embed(ids: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, cls: Optional[torch.Tensor]) -> torch.Tensor:

@@ -356,3 +356,60 @@ def test_flava_full_pretraining_step_gradients_vs_reference_autograd(golden):
           " median rms-rel", float(np.median([v[1] for v in report.values()])), " tensors", len(report))
     for k, (rel, rms) in report.items():
         assert rel <= 8e-2 and rms <= 4e-2, (k, rel, rms)
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,hd,causal,kmask,fmask,shared", [
+    (2, 12, 12, 2, 64, True, False, False, False), (3, 76, 256, 12, 64, False, False, False, False),
+    (2, 257, 256, 8, 96, False, False, False, True), (2, 1, 256, 8, 96, False, False, False, True),
+    (2, 77, 77, 3, 64, False, False, True, False), (2, 77, 77, 2, 96, True, True, False, False),
+    (1, 140, 288, 1, 64, False, True, True, False), (2, 50, 49, 8, 64, False, False, False, True), (2, 130, 130, 2, 96, True, False, False, False)])
+def test_attention_x_backward(B, Sq, Sk, H, hd, causal, kmask, fmask, shared):
+    """Backward of the general attention (cross-attention, 96-wide heads, masks, batch-shared queries) vs float64 autograd math."""
+    from multimodal_amd import ops
+
+    set_rng_seed(Sq * 5 + Sk + hd)
+    D = H * hd
+    qrows = Sq if shared else B * Sq
+    wide = torch.randn(qrows, D + 64).to(torch.bfloat16)
+    kv = torch.randn(B * Sk, 2 * D).to(torch.bfloat16)
+    dout = torch.randn(B * Sq, D).to(torch.bfloat16)
+    km = fm = None
+    if kmask:
+        km = (torch.rand(B, Sk) > 0.3).to(torch.uint8)
+        km[:, 0] = 1
+    if fmask:
+        fm = (torch.rand(B, Sq, Sk) > 0.4).to(torch.uint8)
+        fm[:, :, 0] = 1
+    wg, kvg = wide.cuda(), kv.cuda()
+    mask = ops.AttnMask(causal=causal, key_mask=km.cuda() if km is not None else None, full=fm.cuda() if fm is not None else None)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device="cuda")
+    out, _ = ops.attention_x_fwd(wg[:, 64:], kvg[:, :D], kvg[:, D:], B, Sq, Sk, H, hd, mask, shared_q=shared, lse=lse)
+    dq, dkv = ops.attention_x_bwd(wg[:, 64:], kvg[:, :D], kvg[:, D:], out, dout.cuda(), lse, B, Sq, Sk, H, hd, mask, shared_q=shared)
+    q = wide[:, 64:].float().numpy().astype(np.float64)
+    q = np.broadcast_to(q.reshape(1, Sq, H, hd), (B, Sq, H, hd)) if shared else q.reshape(B, Sq, H, hd)
+    q = q.transpose(0, 2, 1, 3)
+    k = kv[:, :D].float().numpy().astype(np.float64).reshape(B, Sk, H, hd).transpose(0, 2, 1, 3)
+    v = kv[:, D:].float().numpy().astype(np.float64).reshape(B, Sk, H, hd).transpose(0, 2, 1, 3)
+    s = q @ k.transpose(0, 1, 3, 2) / np.sqrt(hd)
+    allow = np.ones((B, 1, Sq, Sk), dtype=bool)
+    if causal:
+        allow = allow & np.tril(np.ones((Sq, Sk), dtype=bool))
+    if km is not None:
+        allow = allow & km.numpy().astype(bool)[:, None, None, :]
+    if fm is not None:
+        allow = allow & fm.numpy().astype(bool)[:, None]
+    s = np.where(allow, s, -np.inf)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    o_used = host(out).reshape(B, Sq, H, hd).transpose(0, 2, 1, 3)
+    do = dout.float().numpy().astype(np.float64).reshape(B, Sq, H, hd).transpose(0, 2, 1, 3)
+    rdv = p.transpose(0, 1, 3, 2) @ do
+    dp = do @ v.transpose(0, 1, 3, 2)
+    ds = p * (dp - (do * o_used).sum(-1, keepdims=True))
+    rdq = (ds @ k / np.sqrt(hd)).transpose(0, 2, 1, 3).reshape(B * Sq, D)
+    rdk = (ds.transpose(0, 1, 3, 2) @ q / np.sqrt(hd)).transpose(0, 2, 1, 3).reshape(B * Sk, D)
+    rdv = rdv.transpose(0, 2, 1, 3).reshape(B * Sk, D)
+    for name, a, b_ in (("dQ", host(dq), rdq), ("dK", host(dkv[:, :D]), rdk), ("dV", host(dkv[:, D:]), rdv)):
+        err = np.abs(a - b_).max()
+        assert err <= 3e-2 * max(1.0, np.abs(b_).max()), (name, err, np.abs(b_).max())
+        assert np.sqrt(((a - b_) ** 2).mean()) <= 6e-3 * max(1e-3, np.sqrt((b_ ** 2).mean())), name
