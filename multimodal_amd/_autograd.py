@@ -32,9 +32,11 @@ def c32(t: Tensor) -> Tensor:
 def dgrad(dy: Tensor, w: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act: Optional[Tensor] = None) -> Tensor:
     """dX[M,K] = dY[M,N] . W[N,K]  (W fp32 [N,K], N % 64 == 0); with act = ACT_MUL_*_GRAD the epilogue multiplies by
     act'(pre_act): the activation's backward without a pass of its own."""
-    if w.shape[0] % 64 != 0:
-        raise ops.MmamdError(f"backward GEMM: output width {w.shape[0]} of a Linear must be a multiple of 64")
-    wT = ops.transpose_to_bf16(w, pad_to=64)  # bf16 [K, N]
+    wT = ops.transpose_to_bf16(w, pad_to=64)  # bf16 [K, N rounded up to 64, zero tail]
+    if wT.shape[1] != dy.shape[1]:            # e.g. a 96-wide vocabulary: pad the contraction with zero columns
+        pad = torch.zeros((dy.shape[0], wT.shape[1]), dtype=bf, device=dy.device)
+        pad[:, :dy.shape[1]].copy_(dy)
+        dy = pad
     return ops.gemm_bf16(dy, wT, None, act=act, residual=pre_act, out_dtype=out_dtype)
 
 
@@ -292,3 +294,225 @@ class MaskedHeadLossFn(torch.autograd.Function):
         dbase = torch.zeros((B * S, d), dtype=f32, device=drows.device)                  # memset; only labelled rows get gradient
         ops.scatter_add_rows_(dbase, idx32.to(torch.int64), drows)
         return dbase.view(B, S, d), None, None, dWd, dbd, dlnw, dlnb, dWp[:V], dbp[:V], None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y[M,N] (fp32) = x[M,K] W^T (+ b) on the bf16 MFMA GEMM, differentiable (dgrad / split-K wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias):
+        xb = ops.convert(x2d.detach() if x2d.is_contiguous() else x2d.detach().contiguous(), bf)
+        N = weight.shape[0]
+        Np = (N + 7) // 8 * 8
+        wb = ops.convert(c32(weight), bf)
+        bb = c32(bias) if bias is not None else None
+        if Np != N:  # GEMM granule: N % 8
+            wp = torch.zeros((Np, weight.shape[1]), dtype=bf, device=xb.device)
+            wp[:N].copy_(wb)
+            wb = wp
+            if bb is not None:
+                bp = torch.zeros(Np, dtype=f32, device=xb.device)
+                bp[:N].copy_(bb)
+                bb = bp
+        y = ops.gemm_bf16(xb, wb, bb, out_dtype=f32)
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        return y if Np == N else y[:, :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, weight = ctx.saved_tensors
+        dyc = dy.detach()
+        dyb = ops.convert(dyc if dyc.is_contiguous() else dyc.contiguous(), bf)
+        dx = dgrad(dyb, c32(weight), f32)
+        if ctx.has_bias:
+            dW, db = wgrad(dyb, xb, bias=True)
+        else:
+            dW, db = wgrad(dyb, xb), None
+        return dx, dW, db
+
+
+class CrossAttentionFn(torch.autograd.Function):
+    """MultiHeadAttentionWithCache(query, kv, kv) without cache (modules/layers/multi_head_attention.py:115-180) for 2-D token
+    matrices: q_in fp32 [B*Sq, dq] — or [Sq, dq] when shared by every sample (AttentionPooler) — and kv_in fp32 [B*Sk, dkv]
+    -> fp32 [B*Sq, dq].  One GEMM for q, one for [k | v], the general attention kernel, the output GEMM; backward likewise."""
+
+    @staticmethod
+    def forward(ctx, q_in, kv_in, B: int, Sq: int, Sk: int, H: int, shared_q: bool, wq, bq, wk, bk, wv, bv, wo, bo):
+        dq = wq.shape[0]
+        hd = dq // H
+        qb_in = ops.convert(q_in.detach().contiguous(), bf)
+        kvb_in = ops.convert(kv_in.detach().contiguous(), bf)
+        has_b = bq is not None
+        q = ops.gemm_bf16(qb_in, ops.convert(c32(wq), bf), c32(bq) if has_b else None)
+        wkv = torch.cat([c32(wk), c32(wv)], 0)
+        bkv = torch.cat([c32(bk), c32(bv)], 0) if has_b else None
+        kv = ops.gemm_bf16(kvb_in, ops.convert(wkv, bf), bkv)
+        lse = torch.empty((B, H, Sq), dtype=f32, device=q.device)
+        att, _ = ops.attention_x_fwd(q, kv[:, :dq], kv[:, dq:], B, Sq, Sk, H, hd, None, shared_q=shared_q, lse=lse)
+        y = ops.gemm_bf16(att, ops.convert(c32(wo), bf), c32(bo), out_dtype=f32)
+        ctx.save_for_backward(qb_in, kvb_in, q, kv, att, lse, wq, wk, wv, wo)
+        ctx.meta = (B, Sq, Sk, H, hd, shared_q, has_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qb_in, kvb_in, q, kv, att, lse, wq, wk, wv, wo = ctx.saved_tensors
+        B, Sq, Sk, H, hd, shared_q, has_b = ctx.meta
+        dq_ = wq.shape[0]
+        dyb = ops.convert(dy.detach().contiguous(), bf)
+        datt = dgrad(dyb, c32(wo), bf)
+        dWo, dbo = wgrad(dyb, att, bias=True)
+        dqa, dkv = ops.attention_x_bwd(q, kv[:, :dq_], kv[:, dq_:], att, datt, lse, B, Sq, Sk, H, hd, None, shared_q=shared_q)
+        if shared_q:  # the same queries for every sample: their gradient is the sum over the batch
+            dqa = ops.convert(ops.colsum(dqa.view(B, Sq * dq_)).view(Sq, dq_), bf)
+        dq_in = dgrad(dqa, c32(wq), f32)
+        wkv = torch.cat([c32(wk), c32(wv)], 0)
+        dkv_in = dgrad(dkv, wkv, f32)
+        if has_b:
+            dWq, dbq = wgrad(dqa, qb_in, bias=True)
+            dWkv, dbkv = wgrad(dkv, kvb_in, bias=True)
+            dbk, dbv = dbkv[:dq_], dbkv[dq_:]
+        else:
+            dWq, dbq = wgrad(dqa, qb_in), None
+            dWkv, dbk, dbv = wgrad(dkv, kvb_in), None, None
+        return dq_in, dkv_in, None, None, None, None, None, dWq, dbq, dWkv[:dq_], dbk, dWkv[dq_:], dbv, dWo, dbo
+
+
+class DecoderStackConfig:
+    """Static description for DecoderStackFn.  layers: list of dicts with n_head, eps (attention / cross / feedforward), act,
+    has_cross; params per layer in the order self q/k/v/o (w, b), attention LN (w, b), [cross q/k/v/o (w, b), cross LN (w, b)],
+    ff0 (w, b), ff1 (w, b), feedforward LN (w, b)."""
+
+    def __init__(self, B: int, S: int, Sk: int, layers, mask: Optional[ops.AttnMask]):
+        self.B, self.S, self.Sk, self.layers, self.mask = B, S, Sk, layers, mask or ops.AttnMask()
+
+    def nparams(self, li: int) -> int:
+        return 26 if self.layers[li]["has_cross"] else 16
+
+
+class DecoderStackFn(torch.autograd.Function):
+    """Pre-norm TransformerDecoder layers (modules/layers/transformer.py:398-433): self-attention with the given mask, optional
+    cross-attention to `enc` (fp32 [B*Sk, dkv], differentiable), feed-forward.  x0 fp32 [B*S, d]."""
+
+    @staticmethod
+    def forward(ctx, x0, enc, cfg: DecoderStackConfig, *params):
+        B, S, Sk = cfg.B, cfg.S, cfg.Sk
+        x = x0.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        encb = ops.convert(enc.detach().contiguous(), bf) if enc is not None else None
+        recs, off = [], 0
+        for li, L in enumerate(cfg.layers):
+            pr = [c32(t) for t in params[off:off + cfg.nparams(li)]]
+            off += cfg.nparams(li)
+            H, d = L["n_head"], x.shape[1]
+            hd = d // H
+            qw, qb, kw, kb, vw, vb, ow, ob, g1, be1 = pr[:10]
+            h1 = ops.layernorm(x, g1, be1, L["eps1"], out_dtype=bf)
+            qkv = ops.gemm_bf16(h1, ops.convert(torch.cat([qw, kw, vw], 0), bf), torch.cat([qb, kb, vb], 0))
+            lse = torch.empty((B, H, S), dtype=f32, device=x.device)
+            att, _ = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, cfg.mask, lse=lse)
+            a = ops.gemm_bf16(att, ops.convert(ow, bf), ob, residual=x, out_dtype=f32, out=torch.empty_like(x))
+            rec = [x, h1, qkv, att, lse, a]
+            if L["has_cross"]:
+                cqw, cqb, ckw, ckb, cvw, cvb, cow, cob, gc, bec = pr[10:20]
+                hc = ops.layernorm(a, gc, bec, L["epsc"], out_dtype=bf)
+                qc = ops.gemm_bf16(hc, ops.convert(cqw, bf), cqb)
+                kvc = ops.gemm_bf16(encb, ops.convert(torch.cat([ckw, cvw], 0), bf), torch.cat([ckb, cvb], 0))
+                lsec = torch.empty((B, H, S), dtype=f32, device=x.device)
+                attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, None, lse=lsec)
+                a2 = ops.gemm_bf16(attc, ops.convert(cow, bf), cob, residual=a, out_dtype=f32, out=torch.empty_like(x))
+                rec += [hc, qc, kvc, attc, lsec, a2]
+                ff = pr[20:]
+            else:
+                a2 = a
+                ff = pr[10:]
+            w1, b1, w2, b2, g2, be2 = ff
+            h2 = ops.layernorm(a2, g2, be2, L["eps2"], out_dtype=bf)
+            u = ops.gemm_bf16(h2, ops.convert(w1, bf), b1)
+            g = ops.act_fwd(u, L["act"])
+            x_out = ops.gemm_bf16(g, ops.convert(w2, bf), b2, residual=a2, out_dtype=f32, out=torch.empty_like(x))
+            rec += [h2, u, g]
+            recs.append(rec)
+            x = x_out
+        flat = [t for rec in recs for t in rec]
+        ctx.save_for_backward(*flat, *params, *([encb] if encb is not None else []))
+        ctx.cfg, ctx.nparam, ctx.counts, ctx.has_enc = cfg, len(params), [len(r) for r in recs], encb is not None
+        return x
+
+    @staticmethod
+    def backward(ctx, dx_out):
+        cfg, nparam, counts, has_enc = ctx.cfg, ctx.nparam, ctx.counts, ctx.has_enc
+        tensors = list(ctx.saved_tensors)
+        encb = tensors.pop() if has_enc else None
+        params = tensors[len(tensors) - nparam:]
+        flat = tensors[:len(tensors) - nparam]
+        recs, o = [], 0
+        for c in counts:
+            recs.append(flat[o:o + c])
+            o += c
+        B, S, Sk = cfg.B, cfg.S, cfg.Sk
+        dX = dx_out.detach()
+        dX = dX if dX.is_contiguous() else dX.contiguous()
+        d_enc = None
+        grads: List[Optional[Tensor]] = [None] * nparam
+        offs, o = [], 0
+        for li in range(len(cfg.layers)):
+            offs.append(o)
+            o += cfg.nparams(li)
+        dXb = None
+        for li in reversed(range(len(cfg.layers))):
+            L, rec = cfg.layers[li], recs[li]
+            pr = [c32(t) for t in params[offs[li]:offs[li] + cfg.nparams(li)]]
+            H = L["n_head"]
+            qw, qb, kw, kb, vw, vb, ow, ob, g1, be1 = pr[:10]
+            d = qw.shape[0]
+            hd = d // H
+            x, h1, qkv, att, lse, a = rec[:6]
+            if L["has_cross"]:
+                hc, qc, kvc, attc, lsec, a2 = rec[6:12]
+                h2, u, g = rec[12:15]
+                cqw, cqb, ckw, ckb, cvw, cvb, cow, cob, gc, bec = pr[10:20]
+                w1, b1, w2, b2, g2, be2 = pr[20:]
+            else:
+                a2 = a
+                h2, u, g = rec[6:9]
+                w1, b1, w2, b2, g2, be2 = pr[10:]
+            if dXb is None:
+                dXb = ops.convert(dX, bf)
+            du = dgrad(dXb, w2, bf, _ACT_GRAD[L["act"]], u)
+            dW2, db2 = wgrad(dXb, g, bias=True)
+            dh2 = dgrad(du, w1, f32)
+            dW1, db1 = wgrad(du, h2, bias=True)
+            d_a2, dg2, dbe2, d_a2b = ops.layernorm_bwd(a2, g2, dh2, L["eps2"], add=dX, want_bf16=True)
+            gl = [None] * cfg.nparams(li)
+            if L["has_cross"]:
+                dattc = dgrad(d_a2b, cow, bf)
+                dWco, dbco = wgrad(d_a2b, attc, bias=True)
+                dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, None)
+                dhc = dgrad(dqc, cqw, f32)
+                dWcq, dbcq = wgrad(dqc, hc, bias=True)
+                wckv = torch.cat([ckw, cvw], 0)
+                de = dgrad(dkvc, wckv, f32)
+                d_enc = de if d_enc is None else ops.gemm_bf16(dkvc, ops.transpose_to_bf16(wckv, pad_to=64), None, residual=d_enc,
+                                                               out_dtype=f32, out=d_enc)
+                dWckv, dbckv = wgrad(dkvc, encb, bias=True)
+                d_a, dgc, dbec, d_ab = ops.layernorm_bwd(a, gc, dhc, L["epsc"], add=d_a2, want_bf16=True)
+                gl[10:20] = [dWcq, dbcq, dWckv[:d], dbckv[:d], dWckv[d:], dbckv[d:], dWco, dbco, dgc, dbec]
+                gl[20:] = [dW1, db1, dW2, db2, dg2, dbe2]
+            else:
+                d_a, d_ab = d_a2, d_a2b
+                gl[10:] = [dW1, db1, dW2, db2, dg2, dbe2]
+            datt = dgrad(d_ab, ow, bf)
+            dWo, dbo = wgrad(d_ab, att, bias=True)
+            dq, dkv = ops.attention_x_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, datt, lse, B, S, S, H, hd, cfg.mask)
+            wqkv = torch.cat([qw, kw, vw], 0)
+            # dh1 = dq Wq + [dk | dv] [Wk; Wv]: two GEMMs, the second accumulates onto the first
+            dh1 = dgrad(dq, qw, f32)
+            dh1 = ops.gemm_bf16(dkv, ops.transpose_to_bf16(wqkv[d:], pad_to=64), None, residual=dh1, out_dtype=f32, out=dh1)
+            dWq, dbq = wgrad(dq, h1, bias=True)
+            dWkv, dbkv = wgrad(dkv, h1, bias=True)
+            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, L["eps1"], add=d_a, want_bf16=True)
+            gl[:10] = [dWq, dbq, dWkv[:d], dbkv[:d], dWkv[d:], dbkv[d:], dWo, dbo, dg1, dbe1]
+            grads[offs[li]:offs[li] + cfg.nparams(li)] = gl
+        return (dX, d_enc, None, *grads)

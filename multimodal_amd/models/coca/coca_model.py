@@ -22,7 +22,7 @@ from ...modules.layers.attention_pooler import AttentionPooler, CascadedAttentio
 from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
 from ...modules.losses.flava import cls_linear
-from ..clip._transformer import forbid_training_forward
+from ..._autograd import CrossEntropyFn, L2NormalizeFn, wants_grad
 from .multimodal_decoder import CoCaMultimodalDecoder
 from .text_decoder import CoCaTextDecoder
 
@@ -56,10 +56,14 @@ class CoCaModel(nn.Module):
         self._packed = PackedCache()
 
     def forward(self, images: Tensor, texts: Tensor, text_padding_mask: Optional[Tensor] = None) -> MultimodalOutput:
-        forbid_training_forward(self)
+        training = wants_grad(self)
+        l2n = L2NormalizeFn.apply if training else ops.l2_normalize
         dev = images.device
         side = None
-        if dev.type == "cuda":  # text decoder on a side stream: its small grids fill the CUs the ViT leaves idle
+        if training:  # differentiable path: autograd nodes with HIP forward and backward, one stream
+            pooled_text_embeddings, text_tokens = self.text_decoder(texts, text_padding_mask)
+            contrastive_text_embeddings = l2n(pooled_text_embeddings)
+        elif dev.type == "cuda":  # text decoder on a side stream: its small grids fill the CUs the ViT leaves idle
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
             side.wait_stream(main)
@@ -85,12 +89,12 @@ class CoCaModel(nn.Module):
             B, nq, D = contrastive_image_embeddings.shape
             # [B, 1, D] stays [B, 1, D], exactly like the reference (its cascaded pooler keeps the query dimension)
             proj = cls_linear(contrastive_image_embeddings.reshape(B * nq, D), self.vision_proj, self._packed)
-            contrastive_image_embeddings = ops.l2_normalize(proj).view(B, nq, -1)
+            contrastive_image_embeddings = l2n(proj).view(B, nq, -1)
         else:
             assert isinstance(pooled_outputs, Tensor), "Pooled image embeddings must be Tensor"
             # contrastive = pooled[:, 0] (projected straight out of the pooled tensor), captioning = pooled[:, 1:]
             captioning_image_embeddings = pooled_outputs[:, 1:]
-            contrastive_image_embeddings = ops.l2_normalize(cls_linear(pooled_outputs, self.vision_proj, self._packed))
+            contrastive_image_embeddings = l2n(cls_linear(pooled_outputs, self.vision_proj, self._packed))
 
         if side is not None:
             main.wait_stream(side)
@@ -222,7 +226,10 @@ class CoCaForPretraining(nn.Module):
         mm = model_outs.multimodal_embeddings
         vocab_size = mm.shape[-1]
         logits = mm.flatten(0, 1)  # a view: rows keep the (padded) pitch of the vocabulary GEMM
-        captioning_loss = ops.cross_entropy(logits, captioning_labels.view(-1), self.caption_loss.ignore_index)
+        if torch.is_grad_enabled() and logits.requires_grad:
+            captioning_loss = CrossEntropyFn.apply(logits, captioning_labels.view(-1), self.caption_loss.ignore_index)
+        else:
+            captioning_loss = ops.cross_entropy(logits, captioning_labels.view(-1), self.caption_loss.ignore_index)
         return {"contrastive": contrastive_loss, "captioning": captioning_loss}
 
 

@@ -42,6 +42,10 @@ class CoCaMultimodalDecoder(nn.Module):
         if self.output_projection is None:
             return hidden_states
         B, S, d = hidden_states.shape
+        if torch.is_grad_enabled() and hidden_states.requires_grad:
+            from ..._autograd import LinearFn  # differentiable vocabulary projection (dgrad + split-K wgrad)
+
+            return LinearFn.apply(hidden_states.reshape(B * S, d), self.output_projection.weight, None).unflatten(0, (B, S))
         h = ops.convert(hidden_states.view(B * S, d), torch.bfloat16)
         V = self.output_projection.out_features
         w = self._packed.get_padded_rows(self.output_projection.weight, torch.bfloat16, 8)

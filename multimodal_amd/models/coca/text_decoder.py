@@ -15,6 +15,40 @@ from ...modules.layers.transformer import TransformerDecoder
 from ...utils.attention import get_causal_attention_mask
 
 
+class CoCaTextEmbedFn(torch.autograd.Function):
+    """token_embeddings[ids] (+ CLS row appended) + position_embeddings, differentiable (models/coca/text_decoder.py:67-88)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, pos, cls, padding_idx):
+        f32 = torch.float32
+        x = ops.coca_text_embed(ids, table.detach().contiguous(), pos.detach().contiguous(), cls.detach().contiguous() if cls is not None else None)
+        B, S = ids.shape
+        T = S + (1 if cls is not None else 0)
+        ctx.save_for_backward(ids)
+        ctx.meta = (tuple(table.shape), tuple(pos.shape), cls is not None, padding_idx, T)
+        return x.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (ids,) = ctx.saved_tensors
+        tshape, pshape, has_cls, padding_idx, T = ctx.meta
+        f32 = torch.float32
+        B, S = ids.shape
+        d = tshape[1]
+        dxc = dx.detach().contiguous().view(B * T, d)
+        dpos_used = ops.colsum(dxc.view(B, T * d)).view(T, d)     # position t is shared by the B samples
+        dpos = torch.zeros(pshape, dtype=f32, device=dx.device)
+        dpos[:T].copy_(dpos_used)
+        dcls = dpos_used[S].clone() if has_cls else None          # the CLS row is cls + pos[S] for every sample
+        rows = (torch.arange(B * T, device=dx.device, dtype=torch.int32).view(B, T)[:, :S]).reshape(-1).contiguous()
+        dtok = ops.gather_rows(dxc, d, rows, d, f32)               # gradients of the token rows, [B*S, d]
+        dtable = torch.zeros(tshape, dtype=f32, device=dx.device)  # memset; rows collide -> fp32 atomics
+        ops.scatter_add_rows_(dtable, ids.reshape(-1).contiguous(), dtok)
+        if padding_idx is not None:
+            dtable[padding_idx].zero_()
+        return None, dtable, dpos, dcls, None
+
+
 class CoCaTextEmbeddings(nn.Module):
     def __init__(self, vocab_size: int, num_positions: int, embedding_dim: int, pad_idx: Optional[int] = 0, embed_cls: bool = True):
         super().__init__()
@@ -38,6 +72,9 @@ class CoCaTextEmbeddings(nn.Module):
         assert input_ids.shape[1] == (self.num_positions if self.cls_embedding is None else self.num_positions - 1)
         pk, f32 = self._packed.get, torch.float32
         ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        if self.training and torch.is_grad_enabled() and self.token_embeddings.weight.requires_grad:
+            return CoCaTextEmbedFn.apply(ids, self.token_embeddings.weight, self.position_embeddings, self.cls_embedding,
+                                         self.token_embeddings.padding_idx)
         x = ops.coca_text_embed(ids, pk(self.token_embeddings.weight, f32), pk(self.position_embeddings, f32),
                                 pk(self.cls_embedding, f32) if self.cls_embedding is not None else None)
         return x.view(ids.shape[0], -1, x.shape[-1])
@@ -104,6 +141,15 @@ class CoCaTextDecoder(nn.Module):
         assert hidden_states is not None, "hidden states must not be None"
         pk, f32 = self._packed.get, torch.float32
         B, S, d = hidden_states.shape
+        if self.embed_cls and torch.is_grad_enabled() and hidden_states.requires_grad:
+            from ..clip._train import PooledHeadFn  # differentiable: LayerNorm on the CLS rows + projection (no bias)
+
+            if getattr(self, "ln_final", None) is None or self.text_projection is None:
+                raise ops.MmamdError("training on the MI355X path: CoCaTextDecoder needs ln_final and text_projection")
+            rows = torch.arange(S - 1, B * S, S, dtype=torch.int64, device=hidden_states.device)
+            pooled = PooledHeadFn.apply(hidden_states.reshape(B * S, d), rows, self.ln_final.weight, self.ln_final.bias,
+                                        self.text_projection.weight, self.ln_final.eps, True)
+            return pooled, hidden_states[:, :-1]
         if self.embed_cls:
             tokens = hidden_states[:, :-1]
             # pooled = text_projection(ln_final(hidden[:, -1])): gather the B CLS rows, LN, exact-fp32 MFMA projection

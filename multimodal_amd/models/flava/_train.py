@@ -27,40 +27,47 @@ class FlavaImageEmbedFn(torch.autograd.Function):
         B = images.shape[0]
         w = conv_w.shape[0]
         K = conv_w.shape[1] * patch * patch
-        if K % 64 != 0:
-            raise ops.MmamdError(f"patch embedding: C*P*P = {K} must be a multiple of 64 on the MI355X path")
-        cols = ops.patchify(images if images.is_contiguous() else images.contiguous(), patch, K)
-        pe = ops.gemm_bf16(cols, ops.convert(c32(conv_w).view(w, K), bf), c32(conv_b), out_dtype=f32)
+        kpad = (K + 63) // 64 * 64  # e.g. patch 14: 588 -> 640 (zero columns on both operands)
+        cols = ops.patchify(images if images.is_contiguous() else images.contiguous(), patch, kpad)
+        wk = ops.convert(c32(conv_w).view(w, K), bf)
+        if kpad != K:
+            wp = torch.zeros((w, kpad), dtype=bf, device=images.device)
+            wp[:, :K].copy_(wk)
+            wk = wp
+        pe = ops.gemm_bf16(cols, wk, c32(conv_b), out_dtype=f32)
         G2 = cols.shape[0] // B
         pm = None
         if patches_mask is not None and mask_token is not None:
             pm = patches_mask.reshape(B, G2)
             pm = (pm if pm.dtype == torch.int64 else pm.to(torch.int64)).contiguous()
-        x = ops.flava_image_embed(pe, c32(cls).view(-1), c32(pos).view(G2 + 1, w), B, G2, pm,
+        hc = 1 if cls is not None else 0  # no CLS row: CoCa's ViT (layers/patch_embedding.py, include_cls_embed=False)
+        x = ops.flava_image_embed(pe, c32(cls).view(-1) if hc else None, c32(pos).view(G2 + hc, w), B, G2, pm,
                                   c32(mask_token).view(-1) if pm is not None else None)
         ctx.save_for_backward(cols, pm if pm is not None else torch.empty(0, device=images.device))
-        ctx.meta = (B, G2, w, tuple(conv_w.shape), tuple(cls.shape), tuple(pos.shape), pm is not None,
-                    tuple(mask_token.shape) if mask_token is not None else None)
-        return x.view(B, G2 + 1, w)
+        ctx.meta = (B, G2, w, tuple(conv_w.shape), tuple(cls.shape) if hc else None, tuple(pos.shape), pm is not None,
+                    tuple(mask_token.shape) if mask_token is not None else None, K)
+        return x.view(B, G2 + hc, w)
 
     @staticmethod
     def backward(ctx, dx):
         cols, pm = ctx.saved_tensors
-        B, G2, w, conv_shape, cls_shape, pos_shape, masked, mt_shape = ctx.meta
-        S = G2 + 1
+        B, G2, w, conv_shape, cls_shape, pos_shape, masked, mt_shape, K = ctx.meta
+        hc = 1 if cls_shape is not None else 0
+        S = G2 + hc
         d_asm = dx.detach().contiguous().view(B * S, w)
         dpos = ops.colsum(d_asm.view(B, S * w)).view(S, w)
-        dcls = dpos[0].clone()
-        idx = (torch.arange(B * S, device=dx.device, dtype=torch.int32).view(B, S)[:, 1:]).reshape(-1).contiguous()
+        dcls = dpos[0].clone() if hc else None
+        idx = (torch.arange(B * S, device=dx.device, dtype=torch.int32).view(B, S)[:, hc:]).reshape(-1).contiguous()
         # masked patches (w = 1) take the mask token instead of their embedding: zero gradient for the embedding there
         d_pe = ops.gather_rows(d_asm, w, idx, w, bf, zero_rows=pm.view(-1) if masked else None)
         dW, db = wgrad(d_pe, cols, bias=True)
         dmt = None
         if masked:  # sum over the masked patch rows = (sum over all patch rows) - (sum over the unmasked ones = the conv-bias gradient)
-            dmt = (dpos[1:].sum(0) - db).view(mt_shape)
+            dmt = (dpos[hc:].sum(0) - db).view(mt_shape)
         elif mt_shape is not None:
             dmt = torch.zeros(mt_shape, dtype=f32, device=dx.device)
-        return None, dW.view(conv_shape), db, dcls.view(cls_shape), dpos.view(pos_shape), None, None, dmt
+        dconv = (dW if dW.shape[1] == K else dW[:, :K].contiguous()).view(conv_shape)
+        return None, dconv, db, dcls.view(cls_shape) if hc else None, dpos.view(pos_shape), None, None, dmt
 
 
 class BertEmbedFn(torch.autograd.Function):

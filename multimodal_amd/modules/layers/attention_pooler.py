@@ -28,6 +28,17 @@ class AttentionPooler(nn.Module):
         if x.dim() != 3 or x.dtype != torch.float32:
             raise ops.MmamdError("AttentionPooler on the MI355X path takes fp32 [batch, seq_len, input_embed_dim] tensors")
         B, S, din = x.shape
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and self.query.requires_grad)):
+            # differentiable path: LayerNorm / cross-attention nodes with HIP forward and backward (queries shared by the batch)
+            from ..._autograd import CrossAttentionFn, LayerNormFn
+
+            nq, dout = self.query.shape
+            k = LayerNormFn.apply(x, self.ln_k.weight, self.ln_k.bias, self.ln_k.eps).reshape(B * S, din)
+            q = LayerNormFn.apply(self.query, self.ln_q.weight, self.ln_q.bias, self.ln_q.eps)
+            a = self.attn
+            out = CrossAttentionFn.apply(q, k, B, nq, S, a.num_heads, True, a.q_proj.weight, a.q_proj.bias, a.k_proj.weight, a.k_proj.bias,
+                                         a.v_proj.weight, a.v_proj.bias, a.output_proj.weight, a.output_proj.bias)
+            return LayerNormFn.apply(out.view(B, nq, dout), self.ln_post.weight, self.ln_post.bias, self.ln_post.eps)
         pk, bf, f32 = self._packed.get, torch.bfloat16, torch.float32
         xc = (x if x.is_contiguous() else x.contiguous()).view(B * S, din)
         k = ops.layernorm(xc, pk(self.ln_k.weight, f32), pk(self.ln_k.bias, f32), self.ln_k.eps, out_dtype=bf)

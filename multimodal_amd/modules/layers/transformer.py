@@ -13,6 +13,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
+from ..._autograd import wants_grad
 from ..._packing import PackedCache
 from .mlp import MLP
 from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask
@@ -97,8 +98,9 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, return_hidden_states: bool = False
                 ) -> TransformerOutput:
-        _forbid_training(self)
         B, S, d = hidden_states.shape
+        if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
+            return self._forward_train(hidden_states, attention_mask, return_hidden_states)
         x = _f32_rows(hidden_states, "TransformerEncoder")
         mask = to_attn_mask(attention_mask, False, B, S, S)
         all_hidden_states = []
@@ -112,6 +114,45 @@ class TransformerEncoder(nn.Module):
         if self.final_layer_norm is not None:
             x = self.final_layer_norm(x)
         return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states if return_hidden_states else None)
+
+
+def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_hidden_states: bool) -> TransformerOutput:
+    """Differentiable TransformerEncoder.forward: the packed input_proj layout is the canonical one of EncoderStackFn."""
+    from ..._autograd import EncoderStackFn, StackConfig
+    from .mlp import fused_activation_code  # noqa: F401
+
+    B, S, d = hidden_states.shape
+    if attention_mask is not None:
+        raise ops.MmamdError("training on the MI355X path: TransformerEncoder attention masks are not implemented")
+    params, eps1, eps2, act = [], [], [], None
+    for layer in self.layer:
+        if not layer.norm_first or layer.attention_dropout.p > 0 or layer.feedforward_dropout.p > 0:
+            raise ops.MmamdError("training on the MI355X path implements pre-norm layers without dropout")
+        steps = layer.feedforward.plan()
+        if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
+            raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
+        act = steps[0][1]
+        at = layer.attention
+        params += [at.input_proj.weight, at.input_proj.bias, at.output_proj.weight, at.output_proj.bias, steps[0][0].weight,
+                   steps[0][0].bias, steps[1][0].weight, steps[1][0].bias, layer.attention_layernorm.weight,
+                   layer.attention_layernorm.bias, layer.feedforward_layernorm.weight, layer.feedforward_layernorm.bias]
+        eps1.append(layer.attention_layernorm.eps)
+        eps2.append(layer.feedforward_layernorm.eps)
+    ident = lambda t: t
+    cfg = StackConfig(len(self.layer), self.layer[0].attention.num_heads, B, S, False, act, eps1, eps2, 12, ident, ident,
+                      keep_hidden=return_hidden_states)
+    xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+    x = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params).view(B, S, d)
+    hidden = None
+    if return_hidden_states:
+        hidden = [h.view(B, S, d) for h in cfg.hidden]
+        hidden[-1] = x
+    if self.final_layer_norm is not None:
+        x = self.final_layer_norm(x)
+    return TransformerOutput(last_hidden_state=x, hidden_states=hidden)
+
+
+TransformerEncoder._forward_train = _encoder_forward_train
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -194,8 +235,9 @@ class TransformerDecoder(nn.Module):
                 use_cache: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
         if past_key_values is not None or use_cache:
             raise ops.MmamdError("key/value caching (incremental decoding) is not implemented on the MI355X path")
-        _forbid_training(self)
         B, S, d = hidden_states.shape
+        if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
+            return self._forward_train(hidden_states, encoder_hidden_states, attention_mask, return_hidden_states)
         x = _f32_rows(hidden_states, "TransformerDecoder")
         mask = to_attn_mask(attention_mask, False, B, S, S)
         enc, Sk = None, 0
@@ -214,3 +256,50 @@ class TransformerDecoder(nn.Module):
         if self.final_layer_norm is not None:
             x = self.final_layer_norm(x)
         return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, current_key_values=[])
+
+
+def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, attention_mask, return_hidden_states: bool) -> TransformerOutput:
+    """Differentiable TransformerDecoder.forward (DecoderStackFn: self-attention with the mask, optional cross-attention, feed-forward)."""
+    from ..._autograd import DecoderStackConfig, DecoderStackFn
+
+    if return_hidden_states:
+        raise ops.MmamdError("training on the MI355X path: return_hidden_states is not implemented for TransformerDecoder")
+    B, S, d = hidden_states.shape
+    mask = to_attn_mask(attention_mask, False, B, S, S)
+    layers, params = [], []
+    for layer in self.layer:
+        if not layer.norm_first or layer.attention_dropout.p > 0 or layer.feedforward_dropout.p > 0:
+            raise ops.MmamdError("training on the MI355X path implements pre-norm layers without dropout")
+        steps = layer.feedforward.plan()
+        if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
+            raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
+        has_cross = bool(layer.use_cross_attention and encoder_hidden_states is not None)
+        at = layer.attention
+        if at.q_proj.bias is None:
+            raise ops.MmamdError("training on the MI355X path: attention projections without bias are not implemented")
+        params += [at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight, at.v_proj.bias,
+                   at.output_proj.weight, at.output_proj.bias, layer.attention_layernorm.weight, layer.attention_layernorm.bias]
+        spec = {"n_head": at.num_heads, "eps1": layer.attention_layernorm.eps, "eps2": layer.feedforward_layernorm.eps, "act": steps[0][1],
+                "has_cross": has_cross}
+        if has_cross:
+            ca = layer.cross_attention
+            params += [ca.q_proj.weight, ca.q_proj.bias, ca.k_proj.weight, ca.k_proj.bias, ca.v_proj.weight, ca.v_proj.bias,
+                       ca.output_proj.weight, ca.output_proj.bias, layer.cross_attention_layernorm.weight, layer.cross_attention_layernorm.bias]
+            spec["epsc"] = layer.cross_attention_layernorm.eps
+        params += [steps[0][0].weight, steps[0][0].bias, steps[1][0].weight, steps[1][0].bias, layer.feedforward_layernorm.weight,
+                   layer.feedforward_layernorm.bias]
+        layers.append(spec)
+    enc2d, Sk = None, 0
+    if encoder_hidden_states is not None:
+        Sk = encoder_hidden_states.shape[1]
+        e = encoder_hidden_states if encoder_hidden_states.is_contiguous() else encoder_hidden_states.contiguous()
+        enc2d = e.view(B * Sk, e.shape[-1])
+    cfg = DecoderStackConfig(B, S, Sk, layers, mask)
+    xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+    x = DecoderStackFn.apply(xc.view(B * S, d), enc2d, cfg, *params).view(B, S, d)
+    if self.final_layer_norm is not None:
+        x = self.final_layer_norm(x)
+    return TransformerOutput(last_hidden_state=x, hidden_states=[], current_key_values=[])
+
+
+TransformerDecoder._forward_train = _decoder_forward_train

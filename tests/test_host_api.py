@@ -61,9 +61,8 @@ def test_no_cpu_fallback():
 
 
 def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
-    """CLIP and FLAVA (encoders, pre-training heads, losses) have a differentiable (training) forward on the HIP kernels; like
-    everything else it has no CPU path.  CoCa is forward-only: a training-mode forward with grad enabled is refused instead of
-    silently returning detached outputs."""
+    """CLIP, FLAVA (encoders, pre-training heads, losses) and CoCa have a differentiable (training) forward on the HIP kernels; like
+    everything else it has no CPU path, and configurations the backward does not cover (post-norm layers, dropout) raise."""
     from multimodal_amd import ops
     from multimodal_amd.models.clip import CLIPViTEncoder
     from multimodal_amd.models.flava.transformer import TransformerEncoder as FlavaEncoder
@@ -77,8 +76,10 @@ def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
         FlavaEncoder(1, 128, 2, 256, activation=torch.nn.GELU, norm_first=True).train()(torch.zeros(1, 4, 128))
     with pytest.raises(ops.MmamdError, match="pre-norm"):
         FlavaEncoder(1, 128, 2, 256, activation=torch.nn.GELU).train()(torch.zeros(1, 4, 128))
-    with pytest.raises(NotImplementedError, match="backward"):
+    with pytest.raises(ops.MmamdError, match="no CPU"):  # CoCa's layers train too
         LayersEncoder(1, 128, 2, 256, activation=torch.nn.GELU, norm_first=True).train()(torch.zeros(1, 4, 128))
+    with pytest.raises(ops.MmamdError, match="pre-norm"):
+        LayersEncoder(1, 128, 2, 256, activation=torch.nn.GELU).train()(torch.zeros(1, 4, 128))
     with pytest.raises(ops.MmamdError, match="no CPU"):  # the pre-training heads are differentiable too: still no CPU path
         FLAVAPretrainingLoss(hidden_size=128, text_vocab_size=64, image_vocab_size=64)(
             image_masked_sequence=torch.zeros(1, 5, 128, requires_grad=True), mim_labels=torch.zeros(1, 4, dtype=torch.long))
