@@ -22,12 +22,15 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--train", action="store_true", help="training step: forward + both losses + backward + SGD")
     a = ap.parse_args()
     from multimodal_amd.models.coca.coca_model import coca_vit, CoCaForPretraining
 
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
-    model = CoCaForPretraining(coca_vit(**L14)).to(dev).eval()
+    model = CoCaForPretraining(coca_vit(**L14)).to(dev)
+    model = model.train() if a.train else model.eval()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4) if a.train else None
     B = a.batch
     g = torch.Generator().manual_seed(1)
     images = torch.randn(B, 3, 224, 224, generator=g).to(dev)
@@ -36,6 +39,12 @@ def main():
     texts = texts.to(dev)
 
     def step():
+        if a.train:
+            opt.zero_grad(set_to_none=True)
+            losses = model(images, texts)
+            (losses["contrastive"] + losses["captioning"]).backward()
+            opt.step()
+            return {k: v.detach() for k, v in losses.items()}
         with torch.no_grad():
             return model(images, texts)
 
@@ -49,8 +58,8 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.steps
-    gf = 205.0
-    print(json.dumps({"workload": "CoCaForPretraining(coca_vit L/14, parallel pooler) fwd + losses", "batch": B,
+    gf = 205.0 * (3 if a.train else 1)
+    print(json.dumps({"workload": ("TRAINING step: " if a.train else "") + "CoCaForPretraining(coca_vit L/14, parallel pooler) fwd + losses" + (" + bwd + SGD" if a.train else ""), "batch": B,
                       "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_sample": gf,
                       "tflops": round(B * gf / ms, 1), "mfma_frac": round(B * gf / ms / 2500.0, 4),
                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
