@@ -21,3 +21,9 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $GRAFT_REPO_ROOT
 grep -h "metric" gpurun_out/rocprof.log | tail -1
 find gpurun_out/prof -name "*stats*" | head
+timeout 300 python tools/train_bench.py > gpurun_out/train_bench.log 2>&1
+tail -1 gpurun_out/train_bench.log
+timeout 400 python tools/flava_bench.py --train --steps 5 > gpurun_out/flava_train_bench.log 2>&1
+tail -1 gpurun_out/flava_train_bench.log
+timeout 400 python tools/coca_bench.py --train --steps 3 --warmup 1 > gpurun_out/coca_train_bench.log 2>&1
+tail -1 gpurun_out/coca_train_bench.log
