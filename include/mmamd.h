@@ -77,6 +77,13 @@ int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float*
                     const void* residual, int ldr, void* C, int ldc, int out_dtype, int M, int N,
                     int K, int act, mmamd_stream_t stream);
 
+/* Training forward of an MLP's first linear (linear1 of the encoder layers, modules/layers/mlp.py:60-79 under autograd): ONE pass
+ * writes the pre-activation U = A W^T + bias (bf16 [M, ldu], kept for the backward) and G = act(U) (bf16 [M, ldg], the input of the
+ * second linear), act = MMAMD_ACT_QUICKGELU or MMAMD_ACT_GELU_ERF applied to the bf16-rounded U (exactly what mmamd_act_fwd on U
+ * gives).  Operand constraints as mmamd_gemm_bf16. */
+int mmamd_gemm_bf16_dual(const void* A, int lda, const void* W, int ldw, const float* bias, void* U, int ldu, void* G, int ldg,
+                         int M, int N, int K, int act, mmamd_stream_t stream);
+
 /* --- K4: multi-head self-attention forward ---------------------------------------------------
  * qkv: bf16 [B*S, 3*H*64] rows = tokens, columns = [q | k | v], each H heads of 64;  out: bf16
  * [B*S, H*64] = softmax(q k^T * scale (+causal)) v, heads merged.  Head dim is 64 for every

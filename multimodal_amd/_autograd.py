@@ -87,8 +87,7 @@ class EncoderStackFn(torch.autograd.Function):
             att, lse = ops.attention_fwd_train(qkv, B, S, H, cfg.causal, cfg.key_mask)
             x_mid = ops.gemm_bf16(att, ops.convert(Wo, bf), bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
             h2 = ops.layernorm(x_mid, g2, be2, cfg.eps2[li], out_dtype=bf)
-            u = ops.gemm_bf16(h2, ops.convert(W1, bf), b1)
-            g = ops.act_fwd(u, cfg.act)
+            u, g = ops.gemm_bf16_dual(h2, ops.convert(W1, bf), b1, cfg.act)  # pre-activation (kept for the backward) + activation
             x_out = ops.gemm_bf16(g, ops.convert(W2, bf), b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
             saved += [x, h1, qkv, att, lse, x_mid, h2, u, g]
             x = x_out
@@ -429,8 +428,7 @@ class DecoderStackFn(torch.autograd.Function):
                 ff = pr[10:]
             w1, b1, w2, b2, g2, be2 = ff
             h2 = ops.layernorm(a2, g2, be2, L["eps2"], out_dtype=bf)
-            u = ops.gemm_bf16(h2, ops.convert(w1, bf), b1)
-            g = ops.act_fwd(u, L["act"])
+            u, g = ops.gemm_bf16_dual(h2, ops.convert(w1, bf), b1, L["act"])
             x_out = ops.gemm_bf16(g, ops.convert(w2, bf), b2, residual=a2, out_dtype=f32, out=torch.empty_like(x))
             rec += [h2, u, g]
             recs.append(rec)

@@ -37,9 +37,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // Softmax VALU diet (the first version spent ~270 instructions per 32-key tile for 8 MFMAs): the score scale is folded
 // into the exp2 argument (one FMA), masking code exists only in the peeled tail / diagonal tile, and the O / l rescale
 // runs only when some row's maximum grows by more than 2^8 (deferred max: P stays <= 256, exact in the normalisation).
-// ABL (timing experiments only, results WRONG): 1 = V staged row-major, 2 = no exp, 4 = no K/V global loads
-template <int NKT, bool CAUSAL, int ABL = 0>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+// ABL (timing experiments only, results WRONG): 1 = V staged row-major, 2 = no exp, 4 = no K/V global loads, 128 = serial key loop;
+// 8 = phase timers (results right; `lse` receives 8 floats of s_memtime cycles per wave instead of the log-sum-exp)
+template <int NKT, bool CAUSAL, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                             int S, int H, int BH, float scale_log2e, float* __restrict__ lse) {
   constexpr int SP = NKT * 32;   // padded key count
   constexpr int VS = SP + 4;     // V^T row stride (elements): (SP+4)/2 dwords = 2 (mod 4)
@@ -57,11 +58,14 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
 
   auto item_base = [&](int item) { return qkv + (size_t)(item / H) * S * row_stride + (item % H) * kDh; };
 
-  bf16x8 kreg[NKT], vreg[NKT];
+  // NW waves stage NW*8 rows per pass; with NW = 8 (16 waves per CU at 2 resident workgroups) the waits of one wave (43 % of
+  // wave-cycles in the 4-wave form: PMC SQ_WAIT_ANY) are covered by three others on the same SIMD instead of one
+  constexpr int RPP = NW * 8, NPASS = (SP + RPP - 1) / RPP;
+  bf16x8 kreg[NPASS], vreg[NPASS];
   auto load_item = [&](const bf16* base) {
 #pragma unroll
-    for (int i = 0; i < NKT; ++i) {
-      const int r = srow + 32 * i;
+    for (int i = 0; i < NPASS; ++i) {
+      const int r = srow + RPP * i;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { kreg[i][j] = (bf16)0.f; vreg[i][j] = (bf16)0.f; }
       if (r < S && (ABL & 4) == 0) {
@@ -72,8 +76,9 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
   };
   auto store_item = [&]() {  // rows >= S are zero so padded keys contribute exact 0
 #pragma unroll
-    for (int i = 0; i < NKT; ++i) {
-      const int r = srow + 32 * i;
+    for (int i = 0; i < NPASS; ++i) {
+      const int r = srow + RPP * i;
+      if (r >= SP) continue;
       *reinterpret_cast<bf16x8*>(Ks + r * kKStride + schunk * 8) = kreg[i];
       if constexpr ((ABL & 1) != 0) {
         *reinterpret_cast<bf16x8*>(Vt + r * 64 + schunk * 8) = vreg[i];
@@ -96,17 +101,25 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
   bf16x8 qcur[4], qnext[4];
   load_q(item_base(item), wave, qcur);
 
+  constexpr bool TIMED = (ABL & 8) != 0;
+  uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> uint64_t { if constexpr (TIMED) return __builtin_amdgcn_s_memtime(); else return 0; };
+  const uint64_t t_begin = now();
   for (; item < BH; item += gridDim.x) {
     const bf16* base = item_base(item);
     const int b = item / H, h = item - b * H;
+    const uint64_t t0 = now();
     store_item();
+    const uint64_t t1 = now();
     __syncthreads();
+    const uint64_t t2 = now();
+    tacc[0] += t1 - t0; tacc[1] += t2 - t1;
     const int nitem = item + gridDim.x;
     if (nitem < BH) load_item(item_base(nitem));  // in flight during the whole compute phase below
 
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += NW) {
       // prefetch the Q fragments this wave needs next: its next tile of this item, else its first tile of the next item
-      if (qt + 4 < nqt) load_q(base, qt + 4, qnext);
+      if (qt + NW < nqt) load_q(base, qt + NW, qnext);
       else if (nitem < BH && wave < nqt) load_q(item_base(nitem), wave, qnext);
       const int q = qt * 32 + l31;
 
@@ -116,6 +129,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+      const uint64_t ta = now();
 
       auto tile = [&](int kt, auto masked) {
         // ---- S^T tile: st[r] = score(query q, key kt*32 + (r&3) + 8*(r>>2) + 4*half)
@@ -190,6 +204,98 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
         }
       };
 
+      if constexpr (!CAUSAL && (ABL & ~8) == 0) {
+        // Software-pipelined key loop (fully unrolled).  The serial form below spends 43 % of its wave-cycles in s_waitcnt (r01 PMC,
+        // profiles/r01_pmc_attention_fwd.txt): ds_read -> 4 chained MFMAs -> ~100 softmax VALU -> ds_read -> 4 MFMAs, nothing
+        // overlapping inside a wave.  Here QK^T of tile kt+1 is issued BEFORE the softmax of tile kt (its K fragments were read one
+        // tile earlier) and the V fragments of tile kt are read before its softmax, so the matrix pipe and the LDS work under the VALU.
+        auto read_k = [&](int kt, bf16x8 (&kf)[4]) {
+          const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(krow + 16 * t);
+        };
+        auto qk = [&](const bf16x8 (&kf)[4]) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qcur[t], acc, 0, 0, 0);
+          return acc;
+        };
+        bf16x8 kf[4];
+        f32x16 st_next;
+        auto body = [&](int kt, auto last) {
+          constexpr bool kLast = decltype(last)::value;
+          f32x16 st = st_next;
+          bf16x8 vf[2][2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const bf16* vrow = Vt + (nt * 32 + l31) * VS + kt * 32 + 16 * jj + 4 * half;
+              const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+              const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+              u32x4 vw;
+              vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+              vf[jj][nt] = __builtin_bit_cast(bf16x8, vw);
+            }
+          if constexpr (!kLast) {
+            st_next = qk(kf);
+            read_k(kt + 2 < NKT ? kt + 2 : NKT - 1, kf);  // (the clamped re-read of the last tile is never used)
+          } else {  // only the last tile can hold padded keys
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+              if (key >= S) st[r] = -INFINITY;
+            }
+          }
+          float tmax = st[0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+          const float ts = tmax * scale_log2e;
+          if (__any(ts > m + 8.0f)) {
+            const float m_new = fmaxf(m, ts);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            lsum *= alpha;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) ot[nt][r] *= alpha;
+          }
+          uint32_t pk[8];
+          f32x2 ps2 = {0.f, 0.f};
+          const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m, -m};
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            f32x2 a = {st[2 * g], st[2 * g + 1]};
+            a = __builtin_elementwise_fma(a, sc2, nm2);
+            f32x2 e;
+            e[0] = __builtin_amdgcn_exp2f(a[0]);
+            e[1] = __builtin_amdgcn_exp2f(a[1]);
+            ps2 += e;
+            bf16x2 p;
+            p[0] = (bf16)e[0]; p[1] = (bf16)e[1];
+            pk[g] = __builtin_bit_cast(uint32_t, p);
+          }
+          lsum += ps2[0] + ps2[1];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            u32x4 pw;
+            pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj][nt], pf, ot[nt], 0, 0, 0);
+          }
+        };
+        read_k(0, kf);
+        st_next = qk(kf);
+        if constexpr (NKT > 1) read_k(1, kf);
+#pragma unroll 1
+        for (int kt = 0; kt < NKT - 1; ++kt) body(kt, std::false_type{});
+        body(NKT - 1, std::true_type{});
+      } else {
       // tiles that cannot contain a dead key run the mask-free body; the (at most one) partial / diagonal tile is peeled
       const int kt_end = CAUSAL ? (qt + 1 < NKT ? qt + 1 : NKT) : NKT;
       const int kt_last = kt_end - 1;
@@ -199,11 +305,14 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
       for (int kt = 0; kt < kt_plain; ++kt) tile(kt, std::false_type{});
       if (last_masked) tile(kt_last, std::true_type{});
 
+      }
       // ---- normalise and store: lane owns row q, channels nt*32 + 8g + 4*half + {0..3}
       lsum += __shfl_xor(lsum, 32);
       const float inv = 1.0f / lsum;
+      const uint64_t tb = now();
+      tacc[2] += tb - ta;
       // training: log2-domain log-sum-exp for the backward kernels (m is the running REFERENCE, not necessarily the max: m + log2(sum) is exact either way)
-      if (lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __builtin_amdgcn_logf(lsum);
+      if (!TIMED && lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __builtin_amdgcn_logf(lsum);
       if (q < S) {
         bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
 #pragma unroll
@@ -218,8 +327,19 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) qcur[t] = qnext[t];
+      // compiler barrier: without it the scheduler stretches live ranges across the query-tile seam and the pipelined key loop
+      // spills 56 VGPRs at NKT = 7
+      asm volatile("" ::: "memory");
+      if constexpr (TIMED) tacc[3] += now() - tb;
     }
+    const uint64_t t3 = now();
     __syncthreads();  // every wave is done with this item's K/V before the next item overwrites LDS
+    tacc[4] += now() - t3;
+  }
+  if constexpr (TIMED) {
+    tacc[5] = now() - t_begin;
+    if (lane == 0 && lse != nullptr)
+      for (int i = 0; i < 6; ++i) lse[((size_t)blockIdx.x * NW + wave) * 8 + i] = (float)tacc[i];
   }
 }
 
@@ -930,7 +1050,8 @@ template <int NKT, bool CAUSAL, int ABL = 0>
 static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st, float* lse = nullptr) {
   constexpr int SP = NKT * 32;
   constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2;
-  auto kern = attention_fwd_kernel<NKT, CAUSAL, ABL>;
+  constexpr int NW = 4;  // 8 waves per workgroup needs <= 128 VGPRs to be resident twice per CU: the kernel uses ~170
+  auto kern = attention_fwd_kernel<NKT, CAUSAL, ABL, NW>;
   static bool attr_done = false;
   if (!attr_done && smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -939,7 +1060,7 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
   }
   const int BH = B * H;
   const int grid = BH < 512 ? BH : 512;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,
                      scale * 1.4426950408889634f, lse);
   return launch_status("attention_fwd");
 }
@@ -980,6 +1101,9 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
       case 3: return launch_attn<7, false, 3>(qkv, out, B, S, H, scale, st);
       case 4: return launch_attn<7, false, 4>(qkv, out, B, S, H, scale, st);
       case 7: return launch_attn<7, false, 7>(qkv, out, B, S, H, scale, st);
+      case 8: return launch_attn<7, false, 8>(qkv, out, B, S, H, scale, st, lse);
+      case 128: return launch_attn<7, false, 128>(qkv, out, B, S, H, scale, st, lse);
+      case 136: return launch_attn<7, false, 136>(qkv, out, B, S, H, scale, st, lse);
     }
   }
 #define ATTN_CASE(N)                                                              \

@@ -63,6 +63,8 @@ struct GemmArgs {
   int res_mode;             // 0: C += R;  1 / 2: C *= QuickGELU'(R) / GELU'(R) (backward of the MLP: R = saved pre-activation, bf16)
   int kt_chunk;             // split-K (weight gradients): K-tiles (of 64) per split, blockIdx.y = split; 0 = no split
   long long c_split_stride; // elements between the partial outputs of consecutive splits
+  void* C2;                 // training forward of the MLP: second bf16 output act2(bf16(C)) next to the pre-activation C (NULL = none)
+  int ldc2, act2;
 };
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
@@ -108,6 +110,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == MMAMD_ACT_QUICKGELU) return quick_gelu(v);
   if (act == MMAMD_ACT_GELU_ERF) return gelu_erf(v);
   return v;
+}
+
+// second output of the dual-store GEMM: the activation of the 8 bf16 values just stored to C (row m, columns n..n+7)
+__device__ __forceinline__ void store_act_copy(const GemmArgs& p, uint4 v, int m, int n) {
+  if (p.C2 == nullptr) return;  // wave-uniform
+  bf16x8 a8 = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a8[j] = (bf16)apply_act((float)a8[j], p.act2);
+  *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C2) + (size_t)m * p.ldc2 + n) = __builtin_bit_cast(uint4, a8);
 }
 
 static int g_gemm_variant = 0;
@@ -197,8 +208,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
           const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           // lower half now holds columns 8g..8g+7 of its row, upper half columns 8(g+1)..8(g+1)+7
           const int n = n0 + wn * TN + ni * 32 + 8 * (g + half);
-          if (mok && n + 7 < p.N)
+          if (mok && n + 7 < p.N) {
             *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+            store_act_copy(p, o, m, n);
+          }
         }
       }
     }
@@ -327,6 +340,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
             v = __builtin_bit_cast(uint4, a8);
           }
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = v;
+          store_act_copy(p, v, m, n);
         }
       }
     }
@@ -1661,6 +1675,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
                 v = __builtin_bit_cast(uint4, a8);
               }
               store16<STP>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v);
+              store_act_copy(p, v, m, n);
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1689,6 +1704,7 @@ __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmArgs p) {
   } else {
     if (p.R) acc += (float)reinterpret_cast<const bf16*>(p.R)[(size_t)m * p.ldr + n];
     reinterpret_cast<bf16*>(p.C)[(size_t)m * p.ldc + n] = (bf16)acc;
+    if (p.C2) reinterpret_cast<bf16*>(p.C2)[(size_t)m * p.ldc2 + n] = (bf16)apply_act((float)(bf16)acc, p.act2);
   }
 }
 
@@ -1828,6 +1844,7 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
           const size_t esz = OUT_F32 ? 4 : 2;
           b.C = reinterpret_cast<char*>(p.C) + rows * p.ldc * esz;
           if (p.R != nullptr) b.R = reinterpret_cast<const char*>(p.R) + rows * p.ldr * esz;
+          if (p.C2 != nullptr) b.C2 = reinterpret_cast<char*>(p.C2) + rows * p.ldc2 * 2;
           const int rc = launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
           if (rc != 0) return rc;
           return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
@@ -1918,9 +1935,25 @@ extern "C" int mmamd_debug_set_gemm_trace(void* buf) {
   return 0;
 }
 
+static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, void* C,
+                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream);
+
 extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
                                int ldr, void* C, int ldc, int out_dtype, int M, int N, int K, int act,
                                mmamd_stream_t stream) {
+  return gemm_bf16_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, out_dtype, M, N, K, act, nullptr, 0, 0, stream);
+}
+
+extern "C" int mmamd_gemm_bf16_dual(const void* A, int lda, const void* W, int ldw, const float* bias, void* U, int ldu, void* G,
+                                    int ldg, int M, int N, int K, int act, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(U && G, MMAMD_E_BADARG, "gemm_dual: null output");
+  MMAMD_CHECK_ARG(act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF, MMAMD_E_BADARG, "gemm_dual: bad activation code %d", act);
+  MMAMD_CHECK_ARG(ldg >= N && ldg % 8 == 0 && aligned16(G), MMAMD_E_ALIGN, "gemm_dual: second output must be 16-byte aligned with ldg %% 8 == 0");
+  return gemm_bf16_impl(A, lda, W, ldw, bias, nullptr, 0, U, ldu, MMAMD_BF16, M, N, K, MMAMD_ACT_NONE, G, ldg, act, stream);
+}
+
+static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, void* C,
+                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(A && W && C, MMAMD_E_BADARG, "gemm: null pointer");
   MMAMD_CHECK_ARG(M >= 0 && N > 0 && K > 0, MMAMD_E_BADARG, "gemm: bad sizes M=%d N=%d K=%d", M, N, K);
   MMAMD_CHECK_ARG(K % 64 == 0, MMAMD_E_UNSUPPORTED, "gemm: K=%d must be a multiple of 64 (pad the operands)", K);
@@ -1938,6 +1971,7 @@ extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, c
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.R = residual; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.act = act; p.tiles_n = 0;
   p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0;
+  p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2;
   if (act == MMAMD_ACT_MUL_QUICKGELU_GRAD || act == MMAMD_ACT_MUL_GELU_GRAD) {
     MMAMD_CHECK_ARG(out_dtype == MMAMD_BF16 && residual != nullptr, MMAMD_E_BADARG,
                     "gemm: the activation-gradient epilogue needs bf16 output and the saved pre-activation as `residual`");
@@ -1982,6 +2016,7 @@ extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = nullptr; p.R = nullptr; p.C = nsplit == 1 ? C : ws;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = N; p.act = MMAMD_ACT_NONE;
   p.kt_chunk = chunk; p.c_split_stride = (long long)M * N; p.res_mode = 0;
+  p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0;
   constexpr int smem = 2 * 512 * 128;
   auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true>;
   static bool attr_done = false;

@@ -20,7 +20,7 @@ __all__ = [
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
-    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd",
+    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "cross_entropy_bwd",
     "attention_x_bwd",
 ]
@@ -97,16 +97,32 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     return out
 
 
-def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 512) -> torch.Tensor:
+def gemm_bf16_dual(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(u, g): u = a @ w^T + bias (bf16, the pre-activation the backward needs) and g = act(u), written by one GEMM."""
+    _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16)
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise MmamdError(f"gemm_dual: inner dims differ ({K} vs {K2})")
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+    u = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    g = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    check(_lib.lib().mmamd_gemm_bf16_dual(a.data_ptr(), K, w.data_ptr(), K, _ptr(bias), u.data_ptr(), N, g.data_ptr(), N, M, N, K,
+                                          int(act), _stream()), "mmamd_gemm_bf16_dual")
+    return u, g
+
+
+def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 256) -> torch.Tensor:
     """fp32 [M,N] = a[M,K] @ w[N,K]^T for a LONG contraction (K % 128 == 0) and few output tiles (weight gradients): the K range
-    is split over grid rows so that about `target_blocks` workgroups run, partials summed by a second kernel."""
+    is split over grid rows so that at most `target_blocks` (= the CU count) workgroups run, partials summed by a second kernel."""
     _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16)
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K:
         raise MmamdError(f"gemm_splitk: inner dims differ ({K} vs {w.shape[1]})")
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    splits = max(1, min(K // 128, (target_blocks + tiles - 1) // tiles))
+    splits = max(1, min(K // 128, target_blocks // tiles))  # one resident workgroup per CU: never start a second, mostly empty round
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ws = torch.empty((splits + 1) * M * N if splits > 1 else 4, dtype=torch.float32, device=a.device)
     check(_lib.lib().mmamd_gemm_bf16_splitk(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), ws.data_ptr(), M, N, K, splits, _stream()),

@@ -490,3 +490,27 @@ def test_training_loop_overfits_a_fixed_batch():
     with torch.no_grad():
         out = clip(images, ids)
     assert (out.embeddings_a @ out.embeddings_b.t()).argmax(1).eq(torch.arange(16, device="cuda")).float().mean() >= 0.9
+
+
+def test_gemm_dual_output_matches_gemm_then_activation():
+    """Training forward of linear1: one GEMM writes the pre-activation and its activation, on every kernel path (128-tiles, 256-tiles
+    with the row-range split, persistent).  The pre-activation must equal the plain GEMM bit for bit; the activation is that of the
+    STORED bf16 pre-activation (what mmamd_act_fwd computes from it: same value up to one bf16 rounding tie — the epilogue uses the
+    rational erf, the standalone kernel libm's)."""
+    from multimodal_amd import ops
+
+    set_rng_seed(21)
+    for (M, N, K) in ((300, 256, 128), (50432, 768, 128), (19712, 2048, 512), (50432, 3072, 768)):
+        a = torch.randn(M, K).to(torch.bfloat16).cuda()
+        w = (torch.randn(N, K) * 0.05).to(torch.bfloat16).cuda()
+        b = torch.randn(N).cuda()
+        for act in (ops.ACT_QUICKGELU, ops.ACT_GELU_ERF):
+            u, g = ops.gemm_bf16_dual(a, w, b, act)
+            u_ref = ops.gemm_bf16(a, w, b)
+            assert torch.equal(u, u_ref), (M, N, K, act)
+            g_ref = ops.act_fwd(u_ref, act).float()
+            diff = (g.float() - g_ref).abs()
+            assert bool((diff <= 2.0 ** -7 * g_ref.abs() + 1e-6).all()), (M, N, K, act)   # one bf16 ulp (+ the rational erf's 1.5e-7 |u| in the far negative tail)
+            assert float((diff > 1e-6).float().mean()) < 1e-3, (M, N, K, act)
+    with pytest.raises(ops.MmamdError):
+        ops.gemm_bf16_dual(a, w, b, ops.ACT_NONE)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--vision-only", action="store_true", help="time the image tower alone (north-star target: >= 40 %% MFMA on ViT-B/16 attention+MLP)")
     a = ap.parse_args()
     from multimodal_amd.models.clip import model as M
     from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
@@ -30,8 +31,12 @@ def main():
     images, ids = clip_batch(a.batch)
     images, ids = images.to(dev), ids.to(dev)
 
+    VISION_GF = {"b16": 35.127, "b32": 8.82, "l14": 162.03}
+
     def step():
         with torch.no_grad():
+            if a.vision_only:
+                return model.encoder_a(images).sum()
             out = model(images, ids)
             return loss_fn(out.embeddings_a, out.embeddings_b)
 
@@ -45,9 +50,11 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.steps
-    print(json.dumps({"workload": f"CLIP ViT-{a.model.upper()} fwd + contrastive loss", "batch": a.batch, "ms_per_step": round(ms, 3),
-                      "pairs_per_s": round(a.batch / ms * 1e3, 1), "gflop_per_pair": GF[a.model],
-                      "tflops": round(a.batch * GF[a.model] / ms, 1), "mfma_frac": round(a.batch * GF[a.model] / ms / 2500.0, 4),
+    gf = VISION_GF[a.model] if a.vision_only else GF[a.model]
+    print(json.dumps({"workload": f"CLIP ViT-{a.model.upper()} " + ("image tower forward" if a.vision_only else "fwd + contrastive loss"),
+                      "batch": a.batch, "ms_per_step": round(ms, 3),
+                      "pairs_per_s": round(a.batch / ms * 1e3, 1), "gflop_per_pair": gf,
+                      "tflops": round(a.batch * gf / ms, 1), "mfma_frac": round(a.batch * gf / ms / 2500.0, 4),
                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "loss": float(loss)}))
 
 

@@ -1,6 +1,9 @@
 #!/bin/bash
-# quick iteration pass: kernel tests for gemm + microbench
+# one GPU iteration: kernel-level tests + model gradient tests + training bench; everything logged under gpurun_out/
 set +e
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "gemm" --maxfail=10 -p no:cacheprovider 2>&1 | tail -15
-timeout 300 python tools/kernel_bench.py --variants ${VARIANTS:-7,18} 2>&1 | tee gpurun_out/kernel_bench.log
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_backward_kernels.py -x -q -m gpu > gpurun_out/pytest_iter.log 2>&1
+grep -E "passed|failed|error" gpurun_out/pytest_iter.log | tail -3
+grep -E "^(FAILED|ERROR)|assert|Error" gpurun_out/pytest_iter.log | head -20
+timeout 300 python tools/train_bench.py > gpurun_out/train_bench.log 2>&1
+tail -1 gpurun_out/train_bench.log | cut -c1-400
