@@ -243,7 +243,7 @@ int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, co
 /* --- row / elementwise kernels of the backward pass (torch autograd of the modules named in the forward entries above)
  * LayerNorm backward: dx[rows,d] (fp32) = LN'(x; gamma)(dy) (+ add), dgamma[d], dbeta[d].  dy fp32 or bf16.  dx_bf16 (optional):
  * the same dx rounded to bf16 (operand of the following gradient GEMMs).
- * ws: (min(512, ceil(rows/4)) * 2 + 2) * d floats. */
+ * ws: (min(768, ceil(rows/4)) * 2 + 2) * d floats. */
 int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
                         void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream);
 /* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(256, rows) * n floats. */

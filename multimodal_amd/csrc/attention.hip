@@ -29,6 +29,21 @@ constexpr int kDh = 64;
 constexpr int kKStride = 72;  // bf16 elements per K row in LDS (144 B: 16-B aligned, 9 slots -> conflict-free)
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read): within each 16-lane group, lane i points at 4 contiguous bf16 — row i>>2, columns
+// 4(i&3)..+3 of a [4][16] block — and receives column i of that block (its 4 rows).  With a row-major [token][channel] image and
+// tr_off() below, a lane gets the 4 consecutive TOKENS of ONE channel an MFMA operand with the token index as k needs: no transposed
+// copy of the tile in LDS (and none of the 2-byte scattered stores that build one).  Addresses must be 8-byte aligned.
+__device__ __forceinline__ uint2 lds_tr_b64(const bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+// element offset of this lane's 4-element piece inside a [rows][stride] image, relative to (row0, col0) of a [4 + 4*half][32] block:
+// lane -> row ((lane&15)>>2) + 4*(lane>>5), column 16*((lane>>4)&1) + 4*(lane&3); the lane then owns channel col0 + (lane&31)
+__device__ __forceinline__ int tr_off(int lane, int stride) {
+  return (((lane & 15) >> 2) + 4 * (lane >> 5)) * stride + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+}
 
 // Persistent kernel: gridDim.x workgroups (2 per CU) walk the (batch, head) items.  While item i is being computed out
 // of LDS, the K/V rows of item i + grid are already in flight into registers (issue-early / write-late staging: the
@@ -753,8 +768,10 @@ static int dispatch_attn_x(const AttnX& p, int B, hipStream_t st) {
 // v_mfma_f32_32x32x16_bf16 with the "lane owns one row" layouts):
 //   P = exp2(s2 - L2[q])            s2 = scale*log2e * q.k (+ mask), L2 = the forward's saved log2-sum-exp
 //   Dq[q] = sum_d dO[q,d] O[q,d];   dP = dO V^T;   dS = P (dP - Dq)
-//   dQ = scale dS K  (kernel 1: lane = query, loop over key tiles; needs K rows, K^T, V rows in LDS)
-//   dV = P^T dO,  dK = scale dS^T Q  (kernel 2: lane = key, loop over query tiles; needs Q rows, Q^T, dO rows, dO^T in LDS)
+//   dQ = scale dS K  (kernel 1: lane = query, loop over key tiles; K rows and V rows in LDS, K^T operands by transpose reads)
+//   dV = P^T dO,  dK = scale dS^T Q  (kernel 2: lane = key, loop over query tiles; Q rows and dO rows in LDS, Q^T / dO^T operands by
+//   transpose reads).  The first version kept explicit transposed copies (94 / 124 KiB of LDS: one workgroup = one wave per SIMD per
+//   CU, built with 2-byte scattered stores) and ran the vision shape in 317 + 415 us against the forward's 108.
 // ---------------------------------------------------------------------------------------------------------
 template <int NKT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
@@ -766,7 +783,6 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Ks = reinterpret_cast<bf16*>(smem);                                  // [SP][72]
   bf16* Vs = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);              // [SP][72]
-  bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * SP * kKStride * 2);          // [64][VS]
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh - b * H;
   const int D = H * kDh;
@@ -785,13 +801,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
     }
     *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
     *reinterpret_cast<bf16x8*>(Vs + r * kKStride + c * 8) = vv;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VS + r] = kv[j];
   }
   __syncthreads();
   const int l31 = lane & 31, half = lane >> 5;
   const float c2 = scale * 1.4426950408889634f;
   const int nqt = (S + 31) >> 5;
+  const bf16* ktr = Ks + tr_off(lane, kKStride);  // K^T fragments by transpose reads of the row-major K image
   for (int qt = wave; qt < nqt; qt += 4) {
     const int q = qt * 32 + l31;
     const int qc = q < S ? q : S - 1;
@@ -852,9 +867,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
         const bf16x8 dsf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const bf16* ktrow = Kt + (nt * 32 + l31) * VS + key0;
-          const uint2 v0 = *reinterpret_cast<const uint2*>(ktrow);
-          const uint2 v1 = *reinterpret_cast<const uint2*>(ktrow + 8);
+          // slots 0-3 = channel nt*32+l31 of keys key0..key0+3, slots 4-7 = keys key0+8..key0+11 (key0 includes 4*half, as tr_off does)
+          const bf16* kp = ktr + (kt * 32 + 16 * jj) * kKStride + nt * 32;
+          const uint2 v0 = lds_tr_b64(kp);
+          const uint2 v1 = lds_tr_b64(kp + 8 * kKStride);
           u32x4 vw;
           vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), dsf, acc[nt], 0, 0, 0);
@@ -886,9 +902,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Qs = reinterpret_cast<bf16*>(smem);                                           // [SP][72]
   bf16* dOs = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);                      // [SP][72]
-  bf16* Qt = reinterpret_cast<bf16*>(smem + 2 * SP * kKStride * 2);                   // [64][VS]
-  bf16* dOt = reinterpret_cast<bf16*>(smem + 2 * SP * kKStride * 2 + 64 * VS * 2);    // [64][VS]
-  float* L2s = reinterpret_cast<float*>(smem + 2 * SP * kKStride * 2 + 2 * 64 * VS * 2);  // [SP]
+  float* L2s = reinterpret_cast<float*>(smem + 2 * SP * kKStride * 2);                // [SP]
   float* Dqs = L2s + SP;                                                                   // [SP]
   const int bh = blockIdx.x;
   const int b = bh / H, h = bh - b * H;
@@ -913,11 +927,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
     *reinterpret_cast<bf16x8*>(dOs + r * kKStride + c * 8) = dv;
     float part = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      Qt[(c * 8 + j) * VS + r] = qv[j];
-      dOt[(c * 8 + j) * VS + r] = dv[j];
-      part += (float)dv[j] * (float)ov[j];
-    }
+    for (int j = 0; j < 8; ++j) part += (float)dv[j] * (float)ov[j];
     // the 8 threads of a row are 8 consecutive lanes: sum their partial dot products
     part += __shfl_xor(part, 1);
     part += __shfl_xor(part, 2);
@@ -928,6 +938,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
   const int l31 = lane & 31, half = lane >> 5;
   const float c2 = scale * 1.4426950408889634f;
   const int nkt = (S + 31) >> 5;
+  const bf16* qtr = Qs + tr_off(lane, kKStride);   // Q^T / dO^T fragments by transpose reads of the row-major images
+  const bf16* dotr = dOs + tr_off(lane, kKStride);
   for (int kt = wave; kt < nkt; kt += 4) {
     const int key = kt * 32 + l31;
     const int kc = key < S ? key : S - 1;
@@ -984,10 +996,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
         const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dw);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const bf16* dorow = dOt + (nt * 32 + l31) * VS + q0;
-          const bf16* qtrow = Qt + (nt * 32 + l31) * VS + q0;
-          const uint2 a0 = *reinterpret_cast<const uint2*>(dorow), a1 = *reinterpret_cast<const uint2*>(dorow + 8);
-          const uint2 b0 = *reinterpret_cast<const uint2*>(qtrow), b1 = *reinterpret_cast<const uint2*>(qtrow + 8);
+          const int toff = (qt * 32 + 16 * jj) * kKStride + nt * 32;  // queries q0..q0+3 / q0+8..q0+11 of channel nt*32+l31
+          const uint2 a0 = lds_tr_b64(dotr + toff), a1 = lds_tr_b64(dotr + toff + 8 * kKStride);
+          const uint2 b0 = lds_tr_b64(qtr + toff), b1 = lds_tr_b64(qtr + toff + 8 * kKStride);
           u32x4 aw, bw;
           aw[0] = a0.x; aw[1] = a0.y; aw[2] = a1.x; aw[3] = a1.y;
           bw[0] = b0.x; bw[1] = b0.y; bw[2] = b1.x; bw[3] = b1.y;
@@ -1016,8 +1027,8 @@ template <int NKT>
 static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
                            float scale, hipStream_t st, const uint8_t* key_mask) {
   constexpr int SP = NKT * 32;
-  constexpr int smem1 = 2 * SP * kKStride * 2 + 64 * (SP + 4) * 2;
-  constexpr int smem2 = 2 * SP * kKStride * 2 + 2 * 64 * (SP + 4) * 2 + 2 * SP * 4;
+  constexpr int smem1 = 2 * SP * kKStride * 2;               // K, V rows (two workgroups per CU up to S = 256)
+  constexpr int smem2 = 2 * SP * kKStride * 2 + 2 * SP * 4;  // Q, dO rows + lse / Dq
   auto k1c = attention_bwd_dq_kernel<NKT, true>;
   auto k1n = attention_bwd_dq_kernel<NKT, false>;
   auto k2c = attention_bwd_dkv_kernel<NKT, true>;

@@ -19,20 +19,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   __shared__ float red[4][2][MAXV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d4 = d >> 2;
-  f32x4 gacc[MAXV], bacc[MAXV];
+  f32x4 gacc[MAXV], bacc[MAXV], gm[MAXV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) { gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < MAXV; ++i) {
+    gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gm[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (lane + 64 * i < d4) gm[i] = load4(gamma + 4 * (lane + 64 * i));
+  }
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const float* xr = x + (size_t)row * d;
     const TD* dr = dy + (size_t)row * d;
-    f32x4 xv[MAXV], gv[MAXV];
-    float sum = 0.f;
+    // every load of the row is issued before the first reduction: one memory round trip per row instead of three dependent ones
+    // (x -> statistics -> dy -> means -> add): the first form ran at 2.7 TB/s, latency-bound with 2 waves per SIMD
+    f32x4 xv[MAXV], gv[MAXV], av[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + 64 * i;
-      xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < d4) { xv[i] = load4(xr + 4 * c); sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]); }
+      xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d4) {
+        xv[i] = load4(xr + 4 * c);
+        gv[i] = load4(dr + 4 * c);
+        if (add != nullptr) av[i] = load4(add + (size_t)row * d + 4 * c);
+      }
     }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);  // lanes past d hold zeros
     const float mean = wave_sum(sum) / (float)d;
     float q = 0.f;
 #pragma unroll
@@ -48,18 +59,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + 64 * i;
-      gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < d4) {
-        const f32x4 dyv = load4(dr + 4 * c), gm = load4(gamma + 4 * c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float xh = (xv[i][j] - mean) * rstd;
+          const float dyj = gv[i][j];
           xv[i][j] = xh;
-          gv[i][j] = dyv[j] * gm[j];
+          gv[i][j] = dyj * gm[i][j];
           sg += gv[i][j];
           sgx += gv[i][j] * xh;
-          gacc[i][j] += dyv[j] * xh;
-          bacc[i][j] += dyv[j];
+          gacc[i][j] += dyj * xh;
+          bacc[i][j] += dyj;
         }
       }
     }
@@ -70,12 +80,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       if (c < d4) {
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[i][j] - mg - xv[i][j] * mgx);
-        if (add != nullptr) {
-          const f32x4 a = load4(add + (size_t)row * d + 4 * c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += a[j];
-        }
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[i][j] - mg - xv[i][j] * mgx) + av[i][j];
         store4(dx + (size_t)row * d + 4 * c, o);
         if (dx_bf16 != nullptr) store4(dx_bf16 + (size_t)row * d + 4 * c, o);  // MFMA operand of the next dgrad / wgrad
       }
@@ -282,7 +287,7 @@ extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const voi
   MMAMD_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && ws && rows > 0 && d > 0, MMAMD_E_BADARG, "layernorm_bwd: bad argument");
   MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "layernorm_bwd: d=%d must be a multiple of 4 and <= 2048", d);
   hipStream_t st = (hipStream_t)stream;
-  const int G = rows < 4 * 512 ? (rows + 3) / 4 : 512;  // ws: G * 2 * d floats
+  const int G = rows < 4 * 768 ? (rows + 3) / 4 : 768;  // 3 workgroups per CU (157 VGPRs at d = 768); ws: (G + 1) * 2 * d floats
   const int d4 = d / 4;
 #define LNB(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(G), dim3(256), 0, st, x, gamma, (const T*)dy, add, dx, (bf16*)dx_bf16, ws, rows, d, eps)
   if (dy_dtype == MMAMD_F32) { if (d4 <= 128) LNB(float, 2); else if (d4 <= 256) LNB(float, 4); else LNB(float, 8); }

@@ -603,7 +603,7 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: f
     dev = x.device
     dx = torch.empty((rows, d), dtype=torch.float32, device=dev)
     dg, db = torch.empty(d, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)
-    G = min(512, (rows + 3) // 4)
+    G = min(768, (rows + 3) // 4)
     ws = torch.empty((G * 2 + 2) * d, dtype=torch.float32, device=dev)
     dxb = torch.empty((rows, d), dtype=torch.bfloat16, device=dev) if want_bf16 else None
     check(_lib.lib().mmamd_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy), _ptr(add), dx.data_ptr(), _ptr(dxb),
