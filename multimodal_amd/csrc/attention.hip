@@ -61,7 +61,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
   constexpr int VS = SP + 4;     // V^T row stride (elements): (SP+4)/2 dwords = 2 (mod 4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* Ks = reinterpret_cast<bf16*>(smem);                       // [SP][kKStride]
-  bf16* Vt = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);   // [64][VS]
+  // V: row-major [SP][kKStride] read through ds_read_b64_tr_b16 (no transposed copy, staged with the same 16-byte stores as K);
+  // S > 256 keeps the transposed [64][VS] image (two workgroups per CU only fit with its smaller footprint)
+  constexpr bool VTR = NKT <= 8 && (ABL & 1) == 0;
+  bf16* Vt = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);   // VTR: [SP][kKStride], else [64][VS]
 
   const int D = H * kDh;
   const size_t row_stride = (size_t)3 * D;
@@ -95,7 +98,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
       const int r = srow + RPP * i;
       if (r >= SP) continue;
       *reinterpret_cast<bf16x8*>(Ks + r * kKStride + schunk * 8) = kreg[i];
-      if constexpr ((ABL & 1) != 0) {
+      if constexpr (VTR) {
+        *reinterpret_cast<bf16x8*>(Vt + r * kKStride + schunk * 8) = vreg[i];
+      } else if constexpr ((ABL & 1) != 0) {
         *reinterpret_cast<bf16x8*>(Vt + r * 64 + schunk * 8) = vreg[i];
       } else {
 #pragma unroll
@@ -108,6 +113,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
     const int qc = q < S ? q : S - 1;
 #pragma unroll
     for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * row_stride + 16 * t + 8 * half);
+  };
+
+  // V operand of the PV MFMA: channel nt*32 + l31, keys key0..key0+3 and key0+8..key0+11 with key0 = kt*32 + 16*jj + 4*half
+  const bf16* vtr = Vt + tr_off(lane, kKStride);
+  auto read_v = [&](int kt, int jj, int nt) -> bf16x8 {
+    uint2 v0, v1;
+    if constexpr (VTR) {
+      const bf16* vp = vtr + (kt * 32 + 16 * jj) * kKStride + nt * 32;
+      v0 = lds_tr_b64(vp);
+      v1 = lds_tr_b64(vp + 8 * kKStride);
+    } else {
+      const bf16* vrow = Vt + (nt * 32 + l31) * VS + kt * 32 + 16 * jj + 4 * half;
+      v0 = *reinterpret_cast<const uint2*>(vrow);
+      v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+    }
+    u32x4 vw;
+    vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+    return __builtin_bit_cast(bf16x8, vw);
   };
 
   int item = blockIdx.x;
@@ -207,15 +230,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
           pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
           const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const bf16* vrow = Vt + (nt * 32 + l31) * VS + key0;
-            const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
-            const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
-            u32x4 vw;
-            vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
-            ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[nt], 0, 0, 0);
-          }
+          for (int nt = 0; nt < 2; ++nt) ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_v(kt, jj, nt), pf, ot[nt], 0, 0, 0);
         }
       };
 
@@ -246,14 +261,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              const bf16* vrow = Vt + (nt * 32 + l31) * VS + kt * 32 + 16 * jj + 4 * half;
-              const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
-              const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
-              u32x4 vw;
-              vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
-              vf[jj][nt] = __builtin_bit_cast(bf16x8, vw);
-            }
+            for (int nt = 0; nt < 2; ++nt) vf[jj][nt] = read_v(kt, jj, nt);
           if constexpr (!kLast) {
             st_next = qk(kf);
             read_k(kt + 2 < NKT ? kt + 2 : NKT - 1, kf);  // (the clamped re-read of the last tile is never used)
@@ -1060,7 +1068,7 @@ static int g_attn_variant = 0;
 template <int NKT, bool CAUSAL, int ABL = 0>
 static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st, float* lse = nullptr) {
   constexpr int SP = NKT * 32;
-  constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2;
+  constexpr int smem = SP * kKStride * 2 + ((NKT <= 8 && (ABL & 1) == 0) ? SP * kKStride * 2 : 64 * (SP + 4) * 2);
   constexpr int NW = 4;  // 8 waves per workgroup needs <= 128 VGPRs to be resident twice per CU: the kernel uses ~170
   auto kern = attention_fwd_kernel<NKT, CAUSAL, ABL, NW>;
   static bool attr_done = false;
