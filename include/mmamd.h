@@ -110,6 +110,11 @@ int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int S
  * outputs go to ws (splits * M * N floats) and are summed by a second kernel.  dW = dY^T X of every nn.Linear on the path. */
 int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
                            mmamd_stream_t stream);
+/* The same weight-gradient GEMM straight from the ROW-major operands: C[M,N] (fp32) = sum_t A[t, m] W[t, n], A = dY [K, lda] and
+ * W = X [K, ldw] as the forward / backward kernels left them (bf16, K = tokens, a multiple of 128; M, N multiples of 8).  No
+ * transposed copies: the kernel reads its MFMA operands from LDS with ds_read_b64_tr_b16. */
+int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
+                              mmamd_stream_t stream);
 
 /* Same, additionally returning the attention probabilities (normalised, [B,H,S,S], probs_dtype F32 or BF16) and honouring a
  * key-padding mask (uint8 [B,S], 0 = masked key, NULL = none).  Non-causal.  Replaces scaled_dot_product_attention of
@@ -246,7 +251,7 @@ int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, co
  * ws: (min(768, ceil(rows/4)) * 2 + 2) * d floats. */
 int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
                         void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream);
-/* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(256, rows) * n floats. */
+/* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(1024, rows) * n floats. */
 int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */
 int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream);

@@ -41,8 +41,14 @@ def dgrad(dy: Tensor, w: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act: Op
 
 
 def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
-    """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens (zero-padded to 128).
-    bias=True also returns db[N] = column sums of dY, produced by the same transpose pass over dY."""
+    """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens.  bias=True also returns
+    db[N] = column sums of the bf16-rounded dY.  Token counts that are multiples of 128 (every full-size batch) go straight from the
+    row-major operands (mmamd_gemm_bf16_tn_splitk); others take transposed, zero-padded copies (db then comes out of the transpose pass)."""
+    if dy.shape[0] % 128 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+        dyb = dy if dy.dtype == bf else ops.convert(dy, bf)
+        xb = x if x.dtype == bf else ops.convert(x, bf)
+        dW = ops.gemm_bf16_tn_splitk(dyb, xb)
+        return (dW, ops.colsum(dyb)) if bias else dW
     if bias:
         dyT, db = ops.transpose_to_bf16(dy, with_colsum=True)
     else:

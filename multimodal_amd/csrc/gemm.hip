@@ -516,9 +516,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 //     3-6x the algorithmic bytes).
 // ABL (ablation bit mask, perf experiments only — results are WRONG for ABL != 0): 1 = no DMA in the loop,
 // 2 = no MFMA, 4 = no epilogue, 8 = no fragment reads, 16 = no global accesses in the epilogue
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true>
+// TNM ("TN" operands, weight gradients): C[M,N] = sum_t A[t][m] W[t][n] with A = [K, lda] and W = [K, ldw] ROW-major over the
+// contraction index t (dW = dY^T X straight from the row-major dY and X: no transposed bf16 copies in HBM).  The LDS image of a
+// K-tile is then [64 t][256 cols], stored as 256-byte units of [4 t][32 cols] (two [4][16] blocks) in [t/4][cols/32] order — the
+// DMA lays it out through its per-lane source addresses — and every MFMA operand is two ds_read_b64_tr_b16 (4 + 4 contraction
+// indices of one column per lane; the two 16-lane groups of a half-wave read one contiguous 256-byte unit: conflict-free).
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m,
                                                                         unsigned long long* trace = nullptr) {
+  static_assert(!TNM || (BM == 256 && BN == 256), "TN image below is laid out for 256-column operand tiles");
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
@@ -554,28 +560,50 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   const int row8 = 2 * (lane >> 4) + (slot >> 3);
   const int chunk = slot & 7;
   uint32_t a_off[A_INSTR], b_off[B_INSTR];
+  if constexpr (TNM) {
+    // piece pi (1 KiB = 4 units) holds contraction rows 4*(pi>>1)..+3, columns 128*(pi&1)..+127: lane -> unit lane>>4, block
+    // (lane>>3)&1, row (lane>>1)&3, 16-byte half of the block row lane&1.  Columns past the matrix are clamped (they only feed
+    // rows / columns of C that are never stored).
+    const int pu = lane >> 4, pcb = (lane >> 3) & 1, prow = (lane >> 1) & 3, phr = lane & 1;
 #pragma unroll
-  for (int j = 0; j < A_INSTR; ++j) {
-    int r = m0 + 8 * (wave + NW * j) + row8;
-    r = r < p.M ? r : p.M - 1;
-    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
-  }
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int pi = wave + NW * j;
+      int c = m0 + (4 * (pi & 1) + pu) * 32 + pcb * 16 + phr * 8;
+      c = c + 8 <= p.M ? c : p.M - 8;
+      a_off[j] = ((uint32_t)(4 * (pi >> 1) + prow) * (uint32_t)p.lda + c) * 2u;
+    }
 #pragma unroll
-  for (int j = 0; j < B_INSTR; ++j) {
-    int r = n0 + 8 * (wave + NW * j) + row8;
-    r = r < p.N ? r : p.N - 1;
-    b_off[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
+    for (int j = 0; j < B_INSTR; ++j) {
+      const int pi = wave + NW * j;
+      int c = n0 + (4 * (pi & 1) + pu) * 32 + pcb * 16 + phr * 8;
+      c = c + 8 <= p.N ? c : p.N - 8;
+      b_off[j] = ((uint32_t)(4 * (pi >> 1) + prow) * (uint32_t)p.ldw + c) * 2u;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      int r = m0 + 8 * (wave + NW * j) + row8;
+      r = r < p.M ? r : p.M - 1;
+      a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      int r = n0 + 8 * (wave + NW * j) + row8;
+      r = r < p.N ? r : p.N - 1;
+      b_off[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
+    }
   }
   // split-K: this block owns K-tiles [kt0, kt0 + KT) and writes its own partial output (no bias / residual / activation)
   const int kt0 = p.kt_chunk > 0 ? (int)blockIdx.y * p.kt_chunk : 0;
-  const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * 128;
-  const char* Wb = reinterpret_cast<const char*>(p.W) + (size_t)kt0 * 128;
+  const size_t a_step = TNM ? (size_t)64 * p.lda * 2 : 128, w_step = TNM ? (size_t)64 * p.ldw * 2 : 128;  // bytes per K-tile
+  const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * a_step;
+  const char* Wb = reinterpret_cast<const char*>(p.W) + (size_t)kt0 * w_step;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
   // piece i of a stage (i < A_INSTR: activation rows, else weight rows): scalar base + K offset, per-lane 32-bit offset
   auto issue_piece = [&](int buf, int kt, int i) {
     const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
-    if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
-    else dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
+    if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * a_step, a_off[i], dst);
+    else dma_piece_s(Wb + (size_t)kt * w_step, b_off[i - A_INSTR], dst);
   };
   auto issue_stage = [&](int buf, int kt) {
 #pragma unroll
@@ -592,11 +620,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   for (int bf = 0; bf < 2; ++bf)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
-      ra[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + (wm * TM) * 128 + ro;
-      rb[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
+      if constexpr (TNM) {
+        // k-step t = contraction rows 16t..16t+15: this lane's slots 0-3 are rows 16t + 4*half + {0..3} (unit row 4t + half),
+        // slots 4-7 the same + 8 (unit row + 2, i.e. + 4096 bytes); 32-column block b of the operand tile = unit column b
+        const uint32_t ro = (uint32_t)((4 * t + half) * 8) * 256 + ((lane >> 4) & 1) * 128 + ((lane & 15) >> 2) * 32 + (lane & 3) * 8;
+        ra[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + (wm * TM / 32) * 256 + ro;
+        rb[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + A_BYTES + (wn * TN / 32) * 256 + ro;
+      } else {
+        const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
+        ra[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + (wm * TM) * 128 + ro;
+        rb[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
+      }
     }
   typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
+  typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_p;
+  auto tr_frag = [&](uint32_t addr) -> bf16x8 {  // two transpose reads: contraction rows r..r+3 and r+8..r+11 of this lane's column
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr_p>((uintptr_t)addr));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr_p>((uintptr_t)(addr + 4096)));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
 
   f32x16 acc[NI][MI];
 #pragma unroll
@@ -619,10 +664,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   auto load_frags = [&](auto bufc, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
     if constexpr ((ABL & 8) != 0) return;
     constexpr int BF = decltype(bufc)::value;
+    if constexpr (TNM) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + ni * 32 * 128));
+      for (int ni = 0; ni < NI; ++ni) wb[ni] = tr_frag(rb[BF][t] + ni * 256);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + mi * 32 * 128));
+      for (int mi = 0; mi < MI; ++mi) xa[mi] = tr_frag(ra[BF][t] + mi * 256);
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + ni * 32 * 128));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + mi * 32 * 128));
+    }
   };
   auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
     if constexpr ((ABL & 2) != 0) {  // keep the fragment reads alive without the matrix work
@@ -669,7 +721,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TNM ? 2 : 1, 0);
       }
       if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
     }
@@ -1999,15 +2051,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 }  // namespace mmamd
 
-extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K,
-                                      int splits, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(A && W && C && ws && M > 0 && N > 0 && K > 0 && splits >= 1, MMAMD_E_BADARG, "gemm_splitk: bad argument");
-  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_splitk: K=%d must be a multiple of 128 (pad the operands)", K);
-  MMAMD_CHECK_ARG(N % 8 == 0 && (M * (long long)N) % 4 == 0, MMAMD_E_UNSUPPORTED, "gemm_splitk: N=%d must be a multiple of 8", N);
-  MMAMD_CHECK_ARG(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "gemm_splitk: bad leading dimension");
-  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws), MMAMD_E_ALIGN, "gemm_splitk: base pointers must be 16-byte aligned");
-  MMAMD_CHECK_ARG((uint64_t)M * (uint64_t)lda * 2u < (1ull << 32) && (uint64_t)N * (uint64_t)ldw * 2u < (1ull << 32),
-                  MMAMD_E_UNSUPPORTED, "gemm_splitk: operand exceeds the 4 GiB 32-bit DMA offset range");
+template <bool TNM>
+static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
+                            mmamd_stream_t stream) {
   const int KT = K / 64;
   int chunk = (KT + splits - 1) / splits;
   chunk += chunk & 1;  // even number of K-tiles per split (the K loop is unrolled by two); KT is even, so is the remainder
@@ -2018,7 +2064,7 @@ extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int
   p.kt_chunk = chunk; p.c_split_stride = (long long)M * N; p.res_mode = 0;
   p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0;
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true>;
+  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true, TNM>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -2034,4 +2080,28 @@ extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit, n, C);
   }
   return launch_status("gemm_bf16_splitk");
+}
+
+extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K,
+                                      int splits, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(A && W && C && ws && M > 0 && N > 0 && K > 0 && splits >= 1, MMAMD_E_BADARG, "gemm_splitk: bad argument");
+  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_splitk: K=%d must be a multiple of 128 (pad the operands)", K);
+  MMAMD_CHECK_ARG(N % 8 == 0 && (M * (long long)N) % 4 == 0, MMAMD_E_UNSUPPORTED, "gemm_splitk: N=%d must be a multiple of 8", N);
+  MMAMD_CHECK_ARG(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "gemm_splitk: bad leading dimension");
+  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws), MMAMD_E_ALIGN, "gemm_splitk: base pointers must be 16-byte aligned");
+  MMAMD_CHECK_ARG((uint64_t)M * (uint64_t)lda * 2u < (1ull << 32) && (uint64_t)N * (uint64_t)ldw * 2u < (1ull << 32),
+                  MMAMD_E_UNSUPPORTED, "gemm_splitk: operand exceeds the 4 GiB 32-bit DMA offset range");
+  return gemm_splitk_impl<false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+}
+
+extern "C" int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K,
+                                         int splits, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(A && W && C && ws && M > 0 && N > 0 && K > 0 && splits >= 1, MMAMD_E_BADARG, "gemm_tn_splitk: bad argument");
+  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk: contraction length K=%d must be a multiple of 128", K);
+  MMAMD_CHECK_ARG(M % 8 == 0 && N % 8 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk: M=%d and N=%d must be multiples of 8", M, N);
+  MMAMD_CHECK_ARG(lda >= M && ldw >= N && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "gemm_tn_splitk: bad leading dimension");
+  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws), MMAMD_E_ALIGN, "gemm_tn_splitk: base pointers must be 16-byte aligned");
+  MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)lda * 2u < (1ull << 31) && (uint64_t)64 * (uint64_t)ldw * 2u < (1ull << 31), MMAMD_E_UNSUPPORTED,
+                  "gemm_tn_splitk: leading dimension too large for the 32-bit DMA offsets");
+  return gemm_splitk_impl<true>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
 }

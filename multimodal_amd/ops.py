@@ -21,7 +21,7 @@ __all__ = [
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
-    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "cross_entropy_bwd",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd",
     "attention_x_bwd",
 ]
 
@@ -127,6 +127,22 @@ def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 256)
     ws = torch.empty((splits + 1) * M * N if splits > 1 else 4, dtype=torch.float32, device=a.device)
     check(_lib.lib().mmamd_gemm_bf16_splitk(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), ws.data_ptr(), M, N, K, splits, _stream()),
           "mmamd_gemm_bf16_splitk")
+    return out
+
+
+def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 256) -> torch.Tensor:
+    """fp32 [M,N] = y[T,M]^T @ x[T,N] (dW = dY^T X) from the row-major bf16 operands, T = tokens (T % 128 == 0)."""
+    _chk(y, "y", torch.bfloat16); _chk(x, "x", torch.bfloat16)
+    T, M = y.shape
+    T2, N = x.shape
+    if T != T2:
+        raise MmamdError(f"gemm_tn_splitk: token counts differ ({T} vs {T2})")
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    splits = max(1, min(T // 128, target_blocks // tiles))
+    out = torch.empty((M, N), dtype=torch.float32, device=y.device)
+    ws = torch.empty((splits + 1) * M * N if splits > 1 else 4, dtype=torch.float32, device=y.device)
+    check(_lib.lib().mmamd_gemm_bf16_tn_splitk(y.data_ptr(), M, x.data_ptr(), N, out.data_ptr(), ws.data_ptr(), M, N, T, splits, _stream()),
+          "mmamd_gemm_bf16_tn_splitk")
     return out
 
 
@@ -616,7 +632,7 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     _chk(x, "x")
     rows, n = x.shape
     out = torch.empty(n, dtype=torch.float32, device=x.device)
-    ws = torch.empty(min(256, rows) * n, dtype=torch.float32, device=x.device)
+    ws = torch.empty(min(1024, rows) * n, dtype=torch.float32, device=x.device)
     check(_lib.lib().mmamd_colsum(x.data_ptr(), _dt(x), rows, n, out.data_ptr(), ws.data_ptr(), _stream()), "mmamd_colsum")
     return out
 

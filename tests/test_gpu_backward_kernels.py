@@ -514,3 +514,19 @@ def test_gemm_dual_output_matches_gemm_then_activation():
             assert float((diff > 1e-6).float().mean()) < 1e-3, (M, N, K, act)
     with pytest.raises(ops.MmamdError):
         ops.gemm_bf16_dual(a, w, b, ops.ACT_NONE)
+
+
+def test_weight_gradient_gemm_from_row_major_operands():
+    """dW = dY^T X straight from the row-major bf16 dY [T, M] and X [T, N] (LDS transpose reads) == the fp32 product of the same
+    operands; shapes with partial tiles in both output dimensions and every split count."""
+    from multimodal_amd import ops
+
+    set_rng_seed(33)
+    for (T, M, N) in ((256, 64, 64), (50432, 768, 3072), (6400, 2304, 768), (1280, 200, 520), (19712, 512, 2048), (128, 8, 8)):
+        y = (torch.randn(T, M) * 0.1).to(torch.bfloat16).cuda()
+        x = torch.randn(T, N).to(torch.bfloat16).cuda()
+        got = host(ops.gemm_bf16_tn_splitk(y, x))
+        ref = host(y.float().t() @ x.float())  # fp32 reference of the same bf16 operands (ATen, test only)
+        assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), (T, M, N)
+    with pytest.raises(ops.MmamdError):
+        ops.gemm_bf16_tn_splitk(y[:64], x[:64])  # token count must be a multiple of 128
