@@ -1900,9 +1900,11 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     };
     if (t256 < 96) {
       v = 6;
-    } else if ((p.K & 127) == 0 && (t256 >= 1024 || (t256 >= 512 && p.K >= 2048))) {
+    } else if ((p.K & 127) == 0 && t256 >= 512) {
       v = 18;  // many tiles per CU: the persistent kernel hides each tile's first-stage load behind the previous epilogue
-      if (try_split(true)) return rc;  // measured on the MLP-down GEMM (591 tiles): 855 -> 896 TF/s
+      // row-range split in front of it only for long K (MLP-down, 591 tiles: 855 -> 896 TF/s); at K <= 768 the plain persistent grid wins
+      // (out-proj 622 vs 598, text MLP-up 692 vs 647 TF/s)
+      if (p.K >= 2048 && try_split(true)) return rc;
     } else {
       v = 7;
       if (try_split(false)) return rc;
