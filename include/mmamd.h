@@ -190,8 +190,19 @@ int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64
 int mmamd_flava_image_embed(const float* patch_emb, const float* cls, const float* pos, const int64_t* patches_mask,
                             const float* mask_token, float* x, int B, int G2, int d, mmamd_stream_t stream);
 
-/* out[B,E] = act(rows . W^T + bias), rows i at h + i*ldh (fp32, exact-f32 MFMA); act 0 none, 1 tanh.  Replaces Pooler
- * (modules/losses/flava.py:84-97) and the CLS projections (models/flava/model.py:243-247,260-264). */
+/* FLAVA position-embedding interpolation (models/flava/image_encoder.py:102-137, interpolate_pos_encoding): pos [1 + n_side^2, d]
+ * fp32 -> out [1 + h0*w0, d]: row 0 copied, the patch grid resampled like F.interpolate(mode="bicubic", align_corners=False,
+ * scale_factor=(scale_h, scale_w)) (torch's upsample_bicubic2d: A = -0.75, clamped taps). */
+int mmamd_bicubic_pos_embed(const float* pos, int n_side, int d, float* out, int h0, int w0, float scale_h, float scale_w,
+                            mmamd_stream_t stream);
+/* labels[i] = keep[i] ? labels[i] : fill (in place; FLAVAForPreTraining's image_labels[~image_patches_mask] = -1, model.py:340-343). */
+int mmamd_mask_labels(int64_t* labels, const uint8_t* keep, int64_t fill, int64_t n, mmamd_stream_t stream);
+/* ReLU backward on fp32: dz = y > 0 ? dy : 0 (classifier MLP of FLAVAForClassification under autograd). */
+int mmamd_relu_bwd(const float* y, const float* dy, float* dz, int64_t n, mmamd_stream_t stream);
+
+/* out[B,E] = act(rows . W^T + bias), rows i at h + i*ldh (fp32, exact-f32 MFMA); act 0 none, 1 tanh, 2 ReLU.  Replaces Pooler
+ * (modules/losses/flava.py:84-97), the CLS projections (models/flava/model.py:243-247,260-264) and the classifier MLP on the CLS row
+ * (FLAVAForClassification, models/flava/model.py:380-422 with modules/layers/mlp.py:13-66, nn.ReLU between the layers). */
 int mmamd_rows_linear_f32(const float* h, int64_t ldh, const float* W, const float* bias, int act, float* out, int B, int d,
                           int E, mmamd_stream_t stream);
 

@@ -192,6 +192,36 @@ class RowsLinearFn(torch.autograd.Function):
         return dx, None, dW, db
 
 
+class SmallLinearF32Fn(torch.autograd.Function):
+    """y = act(x W^T + b) in exact fp32 for a FEW rows (classifier heads on the CLS row): x fp32 [M, K] contiguous; act in
+    {None, "relu"}.  Forward mmamd_rows_linear_f32, backward two strided exact-fp32 GEMMs + a column sum (+ mmamd_relu_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool):
+        xc = c32(x)
+        W = c32(weight)
+        y = ops.rows_linear_f32(xc, xc.shape[1], xc.shape[0], W, c32(bias) if bias is not None else None, relu=relu)
+        ctx.save_for_backward(xc, weight, y if relu else xc.new_empty(0))
+        ctx.meta = (relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight, y = ctx.saved_tensors
+        relu, has_bias = ctx.meta
+        M, K = xc.shape
+        W = c32(weight)
+        E = W.shape[0]
+        dz = dy.detach()
+        dz = dz if dz.is_contiguous() else dz.contiguous()
+        if relu:
+            dz = ops.relu_bwd(y, dz)
+        dW = ops.f32_gemm_strided(dz, 1, E, xc, 1, K, E, K, M)   # dW[j,k] = sum_m dz[m,j] x[m,k]
+        dx = ops.f32_gemm_strided(dz, E, 1, W, 1, K, M, K, E)    # dx[m,k] = sum_j dz[m,j] W[j,k]
+        db = ops.colsum(dz) if has_bias else None
+        return dx, dW, db, None
+
+
 class L2NormalizeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

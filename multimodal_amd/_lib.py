@@ -42,6 +42,9 @@ PROTOTYPES = {
     "mmamd_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "mmamd_colsum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_gemm_bf16_dual": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmamd_bicubic_pos_embed": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _f, _vp]),
+    "mmamd_mask_labels": (_i, [_vp, _vp, _i64, _i64, _vp]),
+    "mmamd_relu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mmamd_transpose_to_bf16": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),

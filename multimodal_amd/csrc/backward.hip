@@ -209,6 +209,11 @@ __device__ __forceinline__ float act_grad(float u, int act) {
   const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));  // d/du [u Phi(u)] = Phi + u phi
   return cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u);
 }
+// dz = dy where the ReLU output y is positive (classifier MLP of FLAVAForClassification, fp32)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dz, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dz[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
 __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ u, bf16* __restrict__ g, int64_t n4, int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const f32x4 v = load4(u + 4 * i);
@@ -406,4 +411,11 @@ extern "C" int mmamd_scatter_add_rows(const float* src, const int64_t* idx, int 
   if (n == 0) return 0;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, n, d, dst, dst_rows);
   return launch_status("scatter_add_rows");
+}
+
+extern "C" int mmamd_relu_bwd(const float* y, const float* dy, float* dz, int64_t n, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(y && dy && dz && n >= 0, MMAMD_E_BADARG, "relu_bwd: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dz, (long long)n);
+  return launch_status("relu_bwd");
 }

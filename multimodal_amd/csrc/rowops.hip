@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void rows_linear_f32_kernel(const float* __res
       if (i < B) {
         float v = acc[r] + bj;
         if (act == 1) v = tanhf(v);
+        else if (act == 2) v = fmaxf(v, 0.f);
         out[(size_t)i * E + j] = v;
       }
     }
@@ -533,6 +534,60 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void convert_kernel(const TI* __restrict__ s, TO* __restrict__ d, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     d[i] = (TO)to_f32(s[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FLAVA position-embedding interpolation (models/flava/image_encoder.py:102-137): the [n_side x n_side] grid of patch position
+// embeddings resampled to [h0 x w0] with F.interpolate(mode="bicubic", align_corners=False, scale_factor=(sh, sw)); row 0 (CLS) is
+// copied.  The resampling itself is PyTorch's upsample_bicubic2d (aten/src/ATen/native/UpSampleBicubic2d.cpp, torch 2.10 — not part
+// of the reference tree): source coordinate (o + 0.5) / scale - 0.5, cubic-convolution weights with A = -0.75, taps clamped to the
+// grid, x pass then y pass in fp32.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_weights(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+__global__ __launch_bounds__(256) void bicubic_pos_embed_kernel(const float* __restrict__ pos, int n_side, int d, float* __restrict__ out,
+                                                                int h0, int w0, float inv_sh, float inv_sw) {
+  const int row = blockIdx.x;  // output row: 0 = CLS, 1 + oy*w0 + ox
+  if (row == 0) {
+    for (int c = threadIdx.x; c < d; c += 256) out[c] = pos[c];
+    return;
+  }
+  const int oy = (row - 1) / w0, ox = (row - 1) - oy * w0;
+  const float ry = (oy + 0.5f) * inv_sh - 0.5f, rx = (ox + 0.5f) * inv_sw - 0.5f;
+  const float fy = floorf(ry), fx = floorf(rx);
+  const int iy = (int)fy, ix = (int)fx;
+  float wy[4], wx[4];
+  cubic_weights(ry - fy, wy);
+  cubic_weights(rx - fx, wx);
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int y = iy - 1 + i;
+      y = y < 0 ? 0 : (y > n_side - 1 ? n_side - 1 : y);
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int x = ix - 1 + j;
+        x = x < 0 ? 0 : (x > n_side - 1 ? n_side - 1 : x);
+        acc += pos[(size_t)(1 + y * n_side + x) * d + c] * wx[j];
+      }
+      col[i] = acc;
+    }
+    out[(size_t)row * d + c] = col[0] * wy[0] + col[1] * wy[1] + col[2] * wy[2] + col[3] * wy[3];
+  }
+}
+
+// labels[i] = keep[i] ? labels[i] : fill   (FLAVAForPreTraining: image_labels[~image_patches_mask] = -1, models/flava/model.py:340-343)
+__global__ __launch_bounds__(256) void mask_labels_kernel(long long* __restrict__ labels, const uint8_t* __restrict__ keep, long long fill, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && keep[i] == 0) labels[i] = fill;
 }
 
 }  // namespace mmamd
@@ -697,7 +752,7 @@ extern "C" int mmamd_flava_image_embed(const float* patch_emb, const float* cls,
 
 extern "C" int mmamd_rows_linear_f32(const float* h, int64_t ldh, const float* W, const float* bias, int act, float* out, int B,
                                      int d, int E, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(h && W && out && B >= 0 && d > 0 && E > 0 && ldh >= d && (act == 0 || act == 1), MMAMD_E_BADARG, "rows_linear_f32: bad argument");
+  MMAMD_CHECK_ARG(h && W && out && B >= 0 && d > 0 && E > 0 && ldh >= d && act >= 0 && act <= 2, MMAMD_E_BADARG, "rows_linear_f32: bad argument");
   if (B == 0) return 0;
   hipLaunchKernelGGL(rows_linear_f32_kernel, dim3((E + 127) / 128, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream, h, (size_t)ldh,
                      W, bias, act, out, B, d, E);
@@ -727,4 +782,20 @@ extern "C" int mmamd_coca_text_mask(const void* src, int kind, int64_t pad_id, u
   const long long n = (long long)B * (S + 1) * (S + 1);
   hipLaunchKernelGGL(coca_text_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, kind, (long long)pad_id, out, B, S);
   return launch_status("coca_text_mask");
+}
+
+extern "C" int mmamd_bicubic_pos_embed(const float* pos, int n_side, int d, float* out, int h0, int w0, float scale_h, float scale_w,
+                                       mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(pos && out && n_side > 0 && d > 0 && h0 > 0 && w0 > 0 && scale_h > 0.f && scale_w > 0.f, MMAMD_E_BADARG, "bicubic_pos_embed: bad argument");
+  hipLaunchKernelGGL(bicubic_pos_embed_kernel, dim3(1 + h0 * w0), dim3(256), 0, (hipStream_t)stream, pos, n_side, d, out, h0, w0, 1.0f / scale_h,
+                     1.0f / scale_w);
+  return launch_status("bicubic_pos_embed");
+}
+
+extern "C" int mmamd_mask_labels(int64_t* labels, const uint8_t* keep, int64_t fill, int64_t n, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(labels && keep && n >= 0, MMAMD_E_BADARG, "mask_labels: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(mask_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long*)labels, keep,
+                     (long long)fill, (long long)n);
+  return launch_status("mask_labels");
 }

@@ -7,6 +7,7 @@ with the conv bias in the epilogue; mask-token blending, the CLS row and the pos
 """
 from __future__ import annotations
 
+import math
 import warnings
 from functools import partial
 from typing import Any, Callable, Optional, Tuple
@@ -42,11 +43,13 @@ class PatchEmbeddings(nn.Module):
 
     def forward(self, pixel_values: Tensor, interpolate_pos_encoding: bool = False) -> Tensor:
         _, _, height, width = pixel_values.shape
-        if interpolate_pos_encoding:
-            raise ops.MmamdError("interpolate_pos_encoding is not implemented on the MI355X path")
-        if height != self.image_size[0] or width != self.image_size[1]:
-            raise ValueError(
-                f"Input image size ({height}*{width}) doesn't match model ({self.image_size[0]}*{self.image_size[1]}).")
+        if not interpolate_pos_encoding:
+            if height != self.image_size[0] or width != self.image_size[1]:
+                raise ValueError(
+                    f"Input image size ({height}*{width}) doesn't match model ({self.image_size[0]}*{self.image_size[1]}).")
+        elif height != width or height % self.patch_size[0] != 0 or self.patch_size[0] != self.patch_size[1]:
+            raise ops.MmamdError(f"interpolate_pos_encoding on the MI355X path takes square images whose side is a multiple of the "
+                                 f"patch size (got {height}x{width}, patch {self.patch_size[0]}): the patch gather is written for square grids")
         B, C = pixel_values.shape[:2]
         if C != self.projection.in_channels:
             raise ValueError(f"expected {self.projection.in_channels} channels, got {C}")
@@ -61,7 +64,7 @@ class PatchEmbeddings(nn.Module):
         cols = ops.patchify(px, P, kpad)
         bias = self._packed.get(self.projection.bias, torch.float32) if self.projection.bias is not None else None
         x = ops.gemm_bf16(cols, wk, bias, out_dtype=torch.float32)
-        return x.view(B, self.num_patches, -1)
+        return x.view(B, (height // P) * (width // P), -1)
 
 
 class ImageEmbeddings(nn.Module):
@@ -81,6 +84,21 @@ class ImageEmbeddings(nn.Module):
         else:
             self.mask_token = None
         self._packed = PackedCache()
+
+    def interpolate_pos_encoding(self, embeddings: Tensor, height: int, width: int) -> Tensor:
+        """Position table for a different resolution (reference :102-137): `embeddings` is the [B, 1 + npatch, d] sequence (CLS
+        included) and only supplies npatch.  Returns [1, 1 + npatch, d]; the trained table itself when nothing changes."""
+        return self._interp_table(embeddings.shape[1] - 1, height, width)
+
+    def _interp_table(self, npatch: int, height: int, width: int) -> Tensor:
+        n = self.position_embeddings.shape[1] - 1
+        if npatch == n and height == width:
+            return self.position_embeddings
+        h0 = height // self.patch_embeddings.patch_size[0] + 0.1  # reference :118-121: +0.1 against floor() of the scaled size
+        w0 = width // self.patch_embeddings.patch_size[1] + 0.1
+        table = self._packed.get(self.position_embeddings, torch.float32).view(n + 1, -1)
+        out = ops.bicubic_pos_embed(table, int(h0), int(w0), h0 / math.sqrt(n), w0 / math.sqrt(n))  # mmamd_bicubic_pos_embed
+        return out.view(1, out.shape[0], out.shape[1])
 
     def forward(self, pixel_values: Tensor, image_patches_mask: Optional[Tensor] = None,
                 interpolate_pos_encoding: bool = False) -> Tensor:
@@ -114,8 +132,10 @@ class ImageEmbeddings(nn.Module):
                 mask, mask_token = m.contiguous(), pk(self.mask_token, f32)
             else:
                 warnings.warn("image_patches_mask passed but use_image_masking in init was false. Ignoring.")
-        x = ops.flava_image_embed(pe.view(B * G2, -1), pk(self.cls_token, f32), pk(self.position_embeddings, f32), B, G2,
-                                  mask, mask_token)
+        pos = pk(self.position_embeddings, f32)
+        if interpolate_pos_encoding:
+            pos = self._interp_table(G2, pixel_values.shape[2], pixel_values.shape[3]).contiguous()
+        x = ops.flava_image_embed(pe.view(B * G2, -1), pk(self.cls_token, f32), pos, B, G2, mask, mask_token)
         return x.view(B, G2 + 1, -1)
 
 

@@ -48,6 +48,10 @@ FLAVAOutput.__annotations__ = {
 }
 
 CKPT_KEY = "flava_full"
+FLAVA_FOR_PRETRAINED_MAPPING = {
+    # reference model.py:75-78
+    "flava_full": "https://download.pytorch.org/models/multimodal/flava/flava_for_pretraining_unified_text_encoder.pt",
+}
 FLAVA_MODEL_MAPPING = {
     CKPT_KEY: "https://download.pytorch.org/models/multimodal/flava/flava_model_unified_text_encoder.pt",
 }
@@ -330,3 +334,143 @@ def flava_model(
     if pretrained:
         load_module_from_url(flava, FLAVA_MODEL_MAPPING[CKPT_KEY])
     return flava
+
+
+FLAVAForClassificationOutput = namedtuple("FLAVAForClassificationOutput", ["logits", "loss"])  # reference model.py:62-66
+FLAVAForClassificationOutput.__annotations__ = {"logits": Tensor, "loss": Tensor}
+
+
+class FLAVAForPreTraining(nn.Module):
+    """Mirror of models/flava/model.py:301-378: model + image codebook + FLAVAPretrainingLoss.  `image_codebook` is any module that
+    maps `image_for_codebook` to integer token ids [B, h, w] (the reference's DalleVAEEncoder, :704-744, is NOT built on the MI355X
+    path: pass your own, or feed pre-computed labels through FLAVAPretrainingLoss directly); the label masking
+    `image_labels[~image_patches_mask] = -1` (:340-343) is mmamd_mask_labels."""
+
+    def __init__(self, model: FLAVAModel, image_codebook: Optional[nn.Module], loss: nn.Module) -> None:
+        super().__init__()
+        self.model = model
+        self.image_codebook = image_codebook
+        self.loss = loss
+
+    def encode_image(self, image: Tensor, cls_index: int = 0) -> Tensor:
+        return self.model.encode_image(image, projection=True)[1]
+
+    def encode_text(self, text: Tensor, text_mask: Optional[Tensor] = None, cls_index: int = 0) -> Tensor:
+        return self.model.encode_text(text, text_mask, projection=True)[1]
+
+    def forward(
+        self,
+        image: Optional[Tensor] = None,
+        text: Optional[Tensor] = None,
+        image_for_codebook: Optional[Tensor] = None,
+        image_patches_mask: Optional[Tensor] = None,
+        text_masked: Optional[Tensor] = None,
+        required_embedding: Optional[EMBEDDING_OPTIONS] = None,
+        skip_unmasked_mm_encoder: bool = True,
+        itm_labels: Optional[Tensor] = None,
+        mlm_labels: Optional[Tensor] = None,
+    ):
+        image_labels = None
+        if image_for_codebook is not None:
+            if self.image_codebook is None:
+                raise ops.MmamdError("FLAVAForPreTraining: image_for_codebook given but no image_codebook module (the DALL-E dVAE encoder "
+                                     "is not built on the MI355X path)")
+            with torch.no_grad():
+                ids = self.image_codebook(image_for_codebook)
+            image_labels = ids.flatten(1).to(torch.int64).contiguous().clone()
+            image_patches_mask = image_patches_mask.flatten(1)
+            keep = image_patches_mask if image_patches_mask.dtype == torch.uint8 else image_patches_mask.to(torch.uint8)  # flag cast only
+            ops.mask_labels_(image_labels, keep.contiguous(), -1)
+            image_patches_mask = image_patches_mask.to(torch.bool)
+        out = self.model(image=image, text=text, image_patches_mask=image_patches_mask, text_masked=text_masked,
+                         required_embedding=required_embedding, skip_unmasked_mm_encoder=skip_unmasked_mm_encoder)
+        return self.loss(
+            image_sequence=out.image.last_hidden_state,
+            text_sequence=out.text.last_hidden_state,
+            image_masked_sequence=out.image_masked.last_hidden_state,
+            text_masked_sequence=out.text_masked.last_hidden_state,
+            multimodal_sequence=(out.multimodal.last_hidden_state if not skip_unmasked_mm_encoder else None),
+            multimodal_masked_sequence=out.multimodal_masked.last_hidden_state,
+            itm_labels=itm_labels,
+            mim_labels=image_labels,
+            mlm_labels=mlm_labels,
+            projected_image_embeddings=out.projected_image_embeddings,
+            projected_text_embeddings=out.projected_text_embeddings,
+        )
+
+
+class FLAVAForClassification(nn.Module):
+    """Mirror of models/flava/model.py:380-422.  The classifier (modules.layers.mlp.MLP with nn.ReLU) runs on the CLS row in exact
+    fp32 (mmamd_rows_linear_f32); an nn.CrossEntropyLoss `loss` is the cross-entropy kernel, any other callable is called as is."""
+
+    def __init__(self, model: FLAVAModel, classifier: nn.Module, loss: Union[nn.Module, Callable[[Tensor, Tensor], Tensor]], **kwargs: Any) -> None:
+        super().__init__()
+        self.model = model
+        self.classifier = classifier
+        self.loss = loss
+
+    def forward(self, image: Optional[Tensor] = None, text: Optional[Tensor] = None, required_embedding: Optional[EMBEDDING_OPTIONS] = None,
+                labels: Optional[Tensor] = None, cls_index: int = 0) -> FLAVAForClassificationOutput:
+        out = self.model(image=image, text=text, required_embedding=required_embedding, skip_unmasked_mm_encoder=False)
+        if required_embedding == "image":
+            hidden_state = out.image.last_hidden_state
+        elif required_embedding == "text":
+            hidden_state = out.text.last_hidden_state
+        else:
+            hidden_state = out.multimodal.last_hidden_state
+        scores = self.classifier(hidden_state[:, cls_index])
+        return FLAVAForClassificationOutput(logits=scores, loss=self._loss(scores, labels))
+
+    def _loss(self, scores: Tensor, labels: Tensor) -> Tensor:
+        if not isinstance(self.loss, nn.CrossEntropyLoss):
+            return self.loss(scores, labels)
+        ce = self.loss
+        if ce.weight is not None or ce.reduction != "mean" or ce.label_smoothing != 0.0:
+            raise ops.MmamdError("FLAVAForClassification on the MI355X path: nn.CrossEntropyLoss with class weights, a reduction other "
+                                 "than 'mean' or label smoothing is not implemented")
+        if labels.dtype != torch.int64:
+            raise ops.MmamdError("FLAVAForClassification: class-index labels (int64) expected")
+        lab = labels.contiguous()
+        if torch.is_grad_enabled() and scores.requires_grad:
+            from ..._autograd import CrossEntropyFn
+
+            return CrossEntropyFn.apply(scores, lab, int(ce.ignore_index))
+        sc = scores if scores.is_contiguous() else scores.contiguous()
+        return ops.cross_entropy(sc, lab, int(ce.ignore_index))
+
+
+def flava_model_for_pretraining(codebook_image_size: int = 112, pretrained: bool = False, image_codebook: Optional[nn.Module] = None,
+                                **flava_model_kwargs: Any) -> FLAVAForPreTraining:
+    """models/flava/model.py:524-544 without the DALL-E codebook (pass `image_codebook` to supply one)."""
+    from ...modules.losses.flava import FLAVAPretrainingLoss
+
+    if pretrained:
+        raise RuntimeError("pretrained FLAVA checkpoints need network access (reference downloads them); load a state_dict instead")
+    model = flava_model(**flava_model_kwargs)
+    hidden_size = flava_model_kwargs.get("multimodal_hidden_size", 768)
+    return FLAVAForPreTraining(model=model, image_codebook=image_codebook, loss=FLAVAPretrainingLoss(hidden_size=hidden_size))
+
+
+def flava_model_for_classification(
+    num_classes: int,
+    classifier_in_dim: int = 768,
+    classifier_hidden_sizes: Union[int, List[int]] = 768,
+    classifier_dropout: float = 0.5,
+    classifier_activation: Callable[..., nn.Module] = nn.ReLU,
+    classifier_normalization: Optional[Callable[..., nn.Module]] = None,
+    loss_fn: Optional[Callable[..., Tensor]] = None,
+    pretrained: bool = True,
+    **flava_model_kwargs: Any,
+) -> FLAVAForClassification:
+    """models/flava/model.py:547-580 (same defaults; pretrained=True needs the network like the reference's and raises offline)."""
+    from ...modules.layers.mlp import MLP
+
+    classifier = MLP(in_dim=classifier_in_dim, out_dim=num_classes, hidden_dims=classifier_hidden_sizes, dropout=classifier_dropout,
+                     activation=classifier_activation, normalization=classifier_normalization)
+    model = flava_model(**flava_model_kwargs)
+    if loss_fn is None:
+        loss_fn = nn.CrossEntropyLoss()
+    classification_model = FLAVAForClassification(model=model, classifier=classifier, loss=loss_fn)
+    if pretrained:
+        load_module_from_url(classification_model, FLAVA_FOR_PRETRAINED_MAPPING[CKPT_KEY], strict=False)
+    return classification_model

@@ -16,12 +16,17 @@ from ..._packing import PackedCache
 from .activation import SiLU
 
 
+ACT_RELU_EXACT = -1  # plan() code of nn.ReLU: no GEMM epilogue has it; MLPs that use it (classifier heads) run the exact-fp32 row path
+
+
 def fused_activation_code(mod: nn.Module) -> Optional[int]:
     """GEMM epilogue code of an activation module, None if the kernels do not have it."""
     if isinstance(mod, nn.GELU) and getattr(mod, "approximate", "none") == "none":
         return ops.ACT_GELU_ERF
     if isinstance(mod, SiLU):
         return ops.ACT_QUICKGELU
+    if isinstance(mod, nn.ReLU):
+        return ACT_RELU_EXACT
     return None
 
 
@@ -67,8 +72,8 @@ class MLP(nn.Module):
             if i < len(mods) and not isinstance(mods[i], (nn.Linear, nn.Dropout)):
                 code = fused_activation_code(mods[i])
                 if code is None:
-                    raise ops.MmamdError(f"MLP on the MI355X path: activation {type(mods[i]).__name__} has no fused GEMM "
-                                         "epilogue (nn.GELU and the CLIP SiLU/QuickGELU do)")
+                    raise ops.MmamdError(f"MLP on the MI355X path: activation {type(mods[i]).__name__} has no kernel "
+                                         "(nn.GELU and the CLIP SiLU/QuickGELU are GEMM epilogues, nn.ReLU runs on the exact-fp32 row path)")
                 act = code
                 i += 1
             if i < len(mods) and isinstance(mods[i], nn.Dropout):
@@ -81,6 +86,8 @@ class MLP(nn.Module):
     def run(self, h: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """h: bf16 [M, in_dim].  Returns fp32 [M, out_dim] (+ residual, which may alias out)."""
         steps = self.plan()
+        if any(act == ACT_RELU_EXACT for _, act in steps):
+            raise ops.MmamdError("MLP.run: nn.ReLU MLPs take the exact-fp32 row path (call the module, not run())")
         pk = self._packed.get
         for n, (lin, act) in enumerate(steps):
             last = n == len(steps) - 1
@@ -91,8 +98,34 @@ class MLP(nn.Module):
                 h = ops.gemm_bf16(h, pk(lin.weight, torch.bfloat16), b, act=act)
         return h
 
+    # rows up to which an MLP with nn.ReLU (or no) activations runs in exact fp32 (mmamd_rows_linear_f32): classifier heads see one
+    # row per sample
+    EXACT_ROWS_MAX = 8192
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        steps = self.plan()
         xc = x if x.is_contiguous() else x.contiguous()
-        h = ops.convert(xc.view(-1, xc.shape[-1]), torch.bfloat16)
+        rows = xc.view(-1, xc.shape[-1])
+        if all(act in (ops.ACT_NONE, ACT_RELU_EXACT) for _, act in steps) and any(act == ACT_RELU_EXACT for _, act in steps):
+            if rows.shape[0] > self.EXACT_ROWS_MAX:
+                raise ops.MmamdError(f"MLP with nn.ReLU on the MI355X path is the exact-fp32 classifier-head form (<= {self.EXACT_ROWS_MAX} "
+                                     f"rows, got {rows.shape[0]}); token-level MLPs use nn.GELU / SiLU (fused GEMM epilogues)")
+            if rows.dtype != torch.float32:
+                raise ops.MmamdError("MLP (exact-fp32 row path) takes fp32 activations")
+            from ..._autograd import SmallLinearF32Fn, wants_grad
+
+            h = rows
+            if wants_grad(self) or (torch.is_grad_enabled() and x.requires_grad):
+                for lin, act in steps:
+                    h = SmallLinearF32Fn.apply(h, lin.weight, lin.bias, act == ACT_RELU_EXACT)
+            else:
+                pk = self._packed.get
+                for lin, act in steps:
+                    b = pk(lin.bias, torch.float32) if lin.bias is not None else None
+                    h = ops.rows_linear_f32(h, h.shape[1], h.shape[0], pk(lin.weight, torch.float32), b, relu=(act == ACT_RELU_EXACT))
+            return h.view(*x.shape[:-1], h.shape[-1])
+        if any(act == ACT_RELU_EXACT for _, act in steps):
+            raise ops.MmamdError("MLP on the MI355X path: nn.ReLU cannot be mixed with the GEMM-epilogue activations in one MLP")
+        h = ops.convert(rows, torch.bfloat16)
         y = self.run(h)
         return y.view(*x.shape[:-1], y.shape[-1])

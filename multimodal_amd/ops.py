@@ -21,7 +21,7 @@ __all__ = [
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
-    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "mask_labels_", "relu_bwd",
     "attention_x_bwd",
 ]
 
@@ -388,7 +388,7 @@ def flava_image_embed(patch_emb: torch.Tensor, cls: Optional[torch.Tensor], pos:
 
 
 def rows_linear_f32(h: torch.Tensor, row_stride: int, B: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                    tanh: bool = False) -> torch.Tensor:
+                    tanh: bool = False, relu: bool = False) -> torch.Tensor:
     """act(rows @ weight.T + bias) in exact fp32: row i starts at h.data_ptr() + i*row_stride floats (e.g. every
     sample's CLS row of a [B,S,d] tensor: row_stride = S*d)."""
     _chk(h, "h", torch.float32); _chk(weight, "weight", torch.float32)
@@ -398,9 +398,41 @@ def rows_linear_f32(h: torch.Tensor, row_stride: int, B: int, weight: torch.Tens
     if B > 0 and (B - 1) * row_stride + d > h.numel():
         raise MmamdError("rows_linear_f32: rows run past the end of h")
     out = torch.empty((B, E), dtype=torch.float32, device=h.device)
-    check(_lib.lib().mmamd_rows_linear_f32(h.data_ptr(), int(row_stride), weight.data_ptr(), _ptr(bias), int(bool(tanh)),
+    check(_lib.lib().mmamd_rows_linear_f32(h.data_ptr(), int(row_stride), weight.data_ptr(), _ptr(bias), 2 if relu else int(bool(tanh)),
                                            out.data_ptr(), B, d, E, _stream()), "mmamd_rows_linear_f32")
     return out
+
+
+def bicubic_pos_embed(pos: torch.Tensor, h0: int, w0: int, scale_h: float, scale_w: float) -> torch.Tensor:
+    """pos fp32 [1 + n*n, d] (CLS row + square patch grid) -> [1 + h0*w0, d], the grid resampled bicubically (align_corners=False,
+    explicit scale factors) like FLAVA's interpolate_pos_encoding."""
+    _chk(pos, "position_embeddings", torch.float32)
+    if pos.dim() != 2:
+        raise MmamdError("bicubic_pos_embed: expected [1 + n*n, d]")
+    n_side = int(round(math.sqrt(pos.shape[0] - 1)))
+    if n_side * n_side != pos.shape[0] - 1:
+        raise MmamdError(f"bicubic_pos_embed: {pos.shape[0] - 1} patch positions are not a square grid")
+    d = pos.shape[1]
+    out = torch.empty((1 + h0 * w0, d), dtype=torch.float32, device=pos.device)
+    check(_lib.lib().mmamd_bicubic_pos_embed(pos.data_ptr(), n_side, d, out.data_ptr(), int(h0), int(w0), float(scale_h), float(scale_w),
+                                             _stream()), "mmamd_bicubic_pos_embed")
+    return out
+
+
+def mask_labels_(labels: torch.Tensor, keep: torch.Tensor, fill: int = -1) -> torch.Tensor:
+    """In place: labels[i] = fill wherever keep[i] == 0 (labels int64, keep uint8, same number of elements)."""
+    _chk(labels, "labels", torch.int64); _chk(keep, "keep", torch.uint8)
+    if labels.numel() != keep.numel():
+        raise MmamdError("mask_labels: labels and keep differ in size")
+    check(_lib.lib().mmamd_mask_labels(labels.data_ptr(), keep.data_ptr(), int(fill), labels.numel(), _stream()), "mmamd_mask_labels")
+    return labels
+
+
+def relu_bwd(y: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _chk(y, "y", torch.float32); _chk(dy, "dy", torch.float32)
+    dz = torch.empty_like(y)
+    check(_lib.lib().mmamd_relu_bwd(y.data_ptr(), dy.data_ptr(), dz.data_ptr(), y.numel(), _stream()), "mmamd_relu_bwd")
+    return dz
 
 
 def select_tokens(labels: torch.Tensor, ignore_index: int, seq_S: int, tok_offset: int,

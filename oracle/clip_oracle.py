@@ -327,8 +327,69 @@ def flava_pooler(hidden: Array, sd, prefix: str) -> Array:
     return np.tanh(hidden[:, 0] @ sd[prefix + "dense.weight"].T + sd[prefix + "dense.bias"])
 
 
+def _cubic_weights(t: float):
+    """Cubic-convolution weights, A = -0.75 (torch aten/src/ATen/native/UpSample.h get_cubic_upsample_coefficients)."""
+    A = -0.75
+    c1 = lambda x: ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0          # |x| <= 1
+    c2 = lambda x: ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A    # 1 < |x| < 2
+    return np.array([c2(t + 1.0), c1(t), c1(1.0 - t), c2(2.0 - t)])
+
+
+def bicubic_resize_grid(grid: Array, h0: int, w0: int, scale_h: float, scale_w: float) -> Array:
+    """F.interpolate(grid[None].permute(0,3,1,2), scale_factor=(scale_h, scale_w), mode="bicubic", align_corners=False) for a
+    [n, n, d] grid -> [h0, w0, d].  The algorithm is PyTorch's upsample_bicubic2d (third-party dependency of the reference, torch
+    2.10, aten/src/ATen/native/UpSampleBicubic2d.cpp — not in /root/reference): source coordinate (o + 0.5)/scale - 0.5, taps at
+    floor - 1 .. floor + 2 clamped to the grid, x pass then y pass.  Pinned by tests/golden/flava_cls_interp.npz (reference output)."""
+    g = np.asarray(grid)
+    n_y, n_x, d = g.shape
+    out = np.zeros((h0, w0, d), dtype=g.dtype)
+    for oy in range(h0):
+        ry = (oy + 0.5) / scale_h - 0.5
+        iy = int(np.floor(ry))
+        wy = _cubic_weights(ry - iy)
+        ys = np.clip(np.arange(iy - 1, iy + 3), 0, n_y - 1)
+        for ox in range(w0):
+            rx = (ox + 0.5) / scale_w - 0.5
+            ix = int(np.floor(rx))
+            wx = _cubic_weights(rx - ix)
+            xs = np.clip(np.arange(ix - 1, ix + 3), 0, n_x - 1)
+            patch = g[np.ix_(ys, xs)]                                   # [4, 4, d]
+            out[oy, ox] = np.einsum("i,ijd,j->d", wy, patch, wx)
+    return out
+
+
+def flava_interpolate_pos_encoding(pos: Array, npatch: int, height: int, width: int, patch: int) -> Array:
+    """ImageEmbeddings.interpolate_pos_encoding (models/flava/image_encoder.py:102-137).  pos [1, 1+n, d]."""
+    n = pos.shape[1] - 1
+    if npatch == n and height == width:
+        return pos
+    dim = pos.shape[-1]
+    side = int(np.sqrt(n))
+    h0, w0 = height // patch + 0.1, width // patch + 0.1
+    grid = bicubic_resize_grid(pos[0, 1:].reshape(side, side, dim), int(h0), int(w0), h0 / np.sqrt(n), w0 / np.sqrt(n))
+    return np.concatenate([pos[:, :1], grid.reshape(1, -1, dim)], axis=1)
+
+
+def mlp_forward(x: Array, sd, prefix: str, n_linear: int, stride: int = 2) -> Array:
+    """modules/layers/mlp.py:13-66 in eval mode with nn.ReLU between the Linears (FLAVAForClassification's classifier; Sequential
+    indices advance by `stride` = 3 when a Dropout follows each activation, as in the default classifier)."""
+    for i in range(n_linear):
+        k = prefix + f"model.{i * stride}."
+        x = x @ sd[k + "weight"].T + sd[k + "bias"]
+        if i + 1 < n_linear:
+            x = np.maximum(x, 0)
+    return x
+
+
+def flava_classification(sd, hidden_state: Array, labels: Array, n_linear: int, stride: int = 3, cls_index: int = 0):
+    """FLAVAForClassification.forward after the encoder (models/flava/model.py:411-418): scores = classifier(h[:, cls_index]),
+    loss = CrossEntropyLoss()(scores, labels)."""
+    scores = mlp_forward(hidden_state[:, cls_index], sd, "classifier.", n_linear, stride)
+    return scores, cross_entropy(scores, labels)
+
+
 def flava_image_encoder(sd, prefix: str, pixel_values: Array, heads: int, image_patches_mask: Optional[Array] = None,
-                        eps: float = 1e-12, dtype=np.float32):
+                        eps: float = 1e-12, dtype=np.float32, interpolate_pos_encoding: bool = False):
     """ImageTransformer.forward (models/flava/image_encoder.py:204-234) incl. ImageEmbeddings (:139-177)."""
     sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
     x = np.asarray(pixel_values).astype(dtype)
@@ -339,7 +400,10 @@ def flava_image_encoder(sd, prefix: str, pixel_values: Array, heads: int, image_
         m = np.asarray(image_patches_mask).astype(dtype)[..., None]
         emb = emb * (1 - m) + sd[prefix + "embeddings.mask_token"].reshape(1, 1, -1) * m
     cls = np.broadcast_to(sd[prefix + "embeddings.cls_token"].reshape(1, 1, -1), (B, 1, emb.shape[2]))
-    emb = np.concatenate([cls, emb], axis=1) + sd[prefix + "embeddings.position_embeddings"].reshape(1, -1, emb.shape[2])
+    pos = sd[prefix + "embeddings.position_embeddings"].reshape(1, -1, emb.shape[2])
+    if interpolate_pos_encoding:  # :170-173
+        pos = flava_interpolate_pos_encoding(pos, emb.shape[1], x.shape[2], x.shape[3], w.shape[2]).astype(dtype)
+    emb = np.concatenate([cls, emb], axis=1) + pos
     last, hidden, attns = flava_transformer_encoder(emb, sd, prefix + "encoder.", heads, eps)
     seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps)
     return {"last_hidden_state": seq, "pooler_output": flava_pooler(seq, sd, prefix + "pooler."), "hidden_states": hidden,

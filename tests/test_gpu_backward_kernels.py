@@ -530,3 +530,25 @@ def test_weight_gradient_gemm_from_row_major_operands():
         assert np.abs(got - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max()), (T, M, N)
     with pytest.raises(ops.MmamdError):
         ops.gemm_bf16_tn_splitk(y[:64], x[:64])  # token count must be a multiple of 128
+
+
+def test_small_fp32_linear_with_relu_backward():
+    """Classifier-head Linear(+ReLU) in exact fp32 (mmamd_rows_linear_f32 / mmamd_relu_bwd / strided fp32 GEMMs) vs float64 autograd."""
+    from multimodal_amd._autograd import SmallLinearF32Fn
+
+    set_rng_seed(17)
+    x = torch.randn(9, 40)
+    w, b = torch.randn(24, 40) * 0.3, torch.randn(24)
+    dy = torch.randn(9, 24)
+    for relu in (False, True):
+        xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+        yd = xd @ wd.t() + bd
+        if relu:
+            yd = torch.relu(yd)
+        yd.backward(dy.double())
+        xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+        y = SmallLinearF32Fn.apply(xg, wg, bg, relu)
+        y.backward(dy.cuda())
+        assert np.abs(host(y) - yd.detach().numpy()).max() <= 1e-5
+        for got, ref in ((xg.grad, xd.grad), (wg.grad, wd.grad), (bg.grad, bd.grad)):
+            assert np.abs(host(got) - ref.numpy()).max() <= 1e-5 * max(1.0, float(ref.abs().max())), relu
