@@ -99,8 +99,14 @@ def test_flava_fails_loudly_without_a_gpu_or_an_implementation():
         FLAVAGlobalContrastiveLoss()(torch.randn(2, 8), torch.randn(2, 8), torch.ones(2, dtype=torch.bool))
     with pytest.raises(ops.MmamdError, match="head_mask"):
         TransformerEncoder(1, 128, 2, 256).eval()(torch.randn(1, 4, 128), head_mask=torch.ones(1))
-    with pytest.raises(ops.MmamdError, match="activation ReLU"):
-        MLP(128, 128, 256, dropout=0.0).plan()
+    # nn.ReLU MLPs (classifier heads) plan onto the exact-fp32 row path; activations without any kernel still raise
+    from multimodal_amd.modules.layers.mlp import ACT_RELU_EXACT
+
+    assert [a for _, a in MLP(128, 128, 256, dropout=0.0).plan()] == [ACT_RELU_EXACT, ops.ACT_NONE]
+    with pytest.raises(ops.MmamdError, match="activation Tanh"):
+        MLP(128, 128, 256, dropout=0.0, activation=nn.Tanh).plan()
+    with pytest.raises(ops.MmamdError, match="no CPU|HIP device"):
+        MLP(128, 128, 256, dropout=0.0).eval()(torch.randn(2, 128))
     assert [a for _, a in MLP(128, 128, [256, 256], dropout=0.0, activation=nn.GELU).plan()] == [ops.ACT_GELU_ERF, ops.ACT_GELU_ERF, ops.ACT_NONE]
     with pytest.raises(ValueError, match="multiple of the number of attention heads"):
         MultiHeadAttention(130, 130, 4)
