@@ -190,6 +190,30 @@ int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64
 int mmamd_flava_image_embed(const float* patch_emb, const float* cls, const float* pos, const int64_t* patches_mask,
                             const float* mask_token, float* x, int B, int G2, int d, mmamd_stream_t stream);
 
+/* --- FLAVA image codebook: the DALL-E dVAE encoder (models/flava/model.py:583-744) -------------------------------------------
+ * Activations are bf16 rows [B*(H+2)*(W+2), C]: NHWC with a one-pixel ZERO border per image (= the convolutions' padding) and at
+ * least W+3 readable zero rows in front of and behind the buffer.  mmamd_conv_gemm_bf16 is one convolution as an implicit GEMM:
+ *   out[m, n] = bias[n] + sum_t sum_c A[m + tap_row_offsets[t], c] * W[n, t*Cin + c]  (+ residual[m, n], bf16)
+ * (3x3: the 9 offsets dy*(W+2)+dx; 1x1: the single offset 0; replaces nn.functional.conv2d in DalleConv2d.forward :597-598 and the
+ * `id_path(x) + post_gain * res_path(x)` of DalleEncoderBlock.forward :624-625 with post_gain folded into W / bias).  Rows on the
+ * border of the grid_h x grid_w image grid are stored as zeros (grid_h = grid_w = 0: no masking).  Outputs: C (bf16 [M, ldc], or
+ * fp32 when out_dtype = MMAMD_F32), optionally with ReLU applied (relu_c), and optionally C_relu = relu(C) (bf16): the nn.ReLU in
+ * front of the next convolution.  Cin % 64 == 0, N % 8 == 0, 1 <= ntaps <= 9. */
+int mmamd_conv_gemm_bf16(const void* A, int lda, const int64_t* tap_row_offsets, int ntaps, const void* W, int ldw, const float* bias,
+                         const void* residual, int ldr, void* C, int ldc, int out_dtype, void* C_relu, int ldc_relu, int relu_c, int M,
+                         int N, int Cin, int grid_h, int grid_w, mmamd_stream_t stream);
+/* 7x7 stem: cols[(b, y, x) over the padded grid][(c, ky, kx) padded to kpad] (bf16) from fp32 NCHW images — the stem is then a one-tap
+ * mmamd_conv_gemm_bf16 on cols with the weight in its own [n_out][n_in*kw*kw] order. */
+int mmamd_dalle_stem_im2col(const float* images, void* cols, int B, int C, int H, int W, int kw, int kpad, mmamd_stream_t stream);
+/* nn.MaxPool2d(2) (:677) on a padded-grid tensor: [B,H+2,W+2,C] -> y [B,H/2+2,W/2+2,C] (zero border) and/or y_relu = relu(y). */
+int mmamd_dalle_maxpool2(const void* x, void* y, void* y_relu, int B, int H, int W, int C, mmamd_stream_t stream);
+/* torch.argmax(z_logits, axis=1) (:733-735): ids[b, y, x] (int64) from fp32 padded-grid logits [B,H+2,W+2,V]; first maximum wins. */
+int mmamd_dalle_argmax(const float* logits, int64_t* ids, int B, int H, int W, int V, mmamd_stream_t stream);
+/* kernel-ready copy of a DalleConv2d parameter (w [n_out, n_in, kw, kw] fp32, taps = kw*kw; a bias is n_in = taps = 1): dst[o*ld_dst +
+ * idx] = gain * w[o][c][t], idx = t*n_in + c (tap_major) or c*taps + t; the tail of each row is zero. */
+int mmamd_dalle_pack(const float* src, void* dst, int dst_dtype, int n_out, int n_in, int taps, int ld_dst, float gain, int tap_major,
+                     mmamd_stream_t stream);
+
 /* FLAVA position-embedding interpolation (models/flava/image_encoder.py:102-137, interpolate_pos_encoding): pos [1 + n_side^2, d]
  * fp32 -> out [1 + h0*w0, d]: row 0 copied, the patch grid resampled like F.interpolate(mode="bicubic", align_corners=False,
  * scale_factor=(scale_h, scale_w)) (torch's upsample_bicubic2d: A = -0.75, clamped taps). */

@@ -45,6 +45,11 @@ PROTOTYPES = {
     "mmamd_bicubic_pos_embed": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _f, _vp]),
     "mmamd_mask_labels": (_i, [_vp, _vp, _i64, _i64, _vp]),
     "mmamd_relu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "mmamd_conv_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mmamd_dalle_stem_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mmamd_dalle_maxpool2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mmamd_dalle_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "mmamd_dalle_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mmamd_transpose_to_bf16": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -26,6 +26,7 @@ from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.flava import cls_linear, Pooler
 from ...utils.common import load_module_from_url
 from ..._autograd import wants_grad
+from ._dalle import DalleConv2d, DalleEncoder, DalleEncoderBlock, DalleVAEEncoder  # noqa: F401  (reference :583-744)
 from .image_encoder import flava_image_encoder
 from .text_encoder import flava_text_encoder
 from .transformer import FLAVATransformerWithoutEmbeddings, TransformerEncoder
@@ -342,8 +343,8 @@ FLAVAForClassificationOutput.__annotations__ = {"logits": Tensor, "loss": Tensor
 
 class FLAVAForPreTraining(nn.Module):
     """Mirror of models/flava/model.py:301-378: model + image codebook + FLAVAPretrainingLoss.  `image_codebook` is any module that
-    maps `image_for_codebook` to integer token ids [B, h, w] (the reference's DalleVAEEncoder, :704-744, is NOT built on the MI355X
-    path: pass your own, or feed pre-computed labels through FLAVAPretrainingLoss directly); the label masking
+    maps `image_for_codebook` to integer token ids [B, h, w] (DalleVAEEncoder, ._dalle: the implicit-GEMM pipeline of csrc/conv.hip);
+    the label masking
     `image_labels[~image_patches_mask] = -1` (:340-343) is mmamd_mask_labels."""
 
     def __init__(self, model: FLAVAModel, image_codebook: Optional[nn.Module], loss: nn.Module) -> None:
@@ -373,8 +374,7 @@ class FLAVAForPreTraining(nn.Module):
         image_labels = None
         if image_for_codebook is not None:
             if self.image_codebook is None:
-                raise ops.MmamdError("FLAVAForPreTraining: image_for_codebook given but no image_codebook module (the DALL-E dVAE encoder "
-                                     "is not built on the MI355X path)")
+                raise ops.MmamdError("FLAVAForPreTraining: image_for_codebook given but the module was built without an image_codebook")
             with torch.no_grad():
                 ids = self.image_codebook(image_for_codebook)
             image_labels = ids.flatten(1).to(torch.int64).contiguous().clone()
@@ -441,14 +441,17 @@ class FLAVAForClassification(nn.Module):
 
 def flava_model_for_pretraining(codebook_image_size: int = 112, pretrained: bool = False, image_codebook: Optional[nn.Module] = None,
                                 **flava_model_kwargs: Any) -> FLAVAForPreTraining:
-    """models/flava/model.py:524-544 without the DALL-E codebook (pass `image_codebook` to supply one)."""
+    """models/flava/model.py:524-544.  The codebook is a randomly initialised DalleVAEEncoder (the reference downloads OpenAI's encoder
+    checkpoint in its constructor, which needs the network) unless `image_codebook` supplies one."""
     from ...modules.losses.flava import FLAVAPretrainingLoss
 
     if pretrained:
         raise RuntimeError("pretrained FLAVA checkpoints need network access (reference downloads them); load a state_dict instead")
     model = flava_model(**flava_model_kwargs)
     hidden_size = flava_model_kwargs.get("multimodal_hidden_size", 768)
-    return FLAVAForPreTraining(model=model, image_codebook=image_codebook, loss=FLAVAPretrainingLoss(hidden_size=hidden_size))
+    losses = FLAVAPretrainingLoss(hidden_size=hidden_size)
+    codebook = image_codebook if image_codebook is not None else DalleVAEEncoder(image_size=codebook_image_size, pretrained=False)
+    return FLAVAForPreTraining(model=model, image_codebook=codebook, loss=losses)
 
 
 def flava_model_for_classification(

@@ -6,6 +6,7 @@ that are not on a HIP device raise (there is no CPU path).
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Optional, Tuple
 
@@ -21,7 +22,7 @@ __all__ = [
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
-    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "mask_labels_", "relu_bwd",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack",
     "attention_x_bwd",
 ]
 
@@ -401,6 +402,50 @@ def rows_linear_f32(h: torch.Tensor, row_stride: int, B: int, weight: torch.Tens
     check(_lib.lib().mmamd_rows_linear_f32(h.data_ptr(), int(row_stride), weight.data_ptr(), _ptr(bias), 2 if relu else int(bool(tanh)),
                                            out.data_ptr(), B, d, E, _stream()), "mmamd_rows_linear_f32")
     return out
+
+
+def conv_gemm_bf16(a: torch.Tensor, tap_offsets: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
+                   M: int, N: int, cin: int, grid_h: int, grid_w: int, residual: Optional[torch.Tensor] = None,
+                   out_relu: Optional[torch.Tensor] = None, relu_c: bool = False) -> None:
+    """One convolution of the DALL-E encoder as an implicit GEMM over a padded NHWC grid (see mmamd_conv_gemm_bf16).  `a`, `out`,
+    `out_relu`, `residual` are 2-D [rows, channels] views whose first row is grid position 0 (guard rows live in front of them in the
+    underlying buffers); tap_offsets int64 (host tensor) holds the row offset of every tap."""
+    for n, t in (("a", a), ("w", w)):
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.stride(-1) == 1):
+            raise MmamdError(f"conv_gemm: {n} must be a bf16 HIP tensor with unit inner stride")
+    if out.dtype not in (torch.bfloat16, torch.float32):
+        raise MmamdError("conv_gemm: out must be bf16 or fp32")
+    ntaps = int(tap_offsets.numel())
+    offs = (C.c_int64 * ntaps)(*[int(v) for v in tap_offsets.tolist()])
+    check(_lib.lib().mmamd_conv_gemm_bf16(a.data_ptr(), a.stride(0), C.addressof(offs), ntaps, w.data_ptr(), w.stride(0), _ptr(bias),
+                                          _ptr(residual), residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
+                                          _dt(out), _ptr(out_relu), out_relu.stride(0) if out_relu is not None else 0, int(bool(relu_c)),
+                                          int(M), int(N), int(cin), int(grid_h), int(grid_w), _stream()), "mmamd_conv_gemm_bf16")
+
+
+def dalle_stem_im2col(images: torch.Tensor, kw: int, kpad: int, out: torch.Tensor) -> None:
+    _chk(images, "images", torch.float32)
+    B, Cc, H, W = images.shape
+    check(_lib.lib().mmamd_dalle_stem_im2col(images.data_ptr(), out.data_ptr(), B, Cc, H, W, int(kw), int(kpad), _stream()),
+          "mmamd_dalle_stem_im2col")
+
+
+def dalle_maxpool2(x: torch.Tensor, y: Optional[torch.Tensor], y_relu: Optional[torch.Tensor], B: int, H: int, W: int, Cc: int) -> None:
+    check(_lib.lib().mmamd_dalle_maxpool2(x.data_ptr(), _ptr(y), _ptr(y_relu), B, H, W, Cc, _stream()), "mmamd_dalle_maxpool2")
+
+
+def dalle_argmax(logits: torch.Tensor, B: int, H: int, W: int, V: int) -> torch.Tensor:
+    ids = torch.empty((B, H, W), dtype=torch.int64, device=logits.device)
+    check(_lib.lib().mmamd_dalle_argmax(logits.data_ptr(), ids.data_ptr(), B, H, W, V, _stream()), "mmamd_dalle_argmax")
+    return ids
+
+
+def dalle_pack(src: torch.Tensor, n_out: int, n_in: int, taps: int, ld: int, gain: float, tap_major: bool, dtype: torch.dtype) -> torch.Tensor:
+    _chk(src, "parameter", torch.float32)
+    dst = torch.empty((n_out, ld), dtype=dtype, device=src.device)
+    check(_lib.lib().mmamd_dalle_pack(src.data_ptr(), dst.data_ptr(), _dt(dst), n_out, n_in, taps, ld, float(gain), int(bool(tap_major)), _stream()),
+          "mmamd_dalle_pack")
+    return dst
 
 
 def bicubic_pos_embed(pos: torch.Tensor, h0: int, w0: int, scale_h: float, scale_w: float) -> torch.Tensor:

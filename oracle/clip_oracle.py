@@ -765,3 +765,48 @@ def contrastive_loss_backward(a: Array, b: Array, logit_scale: float, a_all: Opt
     Gb = dlogits(lb, 0.5 * grad_out3[0] + grad_out3[2])
     return {"grad_a": T * (Ga @ b_all), "grad_b": T * (Gb @ a_all), "grad_a_all": T * (Gb.T @ b), "grad_b_all": T * (Ga.T @ a),
             "grad_logit_scale": (Ga * la).sum() + (Gb * lb).sum()}
+
+
+# =====================================================================================================================
+# FLAVA image codebook: DALL-E dVAE encoder (models/flava/model.py:583-744)
+# =====================================================================================================================
+def conv2d_same(x: Array, w: Array, b: Array) -> Array:
+    """nn.functional.conv2d(x, w, b, padding=(kw-1)//2) for NCHW x, odd square kernels, stride 1 (DalleConv2d.forward :597-598)."""
+    kw = w.shape[2]
+    pad = (kw - 1) // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    win = np.lib.stride_tricks.sliding_window_view(xp, (kw, kw), axis=(2, 3))      # [B, C, H, W, kw, kw] (a view)
+    out = np.tensordot(win, w, axes=([1, 4, 5], [1, 2, 3]))                          # [B, H, W, O]
+    return out.transpose(0, 3, 1, 2) + b.reshape(1, -1, 1, 1)
+
+
+def dalle_encoder_block(x: Array, sd, prefix: str, post_gain: float) -> Array:
+    """DalleEncoderBlock.forward (:624-625): id_path(x) + post_gain * res_path(x), res_path = (ReLU, conv) x 4 (3x3, 3x3, 3x3, 1x1)."""
+    idp = conv2d_same(x, sd[prefix + "id_path.w"], sd[prefix + "id_path.b"]) if prefix + "id_path.w" in sd else x
+    h = x
+    for i in (1, 2, 3, 4):
+        h = conv2d_same(np.maximum(h, 0), sd[prefix + f"res_path.conv_{i}.w"], sd[prefix + f"res_path.conv_{i}.b"])
+    return idp + post_gain * h
+
+
+def dalle_encoder_forward(sd, x: Array, prefix: str = "", dtype=np.float32) -> Array:
+    """DalleEncoder.forward (:690-701): stem 7x7, 4 groups of blocks with 2x2 max pools between them, ReLU + 1x1 output conv.
+    Returns z_logits [B, vocab, H/8, W/8]; group / block counts are read off the state_dict keys."""
+    sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
+    pre = prefix + "blocks."
+    groups = sorted({k[len(pre):].split(".")[0] for k in sd if k.startswith(pre + "group_")})
+    n_blocks = {g: len({k[len(pre + g) + 1:].split(".")[0] for k in sd if k.startswith(pre + g + ".block_")}) for g in groups}
+    n_layers = sum(n_blocks.values())
+    h = conv2d_same(np.asarray(x).astype(dtype), sd[pre + "input.w"], sd[pre + "input.b"])
+    for gi, g in enumerate(groups):
+        for bi in range(n_blocks[g]):
+            h = dalle_encoder_block(h, sd, pre + f"{g}.block_{bi + 1}.", 1.0 / n_layers**2)
+        if gi + 1 < len(groups):  # every group but the last ends in nn.MaxPool2d(2) (:677, use_pool=False for group_4)
+            B, C, H, W = h.shape
+            h = h.reshape(B, C, H // 2, 2, W // 2, 2).max(axis=(3, 5))
+    return conv2d_same(np.maximum(h, 0), sd[pre + "output.conv.w"], sd[pre + "output.conv.b"])
+
+
+def dalle_codebook_indices(sd, images: Array, prefix: str = "encoder.") -> Array:
+    """DalleVAEEncoder.get_codebook_indices (:733-735): argmax over the vocabulary axis."""
+    return np.argmax(dalle_encoder_forward(sd, images, prefix), axis=1)
