@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-loss", action="store_true")
     ap.add_argument("--train", action="store_true", help="training step: forward + pre-training loss + backward + SGD")
+    ap.add_argument("--codebook", action="store_true", help="MIM labels from the DALL-E codebook (112x112 images) inside the step instead of synthetic ones")
     a = ap.parse_args()
     from multimodal_amd.models.flava.model import flava_model
     from multimodal_amd.modules.losses.flava import FLAVAPretrainingLoss
@@ -47,13 +48,27 @@ def main():
     mim[pmask == 0] = -1
     itm = torch.ones(B, dtype=torch.long)
     text, text_masked, mlm, pmask, mim, itm = (t.to(dev) for t in (text, text_masked, mlm, pmask, mim, itm))
+    vae, img112, keep = None, None, None
+    if a.codebook:
+        from multimodal_amd import ops
+        from multimodal_amd.models.flava.model import DalleVAEEncoder
+
+        vae = DalleVAEEncoder(pretrained=False).to(dev).eval()
+        img112 = torch.randn(B, 3, 112, 112, generator=g).to(dev)
+        keep = pmask.to(torch.uint8).contiguous()
+
+    def labels():
+        if vae is None:
+            return mim
+        with torch.no_grad():
+            return ops.mask_labels_(vae(img112).flatten(1).contiguous(), keep, -1)  # FLAVAForPreTraining.forward :338-343
 
     def train_step():
         opt.zero_grad(set_to_none=True)
         o = model(image, text, image_patches_mask=pmask, text_masked=text_masked)
         lo = loss(image_sequence=o.image.last_hidden_state, text_sequence=o.text.last_hidden_state,
                   image_masked_sequence=o.image_masked.last_hidden_state, text_masked_sequence=o.text_masked.last_hidden_state,
-                  multimodal_masked_sequence=o.multimodal_masked.last_hidden_state, itm_labels=itm, mim_labels=mim, mlm_labels=mlm,
+                  multimodal_masked_sequence=o.multimodal_masked.last_hidden_state, itm_labels=itm, mim_labels=labels(), mlm_labels=mlm,
                   projected_image_embeddings=o.projected_image_embeddings, projected_text_embeddings=o.projected_text_embeddings)
         total = lo.losses.itm_loss + lo.losses.mmm_text_loss + lo.losses.mmm_image_loss + lo.losses.global_contrastive_loss
         total.backward()
@@ -69,7 +84,7 @@ def main():
                 return o.projected_image_embeddings
             lo = loss(image_sequence=o.image.last_hidden_state, text_sequence=o.text.last_hidden_state,
                       image_masked_sequence=o.image_masked.last_hidden_state, text_masked_sequence=o.text_masked.last_hidden_state,
-                      multimodal_masked_sequence=o.multimodal_masked.last_hidden_state, itm_labels=itm, mim_labels=mim, mlm_labels=mlm,
+                      multimodal_masked_sequence=o.multimodal_masked.last_hidden_state, itm_labels=itm, mim_labels=labels(), mlm_labels=mlm,
                       projected_image_embeddings=o.projected_image_embeddings, projected_text_embeddings=o.projected_text_embeddings)
             return lo.losses.global_contrastive_loss
 
@@ -84,7 +99,11 @@ def main():
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.steps
     gf = (2 * 35.13 + 2 * 13.30 + 24.75 + (0.0 if a.no_loss else 1.8)) * (3 if a.train else 1)
-    print(json.dumps({"workload": ("TRAINING step: " if a.train else "") + "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + (" + bwd + SGD" if a.train else "") + " (no codebook)",
+    if a.codebook:
+        from tools.codebook_bench import encoder_gflop
+
+        gf += encoder_gflop(vae)  # forward only: the codebook supplies labels
+    print(json.dumps({"workload": ("TRAINING step: " if a.train else "") + "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + (" + bwd + SGD" if a.train else "") + (" + DALL-E codebook labels" if a.codebook else " (no codebook)"),
                       "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_sample": gf,
                       "tflops": round(B * gf / ms, 1), "mfma_frac": round(B * gf / ms / 2500.0, 4),
                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "last": float(r.flatten()[0])}))
