@@ -192,7 +192,7 @@ int mmamd_flava_image_embed(const float* patch_emb, const float* cls, const floa
 
 /* --- FLAVA image codebook: the DALL-E dVAE encoder (models/flava/model.py:583-744) -------------------------------------------
  * Activations are bf16 rows [B*(H+2)*(W+2), C]: NHWC with a one-pixel ZERO border per image (= the convolutions' padding) and at
- * least W+3 readable zero rows in front of and behind the buffer.  mmamd_conv_gemm_bf16 is one convolution as an implicit GEMM:
+ * least W+3 READABLE rows in front of and behind the buffer (contents irrelevant: only border positions, stored as zeros, read them).  mmamd_conv_gemm_bf16 is one convolution as an implicit GEMM:
  *   out[m, n] = bias[n] + sum_t sum_c A[m + tap_row_offsets[t], c] * W[n, t*Cin + c]  (+ residual[m, n], bf16)
  * (3x3: the 9 offsets dy*(W+2)+dx; 1x1: the single offset 0; replaces nn.functional.conv2d in DalleConv2d.forward :597-598 and the
  * `id_path(x) + post_gain * res_path(x)` of DalleEncoderBlock.forward :624-625 with post_gain folded into W / bias).  Rows on the

@@ -3,7 +3,8 @@
 // around it (7x7 stem im2col, 2x2 max pool, argmax).
 //
 // Layout.  An activation tensor is bf16 rows [B * GH * GW, C] with GH = H + 2, GW = W + 2: every image carries a one-pixel ZERO
-// border (= the convolution's padding), and the buffer has GW + 1 zero guard rows in front and behind.  Output pixel m of a
+// border (= the convolution's padding), and the buffer has GW + 1 readable guard rows in front and behind (their contents never
+// reach a stored value: only border positions, which are stored as zeros, read them).  Output pixel m of a
 // 3x3 convolution is then  sum over the 9 taps (dy, dx)  A[m + dy*GW + dx, :] . W_tap^T : nine row-shifted GEMMs that share
 // one accumulator, i.e. ONE GEMM whose K loop walks (tap, channel chunk) — no im2col copy.  Outputs are computed for border
 // positions too and stored as zeros (the next layer's padding).  A 1x1 convolution is the same kernel with one tap.
@@ -226,17 +227,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvArgs p
 // rows are written too (their GEMM output is discarded by the border mask).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dalle_stem_im2col_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int B, int C, int H, int W,
-                                                                int kw, int kpad) {
+                                                                int kw, int kpad, long long rows) {
   const int gh = H + 2, gw = W + 2;
-  const long long row = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // wave per grid position
+  if (row >= rows) return;
   const int b = (int)(row / (gh * gw));
   const int rr = (int)(row - (long long)b * gh * gw);
   const int y = rr / gw - 1, x = rr % gw - 1;  // image coordinates of this grid position
-  const int pad = (kw - 1) / 2;
-  for (int k = threadIdx.x; k < kpad; k += 256) {
+  const int pad = (kw - 1) / 2, kk = kw * kw;
+  for (int k = lane; k < kpad; k += 64) {
     float v = 0.f;
-    if (k < C * kw * kw) {
-      const int c = k / (kw * kw), r2 = k - c * kw * kw;
+    if (k < C * kk) {
+      const int c = k / kk, r2 = k - c * kk;
       const int ky = r2 / kw, kx = r2 - ky * kw;
       const int iy = y + ky - pad, ix = x + kx - pad;
       if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)b * C + c) * H + iy) * W + ix];
@@ -369,7 +372,7 @@ extern "C" int mmamd_dalle_stem_im2col(const float* images, void* cols, int B, i
                   "dalle_stem_im2col: bad argument");
   const long long rows = (long long)B * (H + 2) * (W + 2);
   MMAMD_CHECK_ARG(rows < (1ll << 31), MMAMD_E_UNSUPPORTED, "dalle_stem_im2col: too many rows");
-  hipLaunchKernelGGL(dalle_stem_im2col_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, images, (bf16*)cols, B, C, H, W, kw, kpad);
+  hipLaunchKernelGGL(dalle_stem_im2col_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, images, (bf16*)cols, B, C, H, W, kw, kpad, rows);
   return launch_status("dalle_stem_im2col");
 }
 

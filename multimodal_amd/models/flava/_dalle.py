@@ -81,8 +81,8 @@ class DalleEncoderBlock(nn.Module):
 
 
 class _Grid:
-    """Activation buffers of one resolution: bf16 [guard + B*GH*GW + guard, C] with zeroed guards; .rows(t) is the view that starts at
-    grid position 0."""
+    """Activation buffers of one resolution: bf16 [guard + B*GH*GW + guard, C]; .rows(t) is the view that starts at grid position 0.
+    The guard rows only have to be addressable: they are read for border positions alone, whose outputs are stored as zeros."""
 
     def __init__(self, B: int, H: int, W: int, device) -> None:
         self.B, self.H, self.W = B, H, W
@@ -94,10 +94,7 @@ class _Grid:
         self.tap1 = torch.zeros(1, dtype=torch.int64)
 
     def new(self, C: int, dtype=bf) -> Tensor:
-        t = torch.empty((self.M + 2 * self.guard, C), dtype=dtype, device=self.device)
-        t[:self.guard].zero_()            # memset of the guard rows (the kernels write every grid row, borders as zeros)
-        t[self.guard + self.M:].zero_()
-        return t
+        return torch.empty((self.M + 2 * self.guard, C), dtype=dtype, device=self.device)
 
     def rows(self, t: Tensor) -> Tensor:
         return t[self.guard:self.guard + self.M]
