@@ -209,6 +209,8 @@ int mmamd_dalle_stem_im2col(const float* images, void* cols, int B, int C, int H
 int mmamd_dalle_maxpool2(const void* x, void* y, void* y_relu, int B, int H, int W, int C, mmamd_stream_t stream);
 /* torch.argmax(z_logits, axis=1) (:733-735): ids[b, y, x] (int64) from fp32 padded-grid logits [B,H+2,W+2,V]; first maximum wins. */
 int mmamd_dalle_argmax(const float* logits, int64_t* ids, int B, int H, int W, int V, mmamd_stream_t stream);
+/* In-place fp32 softmax over the V columns of every row (get_codebook_probs :737-739: nn.Softmax(dim=1) of the NCHW logits). */
+int mmamd_row_softmax_(float* x, int64_t rows, int V, mmamd_stream_t stream);
 /* kernel-ready copy of a DalleConv2d parameter (w [n_out, n_in, kw, kw] fp32, taps = kw*kw; a bias is n_in = taps = 1): dst[o*ld_dst +
  * idx] = gain * w[o][c][t], idx = t*n_in + c (tap_major) or c*taps + t; the tail of each row is zero. */
 int mmamd_dalle_pack(const float* src, void* dst, int dst_dtype, int n_out, int n_in, int taps, int ld_dst, float gain, int tap_major,

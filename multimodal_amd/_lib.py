@@ -49,6 +49,7 @@ PROTOTYPES = {
     "mmamd_dalle_stem_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmamd_dalle_maxpool2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_dalle_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "mmamd_row_softmax_": (_i, [_vp, _i64, _i, _vp]),
     "mmamd_dalle_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),

@@ -321,6 +321,23 @@ __global__ __launch_bounds__(256) void dalle_pack_kernel(const float* __restrict
   dst[i] = (TD)v;
 }
 
+// in-place softmax over the V channels of every grid row (DalleVAEEncoder.get_codebook_probs, models/flava/model.py:737-739:
+// nn.Softmax(dim=1) on the NCHW logits = a row softmax on the NHWC rows).  Wave per row, three passes over L2-resident data.
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x, long long rows, int V) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* r = x + row * V;
+  float m = -INFINITY;
+  for (int c = lane; c < V; c += 64) m = fmaxf(m, r[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += __expf(r[c] - m);
+  s = wave_sum(s);
+  const float inv = 1.0f / s;
+  for (int c = lane; c < V; c += 64) r[c] = __expf(r[c] - m) * inv;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(ConvArgs& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
@@ -399,4 +416,11 @@ extern "C" int mmamd_dalle_pack(const float* src, void* dst, int dst_dtype, int 
   else if (dst_dtype == MMAMD_F32) hipLaunchKernelGGL((dalle_pack_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, n_out, n_in, taps, ld_dst, gain, tap_major);
   else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "dalle_pack: bad dtype");
   return launch_status("dalle_pack");
+}
+
+extern "C" int mmamd_row_softmax_(float* x, int64_t rows, int V, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && rows >= 0 && V > 0, MMAMD_E_BADARG, "row_softmax: bad argument");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, V);
+  return launch_status("row_softmax");
 }

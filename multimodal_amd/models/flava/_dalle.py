@@ -225,8 +225,10 @@ class DalleVAEEncoder(nn.Module):
         return self.encoder.codebook_indices(images)
 
     def get_codebook_probs(self, images: Tensor) -> Tensor:
-        raise ops.MmamdError("get_codebook_probs (softmax over the 8192 codes) is not on the pre-training path and has no kernel on the "
-                             "MI355X path; get_codebook_indices / forward are implemented")
+        """nn.Softmax(dim=1)(z_logits) (:737-739), returned as the same strided NCHW view as DalleEncoder.forward."""
+        logits, g = self.encoder._logits_grid(images)
+        ops.row_softmax_(logits)
+        return logits.view(g.B, g.gh, g.gw, -1)[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2)
 
     def forward(self, img_seq_prob: Tensor) -> Tensor:
         return self.get_codebook_indices(img_seq_prob)

@@ -22,7 +22,7 @@ __all__ = [
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
-    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
     "attention_x_bwd",
 ]
 
@@ -438,6 +438,14 @@ def dalle_argmax(logits: torch.Tensor, B: int, H: int, W: int, V: int) -> torch.
     ids = torch.empty((B, H, W), dtype=torch.int64, device=logits.device)
     check(_lib.lib().mmamd_dalle_argmax(logits.data_ptr(), ids.data_ptr(), B, H, W, V, _stream()), "mmamd_dalle_argmax")
     return ids
+
+
+def row_softmax_(x: torch.Tensor) -> torch.Tensor:
+    """In-place softmax over the last dimension of a contiguous fp32 [rows, V] tensor."""
+    _chk(x, "x", torch.float32)
+    V = x.shape[-1]
+    check(_lib.lib().mmamd_row_softmax_(x.data_ptr(), x.numel() // V, V, _stream()), "mmamd_row_softmax_")
+    return x
 
 
 def dalle_pack(src: torch.Tensor, n_out: int, n_in: int, taps: int, ld: int, gain: float, tap_major: bool, dtype: torch.dtype) -> torch.Tensor:
