@@ -88,7 +88,8 @@ int mmamd_gemm_bf16_dual(const void* A, int lda, const void* W, int ldw, const f
  * qkv: bf16 [B*S, 3*H*64] rows = tokens, columns = [q | k | v], each H heads of 64;  out: bf16
  * [B*S, H*64] = softmax(q k^T * scale (+causal)) v, heads merged.  Head dim is 64 for every
  * model on the path.  Replaces F.scaled_dot_product_attention reached from nn.MultiheadAttention
- * (image_encoder.py:108 non-causal; text_encoder.py:121 is_causal=True). */
+ * (image_encoder.py:108 non-causal; text_encoder.py:121 is_causal=True).  S <= 288: whole K/V of a head resident in LDS (persistent
+ * kernel); longer sequences stream K/V through LDS in 128-key chunks (two passes, no log-sum-exp output). */
 int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                         mmamd_stream_t stream);
 

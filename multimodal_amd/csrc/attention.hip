@@ -1063,6 +1063,191 @@ static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const
   return launch_status("attention_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Long sequences (S > 288: 384-pixel ViTs after interpolate_pos_encoding, 512-token BERT inputs): the keys no longer fit LDS at once,
+// so K / V stream through it in chunks of 128 keys (row-major images, V operands by transpose reads).  A workgroup owns one (batch,
+// head) and 128 queries (one 32-query tile per wave) and makes TWO passes over the chunks: pass 1 = row max and row sum (QK^T only),
+// pass 2 = recompute the scores, optionally emit the NORMALISED probabilities ([B,H,S,S], what FLAVA's encoders return) and
+// accumulate P.V with the final normalisation already applied — no rescaling of O, and the same arithmetic whether or not the
+// probabilities are wanted.  Self-attention on the packed qkv layout of the kernels above; causal and key-padding masks; a fully
+// masked row is NaN like the reference's softmax.  Forward only (no lse): training on S > 288 raises.
+template <typename TP, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_long_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
+                                                             bf16* __restrict__ out, TP* __restrict__ probs, int S, int H, float c2) {
+  constexpr int KC = 128;
+  __shared__ __attribute__((aligned(16))) bf16 Ks[KC * kKStride];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[KC * kKStride];
+  __shared__ float Mk[KC];  // 0 for a key that may be attended, -inf otherwise (past the end or masked)
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * kDh;
+  const size_t row_stride = (size_t)3 * D;
+  const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nqt = (S + 31) >> 5;
+  const int qt = blockIdx.y * 4 + wave;
+  const bool active = qt < nqt;  // wave-uniform
+  const int q = qt * 32 + l31;
+  const int qc = q < S ? q : S - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)qc * row_stride + 16 * t + 8 * half);
+  const int nchunks = (S + KC - 1) / KC;
+  // causal: chunks entirely above this workgroup's last query are never needed
+  const int q_hi = (blockIdx.y * 4 + 4) * 32 - 1;
+  const int nch = CAUSAL ? ((q_hi < S ? q_hi : S - 1) / KC + 1) : nchunks;
+
+  auto stage = [&](int c, bool with_v) {
+    for (int r = tid >> 3; r < KC; r += 32) {
+      const int ch = tid & 7, key = c * KC + r;
+      bf16x8 kv, vv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+      if (key < S) {
+        kv = *reinterpret_cast<const bf16x8*>(base + (size_t)key * row_stride + D + ch * 8);
+        if (with_v) vv = *reinterpret_cast<const bf16x8*>(base + (size_t)key * row_stride + 2 * D + ch * 8);
+      }
+      *reinterpret_cast<bf16x8*>(Ks + r * kKStride + ch * 8) = kv;
+      if (with_v) *reinterpret_cast<bf16x8*>(Vs + r * kKStride + ch * 8) = vv;
+      if (ch == 0) Mk[r] = (key < S && (key_mask == nullptr || key_mask[(size_t)b * S + key] != 0)) ? 0.f : -INFINITY;
+    }
+  };
+  // scores of query q against the 32 keys of tile kt of chunk c, scaled into the log2 domain, masked keys = -inf
+  auto scores = [&](int c, int kt) -> f32x16 {
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow + 16 * t), qf[t], st, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kl = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = st[r] * c2 + Mk[kl];
+      if (CAUSAL && c * KC + kl > q) v = -INFINITY;
+      st[r] = v;
+    }
+    return st;
+  };
+
+  // ---- pass 1: running maximum and sum of exp2 per query row
+  float m = -INFINITY, l = 0.f;
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();
+    stage(c, false);
+    __syncthreads();
+    if (!active) continue;
+#pragma unroll 1
+    for (int kt = 0; kt < KC / 32; ++kt) {
+      if (c * KC + kt * 32 >= S) break;
+      const f32x16 st = scores(c, kt);
+      float tmax = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m, tmax);
+      if (m_new == -INFINITY) continue;  // every key so far is masked: nothing to add
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(st[r] - m_new);
+      l = l * __builtin_amdgcn_exp2f(m - m_new) + ps;
+      m = m_new;
+    }
+  }
+  l += __shfl_xor(l, 32);
+  // a fully masked row: the reference's softmax of all -inf is NaN; 0 * inf reproduces it in every probability and in O
+  const float inv = 1.0f / l;
+
+  // ---- pass 2: probabilities (optional) and O = P V
+  f32x16 ot[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+  const bf16* vtr = Vs + tr_off(lane, kKStride);
+  TP* prow = probs != nullptr ? probs + (((size_t)b * H + h) * S + qc) * S : nullptr;
+  for (int c = 0; c < nchunks; ++c) {  // (causal: chunks past nch only get their zero probabilities written)
+    const bool need = c < nch;
+    __syncthreads();
+    if (need) stage(c, true);
+    __syncthreads();
+    if (!active) continue;
+#pragma unroll 1
+    for (int kt = 0; kt < KC / 32; ++kt) {
+      if (c * KC + kt * 32 >= S) break;
+      f32x16 pr;
+      if (need) {
+        const f32x16 st = scores(c, kt);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = (l > 0.f ? __builtin_amdgcn_exp2f(st[r] - m) : 0.f) * inv;  // l == 0: 0 * inf = NaN
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = 0.f;
+      }
+      if (prow != nullptr && q < S) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int key = c * KC + kt * 32 + 8 * g + 4 * half;
+          if (key + 3 < S) {
+            store_probs4(prow + key, f32x4{pr[4 * g], pr[4 * g + 1], pr[4 * g + 2], pr[4 * g + 3]});
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (key + j < S) prow[key + j] = (TP)pr[4 * g + j];
+          }
+        }
+      }
+      if (!need) continue;
+      uint32_t pk[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        bf16x2 p2;
+        p2[0] = (bf16)pr[2 * g]; p2[1] = (bf16)pr[2 * g + 1];
+        pk[g] = __builtin_bit_cast(uint32_t, p2);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        u32x4 pw;
+        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16* vp = vtr + (kt * 32 + 16 * jj) * kKStride + nt * 32;
+          const uint2 v0 = lds_tr_b64(vp), v1 = lds_tr_b64(vp + 8 * kKStride);
+          u32x4 vw;
+          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+          ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, ot[nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (active && q < S) {
+    bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ot[nt][4 * g + j];
+        store4(orow + nt * 32 + 8 * g + 4 * half, o);
+      }
+  }
+}
+
+static int launch_attn_long(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int probs_dtype, int B, int S, int H, int causal,
+                            float scale, hipStream_t st) {
+  const dim3 grid(B * H, ((S + 31) / 32 + 3) / 4), block(256);
+  const float c2 = scale * 1.4426950408889634f;
+#define ATTN_LONG(TP, C) hipLaunchKernelGGL((attention_long_kernel<TP, C>), grid, block, 0, st, (const bf16*)qkv, key_mask, (bf16*)out, (TP*)probs, S, H, c2)
+  if (probs != nullptr && probs_dtype == MMAMD_BF16) { if (causal) ATTN_LONG(bf16, true); else ATTN_LONG(bf16, false); }
+  else { if (causal) ATTN_LONG(float, true); else ATTN_LONG(float, false); }
+#undef ATTN_LONG
+  return launch_status("attention_long");
+}
+
 static int g_attn_variant = 0;
 
 template <int NKT, bool CAUSAL, int ABL = 0>
@@ -1108,10 +1293,11 @@ extern "C" int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, i
 
 static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(qkv && out && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention: bad argument");
-  MMAMD_CHECK_ARG(S <= 288, MMAMD_E_UNSUPPORTED, "attention: S=%d > 288 not supported (single-pass LDS kernel)", S);
+  MMAMD_CHECK_ARG(S <= 288 || lse == nullptr, MMAMD_E_UNSUPPORTED, "attention: S=%d > 288 has no training forward (the streaming kernel does not save the log-sum-exp)", S);
   MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out), MMAMD_E_ALIGN, "attention: pointers must be 16-byte aligned");
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (S > 288) return launch_attn_long(qkv, nullptr, out, nullptr, MMAMD_F32, B, S, H, causal, scale, st);
   const int nkt = (S + 31) / 32;
   if (g_attn_variant != 0 && nkt == 7 && !causal) {  // ablations, vision shape only
     switch (g_attn_variant) {
@@ -1139,10 +1325,11 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
 extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int probs_dtype,
                                          int B, int S, int H, float scale, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(qkv && out && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention_probs: bad argument");
-  MMAMD_CHECK_ARG(S <= 288, MMAMD_E_UNSUPPORTED, "attention_probs: S=%d > 288 not supported", S);
   MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out), MMAMD_E_ALIGN, "attention_probs: pointers must be 16-byte aligned");
+  MMAMD_CHECK_ARG(probs == nullptr || probs_dtype == MMAMD_F32 || probs_dtype == MMAMD_BF16, MMAMD_E_BADARG, "attention_probs: bad probs dtype");
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (S > 288) return launch_attn_long(qkv, key_mask, out, probs, probs_dtype, B, S, H, 0, scale, st);
   const int nkt = (S + 31) / 32;
 #define ATTNP_CASE(N)                                                                                              \
   case N:                                                                                                          \

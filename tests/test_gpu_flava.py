@@ -39,7 +39,10 @@ def bf16_round(a):
 @pytest.mark.parametrize("B,S,H,masked,pdt", [(3, 16, 2, True, torch.float32), (2, 22, 2, False, torch.float32),
                                                (2, 77, 12, True, torch.float32), (2, 197, 12, False, torch.float32),
                                                (1, 197, 3, True, torch.bfloat16), (2, 275, 2, True, torch.float32),
-                                               (1, 1, 1, False, torch.float32), (1, 33, 1, True, torch.float32)])
+                                               (1, 1, 1, False, torch.float32), (1, 33, 1, True, torch.float32),
+                                               # S > 288: streaming kernel (512-token BERT inputs, 384-pixel ViT)
+                                               (2, 512, 2, True, torch.float32), (1, 577, 3, False, torch.float32),
+                                               (1, 300, 1, True, torch.bfloat16)])
 def test_attention_probs_kernel(B, S, H, masked, pdt):
     from multimodal_amd import ops
 
@@ -549,3 +552,41 @@ def test_flava_for_pretraining_with_a_user_codebook(golden):
     assert pre.encode_image(image).shape == (5, 64) and pre.encode_text(text).shape == (5, 64)
     with pytest.raises(ops.MmamdError):
         flava_model_for_pretraining(**SMALL_KW).cuda().eval()(image=image, text=text, image_for_codebook=image, image_patches_mask=pm)
+
+
+def test_long_sequences_through_the_modules(golden):
+    """S > 288 end to end: the small FLAVA image encoder on 320x320 images with interpolated position embeddings (401 tokens) and
+    the text encoder on 300 tokens with padding, against the numpy oracle on the same weights; training on such lengths raises."""
+    from multimodal_amd import ops
+    from multimodal_amd.models.flava.model import flava_model
+
+    z = golden("flava_small.npz")
+    kw = dict(SMALL_KW, max_position_embeddings=512)
+    set_rng_seed(2)
+    model = flava_model(**kw)
+    sd = fixture_sd(z)
+    msd = model.state_dict()
+    for k, v in sd.items():  # same weights as the fixture except the (longer) text position table, which keeps its seeded init
+        if msd[k].shape == tuple(v.shape):
+            msd[k].copy_(torch.from_numpy(v))
+    model = model.cuda().eval()
+    sdn = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    img = torch.randn(2, 3, 320, 320)
+    emb = model.image_encoder.embeddings
+    with torch.no_grad():
+        x = emb(img.cuda(), interpolate_pos_encoding=True)
+        assert x.shape == (2, 401, 128)
+        enc = model.image_encoder.encoder(x, return_attn_weights=True, return_hidden_states=True)
+        ref_x = host(x)
+        last, hidden, attns = oc.flava_transformer_encoder(ref_x.astype(np.float32), sdn, "image_encoder.encoder.", 2, 1e-12)
+        assert np.abs(host(enc.last_hidden_state) - last).max() <= HID_TOL
+        assert np.abs(host(enc.attentions[-1]) - attns[-1]).max() <= PROB_TOL and enc.attentions[-1].shape == (2, 2, 401, 401)
+        text = torch.randint(1, 200, (2, 300))
+        text[1, 250:] = 0
+        to = model.text_encoder(text.cuda(), return_attn_weights=True, return_hidden_states=True)
+        ro = oc.flava_text_encoder(sdn, "text_encoder.", text.numpy(), 2)
+        assert np.abs(host(to.last_hidden_state) - ro["last_hidden_state"]).max() <= HID_TOL
+        assert np.abs(host(to.attentions[0]) - ro["attentions"][0]).max() <= PROB_TOL
+        assert (host(to.attentions[-1])[1][:, :, 250:] == 0).all()  # padded keys
+    with pytest.raises(ops.MmamdError):
+        model.train().text_encoder(text.cuda())

@@ -128,7 +128,9 @@ def test_gemm_argument_errors():
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,S,H,causal", [(3, 50, 2, False), (2, 77, 8, True), (2, 197, 12, False), (1, 257, 3, False),
                                           (2, 64, 1, True), (2, 33, 2, True), (1, 1, 1, False), (1, 275, 2, False),
-                                          (1, 288, 1, True)])
+                                          (1, 288, 1, True),
+                                          # S > 288: the streaming (chunked K/V) kernel — 384-pixel ViT (577), 512-token BERT, ragged tails
+                                          (2, 577, 3, False), (1, 512, 2, True), (1, 289, 1, False), (2, 401, 2, True)])
 def test_attention(B, S, H, causal):
     from multimodal_amd import ops
 
