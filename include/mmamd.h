@@ -285,10 +285,12 @@ int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, co
 
 /* --- row / elementwise kernels of the backward pass (torch autograd of the modules named in the forward entries above)
  * LayerNorm backward: dx[rows,d] (fp32) = LN'(x; gamma)(dy) (+ add), dgamma[d], dbeta[d].  dy fp32 or bf16.  dx_bf16 (optional):
- * the same dx rounded to bf16 (operand of the following gradient GEMMs).
- * ws: (min(768, ceil(rows/4)) * 2 + 2) * d floats. */
+ * the same dx rounded to bf16 (operand of the following gradient GEMMs).  dx_colsum (optional, [d]): column sums of dx — the bias
+ * gradient of the Linear whose output fed this LayerNorm's residual stream.
+ * ws: (min(768, ceil(rows/4)) + 1) * 3 * d floats. */
 int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
-                        void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int d, float eps, mmamd_stream_t stream);
+                        void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int d, float eps,
+                        mmamd_stream_t stream);
 /* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(1024, rows) * n floats. */
 int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */

@@ -113,6 +113,7 @@ class EncoderStackFn(torch.autograd.Function):
         dX = dX if dX.is_contiguous() else dX.contiguous()
         grads: List[Optional[Tensor]] = [None] * nparam
         dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
+        dXsum = None  # ... and its column sums (= the bias gradient of this layer's second MLP Linear) from the same kernel
         for li in reversed(range(cfg.n_layers)):
             x, h1, qkv, att, lse, x_mid, h2, u, g = saved[9 * li:9 * li + 9]
             Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]])
@@ -120,19 +121,22 @@ class EncoderStackFn(torch.autograd.Function):
                 dXb = ops.convert(dX, bf)
             # x_out = x_mid + g W2^T + b2;  g = act(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
             du = dgrad(dXb, W2, bf, _ACT_GRAD[cfg.act], u)
-            dW2, db2 = wgrad(dXb, g, bias=True)
+            if dXsum is None:
+                dW2, db2 = wgrad(dXb, g, bias=True)
+            else:
+                dW2, db2 = wgrad(dXb, g), dXsum
             # u = h2 W1^T + b1
             dh2 = dgrad(du, W1, f32)
             dW1, db1 = wgrad(du, h2, bias=True)
-            dx_mid, dg2, dbe2, dxmb = ops.layernorm_bwd(x_mid, g2, dh2, cfg.eps2[li], add=dX, want_bf16=True)
+            dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, cfg.eps2[li], add=dX, want_bf16=True, want_colsum=True)
             # x_mid = x + att Wo^T + bo
             datt = dgrad(dxmb, Wo, bf)
-            dWo, dbo = wgrad(dxmb, att, bias=True)
+            dWo = wgrad(dxmb, att)
             dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, cfg.causal, cfg.key_mask)
             # qkv = h1 Wqkv^T + bqkv
             dh1 = dgrad(dqkv, Wqkv, f32)
             dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
-            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, cfg.eps1[li], add=dx_mid, want_bf16=True)
+            dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, cfg.eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
             grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical([dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2])
         return (dX, None, *grads)
 

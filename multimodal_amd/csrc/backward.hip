@@ -15,16 +15,15 @@ template <typename TD, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const TD* __restrict__ dy, const float* __restrict__ add,
                                                             float* __restrict__ dx, bf16* __restrict__ dx_bf16, float* __restrict__ part,
-                                                            int rows, int d, float eps) {
-  __shared__ float red[4][2][MAXV * 256];
+                                                            int rows, int d, float eps, int with_cs) {
+  // with_cs: also the column sums of the OUTPUT dx (third partial slot) — dx is the dY of the Linear that produced this LayerNorm's
+  // input stream (out-projection / MLP-down), so its bias gradient needs no pass of its own
+  __shared__ float red[4][3][MAXV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d4 = d >> 2;
-  f32x4 gacc[MAXV], bacc[MAXV], gm[MAXV];
+  f32x4 gacc[MAXV], bacc[MAXV], cacc[MAXV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gm[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (lane + 64 * i < d4) gm[i] = load4(gamma + 4 * (lane + 64 * i));
-  }
+  for (int i = 0; i < MAXV; ++i) { gacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const float* xr = x + (size_t)row * d;
     const TD* dr = dy + (size_t)row * d;
@@ -60,12 +59,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + 64 * i;
       if (c < d4) {
+        const f32x4 gm = load4(gamma + 4 * c);  // L1-resident: kept out of the registers the row loads need
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float xh = (xv[i][j] - mean) * rstd;
           const float dyj = gv[i][j];
           xv[i][j] = xh;
-          gv[i][j] = dyj * gm[i][j];
+          gv[i][j] = dyj * gm[j];
           sg += gv[i][j];
           sgx += gv[i][j] * xh;
           gacc[i][j] += dyj * xh;
@@ -81,6 +81,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rstd * (gv[i][j] - mg - xv[i][j] * mgx) + av[i][j];
+        if (with_cs) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cacc[i][j] += o[j];
+        }
         store4(dx + (size_t)row * d + 4 * c, o);
         if (dx_bf16 != nullptr) store4(dx_bf16 + (size_t)row * d + 4 * c, o);  // MFMA operand of the next dgrad / wgrad
       }
@@ -91,12 +95,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + 64 * i;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[wave][0][4 * c + j] = gacc[i][j]; red[wave][1][4 * c + j] = bacc[i][j]; }
+    for (int j = 0; j < 4; ++j) { red[wave][0][4 * c + j] = gacc[i][j]; red[wave][1][4 * c + j] = bacc[i][j]; red[wave][2][4 * c + j] = cacc[i][j]; }
   }
   __syncthreads();
+  const int nslot = with_cs ? 3 : 2;  // part layout [G][nslot][d]
   for (int c = threadIdx.x; c < d; c += 256) {
-    part[((size_t)blockIdx.x * 2 + 0) * d + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
-    part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+    part[((size_t)blockIdx.x * nslot + 0) * d + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+    part[((size_t)blockIdx.x * nslot + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+    if (with_cs) part[((size_t)blockIdx.x * 3 + 2) * d + c] = (red[0][2][c] + red[1][2][c]) + (red[2][2][c] + red[3][2][c]);
   }
 }
 
@@ -326,22 +332,24 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 using namespace mmamd;
 
 extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
-                                   void* dx_bf16, float* dgamma, float* dbeta, float* ws, int rows, int d, float eps,
+                                   void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int d, float eps,
                                    mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && ws && rows > 0 && d > 0, MMAMD_E_BADARG, "layernorm_bwd: bad argument");
   MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "layernorm_bwd: d=%d must be a multiple of 4 and <= 2048", d);
   hipStream_t st = (hipStream_t)stream;
-  const int G = rows < 4 * 768 ? (rows + 3) / 4 : 768;  // 3 workgroups per CU (157 VGPRs at d = 768); ws: (G + 1) * 2 * d floats
-  const int d4 = d / 4;
-#define LNB(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(G), dim3(256), 0, st, x, gamma, (const T*)dy, add, dx, (bf16*)dx_bf16, ws, rows, d, eps)
+  const int G = rows < 4 * 768 ? (rows + 3) / 4 : 768;  // 3 workgroups per CU; ws: (G + 1) * 3 * d floats
+  const int d4 = d / 4, cs = dx_colsum != nullptr, ns = cs ? 3 : 2;
+#define LNB(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(G), dim3(256), 0, st, x, gamma, (const T*)dy, add, dx, (bf16*)dx_bf16, ws, rows, d, eps, cs)
   if (dy_dtype == MMAMD_F32) { if (d4 <= 128) LNB(float, 2); else if (d4 <= 256) LNB(float, 4); else LNB(float, 8); }
   else if (dy_dtype == MMAMD_BF16) { if (d4 <= 128) LNB(bf16, 2); else if (d4 <= 256) LNB(bf16, 4); else LNB(bf16, 8); }
   else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "layernorm_bwd: bad dy dtype");
 #undef LNB
-  // part layout [G][2][d]: columns 0..d-1 = dgamma partials, d..2d-1 = dbeta partials of one "row" of width 2d
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, st, ws, G, 2 * d, ws + (size_t)G * 2 * d);
-  hipMemcpyAsync(dgamma, ws + (size_t)G * 2 * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(dbeta, ws + (size_t)G * 2 * d + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+  // part layout [G][ns][d] = G rows of width ns*d: dgamma | dbeta | (column sums of dx)
+  float* res = ws + (size_t)G * ns * d;
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((ns * d + 31) / 32), dim3(256), 0, st, ws, G, ns * d, res);
+  hipMemcpyAsync(dgamma, res, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(dbeta, res + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+  if (cs) hipMemcpyAsync(dx_colsum, res + 2 * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
   return launch_status("layernorm_bwd");
 }
 

@@ -691,9 +691,10 @@ def contrastive_bwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
 
 
 def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float,
-                  add: Optional[torch.Tensor] = None, want_bf16: bool = False):
+                  add: Optional[torch.Tensor] = None, want_bf16: bool = False, want_colsum: bool = False):
     """(dx fp32 [rows,d] (+ add), dgamma [d], dbeta [d]) for y = LayerNorm(x) * gamma + beta; dy fp32 or bf16.  With
-    want_bf16=True a bf16 copy of dx (written by the same kernel) is appended to the result."""
+    want_bf16=True a bf16 copy of dx (written by the same kernel) is appended to the result, with want_colsum=True the column
+    sums of dx ([d] fp32: the bias gradient of the Linear that wrote into this residual stream) after that."""
     _chk(x, "x", torch.float32); _chk(gamma, "gamma", torch.float32); _chk(dy, "dy")
     d = x.shape[-1]
     rows = x.numel() // d
@@ -705,11 +706,17 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: f
     dx = torch.empty((rows, d), dtype=torch.float32, device=dev)
     dg, db = torch.empty(d, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)
     G = min(768, (rows + 3) // 4)
-    ws = torch.empty((G * 2 + 2) * d, dtype=torch.float32, device=dev)
+    ws = torch.empty((G + 1) * 3 * d, dtype=torch.float32, device=dev)
     dxb = torch.empty((rows, d), dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    cs = torch.empty(d, dtype=torch.float32, device=dev) if want_colsum else None
     check(_lib.lib().mmamd_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy), _ptr(add), dx.data_ptr(), _ptr(dxb),
-                                         dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, d, float(eps), _stream()), "mmamd_layernorm_bwd")
-    return (dx, dg, db, dxb) if want_bf16 else (dx, dg, db)
+                                         dg.data_ptr(), db.data_ptr(), _ptr(cs), ws.data_ptr(), rows, d, float(eps), _stream()), "mmamd_layernorm_bwd")
+    out = (dx, dg, db)
+    if want_bf16:
+        out += (dxb,)
+    if want_colsum:
+        out += (cs,)
+    return out
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:

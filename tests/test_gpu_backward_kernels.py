@@ -80,6 +80,12 @@ def test_layernorm_backward_and_colsum():
         assert np.abs(host(db) - beta.grad.double().numpy()).max() <= 1e-4 * max(1.0, float(beta.grad.abs().max()))
         cs = ops.colsum(dy.cuda())
         assert np.abs(host(cs) - dy.double().sum(0).numpy()).max() <= 1e-4 * max(1.0, float(dy.double().sum(0).abs().max()))
+        # the same call with the fused column sums of its own output (bias gradient of the Linear upstream of the residual stream)
+        dx2, dg2, db2, dxb2, dxs = ops.layernorm_bwd(x.detach().cuda(), gamma.detach().cuda(), dy.cuda(), 1e-5, add=add.cuda(), want_bf16=True,
+                                                    want_colsum=True)
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(dxb2, dxb)
+        want = host(dx).sum(0)
+        assert np.abs(host(dxs) - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
 def test_activation_transpose_normalize_scatter_kernels():
