@@ -102,9 +102,13 @@ class MultiHeadAttentionWithCache(nn.Module):
         self._packed = PackedCache()
 
     def run(self, q_in: Tensor, kv_in: Optional[Tensor], B: int, Sq: int, Sk: int, mask: AttnMask, residual: Optional[Tensor],
-            shared_q: bool = False, out: Optional[Tensor] = None) -> Tensor:
+            shared_q: bool = False, out: Optional[Tensor] = None, past: Optional[Tuple[Tensor, Tensor]] = None,
+            use_cache: bool = False):
         """q_in: bf16 [B*Sq, dq] (or [Sq, dq] when shared_q); kv_in: bf16 [B*Sk, dkv], None = self-attention over q_in.
-        Returns fp32 [B*Sq, dq] = output_proj(attention) (+ residual)."""
+        Returns fp32 [B*Sq, dq] = output_proj(attention) (+ residual).
+        Incremental decoding (reference :158-179): `past` = (key, value) [B, H, Sp, hd] of the earlier positions is prepended to the
+        Sk new keys / values (mask then spans Sp + Sk keys); with use_cache the result is (output, (key, value)) — the new cache in the
+        reference's [B, H, Sp + Sk, hd] shape, held in bf16 as views of one token-major buffer (feeding it back costs no conversion)."""
         if self.training and self.dropout > 0:
             raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
         dq = self.q_proj.out_features
@@ -122,15 +126,37 @@ class MultiHeadAttentionWithCache(nn.Module):
             bkv = pc.get_cat([self.k_proj.bias, self.v_proj.bias], f32) if has_b else None
             kv = ops.gemm_bf16(kv_in, wkv, bkv)
             k, v = kv[:, :dq], kv[:, dq:]
+        present = None
+        if past is not None or use_cache:
+            if shared_q:
+                raise ops.MmamdError("key/value caching with batch-shared queries is not a configuration of the reference")
+            H = self.num_heads
+            parts_k, parts_v = [], []
+            if past is not None:
+                pk, pv = past
+                if pk.shape != pv.shape or pk.dim() != 4 or pk.shape[0] != B or pk.shape[1] != H or pk.shape[3] != hd:
+                    raise ValueError(f"past_key_value must be two [bsz, num_heads, seq, head_dim] tensors, got {tuple(pk.shape)} / {tuple(pv.shape)}")
+                for t, dst in ((pk, parts_k), (pv, parts_v)):
+                    tok = t.detach().transpose(1, 2).reshape(B, t.shape[2], dq)  # token-major; a free view when `t` came from this module
+                    if tok.dtype != bf:
+                        tok = ops.convert(tok.contiguous() if tok.dtype == f32 else tok.float().contiguous(), bf)
+                    dst.append(tok)
+            parts_k.append(k.unflatten(0, (B, Sk)))
+            parts_v.append(v.unflatten(0, (B, Sk)))
+            k_all = torch.cat(parts_k, dim=1) if len(parts_k) > 1 else parts_k[0].contiguous()  # [B, Sp + Sk, dq] (data movement only)
+            v_all = torch.cat(parts_v, dim=1) if len(parts_v) > 1 else parts_v[0].contiguous()
+            Sk = k_all.shape[1]
+            k, v = k_all.view(B * Sk, dq), v_all.view(B * Sk, dq)
+            if use_cache:
+                present = (k_all.view(B, Sk, H, hd).transpose(1, 2), v_all.view(B, Sk, H, hd).transpose(1, 2))
         att, _ = ops.attention_x_fwd(q, k, v, B, Sq, Sk, self.num_heads, hd, mask, shared_q=shared_q)
-        return ops.gemm_bf16(att, pc.get(self.output_proj.weight, bf), pc.get(self.output_proj.bias, f32), residual=residual,
-                             out_dtype=f32, out=out)
+        y = ops.gemm_bf16(att, pc.get(self.output_proj.weight, bf), pc.get(self.output_proj.bias, f32), residual=residual,
+                          out_dtype=f32, out=out)
+        return (y, present) if use_cache else y
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor] = None,
                 past_key_value: Optional[Tuple[Tensor, Tensor]] = None, is_causal: bool = False, use_cache: bool = False
                 ) -> Union[Tensor, MHAWithCacheOutput]:
-        if past_key_value is not None or use_cache:
-            raise ops.MmamdError("key/value caching (incremental decoding) is not implemented on the MI355X path")
         if key is not value:
             raise ops.MmamdError("key and value must be the same tensor on the MI355X path (self- or cross-attention)")
         if key.size(0) != query.size(0):
@@ -144,5 +170,19 @@ class MultiHeadAttentionWithCache(nn.Module):
         if key is not query:
             kc = key if key.is_contiguous() else key.contiguous()
             kv_in = ops.convert(kc.view(B * Sk, kc.shape[-1]), bf)
-        mask = to_attn_mask(attn_mask, is_causal, B, Sq, Sk)
-        return self.run(q_in, kv_in, B, Sq, Sk, mask, None).view(B, Sq, dq)
+        Sp = past_key_value[0].shape[2] if past_key_value is not None else 0
+        mask = cached_attn_mask(attn_mask, is_causal, B, Sq, Sp + Sk, query.device)
+        r = self.run(q_in, kv_in, B, Sq, Sk, mask, None, past=past_key_value, use_cache=use_cache)
+        if use_cache:
+            return MHAWithCacheOutput(r[0].view(B, Sq, dq), r[1])
+        return r.view(B, Sq, dq)
+
+
+def cached_attn_mask(attn_mask: Optional[Tensor], is_causal: bool, B: int, Sq: int, Sk: int, device) -> AttnMask:
+    """to_attn_mask for a key axis that may include cached positions.  is_causal with Sq != Sk follows
+    F.scaled_dot_product_attention, which the reference calls (:165-167): a TOP-LEFT aligned lower-triangular mask (query i sees keys
+    0..i) — callers that decode incrementally pass an explicit mask or none, as the reference's own do."""
+    if is_causal and attn_mask is None and Sq != Sk:
+        attn_mask = torch.ones(Sq, Sk, dtype=torch.bool, device=device).tril()  # mask construction, not arithmetic
+        is_causal = False
+    return to_attn_mask(attn_mask, is_causal, B, Sq, Sk)

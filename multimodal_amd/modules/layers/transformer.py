@@ -177,19 +177,31 @@ class TransformerDecoderLayer(nn.Module):
         self._packed = PackedCache()
 
     def run(self, x: Tensor, B: int, S: int, mask: ops.AttnMask, enc: Optional[Tensor] = None, Sk: int = 0,
-            cross_mask: Optional[ops.AttnMask] = None) -> Tensor:
-        """x: fp32 [B*S, d]; enc: bf16 [B*Sk, dim_kv] encoder states (already converted once per decoder) or None."""
+            cross_mask: Optional[ops.AttnMask] = None, past: Optional[Tuple[Tensor, Tensor]] = None, use_cache: bool = False):
+        """x: fp32 [B*S, d]; enc: bf16 [B*Sk, dim_kv] encoder states (already converted once per decoder) or None.  With `past` /
+        use_cache the self-attention runs over the cached + new keys (reference :336-359) and the result is (y, present)."""
         if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
             raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
         bf, f32, pc = torch.bfloat16, torch.float32, self._packed
         cross_mask = cross_mask or ops.AttnMask()
+        caching = past is not None or use_cache
+        present = None
+
+        def self_attn(h_in, residual):
+            nonlocal present
+            r = self.attention.run(h_in, None, B, S, S, mask, residual=residual, past=past, use_cache=use_cache)
+            if use_cache:
+                r, present = r
+            return r
+
         if self.norm_first:  # reference :398-433
-            a = self.attention.run(_ln(pc, self.attention_layernorm, x, bf), None, B, S, S, mask, residual=x)
+            a = self_attn(_ln(pc, self.attention_layernorm, x, bf), x)
             if self.use_cross_attention and enc is not None:
                 a = self.cross_attention.run(_ln(pc, self.cross_attention_layernorm, a, bf), enc, B, S, Sk, cross_mask, residual=a, out=a)
-            return self.feedforward.run(_ln(pc, self.feedforward_layernorm, a, bf), residual=a, out=a)
+            y = self.feedforward.run(_ln(pc, self.feedforward_layernorm, a, bf), residual=a, out=a)
+            return (y, present) if caching else y
         # post-norm, :435-472
-        a = self.attention.run(ops.convert(x, bf), None, B, S, S, mask, residual=x)
+        a = self_attn(ops.convert(x, bf), x)
         a = _ln(pc, self.attention_layernorm, a, f32)
         if self.use_cross_attention:
             if enc is None:
@@ -197,22 +209,24 @@ class TransformerDecoderLayer(nn.Module):
             c = self.cross_attention.run(ops.convert(a, bf), enc, B, S, Sk, cross_mask, residual=a)
             a = _ln(pc, self.cross_attention_layernorm, c, f32)
         ff = self.feedforward.run(ops.convert(a, bf), residual=a)
-        return _ln(pc, self.feedforward_layernorm, ff, f32)
+        y = _ln(pc, self.feedforward_layernorm, ff, f32)
+        return (y, present) if caching else y
 
     def forward(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cross_attention_mask: Optional[Tensor] = None, past_key_value: Optional[Tuple[Tensor, Tensor]] = None,
                 use_cache: bool = False) -> Tuple[Tensor, Optional[Tuple[Tensor, Tensor]]]:
-        if past_key_value is not None or use_cache:
-            raise ops.MmamdError("key/value caching (incremental decoding) is not implemented on the MI355X path")
         _forbid_training(self)
         B, S, d = hidden_states.shape
         enc, Sk = None, 0
         if encoder_hidden_states is not None:
             Sk = encoder_hidden_states.shape[1]
             enc = ops.convert(_f32_rows(encoder_hidden_states, "TransformerDecoderLayer"), torch.bfloat16)
-        y = self.run(_f32_rows(hidden_states, "TransformerDecoderLayer"), B, S, to_attn_mask(attention_mask, False, B, S, S), enc, Sk,
-                     to_attn_mask(cross_attention_mask, False, B, S, Sk) if enc is not None else None)
-        return y.view(B, S, d), None
+        St = S + (past_key_value[0].shape[2] if past_key_value is not None else 0)  # keys the self-attention mask spans
+        r = self.run(_f32_rows(hidden_states, "TransformerDecoderLayer"), B, S, to_attn_mask(attention_mask, False, B, S, St), enc, Sk,
+                     to_attn_mask(cross_attention_mask, False, B, S, Sk) if enc is not None else None, past=past_key_value, use_cache=use_cache)
+        if past_key_value is not None or use_cache:
+            return r[0].view(B, S, d), r[1]
+        return r.view(B, S, d), None
 
 
 class TransformerDecoder(nn.Module):
@@ -233,29 +247,40 @@ class TransformerDecoder(nn.Module):
     def forward(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cross_attention_mask: Optional[Tensor] = None, past_key_values: Optional[List[Tuple[Tensor, Tensor]]] = None,
                 use_cache: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
-        if past_key_values is not None or use_cache:
-            raise ops.MmamdError("key/value caching (incremental decoding) is not implemented on the MI355X path")
         B, S, d = hidden_states.shape
+        caching = past_key_values is not None or use_cache
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
+            if caching:
+                raise ops.MmamdError("key/value caching is an inference feature: call the decoder under torch.no_grad() / in eval mode")
             return self._forward_train(hidden_states, encoder_hidden_states, attention_mask, return_hidden_states)
         x = _f32_rows(hidden_states, "TransformerDecoder")
-        mask = to_attn_mask(attention_mask, False, B, S, S)
+        if past_key_values is not None and len(past_key_values) != len(self.layer):
+            raise ValueError(f"past_key_values has {len(past_key_values)} entries for {len(self.layer)} layers")
+        St = S + (past_key_values[0][0].shape[2] if past_key_values is not None else 0)
+        mask = to_attn_mask(attention_mask, False, B, S, St)
         enc, Sk = None, 0
         if encoder_hidden_states is not None:
             Sk = encoder_hidden_states.shape[1]
             enc = ops.convert(_f32_rows(encoder_hidden_states, "TransformerDecoder"), torch.bfloat16)  # once for all layers
         all_hidden_states = []
-        for layer_module in self.layer:
+        current_key_values = []
+        for i, layer_module in enumerate(self.layer):
             if return_hidden_states:
                 all_hidden_states.append(x.view(B, S, d))
             # (the reference does not forward cross_attention_mask to its layers either: transformer.py:630-636)
-            x = layer_module.run(x, B, S, mask, enc, Sk)
+            if caching:
+                x, present = layer_module.run(x, B, S, mask, enc, Sk, past=past_key_values[i] if past_key_values is not None else None,
+                                              use_cache=use_cache)
+                if use_cache:
+                    current_key_values.append(present)
+            else:
+                x = layer_module.run(x, B, S, mask, enc, Sk)
         x = x.view(B, S, d)
         if return_hidden_states:
             all_hidden_states.append(x)
         if self.final_layer_norm is not None:
             x = self.final_layer_norm(x)
-        return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, current_key_values=[])
+        return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, current_key_values=current_key_values)
 
 
 def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, attention_mask, return_hidden_states: bool) -> TransformerOutput:

@@ -592,12 +592,15 @@ def mh_self_attention(x: Array, sd, prefix: str, heads: int, attend=None, causal
     return a @ sd[prefix + "output_proj.weight"].T + sd[prefix + "output_proj.bias"]
 
 
-def mha_with_cache(q_in: Array, kv_in: Array, sd, prefix: str, heads: int, attend=None, causal=False) -> Array:
-    """MultiHeadAttentionWithCache.forward without cache (…:115-180): separate q/k/v projections (k, v from kv_in)."""
+def mha_with_cache(q_in: Array, kv_in: Array, sd, prefix: str, heads: int, attend=None, causal=False, past=None, use_cache=False):
+    """MultiHeadAttentionWithCache.forward (…:115-180): separate q/k/v projections (k, v from kv_in); `past` = (key, value)
+    [B,H,Sp,dh] is concatenated in front of the new keys / values (:158-161); use_cache -> (output, (key, value)) (:177-179)."""
     lin = lambda name, x: x @ sd[prefix + name + ".weight"].T + (sd[prefix + name + ".bias"] if prefix + name + ".bias" in sd else 0)
-    q, k, v = lin("q_proj", q_in), lin("k_proj", kv_in), lin("v_proj", kv_in)
-    a = _merge(sdpa(_heads(q, heads), _heads(k, heads), _heads(v, heads), attend, causal))
-    return lin("output_proj", a)
+    q, k, v = _heads(lin("q_proj", q_in), heads), _heads(lin("k_proj", kv_in), heads), _heads(lin("v_proj", kv_in), heads)
+    if past is not None:
+        k, v = np.concatenate([past[0], k], axis=2), np.concatenate([past[1], v], axis=2)
+    out = lin("output_proj", _merge(sdpa(q, k, v, attend, causal)))
+    return (out, (k, v)) if use_cache else out
 
 
 def _ffn(x: Array, sd, prefix: str) -> Array:
@@ -628,14 +631,20 @@ def layers_encoder(x: Array, sd, prefix: str, heads: int, eps: float, norm_first
     return x, hidden
 
 
-def layers_decoder_layer(x: Array, enc: Optional[Array], sd, prefix: str, heads: int, eps: float, attend=None) -> Array:
-    """TransformerDecoderLayer._forward_prenorm (:398-433): self-attention, optional cross-attention, feed-forward."""
+def layers_decoder_layer(x: Array, enc: Optional[Array], sd, prefix: str, heads: int, eps: float, attend=None, past=None, use_cache=False):
+    """TransformerDecoderLayer._forward_prenorm (:398-433): self-attention (optionally over cached keys / values, :336-359), optional
+    cross-attention, feed-forward.  use_cache -> (output, present_key_value)."""
     ln = lambda name, t: layer_norm(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], eps)
     h = ln("attention_layernorm", x)
-    a = mha_with_cache(h, h, sd, prefix + "attention.", heads, attend) + x
+    r = mha_with_cache(h, h, sd, prefix + "attention.", heads, attend, past=past, use_cache=use_cache)
+    present = None
+    if use_cache:
+        r, present = r
+    a = r + x
     if enc is not None and prefix + "cross_attention.q_proj.weight" in sd:
         a = mha_with_cache(ln("cross_attention_layernorm", a), enc, sd, prefix + "cross_attention.", heads) + a
-    return a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.")
+    y = a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.")
+    return (y, present) if use_cache else y
 
 
 def layers_decoder(x: Array, enc: Optional[Array], sd, prefix: str, heads: int, eps: float, attend=None, final_eps=None) -> Array:
