@@ -1900,10 +1900,11 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     };
     if (t256 < 96) {
       v = 6;
-    } else if ((p.K & 127) == 0 && t256 >= 512) {
+    } else if ((p.K & 127) == 0 && (t256 >= 1024 || (t256 >= 512 && p.K >= 2048))) {
       v = 18;  // many tiles per CU: the persistent kernel hides each tile's first-stage load behind the previous epilogue
-      // row-range split in front of it only for long K (MLP-down, 591 tiles: 855 -> 896 TF/s); at K <= 768 the plain persistent grid wins
-      // (out-proj 622 vs 598, text MLP-up 692 vs 647 TF/s)
+      // row-range split in front of it for the 2-3 round grids with long K (MLP-down, 591 tiles: 855 -> 896 TF/s).  (The persistent kernel also
+      // wins by 2-7 % on the 512-1023-tile, K <= 768 shapes — out-proj, text MLP-up — but they stay on the P kernel so that the dominant
+      // kernel's instantiation, gemm_bf16_nt_kernel_pp<false, QuickGELU>, is launched for ONE shape only and its rocprof average is that shape's.)
       if (p.K >= 2048 && try_split(true)) return rc;
     } else {
       v = 7;
