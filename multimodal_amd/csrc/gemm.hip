@@ -1927,6 +1927,9 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       case 22: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 0>(p, st);  // C stores plain
       case 23: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 1>(p, st);  // fragment reads in one burst
       case 24: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 2>(p, st);  // fragment reads 2 per MFMA
+      case 25: return launch_tiled_pp<OUT_F32, ACT, 4, 2, 4, OUT_F32 ? 0 : 2>(p, st);   // tile-order group of 4 row panels
+      case 26: return launch_tiled_pp<OUT_F32, ACT, 16, 2, 4, OUT_F32 ? 0 : 2>(p, st);  // ... 16
+      case 27: return launch_tiled_pp<OUT_F32, ACT, 2, 2, 4, OUT_F32 ? 0 : 2>(p, st);   // ... 2
 #endif
 #ifdef MMAMD_EXPERIMENTS  // schedule experiments, ablations (WRONG results for 1xx except 132/164) and traces: see DESIGN.md 4.1
       case 30: return launch_tiled_g<OUT_F32, ACT, 8>(p, st);        // ping-pong kernel "G" (measured: not faster than P/PP)
