@@ -521,7 +521,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 // K-tile is then [64 t][256 cols], stored as 256-byte units of [4 t][32 cols] (two [4][16] blocks) in [t/4][cols/32] order — the
 // DMA lays it out through its per-lane source addresses — and every MFMA operand is two ds_read_b64_tr_b16 (4 + 4 contraction
 // indices of one column per lane; the two 16-lane groups of a half-wave read one contiguous 256-byte unit: conflict-free).
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m,
                                                                         unsigned long long* trace = nullptr) {
   static_assert(!TNM || (BM == 256 && BN == 256), "TN image below is laid out for 256-column operand tiles");
@@ -715,7 +715,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     mma(xa1, wb1);
     load_frags(bufc, 3, xa1, wb1);
     mma(xa0, wb0);
-    if constexpr (ABL != 0) return;  // ablations: leave the order to the compiler
+    if constexpr (ABL != 0 || SCH == 2) return;  // ablations / experiment: leave the order to the compiler
+    if constexpr (SCH == 1) {  // experiment: all fragment reads of the next k-step in one burst, then the MFMAs
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x100, (TNM ? 2 : 1) * NF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+      }
+      return;
+    }
+    if constexpr (SCH == 3) {  // experiment: reads first, in pairs, each pair followed by one MFMA
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, TNM ? 2 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
@@ -2061,7 +2081,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 }  // namespace mmamd
 
-template <bool TNM>
+template <bool TNM, int SCH = 0>
 static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
                             mmamd_stream_t stream) {
   const int KT = K / 64;
@@ -2074,7 +2094,7 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   p.kt_chunk = chunk; p.c_split_stride = (long long)M * N; p.res_mode = 0;
   p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0;
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true, TNM>;
+  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true, TNM, SCH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -2113,5 +2133,13 @@ extern "C" int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, 
   MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws), MMAMD_E_ALIGN, "gemm_tn_splitk: base pointers must be 16-byte aligned");
   MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)lda * 2u < (1ull << 31) && (uint64_t)64 * (uint64_t)ldw * 2u < (1ull << 31), MMAMD_E_UNSUPPORTED,
                   "gemm_tn_splitk: leading dimension too large for the 32-bit DMA offsets");
+#ifdef MMAMD_EXPERIMENTS  // fragment-read placement experiments of the TN main loop (mmamd_set_gemm_variant(40 .. 43))
+  if (g_gemm_variant == 40) return gemm_splitk_impl<true, 0>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 41) return gemm_splitk_impl<true, 1>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 42) return gemm_splitk_impl<true, 2>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 43) return gemm_splitk_impl<true, 3>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+#endif
+  // (fragment-read placement variants 40-43 differ by less than the run-to-run spread of a 20-launch loop — the same kernel measured 295 and
+  //  252 us depending on its position in the loop — and the training step time is unchanged by them: the MFMA-first order stays)
   return gemm_splitk_impl<true>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
 }

@@ -13,6 +13,14 @@ for name, T, M, N in (("v.qkv", 50432, 2304, 768), ("v.out", 50432, 768, 768), (
     y = (torch.randn(T, M) * 0.1).to(torch.bfloat16).cuda()
     x = torch.randn(T, N).to(torch.bfloat16).cuda()
     tn = timeit(lambda: ops.gemm_bf16_tn_splitk(y, x), 20) * 1e3
+    if "--sched" in sys.argv:  # experiment builds only (MMAMD_EXPERIMENTS=1): fragment-read placement variants of the TN loop
+        alt = []
+        for v in (40, 41, 42, 43):
+            ops.set_gemm_variant(v)
+            alt.append(timeit(lambda: ops.gemm_bf16_tn_splitk(y, x), 20) * 1e3)
+        ops.set_gemm_variant(0)
+        print(f"{name:7s} TN policy {tn:7.1f} us | MFMA-first {alt[0]:7.1f} | burst {alt[1]:7.1f} | compiler {alt[2]:7.1f} | reads-first {alt[3]:7.1f}", flush=True)
+        continue
 
     def old():
         yt, _ = ops.transpose_to_bf16(y, pad_to=128, with_colsum=True)
