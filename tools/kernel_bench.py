@@ -17,6 +17,8 @@ sys.path.insert(0, str(ROOT))
 
 
 def timeit(fn, iters):
+    """ms per call.  Short loops are unreliable on this part (the same kernel measured 295 and 252 us in 20-launch loops depending on what
+    ran before it: clock / power state): warm up for >= 30 ms of GPU time and time at least `iters` calls AND >= 60 ms."""
     from multimodal_amd import ops
 
     for _ in range(3):
@@ -24,10 +26,19 @@ def timeit(fn, iters):
     torch.cuda.synchronize()
     t = ops.StreamTimer()
     t.start()
-    for _ in range(iters):
+    fn()
+    t.stop()
+    one = max(t.elapsed_ms(), 1e-3)
+    for _ in range(int(30.0 / one) + 1):
+        fn()
+    n = max(iters, int(60.0 / one) + 1)
+    torch.cuda.synchronize()
+    t = ops.StreamTimer()
+    t.start()
+    for _ in range(n):
         fn()
     t.stop()
-    return t.elapsed_ms() / iters
+    return t.elapsed_ms() / n
 
 
 def main():
