@@ -1918,17 +1918,20 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       if (rc == 0) rc = launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
       return true;
     };
+    // (re-measured with warm clocks, tools/kernel_bench.py: the persistent kernel wins from ~400 tiles up at every K — out-proj 625 vs 616 vs
+    //  602 TF/s for PP / P / P + split, text MLP-up 691 / 663 / 620, patch embedding 863 / 851 / 838 — and the row-range split only pays
+    //  with long K: MLP-down 891 with it, 836-838 without)
     if (t256 < 96) {
       v = 6;
-    } else if ((p.K & 127) == 0 && (t256 >= 1024 || (t256 >= 512 && p.K >= 2048))) {
+    } else if ((p.K & 127) == 0 && t256 >= 400) {
       v = 18;  // many tiles per CU: the persistent kernel hides each tile's first-stage load behind the previous epilogue
-      // row-range split in front of it for the 2-3 round grids with long K (MLP-down, 591 tiles: 855 -> 896 TF/s).  (The persistent kernel also
-      // wins by 2-7 % on the 512-1023-tile, K <= 768 shapes — out-proj, text MLP-up — but they stay on the P kernel so that the dominant
-      // kernel's instantiation, gemm_bf16_nt_kernel_pp<false, QuickGELU>, is launched for ONE shape only and its rocprof average is that shape's.)
       if (p.K >= 2048 && try_split(true)) return rc;
+      // the large-M and the small-M launches get different instantiations (tile-order group 8 / 4: equal speed), so that a kernel name in a
+      // rocprof summary is ONE shape class — the bench's dominant kernel, gemm_bf16_nt_kernel_pp<false, QuickGELU, 8, ...>, is the ViT MLP-up only
+      if (p.M < 32768) return launch_tiled_pp<OUT_F32, ACT, 4, 2, 4, OUT_F32 ? 0 : 2>(p, st);
     } else {
       v = 7;
-      if (try_split(false)) return rc;
+      if (p.K >= 2048 && try_split(false)) return rc;
     }
   }
   {
