@@ -63,18 +63,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
   bf16* Ks = reinterpret_cast<bf16*>(smem);                       // [SP][kKStride]
   // V: row-major [SP][kKStride] read through ds_read_b64_tr_b16 (no transposed copy, staged with the same 16-byte stores as K);
   // S > 256 keeps the transposed [64][VS] image (two workgroups per CU only fit with its smaller footprint)
-  constexpr bool VTR = NKT <= 8 && (ABL & 1) == 0;
+  constexpr bool VTR = NKT <= 8 && (ABL & 1) == 0;  // (ABL & 256 keeps it)
   bf16* Vt = reinterpret_cast<bf16*>(smem + SP * kKStride * 2);   // VTR: [SP][kKStride], else [64][VS]
 
   const int D = H * kDh;
-  const size_t row_stride = (size_t)3 * D;
+  // ABL & 256 (layout experiment): qkv given HEAD-major, [3H][B*S][64] — every (batch, head) slice of q, k, v is one contiguous block
+  constexpr bool HM = (ABL & 256) != 0;
+  const size_t Mtot = (size_t)(BH / H) * S;
+  const size_t row_stride = HM ? (size_t)kDh : (size_t)3 * D;
+  const size_t k_off = HM ? (size_t)H * Mtot * kDh : (size_t)D, v_off = 2 * k_off;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int nqt = (S + 31) >> 5;
   const int srow = tid >> 3, schunk = tid & 7;
 
-  auto item_base = [&](int item) { return qkv + (size_t)(item / H) * S * row_stride + (item % H) * kDh; };
+  auto item_base = [&](int item) {
+    if constexpr (HM) return qkv + ((size_t)(item % H) * Mtot + (size_t)(item / H) * S) * kDh;
+    else return qkv + (size_t)(item / H) * S * row_stride + (item % H) * kDh;
+  };
 
   // NW waves stage NW*8 rows per pass; with NW = 8 (16 waves per CU at 2 resident workgroups) the waits of one wave (43 % of
   // wave-cycles in the 4-wave form: PMC SQ_WAIT_ANY) are covered by three others on the same SIMD instead of one
@@ -87,8 +94,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
 #pragma unroll
       for (int j = 0; j < 8; ++j) { kreg[i][j] = (bf16)0.f; vreg[i][j] = (bf16)0.f; }
       if (r < S && (ABL & 4) == 0) {
-        kreg[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + D + schunk * 8);
-        vreg[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + 2 * D + schunk * 8);
+        kreg[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + k_off + schunk * 8);
+        vreg[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)r * row_stride + v_off + schunk * 8);
       }
     }
   };
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
         }
       };
 
-      if constexpr (!CAUSAL && (ABL & ~8) == 0) {
+      if constexpr (!CAUSAL && (ABL & ~(8 | 256)) == 0) {
         // Software-pipelined key loop (fully unrolled).  The serial form below spends 43 % of its wave-cycles in s_waitcnt (r01 PMC,
         // profiles/r01_pmc_attention_fwd.txt): ds_read -> 4 chained MFMAs -> ~100 softmax VALU -> ds_read -> 4 MFMAs, nothing
         // overlapping inside a wave.  Here QK^T of tile kt+1 is issued BEFORE the softmax of tile kt (its K fragments were read one
@@ -1309,6 +1316,7 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
       case 8: return launch_attn<7, false, 8>(qkv, out, B, S, H, scale, st, lse);
       case 128: return launch_attn<7, false, 128>(qkv, out, B, S, H, scale, st, lse);
       case 136: return launch_attn<7, false, 136>(qkv, out, B, S, H, scale, st, lse);
+      case 256: return launch_attn<7, false, 256>(qkv, out, B, S, H, scale, st, lse);
     }
   }
 #define ATTN_CASE(N)                                                              \
