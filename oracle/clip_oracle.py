@@ -323,7 +323,10 @@ def flava_transformer_encoder(x: Array, sd, prefix: str, heads: int, eps: float,
 
 
 def flava_pooler(hidden: Array, sd, prefix: str) -> Array:
-    """Pooler: tanh(Linear(hidden[:, 0])) (modules/losses/flava.py:84-97)."""
+    """Pooler: tanh(Linear(hidden[:, 0])) (modules/losses/flava.py:84-97); a pooler without parameters is nn.Identity (the
+    reference's encoder KATs build their encoders with pooler=nn.Identity())."""
+    if prefix + "dense.weight" not in sd:
+        return hidden
     return np.tanh(hidden[:, 0] @ sd[prefix + "dense.weight"].T + sd[prefix + "dense.bias"])
 
 
@@ -389,7 +392,7 @@ def flava_classification(sd, hidden_state: Array, labels: Array, n_linear: int, 
 
 
 def flava_image_encoder(sd, prefix: str, pixel_values: Array, heads: int, image_patches_mask: Optional[Array] = None,
-                        eps: float = 1e-12, dtype=np.float32, interpolate_pos_encoding: bool = False):
+                        eps: float = 1e-12, dtype=np.float32, interpolate_pos_encoding: bool = False, final_eps: Optional[float] = None):
     """ImageTransformer.forward (models/flava/image_encoder.py:204-234) incl. ImageEmbeddings (:139-177)."""
     sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
     x = np.asarray(pixel_values).astype(dtype)
@@ -405,13 +408,13 @@ def flava_image_encoder(sd, prefix: str, pixel_values: Array, heads: int, image_
         pos = flava_interpolate_pos_encoding(pos, emb.shape[1], x.shape[2], x.shape[3], w.shape[2]).astype(dtype)
     emb = np.concatenate([cls, emb], axis=1) + pos
     last, hidden, attns = flava_transformer_encoder(emb, sd, prefix + "encoder.", heads, eps)
-    seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps)
+    seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps if final_eps is None else final_eps)
     return {"last_hidden_state": seq, "pooler_output": flava_pooler(seq, sd, prefix + "pooler."), "hidden_states": hidden,
             "attentions": attns}
 
 
 def flava_text_encoder(sd, prefix: str, input_ids: Array, heads: int, pad_token_id: int = 0, eps: float = 1e-12,
-                       attention_mask: Optional[Array] = None, dtype=np.float32):
+                       attention_mask: Optional[Array] = None, dtype=np.float32, final_eps: Optional[float] = None):
     """BERTTextEncoder.forward (modules/encoders/bert_text_encoder.py:67-120) + BERTTextEmbeddings (text_embedding.py:74-104)."""
     sd = _cast({k: v for k, v in sd.items() if k.startswith(prefix)}, dtype)
     ids = np.asarray(input_ids)
@@ -422,7 +425,7 @@ def flava_text_encoder(sd, prefix: str, input_ids: Array, heads: int, pad_token_
          + sd[prefix + "embeddings.token_type_embeddings.weight"][0][None, None])
     e = layer_norm(e, sd[prefix + "embeddings.layer_norm.weight"], sd[prefix + "embeddings.layer_norm.bias"], eps)
     last, hidden, attns = flava_transformer_encoder(e, sd, prefix + "encoder.", heads, eps, key_mask=attention_mask)
-    seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps)
+    seq = layer_norm(last, sd[prefix + "layernorm.weight"], sd[prefix + "layernorm.bias"], eps if final_eps is None else final_eps)
     return {"last_hidden_state": seq, "pooler_output": flava_pooler(seq, sd, prefix + "pooler."), "hidden_states": hidden,
             "attentions": attns}
 

@@ -63,3 +63,60 @@ def test_pretraining_loss_oracle_vs_reference_fixture(golden):
     assert abs(float(neg["itm"]["loss"]) - float(z["allneg.itm_loss"])) <= 2e-5
     assert abs(float(neg["mmm_text"]["loss"]) - float(z["allneg.mmm_text_loss"])) <= 2e-5
     assert np.abs(neg["mmm_text"]["logits"] - z["allneg.mmm_text_logits"]).max() <= 2e-5
+
+
+def test_reference_image_encoder_kats():
+    """tests/models/flava/test_image_encoder.py:22-140 of the reference: seed 0, ImageEmbeddings(2, 1, hidden 2) + one pre-norm layer +
+    nn.LayerNorm(2) + Identity pooler on an all-ones image — its hard-coded embeddings / hidden states / last_hidden_state."""
+    import torch
+    from torch import nn
+
+    from multimodal_amd.models.flava.image_encoder import ImageEmbeddings, ImageTransformer
+    from multimodal_amd.models.flava.transformer import TransformerEncoder
+    from tests.conftest import set_rng_seed
+
+    set_rng_seed(0)
+    emb = ImageEmbeddings(image_size=2, patch_size=1, hidden_size=2)
+    enc = TransformerEncoder(n_layer=1, d_model=2, n_head=1, dim_feedforward=1, activation=nn.GELU, norm_first=True)
+    model = ImageTransformer(embeddings=emb, encoder=enc, layernorm=nn.LayerNorm(2), pooler=nn.Identity())
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    out = oc.flava_image_encoder(sd, "", np.ones((2, 3, 2, 2), dtype=np.float32), heads=1, eps=1e-12, final_eps=1e-5)
+    row = lambda a, b: np.array([[a] + [b] * 4] * 2, dtype=np.float64)
+    np.testing.assert_allclose(out["hidden_states"][0], row([0.0, 0.0], [0.0224, 0.0573]), atol=1e-4)
+    np.testing.assert_allclose(out["hidden_states"][1], row([0.0008, 0.0008], [0.0232, 0.0581]), atol=1e-4)
+    np.testing.assert_allclose(out["last_hidden_state"], row([-0.0040, 0.0040], [-0.9840, 0.9840]), atol=1e-4)
+    assert out["pooler_output"] is out["last_hidden_state"]
+
+
+def test_reference_text_encoder_kats():
+    """tests/models/flava/test_text_encoder.py:26-140 of the reference: fixed embedding tables, seed 0, one pre-norm layer, with and
+    without an explicit attention mask."""
+    from functools import partial
+
+    import torch
+    from torch import nn
+
+    from multimodal_amd.models.flava.transformer import init_transformer_weights, TransformerEncoder
+    from multimodal_amd.modules.encoders.bert_text_encoder import BERTTextEncoder
+    from multimodal_amd.modules.layers.text_embedding import BERTTextEmbeddings
+    from tests.conftest import set_rng_seed
+
+    set_rng_seed(0)
+    w = torch.Tensor([[0, 1], [1, 0], [1, 1]])
+    te = BERTTextEmbeddings(hidden_size=2, vocab_size=3, max_position_embeddings=2, dropout=0)
+    te.word_embeddings = nn.Embedding.from_pretrained(w)
+    te.position_embeddings = nn.Embedding.from_pretrained(w)
+    te.token_type_embeddings = nn.Embedding.from_pretrained(w)
+    enc = TransformerEncoder(n_layer=1, d_model=2, n_head=1, dim_feedforward=1, activation=nn.GELU, norm_first=True)
+    model = BERTTextEncoder(embeddings=te, encoder=enc, layernorm=nn.LayerNorm(2), pooler=nn.Identity(),
+                            weight_init_fn=partial(init_transformer_weights, initializer_range=0.02))
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    ids = np.array([[0, 1]])
+    out = oc.flava_text_encoder(sd, "", ids, heads=1, final_eps=1e-5)  # default mask = (ids != pad 0): key 0 is masked
+    np.testing.assert_allclose(out["hidden_states"][0], [[[1.0, -1.0], [-1.0, 1.0]]], atol=1e-4)
+    np.testing.assert_allclose(out["hidden_states"][1], [[[1.0008, -0.9994], [-0.9997, 1.0012]]], atol=1e-4)
+    np.testing.assert_allclose(out["last_hidden_state"], [[[1.0, -1.0], [-1.0, 1.0]]], atol=1e-4)
+    np.testing.assert_allclose(np.stack(out["attentions"])[0], [[[[0.0, 1.0], [0.0, 1.0]]]], atol=1e-6)
+    masked = oc.flava_text_encoder(sd, "", ids, heads=1, final_eps=1e-5, attention_mask=np.array([[1, 0]]))
+    np.testing.assert_allclose(masked["hidden_states"][1], [[[0.9997, -1.0012], [-1.0008, 0.9994]]], atol=1e-4)
+    np.testing.assert_allclose(np.stack(masked["attentions"])[0], [[[[1.0, 0.0], [1.0, 0.0]]]], atol=1e-6)
