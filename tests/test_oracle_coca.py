@@ -58,3 +58,65 @@ def test_coca_text_mask_matches_reference_build_mask():
     pm = (ids != 0).unsqueeze(1)
     ref = (F.pad(pm, (1, 0, pm.shape[2], 0), value=1.0) * torch.tril(torch.ones(5, 5)).bool()).unsqueeze(1)
     assert np.array_equal(oc.coca_text_mask(ids.numpy(), 0), ref.bool().numpy())
+
+
+@pytest.mark.parametrize("pad_idx,expected_pooled", [
+    (0, [[5.5019, -4.5114, 3.0416], [3.4487, -6.2877, 3.1439]]),
+    (None, [[5.5019, -4.5114, 3.0416], [3.4142, -6.3097, 3.1282]]),
+])
+def test_reference_text_decoder_kats(pad_idx, expected_pooled):
+    """tests/models/coca/test_text_decoder.py:186-252 of the reference (embed_cls=True rows): all parameters 1.0
+    (init_weights_with_constant), then seed 0 and nn.init.normal_ on the token embeddings, text projection, the four attention
+    projections of both layers and the CLS embedding, in that order; pooled output and per-token means are hard-coded there."""
+    import torch
+    from torch import nn
+
+    from multimodal_amd.models.coca.text_decoder import CoCaTextDecoder
+    from tests.conftest import set_rng_seed
+
+    dec = CoCaTextDecoder(vocab_size=12, num_positions=6, embedding_dim=8, n_layer=2, n_head=2, dim_feedforward=32, output_dim=3,
+                          pad_idx=pad_idx, embed_cls=True)
+    with torch.no_grad():
+        for p_ in dec.parameters():
+            p_.fill_(1.0)
+    set_rng_seed(0)
+    nn.init.normal_(dec.embeddings.token_embeddings.weight)
+    nn.init.normal_(dec.text_projection.weight)
+    for block in dec.transformer_decoder.layer:
+        for name in ("q_proj", "k_proj", "v_proj", "output_proj"):
+            nn.init.normal_(getattr(block.attention, name).weight)
+    nn.init.normal_(dec.embeddings.cls_embedding)
+    sd = {k: v.detach().numpy() for k, v in dec.state_dict().items()}
+    ids = np.array([[2, 4, 5, 7, 9, 1], [6, 8, 1, 0, 0, 0]])
+    pooled, tokens = oc.coca_text_decoder(sd, "", ids, heads=2, pad_idx=pad_idx)
+    np.testing.assert_allclose(pooled, expected_pooled, atol=1e-3)
+    assert tokens.shape == (2, 5, 8)
+    np.testing.assert_allclose(tokens.mean(-1), [[585.0038, 587.7021, 588.5288, 585.5997, 588.6697], [586.2949, 585.1484, 588.0995, 590.9081, 591.0029]],
+                               atol=2e-3)
+
+
+def test_reference_multimodal_decoder_kat():
+    """tests/models/coca/test_multimodal_decoder.py:30-112 of the reference: all parameters 1.0, then arange weights in the last MLP
+    Linear, the output projection and the final LayerNorm; text = arange(0,1,1/40), image = arange(10,20,1/8); every output row is
+    [58.2492, 66.7214, 75.1935]."""
+    import torch
+    from torch import nn
+
+    from multimodal_amd.models.coca.multimodal_decoder import CoCaMultimodalDecoder
+
+    dec = CoCaMultimodalDecoder(input_seq_len=5, text_embedding_dim=4, n_layer=2, n_head=2, dim_feedforward=16, output_dim=3, final_layer_norm_eps=1e-5)
+    with torch.no_grad():
+        for p_ in dec.parameters():
+            p_.fill_(1.0)
+    last = dec.transformer_decoder.layer[1].feedforward.model[2]
+    last.weight = nn.Parameter(torch.arange(last.weight.numel(), dtype=torch.float).reshape(last.weight.shape))
+    dec.output_projection.weight = nn.Parameter(torch.arange(dec.output_projection.weight.numel(), dtype=torch.float).reshape(dec.output_projection.weight.T.shape).T)
+    fln = dec.transformer_decoder.final_layer_norm
+    fln.weight = nn.Parameter(torch.arange(fln.weight.numel(), dtype=torch.float))
+    sd = {k: v.detach().numpy() for k, v in dec.state_dict().items()}
+    text = np.arange(0.0, 1.0, 1.0 / 40, dtype=np.float32).reshape(2, 5, 4)
+    image = np.arange(10.0, 20.0, 1.0 / 8, dtype=np.float32).reshape(2, 10, 4)
+    causal = np.tril(np.ones((5, 5), dtype=bool))
+    h = oc.layers_decoder(text, image, sd, "transformer_decoder.", 2, 1e-5, attend=causal, final_eps=1e-5)
+    out = h @ sd["output_projection.weight"].T
+    np.testing.assert_allclose(out, np.broadcast_to(np.array([58.2492, 66.7214, 75.1935]), (2, 5, 3)), atol=1e-4)
