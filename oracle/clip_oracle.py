@@ -606,27 +606,34 @@ def mha_with_cache(q_in: Array, kv_in: Array, sd, prefix: str, heads: int, atten
     return (out, (k, v)) if use_cache else out
 
 
-def _ffn(x: Array, sd, prefix: str) -> Array:
-    h = gelu_erf(x @ sd[prefix + "model.0.weight"].T + sd[prefix + "model.0.bias"])
+def _ffn(x: Array, sd, prefix: str, activation=None) -> Array:
+    """MLP(d, d, dim_feedforward) of the layers (modules/layers/mlp.py): Linear -> activation -> Linear; the models on the path pass
+    nn.GELU (default here), the class default — used by the reference's constant-weight KATs — is nn.ReLU."""
+    h = (activation or gelu_erf)(x @ sd[prefix + "model.0.weight"].T + sd[prefix + "model.0.bias"])
     return h @ sd[prefix + "model.2.weight"].T + sd[prefix + "model.2.bias"]
 
 
-def layers_encoder_layer(x: Array, sd, prefix: str, heads: int, eps: float, norm_first: bool = True, attend=None) -> Array:
-    """layers.transformer.TransformerEncoderLayer (modules/layers/transformer.py:96-156), GELU feed-forward."""
+def relu(x: Array) -> Array:
+    return np.maximum(x, 0)
+
+
+def layers_encoder_layer(x: Array, sd, prefix: str, heads: int, eps: float, norm_first: bool = True, attend=None, activation=None) -> Array:
+    """layers.transformer.TransformerEncoderLayer (modules/layers/transformer.py:96-156), GELU feed-forward unless `activation`."""
     ln = lambda name, t: layer_norm(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], eps)
     if norm_first:
         a = mh_self_attention(ln("attention_layernorm", x), sd, prefix + "attention.", heads, attend) + x
-        return a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.")
+        return a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.", activation)
     a = ln("attention_layernorm", mh_self_attention(x, sd, prefix + "attention.", heads, attend) + x)
-    return ln("feedforward_layernorm", a + _ffn(a, sd, prefix + "feedforward."))
+    return ln("feedforward_layernorm", a + _ffn(a, sd, prefix + "feedforward.", activation))
 
 
-def layers_encoder(x: Array, sd, prefix: str, heads: int, eps: float, norm_first: bool = True, final_eps: Optional[float] = None):
+def layers_encoder(x: Array, sd, prefix: str, heads: int, eps: float, norm_first: bool = True, final_eps: Optional[float] = None,
+                   activation=None):
     """layers.transformer.TransformerEncoder.forward (:222-262) with return_hidden_states=True."""
     hidden, n = [], 0
     while f"{prefix}layer.{n}.attention.input_proj.weight" in sd:
         hidden.append(x)
-        x = layers_encoder_layer(x, sd, f"{prefix}layer.{n}.", heads, eps, norm_first)
+        x = layers_encoder_layer(x, sd, f"{prefix}layer.{n}.", heads, eps, norm_first, activation=activation)
         n += 1
     hidden.append(x)
     if final_eps:
@@ -634,10 +641,21 @@ def layers_encoder(x: Array, sd, prefix: str, heads: int, eps: float, norm_first
     return x, hidden
 
 
-def layers_decoder_layer(x: Array, enc: Optional[Array], sd, prefix: str, heads: int, eps: float, attend=None, past=None, use_cache=False):
+def layers_decoder_layer(x: Array, enc: Optional[Array], sd, prefix: str, heads: int, eps: float, attend=None, past=None, use_cache=False,
+                         norm_first: bool = True, activation=None):
     """TransformerDecoderLayer._forward_prenorm (:398-433): self-attention (optionally over cached keys / values, :336-359), optional
-    cross-attention, feed-forward.  use_cache -> (output, present_key_value)."""
+    cross-attention, feed-forward; norm_first=False = _forward_postnorm (:435-472).  use_cache -> (output, present_key_value)."""
     ln = lambda name, t: layer_norm(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], eps)
+    if not norm_first:
+        r = mha_with_cache(x, x, sd, prefix + "attention.", heads, attend, past=past, use_cache=use_cache)
+        present = None
+        if use_cache:
+            r, present = r
+        a = ln("attention_layernorm", r + x)
+        if prefix + "cross_attention.q_proj.weight" in sd:
+            a = ln("cross_attention_layernorm", mha_with_cache(a, enc, sd, prefix + "cross_attention.", heads) + a)
+        y = ln("feedforward_layernorm", a + _ffn(a, sd, prefix + "feedforward.", activation))
+        return (y, present) if use_cache else y
     h = ln("attention_layernorm", x)
     r = mha_with_cache(h, h, sd, prefix + "attention.", heads, attend, past=past, use_cache=use_cache)
     present = None
@@ -646,7 +664,7 @@ def layers_decoder_layer(x: Array, enc: Optional[Array], sd, prefix: str, heads:
     a = r + x
     if enc is not None and prefix + "cross_attention.q_proj.weight" in sd:
         a = mha_with_cache(ln("cross_attention_layernorm", a), enc, sd, prefix + "cross_attention.", heads) + a
-    y = a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.")
+    y = a + _ffn(ln("feedforward_layernorm", a), sd, prefix + "feedforward.", activation)
     return (y, present) if use_cache else y
 
 

@@ -120,3 +120,27 @@ def test_reference_multimodal_decoder_kat():
     h = oc.layers_decoder(text, image, sd, "transformer_decoder.", 2, 1e-5, attend=causal, final_eps=1e-5)
     out = h @ sd["output_projection.weight"].T
     np.testing.assert_allclose(out, np.broadcast_to(np.array([58.2492, 66.7214, 75.1935]), (2, 5, 3)), atol=1e-4)
+
+
+def test_reference_attention_pooler_kats():
+    """tests/modules/layers/test_attention_pooler.py:47-112 of the reference: constant-1 parameters, randn inputs (seed 0): output sums
+    144 for AttentionPooler(4 -> 6, 2 heads, 12 queries) and [144, 20] for the cascade with a second 1-query pooler (6 -> 10)."""
+    import torch
+
+    from multimodal_amd.modules.layers.attention_pooler import AttentionPooler
+    from tests.conftest import set_rng_seed
+
+    set_rng_seed(0)
+    x = torch.randn(2, 8, 4).numpy()
+    p1 = AttentionPooler(input_embed_dim=4, output_embed_dim=6, n_head=2, n_queries=12)
+    p2 = AttentionPooler(input_embed_dim=6, output_embed_dim=10, n_head=2, n_queries=1)
+    sds = []
+    for p_ in (p1, p2):
+        with torch.no_grad():
+            for q in p_.parameters():
+                q.fill_(1.0)
+        sds.append({k: v.numpy() for k, v in p_.state_dict().items()})
+    y1 = oc.attention_pooler(x, sds[0], "", 2)
+    assert y1.shape == (2, 12, 6) and abs(float(y1.sum()) - 144.0) <= 1e-3
+    y2 = oc.attention_pooler(y1, sds[1], "", 2)
+    assert y2.shape == (2, 1, 10) and abs(float(y2.sum()) - 20.0) <= 1e-3
