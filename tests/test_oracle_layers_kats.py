@@ -54,3 +54,45 @@ def test_decoder_layer_without_cross_attention_kat(norm_first, expected):
     y = oc.layers_decoder_layer(np.array([[[1.0, 2.0], [4.0, 2.0], [1.0, 1.0]]], dtype=np.float32), None, sd, "", 1, 1e-12, norm_first=norm_first,
                                 activation=oc.relu)
     np.testing.assert_allclose(y, expected, atol=1e-3)
+
+
+def _decoder_layer_sd(d_model, norm_first, use_cross_attention, custom_init=False):
+    from multimodal_amd.modules.layers.transformer import TransformerDecoderLayer
+
+    m = TransformerDecoderLayer(d_model=d_model, n_head=1, dim_feedforward=2, norm_first=norm_first, use_cross_attention=use_cross_attention)
+    sd = _const_sd(m)
+    if custom_init:  # reference :208-214: every LayerNorm parameter = arange
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if "norm" in name:
+                    p.copy_(torch.arange(p.shape[0]).float())
+        sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    return sd
+
+
+HID = np.array([[[1.0, 2.0, 3.0, 4.0], [4.0, 2.0, 0.0, 2.0]]], dtype=np.float32)
+ENC = np.array([[[5.0, 6.0, 7.0, 8.0], [8.0, 9.0, 11.0, 12.0], [2.0, 1.0, 0.0, 2.0], [0.0, 0.0, 4.0, 4.0]]], dtype=np.float32)
+
+
+@pytest.mark.parametrize("norm_first,mask,expected", [
+    (True, [[False, True], [True, False]], [[[207.6306, 208.6306, 209.6306, 210.6306], [225.2317, 223.2317, 221.2317, 223.2317]]]),
+    (True, None, [[[236.8329, 237.8329, 238.8329, 239.8329], [225.2317, 223.2317, 221.2317, 223.2317]]]),
+    (False, [[False, True], [True, False]], [[[0.0, 0.2642, 1.7713, 8.0006], [0.0, 0.6952, 0.5130, 8.1252]]]),
+    (False, None, [[[0.0, 0.2642, 1.7713, 8.0006], [0.0, 0.6952, 0.5130, 8.1252]]]),
+])
+def test_decoder_layer_with_cross_attention_kats(norm_first, mask, expected):
+    """reference test_transformer.py:262-340: constant weights, arange LayerNorm parameters, optional boolean self-attention mask."""
+    sd = _decoder_layer_sd(4, norm_first, True, custom_init=True)
+    y = oc.layers_decoder_layer(HID, ENC, sd, "", 1, 1e-12, attend=None if mask is None else np.array(mask), norm_first=norm_first, activation=oc.relu)
+    np.testing.assert_allclose(y, expected, atol=1e-3)
+
+
+@pytest.mark.parametrize("norm_first,cur", [(True, [[5.0] * 4, [5.0] * 4]), (False, [[11.0] * 4, [9.0] * 4])])
+def test_decoder_layer_kv_caching_kat(norm_first, cur):
+    """reference test_transformer.py:342-382 (test_kv_caching): the returned cache = the past keys / values followed by this call's."""
+    sd = _decoder_layer_sd(4, norm_first, True)
+    pk = np.array([[[[0.0, 1.0, 2.0, 3.0], [4.0, 5.0, 6.0, 7.0]]]], dtype=np.float32)
+    pv = np.array([[[[7.0, 6.0, 5.0, 4.0], [3.0, 2.0, 1.0, 0.0]]]], dtype=np.float32)
+    _, (k, v) = oc.layers_decoder_layer(HID, ENC, sd, "", 1, 1e-12, past=(pk, pv), use_cache=True, norm_first=norm_first, activation=oc.relu)
+    np.testing.assert_allclose(k, np.concatenate([pk, np.array([[cur]], dtype=np.float32)], axis=2), atol=1e-4)
+    np.testing.assert_allclose(v, np.concatenate([pv, np.array([[cur]], dtype=np.float32)], axis=2), atol=1e-4)
