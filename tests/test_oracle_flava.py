@@ -120,3 +120,17 @@ def test_reference_text_encoder_kats():
     masked = oc.flava_text_encoder(sd, "", ids, heads=1, final_eps=1e-5, attention_mask=np.array([[1, 0]]))
     np.testing.assert_allclose(masked["hidden_states"][1], [[[0.9997, -1.0012], [-1.0008, 0.9994]]], atol=1e-4)
     np.testing.assert_allclose(np.stack(masked["attentions"])[0], [[[[1.0, 0.0], [1.0, 0.0]]]], atol=1e-6)
+
+
+def test_reference_multi_head_attention_kat():
+    """tests/modules/layers/test_attention.py:44-82 of the reference: seed 4, MultiHeadAttention(3, 3, 1 head, SelfAttention) with its default
+    initialisation on 2 * ones(1, 2, 2, 2, 3) (8 latent positions, flattened): every row is [1.069666, 1.304498, -0.016060]."""
+    from multimodal_amd.modules.layers.attention import MultiHeadAttention, SelfAttention
+    from tests.conftest import set_rng_seed
+
+    set_rng_seed(4)
+    mha = MultiHeadAttention(3, 3, 1, SelfAttention(attn_dropout=0.0))
+    sd = {k: v.detach().numpy() for k, v in mha.state_dict().items()}
+    out, probs = oc.flava_attention(2 * np.ones((1, 8, 3), dtype=np.float32), sd, "", 1, None)
+    np.testing.assert_allclose(out, np.broadcast_to(np.array([1.069666, 1.304498, -0.016060], dtype=np.float32), (1, 8, 3)), atol=1e-4)
+    np.testing.assert_allclose(probs, np.full((1, 1, 8, 8), 0.125), atol=1e-6)

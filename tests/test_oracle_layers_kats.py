@@ -96,3 +96,27 @@ def test_decoder_layer_kv_caching_kat(norm_first, cur):
     _, (k, v) = oc.layers_decoder_layer(HID, ENC, sd, "", 1, 1e-12, past=(pk, pv), use_cache=True, norm_first=norm_first, activation=oc.relu)
     np.testing.assert_allclose(k, np.concatenate([pk, np.array([[cur]], dtype=np.float32)], axis=2), atol=1e-4)
     np.testing.assert_allclose(v, np.concatenate([pv, np.array([[cur]], dtype=np.float32)], axis=2), atol=1e-4)
+
+
+Q3 = np.array([[[1.0, 2.0, 3.0, 1.0], [4.0, 3.0, 2.0, 1.0], [1.0, 1.0, 1.0, 1.0]]], dtype=np.float32)
+
+
+def test_multi_head_attention_kats():
+    """reference tests/modules/layers/test_multi_head_attention.py:17-220: constant-1 projections; self-attention rows of 45, cross-attention
+    (dim_kv = 2) rows of 25 (21 without biases), and the cache returned with use_cache = the past followed by this call's keys / values."""
+    from multimodal_amd.modules.layers.multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention
+
+    sd = _const_sd(MultiHeadSelfAttention(4, num_heads=2))
+    np.testing.assert_allclose(oc.mh_self_attention(Q3, sd, "", 2), np.full((1, 3, 4), 45.0), atol=1e-4)
+    sd = _const_sd(MultiHeadAttentionWithCache(4, 4, num_heads=2))
+    past = np.array([[[[7.0, 7.0], [9.0, 9.0], [4.0, 4.0]]] * 2], dtype=np.float32)
+    cur = np.array([[[[8.0, 8.0], [11.0, 11.0], [5.0, 5.0]]] * 2], dtype=np.float32)
+    out, (k, v) = oc.mha_with_cache(Q3, Q3, sd, "", 2, past=(past, past), use_cache=True)
+    np.testing.assert_allclose(out, np.full((1, 3, 4), 45.0), atol=1e-4)
+    np.testing.assert_allclose(k, np.concatenate([past, cur], axis=2), atol=1e-5)
+    np.testing.assert_allclose(v, np.concatenate([past, cur], axis=2), atol=1e-5)
+    kv = np.array([[[3.0, 2.0], [1.0, 1.0]]], dtype=np.float32)
+    sd = _const_sd(MultiHeadAttentionWithCache(4, 2, num_heads=2))
+    np.testing.assert_allclose(oc.mha_with_cache(Q3, kv, sd, "", 2), np.full((1, 3, 4), 25.0), atol=1e-4)
+    sd = _const_sd(MultiHeadAttentionWithCache(4, 2, num_heads=2, add_bias=False))
+    np.testing.assert_allclose(oc.mha_with_cache(Q3, kv, sd, "", 2), np.full((1, 3, 4), 21.0), atol=1e-4)
