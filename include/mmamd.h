@@ -222,6 +222,9 @@ int mmamd_dalle_pack(const float* src, void* dst, int dst_dtype, int n_out, int 
  * scale_factor=(scale_h, scale_w)) (torch's upsample_bicubic2d: A = -0.75, clamped taps). */
 int mmamd_bicubic_pos_embed(const float* pos, int n_side, int d, float* out, int h0, int w0, float scale_h, float scale_w,
                             mmamd_stream_t stream);
+/* out[b,s] = pad_id + (ids[b,s] != pad_id ? number of non-padding tokens in ids[b, :s+1] : 0)  (int64): the RoBERTa-style position ids of
+ * BERTTextEmbeddings.create_position_ids_from_input_ids (modules/layers/text_embedding.py:55-68), used when offset_pos_ids is set. */
+int mmamd_offset_position_ids(const int64_t* ids, int64_t pad_id, int64_t* out, int B, int S, mmamd_stream_t stream);
 /* labels[i] = keep[i] ? labels[i] : fill (in place; FLAVAForPreTraining's image_labels[~image_patches_mask] = -1, model.py:340-343). */
 int mmamd_mask_labels(int64_t* labels, const uint8_t* keep, int64_t fill, int64_t n, mmamd_stream_t stream);
 /* ReLU backward on fp32: dz = y > 0 ? dy : 0 (classifier MLP of FLAVAForClassification under autograd). */

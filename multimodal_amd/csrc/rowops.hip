@@ -584,6 +584,19 @@ __global__ __launch_bounds__(256) void bicubic_pos_embed_kernel(const float* __r
   }
 }
 
+// RoBERTa-style position ids (BERTTextEmbeddings.create_position_ids_from_input_ids, modules/layers/text_embedding.py:55-68): non-padding
+// tokens are numbered 1, 2, ... from the left, + pad_id; padding tokens get pad_id.  One thread per row (S <= 512: a serial scan).
+__global__ __launch_bounds__(64) void offset_position_ids_kernel(const long long* __restrict__ ids, long long pad_id, long long* __restrict__ out, int B, int S) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  long long run = 0;
+  for (int s_ = 0; s_ < S; ++s_) {
+    const bool tok = ids[(size_t)b * S + s_] != pad_id;
+    run += tok ? 1 : 0;
+    out[(size_t)b * S + s_] = (tok ? run : 0) + pad_id;
+  }
+}
+
 // labels[i] = keep[i] ? labels[i] : fill   (FLAVAForPreTraining: image_labels[~image_patches_mask] = -1, models/flava/model.py:340-343)
 __global__ __launch_bounds__(256) void mask_labels_kernel(long long* __restrict__ labels, const uint8_t* __restrict__ keep, long long fill, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -798,4 +811,12 @@ extern "C" int mmamd_mask_labels(int64_t* labels, const uint8_t* keep, int64_t f
   hipLaunchKernelGGL(mask_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long*)labels, keep,
                      (long long)fill, (long long)n);
   return launch_status("mask_labels");
+}
+
+extern "C" int mmamd_offset_position_ids(const int64_t* ids, int64_t pad_id, int64_t* out, int B, int S, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(ids && out && B >= 0 && S > 0, MMAMD_E_BADARG, "offset_position_ids: bad argument");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(offset_position_ids_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const long long*)ids, (long long)pad_id,
+                     (long long*)out, B, S);
+  return launch_status("offset_position_ids");
 }

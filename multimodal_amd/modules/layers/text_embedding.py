@@ -33,6 +33,11 @@ class BERTTextEmbeddings(nn.Module):
         self.offset_pos_ids = offset_pos_ids
         self._packed = PackedCache()
 
+    def create_position_ids_from_input_ids(self, input_ids: Tensor) -> Tensor:
+        """Non-padding tokens numbered from pad_token_id + 1, padding tokens = pad_token_id (reference :55-68); one row-scan kernel."""
+        ids = input_ids if input_ids.dtype == torch.int64 else input_ids.to(torch.int64)
+        return ops.offset_position_ids(ids if ids.is_contiguous() else ids.contiguous(), self.pad_token_id)
+
     def forward(
         self,
         input_ids: Optional[Tensor] = None,
@@ -47,7 +52,7 @@ class BERTTextEmbeddings(nn.Module):
         if inputs_embeds is not None:
             raise ops.MmamdError("inputs_embeds is not implemented on the MI355X path (pass input_ids)")
         if self.offset_pos_ids and position_ids is None:
-            raise ops.MmamdError("offset_pos_ids (RoBERTa position ids) is not implemented on the MI355X path; pass position_ids")
+            position_ids = self.create_position_ids_from_input_ids(input_ids)  # reference :88-89
         if self.training and self.dropout.p > 0:
             raise ops.MmamdError("embedding dropout > 0 in training mode is not implemented on the MI355X path")
         B, S = input_ids.shape

@@ -22,7 +22,7 @@ __all__ = [
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
-    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
+    "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
     "attention_x_bwd",
 ]
 
@@ -469,6 +469,15 @@ def bicubic_pos_embed(pos: torch.Tensor, h0: int, w0: int, scale_h: float, scale
     out = torch.empty((1 + h0 * w0, d), dtype=torch.float32, device=pos.device)
     check(_lib.lib().mmamd_bicubic_pos_embed(pos.data_ptr(), n_side, d, out.data_ptr(), int(h0), int(w0), float(scale_h), float(scale_w),
                                              _stream()), "mmamd_bicubic_pos_embed")
+    return out
+
+
+def offset_position_ids(ids: torch.Tensor, pad_id: int) -> torch.Tensor:
+    """RoBERTa-style position ids of int64 ids [B, S] (see mmamd_offset_position_ids)."""
+    _chk(ids, "input_ids", torch.int64)
+    B, S = ids.shape
+    out = torch.empty_like(ids)
+    check(_lib.lib().mmamd_offset_position_ids(ids.data_ptr(), int(pad_id), out.data_ptr(), B, S, _stream()), "mmamd_offset_position_ids")
     return out
 
 

@@ -612,3 +612,25 @@ def test_reference_full_size_classification_kat():
             assert out.logits.shape == (2, 2)
             assert abs(got[mode] - want) <= 1e-3, (mode, got[mode], want)
     print("reference KAT (0.7180 / 0.7020 / 0.6663):", {k: round(v, 4) for k, v in got.items()})
+
+
+def test_offset_position_ids_like_reference():
+    """BERTTextEmbeddings.create_position_ids_from_input_ids (modules/layers/text_embedding.py:55-68; the reference's
+    tests/modules/layers/test_text_embedding.py expects [[1, 2], [0, 1]] for ids [[1, 2], [0, 2]] with pad 0) and the offset_pos_ids path."""
+    from multimodal_amd.modules.layers.text_embedding import BERTTextEmbeddings
+
+    set_rng_seed(4)
+    emb = BERTTextEmbeddings(hidden_size=128, vocab_size=30, max_position_embeddings=16).cuda().eval()
+    ids = torch.tensor([[1, 2], [0, 2]]).cuda()
+    assert emb.create_position_ids_from_input_ids(ids).tolist() == [[1, 2], [0, 1]]
+    big = torch.randint(0, 30, (5, 12))
+    big[:, 7:] = 0
+    m = big.ne(0).int()
+    want = (torch.cumsum(m, dim=1) * m).long()  # the reference's formula, host side (test only)
+    got = emb.create_position_ids_from_input_ids(big.cuda())
+    assert torch.equal(got.cpu(), want)
+    emb2 = BERTTextEmbeddings(hidden_size=128, vocab_size=30, max_position_embeddings=16, offset_pos_ids=True).cuda().eval()
+    with torch.no_grad():
+        a = emb2(big.cuda())
+        b = emb2(big.cuda(), position_ids=want.cuda())
+    assert torch.equal(a, b)
