@@ -126,9 +126,9 @@ def patch_embed(images: Array, conv_w: Array) -> Array:
     """nn.Conv2d(3,w,k=p,s=p,bias=False) + flatten + permute (image_encoder.py:91-97) -> [B, g*g, w]."""
     B, C, H, W = images.shape
     w, _, p, _ = conv_w.shape
-    g = H // p
-    # [B,C,g,p,g,p] -> [B,g,g,C,p,p] -> [B,g*g,C*p*p]; k-order (c,py,px) == conv weight flattening
-    patches = images.reshape(B, C, g, p, g, p).transpose(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * p * p)
+    gh, gw = H // p, W // p  # (rectangular inputs: layers.PatchEmbeddings accepts them, modules/layers/patch_embedding.py:58-66)
+    # [B,C,gh,p,gw,p] -> [B,gh,gw,C,p,p] -> [B,gh*gw,C*p*p]; k-order (c,py,px) == conv weight flattening
+    patches = images[:, :, :gh * p, :gw * p].reshape(B, C, gh, p, gw, p).transpose(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p)
     return patches @ conv_w.reshape(w, -1).T
 
 

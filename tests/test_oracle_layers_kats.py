@@ -120,3 +120,25 @@ def test_multi_head_attention_kats():
     np.testing.assert_allclose(oc.mha_with_cache(Q3, kv, sd, "", 2), np.full((1, 3, 4), 25.0), atol=1e-4)
     sd = _const_sd(MultiHeadAttentionWithCache(4, 2, num_heads=2, add_bias=False))
     np.testing.assert_allclose(oc.mha_with_cache(Q3, kv, sd, "", 2), np.full((1, 3, 4), 21.0), atol=1e-4)
+
+
+def test_layers_patch_embeddings_kats():
+    """reference tests/modules/layers/test_patch_embedding.py:16-130 (eval-mode rows: plain, rectangular input, no CLS embedding)."""
+    from torch import nn
+
+    from multimodal_amd.modules.layers.patch_embedding import PatchEmbeddings
+
+    w = torch.tensor([[[[0.0]], [[1.0]], [[2.0]]], [[[3.0]], [[4.0]], [[5.0]]]])
+    ones = np.ones((2, 3, 2, 2), dtype=np.float32)
+    for include_cls in (True, False):
+        m = PatchEmbeddings(image_size=2, patch_size=1, hidden_size=2, use_image_masking=True, include_cls_embed=include_cls)
+        assert m.conv_projection.bias.sum().item() == 0
+        m.conv_projection.weight = nn.Parameter(w.clone())
+        sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+        rows = ([[0.0, 0.0]] if include_cls else []) + [[3.0, 12.0]] * 4
+        np.testing.assert_allclose(oc.layers_patch_embeddings(ones, sd, ""), np.array([rows, rows]), atol=1e-4)
+    m = PatchEmbeddings(image_size=(4, 6), patch_size=2, hidden_size=2, use_image_masking=False, num_channels=1)
+    m.conv_projection.weight = nn.Parameter(torch.tensor([[[[0.0, 0.0], [0.0, 0.0]]], [[[3.0, 3.0], [3.0, 3.0]]]]))
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    got = oc.layers_patch_embeddings(np.ones((1, 1, 4, 6), dtype=np.float32), sd, "")
+    np.testing.assert_allclose(got, np.array([[[0.0, 0.0]] + [[0.0, 12.0]] * 6]), atol=1e-4)
