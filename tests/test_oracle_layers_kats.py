@@ -142,3 +142,18 @@ def test_layers_patch_embeddings_kats():
     sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
     got = oc.layers_patch_embeddings(np.ones((1, 1, 4, 6), dtype=np.float32), sd, "")
     np.testing.assert_allclose(got, np.array([[[0.0, 0.0]] + [[0.0, 12.0]] * 6]), atol=1e-4)
+
+
+def test_mlp_no_hidden_layers_kat():
+    """reference tests/modules/layers/test_mlp.py:20-40 (seed 0, input drawn first, MLP(5, 3)); the rows with hidden layers run train-mode
+    dropout in the reference's test and are not reproducible across torch versions."""
+    from multimodal_amd.modules.layers.mlp import MLP
+    from tests.conftest import set_rng_seed
+
+    set_rng_seed(0)
+    x = torch.randn((4, 5))
+    mlp = MLP(in_dim=5, out_dim=3)
+    sd = {"classifier." + k: v.detach().numpy() for k, v in mlp.state_dict().items()}
+    got = oc.mlp_forward(x.numpy(), sd, "classifier.", n_linear=1)
+    want = [[0.165539, 0.455205, -0.331436], [1.186858, -0.380429, -0.888067], [0.813341, -1.444306, 0.507025], [1.710142, -0.744562, -0.199996]]
+    np.testing.assert_allclose(got, want, atol=1e-5)
