@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
 
       if constexpr (!CAUSAL && (ABL & ~(8 | 256)) == 0) {
         // Software-pipelined key loop (fully unrolled).  The serial form below spends 43 % of its wave-cycles in s_waitcnt (r01 PMC,
-        // profiles/r01_pmc_attention_fwd.txt): ds_read -> 4 chained MFMAs -> ~100 softmax VALU -> ds_read -> 4 MFMAs, nothing
+        // profiles/r01_pmc_attention_fwd_before_pipelining.txt): ds_read -> 4 chained MFMAs -> ~100 softmax VALU -> ds_read -> 4 MFMAs, nothing
         // overlapping inside a wave.  Here QK^T of tile kt+1 is issued BEFORE the softmax of tile kt (its K fragments were read one
         // tile earlier) and the V fragments of tile kt are read before its softmax, so the matrix pipe and the LDS work under the VALU.
         auto read_k = [&](int kt, bf16x8 (&kf)[4]) {
