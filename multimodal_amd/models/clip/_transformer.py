@@ -101,9 +101,10 @@ class TransformerStack(nn.Module):
 
 
 def forbid_training_forward(module: nn.Module) -> None:
-    """The engine is forward-only this round (SURVEY.md §8f rank 1 = backward).  Refuse, loudly, to return
-    non-differentiable outputs to a training loop instead of silently detaching them."""
+    """Standalone sub-modules (a single encoder layer, a bare tower called outside its model) have no differentiable forward: training
+    runs through the stack-level autograd nodes (multimodal_amd/_autograd.py) that the models and encoders dispatch to.  Refuse, loudly,
+    to return non-differentiable outputs to a training loop instead of silently detaching them."""
     if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
-            f"{type(module).__name__}: backward is not implemented on the MI355X path yet; call .eval() and/or "
-            "run under torch.no_grad() for forward + loss")
+            f"{type(module).__name__}: this module has no differentiable forward of its own on the MI355X path (training goes through the "
+            "enclosing encoder / model); call .eval() and/or run under torch.no_grad() for inference")

@@ -31,8 +31,8 @@ class TransformerOutput(NamedTuple):
 
 def _forbid_training(module: nn.Module) -> None:
     if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(f"{type(module).__name__}: backward is not implemented on the MI355X path yet; call .eval() "
-                                  "and/or run under torch.no_grad()")
+        raise NotImplementedError(f"{type(module).__name__}: a standalone layer has no differentiable forward on the MI355X path (training runs "
+                                  "through TransformerEncoder / TransformerDecoder); call .eval() and/or run under torch.no_grad()")
 
 
 def _ln(packed: PackedCache, ln: nn.LayerNorm, x: Tensor, out_dtype: torch.dtype) -> Tensor:
