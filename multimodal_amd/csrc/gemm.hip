@@ -2084,7 +2084,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 }  // namespace mmamd
 
-template <bool TNM, int SCH = 0>
+template <bool TNM, int SCH = 0, int GMV = 8>
 static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
                             mmamd_stream_t stream) {
   const int KT = K / 64;
@@ -2097,7 +2097,7 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   p.kt_chunk = chunk; p.c_split_stride = (long long)M * N; p.res_mode = 0;
   p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0;
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, 8, 0, true, TNM, SCH>;
+  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, GMV, 0, true, TNM, SCH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -2141,6 +2141,8 @@ extern "C" int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, 
   if (g_gemm_variant == 41) return gemm_splitk_impl<true, 1>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
   if (g_gemm_variant == 42) return gemm_splitk_impl<true, 2>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
   if (g_gemm_variant == 43) return gemm_splitk_impl<true, 3>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 44) return gemm_splitk_impl<true, 0, 1>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);  // tile order: column tile innermost
+  if (g_gemm_variant == 45) return gemm_splitk_impl<true, 0, 2>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
 #endif
   // (fragment-read placement variants 40-43 differ by less than the run-to-run spread of a 20-launch loop — the same kernel measured 295 and
   //  252 us depending on its position in the loop — and the training step time is unchanged by them: the MFMA-first order stays)
