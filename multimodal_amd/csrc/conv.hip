@@ -80,14 +80,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(const ConvArgs p
   const char* Wb = reinterpret_cast<const char*>(p.W);
   const int kpt = p.Cin >> 6;  // K-tiles per tap
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p_c)smem;
+  // K walk: channel chunk OUTER, tap INNER.  The nine taps of one 64-channel chunk read the same ~(256 + 2 GW) activation rows shifted by
+  // at most GW + 1, back to back, so all but the first find them in the XCD's L2; with the taps outermost every tap re-streamed the whole
+  // [256 rows x Cin] panel after megabytes of other traffic (PMC on the first group-1 conv: FETCH_SIZE 3.6 GB for an 852 MB activation
+  // tensor, TCC hit rate 27 %).  The weight's K order stays (tap, channel): only the tile walk changes.
   auto issue_stage = [&](int buf, int kt) {
-    const int tap = kt / kpt, kin = kt - tap * kpt;  // scalar: once per K-tile
+    const int kin = kt / p.ntaps, tap = kt - kin * p.ntaps;  // scalar: once per K-tile
     const char* abase = Ab + p.tap_off[tap] + (size_t)kin * 128;
+    const char* wbase = Wb + ((size_t)tap * kpt + kin) * 128;
     const uint32_t dst = lds0 + buf * STAGE + wave * 1024;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) conv_dma_piece(abase, a_off[j], dst + NW * j * 1024);
 #pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) conv_dma_piece(Wb + (size_t)kt * 128, b_off[j], dst + A_BYTES + NW * j * 1024);
+    for (int j = 0; j < B_INSTR; ++j) conv_dma_piece(wbase, b_off[j], dst + A_BYTES + NW * j * 1024);
   };
 
   const int l31 = lane & 31, half = lane >> 5;
