@@ -63,6 +63,7 @@ struct GemmArgs {
   int res_mode;             // 0: C += R;  1 / 2: C *= QuickGELU'(R) / GELU'(R) (backward of the MLP: R = saved pre-activation, bf16)
   int kt_chunk;             // split-K (weight gradients): K-tiles (of 64) per split, blockIdx.y = split; 0 = no split
   long long c_split_stride; // elements between the partial outputs of consecutive splits
+  int split_flat;           // split-K with the split index folded into blockIdx.x (1-D grid of tiles * splits, split-major): 0 = blockIdx.y
   void* C2;                 // training forward of the MLP: second bf16 output act2(bf16(C)) next to the pre-activation C (NULL = none)
   int ldc2, act2;
 };
@@ -540,6 +541,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
+  // split-K, flat form: the XCD-contiguous id enumerates (split, tile) split-major, so the ~32 workgroups an XCD runs are ONE split's
+  // neighbouring tiles: they stream the same contraction rows at the same time and share the operand panels in that XCD's L2
+  int split = (int)blockIdx.y;
+  if (p.split_flat) {
+    const int ntile = tiles_m * p.tiles_n;
+    split = bid / ntile;
+    bid -= split * ntile;
+  }
   int tm, tn;
   {
     const int per_group = GM * p.tiles_n;
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     }
   }
   // split-K: this block owns K-tiles [kt0, kt0 + KT) and writes its own partial output (no bias / residual / activation)
-  const int kt0 = p.kt_chunk > 0 ? (int)blockIdx.y * p.kt_chunk : 0;
+  const int kt0 = p.kt_chunk > 0 ? split * p.kt_chunk : 0;
   const size_t a_step = TNM ? (size_t)64 * p.lda * 2 : 128, w_step = TNM ? (size_t)64 * p.ldw * 2 : 128;  // bytes per K-tile
   const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * a_step;
   const char* Wb = reinterpret_cast<const char*>(p.W) + (size_t)kt0 * w_step;
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     return;
   }
   GemmArgs pe = p;
-  if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * (size_t)p.c_split_stride;
+  if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)split * (size_t)p.c_split_stride;
   if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, pe, m0, n0, wm, wn, lane, wave, smem);
   else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, pe, m0, n0, wm, wn, lane);
   if constexpr ((ABL & 64) != 0) {
@@ -2056,7 +2065,7 @@ static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const 
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = bias; p.R = residual; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.act = act; p.tiles_n = 0;
   p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0;
-  p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2;
+  p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.split_flat = 0;
   if (act == MMAMD_ACT_MUL_QUICKGELU_GRAD || act == MMAMD_ACT_MUL_GELU_GRAD) {
     MMAMD_CHECK_ARG(out_dtype == MMAMD_BF16 && residual != nullptr, MMAMD_E_BADARG,
                     "gemm: the activation-gradient epilogue needs bf16 output and the saved pre-activation as `residual`");
@@ -2084,7 +2093,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 }  // namespace mmamd
 
-template <bool TNM, int SCH = 0, int GMV = 8>
+// FLAT (default): 1-D grid of tiles * splits, split-major after the XCD-contiguous remap — an XCD then runs neighbouring tiles of ONE split,
+// which stream the same contraction rows at the same time and share operand panels in its L2 (the 2-D grid scattered a split's tiles over all
+// XCDs: PMC FETCH_SIZE 3x the operand bytes on the MLP-up gradient).  Measured (tools/wgrad_bench.py --sched): -3...-10 % on every shape.
+template <bool TNM, int SCH = 0, int GMV = 8, bool FLAT = true>
 static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
                             mmamd_stream_t stream) {
   const int KT = K / 64;
@@ -2095,7 +2107,7 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.bias = nullptr; p.R = nullptr; p.C = nsplit == 1 ? C : ws;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = N; p.act = MMAMD_ACT_NONE;
   p.kt_chunk = chunk; p.c_split_stride = (long long)M * N; p.res_mode = 0;
-  p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0;
+  p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0; p.split_flat = FLAT ? 1 : 0;
   constexpr int smem = 2 * 512 * 128;
   auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, GMV, 0, true, TNM, SCH>;
   static bool attr_done = false;
@@ -2107,7 +2119,8 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   const int tiles_m = (M + 255) / 256;
   p.tiles_n = (N + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, nsplit), dim3(512), smem, st, p, tiles_m, nullptr);
+  if (FLAT) hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n * nsplit), dim3(512), smem, st, p, tiles_m, nullptr);
+  else hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, nsplit), dim3(512), smem, st, p, tiles_m, nullptr);
   if (nsplit > 1) {
     const long long n = (long long)M * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit, n, C);
@@ -2137,12 +2150,14 @@ extern "C" int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, 
   MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)lda * 2u < (1ull << 31) && (uint64_t)64 * (uint64_t)ldw * 2u < (1ull << 31), MMAMD_E_UNSUPPORTED,
                   "gemm_tn_splitk: leading dimension too large for the 32-bit DMA offsets");
 #ifdef MMAMD_EXPERIMENTS  // fragment-read placement experiments of the TN main loop (mmamd_set_gemm_variant(40 .. 43))
-  if (g_gemm_variant == 40) return gemm_splitk_impl<true, 0>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
-  if (g_gemm_variant == 41) return gemm_splitk_impl<true, 1>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
-  if (g_gemm_variant == 42) return gemm_splitk_impl<true, 2>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
-  if (g_gemm_variant == 43) return gemm_splitk_impl<true, 3>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
-  if (g_gemm_variant == 44) return gemm_splitk_impl<true, 0, 1>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);  // tile order: column tile innermost
-  if (g_gemm_variant == 45) return gemm_splitk_impl<true, 0, 2>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 40) return gemm_splitk_impl<true, 0, 8, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);  // 2-D grid (split = blockIdx.y)
+  if (g_gemm_variant == 41) return gemm_splitk_impl<true, 1, 8, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 42) return gemm_splitk_impl<true, 2, 8, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 43) return gemm_splitk_impl<true, 3, 8, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 44) return gemm_splitk_impl<true, 0, 1, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);  // tile order: column tile innermost
+  if (g_gemm_variant == 45) return gemm_splitk_impl<true, 0, 2, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+  if (g_gemm_variant == 46) return gemm_splitk_impl<true, 0, 1, true>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);  // flat grid, split-major, column tile innermost
+  if (g_gemm_variant == 47) return gemm_splitk_impl<true, 0, 8, true>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);  // flat grid, row tile innermost
 #endif
   // (fragment-read placement variants 40-43 differ by less than the run-to-run spread of a 20-launch loop — the same kernel measured 295 and
   //  252 us depending on its position in the loop — and the training step time is unchanged by them: the MFMA-first order stays)

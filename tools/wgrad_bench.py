@@ -15,11 +15,11 @@ for name, T, M, N in (("v.qkv", 50432, 2304, 768), ("v.out", 50432, 768, 768), (
     tn = timeit(lambda: ops.gemm_bf16_tn_splitk(y, x), 20) * 1e3
     if "--sched" in sys.argv:  # experiment builds only (MMAMD_EXPERIMENTS=1): fragment-read placement variants of the TN loop
         alt = []
-        for v in (40, 41, 42, 43, 44, 45):
+        for v in (40, 41, 42, 43, 44, 45, 46, 47):
             ops.set_gemm_variant(v)
             alt.append(timeit(lambda: ops.gemm_bf16_tn_splitk(y, x), 20) * 1e3)
         ops.set_gemm_variant(0)
-        print(f"{name:7s} TN policy {tn:7.1f} us | MFMA-first {alt[0]:7.1f} | burst {alt[1]:7.1f} | compiler {alt[2]:7.1f} | reads-first {alt[3]:7.1f} | GM=1 {alt[4]:7.1f} | GM=2 {alt[5]:7.1f}", flush=True)
+        print(f"{name:7s} TN policy {tn:7.1f} us | MFMA-first {alt[0]:7.1f} | burst {alt[1]:7.1f} | compiler {alt[2]:7.1f} | reads-first {alt[3]:7.1f} | GM=1 {alt[4]:7.1f} | GM=2 {alt[5]:7.1f} | flat GM=1 {alt[6]:7.1f} | flat GM=8 {alt[7]:7.1f}", flush=True)
         continue
 
     def old():
