@@ -86,7 +86,21 @@ class CLIPViTEncoder(nn.Module):
         kpad = (K + 63) // 64 * 64
         xc = x if x.is_contiguous() else x.contiguous()
         # K1: patch embedding = GEMM over non-overlapping patches (conv has no bias in CLIP), fp32 result
-        patches = ops.patchify(xc, self.patch_size, kpad)
+        return self.forward_patches(ops.patchify(xc, self.patch_size, kpad))
+
+    def forward_patches(self, patches: Tensor) -> Tensor:
+        """Inference entry for a device-side loader (extension; transforms.clip_transform.CLIPImageTransform.patches): bf16 im2col
+        rows [B*G2, Kpad] (column (c*P+py)*P+px, Kpad = 3*P*P rounded up to 64) instead of the fp32 image -- the same rows
+        `forward` builds with mmamd_patchify, so the result is identical."""
+        f32 = torch.float32
+        pk = self._packed.get
+        g = self.image_size // self.patch_size
+        G2 = g * g
+        K = 3 * self.patch_size * self.patch_size
+        kpad = (K + 63) // 64 * 64
+        if patches.dim() != 2 or patches.shape[1] != kpad or patches.shape[0] % G2 != 0 or patches.dtype != torch.bfloat16:
+            raise ValueError(f"Expected bf16 patch rows [B*{G2}, {kpad}], found {patches.dtype} {tuple(patches.shape)}")
+        B = patches.shape[0] // G2
         pe = ops.gemm_bf16(patches, self._conv_weight_bf16(kpad), out_dtype=f32)
         # prepend CLS, + positional embedding, ln_pre  -> fp32 residual stream [B*S, w]
         h = ops.vit_assemble_ln(pe, pk(self.cls_token_embedding, f32), pk(self.positional_embedding, f32),

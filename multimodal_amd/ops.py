@@ -23,7 +23,7 @@ __all__ = [
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
-    "attention_x_bwd",
+    "attention_x_bwd", "image_resample",
 ]
 
 
@@ -873,3 +873,28 @@ class GemmProbe:
 
     def reset(self):
         self._timers = []
+
+
+def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, B: int, crop_h: int, crop_w: int, max_rows: int,
+                   mean, std, want_f32: bool = True, patch: int = 0, kpad: int = 0, want_u8: bool = False):
+    """mmamd_image_resample: Pillow-exact bicubic resize + crop + ToTensor + Normalize (+ im2col) of a ragged uint8 batch.
+    desc int64 [B,16], tables int32, tmp uint8 -- all on the device, laid out as include/mmamd.h says.
+    Returns (f32 [B,3,crop_h,crop_w] | None, bf16 patches [B*G2, kpad] | None, uint8 [B,crop_h,crop_w,3] | None)."""
+    _chk(desc, "desc", torch.int64); _chk(tables, "tables", torch.int32); _chk(tmp, "tmp", torch.uint8)
+    if desc.numel() != B * 16:
+        raise MmamdError(f"desc has {desc.numel()} words, expected {B} x 16")
+    dev = desc.device
+    out = torch.empty((B, 3, crop_h, crop_w), dtype=torch.float32, device=dev) if want_f32 else None
+    pt = None
+    if patch:
+        k = 3 * patch * patch
+        kpad = kpad or k
+        rows = B * (crop_h // patch) * (crop_w // patch)
+        pt = (torch.empty if kpad == k else torch.zeros)((rows, kpad), dtype=torch.bfloat16, device=dev)
+    u8 = torch.empty((B, crop_h, crop_w, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    check(_lib.lib().mmamd_image_resample(desc.data_ptr(), tables.data_ptr(), tmp.data_ptr(), B, crop_h, crop_w, max_rows,
+                                          C.cast(m, C.c_void_p), C.cast(sd, C.c_void_p), _ptr(out), _ptr(pt), patch, kpad,
+                                          _ptr(u8), _stream()), "mmamd_image_resample")
+    return out, pt, u8
