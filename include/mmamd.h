@@ -350,11 +350,13 @@ int mmamd_cross_entropy_bwd(const float* logits, int64_t ld, const int64_t* labe
  *                    pairs [crop_w][2], and ksize_h -- for the crop_w resized columns the crop keeps
  *   [9] / [10] / [11] vertical pass: coefficients [crop_h][ksize_v], (first row - row0, taps) pairs [crop_h][2], ksize_v
  *   [12] byte offset of this image's intermediate [nrows][crop_w][3] in tmp.        ([14], [15] reserved)
- * tables: int32, device.  max_rows = max nrows over the batch.  mean / std: 3 host floats each.  Outputs (any subset, NULL = skip):
+ * tables: int32, device.  max_rows = max nrows over the batch; max_seg_bytes = max over the batch of the source bytes per row the
+ * horizontal pass reads, (last column's first + taps - first column's first) * bytes per pixel (0 = unknown: takes the untiled
+ * kernels).  mean / std: 3 host floats each.  Outputs (any subset, NULL = skip):
  * out_f32 [B,3,crop_h,crop_w]; patches bf16 [B*(crop_h/P)*(crop_w/P), kpad], column (c*P+py)*P+px (columns >= 3*P*P are NOT
  * written: zero the buffer once when kpad > 3*P*P); out_u8 [B,crop_h,crop_w,3], the resized crop itself. */
 int mmamd_image_resample(const int64_t* desc, const int32_t* tables, uint8_t* tmp, int B, int crop_h, int crop_w, int max_rows,
-                         const float* mean, const float* std, float* out_f32, void* patches, int P, int kpad, uint8_t* out_u8,
+                         int max_seg_bytes, const float* mean, const float* std, float* out_f32, void* patches, int P, int kpad, uint8_t* out_u8,
                          mmamd_stream_t stream);
 
 /* Elementwise dtype conversion helper (fp32 <-> bf16), n elements. Used for weight packing. */

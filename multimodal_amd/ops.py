@@ -876,7 +876,7 @@ class GemmProbe:
 
 
 def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, B: int, crop_h: int, crop_w: int, max_rows: int,
-                   mean, std, want_f32: bool = True, patch: int = 0, kpad: int = 0, want_u8: bool = False):
+                   max_seg_bytes: int, mean, std, want_f32: bool = True, patch: int = 0, kpad: int = 0, want_u8: bool = False):
     """mmamd_image_resample: Pillow-exact bicubic resize + crop + ToTensor + Normalize (+ im2col) of a ragged uint8 batch.
     desc int64 [B,16], tables int32, tmp uint8 -- all on the device, laid out as include/mmamd.h says.
     Returns (f32 [B,3,crop_h,crop_w] | None, bf16 patches [B*G2, kpad] | None, uint8 [B,crop_h,crop_w,3] | None)."""
@@ -895,6 +895,6 @@ def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, 
     m = (C.c_float * 3)(*[float(v) for v in mean])
     sd = (C.c_float * 3)(*[float(v) for v in std])
     check(_lib.lib().mmamd_image_resample(desc.data_ptr(), tables.data_ptr(), tmp.data_ptr(), B, crop_h, crop_w, max_rows,
-                                          C.cast(m, C.c_void_p), C.cast(sd, C.c_void_p), _ptr(out), _ptr(pt), patch, kpad,
+                                          int(max_seg_bytes), C.cast(m, C.c_void_p), C.cast(sd, C.c_void_p), _ptr(out), _ptr(pt), patch, kpad,
                                           _ptr(u8), _stream()), "mmamd_image_resample")
     return out, pt, u8

@@ -293,11 +293,12 @@ class CLIPImageTransform(nn.Module):
 
     def _plan_batch(self, items):
         """Host geometry of a batch: the descriptor table (word 0 still relative to each image's first byte), the concatenated
-        int32 coefficient tables, each host image's offset in the pixel staging area (None for device tensors), and the sizes."""
+        int32 coefficient tables, each host image's offset in the pixel staging area (None for device tensors), and the sizes
+        (pixel staging bytes, tmp bytes, max rows of the vertical window, max source bytes per row of the horizontal pass)."""
         ch, cw = self.crop_hw
         B = len(items)
         desc = np.zeros((B, _DESC), np.int64)
-        tabs, tab_len, host_off, host_len, tmp_len, max_rows = [], 0, [], 0, 0, 1
+        tabs, tab_len, host_off, host_len, tmp_len, max_rows, max_seg = [], 0, [], 0, 0, 1, 0
         for b, (a, px) in enumerate(items):
             h, w = int(a.shape[0]), int(a.shape[1])
             if h < 1 or w < 1:
@@ -318,13 +319,14 @@ class CLIPImageTransform(nn.Module):
             d[8], d[11], d[12] = kh.shape[1], kv.shape[1], tmp_len
             tmp_len += (nrows * cw * 3 + 15) // 16 * 16
             max_rows = max(max_rows, nrows)
+            max_seg = max(max_seg, int(bh[-1, 0] + bh[-1, 1] - bh[0, 0]) * px)
             if isinstance(a, Tensor):
                 host_off.append(None)
             else:
                 host_off.append(host_len)
                 host_len += (a.size + 15) // 16 * 16
         tables = np.concatenate(tabs) if tabs else np.zeros(0, np.int32)
-        return desc, tables, host_off, host_len, tmp_len, max_rows
+        return desc, tables, host_off, host_len, tmp_len, max_rows, max_seg
 
     def _run(self, images, want_f32: bool, patch: int = 0, kpad: int = 0, want_u8: bool = False):
         if self.device.type != "cuda" or not torch.cuda.is_available():
@@ -333,7 +335,7 @@ class CLIPImageTransform(nn.Module):
         ch, cw = self.crop_hw
         items = [_as_u8_hwc(im) for im in images]
         B = len(items)
-        desc, tables, host_off, host_len, tmp_len, max_rows = self._plan_batch(items)
+        desc, tables, host_off, host_len, tmp_len, max_rows, max_seg = self._plan_batch(items)
         # one staging buffer [desc | tables | pixels of the host images], one H2D copy
         o_tab = B * _DESC * 8
         n_tab = tables.size * 4
@@ -353,7 +355,7 @@ class CLIPImageTransform(nn.Module):
         dev.copy_(stage, non_blocking=True)
         tmp = torch.empty(max(tmp_len, 16), dtype=torch.uint8, device=self.device)
         tab_dev = dev[o_tab:o_tab + max(n_tab, 4)].view(torch.int32)
-        return ops.image_resample(dev[:o_tab].view(torch.int64), tab_dev, tmp, B, ch, cw, max_rows, self.image_mean,
+        return ops.image_resample(dev[:o_tab].view(torch.int64), tab_dev, tmp, B, ch, cw, max_rows, max_seg, self.image_mean,
                                   self.image_std, want_f32, patch, kpad, want_u8)
 
     def forward(self, image) -> Tensor:

@@ -166,3 +166,18 @@ def test_clip_transform_pairs_images_with_token_ids():
     assert txts[-1].tolist() == [t1[0]] + (t1[1:-1] * 20)[:75] + [t1[-1]]
     assert int(txts[:-1, len(t1):].max()) == 0
     assert np.array_equal(imgs[5].cpu().numpy(), T.clip_image_transform_eval(im2, 224))
+
+
+def test_untiled_kernels_odd_crop_width_and_very_long_rows():
+    """The direct kernels behind the tiled ones: a crop width that is not a multiple of 4 (tmp rows are not whole dwords), and a
+    source row longer than the LDS tile (a 22000-pixel panorama squeezed to 8x8 reads 66 KB per row)."""
+    from multimodal_amd.transforms.clip_transform import CLIPImageTransform
+
+    ims = _ragged(8, [(45, 70), (100, 31), (30, 30)])
+    got = CLIPImageTransform(image_size=30, is_train=False)(ims).cpu().numpy()
+    for b, a in enumerate(ims):
+        assert np.array_equal(got[b], T.clip_image_transform_eval(a, 30)), b
+    wide = _ragged(9, [(16, 22000), (12, 40)])
+    got = CLIPImageTransform(image_size=(8, 8), is_train=False)(wide).cpu().numpy()
+    for b, a in enumerate(wide):
+        assert np.array_equal(got[b], T.clip_image_transform_eval(a, (8, 8))), b
