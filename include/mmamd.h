@@ -339,11 +339,12 @@ int mmamd_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, 
 int mmamd_cross_entropy_bwd(const float* logits, int64_t ld, const int64_t* labels, int N, int V, int64_t ignore_index,
                             const float* grad_out, void* dlogits, int dlogits_dtype, int64_t ldd, float* ws, mmamd_stream_t stream);
 
-/* --- input side: CLIPImageTransform on the device ------------------------------------------------
- * Resize(bicubic) + CenterCrop / resized crop + ToTensor + Normalize (+ im2col) for a ragged batch of decoded uint8 images, bit for
- * bit what torchmultimodal/transforms/clip_transform.py:326-352 computes per image on the host through torchvision + Pillow:
- * Pillow's two 8-bit resampling passes (Resample.c; 22-bit fixed-point coefficients, uint8 intermediate), then x/255 and
- * (x - mean)/std in fp32.  desc: int64 [B,16] in device memory, per image
+/* --- input side: CLIPImageTransform / FLAVAImageTransform on the device ----------------------------
+ * Resize + CenterCrop / resized crop + ToTensor + Normalize (+ im2col) for a ragged batch of decoded uint8 images, bit for bit what
+ * torchmultimodal/transforms/clip_transform.py:326-352 (and flava_transform.py:262-297) compute per image on the host through
+ * torchvision + Pillow: Pillow's two 8-bit resampling passes (Resample.c; 22-bit fixed-point coefficients built by the host for
+ * the filter in use -- bicubic or Lanczos --, uint8 intermediate), then a per-channel value table for the float conversion.
+ * desc: int64 [B,16] in device memory, per image
  *   [0] address of the source view's first pixel   [1] source row stride (bytes)   [2] view height  [3] view width
  *   [4] row0: first view row the vertical pass reads   [5] nrows: how many   [13] bytes per source pixel (3 = RGB, 4 = RGBX)
  *   [6] / [7] / [8]  horizontal pass: index into `tables` of the coefficients [crop_w][ksize_h], of the (first column, taps)
@@ -352,11 +353,12 @@ int mmamd_cross_entropy_bwd(const float* logits, int64_t ld, const int64_t* labe
  *   [12] byte offset of this image's intermediate [nrows][crop_w][3] in tmp.        ([14], [15] reserved)
  * tables: int32, device.  max_rows = max nrows over the batch; max_seg_bytes = max over the batch of the source bytes per row the
  * horizontal pass reads, (last column's first + taps - first column's first) * bytes per pixel (0 = unknown: takes the untiled
- * kernels).  mean / std: 3 host floats each.  Outputs (any subset, NULL = skip):
+ * kernels).  lut: float [3][256], device: the value of byte v in channel c (ToTensor + Normalize: ((v/255) - mean[c]) / std[c]
+ * evaluated in fp32; may be NULL when only out_u8 is requested).  Outputs (any subset, NULL = skip):
  * out_f32 [B,3,crop_h,crop_w]; patches bf16 [B*(crop_h/P)*(crop_w/P), kpad], column (c*P+py)*P+px (columns >= 3*P*P are NOT
  * written: zero the buffer once when kpad > 3*P*P); out_u8 [B,crop_h,crop_w,3], the resized crop itself. */
 int mmamd_image_resample(const int64_t* desc, const int32_t* tables, uint8_t* tmp, int B, int crop_h, int crop_w, int max_rows,
-                         int max_seg_bytes, const float* mean, const float* std, float* out_f32, void* patches, int P, int kpad, uint8_t* out_u8,
+                         int max_seg_bytes, const float* lut, float* out_f32, void* patches, int P, int kpad, uint8_t* out_u8,
                          mmamd_stream_t stream);
 
 /* Elementwise dtype conversion helper (fp32 <-> bf16), n elements. Used for weight packing. */

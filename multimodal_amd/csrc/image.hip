@@ -5,8 +5,8 @@
 // Byte / integer work, HBM-bound and small: no MFMA, no LDS.  The resampling is Pillow's (Resample.c) two 8-bit passes with its
 // fixed-point coefficients (22 fractional bits, built by the host in double precision exactly as precompute_coeffs does):
 //   pass H  source view rows [row0, row0+nrows) x the crop_w output columns the crop keeps  -> uint8 tmp [nrows][crop_w][3]
-//   pass V  the crop_h output rows from tmp -> uint8 -> x/255 -> (x - mean)/std in fp32 (IEEE divide, as torch's CPU kernels)
-//           -> any of: fp32 [B,3,crop_h,crop_w] (what the reference returns), bf16 patch rows [B*G2, kpad] (column
+//   pass V  the crop_h output rows from tmp -> uint8 -> value table [3][256] (the host tabulates ToTensor + Normalize, or FLAVA's
+//           map_pixels, in IEEE fp32: 256 possible results per channel) -> any of: fp32 [B,3,crop_h,crop_w] (what the reference returns), bf16 patch rows [B*G2, kpad] (column
 //           (c*P+py)*P+px: the GEMM operand), uint8 [B,crop_h,crop_w,3] (the resized crop itself).
 // The uint8 intermediate between the passes is part of the algorithm (Pillow rounds there).  Two implementations of each pass:
 //   tiled   (the one that runs for ordinary images) H: a block stages the source segment of R rows in LDS with aligned 16-byte
@@ -53,8 +53,8 @@ __global__ void __launch_bounds__(256) resample_h_kernel(const int64_t* __restri
 }
 
 __global__ void __launch_bounds__(256) resample_v_kernel(const int64_t* __restrict__ desc, const int32_t* __restrict__ tables,
-                                                         const uint8_t* __restrict__ tmp, int crop_h, int crop_w, float m0, float m1,
-                                                         float m2, float s0, float s1, float s2, float* __restrict__ out_f32,
+                                                         const uint8_t* __restrict__ tmp, int crop_h, int crop_w,
+                                                         const float* __restrict__ lut, float* __restrict__ out_f32,
                                                          bf16* __restrict__ patches, int P, int kpad, uint8_t* __restrict__ out_u8) {
   const int64_t* d = desc + (size_t)blockIdx.z * kDesc;
   const int y = blockIdx.y;
@@ -81,11 +81,10 @@ __global__ void __launch_bounds__(256) resample_v_kernel(const int64_t* __restri
     o[0] = u[0]; o[1] = u[1]; o[2] = u[2];
   }
   if (!out_f32 && !patches) return;
-  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
   const int gw = patches ? crop_w / P : 0, gh = patches ? crop_h / P : 0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)u[c], 255.0f), mean[c]), sd[c]);
+    const float v = lut[c * 256 + u[c]];
     if (out_f32) out_f32[(((size_t)b * 3 + c) * crop_h + y) * crop_w + x] = v;
     if (patches) {
       const size_t row = ((size_t)b * gh + y / P) * gw + x / P;
@@ -233,18 +232,15 @@ __global__ void __launch_bounds__(256) resample_h_tiled_kernel(const int64_t* __
 // patch rows are written as vectors (VEC_PATCH: P % 4 == 0).
 template <bool VEC_PATCH>
 __global__ void __launch_bounds__(256) resample_v_tiled_kernel(const int64_t* __restrict__ desc, const int32_t* __restrict__ tables,
-                                                               const uint8_t* __restrict__ tmp, int crop_h, int crop_w, float m0,
-                                                               float m1, float m2, float s0, float s1, float s2,
-                                                               float* __restrict__ out_f32, bf16* __restrict__ patches, int P, int kpad,
-                                                               uint8_t* __restrict__ out_u8) {
-  // ToTensor + Normalize has 3 x 256 possible results: the block tabulates them once (the two IEEE divides cost ~25 instructions
-  // per element), then every output is one LDS lookup
+                                                               const uint8_t* __restrict__ tmp, int crop_h, int crop_w,
+                                                               const float* __restrict__ lut_g, float* __restrict__ out_f32,
+                                                               bf16* __restrict__ patches, int P, int kpad, uint8_t* __restrict__ out_u8) {
+  // the value table (3 channels x 256 byte values) rides in LDS: every output element is one lookup
   __shared__ float lut[3][256];
-  {
-    const float u = (float)threadIdx.x;
-    lut[0][threadIdx.x] = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), m0), s0);
-    lut[1][threadIdx.x] = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), m1), s1);
-    lut[2][threadIdx.x] = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), m2), s2);
+  if (out_f32 || patches) {
+    lut[0][threadIdx.x] = lut_g[threadIdx.x];
+    lut[1][threadIdx.x] = lut_g[256 + threadIdx.x];
+    lut[2][threadIdx.x] = lut_g[512 + threadIdx.x];
   }
   __syncthreads();
   const int b = blockIdx.y;
@@ -328,17 +324,17 @@ __global__ void __launch_bounds__(256) resample_v_tiled_kernel(const int64_t* __
 using namespace mmamd;
 
 extern "C" int mmamd_image_resample(const int64_t* desc, const int32_t* tables, uint8_t* tmp, int B, int crop_h, int crop_w,
-                                    int max_rows, int max_seg_bytes, const float* mean, const float* std, float* out_f32,
-                                    void* patches, int P, int kpad, uint8_t* out_u8, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(desc && tables && tmp && mean && std && B >= 0 && crop_h > 0 && crop_w > 0 && max_rows > 0, MMAMD_E_BADARG,
+                                    int max_rows, int max_seg_bytes, const float* lut, float* out_f32, void* patches, int P,
+                                    int kpad, uint8_t* out_u8, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(desc && tables && tmp && B >= 0 && crop_h > 0 && crop_w > 0 && max_rows > 0, MMAMD_E_BADARG,
                   "image_resample: bad argument");
   MMAMD_CHECK_ARG(out_f32 || patches || out_u8, MMAMD_E_BADARG, "image_resample: no output requested");
+  MMAMD_CHECK_ARG(lut || !(out_f32 || patches), MMAMD_E_BADARG, "image_resample: float outputs need the value table");
   MMAMD_CHECK_ARG(B <= 65535 && max_rows <= 65535 && crop_h <= 65535, MMAMD_E_UNSUPPORTED,
                   "image_resample: B=%d / rows=%d / crop_h=%d above the 65535 grid limit", B, max_rows, crop_h);
   if (patches)
     MMAMD_CHECK_ARG(P > 0 && crop_h % P == 0 && crop_w % P == 0 && kpad >= 3 * P * P, MMAMD_E_BADARG,
                     "image_resample: crop %dx%d is not a grid of %d-pixel patches with kpad=%d >= 3*P*P", crop_h, crop_w, P, kpad);
-  for (int c = 0; c < 3; ++c) MMAMD_CHECK_ARG(std[c] != 0.f, MMAMD_E_BADARG, "image_resample: std[%d] is zero", c);
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool quad = crop_w % 4 == 0;  // tmp rows are whole dwords
@@ -359,14 +355,14 @@ extern "C" int mmamd_image_resample(const int64_t* desc, const int32_t* tables, 
   if (quad) {
     const dim3 grid((crop_h * (crop_w / 4) + 255) / 256, B);
     if (patches && P % 4 == 0 && kpad % 4 == 0)
-      hipLaunchKernelGGL((resample_v_tiled_kernel<true>), grid, dim3(256), 0, st, desc, tables, tmp, crop_h, crop_w, mean[0], mean[1],
-                         mean[2], std[0], std[1], std[2], out_f32, (bf16*)patches, P, kpad, out_u8);
+      hipLaunchKernelGGL((resample_v_tiled_kernel<true>), grid, dim3(256), 0, st, desc, tables, tmp, crop_h, crop_w, lut, out_f32,
+                         (bf16*)patches, P, kpad, out_u8);
     else
-      hipLaunchKernelGGL((resample_v_tiled_kernel<false>), grid, dim3(256), 0, st, desc, tables, tmp, crop_h, crop_w, mean[0], mean[1],
-                         mean[2], std[0], std[1], std[2], out_f32, (bf16*)patches, P, kpad, out_u8);
+      hipLaunchKernelGGL((resample_v_tiled_kernel<false>), grid, dim3(256), 0, st, desc, tables, tmp, crop_h, crop_w, lut, out_f32,
+                         (bf16*)patches, P, kpad, out_u8);
   } else {
     hipLaunchKernelGGL(resample_v_kernel, dim3((crop_w + 255) / 256, crop_h, B), dim3(256), 0, st, desc, tables, tmp, crop_h, crop_w,
-                       mean[0], mean[1], mean[2], std[0], std[1], std[2], out_f32, (bf16*)patches, P, kpad, out_u8);
+                       lut, out_f32, (bf16*)patches, P, kpad, out_u8);
   }
   return launch_status("image_resample");
 }

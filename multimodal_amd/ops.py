@@ -876,11 +876,16 @@ class GemmProbe:
 
 
 def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, B: int, crop_h: int, crop_w: int, max_rows: int,
-                   max_seg_bytes: int, mean, std, want_f32: bool = True, patch: int = 0, kpad: int = 0, want_u8: bool = False):
-    """mmamd_image_resample: Pillow-exact bicubic resize + crop + ToTensor + Normalize (+ im2col) of a ragged uint8 batch.
-    desc int64 [B,16], tables int32, tmp uint8 -- all on the device, laid out as include/mmamd.h says.
+                   max_seg_bytes: int, lut: Optional[torch.Tensor], want_f32: bool = True, patch: int = 0, kpad: int = 0,
+                   want_u8: bool = False):
+    """mmamd_image_resample: Pillow-exact resize + crop + byte -> float value table (+ im2col) of a ragged uint8 batch.
+    desc int64 [B,16], tables int32, tmp uint8, lut float32 [3,256] -- all on the device, laid out as include/mmamd.h says.
     Returns (f32 [B,3,crop_h,crop_w] | None, bf16 patches [B*G2, kpad] | None, uint8 [B,crop_h,crop_w,3] | None)."""
     _chk(desc, "desc", torch.int64); _chk(tables, "tables", torch.int32); _chk(tmp, "tmp", torch.uint8)
+    if lut is not None:
+        _chk(lut, "lut", torch.float32)
+        if lut.numel() != 768:
+            raise MmamdError(f"lut has {lut.numel()} entries, expected 3 x 256")
     if desc.numel() != B * 16:
         raise MmamdError(f"desc has {desc.numel()} words, expected {B} x 16")
     dev = desc.device
@@ -892,9 +897,7 @@ def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, 
         rows = B * (crop_h // patch) * (crop_w // patch)
         pt = (torch.empty if kpad == k else torch.zeros)((rows, kpad), dtype=torch.bfloat16, device=dev)
     u8 = torch.empty((B, crop_h, crop_w, 3), dtype=torch.uint8, device=dev) if want_u8 else None
-    m = (C.c_float * 3)(*[float(v) for v in mean])
-    sd = (C.c_float * 3)(*[float(v) for v in std])
     check(_lib.lib().mmamd_image_resample(desc.data_ptr(), tables.data_ptr(), tmp.data_ptr(), B, crop_h, crop_w, max_rows,
-                                          int(max_seg_bytes), C.cast(m, C.c_void_p), C.cast(sd, C.c_void_p), _ptr(out), _ptr(pt), patch, kpad,
-                                          _ptr(u8), _stream()), "mmamd_image_resample")
+                                          int(max_seg_bytes), _ptr(lut), _ptr(out), _ptr(pt), patch, kpad, _ptr(u8), _stream()),
+          "mmamd_image_resample")
     return out, pt, u8

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import gzip
 import math
+from functools import lru_cache
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -199,9 +200,10 @@ class CLIPTextTransform(nn.Module):
 
 # ------------------------------------------------------------------------------------------------------------------ images
 from .. import ops  # noqa: E402
-from ._resample import axis_tables, center_crop_origin, resize_output_size  # noqa: E402
+from ._device_resample import DeviceResampler, as_u8_hwc, random_resized_crop_params  # noqa: E402,F401
+from ._resample import center_crop_origin, normalize_lut, resize_output_size  # noqa: E402
 
-_DESC = 16  # int64 words per image (include/mmamd.h, mmamd_image_resample)
+_as_u8_hwc = as_u8_hwc
 
 
 def _interp_name(mode) -> str:
@@ -211,52 +213,6 @@ def _interp_name(mode) -> str:
 
 def convert_to_rgb(img):
     return img.convert("RGB")
-
-
-def _as_u8_hwc(img):
-    """One decoded image -> (uint8 [H, W, 3 or 4] array or CUDA tensor, bytes per pixel).  PIL images go through convert('RGB')
-    like the reference (clip_transform.py:27-28); arrays / tensors must already be uint8 HWC with 3 (RGB) or 4 (RGBX) channels."""
-    if hasattr(img, "convert") and hasattr(img, "size") and not isinstance(img, (np.ndarray, Tensor)):
-        return np.asarray(img.convert("RGB")), 3
-    if isinstance(img, Tensor):
-        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] not in (3, 4):
-            raise ops.MmamdError(f"image tensor must be uint8 [H, W, 3|4], got {img.dtype} {tuple(img.shape)}")
-        if img.is_cuda:
-            if img.stride(2) != 1 or img.stride(1) != img.shape[2]:
-                raise ops.MmamdError("CUDA image tensors must be dense along W and C (row stride is free)")
-            return img, int(img.shape[2])
-        img = img.numpy()
-    if isinstance(img, np.ndarray):
-        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] not in (3, 4):
-            raise ops.MmamdError(f"image array must be uint8 [H, W, 3|4], got {img.dtype} {img.shape}")
-        return np.ascontiguousarray(img), int(img.shape[2])
-    raise TypeError(f"unsupported image type {type(img)}")
-
-
-def random_resized_crop_params(height: int, width: int, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)) -> Tuple[int, int, int, int]:
-    """The crop box (top, left, h, w) torchvision's RandomResizedCrop.get_params draws -- same draws from torch's global CPU
-    generator in the same order: up to 10 tries of area * U(scale), exp(U(log ratio)), a random origin; then the centred fallback."""
-    area = height * width
-    log_ratio = torch.log(torch.tensor(ratio))
-    for _ in range(10):
-        target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
-        aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
-        w = int(round(math.sqrt(target_area * aspect_ratio)))
-        h = int(round(math.sqrt(target_area / aspect_ratio)))
-        if 0 < w <= width and 0 < h <= height:
-            i = torch.randint(0, height - h + 1, size=(1,)).item()
-            j = torch.randint(0, width - w + 1, size=(1,)).item()
-            return i, j, h, w
-    in_ratio = float(width) / float(height)
-    if in_ratio < min(ratio):
-        w = width
-        h = int(round(w / min(ratio)))
-    elif in_ratio > max(ratio):
-        h = height
-        w = int(round(h * max(ratio)))
-    else:
-        w, h = width, height
-    return (height - h) // 2, (width - w) // 2, h, w
 
 
 class CLIPImageTransform(nn.Module):
@@ -277,8 +233,15 @@ class CLIPImageTransform(nn.Module):
         self.crop_hw: Tuple[int, int] = (image_size, image_size) if isinstance(image_size, int) else (int(image_size[0]), int(image_size[1]))
         self.image_mean = tuple(float(v) for v in image_mean)
         self.image_std = tuple(float(v) for v in image_std)
+        if any(v == 0.0 for v in self.image_std):
+            raise ValueError("image_std has a zero entry")
         self.is_train = is_train
-        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.lut = normalize_lut(self.image_mean, self.image_std)
+        self.resampler = DeviceResampler(self.crop_hw, "bicubic", device)
+
+    @property
+    def device(self) -> torch.device:
+        return self.resampler.device
 
     # -- geometry of one image: source view, resized size, crop window ------------------------------------------------------
     def _plan(self, h: int, w: int):
@@ -292,71 +255,12 @@ class CLIPImageTransform(nn.Module):
         return (0, 0, h, w), (oh, ow), center_crop_origin(oh, ow, ch, cw)
 
     def _plan_batch(self, items):
-        """Host geometry of a batch: the descriptor table (word 0 still relative to each image's first byte), the concatenated
-        int32 coefficient tables, each host image's offset in the pixel staging area (None for device tensors), and the sizes
-        (pixel staging bytes, tmp bytes, max rows of the vertical window, max source bytes per row of the horizontal pass)."""
-        ch, cw = self.crop_hw
-        B = len(items)
-        desc = np.zeros((B, _DESC), np.int64)
-        tabs, tab_len, host_off, host_len, tmp_len, max_rows, max_seg = [], 0, [], 0, 0, 1, 0
-        for b, (a, px) in enumerate(items):
-            h, w = int(a.shape[0]), int(a.shape[1])
-            if h < 1 or w < 1:
-                raise ops.MmamdError("empty image")
-            (vi, vj, vh, vw), (oh, ow), (top, left) = self._plan(h, w)
-            kh, bh = axis_tables(vw, ow, left, cw)
-            kv, bv = axis_tables(vh, oh, top, ch)
-            row0 = int(bv[:, 0].min())
-            nrows = int((bv[:, 0] + bv[:, 1]).max()) - row0
-            bv = bv - np.array([row0, 0], np.int32)
-            stride = a.stride(0) if isinstance(a, Tensor) else w * px
-            d = desc[b]
-            d[0], d[1], d[2], d[3], d[4], d[5], d[13] = vi * stride + vj * px, stride, vh, vw, row0, nrows, px
-            for slot, arr in ((6, kh), (7, bh), (9, kv), (10, bv)):
-                d[slot] = tab_len
-                tabs.append(arr.reshape(-1))
-                tab_len += arr.size
-            d[8], d[11], d[12] = kh.shape[1], kv.shape[1], tmp_len
-            tmp_len += (nrows * cw * 3 + 15) // 16 * 16
-            max_rows = max(max_rows, nrows)
-            max_seg = max(max_seg, int(bh[-1, 0] + bh[-1, 1] - bh[0, 0]) * px)
-            if isinstance(a, Tensor):
-                host_off.append(None)
-            else:
-                host_off.append(host_len)
-                host_len += (a.size + 15) // 16 * 16
-        tables = np.concatenate(tabs) if tabs else np.zeros(0, np.int32)
-        return desc, tables, host_off, host_len, tmp_len, max_rows, max_seg
+        return self.resampler.plan(items, [self._plan(int(a.shape[0]), int(a.shape[1])) for a, _ in items])
 
     def _run(self, images, want_f32: bool, patch: int = 0, kpad: int = 0, want_u8: bool = False):
-        if self.device.type != "cuda" or not torch.cuda.is_available():
-            raise ops.MmamdError(f"CLIPImageTransform runs on a HIP device (device={self.device}, available="
-                                 f"{torch.cuda.is_available()}): there is no CPU path")
-        ch, cw = self.crop_hw
-        items = [_as_u8_hwc(im) for im in images]
-        B = len(items)
-        desc, tables, host_off, host_len, tmp_len, max_rows, max_seg = self._plan_batch(items)
-        # one staging buffer [desc | tables | pixels of the host images], one H2D copy
-        o_tab = B * _DESC * 8
-        n_tab = tables.size * 4
-        o_pix = (o_tab + n_tab + 15) // 16 * 16
-        stage = torch.empty(o_pix + host_len, dtype=torch.uint8, pin_memory=True)
-        dev = torch.empty(stage.numel(), dtype=torch.uint8, device=self.device)
-        sn = stage.numpy()
-        for b, (a, px) in enumerate(items):
-            if host_off[b] is None:
-                desc[b, 0] += a.data_ptr()
-            else:
-                o = o_pix + host_off[b]
-                sn[o:o + a.size] = a.reshape(-1)
-                desc[b, 0] += dev.data_ptr() + o
-        sn[:o_tab] = desc.reshape(-1).view(np.uint8)
-        sn[o_tab:o_tab + n_tab] = tables.view(np.uint8)
-        dev.copy_(stage, non_blocking=True)
-        tmp = torch.empty(max(tmp_len, 16), dtype=torch.uint8, device=self.device)
-        tab_dev = dev[o_tab:o_tab + max(n_tab, 4)].view(torch.int32)
-        return ops.image_resample(dev[:o_tab].view(torch.int64), tab_dev, tmp, B, ch, cw, max_rows, max_seg, self.image_mean,
-                                  self.image_std, want_f32, patch, kpad, want_u8)
+        items = [as_u8_hwc(im) for im in images]
+        geoms = [self._plan(int(a.shape[0]), int(a.shape[1])) for a, _ in items]
+        return self.resampler.run(items, geoms, self.lut, want_f32, patch, kpad, want_u8)
 
     def forward(self, image) -> Tensor:
         if isinstance(image, (list, tuple)):

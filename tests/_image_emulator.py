@@ -11,8 +11,8 @@ def _clip8(acc):
     return np.clip(acc >> PREC, 0, 255).astype(np.uint8)
 
 
-def run(items, desc, tables, tmp_len, crop_h, crop_w, mean, std, patch=0, kpad=0):
-    """items: [(uint8 HWC array, bytes per pixel)], desc word 0 relative to each image's first byte.
+def run(items, desc, tables, tmp_len, crop_h, crop_w, lut, patch=0, kpad=0):
+    """items: [(uint8 HWC array, bytes per pixel)], desc word 0 relative to each image's first byte; lut float32 [3, 256].
     Returns (f32 [B,3,ch,cw], patches f32-of-bf16-free [B*G2, kpad] as float32 (unrounded) or None, u8 [B,ch,cw,3])."""
     B = len(items)
     tmp = np.zeros(max(tmp_len, 16), np.uint8)
@@ -38,8 +38,7 @@ def run(items, desc, tables, tmp_len, crop_h, crop_w, mean, std, patch=0, kpad=0
             y0, n = int(tables[d[10] + 2 * y]), int(tables[d[10] + 2 * y + 1])
             assert 0 <= y0 and y0 + n <= int(d[5])
             out_u8[b, y] = _clip8((t[y0:y0 + n] * kk[:n, None, None]).sum(0) + (1 << (PREC - 1)))
-    x = out_u8.astype(np.float32).transpose(0, 3, 1, 2) / np.float32(255)
-    f32 = ((x - np.asarray(mean, np.float32)[None, :, None, None]) / np.asarray(std, np.float32)[None, :, None, None]).astype(np.float32)
+    f32 = np.stack([lut[c][out_u8[..., c]] for c in range(3)], axis=1).astype(np.float32)  # the kernel's value-table lookup
     patches = None
     if patch:
         gh, gw = crop_h // patch, crop_w // patch

@@ -181,3 +181,54 @@ def test_untiled_kernels_odd_crop_width_and_very_long_rows():
     got = CLIPImageTransform(image_size=(8, 8), is_train=False)(wide).cpu().numpy()
     for b, a in enumerate(wide):
         assert np.array_equal(got[b], T.clip_image_transform_eval(a, (8, 8))), b
+
+
+# ------------------------------------------------------------------------------------------------------------------ FLAVA
+def test_flava_eval_transform_is_bit_exact():
+    """FLAVAImageTransform(is_train=False): encoder image (exact 224x224 bicubic, normalised) and codebook image (Lanczos 112x112 of
+    the resized image, map_pixels) against the Pillow-pinned oracle; mask shape / count."""
+    from multimodal_amd.transforms.flava_transform import FLAVAImageTransform
+
+    ims = _ragged(10, SIZES[:6])
+    t = FLAVAImageTransform(is_train=False)
+    out = t(ims)
+    assert set(out) == {"image", "image_for_codebook", "image_patches_mask"} and len(out["image"]) == len(ims)
+    for b, a in enumerate(ims):
+        want_enc, want_cb = T.flava_image_transform_eval(a)
+        assert out["image"][b].shape == (3, 224, 224) and out["image_for_codebook"][b].shape == (3, 112, 112)
+        assert np.array_equal(out["image"][b].cpu().numpy(), want_enc), b
+        assert np.array_equal(out["image_for_codebook"][b].cpu().numpy(), want_cb), b
+        m = out["image_patches_mask"][b]
+        assert m.shape == (14, 14) and m.dtype == torch.int64 and 16 <= int(m.sum()) <= 75
+    one = t(ims[1])
+    assert np.array_equal(one["image"].cpu().numpy(), T.flava_image_transform_eval(ims[1])[0])
+    bt = t.batch(ims)
+    assert bt["image"].shape == (6, 3, 224, 224) and bt["image_for_codebook"].shape == (6, 3, 112, 112)
+    assert bt["image_patches_mask"].shape == (6, 14, 14) and bt["image_patches_mask"].is_cuda
+    assert torch.equal(bt["image"], torch.stack(out["image"]))
+
+
+def test_flava_train_transform_reference_kat_and_same_draws():
+    """tests/transforms/test_flava_transform.py:19-51 (2x2 white image -> 3x3: (1 - mean) / std, codebook 0.9, one masked patch),
+    then random photographs against the oracle for the same crop boxes."""
+    from multimodal_amd.transforms._device_resample import random_resized_crop_params
+    from multimodal_amd.transforms.flava_transform import FLAVAImageTransform
+
+    set_rng_seed(1234)
+    t = FLAVAImageTransform(encoder_input_size=3, codebook_input_size=3, mask_max_patches=1, mask_min_patches=1, mask_num_patches=1)
+    out = t(np.full((2, 2, 3), 255, np.uint8))
+    want = torch.tensor([1.9303, 2.0749, 2.1459]).view(3, 1, 1).expand(3, 3, 3)
+    assert torch.allclose(out["image"].cpu(), want, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(out["image_for_codebook"].cpu(), torch.full((3, 3, 3), 0.9))
+    assert int(out["image_patches_mask"].sum()) == 1
+
+    ims = _ragged(12, SIZES[:5])
+    t = FLAVAImageTransform(is_train=True)
+    set_rng_seed(7)
+    boxes = [random_resized_crop_params(a.shape[0], a.shape[1], scale=(0.9, 1.0)) for a in ims]
+    set_rng_seed(7)
+    out = t(ims)
+    for b, a in enumerate(ims):
+        want_enc, want_cb = T.flava_image_transform_train(a, boxes[b])
+        assert np.array_equal(out["image"][b].cpu().numpy(), want_enc), b
+        assert np.array_equal(out["image_for_codebook"][b].cpu().numpy(), want_cb), b

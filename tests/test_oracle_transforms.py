@@ -9,7 +9,7 @@ import torch
 from oracle import transforms_oracle as T
 from multimodal_amd import ops
 from multimodal_amd.transforms import text_transforms as tt
-from multimodal_amd.transforms._resample import axis_tables, center_crop_origin, resize_output_size
+from multimodal_amd.transforms._resample import axis_tables, center_crop_origin, normalize_lut, resize_output_size
 from multimodal_amd.transforms.clip_transform import (CLIP_DEFAULT_MEAN, CLIP_DEFAULT_STD, CLIPBPETokenizer, CLIPBPETransform,
                                                       CLIPImageTransform, CLIPTextTransform, _as_u8_hwc, random_resized_crop_params)
 
@@ -75,7 +75,7 @@ def test_eval_geometry_equals_oracle():
     desc, tables, host_off, host_len, tmp_len, max_rows, max_seg = t._plan_batch(items)
     assert max_rows == int(desc[:, 5].max()) and host_len >= sum(a.size for a, _ in items)
     assert 0 < max_seg <= max(a.shape[1] * px for a, px in items)
-    f32, patches, u8 = emulate(items, desc, tables, tmp_len, 32, 32, CLIP_DEFAULT_MEAN, CLIP_DEFAULT_STD, patch=16, kpad=768)
+    f32, patches, u8 = emulate(items, desc, tables, tmp_len, 32, 32, t.lut, patch=16, kpad=768)
     for b, a in enumerate(ims + [rgbx[:, :, :3].copy()]):
         want = T.clip_image_transform_eval(a, 32)
         assert np.array_equal(f32[b], want), b
@@ -89,7 +89,7 @@ def test_eval_geometry_rectangular_size_and_pil_input():
     pil = [Image.fromarray(ims[0]), Image.fromarray(ims[1][:, :, 0]), Image.fromarray(np.dstack([ims[2], ims[2][:, :, :1]]), "RGBA")]
     items = [_as_u8_hwc(p) for p in pil]
     desc, tables, _, _, tmp_len, _, _ = t._plan_batch(items)
-    f32, _, _ = emulate(items, desc, tables, tmp_len, 24, 40, CLIP_DEFAULT_MEAN, CLIP_DEFAULT_STD)
+    f32, _, _ = emulate(items, desc, tables, tmp_len, 24, 40, t.lut)
     for b, p in enumerate(pil):
         assert np.array_equal(f32[b], T.clip_image_transform_eval(np.asarray(p.convert("RGB")), (24, 40)))
 
@@ -105,7 +105,7 @@ def test_train_geometry_equals_oracle_for_the_same_draws():
     torch.manual_seed(1234)
     items = [_as_u8_hwc(a) for a in ims]
     desc, tables, _, _, tmp_len, _, _ = t._plan_batch(items)
-    f32, _, _ = emulate(items, desc, tables, tmp_len, 32, 32, CLIP_DEFAULT_MEAN, CLIP_DEFAULT_STD)
+    f32, _, _ = emulate(items, desc, tables, tmp_len, 32, 32, t.lut)
     for b, (a, (i, j, h, w)) in enumerate(zip(ims, boxes)):
         assert np.array_equal(f32[b], T.resized_crop(a, i, j, h, w, 32)), b
 
@@ -209,3 +209,70 @@ def test_text_transform_kats():
     assert torch.equal(pad(torch.ones(5)), torch.cat([torch.ones(5), torch.zeros(2)]))
     assert torch.equal(pad(torch.ones(8, 5)), torch.cat([torch.ones(8, 5), torch.zeros(8, 2)], dim=-1))
     assert torch.equal(tt.PadTransform(max_length=3, pad_value=0)(torch.ones(8, 5)), torch.ones(8, 5))
+
+
+# ------------------------------------------------------------------------------------------------------------------ FLAVA
+@pytest.mark.parametrize("hw", [(224, 224), (300, 500), (50, 70), (375, 500), (1000, 640)])
+def test_oracle_lanczos_is_pillow_bit_for_bit(hw):
+    Image = pytest.importorskip("PIL.Image")
+    h, w = hw
+    a = np.random.default_rng(h + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    for oh, ow in [(112, 112), (224, 224), (h // 3 + 1, w * 2)]:
+        ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS))
+        assert np.array_equal(T.pil_resize(a, oh, ow, "lanczos"), ref), (hw, oh, ow)
+    kk, bd = T.pil_resample_coeffs(w, 112, "lanczos")
+    k2, b2 = axis_tables(w, 112, 5, 100, "lanczos")
+    assert np.array_equal(kk[5:105], k2) and np.array_equal(bd[5:105], b2)
+
+
+def test_value_tables_equal_the_float_formulas():
+    from multimodal_amd.transforms._resample import map_pixels_lut
+
+    u = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, 2)
+    want = T.to_tensor_normalize(u, CLIP_DEFAULT_MEAN, CLIP_DEFAULT_STD).reshape(3, 256)
+    assert np.array_equal(normalize_lut(CLIP_DEFAULT_MEAN, CLIP_DEFAULT_STD), want)
+    assert np.array_equal(map_pixels_lut(), T.map_pixels(T.to_tensor(u)).reshape(3, 256))
+    x = torch.from_numpy(T.to_tensor(u))
+    from multimodal_amd.transforms.flava_transform import map_pixels
+
+    assert np.array_equal(map_pixels(x).numpy(), T.map_pixels(x.numpy()))  # torch's fp32 kernels == the numpy restatement
+    with pytest.raises(ValueError):
+        map_pixels(torch.zeros(2, dtype=torch.float64))
+
+
+def test_masking_generator_equals_reference_fixture(golden):
+    """Draw for draw the reference ImageMaskingGenerator (flava_transform.py:31-106), including the `random` state afterwards."""
+    import random
+
+    from multimodal_amd.transforms.flava_transform import ImageMaskingGenerator
+    from tests.golden.make_golden_flava_transform import CONFIGS, DRAWS, SEEDS
+
+    z = golden("flava_transform.npz")
+    for name, cfg in CONFIGS.items():
+        gen = ImageMaskingGenerator(**cfg)
+        assert repr(gen) == bytes(z[f"{name}.repr"]).decode()
+        assert gen.get_shape() == z[f"{name}.seed0"].shape[1:]
+        for seed in SEEDS:
+            random.seed(seed)
+            got = np.stack([gen() for _ in range(DRAWS)])
+            assert got.dtype == np.int64 and np.array_equal(got, z[f"{name}.seed{seed}"]), (name, seed)
+            assert random.random() == float(z[f"{name}.seed{seed}.next"])
+    assert int(z["default.seed0"][0].sum()) == 75 and int(z["single.seed1234"][0].sum()) == 1
+
+
+def test_flava_eval_geometry_chains_two_resamplings():
+    """Encoder image = exact (S, S) bicubic; codebook image = Lanczos of THAT uint8 image: both plans through the emulator."""
+    from multimodal_amd.transforms.flava_transform import FLAVAImageTransform
+
+    ims, _ = _images(11)
+    t = FLAVAImageTransform(is_train=False, encoder_input_size=32, codebook_input_size=16)
+    items = [_as_u8_hwc(a) for a in ims]
+    whole = [((0, 0, a.shape[0], a.shape[1]), (32, 32), (0, 0)) for a in ims]
+    desc, tables, _, _, tmp_len, _, _ = t.encoder.plan(items, whole)
+    enc, _, small = emulate(items, desc, tables, tmp_len, 32, 32, t.image_lut)
+    second = [(small[b], 3) for b in range(len(ims))]
+    desc, tables, _, _, tmp_len, _, _ = t.codebook.plan(second, [((0, 0, 32, 32), (16, 16), (0, 0))] * len(ims))
+    cb, _, _ = emulate(second, desc, tables, tmp_len, 16, 16, t.codebook_lut)
+    for b, a in enumerate(ims):
+        want_enc, want_cb = T.flava_image_transform_eval(a, 32, 16)
+        assert np.array_equal(enc[b], want_enc) and np.array_equal(cb[b], want_cb), b
