@@ -361,6 +361,18 @@ int mmamd_image_resample(const int64_t* desc, const int32_t* tables, uint8_t* tm
                          int max_seg_bytes, const float* lut, float* out_f32, void* patches, int P, int kpad, uint8_t* out_u8,
                          mmamd_stream_t stream);
 
+/* --- zero-shot classification / retrieval read-outs -------------------------------------------------
+ * The torch expressions of examples/flava/native/utils.py:100-160 and examples/flava/coco_zero_shot.py:24-31,78-90 on fp32 rows.
+ * group_mean_normalize: out[g,:] = n(mean_t n(x[g*T+t,:])), n(v) = v/|v| -- one class of the zero-shot classifier from its T
+ *   prompt embeddings (utils.py:108-111); x [G*T, d], out [G, d].
+ * scale_normalize: y = scale * x/|x| per row (utils.py:141-142, the 100.0 * normalised image features).
+ * target_rank: rank[r] = number of entries of scores[r, :C] that beat scores[r, target[r]] (ties: lower index first; target NULL =
+ *   the row index, the diagonal of a retrieval matrix; a target outside [0, C) ranks C).  rank < k  <=>  the target is in torch.topk(k):
+ *   replaces topk + eq + sum of `_accuracy` (utils.py:117-123) and `compute_recall` (coco_zero_shot.py:24-31). */
+int mmamd_group_mean_normalize(const float* x, int G, int T, int d, float* out, mmamd_stream_t stream);
+int mmamd_scale_normalize(const float* x, float* y, int rows, int d, float scale, mmamd_stream_t stream);
+int mmamd_target_rank(const float* scores, int64_t ld, const int64_t* target, int R, int C, int32_t* rank, mmamd_stream_t stream);
+
 /* Elementwise dtype conversion helper (fp32 <-> bf16), n elements. Used for weight packing. */
 int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
                   mmamd_stream_t stream);

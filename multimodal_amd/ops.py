@@ -23,7 +23,7 @@ __all__ = [
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
-    "attention_x_bwd", "image_resample",
+    "attention_x_bwd", "image_resample", "group_mean_normalize", "scale_normalize", "target_rank",
 ]
 
 
@@ -901,3 +901,40 @@ def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, 
                                           int(max_seg_bytes), _ptr(lut), _ptr(out), _ptr(pt), patch, kpad, _ptr(u8), _stream()),
           "mmamd_image_resample")
     return out, pt, u8
+
+
+def group_mean_normalize(x: torch.Tensor, groups: int) -> torch.Tensor:
+    """out[g] = normalize(mean_t normalize(x[g*T + t])) for x [groups*T, d] fp32 -> [groups, d]."""
+    _chk(x, "x", torch.float32)
+    if x.dim() != 2 or groups <= 0 or x.shape[0] % groups != 0:
+        raise MmamdError(f"group_mean_normalize: {tuple(x.shape)} rows do not split into {groups} groups")
+    out = torch.empty((groups, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmamd_group_mean_normalize(x.data_ptr(), groups, x.shape[0] // groups, x.shape[1], out.data_ptr(), _stream()),
+          "mmamd_group_mean_normalize")
+    return out
+
+
+def scale_normalize(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """scale * x / |x| per row of an fp32 [rows, d] tensor."""
+    _chk(x, "x", torch.float32)
+    if x.dim() != 2:
+        raise MmamdError("scale_normalize expects a [rows, d] tensor")
+    out = torch.empty_like(x)
+    check(_lib.lib().mmamd_scale_normalize(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], float(scale), _stream()),
+          "mmamd_scale_normalize")
+    return out
+
+
+def target_rank(scores: torch.Tensor, target: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 [R]: how many entries of scores[r] beat scores[r, target[r]] (target None = the diagonal)."""
+    _chk(scores, "scores", torch.float32)
+    if scores.dim() != 2:
+        raise MmamdError("target_rank expects a [R, C] tensor")
+    R, Cc = scores.shape
+    if target is not None:
+        _chk(target, "target", torch.int64)
+        if target.numel() != R:
+            raise MmamdError(f"target has {target.numel()} entries, expected {R}")
+    rank = torch.empty((R,), dtype=torch.int32, device=scores.device)
+    check(_lib.lib().mmamd_target_rank(scores.data_ptr(), Cc, _ptr(target), R, Cc, rank.data_ptr(), _stream()), "mmamd_target_rank")
+    return rank

@@ -840,3 +840,35 @@ def dalle_encoder_forward(sd, x: Array, prefix: str = "", dtype=np.float32) -> A
 def dalle_codebook_indices(sd, images: Array, prefix: str = "encoder.") -> Array:
     """DalleVAEEncoder.get_codebook_indices (:733-735): argmax over the vocabulary axis."""
     return np.argmax(dalle_encoder_forward(sd, images, prefix), axis=1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Zero-shot / retrieval read-outs (SURVEY.md §8f rank 4): examples/flava/native/utils.py:100-160, examples/flava/coco_zero_shot.py:24-31,84-88
+def zero_shot_class_embedding(prompt_emb, dtype=np.float64):
+    """utils.py:108-111: normalise the prompt embeddings [T, E], average, normalise."""
+    e = np.asarray(prompt_emb, dtype)
+    e = e / np.linalg.norm(e, axis=-1, keepdims=True)
+    m = e.mean(0)
+    return m / np.linalg.norm(m)
+
+
+def zero_shot_logits(image_features, classifier, scale=100.0, dtype=np.float64):
+    """utils.py:141-142: (scale * features / |features|) @ classifier [E, C]."""
+    f = np.asarray(image_features, dtype)
+    f = f / np.linalg.norm(f, axis=-1, keepdims=True)
+    return (scale * f) @ np.asarray(classifier, dtype)
+
+
+def topk_hits(output, target, topk=(1,)):
+    """utils.py:117-123 `_accuracy`: for each k the number of rows whose target index is among the k largest scores
+    (stable descending order: on ties the lower index first)."""
+    out = np.asarray(output)
+    order = np.argsort(-out, axis=1, kind="stable")
+    t = np.asarray(target).reshape(-1, 1)
+    return [float((order[:, :k] == t).sum()) for k in topk]
+
+
+def recall_at_k(similarity, k=5):
+    """coco_zero_shot.py:24-31 `compute_recall`: targets on the diagonal."""
+    n = similarity.shape[0]
+    return topk_hits(similarity, np.arange(n), (k,))[0] / n
