@@ -166,3 +166,27 @@ def test_text_clip_init_std():
     m = CLIPTextEncoder(context_length=4, heads=2, width=64, layers=1).build_attention_mask()
     inf = float("inf")
     assert torch.equal(m, torch.tensor([[0, -inf, -inf, -inf], [0, 0, -inf, -inf], [0, 0, 0, -inf], [0, 0, 0, 0.0]]))
+
+
+def test_load_module_from_url_reads_a_reference_layout_checkpoint(golden, tmp_path):
+    """utils/common.py:99-107 without iopath: a checkpoint file in the reference's state_dict layout (here the midsize fixture's
+    weights, written with torch.save like the published .pt files) loads with strict=True; a wrong layout raises like torch does."""
+    from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
+    from multimodal_amd.utils.common import load_module_from_url
+    from tests._util import fixture_sd
+
+    z = golden("midsize.npz")
+    sd = {k: torch.from_numpy(v) for k, v in fixture_sd(z).items()}
+    path = tmp_path / "clip_midsize.pt"
+    torch.save(sd, path)
+    vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=2, patch_size=16, image_size=64, width=128)
+    txt = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=1000, width=128, dim_feedforward=256, heads=2, layers=2)
+    clip = CLIP(vit, txt)
+    load_module_from_url(clip, str(path))
+    for k, v in clip.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    sd.pop("encoder_a.projection")
+    torch.save(sd, path)
+    with pytest.raises(RuntimeError, match="Missing key"):
+        load_module_from_url(clip, str(path))
+    load_module_from_url(clip, str(path), strict=False)
