@@ -44,7 +44,7 @@ PROTOTYPES = {
     "mmamd_gemm_bf16_dual": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmamd_bicubic_pos_embed": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _f, _vp]),
     "mmamd_offset_position_ids": (_i, [_vp, _i64, _vp, _i, _i, _vp]),
-    "mmamd_image_resample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "mmamd_image_resample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmamd_group_mean_normalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmamd_scale_normalize": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "mmamd_target_rank": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),

@@ -128,21 +128,27 @@ __device__ __forceinline__ void h_tile_taps(int out_tile, int coef_lds, const in
           w[k] = (k0 + k < n) ? c : 0;
         }
         if (PX == 3) {
-          // RGB: two neighbouring taps are 6 consecutive bytes -> one (unaligned) 8-byte LDS read per tap pair and row; a pair that
-          // straddles the last tap reads bytes past the window (inside the LDS allocation) under a zero weight
+          // RGB: four neighbouring taps are 12 consecutive bytes -> one (unaligned) 16-byte LDS read per tap quad and row; a quad
+          // that straddles the last tap reads bytes past the window (inside the LDS allocation) under zero weights
 #pragma unroll
-          for (int k = 0; k < kTapBlock; k += 2) {
+          for (int k = 0; k < kTapBlock; k += 4) {
             if (k0 + k < n) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                uint2 v;
-                __builtin_memcpy(&v, lds + base[j] + k * 3, 8);
+                uint4 v;
+                __builtin_memcpy(&v, lds + base[j] + k * 3, 16);
                 acc[j][0] += __mul24((int)(v.x & 0xffu), w[k]);
                 acc[j][1] += __mul24((int)((v.x >> 8) & 0xffu), w[k]);
                 acc[j][2] += __mul24((int)((v.x >> 16) & 0xffu), w[k]);
                 acc[j][0] += __mul24((int)(v.x >> 24), w[k + 1]);
                 acc[j][1] += __mul24((int)(v.y & 0xffu), w[k + 1]);
                 acc[j][2] += __mul24((int)((v.y >> 8) & 0xffu), w[k + 1]);
+                acc[j][0] += __mul24((int)((v.y >> 16) & 0xffu), w[k + 2]);
+                acc[j][1] += __mul24((int)(v.y >> 24), w[k + 2]);
+                acc[j][2] += __mul24((int)(v.z & 0xffu), w[k + 2]);
+                acc[j][0] += __mul24((int)((v.z >> 8) & 0xffu), w[k + 3]);
+                acc[j][1] += __mul24((int)((v.z >> 16) & 0xffu), w[k + 3]);
+                acc[j][2] += __mul24((int)(v.z >> 24), w[k + 3]);
               }
             }
           }
@@ -324,8 +330,8 @@ __global__ void __launch_bounds__(256) resample_v_tiled_kernel(const int64_t* __
 using namespace mmamd;
 
 extern "C" int mmamd_image_resample(const int64_t* desc, const int32_t* tables, uint8_t* tmp, int B, int crop_h, int crop_w,
-                                    int max_rows, int max_seg_bytes, const float* lut, float* out_f32, void* patches, int P,
-                                    int kpad, uint8_t* out_u8, mmamd_stream_t stream) {
+                                    int max_rows, int max_seg_bytes, int max_coef_ints, const float* lut, float* out_f32,
+                                    void* patches, int P, int kpad, uint8_t* out_u8, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(desc && tables && tmp && B >= 0 && crop_h > 0 && crop_w > 0 && max_rows > 0, MMAMD_E_BADARG,
                   "image_resample: bad argument");
   MMAMD_CHECK_ARG(out_f32 || patches || out_u8, MMAMD_E_BADARG, "image_resample: no output requested");
@@ -341,7 +347,9 @@ extern "C" int mmamd_image_resample(const int64_t* desc, const int32_t* tables, 
   // H pass: tiled when a row segment (+ up to 15 bytes of alignment slack, rounded to 16) and the result tile fit the 64 KiB LDS
   const int seg_pitch = (max_seg_bytes + 15 + 15) & ~15;
   const int out_pitch = (crop_w * 3 + 15) & ~15;
-  const int coef_cap = 4096;  // ints of LDS for the coefficient table (16 KiB: 224 columns x 18 taps, i.e. down-scales to 4.25x)
+  // ints of LDS for the horizontal coefficient table: what the batch needs, up to 16 KiB (224 columns x 18 taps, i.e. down-scales
+  // to 4.25x); larger tables are read from global memory by the blocks that have them
+  const int coef_cap = max_coef_ints <= 0 ? 0 : (max_coef_ints < 4096 ? (max_coef_ints + 3) & ~3 : 4096);
   int R = 0;
   if (quad && max_seg_bytes > 0)
     for (int r = 8; r >= 1; r >>= 1)

@@ -876,7 +876,7 @@ class GemmProbe:
 
 
 def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, B: int, crop_h: int, crop_w: int, max_rows: int,
-                   max_seg_bytes: int, lut: Optional[torch.Tensor], want_f32: bool = True, patch: int = 0, kpad: int = 0,
+                   max_seg_bytes: int, max_coef_ints: int, lut: Optional[torch.Tensor], want_f32: bool = True, patch: int = 0, kpad: int = 0,
                    want_u8: bool = False):
     """mmamd_image_resample: Pillow-exact resize + crop + byte -> float value table (+ im2col) of a ragged uint8 batch.
     desc int64 [B,16], tables int32, tmp uint8, lut float32 [3,256] -- all on the device, laid out as include/mmamd.h says.
@@ -898,7 +898,7 @@ def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, 
         pt = (torch.empty if kpad == k else torch.zeros)((rows, kpad), dtype=torch.bfloat16, device=dev)
     u8 = torch.empty((B, crop_h, crop_w, 3), dtype=torch.uint8, device=dev) if want_u8 else None
     check(_lib.lib().mmamd_image_resample(desc.data_ptr(), tables.data_ptr(), tmp.data_ptr(), B, crop_h, crop_w, max_rows,
-                                          int(max_seg_bytes), _ptr(lut), _ptr(out), _ptr(pt), patch, kpad, _ptr(u8), _stream()),
+                                          int(max_seg_bytes), int(max_coef_ints), _ptr(lut), _ptr(out), _ptr(pt), patch, kpad, _ptr(u8), _stream()),
           "mmamd_image_resample")
     return out, pt, u8
 

@@ -98,12 +98,13 @@ class DeviceResampler:
     def plan(self, items: Sequence, geoms: Sequence[Geometry]):
         """Host geometry of a batch: the descriptor table (word 0 still relative to each image's first byte), the concatenated
         int32 coefficient tables, each host image's offset in the pixel staging area (None for device tensors), and the sizes
-        (pixel staging bytes, tmp bytes, max rows of the vertical window, max source bytes per row of the horizontal pass).
+        (pixel staging bytes, tmp bytes, max rows of the vertical window, max source bytes per row of the horizontal pass, max size of
+        a horizontal coefficient table).
         Images with the same geometry share one copy of their tables."""
         ch, cw = self.crop_hw
         B = len(items)
         desc = np.zeros((B, _DESC), np.int64)
-        tabs, slots, tab_len, host_off, host_len, tmp_len, max_rows, max_seg = [], {}, 0, [], 0, 0, 1, 0
+        tabs, slots, tab_len, host_off, host_len, tmp_len, max_rows, max_seg, max_coef = [], {}, 0, [], 0, 0, 1, 0, 0
         for b, ((a, px), ((vi, vj, vh, vw), (oh, ow), (top, left))) in enumerate(zip(items, geoms)):
             h, w = int(a.shape[0]), int(a.shape[1])
             if h < 1 or w < 1:
@@ -123,13 +124,14 @@ class DeviceResampler:
             tmp_len += (nrows * cw * 3 + 15) // 16 * 16
             max_rows = max(max_rows, nrows)
             max_seg = max(max_seg, seg_cols * px)
+            max_coef = max(max_coef, cw * ksh)
             if isinstance(a, Tensor):
                 host_off.append(None)
             else:
                 host_off.append(host_len)
                 host_len += (a.size + 15) // 16 * 16
         tables = np.concatenate(tabs) if tabs else np.zeros(0, np.int32)
-        return desc, tables, host_off, host_len, tmp_len, max_rows, max_seg
+        return desc, tables, host_off, host_len, tmp_len, max_rows, max_seg, max_coef
 
     def upload(self, items: Sequence) -> List:
         """Move the host images of `items` to the device in one pinned-buffer copy; device tensors pass through.  Lets several
@@ -160,7 +162,7 @@ class DeviceResampler:
                                  f"{torch.cuda.is_available()}): there is no CPU path")
         ch, cw = self.crop_hw
         B = len(items)
-        desc, tables, host_off, host_len, tmp_len, max_rows, max_seg = self.plan(items, geoms)
+        desc, tables, host_off, host_len, tmp_len, max_rows, max_seg, max_coef = self.plan(items, geoms)
         # one staging buffer [desc | value table | coefficient tables | pixels of the host images], one H2D copy
         o_lut = B * _DESC * 8
         o_tab = o_lut + 768 * 4
@@ -184,5 +186,5 @@ class DeviceResampler:
         tmp = torch.empty(max(tmp_len, 16), dtype=torch.uint8, device=self.device)
         tab_dev = dev[o_tab:o_tab + max(n_tab, 4)].view(torch.int32)
         lut_dev = dev[o_lut:o_tab].view(torch.float32) if lut is not None else None
-        return ops.image_resample(dev[:o_lut].view(torch.int64), tab_dev, tmp, B, ch, cw, max_rows, max_seg, lut_dev, want_f32,
+        return ops.image_resample(dev[:o_lut].view(torch.int64), tab_dev, tmp, B, ch, cw, max_rows, max_seg, max_coef, lut_dev, want_f32,
                                   patch, kpad, want_u8)

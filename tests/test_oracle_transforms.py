@@ -72,9 +72,9 @@ def test_eval_geometry_equals_oracle():
     ims, rgbx = _images()
     t = CLIPImageTransform(image_size=32, is_train=False)
     items = [_as_u8_hwc(a) for a in ims + [rgbx]]
-    desc, tables, host_off, host_len, tmp_len, max_rows, max_seg = t._plan_batch(items)
+    desc, tables, host_off, host_len, tmp_len, max_rows, max_seg, max_coef = t._plan_batch(items)
     assert max_rows == int(desc[:, 5].max()) and host_len >= sum(a.size for a, _ in items)
-    assert 0 < max_seg <= max(a.shape[1] * px for a, px in items)
+    assert 0 < max_seg <= max(a.shape[1] * px for a, px in items) and max_coef == 32 * int(desc[:, 8].max())
     f32, patches, u8 = emulate(items, desc, tables, tmp_len, 32, 32, t.lut, patch=16, kpad=768)
     for b, a in enumerate(ims + [rgbx[:, :, :3].copy()]):
         want = T.clip_image_transform_eval(a, 32)
@@ -88,7 +88,7 @@ def test_eval_geometry_rectangular_size_and_pil_input():
     t = CLIPImageTransform(image_size=(24, 40), is_train=False)
     pil = [Image.fromarray(ims[0]), Image.fromarray(ims[1][:, :, 0]), Image.fromarray(np.dstack([ims[2], ims[2][:, :, :1]]), "RGBA")]
     items = [_as_u8_hwc(p) for p in pil]
-    desc, tables, _, _, tmp_len, _, _ = t._plan_batch(items)
+    desc, tables, _, _, tmp_len, _, _, _ = t._plan_batch(items)
     f32, _, _ = emulate(items, desc, tables, tmp_len, 24, 40, t.lut)
     for b, p in enumerate(pil):
         assert np.array_equal(f32[b], T.clip_image_transform_eval(np.asarray(p.convert("RGB")), (24, 40)))
@@ -104,7 +104,7 @@ def test_train_geometry_equals_oracle_for_the_same_draws():
         assert 0.08 * a.shape[0] * a.shape[1] * 0.7 <= h * w  # rounding slack on the 8 % lower area bound
     torch.manual_seed(1234)
     items = [_as_u8_hwc(a) for a in ims]
-    desc, tables, _, _, tmp_len, _, _ = t._plan_batch(items)
+    desc, tables, _, _, tmp_len, _, _, _ = t._plan_batch(items)
     f32, _, _ = emulate(items, desc, tables, tmp_len, 32, 32, t.lut)
     for b, (a, (i, j, h, w)) in enumerate(zip(ims, boxes)):
         assert np.array_equal(f32[b], T.resized_crop(a, i, j, h, w, 32)), b
@@ -268,10 +268,10 @@ def test_flava_eval_geometry_chains_two_resamplings():
     t = FLAVAImageTransform(is_train=False, encoder_input_size=32, codebook_input_size=16)
     items = [_as_u8_hwc(a) for a in ims]
     whole = [((0, 0, a.shape[0], a.shape[1]), (32, 32), (0, 0)) for a in ims]
-    desc, tables, _, _, tmp_len, _, _ = t.encoder.plan(items, whole)
+    desc, tables, _, _, tmp_len, _, _, _ = t.encoder.plan(items, whole)
     enc, _, small = emulate(items, desc, tables, tmp_len, 32, 32, t.image_lut)
     second = [(small[b], 3) for b in range(len(ims))]
-    desc, tables, _, _, tmp_len, _, _ = t.codebook.plan(second, [((0, 0, 32, 32), (16, 16), (0, 0))] * len(ims))
+    desc, tables, _, _, tmp_len, _, _, _ = t.codebook.plan(second, [((0, 0, 32, 32), (16, 16), (0, 0))] * len(ims))
     cb, _, _ = emulate(second, desc, tables, tmp_len, 16, 16, t.codebook_lut)
     for b, a in enumerate(ims):
         want_enc, want_cb = T.flava_image_transform_eval(a, 32, 16)
