@@ -13,7 +13,7 @@ for f in sorted(root.rglob("*counter_collection.csv")):
             k = row.get("Kernel_Name", "?")[:70]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
-    if "gemm" not in k and "attention" not in k:
+    if "gemm" not in k and "attention" not in k and "resample" not in k:
         continue
     print(k)
     for c, v in sorted(d.items()):
