@@ -237,6 +237,7 @@ class CLIPImageTransform(nn.Module):
             raise ValueError("image_std has a zero entry")
         self.is_train = is_train
         self.lut = normalize_lut(self.image_mean, self.image_std)
+        self._eval_plans: dict = {}  # (h, w) -> geometry of the Resize + CenterCrop branch
         self.resampler = DeviceResampler(self.crop_hw, "bicubic", device)
 
     @property
@@ -249,10 +250,13 @@ class CLIPImageTransform(nn.Module):
         if self.is_train:
             i, j, vh, vw = random_resized_crop_params(h, w)
             return (i, j, vh, vw), (ch, cw), (0, 0)
-        oh, ow = resize_output_size(h, w, self.image_size)
-        if oh < ch or ow < cw:
-            raise ops.MmamdError(f"resized image {oh}x{ow} is smaller than the crop {ch}x{cw}: padding crops are not implemented")
-        return (0, 0, h, w), (oh, ow), center_crop_origin(oh, ow, ch, cw)
+        hit = self._eval_plans.get((h, w))
+        if hit is None:
+            oh, ow = resize_output_size(h, w, self.image_size)
+            if oh < ch or ow < cw:
+                raise ops.MmamdError(f"resized image {oh}x{ow} is smaller than the crop {ch}x{cw}: padding crops are not implemented")
+            hit = self._eval_plans[(h, w)] = ((0, 0, h, w), (oh, ow), center_crop_origin(oh, ow, ch, cw))
+        return hit
 
     def _plan_batch(self, items):
         return self.resampler.plan(items, [self._plan(int(a.shape[0]), int(a.shape[1])) for a, _ in items])
