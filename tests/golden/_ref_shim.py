@@ -54,3 +54,33 @@ def install() -> None:
     _mod("torchvision.models.resnet", Bottleneck=_Absent, ResNet=_Absent)
     _mod("torchvision.ops"); _mod("torchvision.ops.stochastic_depth", StochasticDepth=StochasticDepth)
     sys.path.append(REFERENCE_ROOT)  # append: the reference also has a top-level `tests` package
+
+
+def install_transform_stubs() -> None:
+    """Stand-ins that let torchmultimodal/transforms/{clip,flava}_transform.py be IMPORTED here (ftfy and torchvision.transforms are
+    absent): the tokenizer's encode() path and the mask generator touch none of them; the image classes are never instantiated."""
+    install()
+    if "torchvision.transforms" in sys.modules:
+        return
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Base:
+        def __init__(self, *a, **k):
+            pass
+
+    _mod("ftfy", fix_text=lambda s: s)
+    modes = types.SimpleNamespace(BICUBIC="bicubic", LANCZOS="lanczos")
+    tr = _mod("torchvision.transforms", InterpolationMode=modes, Resize=_Base, RandomResizedCrop=_Base, Compose=_Base, Lambda=_Base,
+              ToTensor=_Base, Normalize=_Base)
+    fn = _mod("torchvision.transforms.functional")
+    sys.modules["torchvision"].transforms = tr
+    tr.functional = fn
+    import torchmultimodal
+
+    torchmultimodal._PATH_MANAGER.open = lambda p, *a, **k: open(p, *a, **k)
+    torchmultimodal._PATH_MANAGER.get_local_path = lambda p: p
