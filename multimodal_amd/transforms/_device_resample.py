@@ -193,6 +193,11 @@ class DeviceResampler:
                                  f"{torch.cuda.is_available()}): there is no CPU path")
         ch, cw = self.crop_hw
         B = len(items)
+        if B == 0:  # nothing to launch: empty outputs of the right shapes
+            k = kpad or 3 * patch * patch
+            return (torch.empty((0, 3, ch, cw), dtype=torch.float32, device=self.device) if want_f32 else None,
+                    torch.empty((0, k), dtype=torch.bfloat16, device=self.device) if patch else None,
+                    torch.empty((0, ch, cw, 3), dtype=torch.uint8, device=self.device) if want_u8 else None)
         desc, tables, host_off, host_len, tmp_len, max_rows, max_seg, max_coef = self.plan(items, geoms)
         # one staging buffer [desc | value table | coefficient tables | pixels of the host images], one H2D copy
         o_lut = B * _DESC * 8

@@ -232,3 +232,11 @@ def test_flava_train_transform_reference_kat_and_same_draws():
         want_enc, want_cb = T.flava_image_transform_train(a, boxes[b])
         assert np.array_equal(out["image"][b].cpu().numpy(), want_enc), b
         assert np.array_equal(out["image_for_codebook"][b].cpu().numpy(), want_cb), b
+
+
+def test_empty_batch_returns_empty_tensors():
+    from multimodal_amd.transforms.clip_transform import CLIPImageTransform
+
+    t = CLIPImageTransform(is_train=False)
+    assert t([]).shape == (0, 3, 224, 224)
+    assert t.patches([], 16, 768).shape == (0, 768)
