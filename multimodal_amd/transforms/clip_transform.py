@@ -176,6 +176,15 @@ class CLIPTextTransform(nn.Module):
         self.text_max_length = text_max_length
         self.device = torch.device(device) if device is not None else None
 
+    @property
+    def text_transform(self) -> nn.Sequential:
+        """The stage-by-stage pipeline the reference keeps under this name (clip_transform.py:281-294): tokenizer, Truncate, AddToken
+        (start), AddToken (end), ToTensor, PadTransform.  forward() computes the same ids in one pass over a single buffer."""
+        return nn.Sequential(self.tokenizer, text_transforms.Truncate(self.text_max_length - 2),
+                             text_transforms.AddToken(self.text_start_token, begin=True),
+                             text_transforms.AddToken(self.text_end_token, begin=False), text_transforms.ToTensor(padding_value=0),
+                             text_transforms.PadTransform(max_length=self.text_max_length, pad_value=self.text_pad_token_id))
+
     def forward(self, text: Union[List[str], str]) -> Tensor:
         L = self.text_max_length
         single = isinstance(text, str)

@@ -185,6 +185,15 @@ def test_pad_token_fills_only_beyond_the_longest_row():
     assert got[0, 4:].tolist() == [pad] * 8 and got[1, 3].item() == 0 and got[1, 4:].tolist() == [pad] * 8
 
 
+def test_staged_pipeline_equals_the_fused_forward(clip_text):
+    """`text_transform` (the reference's nn.Sequential of text_transforms stages) and the one-pass forward agree."""
+    texts = [TEXT1, "a", "", (TEXT1 + " ") * 20]
+    assert torch.equal(clip_text.text_transform(texts), clip_text(texts))
+    assert torch.equal(clip_text.text_transform(TEXT1), clip_text(TEXT1))
+    t = CLIPTextTransform(text_max_length=12, text_bpe_merges_path=MERGES, text_pad_token="!")
+    assert torch.equal(t.text_transform(["a photo", "a"]), t(["a photo", "a"]))
+
+
 def test_remote_merges_path_fails_loudly():
     with pytest.raises(RuntimeError, match="no network"):
         CLIPBPETokenizer()
