@@ -342,3 +342,16 @@ def test_masking_generator_equals_reference_on_random_configs():
         random.seed(trial)
         mb = [b() for _ in range(3)]
         assert random.random() == sa and all(np.array_equal(x, y) for x, y in zip(ma, mb)), cfg
+
+
+def test_resize_rule_agrees_with_an_independent_restatement():
+    """torchvision is not installed here; Hugging Face transformers ships its own restatement of transforms.Resize(int) ("will
+    replicate torchvision.transforms.Resize", image_transforms.get_resize_output_image_size(default_to_square=False)).  A second
+    opinion on the size rule, not a pin: the reference KAT above is the pin."""
+    it = pytest.importorskip("transformers.image_transforms")
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        h, w, s = int(rng.integers(1, 3000)), int(rng.integers(1, 3000)), int(rng.integers(1, 600))
+        want = tuple(int(v) for v in it.get_resize_output_image_size(np.zeros((h, w, 3), np.uint8), s, default_to_square=False,
+                                                                     input_data_format="channels_last"))
+        assert resize_output_size(h, w, s) == want == T.tv_resize_output_size(h, w, s), (h, w, s)
