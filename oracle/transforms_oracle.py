@@ -17,7 +17,8 @@ The arithmetic of that transform lives in two third-party dependencies of the re
 
 Pinning: `pil_resize` (bicubic and Lanczos) is checked bit for bit against Pillow itself (tests/test_oracle_transforms.py, random images over
 up- and down-scales, extreme aspect ratios, 1-pixel edges); `tv_resize_output_size` against the reference's own KAT
-(tests/transforms/test_clip_transform.py:141-149: 500x300 -> (373, 224)).  The torchvision parts have no executable reference in
+(tests/transforms/test_clip_transform.py:141-149: 500x300 -> (373, 224)) and, as a second opinion, against Hugging Face
+transformers' own restatement of torchvision's Resize (image_transforms.get_resize_output_image_size) over random sizes.  The torchvision parts have no executable reference in
 this container: CenterCrop / ToTensor / Normalize are restated from their published definitions ("parity unpinned" for those three
 one-liners and for the RandomResizedCrop parameter draw).
 
