@@ -49,25 +49,38 @@ class CLIP(nn.Module):
         self.encoder_b = encoder_b
 
     def forward(self, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
+        return self._forward(self.encoder_a, features_a, features_b)
+
+    def forward_patches(self, patches_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
+        """Inference entry for a device-side loader (extension): modality A arrives as the bf16 im2col rows of
+        transforms.clip_transform.CLIPImageTransform.patches instead of the fp32 image (CLIPViTEncoder.forward_patches);
+        same towers, same two-stream schedule, same result as forward() on the corresponding image tensor."""
+        if _train.wants_grad(self):
+            raise ops.MmamdError("forward_patches is an inference entry: call it under torch.no_grad() / in eval mode")
+        if not hasattr(self.encoder_a, "forward_patches"):
+            raise ops.MmamdError(f"{type(self.encoder_a).__name__} has no forward_patches entry")
+        return self._forward(self.encoder_a.forward_patches, patches_a, features_b)
+
+    def _forward(self, tower_a, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
         # The two towers are independent until the normalised features meet in the loss: run tower B on a side HIP
         # stream so its small-grid kernels (77-token sequences: 150-600 workgroups per GEMM) fill the CUs that tower
         # A's kernels leave idle in their last, partial wave of workgroups.  Pure stream plumbing: same kernels,
         # same results.  MMAMD_SINGLE_STREAM=1 disables it.
         if _train.wants_grad(self):
             # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward, one stream
-            embeddings_a = _train.L2NormalizeFn.apply(self.encoder_a(features_a))
+            embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
             embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))
             return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
         side = self._side_stream(features_a)
         if side is None:
-            embeddings_a = self.encoder_a(features_a)
+            embeddings_a = tower_a(features_a)
             embeddings_b = self.encoder_b(features_b)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 embeddings_b = self.encoder_b(features_b)
-            embeddings_a = self.encoder_a(features_a)
+            embeddings_a = tower_a(features_a)
             main.wait_stream(side)
             embeddings_b.record_stream(main)
         embeddings_a = ops.l2_normalize(embeddings_a.detach().contiguous(), eps=1e-12)

@@ -240,3 +240,21 @@ def test_empty_batch_returns_empty_tensors():
     t = CLIPImageTransform(is_train=False)
     assert t([]).shape == (0, 3, 224, 224)
     assert t.patches([], 16, 768).shape == (0, 768)
+
+
+def test_clip_forward_patches_equals_forward_on_the_image_tensor():
+    from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
+    from multimodal_amd.transforms.clip_transform import CLIPTransform
+
+    set_rng_seed(2)
+    vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=2, patch_size=16, image_size=224, width=128)
+    txt = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=49408, width=128, dim_feedforward=256, heads=2, layers=2)
+    clip = CLIP(vit, txt).cuda().eval()
+    tr = CLIPTransform(text_bpe_merges_path=MERGES, is_train=False)
+    ims = _ragged(13, SIZES[:4])
+    texts = ["a photo of a cat", "two dogs", "a bicycle in the rain", "x"]
+    images, ids = tr(image=ims, text=texts)
+    with torch.no_grad():
+        a = clip(images, ids.cuda())
+        b = clip.forward_patches(tr.image_transform.patches(ims, 16, 768), ids.cuda())
+    assert torch.equal(a.embeddings_a, b.embeddings_a) and torch.equal(a.embeddings_b, b.embeddings_b)

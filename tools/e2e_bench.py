@@ -48,9 +48,8 @@ def main():
     images, ids = images.to(dev), ids.to(dev)
 
     def towers(patches, token_ids):
-        ea = model.encoder_a.forward_patches(patches)
-        eb = model.encoder_b(token_ids)
-        return loss_fn(ops.l2_normalize(ea.contiguous()), ops.l2_normalize(eb.contiguous()))
+        out = model.forward_patches(patches, token_ids)  # the same two-stream schedule as model(images, ids)
+        return loss_fn(out.embeddings_a, out.embeddings_b)
 
     def resident():
         out = model(images, ids)
