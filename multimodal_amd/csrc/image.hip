@@ -2,17 +2,19 @@
 // Resize(bicubic) + crop + ToTensor + Normalize (+ im2col for the patch-embedding GEMM), replacing the per-image PIL / torch
 // host loop of torchmultimodal/transforms/clip_transform.py:326-352.
 //
-// Byte / integer work, HBM-bound and small: no MFMA, no LDS.  The resampling is Pillow's (Resample.c) two 8-bit passes with its
+// Byte / integer work, HBM-bound by nature and small: no MFMA.  The resampling is Pillow's (Resample.c) two 8-bit passes with its
 // fixed-point coefficients (22 fractional bits, built by the host in double precision exactly as precompute_coeffs does):
 //   pass H  source view rows [row0, row0+nrows) x the crop_w output columns the crop keeps  -> uint8 tmp [nrows][crop_w][3]
 //   pass V  the crop_h output rows from tmp -> uint8 -> value table [3][256] (the host tabulates ToTensor + Normalize, or FLAVA's
-//           map_pixels, in IEEE fp32: 256 possible results per channel) -> any of: fp32 [B,3,crop_h,crop_w] (what the reference returns), bf16 patch rows [B*G2, kpad] (column
-//           (c*P+py)*P+px: the GEMM operand), uint8 [B,crop_h,crop_w,3] (the resized crop itself).
+//           map_pixels, in IEEE fp32: 256 possible results per channel) -> any of: fp32 [B,3,crop_h,crop_w] (what the reference
+//           returns), bf16 patch rows [B*G2, kpad] (column (c*P+py)*P+px: the GEMM operand), uint8 [B,crop_h,crop_w,3] (the resized
+//           crop itself).
 // The uint8 intermediate between the passes is part of the algorithm (Pillow rounds there).  Two implementations of each pass:
-//   tiled   (the one that runs for ordinary images) H: a block stages the source segment of R rows in LDS with aligned 16-byte
-//           loads, one thread per output pixel walks its taps out of LDS for all R rows (a coefficient is fetched once per tap,
-//           not once per byte), the R x crop_w x 3 result tile goes back through LDS as 16-byte stores.  V: one thread per 4
-//           output pixels = 12 consecutive bytes = 3 dword loads per tap row, 12 accumulators, vector stores (f32x4 / bf16x4).
+//   tiled   (the one that runs for ordinary images) H: a block stages the source segment of R rows (and the image's coefficient
+//           table) in LDS with aligned 16-byte loads, one thread per output pixel walks its taps out of LDS for 4 rows at a time
+//           (RGB: four taps = 12 bytes per LDS read), the R x crop_w x 3 result tile goes back through LDS as dword stores.
+//           V: one thread per 4 output pixels = 12 consecutive bytes = one 12-byte load per tap row, 12 accumulators, value-table
+//           lookups out of LDS, vector stores (f32x4 / bf16x4).
 //   direct  one thread per output byte (H) / pixel (V) straight from global memory: any crop width, any row length.
 // Algorithmic bytes per image: source segment rows + 2 x tmp + outputs.
 #include "common.h"
