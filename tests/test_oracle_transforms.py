@@ -367,3 +367,21 @@ def test_resize_rule_agrees_with_an_independent_restatement():
         pytest.skip("transformers.image_transforms not importable")
     for (h, w, sz), wv in zip(cases, want):
         assert resize_output_size(h, w, sz) == tuple(wv) == T.tv_resize_output_size(h, w, sz), (h, w, sz)
+
+
+def test_batch_plan_cache_returns_equal_and_independent_plans():
+    """An evaluation loader repeats the same batch geometry: the second plan comes from the cache, equals the first, and the caller's
+    in-place edits of its descriptor table (the base addresses added at launch time) do not leak back."""
+    ims, _ = _images(21)
+    t = CLIPImageTransform(image_size=32, is_train=False)
+    items = [_as_u8_hwc(a) for a in ims]
+    first = t._plan_batch(items)
+    first[0][:, 0] += 12345                      # what run() does to word 0
+    second = t._plan_batch(items)
+    assert second[0] is not first[0] and int(second[0][0, 0]) == int(first[0][0, 0]) - 12345
+    assert np.array_equal(second[1], first[1]) and second[2:] == first[2:]
+    other = t._plan_batch(items[:3])              # a different batch is a different plan
+    assert other[0].shape == (3, 16)
+    for _ in range(12):                           # the cache is bounded
+        t._plan_batch([_as_u8_hwc(np.zeros((40 + _, 50, 3), np.uint8))])
+    assert len(t.resampler._plans) <= 8
