@@ -1,22 +1,35 @@
 #!/usr/bin/env python
 """bench.py — image-text pairs/sec of the dual-encoder contrastive forward + loss on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python bench.py --gpus N --steps K --warmup W
+        N = 1: runs in this process.  N > 1 without a launcher environment (WORLD_SIZE unset): re-executes itself under
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` —
+        one process per GPU over RCCL; rank 0 prints the ONE JSON line.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+        the same, launched by the caller (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+    python bench.py --gpus 2 --backend gloo --dry-run
+        control flow of the N > 1 path on CPU (launcher, rendezvous, barrier + max-over-ranks timing, the packed all-gather
+        and its layout check, the JSON line) with stand-in features instead of the towers: what tests/test_bench_launcher.py
+        runs.  Not a measurement: the line says "dry_run": true and carries no roofline.
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): CLIP ViT-B/16 + text transformer,
 per-GPU batch 256, 224x224 synthetic images + 77 synthetic token ids, forward of both towers + L2 normalise +
 ContrastiveLossWithTemperature (local loss at N=1; global loss with one packed RCCL all-gather at N>1).
 One "step" = one such pass over one batch that is already resident in HBM.  Weak scaling: every rank encodes its
-own 256 pairs; `value` = N*256*K / max-over-ranks wall time of the K timed steps.
+own 256 pairs; `value` = N*256*K / max-over-ranks wall time of the K timed steps (warm-up 10, 50 timed steps by
+default; `ms_per_step_median` = the median of the per-step HIP-event durations of rank 0, reported next to the mean).
 
 Extra objects on the JSON line:
   roofline      the dominant kernel = the MLP-up GEMM of the vision tower ([50432 x 3072 x 768], 238 GFLOP per launch,
                 12 launches per step): algorithmic FLOPs / its mean launch duration, measured with HIP events on the
                 launch stream inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak.
   step_mfma_frac  whole-step figure: pairs/s x 41.09 GFLOP/pair / 2.5 PFLOP/s.
-  cpu_baseline  the numpy oracle (a port, not the reference) on the host cores, on a bounded sample (B=32) of the
-                same workload; rank 0, N=1 only.
+  cpu_baseline  rank 0, N=1 only: the reference's CPU path on this box's host cores, on a bounded sample (B=32, 1 warm-up +
+                3 timed passes) of the same batch.  /root/reference does not exist on the GPU box, so what is timed here is
+                oracle/torch_cpu_clip.py — the reference's module composition restated on the same torch.nn modules, i.e. the
+                same ATen CPU kernels ("kind": "reference-restatement"); the figure of the reference ITSELF, measured in the
+                build container by tests/golden/make_golden_headline.py, is carried next to it ("reference_itself").
+  rccl_ranks_seen  N > 1: all_reduce(SUM) of a one per rank over the bench's process group (RCCL for --backend nccl).
 """
 from __future__ import annotations
 
@@ -24,6 +37,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -33,51 +48,154 @@ sys.path.insert(0, str(ROOT))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md "Chip-level parameters")
 GF_PER_PAIR = 41.09             # BASELINE.md §3, CLIP ViT-B/16 + text, full S^2 attention counted
+METRIC = "image-text pairs/sec (fwd+contrastive loss), CLIP ViT-B/16 B=256"
 
 
-def _blas_threads() -> int:
-    """Threads the numpy BLAS actually uses (OpenBLAS caps at its build-time MAX_THREADS, not os.cpu_count())."""
-    try:
-        from threadpoolctl import threadpool_info
-
-        n = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
-        if n:
-            return int(max(n))
-    except Exception:
-        pass
-    return os.cpu_count() or 1
-
-
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="batch of the CPU-baseline sample; 0 = skip")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--no-probe", action="store_true", help="do not bracket the dominant GEMM with events")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" IS RCCL on ROCm; gloo only with --dry-run')
+    ap.add_argument("--dry-run", action="store_true", help="CPU control-flow run of the multi-rank path (no towers, no measurement)")
+    return ap.parse_args(argv)
 
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relaunch(args) -> int:
+    """--gpus N > 1 outside a launcher: become `torch.distributed.run` with N local ranks (same argv)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def fence(dev, dist, world):
     import torch
+
+    if dev is not None:
+        torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+
+
+def dry_main(args, rank, world) -> None:
+    """The N > 1 control flow on CPU tensors: rendezvous, ranks-seen reduction, packed gather + layout check, fenced timing, JSON."""
+    import torch
+    import torch.distributed as dist
+
+    from multimodal_amd.utils.distributed import gather_packed_features
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend)
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
+    B, E = args.batch, 512
+    g = torch.Generator().manual_seed(1234 + rank)
+    a = torch.nn.functional.normalize(torch.randn(B, E, generator=g))
+    b = torch.nn.functional.normalize(torch.randn(B, E, generator=g))
+    for _ in range(args.warmup):
+        gather_packed_features(a, b)
+    fence(None, dist, world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        buf, r, w = gather_packed_features(a, b)
+    fence(None, dist, world)
+    dt = time.perf_counter() - t0
+    assert (r, w) == (rank, world) and buf.shape == (world * B, 2 * E)
+    assert torch.equal(buf[rank * B:(rank + 1) * B, :E], a) and torch.equal(buf[rank * B:(rank + 1) * B, E:], b)
+    t = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(float(t) / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "backend": args.backend,
+                          "ranks_seen": int(ones.item()),
+                          "config": {"workload": "control flow of the multi-rank path on CPU tensors (no towers)", "per_gpu_batch": B,
+                                     "global_batch": world * B, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_leg(sd_host, images, ids, n):
+    """The reference's CPU path, timed on this host (see the module docstring): 1 warm-up + 3 timed passes of n pairs."""
+    import torch
+
+    from oracle.torch_cpu_clip import TorchCPUCLIP
+
+    m = TorchCPUCLIP(sd_host, vision_heads=12, text_heads=8)
+    im_s, id_s = images[:n].clone(), ids[:n].clone()
+    times = []
+    for _ in range(4):
+        tc = time.perf_counter()
+        out = m.forward_loss(im_s, id_s)
+        times.append(time.perf_counter() - tc)
+    med = sorted(times[1:])[1]
+    ref_itself = None
+    p = ROOT / "profiles" / "r02_reference_cpu.json"
+    if p.exists():
+        try:
+            z = json.loads(p.read_text())["clip_b16_b256"]
+            ref_itself = {"value": z["pairs_per_s"], "unit": "pairs/s", "cores": z["cores"], "threads": z["threads"], "batch": z["batch"],
+                          "where": "build container, tests/golden/make_golden_headline.py (the imported reference, fp32)"}
+        except Exception:
+            ref_itself = None
+    return {"value": round(n / med, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "host_logical_cpus": os.cpu_count(),
+            "kind": "reference-restatement",
+            "sample": f"first {n} pairs of the same synthetic ViT-B/16 batch, fp32, torch {torch.__version__} CPU kernels through "
+                      f"nn.TransformerEncoder (oracle/torch_cpu_clip.py), 1 warm-up + 3 timed passes, median {med:.2f} s",
+            "loss_on_sample": round(float(out[4]), 5), "reference_itself": ref_itself}
+
+
+def main() -> None:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(relaunch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_main(args, rank, world)
+    if args.backend != "nccl":
+        raise SystemExit("the measured path runs over RCCL (--backend nccl); gloo is for --dry-run")
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path to measure")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible); one process per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
 
+    ranks_seen = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm; intra-node transport = xGMI
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     from multimodal_amd import build
 
@@ -94,7 +212,7 @@ def main() -> None:
     ops.set_gemm_variant(args.gemm_variant)
     torch.manual_seed(0)
     model = clip_vit_b16()
-    sd_host = {k: v.numpy() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and args.cpu_sample) else None
+    sd_host = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and args.cpu_sample) else None
     model = model.to(dev).eval()
     loss_fn = ContrastiveLossWithTemperature().to(dev)
     B = args.batch
@@ -105,31 +223,31 @@ def main() -> None:
         out = model(images_d, ids_d)
         return loss_fn(out.embeddings_a, out.embeddings_b)
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
     S_img = 197
     probe = ops.GemmProbe(B * S_img, 3072, 768)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     with torch.no_grad():
         for _ in range(args.warmup):
             loss = step()
-        fence()
+        fence(dev, dist, world)
         t0 = time.perf_counter()
+        marks[0].record()
         if args.no_probe:
-            for _ in range(args.steps):
+            for i in range(args.steps):
                 loss = step()
+                marks[i + 1].record()
         else:
             with probe:
-                for _ in range(args.steps):
+                for i in range(args.steps):
                     loss = step()
-        fence()
+                    marks[i + 1].record()
+        fence(dev, dist, world)
         dt = time.perf_counter() - t0
     loss_val = float(loss)
     if not math.isfinite(loss_val):
         raise SystemExit(f"non-finite loss {loss_val}")
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if per_step else float("nan")
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -178,25 +296,14 @@ def main() -> None:
                     "isolated": {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
                                  "frac": round(flops / (iso_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}}
 
-    cpu_baseline = None
-    if sd_host is not None:
-        from oracle import clip_oracle as oc
-
-        n = args.cpu_sample
-        im_s, id_s = images[:n].numpy(), ids[:n].numpy()
-        tc = time.perf_counter()
-        a, b = oc.clip_forward(sd_host, im_s, id_s, 12, 8)
-        o = oc.contrastive_loss_with_temperature(a, b, math.log(1 / 0.07))
-        tcpu = time.perf_counter() - tc
-        cpu_baseline = {"value": round(n / tcpu, 3), "unit": "pairs/s", "cores": _blas_threads(), "kind": "port",
-                        "sample": f"first {n} pairs of the same synthetic ViT-B/16 batch, fp32 numpy+OpenBLAS oracle, "
-                                  f"1 pass, {tcpu:.1f} s", "loss_on_sample": round(float(o["loss"]), 5)}
+    cpu_baseline = cpu_baseline_leg(sd_host, images, ids, args.cpu_sample) if sd_host is not None else None
 
     if rank == 0:
         line = {
-            "metric": "image-text pairs/sec (fwd+contrastive loss), CLIP ViT-B/16 B=256",
+            "metric": METRIC,
             "value": round(pairs_per_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "CLIP ViT-B/16 + text transformer forward + ContrastiveLossWithTemperature "
                                    f"({'local' if world == 1 else 'global, packed RCCL all-gather'}), random-init weights",
@@ -206,6 +313,8 @@ def main() -> None:
             "step_mfma_frac": round(pairs_per_s / world * GF_PER_PAIR * 1e9 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if ranks_seen is not None:
+            line["rccl_ranks_seen"] = ranks_seen
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -299,6 +299,10 @@ int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* w
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */
 int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream);
 int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n, int act, mmamd_stream_t stream);
+/* The activation MODULE called on its own (reference: modules/layers/activation.py:24-25, SiLU.forward = x * sigmoid(1.702 x); KAT
+ * tests/modules/layers/test_activation.py:12-16): out = act(x) when dy == NULL, else out = dy * act'(x).  Any n; x / dy / out all of
+ * `dtype` (MMAMD_F32 or MMAMD_BF16).  On the hot path the activation never runs as its own launch (GEMM epilogue). */
+int mmamd_activation(const void* x, const void* dy, void* out, int dtype, int64_t n, int act, mmamd_stream_t stream);
 /* dst[c*ld_dst + r] = bf16(src[r*ld_src + c]) for r < rows, 0 for rows <= r < ld_dst: operands of the weight-gradient GEMM
  * dW[N,K] = dY^T X computed by mmamd_gemm_bf16 as (dY^T)[N,M] . (X^T)[K,M]^T with the token index M as contraction.
  * colsum (optional, [cols] fp32) = column sums of the bf16-rounded source = the bias gradient of the same dY, produced in the same

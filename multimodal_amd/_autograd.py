@@ -239,8 +239,39 @@ class L2NormalizeFn(torch.autograd.Function):
         return ops.l2_normalize_bwd(x, dy.contiguous())
 
 
-def wants_grad(module) -> bool:
-    return module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+def grad_requested(module, *inputs) -> bool:
+    """autograd would record this forward in the reference: grad mode is on and a parameter or an input requires grad."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
+_EVAL_GRAD_MSG = ("{name}: forward in eval mode with autograd enabled would return outputs that are detached from the graph (the "
+                  "differentiable MI355X path of this module runs in train mode and returns no attention probabilities); call it under "
+                  "torch.no_grad() / with requires_grad_(False) parameters for inference, or .train() to differentiate")
+
+
+def wants_grad(module, *inputs) -> bool:
+    """True: take the differentiable (autograd-node) path.  Modules whose differentiable path changes what they return (FLAVA /
+    CoCa: no attention probabilities, only the last hidden state attached) take it in train mode only; an eval-mode forward
+    that autograd would have recorded raises instead of silently detaching its outputs."""
+    if not grad_requested(module, *inputs):
+        return False
+    if module.training:
+        return True
+    raise NotImplementedError(_EVAL_GRAD_MSG.format(name=type(module).__name__))
+
+
+def forbid_detached_forward(module, *inputs) -> None:
+    """Stand-alone layer forwards (one attention module, one MLP called outside its stack) have no differentiable path of their own:
+    training runs through the stack-level autograd nodes.  Where the reference would have recorded the call (grad mode on and a
+    parameter or an input requires grad, train OR eval mode), refuse loudly instead of returning detached tensors."""
+    if grad_requested(module, *inputs):
+        raise NotImplementedError(
+            f"{type(module).__name__}: this stand-alone forward has no differentiable path on the MI355X kernels (training goes "
+            "through the enclosing encoder / model); call it under torch.no_grad(), or freeze its parameters and detach its inputs")
 
 
 class CrossEntropyFn(torch.autograd.Function):

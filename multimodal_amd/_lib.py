@@ -58,6 +58,7 @@ PROTOTYPES = {
     "mmamd_dalle_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "mmamd_activation": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),
     "mmamd_transpose_to_bf16": (_i, [_vp, _i, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_l2_normalize_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "mmamd_scatter_add_rows": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp]),

@@ -4,7 +4,14 @@ The kernels want GEMM weights in bf16 and every small vector (biases, LayerNorm 
 positional rows, projections of the pooled row) in fp32, whatever dtype the nn.Parameters are kept in.
 Conversions run on the HIP convert kernel (ops.convert) and are cached per parameter; a cached copy is
 invalidated when the parameter's storage pointer or in-place version counter changes (load_state_dict,
-optimizer.step, .to(...)).  Parameters that already have the wanted dtype are used in place (no copy).
+optimizer.step, .to(...), any in-place op ON THE PARAMETER).  Parameters that already have the wanted dtype are used
+in place (no copy).
+
+LIMITATION: writes through `p.data` (`p.data.copy_(ckpt)`, `p.data.add_(...)` of a hand-written EMA, `module.weight.data.normal_()`)
+do not bump torch's version counter, so they cannot be seen from here.  Three things cover the common cases: every top-level model
+and encoder (PackedModeMixin) drops all packed copies on a train() <-> eval() transition (an EMA/averaged model is evaluated after
+`.eval()`); `load_module_from_url` drops them after loading; and `invalidate_packed()` is public for everything else (call it after
+editing `.data` of a module that has already run an inference forward).  The training path converts per step and is not affected.
 """
 from __future__ import annotations
 
@@ -15,12 +22,38 @@ import torch
 from . import ops
 
 
+_EPOCH = 0  # bumped by invalidate_packed(): every PackedCache re-packs lazily on its next lookup
+
+
+def invalidate_packed(model=None) -> None:
+    """Drop every cached kernel-ready parameter copy (of all modules: the argument is accepted for readability only).  Needed after
+    parameter edits that bypass torch's version counter (`.data` writes); cheap — copies are rebuilt on the next forward."""
+    global _EPOCH
+    _EPOCH += 1
+
+
+class PackedModeMixin:
+    """nn.Module mixin (list it BEFORE nn.Module): a train() <-> eval() transition drops the packed parameter copies."""
+
+    def train(self, mode: bool = True):
+        if bool(mode) != self.training:
+            invalidate_packed()
+        return super().train(mode)
+
+
 class PackedCache:
     def __init__(self) -> None:
         self._store: Dict[Tuple[int, torch.dtype], Tuple[int, int, torch.device, torch.Tensor]] = {}
         self._cat: Dict[tuple, tuple] = {}
+        self._epoch = _EPOCH
+
+    def _sync_epoch(self) -> None:
+        if self._epoch != _EPOCH:
+            self.clear()
+            self._epoch = _EPOCH
 
     def get(self, p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        self._sync_epoch()
         t = p.detach()
         if not t.is_cuda:
             raise ops.MmamdError(
@@ -39,6 +72,7 @@ class PackedCache:
     def get_cat(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
         """One contiguous kernel-ready buffer holding `params` stacked along dim 0 (e.g. FLAVA's separate query / key /
         value Linear weights as ONE [3d, d] in-projection, so q, k and v come out of a single GEMM)."""
+        self._sync_epoch()
         ts = [p.detach() for p in params]
         for t in ts:
             if not t.is_cuda:
@@ -62,6 +96,7 @@ class PackedCache:
     def get_padded_rows(self, p: torch.Tensor, dtype: torch.dtype, multiple: int) -> torch.Tensor:
         """`p` ([rows, ...]) with its row count rounded up to `multiple` (zero rows appended) — e.g. a [30522, d] vocabulary
         projection padded to the GEMM's N % 8 == 0."""
+        self._sync_epoch()
         t = p.detach()
         if not t.is_cuda:
             raise ops.MmamdError(

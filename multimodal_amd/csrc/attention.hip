@@ -556,12 +556,8 @@ static int launch_attn_probs(const void* qkv, const uint8_t* key_mask, void* out
   constexpr int SP = NKT * 32;
   constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2 + SP * 4 + 4 * 32 * 36 * 4;
   auto kern = attention_probs_kernel<NKT, TP>;
-  static bool attr_done = false;
-  if (!attr_done && smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("attention_probs: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), smem, st, (const bf16*)qkv, key_mask, (bf16*)out, (TP*)probs, S, H,
                      scale * 1.4426950408889634f);
   return launch_status("attention_probs_fwd");
@@ -749,12 +745,8 @@ static int launch_attn_x(const AttnX& p, int B, hipStream_t st) {
   constexpr int SP = NKT * 32;
   constexpr int smem = SP * (DH + 8) * 2 + DH * (SP + 4) * 2 + SP * 4;
   auto kern = attention_x_kernel<NKT, DH, TP>;
-  static bool attr_done = false;
-  if (!attr_done && smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("attention_x: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   hipLaunchKernelGGL(kern, dim3(B * p.H), dim3(256), smem, st, p);
   return launch_status("attention_x_fwd");
 }
@@ -1048,18 +1040,11 @@ static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const
   auto k1n = attention_bwd_dq_kernel<NKT, false>;
   auto k2c = attention_bwd_dkv_kernel<NKT, true>;
   auto k2n = attention_bwd_dkv_kernel<NKT, false>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    for (const void* f : {(const void*)k1c, (const void*)k1n})
-      if (smem1 > 64 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess) {
-        set_error("attention_bwd: hipFuncSetAttribute failed"); return MMAMD_E_UNSUPPORTED;
-      }
-    for (const void* f : {(const void*)k2c, (const void*)k2n})
-      if (smem2 > 64 * 1024 && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem2) != hipSuccess) {
-        set_error("attention_bwd: hipFuncSetAttribute failed"); return MMAMD_E_UNSUPPORTED;
-      }
-    attr_done = true;
-  }
+  static unsigned long long m1c = 0, m1n = 0, m2c = 0, m2n = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds((const void*)k1c, smem1, m1c)) return rc_attr;
+  if (int rc_attr = opt_in_lds((const void*)k1n, smem1, m1n)) return rc_attr;
+  if (int rc_attr = opt_in_lds((const void*)k2c, smem2, m2c)) return rc_attr;
+  if (int rc_attr = opt_in_lds((const void*)k2n, smem2, m2n)) return rc_attr;
   if (causal) {
     hipLaunchKernelGGL(k1c, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
     hipLaunchKernelGGL(k2c, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
@@ -1263,12 +1248,8 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
   constexpr int smem = SP * kKStride * 2 + ((NKT <= 8 && (ABL & 1) == 0) ? SP * kKStride * 2 : 64 * (SP + 4) * 2);
   constexpr int NW = 4;  // 8 waves per workgroup needs <= 128 VGPRs to be resident twice per CU: the kernel uses ~170
   auto kern = attention_fwd_kernel<NKT, CAUSAL, ABL, NW>;
-  static bool attr_done = false;
-  if (!attr_done && smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int BH = B * H;
   const int grid = BH < 512 ? BH : 512;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,

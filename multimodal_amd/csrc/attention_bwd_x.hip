@@ -301,20 +301,10 @@ static int launch_x_bwd(const AttnXB& p, int B, hipStream_t st) {
   if (smem1 > 160 * 1024) { set_error("attention_x_bwd: Sk=%d with head_dim=%d needs %d B of LDS (> 160 KiB)", p.Sk, DH, smem1); return MMAMD_E_UNSUPPORTED; }
   auto k1 = attention_x_bwd_dq_kernel<DH>;
   auto k2 = attention_x_bwd_dkv_kernel<DH>;
-  static int attr1 = 0;
-  static bool attr2 = false;
-  if (smem1 > attr1) {
-    if (smem1 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, smem1) != hipSuccess) {
-      set_error("attention_x_bwd: hipFuncSetAttribute failed"); return MMAMD_E_UNSUPPORTED;
-    }
-    attr1 = smem1;
-  }
-  if (!attr2) {
-    if (smem2 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, smem2) != hipSuccess) {
-      set_error("attention_x_bwd: hipFuncSetAttribute failed"); return MMAMD_E_UNSUPPORTED;
-    }
-    attr2 = true;
-  }
+  // per-device opt-in to > 64 KiB dynamic LDS; the dQ kernel's size varies with Sk, so it opts in to the 160 KiB maximum once
+  static unsigned long long m1 = 0, m2 = 0;
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(k1), smem1 > 64 * 1024 ? 160 * 1024 : 0, m1)) return rc_attr;
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(k2), smem2, m2)) return rc_attr;
   hipLaunchKernelGGL(k1, dim3(B * p.H), dim3(256), smem1, st, p);
   hipLaunchKernelGGL(k2, dim3(B * p.H), dim3(256), smem2, st, p);
   return launch_status("attention_x_bwd");

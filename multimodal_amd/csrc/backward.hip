@@ -234,6 +234,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ u
   }
 }
 
+// stand-alone activation module (modules/layers/activation.py:24-25 called on its own): any element count, fp32 or bf16
+template <typename T>
+__global__ __launch_bounds__(256) void act_elem_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = to_f32<T>(x[i]);
+    out[i] = (T)(dy == nullptr ? act_value(v, act) : to_f32<T>(dy[i]) * act_grad(v, act));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 transpose with zero padding: dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < ld_dst   (64 x 64 tiles through LDS)
 // ---------------------------------------------------------------------------------------------
@@ -390,6 +399,16 @@ extern "C" int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n,
   const int blocks = (int)((n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (const bf16*)dg, (bf16*)du, n4, act);
   return launch_status("act_bwd");
+}
+
+extern "C" int mmamd_activation(const void* x, const void* dy, void* out, int dtype, int64_t n, int act, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && out && n >= 0 && (act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF), MMAMD_E_BADARG, "activation: bad argument");
+  MMAMD_CHECK_ARG(dtype == MMAMD_F32 || dtype == MMAMD_BF16, MMAMD_E_BADARG, "activation: bad dtype %d", dtype);
+  if (n == 0) return 0;
+  const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+  if (dtype == MMAMD_F32) hipLaunchKernelGGL((act_elem_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, (float*)out, n, act);
+  else hipLaunchKernelGGL((act_elem_kernel<bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, (bf16*)out, n, act);
+  return launch_status("activation");
 }
 
 extern "C" int mmamd_transpose_to_bf16(const void* src, int src_dtype, int64_t ld_src, void* dst, int rows, int cols, int ld_dst,

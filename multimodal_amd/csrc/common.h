@@ -38,6 +38,20 @@ inline int launch_status(const char* what) {
   return 0;
 }
 
+// One-time opt-in to > 64 KiB of dynamic LDS (160 KiB per CU on gfx950), PER DEVICE: the attribute belongs to the function on the
+// current device, so a second GPU in the same process needs its own call (`mask`: one bit per device ordinal).
+inline int opt_in_lds(const void* kern, int smem, unsigned long long& mask) {
+  if (smem <= 64 * 1024) return 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute(%d B of dynamic LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
+  mask |= bit;
+  return 0;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers -------------------------------------------------------------------------

@@ -347,12 +347,8 @@ template <int BM, int BN, int WM, int WN>
 static int launch_conv(ConvArgs& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
-  static bool attr_done = false;
-  if (!attr_done && smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("conv_gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, st, p);

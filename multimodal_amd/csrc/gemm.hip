@@ -1793,12 +1793,8 @@ template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB>
 static int launch_tiled(GemmArgs& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, OUT_F32, ACT, SGB>;
-  static bool attr_done = false;  // one-time opt-in to >64 KiB dynamic LDS (160 KiB per CU on gfx950)
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, st, p);
@@ -1811,12 +1807,8 @@ static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<BM, BN, WM, WN, OUT_F32, ACT, true>(p, st);
   constexpr int smem = 2 * (BM + BN) * 128;
   auto kern = gemm_bf16_nt_kernel_p<BM, BN, WM, WN, OUT_F32, ACT, GM, ABL, LDSEPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), smem, st, p, tiles_m,
@@ -1828,12 +1820,8 @@ template <bool OUT_F32, int ACT, int GM, int SCHED = 0>
 static int launch_tiled_q(GemmArgs& p, hipStream_t st) {
   constexpr int smem = 4 * 512 * 64;
   auto kern = gemm_bf16_nt_kernel_q<OUT_F32, ACT, GM, SCHED>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m);
@@ -1844,12 +1832,8 @@ template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
 static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
   constexpr int smem = 4 * 512 * 64;
   auto kern = gemm_bf16_nt_kernel_s<OUT_F32, ACT, GM, TRACE, ABL>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m, TRACE ? g_gemm_trace : nullptr);
@@ -1862,12 +1846,8 @@ static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
   constexpr int smem = 2 * 512 * 128;
   auto kern = gemm_bf16_nt_kernel_g<OUT_F32, ACT, GM, TRACE, ABL>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m, TRACE ? g_gemm_trace : nullptr);
@@ -1881,12 +1861,8 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
   constexpr int smem = 2 * 512 * 128;
   auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("gemm: hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   const int ntiles = tiles_m * p.tiles_n;
@@ -2110,12 +2086,8 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0; p.split_flat = FLAT ? 1 : 0;
   constexpr int smem = 2 * 512 * 128;
   auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, GMV, 0, true, TNM, SCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("gemm_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (M + 255) / 256;
   p.tiles_n = (N + 255) / 256;
   hipStream_t st = (hipStream_t)stream;

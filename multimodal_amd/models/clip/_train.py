@@ -18,7 +18,9 @@ import torch
 from torch import Tensor
 
 from ... import ops
-from ..._autograd import EncoderStackFn, L2NormalizeFn, StackConfig, c32 as _c32, wants_grad, wgrad as _wgrad  # noqa: F401
+from ..._autograd import EncoderStackFn, L2NormalizeFn, StackConfig, c32 as _c32, grad_requested as wants_grad, wgrad as _wgrad  # noqa: F401
+# (CLIP: the differentiable path returns exactly what the inference path returns, so it is taken whenever autograd would record
+#  the call in the reference -- train OR eval mode; `wants_grad(module, *inputs)`)
 
 bf, f32 = torch.bfloat16, torch.float32
 

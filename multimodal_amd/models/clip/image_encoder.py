@@ -11,7 +11,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
-from ..._packing import PackedCache
+from ..._packing import PackedCache, PackedModeMixin
 from ...modules.layers.normalizations import Fp32LayerNorm
 from . import _train
 from ._transformer import TransformerStack, forbid_training_forward
@@ -19,7 +19,7 @@ from ._transformer import TransformerStack, forbid_training_forward
 EXPANSION = 4
 
 
-class CLIPViTEncoder(nn.Module):
+class CLIPViTEncoder(PackedModeMixin, nn.Module):
     """
     Vision transformer encoder for CLIP.
 
@@ -75,7 +75,7 @@ class CLIPViTEncoder(nn.Module):
                 f"Expected input with width and height as {self.image_size}, found {x.size(2)} by {x.size(3)} ")
         if x.size(1) != 3:
             raise ValueError(f"Expected 3 channels found {x.size(1)}")
-        if _train.wants_grad(self):
+        if _train.wants_grad(self, x):
             return self._forward_train(x)
         f32 = torch.float32
         pk = self._packed.get

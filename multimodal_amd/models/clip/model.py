@@ -11,6 +11,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ..._packing import PackedModeMixin
 from ...utils.common import load_module_from_url
 from . import _train
 from .image_encoder import CLIPViTEncoder
@@ -32,7 +33,7 @@ CLIP_MODEL_MAPPING = {
 }
 
 
-class CLIP(nn.Module):
+class CLIP(PackedModeMixin, nn.Module):
     """CLIP is a model for contrastive pretraining between two modalities.
 
     Args:   encoder_a (nn.Module): Instantiated encoder for modality A (e.g. CLIPViTEncoder).
@@ -55,7 +56,7 @@ class CLIP(nn.Module):
         """Inference entry for a device-side loader (extension): modality A arrives as the bf16 im2col rows of
         transforms.clip_transform.CLIPImageTransform.patches instead of the fp32 image (CLIPViTEncoder.forward_patches);
         same towers, same two-stream schedule, same result as forward() on the corresponding image tensor."""
-        if _train.wants_grad(self):
+        if _train.wants_grad(self, patches_a):
             raise ops.MmamdError("forward_patches is an inference entry: call it under torch.no_grad() / in eval mode")
         if not hasattr(self.encoder_a, "forward_patches"):
             raise ops.MmamdError(f"{type(self.encoder_a).__name__} has no forward_patches entry")
@@ -66,7 +67,7 @@ class CLIP(nn.Module):
         # stream so its small-grid kernels (77-token sequences: 150-600 workgroups per GEMM) fill the CUs that tower
         # A's kernels leave idle in their last, partial wave of workgroups.  Pure stream plumbing: same kernels,
         # same results.  MMAMD_SINGLE_STREAM=1 disables it.
-        if _train.wants_grad(self):
+        if _train.wants_grad(self, features_a, features_b):
             # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward, one stream
             embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
             embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))

@@ -12,13 +12,13 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
-from ..._packing import PackedCache
+from ..._packing import PackedCache, PackedModeMixin
 from ...modules.layers.normalizations import Fp32LayerNorm
 from . import _train
 from ._transformer import TransformerStack, forbid_training_forward
 
 
-class CLIPTextEncoder(nn.Module):
+class CLIPTextEncoder(PackedModeMixin, nn.Module):
     """CLIP text encoder class. Should be instantiated and passed to CLIP (models/clip/model.py)
 
     Args:

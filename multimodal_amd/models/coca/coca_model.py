@@ -16,7 +16,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
-from ..._packing import PackedCache
+from ..._packing import PackedCache, PackedModeMixin
 from ...modules.encoders.vision_transformer import vision_transformer
 from ...modules.layers.attention_pooler import AttentionPooler, CascadedAttentionPooler
 from ...modules.layers.transformer import TransformerOutput
@@ -44,7 +44,7 @@ def _side_stream(device: torch.device) -> torch.cuda.Stream:
     return s
 
 
-class CoCaModel(nn.Module):
+class CoCaModel(PackedModeMixin, nn.Module):
     def __init__(self, vision_encoder: nn.Module, text_decoder: CoCaTextDecoder, multimodal_decoder: CoCaMultimodalDecoder,
                  vision_pooler: nn.Module, vision_proj: nn.Module):
         super().__init__()
@@ -203,7 +203,7 @@ def coca_vit_l_14() -> CoCaModel:
         cascaded_pooler=True)
 
 
-class CoCaForPretraining(nn.Module):
+class CoCaForPretraining(PackedModeMixin, nn.Module):
     """CoCa model tied to the captioning and contrastive losses (reference :434-466)."""
 
     def __init__(self, model: CoCaModel, pad_idx: int = 0, contrastive_logit_scale_min: Optional[float] = math.log(1.0),
@@ -241,7 +241,7 @@ def coca_for_pretraining(pad_idx: int = 0, **kwargs: Any) -> CoCaForPretraining:
 default_coca_cls_pooler = partial(torch.select, dim=1, index=-1)
 
 
-class CoCaModelWithHeads(nn.Module):
+class CoCaModelWithHeads(PackedModeMixin, nn.Module):
     """CoCa with task heads on the pooled multimodal embeddings (reference :477-508).  The pooler / heads are user modules:
     they run as given (they are not part of the contrastive hot path)."""
 

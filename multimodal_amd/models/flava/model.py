@@ -20,7 +20,7 @@ from torch import nn, Tensor
 from typing_extensions import Literal
 
 from ... import ops
-from ..._packing import PackedCache
+from ..._packing import PackedCache, PackedModeMixin
 from ...modules.layers.normalizations import Fp32LayerNorm
 from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.flava import cls_linear, Pooler
@@ -84,7 +84,7 @@ def flava_multimodal_encoder(
     return FLAVATransformerWithoutEmbeddings(encoder=encoder, layernorm=layernorm, pooler=pooler, hidden_size=hidden_size)
 
 
-class FLAVAModel(nn.Module):
+class FLAVAModel(PackedModeMixin, nn.Module):
     def __init__(
         self,
         image_encoder: nn.Module,
@@ -341,7 +341,7 @@ FLAVAForClassificationOutput = namedtuple("FLAVAForClassificationOutput", ["logi
 FLAVAForClassificationOutput.__annotations__ = {"logits": Tensor, "loss": Tensor}
 
 
-class FLAVAForPreTraining(nn.Module):
+class FLAVAForPreTraining(PackedModeMixin, nn.Module):
     """Mirror of models/flava/model.py:301-378: model + image codebook + FLAVAPretrainingLoss.  `image_codebook` is any module that
     maps `image_for_codebook` to integer token ids [B, h, w] (DalleVAEEncoder, ._dalle: the implicit-GEMM pipeline of csrc/conv.hip);
     the label masking
@@ -399,7 +399,7 @@ class FLAVAForPreTraining(nn.Module):
         )
 
 
-class FLAVAForClassification(nn.Module):
+class FLAVAForClassification(PackedModeMixin, nn.Module):
     """Mirror of models/flava/model.py:380-422.  The classifier (modules.layers.mlp.MLP with nn.ReLU) runs on the CLS row in exact
     fp32 (mmamd_rows_linear_f32); an nn.CrossEntropyLoss `loss` is the cross-entropy kernel, any other callable is called as is."""
 

@@ -11,6 +11,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
+from ..._autograd import forbid_detached_forward
 from ..._packing import PackedCache
 
 HEAD_DIM = 64
@@ -92,6 +93,7 @@ class MultiHeadAttention(nn.Module):
             raise ops.MmamdError("use_cache / causal / head_mask are not implemented on the MI355X path")
         if q.dim() != 3:
             raise ops.MmamdError("MultiHeadAttention on the MI355X path takes [b, seq, c] inputs")
+        forbid_detached_forward(self, q)
         B, S, d = q.shape
         qc = q if q.is_contiguous() else q.contiguous()
         km = key_mask_from_attention_mask(attn_kwargs.get("attention_mask"), B, S)

@@ -126,6 +126,9 @@ class MLP(nn.Module):
             return h.view(*x.shape[:-1], h.shape[-1])
         if any(act == ACT_RELU_EXACT for _, act in steps):
             raise ops.MmamdError("MLP on the MI355X path: nn.ReLU cannot be mixed with the GEMM-epilogue activations in one MLP")
+        from ..._autograd import forbid_detached_forward
+
+        forbid_detached_forward(self, x)
         h = ops.convert(rows, torch.bfloat16)
         y = self.run(h)
         return y.view(*x.shape[:-1], y.shape[-1])

@@ -14,6 +14,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
+from ..._autograd import forbid_detached_forward
 from ..._packing import PackedCache
 from ...ops import AttnMask
 
@@ -84,6 +85,7 @@ class MultiHeadSelfAttention(nn.Module):
     def forward(self, query: Tensor, attn_mask: Optional[Tensor] = None, is_causal: bool = False) -> Tensor:
         if query.dim() != 3:
             raise ops.MmamdError("MultiHeadSelfAttention takes bsz x seq_len x embed_dim inputs")
+        forbid_detached_forward(self, query)
         B, S, d = query.shape
         qc = query if query.is_contiguous() else query.contiguous()
         mask = to_attn_mask(attn_mask, is_causal, B, S, S)
@@ -161,6 +163,7 @@ class MultiHeadAttentionWithCache(nn.Module):
             raise ops.MmamdError("key and value must be the same tensor on the MI355X path (self- or cross-attention)")
         if key.size(0) != query.size(0):
             raise ValueError("key and value should have the same bsz as query.")
+        forbid_detached_forward(self, query, key)
         B, Sq, dq = query.shape
         Sk = key.shape[1]
         bf = torch.bfloat16

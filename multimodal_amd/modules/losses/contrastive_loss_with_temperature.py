@@ -108,22 +108,25 @@ class _ContrastiveFn(torch.autograd.Function):
     forward = one packed all-gather + mmamd_contrastive_fwd; backward = mmamd_contrastive_bwd and, for BackpropType.GLOBAL with
     world > 1, ONE reduce-scatter of the packed [W*B, 2E] gathered-feature gradients (the reference: two autograd all-gathers whose
     backward are two reduce-scatters, utils/distributed.py:47-48).  LOCAL keeps only this rank's block of the gathered gradients
-    (no communication), NONE drops them.  The logits outputs are not differentiable through this node."""
+    (no communication), NONE drops them — inside an initialised process group (world size 1 included); without one the reference
+    never gathers, both operands of both matmuls are the live tensors, and every backprop_type differentiates through them.  The logits outputs are not differentiable through this node."""
 
     @staticmethod
     def forward(ctx, embeddings_a, embeddings_b, logit_scale, mask, backprop_type, smoothing, red_code):
         out3, logits_a, logits_b, saved = _contrastive_forward(embeddings_a, embeddings_b, logit_scale, mask, smoothing, red_code)
         a, b, buf, scale32, row_mask, rank, world = saved
         ctx.save_for_backward(a, b, buf, scale32, logits_a, logits_b, row_mask if row_mask is not None else torch.empty(0, device=a.device))
+        from ...utils.distributed import _dist_ready
+
         ctx.meta = (rank, world, backprop_type, smoothing, red_code, row_mask is not None, embeddings_a.dtype, embeddings_b.dtype,
-                    logit_scale.dtype, tuple(logit_scale.shape))
+                    logit_scale.dtype, tuple(logit_scale.shape), _dist_ready())
         ctx.mark_non_differentiable(logits_a, logits_b)
         return out3, logits_a, logits_b
 
     @staticmethod
     def backward(ctx, g_out3, _g_la, _g_lb):
         a, b, buf, scale32, logits_a, logits_b, row_mask = ctx.saved_tensors
-        rank, world, backprop_type, smoothing, red_code, has_mask, dt_a, dt_b, dt_s, s_shape = ctx.meta
+        rank, world, backprop_type, smoothing, red_code, has_mask, dt_a, dt_b, dt_s, s_shape, dist_on = ctx.meta
         B, E = a.shape
         g3 = g_out3.detach()
         g3 = (g3 if g3.is_contiguous() else g3.contiguous())
@@ -131,7 +134,11 @@ class _ContrastiveFn(torch.autograd.Function):
         rm = row_mask if has_mask else None
         a_all, b_all = buf[:, :E], buf[:, E:]
         add, all_rows, add_all = None, None, False
-        if backprop_type == BackpropType.GLOBAL and world > 1:
+        if not dist_on:
+            # no process group: the reference's _gather_embeddings_and_labels returns embeddings_a / embeddings_b THEMSELVES and never
+            # looks at backprop_type (…:31-33), so both matmul operands stay differentiable for GLOBAL, LOCAL and NONE alike
+            all_rows, add_all = (0, B), True
+        elif backprop_type == BackpropType.GLOBAL and world > 1:
             # gradients of every rank's gathered features, then ONE reduce-scatter; this rank's share is added to grad_a / grad_b
             _, _, g_all, _ = ops.contrastive_bwd(a, b, a_all, b_all, 2 * E, scale32, logits_a, logits_b, B * rank, rm, smoothing,
                                                  red_code, g3, None, (0, world * B))

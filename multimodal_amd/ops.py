@@ -21,7 +21,7 @@ __all__ = [
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
-    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "gemm_bf16_dual",
+    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
     "attention_x_bwd", "image_resample", "group_mean_normalize", "scale_normalize", "target_rank",
 ]
@@ -40,6 +40,10 @@ def _chk(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> tor
         raise TypeError(f"{name} must be a tensor")
     if not t.is_cuda:
         raise MmamdError(f"{name} is on {t.device}: the MI355X path needs HIP device tensors (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's stream: a tensor of another GPU would be dereferenced by the wrong device
+        raise MmamdError(f"{name} is on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: call "
+                         "torch.cuda.set_device(...) (one process per GPU) or wrap the call in `with torch.cuda.device(tensor.device)`")
     if dtype is not None and t.dtype != dtype:
         raise MmamdError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -750,6 +754,18 @@ def act_bwd(u: torch.Tensor, dg: torch.Tensor, act: int) -> torch.Tensor:
     du = torch.empty_like(u)
     check(_lib.lib().mmamd_act_bwd(u.data_ptr(), dg.data_ptr(), du.data_ptr(), u.numel(), int(act), _stream()), "mmamd_act_bwd")
     return du
+
+
+def activation(x: torch.Tensor, act: int, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x), or dy * act'(x) when dy is given: the activation module on its own (fp32 / bf16, any shape)."""
+    _chk(x, "x")
+    if dy is not None:
+        _chk(dy, "dy", x.dtype)
+        if dy.shape != x.shape:
+            raise MmamdError("activation: dy must have the shape of x")
+    out = torch.empty_like(x)
+    check(_lib.lib().mmamd_activation(x.data_ptr(), _ptr(dy), out.data_ptr(), _dt(x), x.numel(), int(act), _stream()), "mmamd_activation")
+    return out
 
 
 def transpose_to_bf16(src: torch.Tensor, pad_to: int = 128, with_colsum: bool = False):

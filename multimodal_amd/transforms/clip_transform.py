@@ -57,7 +57,21 @@ def _vocab_order() -> List[int]:
 
 def _open_text(path: str) -> str:
     if path.startswith(("http://", "https://")):
-        raise RuntimeError(f"no network on this path: download {path} and pass the local file as bpe_path / text_bpe_merges_path")
+        # same behaviour as utils.common.load_module_from_url: fetch once into the torch hub cache (the reference goes through
+        # iopath's HTTPURLHandler, transforms/clip_transform.py:100-104); offline this raises URLError, loudly
+        import os
+
+        import torch
+
+        cache = os.path.join(torch.hub.get_dir(), "checkpoints")
+        os.makedirs(cache, exist_ok=True)
+        local = os.path.join(cache, os.path.basename(path))
+        if not os.path.exists(local):
+            try:
+                torch.hub.download_url_to_file(path, local, progress=False)
+            except Exception as e:
+                raise RuntimeError(f"cannot fetch {path} ({e}): download it and pass the local file as bpe_path / text_bpe_merges_path") from e
+        path = local
     if path.endswith(".gz"):
         with gzip.open(path, "rt", encoding="utf-8") as f:
             return f.read()

@@ -39,3 +39,6 @@ def load_module_from_url(model: nn.Module, url: str, strict: bool = True, progre
     else:
         state_dict = torch.load(url, map_location="cpu")
     model.load_state_dict(state_dict, strict=strict)
+    from .._packing import invalidate_packed
+
+    invalidate_packed(model)  # kernel-ready copies of the old weights (bf16 / fp32 packs) are rebuilt on the next forward

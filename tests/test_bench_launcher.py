@@ -1,0 +1,72 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N ...` with no launcher around it must start its own N ranks.
+CPU coverage of that path (the reference's 2-worker pattern: tests/modules/losses/test_contrastive_loss_with_temperature.py:129-199,
+tests/test_utils.py:31-42 — mp.spawn + rendezvous; here torch.distributed.run + gloo):
+  * `--gpus 2 --backend gloo --dry-run` goes through the self-launch, the rendezvous on 127.0.0.1, the ranks-seen all-reduce, the
+    packed all-gather with its layout check, the fenced max-over-ranks timing and prints ONE JSON line from rank 0;
+  * `--gpus 2` on a box without GPUs fails at DEVICE SELECTION inside the ranks, not at argument checking."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def run_bench(*argv, timeout=300):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OMP_NUM_THREADS"] = "1"
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], cwd=str(ROOT), env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def json_lines(text):
+    out = []
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                out.append(json.loads(ln))
+            except ValueError:
+                pass
+    return out
+
+
+def test_self_launch_two_ranks_gloo_dry_run():
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "3", "--warmup", "1", "--batch", "8")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout  # rank 0 only
+    line = lines[0]
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo"
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert line["ms_per_step"] > 0
+
+
+def test_single_process_dry_run_needs_no_launcher():
+    p = run_bench("--gpus", "1", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "0", "--batch", "4")
+    assert p.returncode == 0, p.stderr[-2000:]
+    (line,) = json_lines(p.stdout)
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the failure mode of a box without GPUs")
+def test_gpus_2_without_devices_fails_at_device_selection():
+    p = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0
+    err = p.stderr + p.stdout
+    assert "no HIP device visible" in err  # reached the ranks' device selection ...
+    assert "must be launched with" not in err  # ... and did not stop at argument checking
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo"], cwd=str(ROOT), env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=4" in (p.stderr + p.stdout)

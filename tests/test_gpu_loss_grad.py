@@ -112,7 +112,9 @@ def test_backward_at_headline_size_vs_oracle_and_bf16_inputs():
     b0 = torch.nn.functional.normalize(torch.randn(B, E), dim=1)
     loss_fn = ContrastiveLossWithTemperature().cuda()
     ref = oc.contrastive_loss_backward(a0.numpy(), b0.numpy(), np.log(1 / 0.07))
-    for bt, extra in ((BackpropType.GLOBAL, True), (BackpropType.LOCAL, True), (BackpropType.NONE, False)):
+    # no process group here: the reference returns the embeddings themselves from its gather and ignores backprop_type
+    # (contrastive_loss_with_temperature.py:31-33), so NONE differentiates through the "gathered" side too
+    for bt, extra in ((BackpropType.GLOBAL, True), (BackpropType.LOCAL, True), (BackpropType.NONE, True)):
         a, b = a0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
         loss_fn.zero_grad()
         loss_fn(a, b, backprop_type=bt).backward()

@@ -1,0 +1,134 @@
+"""Round-2 boundary fixes on an MI355X: the stand-alone SiLU module, the autograd contract of
+eval-mode / stand-alone forwards, packed-parameter invalidation, BackpropType semantics without a process group."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from multimodal_amd import build
+
+    build.build()
+
+
+def test_silu_reference_kat_and_gradient():
+    """reference tests/modules/layers/test_activation.py:12-16: silu(ones(3)) == 0.8458 (assert_close fp32 defaults)."""
+    from multimodal_amd.modules.layers.activation import SiLU
+
+    silu = SiLU()
+    actual = silu(torch.ones(3, device="cuda"))
+    torch.testing.assert_close(actual.cpu(), torch.tensor([0.8458, 0.8458, 0.8458]), rtol=1.3e-6, atol=1e-5)
+    x = torch.randn(5, 37, device="cuda", dtype=torch.float64).float().requires_grad_(True)  # odd element count
+    y = silu(x)
+    ref = x.detach().double() * torch.sigmoid(1.702 * x.detach().double())
+    assert (y.detach().double() - ref).abs().max() < 2e-6
+    y.backward(torch.ones_like(y))
+    xd = x.detach().double()
+    s = torch.sigmoid(1.702 * xd)
+    assert (x.grad.double() - (s + 1.702 * xd * s * (1 - s))).abs().max() < 5e-6
+    yb = silu(torch.randn(4, 8, device="cuda").to(torch.bfloat16))
+    assert yb.dtype == torch.bfloat16 and torch.isfinite(yb.float()).all()
+
+
+def _small_clip():
+    from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
+
+    torch.manual_seed(3)
+    vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=2, patch_size=16, image_size=64, width=128)
+    txt = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=1000, width=128, dim_feedforward=256, heads=2, layers=2)
+    return CLIP(vit, txt).cuda()
+
+
+def test_clip_in_eval_mode_is_differentiable_like_the_reference():
+    """eval() + grad enabled must not silently detach.  CLIP takes its autograd-node path whenever autograd would record the
+    call: input gradients (saliency) flow in eval mode, and the values equal the no_grad inference path's."""
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    clip = _small_clip().eval()
+    images, ids = clip_batch(4, image_size=64, vocab_size=1000)
+    x = images.cuda().requires_grad_(True)
+    out = clip(x, ids.cuda())
+    assert out.embeddings_a.grad_fn is not None and out.embeddings_b.grad_fn is not None
+    (out.embeddings_a * out.embeddings_b).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    assert clip.encoder_a.conv.weight.grad is not None
+    with torch.no_grad():
+        ref = clip(images.cuda(), ids.cuda())
+    assert ref.embeddings_a.grad_fn is None
+    assert (out.embeddings_a.detach() - ref.embeddings_a).abs().max() < 2e-3
+
+
+def test_standalone_forwards_refuse_to_detach():
+    from multimodal_amd.modules.layers.mlp import MLP
+    from multimodal_amd.modules.layers.multi_head_attention import MultiHeadSelfAttention
+
+    mha = MultiHeadSelfAttention(128, 2).cuda()
+    q = torch.randn(2, 5, 128, device="cuda")
+    for mode in (mha.train, mha.eval):  # train OR eval: parameters require grad and grad mode is on
+        mode()
+        with pytest.raises(NotImplementedError, match="no differentiable path"):
+            mha(q)
+    with torch.no_grad():
+        assert mha(q).shape == (2, 5, 128)
+    mha.requires_grad_(False)
+    assert mha(q).shape == (2, 5, 128)  # frozen parameters, plain input: nothing to record
+    with pytest.raises(NotImplementedError):
+        mha(q.clone().requires_grad_(True))  # ... but an input that requires grad would be cut off
+    mlp = MLP(128, 128, 256, dropout=0.0, activation=torch.nn.GELU).cuda().eval()
+    with pytest.raises(NotImplementedError, match="no differentiable path"):
+        mlp(torch.randn(3, 128, device="cuda"))
+    with torch.no_grad():
+        assert mlp(torch.randn(3, 128, device="cuda")).shape == (3, 128)
+
+
+def test_packed_copies_follow_data_writes_after_invalidate_or_mode_change():
+    """`.data` writes do not bump torch's version counter; invalidate_packed() and the train()<->eval() transition do the job."""
+    from multimodal_amd._packing import invalidate_packed
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    clip = _small_clip().eval()
+    images, ids = clip_batch(2, image_size=64, vocab_size=1000)
+    with torch.no_grad():
+        a0 = clip(images.cuda(), ids.cuda()).embeddings_a.clone()
+        w = clip.encoder_a.encoder.layers[0].linear1.weight
+        w.data.mul_(-1.0)  # invisible to the version counter
+        invalidate_packed(clip)
+        a1 = clip(images.cuda(), ids.cuda()).embeddings_a.clone()
+        assert (a1 - a0).abs().max() > 1e-4
+        w.data.mul_(-1.0)
+        clip.train()
+        clip.eval()  # mode transition drops the packs
+        a2 = clip(images.cuda(), ids.cuda()).embeddings_a
+        assert torch.equal(a2, a0)
+
+
+def test_backprop_type_none_without_a_process_group_differentiates_both_operands():
+    """reference contrastive_loss_with_temperature.py:31-33 returns the live embeddings when torch.distributed is not
+    initialised and never reads backprop_type: NONE == GLOBAL there."""
+    from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
+    from multimodal_amd.utils.distributed import BackpropType
+
+    torch.manual_seed(5)
+    a0 = torch.nn.functional.normalize(torch.randn(6, 16), dim=1)
+    b0 = torch.nn.functional.normalize(torch.randn(6, 16), dim=1)
+    grads = {}
+    for bt in (BackpropType.GLOBAL, BackpropType.NONE):
+        loss_fn = ContrastiveLossWithTemperature().cuda()
+        a, b = a0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+        loss_fn(a, b, backprop_type=bt).backward()
+        grads[bt] = (a.grad.clone(), b.grad.clone())
+    assert torch.equal(grads[BackpropType.GLOBAL][0], grads[BackpropType.NONE][0])
+    assert torch.equal(grads[BackpropType.GLOBAL][1], grads[BackpropType.NONE][1])
+    # and it is the torch-autograd gradient of the reference expression
+    a, b = a0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    t = math.exp(math.log(1 / 0.07))
+    lab = torch.arange(6)
+    loss = 0.5 * (torch.nn.functional.cross_entropy(a @ b.t() * t, lab) + torch.nn.functional.cross_entropy(b @ a.t() * t, lab))
+    loss.backward()
+    assert (grads[BackpropType.NONE][0].cpu().double() - a.grad).abs().max() < 1e-5
+    assert (grads[BackpropType.NONE][1].cpu().double() - b.grad).abs().max() < 1e-5

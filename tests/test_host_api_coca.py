@@ -37,6 +37,7 @@ def test_coca_seeded_init_matches_reference(golden, fixture, kw, cascaded, seed_
     assert_checksums(model, {"keys": z[prefix + "keys"], "sums": z[prefix + "sums"], "asums": z[prefix + "asums"]})
 
 
+@torch.no_grad()  # inference contract of the eval-mode modules (the train-mode calls below enable grad explicitly)
 def test_coca_records_and_loud_failures():
     from multimodal_amd.models.coca.coca_model import (coca_for_pretraining, coca_vit, CoCaForPretraining, CoCaModel,
                                                        CoCaModelWithHeads, MultimodalOutput)
@@ -57,13 +58,16 @@ def test_coca_records_and_loud_failures():
     pre = coca_for_pretraining(**SMALL, cascaded_pooler=False)
     assert isinstance(pre, CoCaForPretraining) and isinstance(pre.model, CoCaModel) and pre.caption_loss.ignore_index == 0
     m = coca_vit(**SMALL, cascaded_pooler=False).eval()
-    with pytest.raises(ops.MmamdError, match="no CPU"):
+    with pytest.raises(ops.MmamdError, match="no CPU"), torch.no_grad():
+        m(torch.randn(1, 3, 64, 64), torch.randint(1, 96, (1, 13)))
+    # eval mode + autograd recording: the reference would return differentiable outputs; refuse instead of detaching silently
+    with pytest.raises(NotImplementedError, match="eval mode with autograd enabled"), torch.enable_grad():
         m(torch.randn(1, 3, 64, 64), torch.randint(1, 96, (1, 13)))
     with pytest.raises(ValueError, match="doesn't match image size"):
         m.vision_encoder(torch.randn(1, 3, 32, 32))
     with pytest.raises(AssertionError):
         m.text_decoder(torch.randint(1, 96, (1, 9)))
-    with pytest.raises(ops.MmamdError, match="no CPU"):  # CoCa trains on the HIP kernels; there is still no CPU path
+    with pytest.raises(ops.MmamdError, match="no CPU"), torch.enable_grad():  # CoCa trains on the HIP kernels; there is still no CPU path
         m.train()(torch.randn(1, 3, 64, 64), torch.randint(1, 96, (1, 13)))
     m.eval()
     with pytest.raises(ValueError, match="divisible by patch size"):

@@ -73,6 +73,7 @@ def test_output_records_and_factories():
     assert FLAVAGlobalContrastiveLoss(logit_scale=p).logit_scale is p
 
 
+@torch.no_grad()  # inference contract of the eval-mode modules (the train-mode calls below enable grad explicitly)
 def test_flava_fails_loudly_without_a_gpu_or_an_implementation():
     from multimodal_amd.models.flava.image_encoder import PatchEmbeddings
     from multimodal_amd.models.flava.model import flava_model
@@ -82,7 +83,10 @@ def test_flava_fails_loudly_without_a_gpu_or_an_implementation():
     from multimodal_amd.modules.losses.flava import FLAVAGlobalContrastiveLoss
 
     m = flava_model(**SMALL_KW).eval()
-    with pytest.raises(ops.MmamdError, match="no CPU"):
+    with pytest.raises(ops.MmamdError, match="no CPU"), torch.no_grad():
+        m(torch.randn(1, 3, 32, 32), torch.randint(1, 200, (1, 16)))
+    # eval mode + autograd recording: the reference would return differentiable outputs; refuse instead of detaching silently
+    with pytest.raises(NotImplementedError, match="eval mode with autograd enabled"), torch.enable_grad():
         m(torch.randn(1, 3, 32, 32), torch.randint(1, 200, (1, 16)))
     with pytest.raises(ValueError, match="doesn't match model"):
         m.image_encoder(torch.randn(1, 3, 48, 48))
@@ -92,7 +96,7 @@ def test_flava_fails_loudly_without_a_gpu_or_an_implementation():
         m.text_encoder()
     with pytest.raises(ValueError, match="hidden_states"):
         m.mm_encoder(None)
-    with pytest.raises(ops.MmamdError, match="no CPU"):  # FLAVA trains on the HIP kernels; there is still no CPU path
+    with pytest.raises(ops.MmamdError, match="no CPU"), torch.enable_grad():  # FLAVA trains on the HIP kernels; there is still no CPU path
         m.train()(torch.randn(1, 3, 32, 32), torch.randint(1, 200, (1, 16)))
     m.eval()
     with pytest.raises(ops.MmamdError):

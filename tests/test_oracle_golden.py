@@ -2,6 +2,8 @@
   (1) the reference's own hard-coded known-answer vectors for this path, and
   (2) outputs of the reference itself, generated in the build container (tests/golden/make_golden.py).
 CPU-only; runs everywhere."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -128,3 +130,45 @@ def test_full_size_clip_against_reference_run(golden, name, factory, B, vh):
     np.testing.assert_allclose(o["logits_a"], z["logits_a"], atol=2e-4)
     np.testing.assert_allclose(o["loss"], z["loss"], atol=1e-4)
     assert np.array_equal(o["logits_a"].argmax(1), z["logits_a"].argmax(1))
+
+
+@pytest.mark.parametrize("name,factory,B", [("clip_b32_b8", "clip_vit_b32", 8), ("clip_b16_b4", "clip_vit_b16", 4)])
+def test_torch_cpu_restatement_matches_reference_fixtures(golden, name, factory, B):
+    """oracle/torch_cpu_clip.py (what bench.py's cpu_baseline leg times on the GPU box, where /root/reference is absent) is the reference's
+    own module composition on the same torch.nn modules: its outputs equal the reference's at fp32 round-off."""
+    import multimodal_amd.models.clip as mc
+    from multimodal_amd.utils.synthetic import clip_batch
+    from oracle.torch_cpu_clip import TorchCPUCLIP
+
+    z = golden(name + ".npz")
+    set_rng_seed(0)
+    model = getattr(mc, factory)()
+    assert_checksums(model, z)
+    torch.set_num_threads(8)
+    m = TorchCPUCLIP(model.state_dict(), vision_heads=12, text_heads=8)
+    images, ids = clip_batch(B)
+    a, b, la, lb, loss = m.forward_loss(images, ids)
+    np.testing.assert_allclose(a.numpy(), z["emb_a"], atol=2e-5)
+    np.testing.assert_allclose(b.numpy(), z["emb_b"], atol=2e-5)
+    np.testing.assert_allclose(la.numpy(), z["logits_a"], atol=5e-4)
+    np.testing.assert_allclose(lb.numpy(), z["logits_b"], atol=5e-4)
+    assert abs(float(loss) - float(z["loss"])) < 2e-5
+
+
+def test_headline_fixture_records_the_reference_bf16_cpu_rates(golden):
+    """clip_b16_b256.npz carries the reference's own bf16-CPU argmax agreement (97.3 % image->text at B = 256), the bar
+    tests/test_gpu_headline_parity.py holds the HIP path to; its loss is the one committed in profiles/r02_reference_cpu.json."""
+    import json
+    from pathlib import Path
+
+    z = golden("clip_b16_b256.npz")
+    assert z["emb_a"].shape == (256, 512) and z["logits_a"].shape == (256, 256) and z["bf16_logits_b"].shape == (256, 256)
+    ra = float((z["bf16_logits_a"].argmax(1) == z["logits_a"].argmax(1)).mean())
+    assert ra == float(z["bf16_agree_a"]) and 0.9 < ra <= 1.0
+    np.testing.assert_allclose(np.linalg.norm(z["emb_a"], axis=1), 1.0, atol=1e-5)
+    t = math.exp(math.log(1 / 0.07))
+    np.testing.assert_allclose(z["emb_a"].astype(np.float64) @ z["emb_b"].astype(np.float64).T * t, z["logits_a"], atol=2e-4)
+    o = oc.contrastive_loss_with_temperature(z["emb_a"], z["emb_b"], math.log(1 / 0.07))
+    assert abs(float(o["loss"]) - float(z["loss"])) < 1e-5  # the oracle's loss arithmetic at the headline size
+    rec = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "r02_reference_cpu.json").read_text())["clip_b16_b256"]
+    assert abs(rec["loss"] - float(z["loss"])) < 1e-6 and rec["batch"] == 256
