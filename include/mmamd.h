@@ -297,6 +297,15 @@ int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int 
 /* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(1024, rows) * n floats. */
 int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */
+/* Streams confined to a subset of the CUs (hipExtStreamCreateWithCUMask): the two towers of the dual encoder are independent until
+ * the loss (reference models/clip/model.py:70-71 runs them one after the other); here each gets its own CU partition so that neither
+ * tower's persistent kernels queue behind the other's.  mask: `words` 32-bit words, bit i = CU i in the runtime's CU numbering.
+ * mmamd_stream_cus(stream): CUs a launch on the stream may occupy (256 for any stream not created here) -- what the persistent
+ * GEMM / attention kernels size their grids with.  mmamd_debug_cu_census: blocks x {XCC_ID, HW_ID} of a spinning grid (placement probe). */
+int mmamd_stream_create_cu_mask(const uint32_t* mask, int words, mmamd_stream_t* out);
+int mmamd_stream_destroy(mmamd_stream_t stream);
+int mmamd_stream_cus(mmamd_stream_t stream);
+int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks, mmamd_stream_t stream);
 int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream);
 int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n, int act, mmamd_stream_t stream);
 /* The activation MODULE called on its own (reference: modules/layers/activation.py:24-25, SiLU.forward = x * sigmoid(1.702 x); KAT

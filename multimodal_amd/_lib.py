@@ -56,6 +56,10 @@ PROTOTYPES = {
     "mmamd_dalle_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_row_softmax_": (_i, [_vp, _i64, _i, _vp]),
     "mmamd_dalle_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "mmamd_stream_create_cu_mask": (_i, [_vp, _i, _vp]),
+    "mmamd_stream_destroy": (_i, [_vp]),
+    "mmamd_stream_cus": (_i, [_vp]),
+    "mmamd_debug_cu_census": (_i, [_vp, _i, C.c_longlong, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mmamd_activation": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),

@@ -1251,7 +1251,8 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int BH = B * H;
-  const int grid = BH < 512 ? BH : 512;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
+  const int slots = 2 * stream_cus(st);
+  const int grid = BH < slots ? BH : slots;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,
                      scale * 1.4426950408889634f, lse);
   return launch_status("attention_fwd");

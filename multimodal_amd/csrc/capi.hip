@@ -2,10 +2,34 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace mmamd {
 static thread_local char g_err[512] = "";
+
+// CU budget of streams created with a CU mask (mmamd_stream_create_cu_mask): the persistent kernels size their grids with it
+static std::mutex g_stream_mu;
+static std::unordered_map<void*, int> g_stream_cus;
+
+int stream_cus(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  if (g_stream_cus.empty()) return kChipCUs;
+  auto it = g_stream_cus.find((void*)st);
+  return it == g_stream_cus.end() ? kChipCUs : it->second;
+}
+
+// census: every workgroup records where it ran (XCC id, HW_ID) and then holds its CU for `spin` clock ticks so the grid spreads
+__global__ void cu_census_kernel(int* __restrict__ out, long long spin) {
+  const long long t0 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));      // HW_REG_XCC_ID, all 32 bits
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+  }
+  while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -52,4 +76,35 @@ extern "C" int mmamd_timer_elapsed_ms(void* p, float* ms_host) {
   hipError_t e = hipEventSynchronize(t->stop);
   if (e != hipSuccess) return (int)e;
   return (int)hipEventElapsedTime(ms_host, t->start, t->stop);
+}
+
+// ---- streams confined to a CU subset (tower co-scheduling: DESIGN.md section 3) ------------------------------------------------
+extern "C" int mmamd_stream_create_cu_mask(const uint32_t* mask, int words, mmamd_stream_t* out) {
+  MMAMD_CHECK_ARG(mask && out && words > 0 && words <= 16, MMAMD_E_BADARG, "stream_create_cu_mask: bad argument");
+  int cus = 0;
+  for (int i = 0; i < words; ++i) cus += __builtin_popcount(mask[i]);
+  MMAMD_CHECK_ARG(cus > 0, MMAMD_E_BADARG, "stream_create_cu_mask: empty mask");
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+  if (e != hipSuccess) { mmamd::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return (int)e; }
+  {
+    std::lock_guard<std::mutex> lk(mmamd::g_stream_mu);
+    mmamd::g_stream_cus[(void*)st] = cus;
+  }
+  *out = (mmamd_stream_t)st;
+  return 0;
+}
+extern "C" int mmamd_stream_destroy(mmamd_stream_t stream) {
+  if (!stream) return MMAMD_E_BADARG;
+  {
+    std::lock_guard<std::mutex> lk(mmamd::g_stream_mu);
+    mmamd::g_stream_cus.erase((void*)stream);
+  }
+  return (int)hipStreamDestroy((hipStream_t)stream);
+}
+extern "C" int mmamd_stream_cus(mmamd_stream_t stream) { return mmamd::stream_cus((hipStream_t)stream); }
+extern "C" int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(out && blocks > 0, MMAMD_E_BADARG, "cu_census: bad argument");
+  hipLaunchKernelGGL(mmamd::cu_census_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, out, spin_ticks);
+  return mmamd::launch_status("cu_census");
 }

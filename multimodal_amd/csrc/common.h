@@ -17,6 +17,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kWave = 64;
+constexpr int kChipCUs = 256;  // MI355X: 8 XCDs x 32 CUs
+
+// CUs a launch on `st` may occupy: 256, or the popcount of the mask of a stream made by mmamd_stream_create_cu_mask
+int stream_cus(hipStream_t st);
 
 // thread-local last-error string, written by the host-side launchers
 void set_error(const char* fmt, ...);

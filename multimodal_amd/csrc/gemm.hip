@@ -1866,7 +1866,8 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   const int tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   const int ntiles = tiles_m * p.tiles_n;
-  const int grid = ntiles < 256 ? ntiles : 256;  // one persistent workgroup per CU (multiple of 8 when it matters)
+  const int cus = stream_cus(st);                   // 256, or the CU partition of a masked stream (multiple of 8: whole XCD slices)
+  const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, st, p, tiles_m, ntiles);
   return launch_status("gemm_bf16_pp");
 }
@@ -1883,12 +1884,14 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     //    the time each), as a second launch on the same stream.
     const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
     const long t256 = (long)tiles_m * tiles_n;
+    const int cus = stream_cus(st);              // CU partition of a masked stream, else 256
+    const long t_eq = t256 * kChipCUs / cus;     // tile count scaled to a whole chip: the thresholds below were measured on 256 CUs
     // row-range split for the wave-quantisation tail: returns true when it launched (rc holds the status)
     int rc = 0;
     auto try_split = [&](bool big_pp) -> bool {
-      const long full = t256 / 256, rem = t256 - full * 256;
-      if (!(full >= 1 && full <= 4 && rem > 0 && rem <= 128)) return false;
-      const int m_tiles_big = (int)((full * 256) / tiles_n);  // whole row-panels that fit in the full rounds
+      const long full = t256 / cus, rem = t256 - full * cus;
+      if (!(full >= 1 && full <= 4 && rem > 0 && rem <= cus / 2)) return false;
+      const int m_tiles_big = (int)((full * cus) / tiles_n);  // whole row-panels that fit in the full rounds
       if (!(m_tiles_big >= 1 && m_tiles_big < tiles_m)) return false;
       GemmArgs a = p, b = p;
       const size_t rows = (size_t)m_tiles_big * 256;
@@ -1906,9 +1909,9 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     // (re-measured with warm clocks, tools/kernel_bench.py: the persistent kernel wins from ~400 tiles up at every K — out-proj 625 vs 616 vs
     //  602 TF/s for PP / P / P + split, text MLP-up 691 / 663 / 620, patch embedding 863 / 851 / 838 — and the row-range split only pays
     //  with long K: MLP-down 891 with it, 836-838 without)
-    if (t256 < 96) {
+    if (t_eq < 96) {
       v = 6;
-    } else if ((p.K & 127) == 0 && t256 >= 400) {
+    } else if ((p.K & 127) == 0 && t_eq >= 400) {
       v = 18;  // many tiles per CU: the persistent kernel hides each tile's first-stage load behind the previous epilogue
       if (p.K >= 2048 && try_split(true)) return rc;
       // the large-M and the small-M launches get different instantiations (tile-order group 8 / 4: equal speed), so that a kernel name in a

@@ -19,6 +19,7 @@ from .text_encoder import CLIPTextEncoder
 
 
 _SIDE_STREAMS = {}
+_PART_STREAMS = {}
 
 
 class CLIPOutput(NamedTuple):
@@ -73,9 +74,25 @@ class CLIP(PackedModeMixin, nn.Module):
             embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))
             return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
         side = self._side_stream(features_a)
+        part = self._cu_partition(features_a) if side is not None else None
         if side is None:
             embeddings_a = tower_a(features_a)
             embeddings_b = self.encoder_b(features_b)
+        elif part is not None:
+            # each tower on its own CU partition (hipExtStreamCreateWithCUMask): neither tower's persistent kernels wait for CUs the
+            # other one holds; both streams fork from / join the caller's stream
+            main = torch.cuda.current_stream()
+            sa, sb = part
+            sa.wait_stream(main)
+            sb.wait_stream(main)
+            with torch.cuda.stream(sb):
+                embeddings_b = self.encoder_b(features_b)
+            with torch.cuda.stream(sa):
+                embeddings_a = tower_a(features_a)
+            main.wait_stream(sa)
+            main.wait_stream(sb)
+            embeddings_a.record_stream(main)
+            embeddings_b.record_stream(main)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
@@ -87,6 +104,22 @@ class CLIP(PackedModeMixin, nn.Module):
         embeddings_a = ops.l2_normalize(embeddings_a.detach().contiguous(), eps=1e-12)
         embeddings_b = ops.l2_normalize(embeddings_b.detach().contiguous(), eps=1e-12)
         return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
+
+    def _cu_partition(self, ref):
+        """(stream of tower A, stream of tower B) confined to complementary CU sets, or None.  MMAMD_CU_SPLIT = CUs per XCD given to
+        tower B (0 / unset = no partition: plain side stream); MMAMD_CU_LAYOUT = interleaved | contiguous (ops.cu_partition_masks)."""
+        import os
+
+        t = int(os.environ.get("MMAMD_CU_SPLIT", "0") or 0)
+        if t <= 0:
+            return None
+        key = (ref.device, t, os.environ.get("MMAMD_CU_LAYOUT", "interleaved"))
+        got = _PART_STREAMS.get(key)
+        if got is None:
+            ma, mb = ops.cu_partition_masks(t, key[2])
+            got = (ops.create_cu_mask_stream(ma, ref.device), ops.create_cu_mask_stream(mb, ref.device))
+            _PART_STREAMS[key] = got
+        return got
 
     def _side_stream(self, ref):
         import os

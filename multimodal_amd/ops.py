@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -57,6 +57,43 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def cu_partition_masks(cus_per_xcd_b: int, layout: str = "interleaved", xcds: int = 8, cus_per_xcd: int = 32):
+    """CU masks (lists of 32-bit words, bit i = CU i of the runtime's numbering) that split every XCD into the first
+    `cus_per_xcd - cus_per_xcd_b` CUs (partition A) and the last `cus_per_xcd_b` (partition B).  `layout` says how the runtime numbers the
+    CUs: "interleaved" = CU i lives on XCD i % 8 (what tools/cu_census.py measures on MI355X), "contiguous" = on XCD i // 32."""
+    if not (0 < cus_per_xcd_b < cus_per_xcd):
+        raise MmamdError(f"cu_partition_masks: partition B must get 1..{cus_per_xcd - 1} CUs per XCD, got {cus_per_xcd_b}")
+    n = xcds * cus_per_xcd
+    bits_a, bits_b = [0] * (n // 32), [0] * (n // 32)
+    for i in range(n):
+        local = i // xcds if layout == "interleaved" else i % cus_per_xcd
+        tgt = bits_b if local >= cus_per_xcd - cus_per_xcd_b else bits_a
+        tgt[i // 32] |= 1 << (i % 32)
+    return bits_a, bits_b
+
+
+def create_cu_mask_stream(mask_words, device=None) -> "torch.cuda.Stream":
+    """A HIP stream whose kernels may only occupy the CUs of `mask_words` (mmamd_stream_create_cu_mask), wrapped for torch."""
+    arr = (C.c_uint32 * len(mask_words))(*[int(w) & 0xFFFFFFFF for w in mask_words])
+    out = C.c_void_p()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        check(_lib.lib().mmamd_stream_create_cu_mask(arr, len(mask_words), C.byref(out)), "mmamd_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=dev)
+
+
+def stream_cus(stream: Optional["torch.cuda.Stream"] = None) -> int:
+    s = torch.cuda.current_stream() if stream is None else stream
+    return int(_lib.lib().mmamd_stream_cus(s.cuda_stream))
+
+
+def cu_census(blocks: int = 2048, spin_ticks: int = 200000) -> torch.Tensor:
+    """[blocks, 2] int32 = (XCC_ID, HW_ID) register values of a spinning grid launched on the current stream (placement probe)."""
+    out = torch.zeros((blocks, 2), dtype=torch.int32, device="cuda")
+    check(_lib.lib().mmamd_debug_cu_census(out.data_ptr(), blocks, int(spin_ticks), _stream()), "mmamd_debug_cu_census")
+    return out
 
 
 def set_gemm_variant(v: int) -> None:
