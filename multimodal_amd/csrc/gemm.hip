@@ -66,7 +66,91 @@ struct GemmArgs {
   int split_flat;           // split-K with the split index folded into blockIdx.x (1-D grid of tiles * splits, split-major): 0 = blockIdx.y
   void* C2;                 // training forward of the MLP: second bf16 output act2(bf16(C)) next to the pre-activation C (NULL = none)
   int ldc2, act2;
+  // LayerNorm folded into the GEMMs either side of it (file header of the "LN fold" section below).
+  // producer (fp32 residual GEMM): bf16 copy of the output rows + per-row partial (sum, sum of squares) of every 64-column block
+  bf16* Xh = nullptr;
+  int ldxh = 0;
+  float* st_out = nullptr;  // [M][nslot_out][2]
+  int nslot_out = 0;
+  // consumer (A = that bf16 copy, W = gamma-scaled weight): C = rstd_m (acc - mu_m c1[n]) + bias[n], then the activation
+  const float* st_in = nullptr;  // [M][nslot_in][2]
+  int nslot_in = 0;
+  const float* c1 = nullptr;     // [N] row sums of the gamma-scaled bf16 weight
+  float inv_d = 0.f, ln_eps = 0.f;
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// LN fold.  A pre-norm block computes  y = LN(x) W^T + b  with  LN(x) = (x - mu) rstd gamma + beta  per token row.  Algebra:
+//     y[m][n] = rstd_m ( sum_k x[m][k] (gamma_k W[n][k])  -  mu_m sum_k gamma_k W[n][k] )  +  ( sum_k beta_k W[n][k] + b[n] )
+//             = rstd_m ( acc[m][n] - mu_m c1[n] ) + c2[n]          acc = xh . W'^T,  xh = bf16(x),  W' = bf16(gamma (.) W)
+// so the LayerNorm pass (a 155 MB fp32 read + 77 MB bf16 write per call at ViT-B/16, B = 256) disappears: the GEMM that PRODUCES x
+// (attention out-projection / MLP down-projection with the fp32 residual) also writes xh and, per row and 64-column block, the
+// partial sums (sum x, sum x^2) of the fp32 values; the GEMM that CONSUMES LN(x) reads xh as its A operand and finishes the
+// statistics (mu, rstd from the N/64 partials of its rows, fixed summation order -> bit-reproducible) in its epilogue.
+// Numerics: x instead of LN(x) is rounded to bf16, which scales the operand rounding error of a token by sqrt(1 + mu^2/sigma^2)
+// (tools/ln_fold_numerics.py); var = E[x^2] - mu^2 in fp32.  Parity at the headline size: tests/test_gpu_headline_parity.py.
+// ---------------------------------------------------------------------------------------------------------
+template <int MI, int NI, int TM, int TN>
+__device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+  const int l31 = lane & 31, half = lane >> 5;
+  if (p.st_in != nullptr) {  // wave-uniform
+    float mu[MI], rs[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      int m = m0 + wm * TM + mi * 32 + l31;
+      m = m < p.M ? m : p.M - 1;
+      const float* s = p.st_in + (size_t)m * (size_t)(2 * p.nslot_in);
+      float s1 = 0.f, s2 = 0.f;
+      for (int k = 0; k < p.nslot_in; k += 2) {  // nslot is even (N % 128 == 0 of the producing GEMM is checked on the host)
+        const f32x4 v = load4(s + 2 * k);
+        s1 += v[0]; s2 += v[1];
+        s1 += v[2]; s2 += v[3];
+      }
+      const float mean = s1 * p.inv_d;
+      const float var = fmaxf(fmaf(s2, p.inv_d, -mean * mean), 0.f);
+      mu[mi] = mean;
+      rs[mi] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
+        f32x4 cv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) { cv = load4(p.c1 + n); bv = load4(p.bias + n); }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] = fmaf(rs[mi], fmaf(-mu[mi], cv[j], acc[ni][mi][4 * g + j]), bv[j]);
+      }
+  } else if (p.bias != nullptr) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) bv = load4(p.bias + n);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
+      }
+  }
+}
+
+// producer side, for epilogues that hold an output row segment of 4 consecutive fp32 per lane with LPR lanes per row (row-contiguous
+// layouts after the LDS transpose): bf16 copy of the 4 values and the lane group's (sum, sum of squares)
+template <int LPR>
+__device__ __forceinline__ void lnfold_emit4(const GemmArgs& p, f32x4 v, int m, int n, bool ok, float& s1, float& s2) {
+  if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, v);
+  float a = (v[0] + v[1]) + (v[2] + v[3]);
+  float b = fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  s1 += a;
+  s2 += b;
+}
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
 // `/` compiles to the ~10-instruction IEEE division sequence: measured at 29 % of the MLP-up GEMM's time.
@@ -131,21 +215,8 @@ template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn,
                                               int lane) {
   const int l31 = lane & 31, half = lane >> 5;
-  // pass 1: bias (depends on n only).  pass 2: activation behind ONE uniform branch.  pass 3: residual + store.
-  if (p.bias != nullptr) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) bv = load4(p.bias + n);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
-      }
-  }
+  // pass 1: bias (depends on n only) or the folded LayerNorm.  pass 2: activation behind ONE uniform branch.  pass 3: residual + store.
+  bias_or_lnfold<MI, NI, TM, TN>(acc, p, m0, n0, wm, wn, lane);
   if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -172,6 +243,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * TM + mi * 32 + l31;
     const bool mok = m < p.M;
+    float ls1 = 0.f, ls2 = 0.f;  // LN fold (producer): this lane's share of row m over the wave's 64 columns
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int nb = n0 + wn * TN + ni * 32 + 4 * half;
@@ -192,6 +264,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
         }
         if constexpr (OUT_F32) {
           if (ok) store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, t);
+          if (p.Xh != nullptr) {  // wave-uniform
+            if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, t);
+            ls1 += (t[0] + t[1]) + (t[2] + t[3]);
+            ls2 += fmaf(t[0], t[0], t[1] * t[1]) + fmaf(t[2], t[2], t[3] * t[3]);
+          }
         }
         v[g] = t;
       }
@@ -216,6 +293,16 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
         }
       }
     }
+    if constexpr (OUT_F32) {
+      if (p.st_out != nullptr) {  // TN == 64: the wave's columns are ONE 64-column block
+        ls1 += __shfl_xor(ls1, 32);
+        ls2 += __shfl_xor(ls2, 32);
+        if (mok && half == 0) {
+          const int slot = (n0 + wn * TN) >> 6;
+          *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + slot) * 2) = f32x2{ls1, ls2};
+        }
+      }
+    }
   }
 }
 
@@ -229,20 +316,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
                                                   int wn, int lane, int wave, char* smem) {
   static_assert(TN == 64, "row strip below is laid out for 64-column wave tiles");
   const int l31 = lane & 31, half = lane >> 5;
-  if (p.bias != nullptr) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) bv = load4(p.bias + n);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
-      }
-  }
+  bias_or_lnfold<MI, NI, TM, TN>(acc, p, m0, n0, wm, wn, lane);
   if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -297,13 +371,20 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int m = mrow0 + it * 4 + (lane >> 4), n = nw0 + (lane & 15) * 4;
-        if (m < p.M && n + 3 < p.N && ((ABL & 16) == 0 || vv[it][0] == 1.2345678e33f)) {
-          f32x4 v = vv[it];
+        const bool ok = m < p.M && n + 3 < p.N && ((ABL & 16) == 0 || vv[it][0] == 1.2345678e33f);
+        f32x4 v = vv[it];
+        if (ok) {
           if (has_res) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += rr[it][j];
           }
           store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
+        }
+        if (p.Xh != nullptr) {  // wave-uniform; LN fold (producer): 16 lanes hold the 64 columns of row m
+          float s1 = 0.f, s2 = 0.f;
+          lnfold_emit4<16>(p, v, m, n, ok, s1, s2);
+          if (m < p.M && (lane & 15) == 0)
+            *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{s1, s2};
         }
       }
 #pragma unroll
@@ -1646,20 +1727,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     mma(xa1, wb1);  // flush the rotated last k-step
 
     // ---------------- epilogue (LDS strips in ring buffer 1; buffer 0 is receiving the next tile) ----------------
-    if (p.bias != nullptr) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (n + 3 < p.N) bv = load4(p.bias + n);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
-        }
-    }
+    bias_or_lnfold<MI, NI, TM, TN>(acc, p, m0, n0, wm, wn, lane);
     if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -1686,11 +1754,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
         }
       };
       if (has_res) res_load(0, rr);
+      float fs1[4], fs2[4];  // LN fold (producer): row partials of the 4 rows this lane touches per pass, over the wave's TN columns
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int pass = mi * NI + ni;
+          if (ni == 0) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) fs1[it] = fs2[it] = 0.f;
+          }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             f32x4 t;
@@ -1706,13 +1779,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
-            if (m < p.M && n + 3 < p.N) {
-              f32x4 v = vv[it];
+            const bool ok = m < p.M && n + 3 < p.N;
+            f32x4 v = vv[it];
+            if (ok) {
               if (has_res) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += rr[it][j];
               }
               store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
+            }
+            if (p.Xh != nullptr) {  // wave-uniform: 8 lanes hold 32 columns of row m in this pass
+              lnfold_emit4<8>(p, v, m, n, ok, fs1[it], fs2[it]);
+              if (ni == NI - 1 && m < p.M && (lane & 7) == 0)
+                *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{fs1[it], fs2[it]};
             }
           }
 #pragma unroll
@@ -1902,6 +1981,9 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       b.C = reinterpret_cast<char*>(p.C) + rows * p.ldc * esz;
       if (p.R != nullptr) b.R = reinterpret_cast<const char*>(p.R) + rows * p.ldr * esz;
       if (p.C2 != nullptr) b.C2 = reinterpret_cast<char*>(p.C2) + rows * p.ldc2 * 2;
+      if (p.Xh != nullptr) b.Xh = p.Xh + rows * p.ldxh;
+      if (p.st_out != nullptr) b.st_out = p.st_out + rows * (size_t)(2 * p.nslot_out);
+      if (p.st_in != nullptr) b.st_in = p.st_in + rows * (size_t)(2 * p.nslot_in);
       rc = big_pp ? launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(a, st) : launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
       if (rc == 0) rc = launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
       return true;
@@ -2008,8 +2090,36 @@ extern "C" int mmamd_debug_set_gemm_trace(void* buf) {
   return 0;
 }
 
+struct LnFoldArgs {  // see "LN fold" at the top of this file
+  void* xh = nullptr; int ldxh = 0; float* st_out = nullptr;                         // producer
+  const float* st_in = nullptr; int nslot_in = 0; const float* c1 = nullptr; float eps = 0.f;  // consumer
+};
 static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, void* C,
-                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream);
+                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream,
+                          const LnFoldArgs* lf = nullptr);
+
+extern "C" int mmamd_gemm_bf16_res_stats(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr,
+                                         float* C, int ldc, void* Xh, int ldxh, float* stats, int M, int N, int K, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(Xh && stats, MMAMD_E_BADARG, "gemm_res_stats: null output");
+  MMAMD_CHECK_ARG(N % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_res_stats: N=%d must be a multiple of 128 (whole 64-column statistic blocks, even count)", N);
+  MMAMD_CHECK_ARG(ldxh >= N && ldxh % 4 == 0 && (reinterpret_cast<uintptr_t>(Xh) & 7) == 0 && (reinterpret_cast<uintptr_t>(stats) & 15) == 0,
+                  MMAMD_E_ALIGN, "gemm_res_stats: bf16 copy needs 8-byte aligned rows, the statistics 16-byte alignment");
+  LnFoldArgs lf;
+  lf.xh = Xh; lf.ldxh = ldxh; lf.st_out = stats;
+  return gemm_bf16_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, MMAMD_F32, M, N, K, MMAMD_ACT_NONE, nullptr, 0, 0, stream, &lf);
+}
+
+extern "C" int mmamd_gemm_bf16_lnfold(const void* Xh, int lda, const void* Wg, int ldw, const float* c1, const float* c2, const float* stats,
+                                      int nslot, float eps, void* C, int ldc, int M, int N, int K, int act, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(c1 && c2 && stats, MMAMD_E_BADARG, "gemm_lnfold: null argument");
+  MMAMD_CHECK_ARG(nslot > 0 && nslot % 2 == 0 && nslot * 64 == K, MMAMD_E_BADARG,
+                  "gemm_lnfold: %d statistic blocks of 64 columns do not cover the normalised width K=%d", nslot, K);
+  MMAMD_CHECK_ARG(aligned16(c1) && aligned16(stats), MMAMD_E_ALIGN, "gemm_lnfold: c1 / stats must be 16-byte aligned");
+  MMAMD_CHECK_ARG(act == MMAMD_ACT_NONE || act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF, MMAMD_E_BADARG, "gemm_lnfold: bad activation code %d", act);
+  LnFoldArgs lf;
+  lf.st_in = stats; lf.nslot_in = nslot; lf.c1 = c1; lf.eps = eps;
+  return gemm_bf16_impl(Xh, lda, Wg, ldw, c2, nullptr, 0, C, ldc, MMAMD_BF16, M, N, K, act, nullptr, 0, 0, stream, &lf);
+}
 
 extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
                                int ldr, void* C, int ldc, int out_dtype, int M, int N, int K, int act,
@@ -2026,7 +2136,8 @@ extern "C" int mmamd_gemm_bf16_dual(const void* A, int lda, const void* W, int l
 }
 
 static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, void* C,
-                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream) {
+                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream,
+                          const LnFoldArgs* lf) {
   MMAMD_CHECK_ARG(A && W && C, MMAMD_E_BADARG, "gemm: null pointer");
   MMAMD_CHECK_ARG(M >= 0 && N > 0 && K > 0, MMAMD_E_BADARG, "gemm: bad sizes M=%d N=%d K=%d", M, N, K);
   MMAMD_CHECK_ARG(K % 64 == 0, MMAMD_E_UNSUPPORTED, "gemm: K=%d must be a multiple of 64 (pad the operands)", K);
@@ -2045,6 +2156,10 @@ static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.act = act; p.tiles_n = 0;
   p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0;
   p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.split_flat = 0;
+  if (lf != nullptr) {
+    p.Xh = (bf16*)lf->xh; p.ldxh = lf->ldxh; p.st_out = lf->st_out; p.nslot_out = N / 64;
+    p.st_in = lf->st_in; p.nslot_in = lf->nslot_in; p.c1 = lf->c1; p.inv_d = 1.0f / (float)K; p.ln_eps = lf->eps;
+  }
   if (act == MMAMD_ACT_MUL_QUICKGELU_GRAD || act == MMAMD_ACT_MUL_GELU_GRAD) {
     MMAMD_CHECK_ARG(out_dtype == MMAMD_BF16 && residual != nullptr, MMAMD_E_BADARG,
                     "gemm: the activation-gradient epilogue needs bf16 output and the saved pre-activation as `residual`");

@@ -83,6 +83,8 @@ class TransformerStack(nn.Module):
         att = torch.empty((M, d), dtype=bf, device=dev)
         up = torch.empty((M, self.dim_feedforward), dtype=bf, device=dev)
         bf16_stream = os.environ.get("MMAMD_RESIDUAL", "fp32") == "bf16"  # experiment knob: residual stream dtype
+        if not bf16_stream and d % 128 == 0 and os.environ.get("MMAMD_LN_FOLD", "1") != "0":
+            return self._run_ln_folded(x, B, S, causal, qkv, att, up)
         x_f32 = x
         if bf16_stream:
             x = ops.convert(x, bf)
@@ -98,6 +100,37 @@ class TransformerStack(nn.Module):
         if bf16_stream:
             x = ops.convert(x, f32)
         return x
+
+
+def _run_ln_folded(self, x, B, S, causal, qkv, att, up):
+    """The same layers with both LayerNorms folded into the GEMMs around them (csrc/gemm.hip "LN fold"): the GEMM that produces the
+    residual stream x also writes xh = bf16(x) and the per-row block statistics, the GEMM that consumes LN(x) reads xh and applies
+    mu / rstd / gamma / beta in its epilogue — no stand-alone LayerNorm launches, no fp32 re-read of x.  MMAMD_LN_FOLD=0 selects
+    the unfused form above (same arithmetic up to the rounding point of the GEMM operand: xh instead of bf16(LN(x)))."""
+    d, H = self.d_model, self.nhead
+    M = B * S
+    bf, f32 = torch.bfloat16, torch.float32
+    pk, fold = self._packed.get, self._packed.get_lnfold
+    xh = torch.empty((M, d), dtype=bf, device=x.device)
+    stats = torch.empty((M, d // 64, 2), dtype=f32, device=x.device)
+    ops.row_stats(x, xh, stats)
+    last = len(self.layers) - 1
+    for li, layer in enumerate(self.layers):
+        sa = layer.self_attn
+        wg, c1, c2 = fold(sa.in_proj_weight, layer.norm1.weight, layer.norm1.bias, sa.in_proj_bias)
+        ops.gemm_bf16_lnfold(xh, wg, c1, c2, stats, layer.norm1.eps, out=qkv)
+        ops.attention_fwd(qkv, B, S, H, causal, out=att)
+        ops.gemm_bf16_res_stats(att, pk(sa.out_proj.weight, bf), pk(sa.out_proj.bias, f32), x, xh, stats)
+        wg, c1, c2 = fold(layer.linear1.weight, layer.norm2.weight, layer.norm2.bias, layer.linear1.bias)
+        ops.gemm_bf16_lnfold(xh, wg, c1, c2, stats, layer.norm2.eps, act=ops.ACT_QUICKGELU, out=up)
+        if li == last:  # nothing consumes a bf16 copy of the final stream (ln_post / ln_final read the fp32 rows)
+            ops.gemm_bf16(up, pk(layer.linear2.weight, bf), pk(layer.linear2.bias, f32), residual=x, out=x)
+        else:
+            ops.gemm_bf16_res_stats(up, pk(layer.linear2.weight, bf), pk(layer.linear2.bias, f32), x, xh, stats)
+    return x
+
+
+TransformerStack._run_ln_folded = _run_ln_folded
 
 
 def forbid_training_forward(module: nn.Module) -> None:

