@@ -79,79 +79,6 @@ struct GemmArgs {
   float inv_d = 0.f, ln_eps = 0.f;
 };
 
-// ---------------------------------------------------------------------------------------------------------
-// LN fold.  A pre-norm block computes  y = LN(x) W^T + b  with  LN(x) = (x - mu) rstd gamma + beta  per token row.  Algebra:
-//     y[m][n] = rstd_m ( sum_k x[m][k] (gamma_k W[n][k])  -  mu_m sum_k gamma_k W[n][k] )  +  ( sum_k beta_k W[n][k] + b[n] )
-//             = rstd_m ( acc[m][n] - mu_m c1[n] ) + c2[n]          acc = xh . W'^T,  xh = bf16(x),  W' = bf16(gamma (.) W)
-// so the LayerNorm pass (a 155 MB fp32 read + 77 MB bf16 write per call at ViT-B/16, B = 256) disappears: the GEMM that PRODUCES x
-// (attention out-projection / MLP down-projection with the fp32 residual) also writes xh and, per row and 64-column block, the
-// partial sums (sum x, sum x^2) of the fp32 values; the GEMM that CONSUMES LN(x) reads xh as its A operand and finishes the
-// statistics (mu, rstd from the N/64 partials of its rows, fixed summation order -> bit-reproducible) in its epilogue.
-// Numerics: x instead of LN(x) is rounded to bf16, which scales the operand rounding error of a token by sqrt(1 + mu^2/sigma^2)
-// (tools/ln_fold_numerics.py); var = E[x^2] - mu^2 in fp32.  Parity at the headline size: tests/test_gpu_headline_parity.py.
-// ---------------------------------------------------------------------------------------------------------
-template <int MI, int NI, int TM, int TN>
-__device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
-  const int l31 = lane & 31, half = lane >> 5;
-  if (p.st_in != nullptr) {  // wave-uniform
-    float mu[MI], rs[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      int m = m0 + wm * TM + mi * 32 + l31;
-      m = m < p.M ? m : p.M - 1;
-      const float* s = p.st_in + (size_t)m * (size_t)(2 * p.nslot_in);
-      float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < p.nslot_in; k += 2) {  // nslot is even (N % 128 == 0 of the producing GEMM is checked on the host)
-        const f32x4 v = load4(s + 2 * k);
-        s1 += v[0]; s2 += v[1];
-        s1 += v[2]; s2 += v[3];
-      }
-      const float mean = s1 * p.inv_d;
-      const float var = fmaxf(fmaf(s2, p.inv_d, -mean * mean), 0.f);
-      mu[mi] = mean;
-      rs[mi] = __builtin_amdgcn_rsqf(var + p.ln_eps);
-    }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-        f32x4 cv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) { cv = load4(p.c1 + n); bv = load4(p.bias + n); }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] = fmaf(rs[mi], fmaf(-mu[mi], cv[j], acc[ni][mi][4 * g + j]), bv[j]);
-      }
-  } else if (p.bias != nullptr) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) bv = load4(p.bias + n);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
-      }
-  }
-}
-
-// producer side, for epilogues that hold an output row segment of 4 consecutive fp32 per lane with LPR lanes per row (row-contiguous
-// layouts after the LDS transpose): bf16 copy of the 4 values and the lane group's (sum, sum of squares)
-template <int LPR>
-__device__ __forceinline__ void lnfold_emit4(const GemmArgs& p, f32x4 v, int m, int n, bool ok, float& s1, float& s2) {
-  if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, v);
-  float a = (v[0] + v[1]) + (v[2] + v[3]);
-  float b = fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
-#pragma unroll
-  for (int o = 1; o < LPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-  s1 += a;
-  s2 += b;
-}
-
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
 // `/` compiles to the ~10-instruction IEEE division sequence: measured at 29 % of the MLP-up GEMM's time.
 __device__ __forceinline__ float quick_gelu(float v) {
@@ -206,18 +133,99 @@ __device__ __forceinline__ void store_act_copy(const GemmArgs& p, uint4 v, int m
   *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C2) + (size_t)m * p.ldc2 + n) = __builtin_bit_cast(uint4, a8);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LN fold.  A pre-norm block computes  y = LN(x) W^T + b  with  LN(x) = (x - mu) rstd gamma + beta  per token row.  Algebra:
+//     y[m][n] = rstd_m ( sum_k x[m][k] (gamma_k W[n][k])  -  mu_m sum_k gamma_k W[n][k] )  +  ( sum_k beta_k W[n][k] + b[n] )
+//             = rstd_m ( acc[m][n] - mu_m c1[n] ) + c2[n]          acc = xh . W'^T,  xh = bf16(x),  W' = bf16(gamma (.) W)
+// so the LayerNorm pass (a 155 MB fp32 read + 77 MB bf16 write per call at ViT-B/16, B = 256) disappears: the GEMM that PRODUCES x
+// (attention out-projection / MLP down-projection with the fp32 residual) also writes xh and, per row and 64-column block, the
+// partial sums (sum x, sum x^2) of the fp32 values; the GEMM that CONSUMES LN(x) reads xh as its A operand and finishes the
+// statistics (mu, rstd from the N/64 partials of its rows, fixed summation order -> bit-reproducible) in its epilogue.
+// Numerics: x instead of LN(x) is rounded to bf16, which scales the operand rounding error of a token by sqrt(1 + mu^2/sigma^2)
+// (tools/ln_fold_numerics.py); var = E[x^2] - mu^2 in fp32.  Parity at the headline size: tests/test_gpu_headline_parity.py.
+// ---------------------------------------------------------------------------------------------------------
+template <int MI, int NI, int TM, int TN, int FOLD, int ACT>
+__device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+  const int l31 = lane & 31, half = lane >> 5;
+  if constexpr (FOLD == 1) {
+    // the 128 accumulators leave ~100 VGPRs to this code: statistics first (2 * MI live values), then one column group at a time with
+    // a scheduling fence between groups (hipcc otherwise hoists the c1 / c2 loads of all 8 groups to the top: 64 more live registers)
+    float rs[MI], nmr[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      int m = m0 + wm * TM + mi * 32 + l31;
+      m = m < p.M ? m : p.M - 1;
+      const float* s = p.st_in + (size_t)m * (size_t)(2 * p.nslot_in);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+      for (int k = 0; k < p.nslot_in; k += 2) {  // nslot is even (host check)
+        const f32x4 v = load4(s + 2 * k);
+        s1 += v[0]; s2 += v[1];
+        s1 += v[2]; s2 += v[3];
+      }
+      const float mean = s1 * p.inv_d;
+      rs[mi] = __builtin_amdgcn_rsqf(fmaxf(fmaf(s2, p.inv_d, -mean * mean), 0.f) + p.ln_eps);
+      nmr[mi] = -mean * rs[mi];  // acc' = rs acc + (-mu rs) c1 + c2
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
+        f32x4 cv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) { cv = load4(p.c1 + n); bv = load4(p.bias + n); }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = fmaf(rs[mi], acc[ni][mi][4 * g + j], fmaf(nmr[mi], cv[j], bv[j]));
+            // QuickGELU right here (the callers skip their own pass when FOLD == 1): one column group's temporaries at a time
+            acc[ni][mi][4 * g + j] = ACT == MMAMD_ACT_QUICKGELU ? quick_gelu(v) : v;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  } else if (p.bias != nullptr) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) bv = load4(p.bias + n);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g + j] += bv[j];
+      }
+  }
+}
+
+// producer side, for epilogues that hold an output row segment of 4 consecutive fp32 per lane with LPR lanes per row (row-contiguous
+// layouts after the LDS transpose): bf16 copy of the 4 values and the lane group's (sum, sum of squares)
+template <int LPR>
+__device__ __forceinline__ void lnfold_emit4(const GemmArgs& p, f32x4 v, int m, int n, bool ok, float& s1, float& s2) {
+  if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, v);
+  float a = (v[0] + v[1]) + (v[2] + v[3]);
+  float b = fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  s1 += a;
+  s2 += b;
+}
+
 static int g_gemm_variant = 0;
 static unsigned long long* g_gemm_trace = nullptr;
 
 // Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
 // n = .. + 8g + 4*(lane>>5) + {0..3}.
-template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT>
+template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT, int FOLD = 0>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn,
                                               int lane) {
   const int l31 = lane & 31, half = lane >> 5;
   // pass 1: bias (depends on n only) or the folded LayerNorm.  pass 2: activation behind ONE uniform branch.  pass 3: residual + store.
-  bias_or_lnfold<MI, NI, TM, TN>(acc, p, m0, n0, wm, wn, lane);
-  if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+  bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT>(acc, p, m0, n0, wm, wn, lane);
+  if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -264,7 +272,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
         }
         if constexpr (OUT_F32) {
           if (ok) store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, t);
-          if (p.Xh != nullptr) {  // wave-uniform
+          if constexpr (FOLD == 2) {
             if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, t);
             ls1 += (t[0] + t[1]) + (t[2] + t[3]);
             ls2 += fmaf(t[0], t[0], t[1] * t[1]) + fmaf(t[2], t[2], t[3] * t[3]);
@@ -293,8 +301,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
         }
       }
     }
-    if constexpr (OUT_F32) {
-      if (p.st_out != nullptr) {  // TN == 64: the wave's columns are ONE 64-column block
+    if constexpr (OUT_F32 && FOLD == 2) {
+      {  // TN == 64: the wave's columns are ONE 64-column block
         ls1 += __shfl_xor(ls1, 32);
         ls2 += __shfl_xor(ls2, 32);
         if (mok && half == 0) {
@@ -311,13 +319,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
 // at 30-50 % of the kernel time.  Here every wave transposes its sub-tile through a private LDS strip, 32 rows at a
 // time, and then stores/loads FULL rows: one wave-instruction covers 8 rows x 128 B (bf16) or 4 rows x 256 B (fp32),
 // i.e. whole cache lines; the fp32 residual is read with the same row-contiguous pattern.
-template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT, int ABL = 0>
+template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT, int ABL = 0, int FOLD = 0>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm,
                                                   int wn, int lane, int wave, char* smem) {
   static_assert(TN == 64, "row strip below is laid out for 64-column wave tiles");
   const int l31 = lane & 31, half = lane >> 5;
-  bias_or_lnfold<MI, NI, TM, TN>(acc, p, m0, n0, wm, wn, lane);
-  if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+  bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT>(acc, p, m0, n0, wm, wn, lane);
+  if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -380,7 +388,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
           }
           store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
         }
-        if (p.Xh != nullptr) {  // wave-uniform; LN fold (producer): 16 lanes hold the 64 columns of row m
+        if constexpr (FOLD == 2) {  // LN fold (producer): 16 lanes hold the 64 columns of row m
           float s1 = 0.f, s2 = 0.f;
           lnfold_emit4<16>(p, v, m, n, ok, s1, s2);
           if (m < p.M && (lane & 15) == 0)
@@ -461,7 +469,7 @@ __device__ __forceinline__ void store16(void* ptr, uint4 v) {
 }
 
 // BM x BN block tile, WM x WN waves, BK = 64
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB, int FOLD = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
   const char* Wb = reinterpret_cast<const char*>(p.W);
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  auto issue_stage = [&](int buf, int kt) {  // scalar base + K offset, per-lane 32-bit offset: no VALU per piece
+  auto issue_stage = [&](int buf, int kt) __attribute__((always_inline)) {  // scalar base + K offset, per-lane 32-bit offset: no VALU per piece
     const uint32_t dst = lds0 + buf * STAGE + wave * 1024;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) dma_piece_s(Ab + (size_t)kt * 128, a_off[j], dst + NW * j * 1024);
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
     }
   }
 
-  gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane);
+  gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT, FOLD>(acc, p, m0, n0, wm, wn, lane);
 }
 
 
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 // K-tile is then [64 t][256 cols], stored as 256-byte units of [4 t][32 cols] (two [4][16] blocks) in [t/4][cols/32] order — the
 // DMA lays it out through its per-lane source addresses — and every MFMA operand is two ds_read_b64_tr_b16 (4 + 4 contraction
 // indices of one column per lane; the two 16-lane groups of a half-wave read one contiguous 256-byte unit: conflict-free).
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0, int FOLD = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m,
                                                                         unsigned long long* trace = nullptr) {
   static_assert(!TNM || (BM == 256 && BN == 256), "TN image below is laid out for 256-column operand tiles");
@@ -690,12 +698,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   const char* Wb = reinterpret_cast<const char*>(p.W) + (size_t)kt0 * w_step;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
   // piece i of a stage (i < A_INSTR: activation rows, else weight rows): scalar base + K offset, per-lane 32-bit offset
-  auto issue_piece = [&](int buf, int kt, int i) {
+  auto issue_piece = [&](int buf, int kt, int i) __attribute__((always_inline)) {
     const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
     if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * a_step, a_off[i], dst);
     else dma_piece_s(Wb + (size_t)kt * w_step, b_off[i - A_INSTR], dst);
   };
-  auto issue_stage = [&](int buf, int kt) {
+  auto issue_stage = [&](int buf, int kt) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) issue_piece(buf, kt, i);
   };
@@ -785,7 +793,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   auto mma_one = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI], int i) {
     acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
   };
-  auto tile_body = [&](int kt, auto bufc, const bool has_next) {
+  auto tile_body = [&](int kt, auto bufc, const bool has_next) __attribute__((always_inline)) {
     constexpr int BF = decltype(bufc)::value;
     const bool NEXT = has_next && (ABL & 1) == 0;
     // segment 1 (hand-ordered; the asm DMA is invisible to sched_group_barrier): this tile's first fragments, then the
@@ -841,7 +849,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   if constexpr ((ABL & 64) != 0) {
     if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
   }
-  auto stamp = [&]() {
+  auto stamp = [&]() __attribute__((always_inline)) {
     if constexpr ((ABL & 64) != 0) {
       if (tr != nullptr && tix < 255) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   stamp();
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  auto sync_tile = [&]() {
+  auto sync_tile = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the tile have landed
     __syncthreads();                                   // ... everyone's; and the previous tile's reads are done
   };
@@ -891,10 +899,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     if (ssum == 1.2345678e33f) reinterpret_cast<float*>(p.C)[0] = ssum;
     return;
   }
-  GemmArgs pe = p;
-  if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)split * (size_t)p.c_split_stride;
-  if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, pe, m0, n0, wm, wn, lane, wave, smem);
-  else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, pe, m0, n0, wm, wn, lane);
+  if constexpr (FOLD != 0) {  // never split-K: the kernel argument is used as is (a local copy of the enlarged struct is not promoted to SGPRs)
+    if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL, FOLD>(acc, p, m0, n0, wm, wn, lane, wave, smem);
+    else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT, FOLD>(acc, p, m0, n0, wm, wn, lane);
+  } else {
+    GemmArgs pe = p;
+    if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)split * (size_t)p.c_split_stride;
+    if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL, 0>(acc, pe, m0, n0, wm, wn, lane, wave, smem);
+    else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT, 0>(acc, pe, m0, n0, wm, wn, lane);
+  }
   if constexpr ((ABL & 64) != 0) {
     stamp();                                           // stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores retired
@@ -979,7 +992,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_g(const GemmArgs p, c
   const char* Wb = reinterpret_cast<const char*>(p.W);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
   // unit u of K-tile kt into stage buf: 0 = A-lo, 1 = A-hi, 2 = W-lo, 3 = W-hi (pieces j = 2(u&1), 2(u&1)+1 of the operand)
-  auto issue_unit = [&](int buf, int kt, int u) {
+  auto issue_unit = [&](int buf, int kt, int u) __attribute__((always_inline)) {
     if constexpr ((ABL & 1) != 0) { if (kt > 0) return; }  // ablation: no DMA after the prologue
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1011,7 +1024,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_g(const GemmArgs p, c
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
   bf16x8 xa[2][4], w0[4], w1[4];  // A fragments of the current m-half (2 row blocks x 4 k-steps); both W column blocks
 
-  auto bar = [&]() {
+  auto bar = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1024,7 +1037,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_g(const GemmArgs p, c
   if constexpr (TRACE) {
     if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
   }
-  auto stamp = [&]() {
+  auto stamp = [&]() __attribute__((always_inline)) {
     if constexpr (TRACE) {
       if (tr != nullptr && tix < 255) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -1035,7 +1048,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_g(const GemmArgs p, c
   };
 
   // one phase.  BF: stage of the current K-tile (compile-time), PH: phase 0..3, kt: current K-tile
-  auto phase = [&](auto bufc, auto phc, int kt) {
+  auto phase = [&](auto bufc, auto phc, int kt) __attribute__((always_inline)) {
     constexpr int BF = decltype(bufc)::value, PH = decltype(phc)::value;
     constexpr int MH = (PH >= 2) ? 1 : 0;             // m-half of the wave tile
     constexpr int NB = (PH == 1 || PH == 2) ? 1 : 0;  // n-block
@@ -1206,7 +1219,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_q(const GemmArgs p, c
   }
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
-  auto issue_stage = [&](int st) {
+  auto issue_stage = [&](int st) __attribute__((always_inline)) {
     char* sbase = smem + (st & 3) * STAGE;
     const uint32_t kbytes = (uint32_t)st * 64u;
 #pragma unroll
@@ -1263,7 +1276,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_q(const GemmArgs p, c
         acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  auto stage_body = [&](int st, auto issue_next) {
+  auto stage_body = [&](int st, auto issue_next) __attribute__((always_inline)) {
     const char* sa = smem + (st & 3) * STAGE + (wm * TM) * 64;
     const char* sb = smem + (st & 3) * STAGE + A_BYTES + (wn * TN) * 64;
     if constexpr (SCHED == 1) {
@@ -1413,7 +1426,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
   }
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
-  auto issue_stage = [&](int st) {
+  auto issue_stage = [&](int st) __attribute__((always_inline)) {
     char* sbase = smem + (st & 3) * STAGE;
     const uint32_t kbytes = (uint32_t)st * 64u;
 #pragma unroll
@@ -1444,7 +1457,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
   if constexpr (TRACE) {
     if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
   }
-  auto stamp = [&]() {
+  auto stamp = [&]() __attribute__((always_inline)) {
     if constexpr (TRACE) {
       if (tr != nullptr && tix < 255) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -1455,7 +1468,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
   };
 
   // LOAD section of stage st: DMA of stage st+3 first (an LDS-DMA behind pending ds_reads would make hipcc drain them)
-  auto load_section = [&](int st, auto issue_next, auto waitcode) {
+  auto load_section = [&](int st, auto issue_next, auto waitcode) __attribute__((always_inline)) {
     if constexpr (decltype(issue_next)::value && (ABL & 1) == 0) issue_stage(st + 3);
     if constexpr (TRACE) { __builtin_amdgcn_sched_barrier(0); stamp(); }
     const char* sa = smem + (st & 3) * STAGE + (wm * TM) * 64;
@@ -1477,7 +1490,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
     __builtin_amdgcn_s_waitcnt(decltype(waitcode)::value);  // fragments in registers; next stage's own pieces landed
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto matrix_section = [&]() {
+  auto matrix_section = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1545,7 +1558,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
 // WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
 // SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
   constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -1560,7 +1573,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, half = lane >> 5;
 
-  auto tile_of = [&](int vb, int& tm, int& tn) {
+  auto tile_of = [&](int vb, int& tm, int& tn) __attribute__((always_inline)) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, loc = vb >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int per_group = GM * p.tiles_n;
@@ -1594,7 +1607,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   const char* Wb = reinterpret_cast<const char*>(p.W);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
   uint32_t a_off[A_INSTR], b_off[B_INSTR], a_nxt[A_INSTR], b_nxt[B_INSTR];
-  auto issue_piece = [&](int buf, int kt, int i) {
+  auto issue_piece = [&](int buf, int kt, int i) __attribute__((always_inline)) {
     const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
     if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
     else dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
@@ -1632,7 +1645,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
   };
   // one K-tile out of ring buffer BF; behind the first MFMA group one DMA piece each of (ktsrc -> buffer BF^1)
-  auto tile_body = [&](auto bufc, int ktsrc, const bool issue) {
+  auto tile_body = [&](auto bufc, int ktsrc, const bool issue) __attribute__((always_inline)) {
     constexpr int BF = decltype(bufc)::value;
     load_frags(bufc, 0, xa0, wb0);
     __builtin_amdgcn_sched_barrier(0);
@@ -1673,7 +1686,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  auto sync_tile = [&]() {
+  auto sync_tile = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
@@ -1727,8 +1740,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     mma(xa1, wb1);  // flush the rotated last k-step
 
     // ---------------- epilogue (LDS strips in ring buffer 1; buffer 0 is receiving the next tile) ----------------
-    bias_or_lnfold<MI, NI, TM, TN>(acc, p, m0, n0, wm, wn, lane);
-    if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+    bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT>(acc, p, m0, n0, wm, wn, lane);
+    if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -1760,9 +1773,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int pass = mi * NI + ni;
-          if (ni == 0) {
+          if constexpr (FOLD == 2) {
+            if (ni == 0) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) fs1[it] = fs2[it] = 0.f;
+              for (int it = 0; it < 4; ++it) fs1[it] = fs2[it] = 0.f;
+            }
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -1788,7 +1803,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
               }
               store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
             }
-            if (p.Xh != nullptr) {  // wave-uniform: 8 lanes hold 32 columns of row m in this pass
+            if constexpr (FOLD == 2) {  // 8 lanes hold 32 columns of row m in this pass
               lnfold_emit4<8>(p, v, m, n, ok, fs1[it], fs2[it]);
               if (ni == NI - 1 && m < p.M && (lane & 7) == 0)
                 *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{fs1[it], fs2[it]};
@@ -1868,10 +1883,10 @@ __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB, int FOLD = 0>
 static int launch_tiled(GemmArgs& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, OUT_F32, ACT, SGB>;
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, OUT_F32, ACT, SGB, FOLD>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -1880,12 +1895,12 @@ static int launch_tiled(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16");
 }
 
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, int FOLD = 0>
 static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
   // the pipelined kernel walks the K-tiles in pairs (compile-time buffer index): odd tile counts take the plain kernel
-  if (((p.K >> 6) & 1) != 0) return launch_tiled<BM, BN, WM, WN, OUT_F32, ACT, true>(p, st);
+  if (((p.K >> 6) & 1) != 0) return launch_tiled<BM, BN, WM, WN, OUT_F32, ACT, true, FOLD>(p, st);
   constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = gemm_bf16_nt_kernel_p<BM, BN, WM, WN, OUT_F32, ACT, GM, ABL, LDSEPI>;
+  auto kern = gemm_bf16_nt_kernel_p<BM, BN, WM, WN, OUT_F32, ACT, GM, ABL, LDSEPI, false, 0, FOLD>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -1935,11 +1950,11 @@ static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
 
 #endif  // MMAMD_EXPERIMENTS
 
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
-  if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
+  if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true, FOLD>(p, st);
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP>;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
@@ -1951,9 +1966,9 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_pp");
 }
 
-template <bool OUT_F32, int ACT>
+template <bool OUT_F32, int ACT, int FOLD = 0>
 static int dispatch_variant(GemmArgs& p, hipStream_t st) {
-  int v = g_gemm_variant;
+  int v = FOLD != 0 ? 0 : g_gemm_variant;  // the LN-fold epilogues exist in the default-policy kernels only
   if (v == 0) {
     // Default policy (measured per shape with tools/kernel_bench.py):
     //  * the pipelined 256x256 kernel whenever its grid reaches a good fraction of the 256 CUs, else 128x128 tiles;
@@ -1984,8 +1999,8 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       if (p.Xh != nullptr) b.Xh = p.Xh + rows * p.ldxh;
       if (p.st_out != nullptr) b.st_out = p.st_out + rows * (size_t)(2 * p.nslot_out);
       if (p.st_in != nullptr) b.st_in = p.st_in + rows * (size_t)(2 * p.nslot_in);
-      rc = big_pp ? launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(a, st) : launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
-      if (rc == 0) rc = launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
+      rc = big_pp ? launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, FOLD>(a, st) : launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, true, FOLD>(a, st);
+      if (rc == 0) rc = launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true, FOLD>(b, st);
       return true;
     };
     // (re-measured with warm clocks, tools/kernel_bench.py: the persistent kernel wins from ~400 tiles up at every K — out-proj 625 vs 616 vs
@@ -1998,13 +2013,19 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       if (p.K >= 2048 && try_split(true)) return rc;
       // the large-M and the small-M launches get different instantiations (tile-order group 8 / 4: equal speed), so that a kernel name in a
       // rocprof summary is ONE shape class — the bench's dominant kernel, gemm_bf16_nt_kernel_pp<false, QuickGELU, 8, ...>, is the ViT MLP-up only
-      if (p.M < 32768) return launch_tiled_pp<OUT_F32, ACT, 4, 2, 4, OUT_F32 ? 0 : 2>(p, st);
+      if (p.M < 32768) return launch_tiled_pp<OUT_F32, ACT, 4, 2, 4, OUT_F32 ? 0 : 2, 0, FOLD>(p, st);
     } else {
       v = 7;
       if (p.K >= 2048 && try_split(false)) return rc;
     }
   }
-  {
+  if constexpr (FOLD != 0) {
+    switch (v) {
+      case 6: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true, FOLD>(p, st);
+      case 7: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, true, FOLD>(p, st);
+      default: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, FOLD>(p, st);
+    }
+  } else {
     switch (v) {
       case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);
       case 2: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, false>(p, st);
@@ -2067,6 +2088,17 @@ static int dispatch(GemmArgs& p, hipStream_t st) {
   if (g_gemm_variant == 99) {
     hipLaunchKernelGGL((gemm_naive_kernel<OUT_F32>), dim3((p.N + 63) / 64, (p.M + 3) / 4), dim3(256), 0, st, p);
     return launch_status("gemm_naive");
+  }
+  if constexpr (OUT_F32) {
+    if (p.Xh != nullptr) return dispatch_variant<true, MMAMD_ACT_NONE, 2>(p, st);  // LN fold, producer (host: act == NONE)
+  } else {
+    if (p.st_in != nullptr) {  // LN fold, consumer
+      switch (p.act) {
+        case MMAMD_ACT_NONE: return dispatch_variant<false, MMAMD_ACT_NONE, 1>(p, st);
+        case MMAMD_ACT_QUICKGELU: return dispatch_variant<false, MMAMD_ACT_QUICKGELU, 1>(p, st);
+        default: return dispatch_variant<false, MMAMD_ACT_GELU_ERF, 1>(p, st);
+      }
+    }
   }
   switch (p.act) {
     case MMAMD_ACT_NONE: return dispatch_variant<OUT_F32, MMAMD_ACT_NONE>(p, st);
