@@ -144,8 +144,10 @@ __device__ __forceinline__ void store_act_copy(const GemmArgs& p, uint4 v, int m
 // Numerics: x instead of LN(x) is rounded to bf16, which scales the operand rounding error of a token by sqrt(1 + mu^2/sigma^2)
 // (tools/ln_fold_numerics.py); var = E[x^2] - mu^2 in fp32.  Parity at the headline size: tests/test_gpu_headline_parity.py.
 // ---------------------------------------------------------------------------------------------------------
-template <int MI, int NI, int TM, int TN, int FOLD, int ACT>
-__device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn, int lane) {
+// st_lds (FOLD == 1, persistent kernel): the statistics of the tile's rows, [BM][nslot][2] floats, DMA'd into LDS during the K loop
+template <int MI, int NI, int TM, int TN, int FOLD, int ACT, bool STLDS = false>
+__device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn, int lane,
+                                               const char* st_lds = nullptr) {
   const int l31 = lane & 31, half = lane >> 5;
   if constexpr (FOLD == 1) {
     // the 128 accumulators leave ~100 VGPRs to this code: statistics first (2 * MI live values), then one column group at a time with
@@ -153,38 +155,54 @@ __device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const Gemm
     float rs[MI], nmr[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      int m = m0 + wm * TM + mi * 32 + l31;
-      m = m < p.M ? m : p.M - 1;
-      const float* s = p.st_in + (size_t)m * (size_t)(2 * p.nslot_in);
       float s1 = 0.f, s2 = 0.f;
-#pragma unroll 1
-      for (int k = 0; k < p.nslot_in; k += 2) {  // nslot is even (host check)
-        const f32x4 v = load4(s + 2 * k);
-        s1 += v[0]; s2 += v[1];
-        s1 += v[2]; s2 += v[3];
+      if constexpr (STLDS) {
+        const float* s = reinterpret_cast<const float*>(st_lds) + (size_t)(wm * TM + mi * 32 + l31) * (size_t)(2 * p.nslot_in);
+        for (int k = 0; k < p.nslot_in; k += 2) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(s + 2 * k);
+          s1 += v[0]; s2 += v[1];
+          s1 += v[2]; s2 += v[3];
+        }
+      } else {
+        int m = m0 + wm * TM + mi * 32 + l31;
+        m = m < p.M ? m : p.M - 1;
+        const float* s = p.st_in + (size_t)m * (size_t)(2 * p.nslot_in);
+#pragma unroll 4
+        for (int k = 0; k < p.nslot_in; k += 2) {  // nslot is even (host check); fixed order: block 0, 1, 2, ...
+          const f32x4 v = load4(s + 2 * k);
+          s1 += v[0]; s2 += v[1];
+          s1 += v[2]; s2 += v[3];
+        }
       }
       const float mean = s1 * p.inv_d;
       rs[mi] = __builtin_amdgcn_rsqf(fmaxf(fmaf(s2, p.inv_d, -mean * mean), 0.f) + p.ln_eps);
       nmr[mi] = -mean * rs[mi];  // acc' = rs acc + (-mu rs) c1 + c2
       __builtin_amdgcn_sched_barrier(0);
     }
+    // one 32-column half (4 column groups) at a time: its 8 c1 / c2 loads are issued together (ONE L2 round trip per half; a fence
+    // per group made it one per group: +10 % on the ViT MLP-up GEMM, 2 x on the text tower's), 32 live registers
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int ni = 0; ni < NI; ++ni) {
+      f32x4 cv[4], bv[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-        f32x4 cv = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) { cv = load4(p.c1 + n); bv = load4(p.bias + n); }
+        cv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < p.N) { cv[g] = load4(p.c1 + n); bv[g] = load4(p.bias + n); }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float v = fmaf(rs[mi], acc[ni][mi][4 * g + j], fmaf(nmr[mi], cv[j], bv[j]));
-            // QuickGELU right here (the callers skip their own pass when FOLD == 1): one column group's temporaries at a time
+            const float v = fmaf(rs[mi], acc[ni][mi][4 * g + j], fmaf(nmr[mi], cv[g][j], bv[g][j]));
+            // QuickGELU right here (the callers skip their own pass when FOLD == 1)
             acc[ni][mi][4 * g + j] = ACT == MMAMD_ACT_QUICKGELU ? quick_gelu(v) : v;
           }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   } else if (p.bias != nullptr) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -201,17 +219,18 @@ __device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const Gemm
   }
 }
 
-// producer side, for epilogues that hold an output row segment of 4 consecutive fp32 per lane with LPR lanes per row (row-contiguous
-// layouts after the LDS transpose): bf16 copy of the 4 values and the lane group's (sum, sum of squares)
-template <int LPR>
-__device__ __forceinline__ void lnfold_emit4(const GemmArgs& p, f32x4 v, int m, int n, bool ok, float& s1, float& s2) {
-  if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, v);
-  float a = (v[0] + v[1]) + (v[2] + v[3]);
-  float b = fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+// producer side.  CANONICAL summation order of a row's 64-column block (every epilogue reproduces it, so a row's statistics are
+// bit-identical whichever kernel the dispatcher picks for a batch size): column quads q_c = (v0 + v1) + (v2 + v3), c = 0..15;
+// u_c = q_c + q_(c+8), c = 0..7 (the two 32-column halves); then a butterfly over c with partners c^1, c^2, c^4.  Sum of squares alike
+// with quads fma(v0, v0, v1 v1) + fma(v2, v2, v3 v3).
+__device__ __forceinline__ void lnfold_store_acc(const GemmArgs& p, f32x4 v, int m, int n, bool ok, float& s1, float& s2) {
+  if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, v);  // bf16 copy of the 4 values
+  s1 += (v[0] + v[1]) + (v[2] + v[3]);
+  s2 += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+}
+__device__ __forceinline__ void lnfold_butterfly8(float& a, float& b) {  // partners c^1, c^2, c^4 = lanes ^1, ^2, ^4
 #pragma unroll
-  for (int o = 1; o < LPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-  s1 += a;
-  s2 += b;
+  for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
 }
 
 static int g_gemm_variant = 0;
@@ -251,7 +270,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * TM + mi * 32 + l31;
     const bool mok = m < p.M;
-    float ls1 = 0.f, ls2 = 0.f;  // LN fold (producer): this lane's share of row m over the wave's 64 columns
+    // LN fold (producer): the canonical order (lnfold_store_acc) in this layout: quad c = 2 g + half of 32-column half ni, so
+    // u_c = ua[g] (sum over ni, in-lane), partner c^1 = the other lane half, partners c^2 / c^4 = accumulator groups g^1 / g^2
+    float ua[4] = {0.f, 0.f, 0.f, 0.f}, ub[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int nb = n0 + wn * TN + ni * 32 + 4 * half;
@@ -274,8 +295,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
           if (ok) store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, t);
           if constexpr (FOLD == 2) {
             if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, t);
-            ls1 += (t[0] + t[1]) + (t[2] + t[3]);
-            ls2 += fmaf(t[0], t[0], t[1] * t[1]) + fmaf(t[2], t[2], t[3] * t[3]);
+            ua[g] += (t[0] + t[1]) + (t[2] + t[3]);
+            ub[g] += fmaf(t[0], t[0], t[1] * t[1]) + fmaf(t[2], t[2], t[3] * t[3]);
           }
         }
         v[g] = t;
@@ -303,8 +324,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
     }
     if constexpr (OUT_F32 && FOLD == 2) {
       {  // TN == 64: the wave's columns are ONE 64-column block
-        ls1 += __shfl_xor(ls1, 32);
-        ls2 += __shfl_xor(ls2, 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ua[g] += __shfl_xor(ua[g], 32);
+          ub[g] += __shfl_xor(ub[g], 32);
+        }
+        const float ls1 = (ua[0] + ua[1]) + (ua[2] + ua[3]), ls2 = (ub[0] + ub[1]) + (ub[2] + ub[3]);
         if (mok && half == 0) {
           const int slot = (n0 + wn * TN) >> 6;
           *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + slot) * 2) = f32x2{ls1, ls2};
@@ -390,7 +415,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
         }
         if constexpr (FOLD == 2) {  // LN fold (producer): 16 lanes hold the 64 columns of row m
           float s1 = 0.f, s2 = 0.f;
-          lnfold_emit4<16>(p, v, m, n, ok, s1, s2);
+          lnfold_store_acc(p, v, m, n, ok, s1, s2);  // lane c = lane & 15 holds quad c
+          s1 += __shfl_xor(s1, 8);                   // u_c = q_c + q_(c+8)
+          s2 += __shfl_xor(s2, 8);
+          lnfold_butterfly8(s1, s2);
           if (m < p.M && (lane & 15) == 0)
             *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{s1, s2};
         }
@@ -1726,6 +1754,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll 1
     for (int kt = 0; kt < KT; kt += 2) {
       sync_tile();
+      if constexpr (FOLD == 1) {
+        // LN fold (consumer): the block statistics of this tile's 256 rows ([256][nslot][2] floats, one contiguous 256 * nslot * 8 B
+        // block of p.st_in) go to LDS behind the ring by LDS-DMA, issued after the first barrier of the tile (every wave has left the
+        // previous tile's epilogue, which read the previous statistics) and waited for by the next sync_tile: the epilogue finds
+        // them in LDS instead of paying nslot/2 dependent L2 round trips per row
+        if (kt == 0) {
+          const uint32_t total = (uint32_t)p.nslot_in * (BM * 8u), limit = (uint32_t)(p.M - m0) * (uint32_t)p.nslot_in * 8u - 16u;
+          const char* sbase = reinterpret_cast<const char*>(p.st_in) + (size_t)m0 * (size_t)p.nslot_in * 8u;
+          for (uint32_t pc = wave; pc * 1024u < total; pc += NW) {
+            uint32_t off = pc * 1024u + lane * 16u;
+            off = off < limit ? off : limit;  // rows past M (last tile) read the last valid 16 bytes: never stored anyway
+            dma_piece_s(sbase, off, lds0 + 2 * STAGE + pc * 1024u);
+          }
+        }
+      }
       tile_body(B0{}, kt + 1, true);
       const bool last = kt + 2 >= KT;
       if (last && more) {  // this tile's loads are all issued: switch the DMA source to the next tile's first K-tile
@@ -1740,7 +1783,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     mma(xa1, wb1);  // flush the rotated last k-step
 
     // ---------------- epilogue (LDS strips in ring buffer 1; buffer 0 is receiving the next tile) ----------------
-    bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT>(acc, p, m0, n0, wm, wn, lane);
+    bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT, FOLD == 1>(acc, p, m0, n0, wm, wn, lane, smem + 2 * STAGE);
     if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -1804,9 +1847,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
               store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
             }
             if constexpr (FOLD == 2) {  // 8 lanes hold 32 columns of row m in this pass
-              lnfold_emit4<8>(p, v, m, n, ok, fs1[it], fs2[it]);
-              if (ni == NI - 1 && m < p.M && (lane & 7) == 0)
-                *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{fs1[it], fs2[it]};
+              lnfold_store_acc(p, v, m, n, ok, fs1[it], fs2[it]);  // lane c = lane & 7: quad c of pass 0, quad c + 8 of pass 1
+              if (ni == NI - 1) {
+                lnfold_butterfly8(fs1[it], fs2[it]);
+                if (m < p.M && (lane & 7) == 0)
+                  *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{fs1[it], fs2[it]};
+              }
             }
           }
 #pragma unroll
@@ -1953,7 +1999,8 @@ static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
 template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true, FOLD>(p, st);
-  constexpr int smem = 2 * 512 * 128;
+  constexpr int smem = 2 * 512 * 128 + (FOLD == 1 ? 256 * 16 * 8 : 0);  // + the tile's row statistics (nslot <= 16: K <= 1024)
+  if (FOLD == 1 && p.nslot_in > 16) return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, GM, 0, true, FOLD>(p, st);
   auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;

@@ -83,7 +83,11 @@ class TransformerStack(nn.Module):
         att = torch.empty((M, d), dtype=bf, device=dev)
         up = torch.empty((M, self.dim_feedforward), dtype=bf, device=dev)
         bf16_stream = os.environ.get("MMAMD_RESIDUAL", "fp32") == "bf16"  # experiment knob: residual stream dtype
-        if not bf16_stream and d % 128 == 0 and os.environ.get("MMAMD_LN_FOLD", "1") != "0":
+        # LayerNorm folded into the neighbouring GEMMs: built, parity-tested, and measured SLOWER on this GEMM structure (isolated, ViT-B/16
+        # B = 256: consumers 193 / 284 us vs LayerNorm 35 + GEMM 163 / 254; producers 138 / 297 vs 98 / 269 — the per-tile epilogue is the
+        # exposed part of these kernels and the streaming LayerNorm kernel runs at 6.6 TB/s; profiles/r02_lnfold_bench.txt).
+        # Opt-in for experiments: MMAMD_LN_FOLD=1.
+        if not bf16_stream and d % 128 == 0 and os.environ.get("MMAMD_LN_FOLD", "0") == "1":
             return self._run_ln_folded(x, B, S, causal, qkv, att, up)
         x_f32 = x
         if bf16_stream:
