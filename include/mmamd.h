@@ -49,6 +49,10 @@ typedef void* mmamd_stream_t; /* hipStream_t */
 
 int mmamd_abi_version(void);
 const char* mmamd_last_error(void);
+/* Reset the calling thread's sticky HIP error (returns the value it held).  The entry points report launch failures through
+ * hipGetLastError(), which also returns statuses left behind by unrelated runtime calls of the same thread (an event query's
+ * hipErrorNotReady, a device probe's hipErrorNoDevice): bindings call this immediately before an entry point. */
+int mmamd_clear_last_hip_error(void);
 
 /* Select a GEMM kernel variant at run time (0 = default).  Test/bench hook; variants are bit-compatible
  * in what they compute, they differ in tiling/pipelining only. */

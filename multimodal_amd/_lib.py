@@ -26,6 +26,7 @@ _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 PROTOTYPES = {
     "mmamd_abi_version": (_i, []),
     "mmamd_last_error": (C.c_char_p, []),
+    "mmamd_clear_last_hip_error": (_i, []),
     "mmamd_set_gemm_variant": (_i, [_i]),
     "mmamd_get_gemm_variant": (_i, []),
     "mmamd_debug_set_gemm_trace": (_i, [_vp]),

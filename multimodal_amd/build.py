@@ -20,6 +20,7 @@ CSRC = PKG / "csrc"
 LIBDIR = PKG / "lib"
 OBJDIR = LIBDIR / "obj"
 LIB = LIBDIR / "libmmamd.so"
+TORCH_LIB = LIBDIR / "libmmamd_torch.so"  # TORCH_LIBRARY(mmamd, ...) shim over the C-ABI (csrc/torch_ops.cpp)
 INCLUDE = PKG.parent / "include"
 
 ARCH = "gfx950"
@@ -80,6 +81,36 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_torch_ops(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/torch_ops.cpp (host C++: TORCH_LIBRARY registrations that call the C-ABI) against the installed torch and link it
+    to libmmamd.so.  No kernels in it: hipcc is used as the C++ driver because torch's HIP headers need the HIP platform defines."""
+    import torch
+
+    build(force=False, verbose=verbose)
+    src = CSRC / "torch_ops.cpp"
+    tdir = Path(torch.__file__).resolve().parent
+    flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-I{tdir / 'include'}",
+             f"-I{tdir / 'include' / 'torch' / 'csrc' / 'api' / 'include'}", "-I/opt/rocm/include", "-Wno-unused-result"]
+    h = hashlib.sha256()
+    h.update((" ".join(flags) + torch.__version__).encode())
+    for f in [src, *sorted(INCLUDE.glob("*.h"))]:
+        h.update(f.read_bytes())
+    dig = h.hexdigest()
+    stamp = OBJDIR / "torch_ops.sha"
+    if not force and TORCH_LIB.exists() and stamp.exists() and stamp.read_text() == dig:
+        return TORCH_LIB
+    cmd = [_hipcc(), *flags, str(src), "-o", str(TORCH_LIB), f"-L{LIBDIR}", "-lmmamd", f"-L{tdir / 'lib'}", "-ltorch", "-ltorch_cpu", "-lc10",
+           "-ltorch_hip", "-lc10_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir / 'lib'}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"torch_ops.cpp failed to build:\n{res.stdout}\n{res.stderr}")
+    stamp.write_text(dig)
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
     print(path)
+    print(build_torch_ops(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -40,6 +40,10 @@ void set_error(const char* fmt, ...) {
 }  // namespace mmamd
 
 extern "C" int mmamd_abi_version(void) { return MMAMD_ABI_VERSION; }
+// hipGetLastError() is per host thread and STICKY across unrelated runtime calls: a benign status left behind by somebody else's
+// call (hipErrorNotReady from an event query, hipErrorNoDevice from a device probe during torch's lazy initialisation, ...) would
+// otherwise be reported by the next launch_status() as if our launch had failed.  Bindings call this right before an entry point.
+extern "C" int mmamd_clear_last_hip_error(void) { return (int)hipGetLastError(); }
 extern "C" const char* mmamd_last_error(void) { return mmamd::g_err; }
 
 struct MmamdTimer {

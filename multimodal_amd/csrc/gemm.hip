@@ -1909,6 +1909,160 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "W" kernel: TWO workgroups per CU.  The lock-step kernels above stop the matrix pipe for the whole per-tile epilogue (22-55 % of a
+// tile's time at K = 768: bias / activation VALU, the LDS transpose, the stores) because all eight waves of the CU's one workgroup are
+// in it together.  Here a workgroup is 4 waves (one per SIMD) on a 256 x 128 tile (2 x 2 waves of 128 x 64, the same wave tile and
+// fragment traffic as above) with a 3-stage BK = 32 LDS-DMA ring (72 KiB), so two workgroups are resident per CU with independent
+// barriers: they drift out of phase, and while one is in its prologue / epilogue the other one's K loop owns the matrix pipe.
+//   LDS image of a K-tile: 64-byte rows (32 bf16), 4 rows per 256-byte bank row = 16 slots of 16 B; logical slot s = 4 (r & 3) + c
+//   (c = 16-byte chunk) is stored at s ^ (R & 15), R = r >> 2 -- the permutation is applied to the DMA SOURCE address (the LDS
+//   destination of a piece is lane-linear) and undone by the ds_read_b128 address: the 16 lanes of every read group hit 16 slots.
+//   RAW: tile kt's pieces (issued two iterations earlier) are waited with vmcnt(6) (tile kt+1's six may stay in flight) + barrier.
+//   WAR: tile kt+2 goes into the stage read during iteration kt-1; every wave has passed iteration kt's barrier by then.
+// SCH 0: DMA burst behind the barrier, then reads, then MFMAs.  SCH 1: one DMA piece behind each of the first six MFMAs (the burst is
+// ~6 x 60-100 cycles in front of a 512-cycle MFMA block).  SCH 2: SCH 1 + raised priority over the MFMA block.
+template <bool OUT_F32, int ACT, int GM, int SCH = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel_w(const GemmArgs p, const int tiles_m) {
+  constexpr int BM = 256, BN = 128, WN = 2, NW = 4, TM = 128, TN = 64, MI = 4, NI = 2;
+  constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64, A_INSTR = 4, B_INSTR = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tm, tn;
+  {
+    const int per_group = GM * p.tiles_n;
+    const int grp = bid / per_group, within = bid - grp * per_group;
+    const int gm0 = grp * GM;
+    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tn = within / rows;
+    tm = gm0 + (within - tn * rows);
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // DMA source offsets: piece q = wave + 4 j covers image rows 16 q .. 16 q + 15; lane -> bank row R = 4 q + (lane >> 4), stored
+  // slot lane & 15 holds logical slot s = (lane & 15) ^ (R & 15); (R & 15) = (4 wave + (lane >> 4)) & 15 for every j
+  const int sxr = (4 * wave + (lane >> 4)) & 15;
+  const int ls = (lane & 15) ^ sxr;
+  const int prow = 4 * (lane >> 4) + (ls >> 2), pchunk = ls & 3;
+  uint32_t a_off[A_INSTR], b_off[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    int r = m0 + 16 * (wave + NW * j) + prow;
+    r = r < p.M ? r : p.M - 1;
+    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + pchunk * 8) * 2u;
+  }
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    int r = n0 + 16 * (wave + NW * j) + prow;
+    r = r < p.N ? r : p.N - 1;
+    b_off[j] = ((uint32_t)r * (uint32_t)p.ldw + pchunk * 8) * 2u;
+  }
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
+  auto issue_tile = [&](int stage, int kt) __attribute__((always_inline)) {
+    const uint32_t dst = lds0 + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) dma_piece_s(Ab + (size_t)kt * 64, a_off[j], dst + NW * j * 1024);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) dma_piece_s(Wb + (size_t)kt * 64, b_off[j], dst + A_BYTES + NW * j * 1024);
+  };
+
+  // fragment read offsets inside a stage: operand row r, k-step t -> chunk c = 2 t + half
+  uint32_t ra[MI][2], rb[NI][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int r = wm * TM + mi * 32 + l31, R = r >> 2;
+      ra[mi][t] = R * 256 + (((((r & 3) << 2) | (2 * t + half)) ^ (R & 15)) << 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int r = wn * TN + ni * 32 + l31, R = r >> 2;
+      rb[ni][t] = A_BYTES + R * 256 + (((((r & 3) << 2) | (2 * t + half)) ^ (R & 15)) << 4);
+    }
+  }
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  const int KT = p.K >> 5;  // >= 2 (K % 64 == 0)
+  issue_tile(0, 0);
+  issue_tile(1, 1);
+  auto body = [&](auto stagec, int kt) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stagec)::value;
+    if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt landed; tile kt+1's six pieces may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool issue = kt + 2 < KT;
+    if constexpr (SCH == 0) {
+      if (issue) issue_tile((ST + 2) % 3, kt + 2);
+    }
+    const char* sb = smem + ST * STAGE;
+    bf16x8 xa[2][MI], wb[2][NI];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wb[t][ni] = *reinterpret_cast<const bf16x8*>(sb + rb[ni][t]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xa[t][mi] = *reinterpret_cast<const bf16x8*>(sb + ra[mi][t]);
+    }
+    if constexpr (SCH == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[t][ni], xa[t][mi], acc[ni][mi], 0, 0, 0);
+    } else {
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SCH == 2) __builtin_amdgcn_s_setprio(1);
+      const uint32_t dst = lds0 + ((ST + 2) % 3) * STAGE + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < NI * MI; ++i) {
+        acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[0][i / MI], xa[0][i % MI], acc[i / MI][i % MI], 0, 0, 0);
+        if (issue && i < A_INSTR + B_INSTR) {  // wave-uniform scalar branch
+          if (i < A_INSTR) dma_piece_s(Ab + (size_t)(kt + 2) * 64, a_off[i], dst + NW * i * 1024);
+          else dma_piece_s(Wb + (size_t)(kt + 2) * 64, b_off[i - A_INSTR], dst + A_BYTES + NW * (i - A_INSTR) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[1][ni], xa[1][mi], acc[ni][mi], 0, 0, 0);
+      if constexpr (SCH == 2) __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+  for (int kt = 0; kt < KT; kt += 3) {
+    body(S0{}, kt);
+    if (kt + 1 < KT) body(S1{}, kt + 1);
+    if (kt + 2 < KT) body(S2{}, kt + 2);
+  }
+  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
+}
+
 // plain one-thread-per-output kernel: on-device cross-check for the MFMA kernels (tests / debugging)
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmArgs p) {
@@ -2013,6 +2167,18 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_pp");
 }
 
+template <bool OUT_F32, int ACT, int GM, int SCH = 0>
+static int launch_tiled_w(GemmArgs& p, hipStream_t st) {
+  constexpr int smem = 3 * (256 + 128) * 64;
+  auto kern = gemm_bf16_nt_kernel_w<OUT_F32, ACT, GM, SCH>;
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
+  const int tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 127) / 128;
+  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), smem, st, p, tiles_m);
+  return launch_status("gemm_bf16_w");
+}
+
 template <bool OUT_F32, int ACT, int FOLD = 0>
 static int dispatch_variant(GemmArgs& p, hipStream_t st) {
   int v = FOLD != 0 ? 0 : g_gemm_variant;  // the LN-fold epilogues exist in the default-policy kernels only
@@ -2082,6 +2248,9 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       // bf16 C tiles are stored non-temporal (measured +6-7 % on the qkv / MLP-up GEMMs: the 128 KiB a block writes per
       // tile no longer competes with the operand panels for the XCD's L2); the in-place fp32 residual update stays plain
       case 18: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(p, st);
+      case 50: return launch_tiled_w<OUT_F32, ACT, 8>(p, st);   // two workgroups per CU, 256 x 128 tiles, BK = 32 ring of 3
+      case 51: return launch_tiled_w<OUT_F32, ACT, 8, 1>(p, st);
+      case 52: return launch_tiled_w<OUT_F32, ACT, 8, 2>(p, st);
 #ifdef MMAMD_EXPERIMENTS
       case 20: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 1>(p, st);  // C stores sc1 (write-through, not kept in L2)
       case 21: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 2>(p, st);  // C stores nt

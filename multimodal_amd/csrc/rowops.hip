@@ -265,6 +265,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ im
 //   (the first version did the projection as a block-per-sample mat-vec that re-read the whole matrix per sample:
 //    276 us per call in the r01 rocprof trace)
 // ---------------------------------------------------------------------------------------------
+// (r02: the first pool_ln_kernel walked the row three times with dependent scalar loads, 82 us for 256 rows; the first proj_f32_kernel
+//  gave one wave a whole 32 x 32 x d tile with a load -> 4 MFMA -> load chain, 106-152 us for 0.2 GFLOP.  Now the row is read once
+//  into registers, and the contraction is split over the 4 waves of a block with 32 k's of loads in flight per wave.)
+template <int MAXV>
 __global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ x, int S, int d,
                                                       const int64_t* __restrict__ ids, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, float* __restrict__ h, int B) {
@@ -287,22 +291,56 @@ __global__ __launch_bounds__(256) void pool_ln_kernel(const float* __restrict__ 
     }
   }
   const float* xr = x + ((size_t)b * S + best_i) * d;
-  float s1 = 0.f;
-  for (int k = lane; k < d; k += 64) s1 += xr[k];
-  const float mean = wave_sum(s1) / (float)d;
-  float s2 = 0.f;
-  for (int k = lane; k < d; k += 64) { const float t = xr[k] - mean; s2 += t * t; }
-  const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + eps);
   float* hr = h + (size_t)b * d;
-  for (int k = lane; k < d; k += 64) hr[k] = (xr[k] - mean) * rstd * gamma[k] + beta[k];
+  if constexpr (MAXV > 0) {  // d % 4 == 0, d <= 256 * MAXV: the row lives in registers (one batch of 16-byte loads)
+    const int d4 = d >> 2;
+    f32x4 v[MAXV];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < d4 ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s1) / (float)d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (lane + 64 * i < d4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mean; s2 += t * t; }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) {
+        const f32x4 g = load4(gamma + 4 * c), bb = load4(beta + 4 * c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+        store4(hr + 4 * c, o);
+      }
+    }
+  } else {
+    float s1 = 0.f;
+    for (int k = lane; k < d; k += 64) s1 += xr[k];
+    const float mean = wave_sum(s1) / (float)d;
+    float s2 = 0.f;
+    for (int k = lane; k < d; k += 64) { const float t = xr[k] - mean; s2 += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)d + eps);
+    for (int k = lane; k < d; k += 64) hr[k] = (xr[k] - mean) * rstd * gamma[k] + beta[k];
+  }
 }
 
+// out[B,E] = h[B,d] . P in exact fp32 (v_mfma_f32_32x32x2_f32).  One block per 32 x 32 output tile; its 4 waves split the contraction
+// (wave w: k in [w kq, (w+1) kq), kq a multiple of 32) and sum their partial tiles through LDS in wave order (deterministic).
 __global__ __launch_bounds__(256) void proj_f32_kernel(const float* __restrict__ h, const float* __restrict__ proj, int sk,
                                                        int se, float* __restrict__ out, int B, int d, int E) {
+  __shared__ float red[4][32][33];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * 32;
-  const int j0 = (blockIdx.x * 4 + wv) * 32;
-  if (j0 >= E) return;  // wave-uniform
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const int half = lane >> 5;
   int ri = i0 + (lane & 31); ri = ri < B ? ri : B - 1;
   int rj = j0 + (lane & 31); rj = rj < E ? rj : E - 1;
@@ -310,30 +348,45 @@ __global__ __launch_bounds__(256) void proj_f32_kernel(const float* __restrict__
   const float* rp = proj + (size_t)rj * se;
   const bool vec = (sk == 1) && ((d & 3) == 0) && ((se & 3) == 0) && ((reinterpret_cast<uintptr_t>(proj) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(h) & 15) == 0);
+  const bool xvec = ((d & 3) == 0) && ((reinterpret_cast<uintptr_t>(h) & 15) == 0);
+  const int kq = ((d + 127) / 128) * 32;  // per-wave share of the contraction, multiple of 32
+  const int kbeg = wv * kq, kend = (kbeg + kq) < d ? (kbeg + kq) : d;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < d; k0 += 8) {
-    const int k = k0 + 4 * half;
-    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
-    if (vec && k + 3 < d) {
-      xv = load4(lp + k);
-      yv = load4(rp + k);
-    } else {
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    f32x4 xv[4], yv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (k + u < d) { xv[u] = lp[k + u]; yv[u] = rp[(size_t)(k + u) * sk]; }
+    for (int q = 0; q < 4; ++q) {  // all loads of 32 k's first: one memory round trip per 16 MFMAs instead of one per 4
+      const int k = k0 + 8 * q + 4 * half;
+      xv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      yv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (xvec && k + 3 < kend) {
+        xv[q] = load4(lp + k);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k + u < kend) xv[q][u] = lp[k + u];
+      }
+      if (vec && k + 3 < kend) {
+        yv[q] = load4(rp + k);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k + u < kend) yv[q][u] = rp[(size_t)(k + u) * sk];
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u], yv[u], acc, 0, 0, 0);
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[q][u], yv[q][u], acc, 0, 0, 0);
   }
-  const int j = j0 + (lane & 31);
-  if (j < E) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (i < B) out[(size_t)i * E + j] = acc[r];
-    }
+  for (int r = 0; r < 16; ++r) red[wv][(r & 3) + 8 * (r >> 2) + 4 * half][lane & 31] = acc[r];
+  __syncthreads();
+  for (int t = threadIdx.x; t < 32 * 32; t += 256) {
+    const int i = t >> 5, j = t & 31;
+    if (i0 + i < B && j0 + j < E) out[(size_t)(i0 + i) * E + j0 + j] = ((red[0][i][j] + red[1][i][j]) + red[2][i][j]) + red[3][i][j];
   }
 }
 
@@ -768,8 +821,13 @@ extern "C" int mmamd_pool_ln_proj(const float* x, int S, int d, const int64_t* i
   MMAMD_CHECK_ARG(proj_se == 1 || proj_sk == 1, MMAMD_E_UNSUPPORTED, "pool_ln_proj: projection must be contiguous along k or e");
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pool_ln_kernel, dim3((B + 3) / 4), dim3(256), 0, st, x, S, d, ids, gamma, beta, eps, ws, B);
-  hipLaunchKernelGGL(proj_f32_kernel, dim3((E + 127) / 128, (B + 31) / 32), dim3(256), 0, st, ws, proj, proj_sk, proj_se, out, B, d, E);
+  const dim3 pgrid((B + 3) / 4), pblock(256);
+  const bool rowvec = d % 4 == 0 && aligned16(x) && aligned16(gamma) && aligned16(beta) && aligned16(ws);
+  if (rowvec && d <= 512) hipLaunchKernelGGL((pool_ln_kernel<2>), pgrid, pblock, 0, st, x, S, d, ids, gamma, beta, eps, ws, B);
+  else if (rowvec && d <= 1024) hipLaunchKernelGGL((pool_ln_kernel<4>), pgrid, pblock, 0, st, x, S, d, ids, gamma, beta, eps, ws, B);
+  else if (rowvec && d <= 2048) hipLaunchKernelGGL((pool_ln_kernel<8>), pgrid, pblock, 0, st, x, S, d, ids, gamma, beta, eps, ws, B);
+  else hipLaunchKernelGGL((pool_ln_kernel<0>), pgrid, pblock, 0, st, x, S, d, ids, gamma, beta, eps, ws, B);
+  hipLaunchKernelGGL(proj_f32_kernel, dim3((E + 31) / 32, (B + 31) / 32), dim3(256), 0, st, ws, proj, proj_sk, proj_se, out, B, d, E);
   if (normalize)
     hipLaunchKernelGGL(l2_normalize_inplace_f32_kernel, dim3((B + 3) / 4), dim3(256), 0, st, out, B, E, 1e-12f);
   return launch_status("pool_ln_proj");

@@ -21,8 +21,10 @@ import os
 import torch
 from torch import nn
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedCache
+
+_torch_ops.try_load()
 
 HEAD_DIM = 64  # every model on the path (CLIP B/32, B/16, L/14 and both text towers) has 64-wide heads
 
@@ -69,6 +71,21 @@ class TransformerStack(nn.Module):
         self.dim_feedforward = dim_feedforward
         self._packed = PackedCache()
 
+    def forward(self, x: torch.Tensor, B: int, S: int, causal: bool) -> torch.Tensor:
+        """Scriptable / traceable form of run(): the same kernels, called through the dispatcher ops of csrc/torch_ops.cpp
+        (`torch.ops.mmamd.*`; dtype codes 0 = fp32, 1 = bf16; act code 1 = QuickGELU).  Functional: x is not updated in place."""
+        H = self.nhead
+        for layer in self.layers:
+            hn = torch.ops.mmamd.layernorm(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, 1)
+            qkv = torch.ops.mmamd.gemm_bf16(hn, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias, None, 0, 1)
+            att = torch.ops.mmamd.attn_fwd(qkv, B, S, H, causal)
+            x = torch.ops.mmamd.gemm_bf16(att, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias, x, 0, 0)
+            hn = torch.ops.mmamd.layernorm(x, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps, 1)
+            up = torch.ops.mmamd.gemm_bf16(hn, layer.linear1.weight, layer.linear1.bias, None, 1, 1)
+            x = torch.ops.mmamd.gemm_bf16(up, layer.linear2.weight, layer.linear2.bias, x, 0, 0)
+        return x
+
+    @torch.jit.unused
     def run(self, x: torch.Tensor, B: int, S: int, causal: bool) -> torch.Tensor:
         """x: fp32 [B*S, d] residual stream (updated in place and returned)."""
         d, H = self.d_model, self.nhead

@@ -55,6 +55,7 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
         self._packed = PackedCache()
         self._conv_w_cache = None  # (ptr, version, device, packed [width, Kpad] bf16)
 
+    @torch.jit.unused
     def _conv_weight_bf16(self, kpad: int) -> Tensor:
         """conv.weight [w,3,p,p] viewed as the GEMM weight [w, 3*p*p] (K-contiguous), zero-padded to Kpad."""
         w = self.conv.weight.detach()
@@ -75,6 +76,26 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
                 f"Expected input with width and height as {self.image_size}, found {x.size(2)} by {x.size(3)} ")
         if x.size(1) != 3:
             raise ValueError(f"Expected 3 channels found {x.size(1)}")
+        if torch.jit.is_scripting():
+            return self._forward_ops(x)
+        else:
+            return self._forward_host(x)
+
+    def _forward_ops(self, x: Tensor) -> Tensor:
+        """The forward through the dispatcher ops (torch.ops.mmamd.*, csrc/torch_ops.cpp): scriptable / compilable, inference only."""
+        B = x.size(0)
+        g = self.image_size // self.patch_size
+        S = g * g + 1
+        h = torch.ops.mmamd.patch_embed(x.contiguous(), self.conv.weight, self.cls_token_embedding, self.positional_embedding,
+                                        self.ln_pre.weight, self.ln_pre.bias, self.ln_pre.eps, self.patch_size)
+        h = self.encoder(h, B, S, False)
+        return torch.ops.mmamd.pool_proj_normalize(h, B, S, None, self.ln_post.weight, self.ln_post.bias, self.ln_post.eps,
+                                                   self.projection, False, False)
+
+    @torch.jit.unused
+    def _forward_host(self, x: Tensor) -> Tensor:
+        if torch.compiler.is_compiling() and not _train.wants_grad(self, x):
+            return self._forward_ops(x)
         if _train.wants_grad(self, x):
             if x.requires_grad:
                 # the reference back-propagates into the pixels (Conv2d input gradient); the MI355X training nodes stop at the patch
@@ -93,6 +114,7 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
         # K1: patch embedding = GEMM over non-overlapping patches (conv has no bias in CLIP), fp32 result
         return self.forward_patches(ops.patchify(xc, self.patch_size, kpad))
 
+    @torch.jit.unused
     def forward_patches(self, patches: Tensor) -> Tensor:
         """Inference entry for a device-side loader (extension; transforms.clip_transform.CLIPImageTransform.patches): bf16 im2col
         rows [B*G2, Kpad] (column (c*P+py)*P+px, Kpad = 3*P*P rounded up to 64) instead of the fp32 image -- the same rows
@@ -116,6 +138,7 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
                                self.ln_post.eps, pk(self.projection, f32), proj_is_linear_weight=False)
         return out if self.projection.dtype == f32 else ops.convert(out, self.projection.dtype)
 
+    @torch.jit.unused
     def _forward_train(self, x: Tensor) -> Tensor:
         """Differentiable forward (train mode, grad enabled): the autograd nodes of models/clip/_train.py."""
         B = x.size(0)

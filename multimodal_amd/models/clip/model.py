@@ -10,7 +10,7 @@ from typing import NamedTuple
 import torch
 from torch import nn
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedModeMixin
 from ...utils.common import load_module_from_url
 from . import _train
@@ -18,6 +18,7 @@ from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
 
 
+_torch_ops.try_load()
 _SIDE_STREAMS = {}
 _PART_STREAMS = {}
 
@@ -51,8 +52,24 @@ class CLIP(PackedModeMixin, nn.Module):
         self.encoder_b = encoder_b
 
     def forward(self, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
+        if torch.jit.is_scripting():  # dispatcher ops (csrc/torch_ops.cpp); one stream, inference only
+            a = self.encoder_a(features_a)
+            b = self.encoder_b(features_b)
+            return CLIPOutput(embeddings_a=torch.ops.mmamd.l2_normalize(a.contiguous(), 1e-12),
+                              embeddings_b=torch.ops.mmamd.l2_normalize(b.contiguous(), 1e-12))
+        else:
+            return self._forward_host(features_a, features_b)
+
+    @torch.jit.unused
+    def _forward_host(self, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
+        if torch.compiler.is_compiling() and not _train.wants_grad(self, features_a, features_b):
+            a = self.encoder_a(features_a)
+            b = self.encoder_b(features_b)
+            return CLIPOutput(embeddings_a=torch.ops.mmamd.l2_normalize(a.contiguous(), 1e-12),
+                              embeddings_b=torch.ops.mmamd.l2_normalize(b.contiguous(), 1e-12))
         return self._forward(self.encoder_a, features_a, features_b)
 
+    @torch.jit.unused
     def forward_patches(self, patches_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
         """Inference entry for a device-side loader (extension): modality A arrives as the bf16 im2col rows of
         transforms.clip_transform.CLIPImageTransform.patches instead of the fp32 image (CLIPViTEncoder.forward_patches);
@@ -63,6 +80,7 @@ class CLIP(PackedModeMixin, nn.Module):
             raise ops.MmamdError(f"{type(self.encoder_a).__name__} has no forward_patches entry")
         return self._forward(self.encoder_a.forward_patches, patches_a, features_b)
 
+    @torch.jit.unused
     def _forward(self, tower_a, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
         # The two towers are independent until the normalised features meet in the loss: run tower B on a side HIP
         # stream so its small-grid kernels (77-token sequences: 150-600 workgroups per GEMM) fill the CUs that tower
@@ -105,6 +123,7 @@ class CLIP(PackedModeMixin, nn.Module):
         embeddings_b = ops.l2_normalize(embeddings_b.detach().contiguous(), eps=1e-12)
         return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
 
+    @torch.jit.unused
     def _cu_partition(self, ref):
         """(stream of tower A, stream of tower B) confined to complementary CU sets, or None.  MMAMD_CU_SPLIT = CUs per XCD given to
         tower B (0 / unset = no partition: plain side stream); MMAMD_CU_LAYOUT = interleaved | contiguous (ops.cu_partition_masks)."""
@@ -121,6 +140,7 @@ class CLIP(PackedModeMixin, nn.Module):
             _PART_STREAMS[key] = got
         return got
 
+    @torch.jit.unused
     def _side_stream(self, ref):
         import os
 

@@ -77,6 +77,28 @@ class CLIPTextEncoder(PackedModeMixin, nn.Module):
     def forward(self, text: Tensor, return_hidden_state: bool = False) -> Tensor:
         if text.size(1) != self.context_length:
             raise ValueError(f"length of input should be {self.context_length} but found {text.size(1)}")
+        if torch.jit.is_scripting():
+            return self._forward_ops(text, return_hidden_state)
+        else:
+            return self._forward_host(text, return_hidden_state)
+
+    def _forward_ops(self, text: Tensor, return_hidden_state: bool) -> Tensor:
+        """The forward through the dispatcher ops (torch.ops.mmamd.*, csrc/torch_ops.cpp): what torch.jit.script and torch.compile see
+        (reference: tests/models/clip/test_text_encoder.py:162-174 scripts this module).  Inference only."""
+        B, S = text.size(0), text.size(1)
+        ids = text.to(torch.int64).contiguous()
+        h = torch.ops.mmamd.embed_tokens(ids, self.token_embedding.weight, self.positional_embedding)
+        h = self.encoder(h, B, S, True)
+        if return_hidden_state:
+            hs = torch.ops.mmamd.layernorm(h, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps, 0)
+            return hs.view(B, S, self.width)
+        return torch.ops.mmamd.pool_proj_normalize(h, B, S, ids, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps,
+                                                   self.projection.weight, True, False)
+
+    @torch.jit.unused
+    def _forward_host(self, text: Tensor, return_hidden_state: bool = False) -> Tensor:
+        if torch.compiler.is_compiling() and not _train.wants_grad(self):
+            return self._forward_ops(text, return_hidden_state)
         f32 = torch.float32
         pk = self._packed.get
         B, S = text.shape

@@ -8,7 +8,9 @@ through its own backward launch.
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
+
+_torch_ops.try_load()
 
 
 class _ActivationFn(torch.autograd.Function):
@@ -41,4 +43,13 @@ class SiLU(nn.Module):
     coefficient = 1.702
 
     def forward(self, x: Tensor) -> Tensor:
+        if torch.jit.is_scripting():
+            return torch.ops.mmamd.activation(x.contiguous(), 1)  # 1 = MMAMD_ACT_QUICKGELU
+        else:
+            return self._forward_host(x)
+
+    @torch.jit.unused
+    def _forward_host(self, x: Tensor) -> Tensor:
+        if torch.compiler.is_compiling() and not (torch.is_grad_enabled() and x.requires_grad):
+            return torch.ops.mmamd.activation(x.contiguous(), 1)
         return _ActivationFn.apply(x, ops.ACT_QUICKGELU)

@@ -13,10 +13,13 @@ from typing import NamedTuple, Optional, Tuple, Union
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._autograd import forbid_detached_forward
 from ..._packing import PackedCache
 from ...ops import AttnMask
+
+
+_torch_ops.try_load()
 
 
 class MHAWithCacheOutput(NamedTuple):
@@ -65,6 +68,7 @@ class MultiHeadSelfAttention(nn.Module):
         self.dropout = dropout
         self._packed = PackedCache()
 
+    @torch.jit.unused
     def run(self, hn: Tensor, B: int, S: int, mask: AttnMask, residual: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
         """hn: bf16 [B*S, d] -> fp32 [B*S, d] = output_proj(attention) (+ residual)."""
         if self.training and self.dropout > 0:
@@ -83,6 +87,30 @@ class MultiHeadSelfAttention(nn.Module):
                              out_dtype=f32, out=out)
 
     def forward(self, query: Tensor, attn_mask: Optional[Tensor] = None, is_causal: bool = False) -> Tensor:
+        if torch.jit.is_scripting():
+            return self._forward_ops(query, attn_mask, is_causal)
+        else:
+            return self._forward_host(query, attn_mask, is_causal)
+
+    def _forward_ops(self, query: Tensor, attn_mask: Optional[Tensor], is_causal: bool) -> Tensor:
+        """The forward through the dispatcher ops (torch.ops.mmamd.*, csrc/torch_ops.cpp) — what torch.jit.script sees (reference:
+        tests/modules/layers/test_multi_head_attention.py:50-57 scripts this module and calls it without a mask).  64-wide heads,
+        no mask other than is_causal; everything else needs the eager forward."""
+        if attn_mask is not None:
+            raise RuntimeError("scripted MultiHeadSelfAttention on the MI355X path takes no attn_mask (use is_causal, or the eager forward)")
+        if query.dim() != 3:
+            raise RuntimeError("MultiHeadSelfAttention takes bsz x seq_len x embed_dim inputs")
+        B, S, d = query.size(0), query.size(1), query.size(2)
+        if d != 64 * self.num_heads:
+            raise RuntimeError("scripted MultiHeadSelfAttention on the MI355X path is built for 64-wide heads")
+        x = torch.ops.mmamd.convert(query.contiguous().view(B * S, d), 1)
+        qkv = torch.ops.mmamd.gemm_bf16(x, self.input_proj.weight, self.input_proj.bias, None, 0, 1)
+        att = torch.ops.mmamd.attn_fwd(qkv, B, S, self.num_heads, is_causal)
+        out = torch.ops.mmamd.gemm_bf16(att, self.output_proj.weight, self.output_proj.bias, None, 0, 0)
+        return out.view(B, S, d)
+
+    @torch.jit.unused
+    def _forward_host(self, query: Tensor, attn_mask: Optional[Tensor] = None, is_causal: bool = False) -> Tensor:
         if query.dim() != 3:
             raise ops.MmamdError("MultiHeadSelfAttention takes bsz x seq_len x embed_dim inputs")
         forbid_detached_forward(self, query)

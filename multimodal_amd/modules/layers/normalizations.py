@@ -3,10 +3,12 @@ from typing import Any
 
 from torch import nn, Tensor
 
-from ... import ops
+import torch
+
+from ... import _torch_ops, ops
 from ..._packing import PackedCache
 
-import torch
+_torch_ops.try_load()
 
 
 class Fp32LayerNorm(nn.LayerNorm):
@@ -18,8 +20,17 @@ class Fp32LayerNorm(nn.LayerNorm):
         self._packed = PackedCache()
 
     def forward(self, x: Tensor) -> Tensor:
+        if torch.jit.is_scripting():  # dispatcher op (csrc/torch_ops.cpp): the same kernel, visible to TorchScript
+            return torch.ops.mmamd.layernorm(x.contiguous(), self.weight, self.bias, self.eps, 0 if x.dtype == torch.float32 else 1)
+        else:
+            return self._forward_host(x)
+
+    @torch.jit.unused
+    def _forward_host(self, x: Tensor) -> Tensor:
         if self.weight is None or self.bias is None or len(self.normalized_shape) != 1:
             raise ops.MmamdError("Fp32LayerNorm on the MI355X path needs a 1-D affine LayerNorm")
+        if torch.compiler.is_compiling():
+            return torch.ops.mmamd.layernorm(x.contiguous(), self.weight, self.bias, self.eps, 0 if x.dtype == torch.float32 else 1)
         if torch.is_grad_enabled() and (x.requires_grad or (self.training and self.weight.requires_grad)):
             from ..._autograd import LayerNormFn  # differentiable path: forward and backward HIP kernels
 

@@ -56,6 +56,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _stream() -> int:
+    # evaluated as the LAST argument of every C-ABI call, i.e. right before it: also the place to drop a stale per-thread HIP status
+    # (include/mmamd.h: mmamd_clear_last_hip_error) that the entry point's launch check would otherwise report as its own
+    _lib.lib().mmamd_clear_last_hip_error()
     return torch.cuda.current_stream().cuda_stream
 
 

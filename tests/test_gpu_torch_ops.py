@@ -1,0 +1,102 @@
+"""The reference's scripting tests on an MI355X (row b of SURVEY.md section 8): tests/models/clip/test_text_encoder.py:162-174,
+tests/modules/layers/test_multi_head_attention.py:50-57 — a scripted module must return what the eager module returns — plus
+torch.compile of the CLIP model through the dispatcher ops of csrc/torch_ops.cpp (torch.ops.mmamd.*)."""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import assert_checksums
+from tests.conftest import set_rng_seed
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from multimodal_amd import _torch_ops, build
+
+    build.build()
+    _torch_ops.load()
+
+
+def test_scripted_text_encoder_reference_kat(golden):
+    """reference test_text_encoder.py:162-174: scripted CLIPTextEncoder(embedding_dim=4, width=512, heads=2), seed 1234, expected
+    [[-1.3103, -0.6713, -0.9614, 0.7010], [1.1780, 0.1888, 0.8019, 0.7287]] (the reference asserts atol 1e-4 for its fp32 CPU path;
+    bf16 MFMA operands here: the tolerance of the eager KAT test, 2e-2)."""
+    from multimodal_amd.models.clip import CLIPTextEncoder
+
+    z = golden("kat_text_full.npz")
+    set_rng_seed(1234)
+    _ = torch.randint(1, 10, (2, 77), dtype=torch.long)
+    enc = CLIPTextEncoder(embedding_dim=4, use_clip_init=True, context_length=77, width=512, heads=2)
+    assert_checksums(enc, z)
+    enc = enc.cuda().eval()
+    text = torch.from_numpy(z["text"]).cuda()
+    scripted = torch.jit.script(enc)
+    with torch.no_grad():
+        actual = scripted(text)
+        eager = enc(text)
+        hid_s, hid_e = scripted(text, True), enc(text, return_hidden_state=True)
+    expected = torch.tensor([[-1.3103, -0.6713, -0.9614, 0.7010], [1.1780, 0.1888, 0.8019, 0.7287]])
+    assert (actual.cpu() - expected).abs().max() < 2e-2
+    assert np.abs(actual.cpu().numpy() - z["y"]).max() < 2e-2
+    assert torch.equal(actual, eager) and torch.equal(hid_s, hid_e)  # same kernels, same arithmetic: scripted == eager, bit for bit
+    with pytest.raises((ValueError, torch.jit.Error), match="length of input should be 77"):
+        scripted(text[:, :76])
+
+
+def test_scripted_multi_head_self_attention_equals_eager():
+    """reference test_multi_head_attention.py:50-57 (there: embed_dim 4; the MI355X kernels are built for 64-wide heads)."""
+    from multimodal_amd.modules.layers.multi_head_attention import MultiHeadSelfAttention
+
+    set_rng_seed(4)
+    mha = MultiHeadSelfAttention(128, 2).cuda().eval().requires_grad_(False)
+    q = torch.randn(3, 50, 128, device="cuda")
+    scripted = torch.jit.script(mha)
+    assert torch.equal(scripted(q), mha(q))
+    assert torch.equal(scripted(q, None, True), mha(q, is_causal=True))
+    with pytest.raises(Exception, match="attn_mask"):
+        scripted(q, torch.ones(50, 50, dtype=torch.bool, device="cuda"))
+
+
+def _small_clip():
+    from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
+
+    set_rng_seed(3)
+    vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=2, patch_size=16, image_size=64, width=128)
+    txt = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=1000, width=128, dim_feedforward=256, heads=2, layers=2)
+    return CLIP(vit, txt).cuda().eval()
+
+
+def test_scripted_and_compiled_clip_equal_eager():
+    from multimodal_amd.modules.layers.activation import SiLU
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    clip = _small_clip()
+    images, ids = clip_batch(5, image_size=64, vocab_size=1000)
+    images, ids = images.cuda(), ids.cuda()
+    with torch.no_grad():
+        eager = clip(images, ids)
+        scripted = torch.jit.script(clip)(images, ids)
+        assert torch.equal(scripted.embeddings_a, eager.embeddings_a) and torch.equal(scripted.embeddings_b, eager.embeddings_b)
+        # torch.compile: dynamo traces the module into ONE graph of torch.ops.mmamd.* calls (fullgraph: no graph break, i.e. no opaque
+        # ctypes call was hit), FakeTensor propagation runs on the Meta kernels of the shim; aot_eager executes the real ops
+        compiled = torch.compile(clip, backend="aot_eager", fullgraph=True)
+        got = compiled(images, ids)
+        assert torch.equal(got.embeddings_a, eager.embeddings_a) and torch.equal(got.embeddings_b, eager.embeddings_b)
+        x = torch.randn(7, 33, device="cuda")
+        assert torch.equal(torch.jit.script(SiLU())(x), SiLU()(x))
+
+
+def test_ops_pack_parameters_and_follow_updates():
+    """`packed` keeps one kernel-ready copy per parameter and refreshes it when the parameter changes in place."""
+    ns = torch.ops.mmamd
+    w = torch.nn.Parameter(torch.randn(64, 128, device="cuda"))
+    a = torch.randn(10, 128, device="cuda").to(torch.bfloat16)
+    y0 = ns.gemm_bf16(a, w, None, None, 0, 0)
+    assert ns.packed(w, 1).data_ptr() == ns.packed(w, 1).data_ptr()  # cached
+    ref = a.float() @ w.detach().to(torch.bfloat16).float().t()
+    assert (y0 - ref).abs().max() < 1e-3 * ref.abs().max() + 1e-3
+    with torch.no_grad():
+        w.mul_(2.0)  # in-place: version counter moves
+    assert torch.equal(ns.gemm_bf16(a, w, None, None, 0, 0), 2 * y0)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Isolated timings (warm clocks) + bit-equality of GEMM kernel variants on the cfg-2 problem shapes:
+    python tools/gemm_variant_bench.py --variants 0,50,51   (0 = the default dispatch policy)"""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from tools.kernel_bench import timeit  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0,50,51,52")
+    ap.add_argument("--rounds", type=int, default=2)
+    args = ap.parse_args()
+    from multimodal_amd import build, ops
+
+    build.build()
+    variants = [int(v) for v in args.variants.split(",")]
+    g = torch.Generator().manual_seed(0)
+
+    def rnd(*shape, dtype=torch.bfloat16, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).cuda().to(dtype)
+
+    shapes = [("v.qkv", 50432, 2304, 768, ops.ACT_NONE, False), ("v.mlp_up", 50432, 3072, 768, ops.ACT_QUICKGELU, False),
+              ("v.out_proj", 50432, 768, 768, ops.ACT_NONE, True), ("v.mlp_down", 50432, 768, 3072, ops.ACT_NONE, True),
+              ("t.qkv", 19712, 1536, 512, ops.ACT_NONE, False), ("t.mlp_up", 19712, 2048, 512, ops.ACT_QUICKGELU, False),
+              ("t.out_proj", 19712, 512, 512, ops.ACT_NONE, True), ("t.mlp_down", 19712, 512, 2048, ops.ACT_NONE, True),
+              ("patch", 50176, 768, 768, ops.ACT_NONE, None)]
+    for name, M, N, K, act, res in shapes:
+        a, w, bias = rnd(M, K), rnd(N, K, scale=0.05), rnd(N, dtype=torch.float32)
+        f32out = res is not False
+        x0 = rnd(M, N, dtype=torch.float32) if res else None
+        ref = None
+        line = f"{name:10s} [{M}x{N}x{K}]"
+        for v in variants:
+            ops.set_gemm_variant(v)
+            out = torch.empty(M, N, dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")
+
+            def run():
+                ops.gemm_bf16(a, w, bias, act=act, residual=x0, out=out)  # (out != residual: no accumulation across calls)
+
+            run()
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.clone()
+                same = "ref"
+            else:
+                same = "==" if torch.equal(out, ref) else f"!= (max {float((out.float() - ref.float()).abs().max()):.3g})"
+            best = min(timeit(run, 10) for _ in range(args.rounds))
+            line += f" | v{v}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:5.0f} TF/s {same}"
+        ops.set_gemm_variant(0)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
