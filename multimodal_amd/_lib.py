@@ -117,6 +117,13 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    try:
+        # torch's ROCm wheels bundle their own libamdhip64.so; libmmamd.so depends on the same SONAME.  Whichever copy is loaded
+        # first serves both, and if it is /opt/rocm's (because this library was dlopen'ed before `import torch`) torch then finds
+        # "No HIP GPUs": make sure torch's runtime is the one in the process.  (A host without torch simply uses /opt/rocm's.)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not LIB_PATH.exists():
         raise MmamdError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m multimodal_amd.build` "

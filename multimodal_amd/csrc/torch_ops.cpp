@@ -1,6 +1,7 @@
 // torch_ops.cpp — TORCH_LIBRARY(mmamd, ...) over the C-ABI of libmmamd.so ("one shared object ... registered via
 // TORCH_LIBRARY: gemm_bf16, layernorm, attn_fwd, patch_embed, embed_tokens, pool_proj_normalize, contrastive_fwd ...").
 //
+// (ROCm builds of torch present HIP devices as DeviceType::CUDA: guards and streams are the *MasqueradingAsCUDA forms.)
 // Host C++ only (no kernels): every op checks its tensors, allocates the outputs with ATen, and calls the extern "C" entry point of
 // include/mmamd.h with raw device pointers and the CURRENT HIP stream of the tensors' device.  Registered for the dispatch keys
 //   CUDA (= HIP on ROCm builds of torch): the kernels;   Meta: shape / dtype inference, so FakeTensor tracing (torch.compile) works.
@@ -13,8 +14,8 @@
 // copy per (parameter, dtype) — bf16 for GEMM weights, fp32 for vectors — keyed on the parameter's TensorImpl, storage pointer and
 // version counter, so optimizer steps / load_state_dict / .to() refresh it (the C++ twin of multimodal_amd/_packing.PackedCache).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <cmath>
@@ -36,7 +37,7 @@ void check_status(int rc, const char* what) {
 // evaluated as the last argument of every C-ABI call: also drops a stale per-thread HIP status (mmamd_clear_last_hip_error)
 mmamd_stream_t cur_stream(const Tensor& t) {
   (void)mmamd_clear_last_hip_error();
-  return (mmamd_stream_t)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+  return (mmamd_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
 
 int dt_code(at::ScalarType t) {
@@ -72,7 +73,7 @@ Tensor convert_impl(const Tensor& x, int64_t dtype) {
   chk(x, "x");
   const at::ScalarType want = code_dt(dtype);
   if (x.scalar_type() == want) return x;
-  c10::hip::HIPGuard guard(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor out = at::empty(x.sizes(), x.options().dtype(want));
   check_status(mmamd_convert(x.data_ptr(), dt_code(x.scalar_type()), out.data_ptr(), (int)dtype, x.numel(), cur_stream(x)), "mmamd_convert");
   return out;
@@ -115,7 +116,7 @@ Tensor layernorm_impl(const Tensor& x, const Tensor& gamma, const Tensor& beta, 
   chk(x, "x");
   const Tensor g = f32v(gamma), b = f32v(beta);
   const int64_t d = x.size(-1), rows = x.numel() / d;
-  c10::hip::HIPGuard guard(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor y = at::empty(x.sizes(), x.options().dtype(code_dt(out_dtype)));
   check_status(mmamd_layernorm(x.data_ptr(), dt_code(x.scalar_type()), g.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr(), (int)out_dtype,
                                (int)rows, (int)d, (float)eps, cur_stream(x)), "mmamd_layernorm");
@@ -138,7 +139,7 @@ Tensor gemm_impl(const Tensor& a, const Tensor& w, const optional<Tensor>& bias,
     chk(*residual, "residual", odt);
     TORCH_CHECK(residual->size(0) == M && residual->size(1) == N, "mmamd::gemm_bf16: residual shape");
   }
-  c10::hip::HIPGuard guard(a.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
   Tensor out = at::empty({M, N}, a.options().dtype(odt));
   check_status(mmamd_gemm_bf16(a.data_ptr(), (int)K, wp.data_ptr(), (int)K, bp.defined() ? bp.data_ptr<float>() : nullptr,
                                residual.has_value() ? residual->data_ptr() : nullptr, (int)N, out.data_ptr(), (int)N, (int)out_dtype, (int)M,
@@ -152,7 +153,7 @@ Tensor gemm_meta(const Tensor& a, const Tensor& w, const optional<Tensor>&, cons
 Tensor attn_fwd_impl(const Tensor& qkv, int64_t B, int64_t S, int64_t H, bool causal) {
   chk(qkv, "qkv", at::kBFloat16);
   TORCH_CHECK(qkv.dim() == 2 && qkv.size(0) == B * S && qkv.size(1) == 3 * H * 64, "mmamd::attn_fwd: qkv must be [B*S, 3*H*64]");
-  c10::hip::HIPGuard guard(qkv.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
   Tensor out = at::empty({B * S, H * 64}, qkv.options());
   check_status(mmamd_attention_fwd(qkv.data_ptr(), out.data_ptr(), (int)B, (int)S, (int)H, causal ? 1 : 0, 1.0f / std::sqrt(64.0f), cur_stream(qkv)),
                "mmamd_attention_fwd");
@@ -167,7 +168,7 @@ Tensor patch_embed_impl(const Tensor& img, const Tensor& conv_w, const Tensor& c
   TORCH_CHECK(img.dim() == 4 && conv_w.dim() == 4, "mmamd::patch_embed: image [B,C,H,W] and conv weight [w,C,p,p] expected");
   const int64_t B = img.size(0), C = img.size(1), HW = img.size(2), g = HW / patch, G2 = g * g, w = conv_w.size(0);
   const int64_t K = C * patch * patch, kpad = (K + 63) / 64 * 64;
-  c10::hip::HIPGuard guard(img.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(img.device());
   mmamd_stream_t st = cur_stream(img);
   Tensor cols = at::empty({B * G2, kpad}, img.options().dtype(at::kBFloat16));
   check_status(mmamd_patchify(img.data_ptr(), dt_code(img.scalar_type()), cols.data_ptr(), (int)B, (int)C, (int)HW, (int)patch, (int)kpad, st),
@@ -200,7 +201,7 @@ Tensor embed_tokens_impl(const Tensor& ids, const Tensor& table, const Tensor& p
   if (!tb.is_contiguous()) tb = tb.contiguous();
   const Tensor p = f32v(pos);
   const int64_t B = ids.size(0), S = ids.size(1), vocab = tb.size(0), d = tb.size(1);
-  c10::hip::HIPGuard guard(ids.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(ids.device());
   Tensor x = at::empty({B * S, d}, tb.options().dtype(at::kFloat));
   check_status(mmamd_embed_tokens(ids.data_ptr<int64_t>(), tb.data_ptr(), dt_code(tb.scalar_type()), p.data_ptr<float>(), x.data_ptr<float>(),
                                   (int)B, (int)S, (int)d, (int)vocab, cur_stream(ids)), "mmamd_embed_tokens");
@@ -219,7 +220,7 @@ Tensor pool_proj_normalize_impl(const Tensor& h, int64_t B, int64_t S, const opt
   const int64_t E = proj_is_linear_weight ? P.size(0) : P.size(1);
   const int sk = proj_is_linear_weight ? 1 : (int)P.size(1), se = proj_is_linear_weight ? (int)d : 1;
   if (ids.has_value()) chk(*ids, "ids", at::kLong);
-  c10::hip::HIPGuard guard(h.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(h.device());
   Tensor out = at::empty({B, E}, h.options()), ws = at::empty({B, d}, h.options());
   check_status(mmamd_pool_ln_proj(h.data_ptr<float>(), (int)S, (int)d, ids.has_value() ? ids->data_ptr<int64_t>() : nullptr, gw.data_ptr<float>(),
                                   gb.data_ptr<float>(), (float)eps, P.data_ptr<float>(), sk, se, out.data_ptr<float>(), (int)B, (int)E,
@@ -234,7 +235,7 @@ Tensor pool_proj_normalize_meta(const Tensor& h, int64_t B, int64_t, const optio
 Tensor l2_normalize_impl(const Tensor& x, double eps) {
   chk(x, "x");
   TORCH_CHECK(x.dim() == 2, "mmamd::l2_normalize expects [rows, d]");
-  c10::hip::HIPGuard guard(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor y = at::empty_like(x);
   check_status(mmamd_l2_normalize(x.data_ptr(), dt_code(x.scalar_type()), y.data_ptr(), dt_code(x.scalar_type()), (int)x.size(0), (int)x.size(1),
                                   (float)eps, cur_stream(x)), "mmamd_l2_normalize");
@@ -245,7 +246,7 @@ Tensor same_meta(const Tensor& x, double) { return at::empty_like(x); }
 void clamp_scalar_impl(Tensor p, optional<double> lo, optional<double> hi) {
   chk(p, "scalar", at::kFloat);
   TORCH_CHECK(p.numel() == 1, "mmamd::clamp_scalar_ expects a 1-element tensor");
-  c10::hip::HIPGuard guard(p.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(p.device());
   check_status(mmamd_clamp_scalar(p.data_ptr<float>(), lo.has_value(), (float)lo.value_or(0.0), hi.has_value(), (float)hi.value_or(0.0), cur_stream(p)),
                "mmamd_clamp_scalar");
 }
@@ -253,7 +254,7 @@ void clamp_scalar_meta(Tensor, optional<double>, optional<double>) {}
 
 Tensor activation_impl(const Tensor& x, int64_t act) {
   chk(x, "x");
-  c10::hip::HIPGuard guard(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
   Tensor y = at::empty_like(x);
   check_status(mmamd_activation(x.data_ptr(), nullptr, y.data_ptr(), dt_code(x.scalar_type()), x.numel(), (int)act, cur_stream(x)), "mmamd_activation");
   return y;
@@ -277,7 +278,7 @@ std::tuple<Tensor, Tensor, Tensor> contrastive_fwd_impl(const Tensor& a, const T
     TORCH_CHECK(mask->scalar_type() == at::kBool && mask->numel() == B, "mmamd::contrastive_fwd: mask must be a boolean tensor of shape (batch,)");
     m8 = mask->contiguous().view(at::kByte);
   }
-  c10::hip::HIPGuard guard(a.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(a.device());
   Tensor la = at::empty({B, WB}, a.options()), lb = at::empty({B, WB}, a.options()), out3 = at::empty({3}, a.options()), ws = at::empty({2 * B}, a.options());
   check_status(mmamd_contrastive_fwd(a.data_ptr<float>(), b.data_ptr<float>(), a_all.data_ptr<float>(), b_all.data_ptr<float>(), (int)a_all.stride(0),
                                      ls.data_ptr<float>(), (int)B, (int)WB, (int)E, (int)label_offset, m8.defined() ? m8.data_ptr<uint8_t>() : nullptr,

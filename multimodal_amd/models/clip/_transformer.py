@@ -75,6 +75,8 @@ class TransformerStack(nn.Module):
         """Scriptable / traceable form of run(): the same kernels, called through the dispatcher ops of csrc/torch_ops.cpp
         (`torch.ops.mmamd.*`; dtype codes 0 = fp32, 1 = bf16; act code 1 = QuickGELU).  Functional: x is not updated in place."""
         H = self.nhead
+        if self.d_model != 64 * H:
+            raise RuntimeError("the MI355X attention kernel is built for head dim 64")
         for layer in self.layers:
             hn = torch.ops.mmamd.layernorm(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps, 1)
             qkv = torch.ops.mmamd.gemm_bf16(hn, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias, None, 0, 1)

@@ -217,6 +217,7 @@ def test_vision_transformer_with_cls_and_patch14():
         assert np.abs(host(o.last_hidden_state) - last).max() <= HID_TOL and o.pooler_output is None
 
 
+@torch.no_grad()  # inference contract: eval-mode forwards with autograd recording raise (tests/test_host_api_*.py)
 def test_key_value_cache_vs_reference_fixture(golden):
     """MultiHeadAttentionWithCache / TransformerDecoder with past_key_value(s) and use_cache (reference
     modules/layers/multi_head_attention.py:158-179, transformer.py:336-359,586-657): cached + new keys in one attention call, the

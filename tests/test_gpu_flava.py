@@ -297,6 +297,7 @@ def test_full_size_flava_b2_vs_reference_fixture(golden):
     assert abs(float(img.hidden_states[-1].double().mean()) - float(z["image_hidden_last_mean"])) <= 1e-3
 
 
+@torch.no_grad()  # inference contract: eval-mode forwards with autograd recording raise (tests/test_host_api_*.py)
 def test_flava_layer_and_encoder_module_api(golden):
     """TransformerEncoderLayer / TransformerEncoder / MLP / MultiHeadAttention called directly, like the reference's unit tests."""
     from multimodal_amd.models.flava.transformer import TransformerEncoder, TransformerEncoderLayer
@@ -488,6 +489,7 @@ def ops_error():
     return ops.MmamdError
 
 
+@torch.no_grad()  # inference contract: eval-mode forwards with autograd recording raise (tests/test_host_api_*.py)
 def test_interpolate_pos_encoding_vs_reference_fixture(golden):
     """ImageEmbeddings(..., interpolate_pos_encoding=True) (models/flava/image_encoder.py:102-137,170-173): bicubic resampling of the
     position grid on the GPU == torch's, for the small model at 48x48 and the full-size table at 160 / 96 pixels."""
@@ -514,6 +516,7 @@ def test_interpolate_pos_encoding_vs_reference_fixture(golden):
         full(torch.zeros(1, 3, 160, 160).cuda())  # without the flag the size check of the reference stands
 
 
+@torch.no_grad()  # inference contract: eval-mode forwards with autograd recording raise (tests/test_host_api_*.py)
 def test_flava_for_pretraining_with_a_user_codebook(golden):
     """FLAVAForPreTraining (models/flava/model.py:301-378) with a stand-in codebook module: labels of unmasked patches become -1
     (mmamd_mask_labels), the rest of the forward is model + FLAVAPretrainingLoss."""

@@ -5,7 +5,6 @@ import numpy as np
 import pytest
 import torch
 
-from tests._util import assert_checksums
 from tests.conftest import set_rng_seed
 
 pytestmark = pytest.mark.gpu
@@ -19,30 +18,37 @@ def _built():
     _torch_ops.load()
 
 
-def test_scripted_text_encoder_reference_kat(golden):
-    """reference test_text_encoder.py:162-174: scripted CLIPTextEncoder(embedding_dim=4, width=512, heads=2), seed 1234, expected
-    [[-1.3103, -0.6713, -0.9614, 0.7010], [1.1780, 0.1888, 0.8019, 0.7287]] (the reference asserts atol 1e-4 for its fp32 CPU path;
-    bf16 MFMA operands here: the tolerance of the eager KAT test, 2e-2)."""
-    from multimodal_amd.models.clip import CLIPTextEncoder
+def test_scripted_text_encoder_equals_eager_and_reference(golden):
+    """reference test_text_encoder.py:162-174 scripts CLIPTextEncoder and compares with known answers.  Its KAT model (width 512 on 2
+    heads = 256-wide heads) is outside the MI355X attention kernels (64-wide heads; the eager forward refuses it too), so the scripted
+    module is checked on the kernel-legal text tower of tests/golden/midsize.npz: bit-identical to the eager forward, and within the
+    usual tolerance of the reference's own output."""
+    from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
+    from tests._util import fixture_sd
 
-    z = golden("kat_text_full.npz")
-    set_rng_seed(1234)
-    _ = torch.randint(1, 10, (2, 77), dtype=torch.long)
-    enc = CLIPTextEncoder(embedding_dim=4, use_clip_init=True, context_length=77, width=512, heads=2)
-    assert_checksums(enc, z)
-    enc = enc.cuda().eval()
-    text = torch.from_numpy(z["text"]).cuda()
+    z = golden("midsize.npz")
+    vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=2, patch_size=16, image_size=64, width=128)
+    txt = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=1000, width=128, dim_feedforward=256, heads=2, layers=2)
+    clip = CLIP(vit, txt)
+    clip.load_state_dict({k: torch.from_numpy(v) for k, v in fixture_sd(z).items()}, strict=True)
+    enc = clip.encoder_b.cuda().eval()
+    text = torch.from_numpy(z["ids"]).cuda()
     scripted = torch.jit.script(enc)
     with torch.no_grad():
-        actual = scripted(text)
-        eager = enc(text)
+        actual, eager = scripted(text), enc(text)
         hid_s, hid_e = scripted(text, True), enc(text, return_hidden_state=True)
-    expected = torch.tensor([[-1.3103, -0.6713, -0.9614, 0.7010], [1.1780, 0.1888, 0.8019, 0.7287]])
-    assert (actual.cpu() - expected).abs().max() < 2e-2
-    assert np.abs(actual.cpu().numpy() - z["y"]).max() < 2e-2
     assert torch.equal(actual, eager) and torch.equal(hid_s, hid_e)  # same kernels, same arithmetic: scripted == eager, bit for bit
+    assert np.abs(hid_s.float().cpu().numpy() - z["text_hidden"]).max() <= 3e-2
+    nb = torch.nn.functional.normalize(actual.float().cpu(), dim=1).numpy()
+    assert np.abs(nb - z["emb_b"]).max() <= 4e-3
     with pytest.raises((ValueError, torch.jit.Error), match="length of input should be 77"):
         scripted(text[:, :76])
+    # the reference's KAT configuration itself: refused identically by both forwards (head width 256)
+    kat = CLIPTextEncoder(embedding_dim=4, use_clip_init=True, context_length=77, width=512, heads=2).cuda().eval()
+    with pytest.raises(Exception, match="64"), torch.no_grad():
+        kat(text.clamp(max=9))
+    with pytest.raises(Exception, match="64"):
+        torch.jit.script(kat)(text.clamp(max=9))
 
 
 def test_scripted_multi_head_self_attention_equals_eager():
