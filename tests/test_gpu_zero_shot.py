@@ -97,3 +97,22 @@ def test_zero_shot_pipeline_on_clip_towers():
         h1, h5 = oc.topk_hits(logits, labels.numpy(), (1, 5))
         assert abs(res["top1"] - h1 / 24) < 1e-9 and abs(res["top5"] - h5 / 24) < 1e-9
     assert 0.0 <= res["top1"] <= res["top5"] <= 1.0
+
+
+def test_reference_example_loop_and_classifier_vs_fixture(golden):
+    """The fixture holds what the REFERENCE'S OWN `_zero_shot_classifier` and `run_imagenet_zero_shot` (examples/flava/native/utils.py:
+    100-160) returned for a table-lookup stand-in of the towers (tests/golden/make_golden_zero_shot.py): same classifier, same top-1 /
+    top-5 rates — including the example's quirk of stopping after six batches."""
+    from multimodal_amd.utils import zero_shot as zs
+    from tests.golden.make_golden_zero_shot import CLASSNAMES, TEMPLATES, text_transform
+
+    z = golden("zero_shot.npz")
+    table = torch.from_numpy(z["table"]).cuda()
+    w = zs.zero_shot_classifier(lambda ids: table[ids].sum(1), text_transform, CLASSNAMES, TEMPLATES)  # stand-in tower: a gather
+    np.testing.assert_allclose(w.cpu().numpy(), z["classifier"], atol=1e-6)
+    feats, labels = torch.from_numpy(z["batch_feats"]).cuda(), torch.from_numpy(z["batch_labels"]).cuda()
+    batches = [{"image": feats[i], "label": labels[i]} for i in range(feats.shape[0])]
+    res = zs.run_zero_shot(lambda x: x, batches, w, topk=(1, 5), max_batches=6)
+    assert abs(res["top1"] - float(z["run_top1"])) < 1e-12 and abs(res["top5"] - float(z["run_top5"])) < 1e-12
+    every = zs.run_zero_shot(lambda x: x, batches, w, topk=(1, 5))
+    assert every["top1"] != res["top1"] or every["top5"] != res["top5"] or feats.shape[0] <= 6  # all 8 batches: a different denominator
