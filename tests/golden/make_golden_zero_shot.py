@@ -26,7 +26,7 @@ CLASSNAMES = ["tench", "goldfish", "great white shark", "tiger shark", "hammerhe
               "brambling"]
 TEMPLATES = [lambda c: f"a photo of a {c}.", lambda c: f"a bad photo of a {c}.", lambda c: f"a sculpture of a {c}.",
              lambda c: f"a photo of the hard to see {c}.", lambda c: f"a low resolution photo of the {c}."]
-VOCAB, L, E = 211, 12, 96
+VOCAB, L, E = 211, 48, 96
 
 
 def _mod(name, **attrs):

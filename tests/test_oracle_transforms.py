@@ -195,7 +195,7 @@ def test_staged_pipeline_equals_the_fused_forward(clip_text):
 
 
 def test_remote_merges_path_fails_loudly():
-    with pytest.raises(RuntimeError, match="no network"):
+    with pytest.raises(RuntimeError, match="cannot fetch|no network"):
         CLIPBPETokenizer()
 
 
