@@ -4,7 +4,7 @@ export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 for v in 0 50; do
   for pass in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
     tag=$(echo $pass | cut -d' ' -f1)
-    cd /tmp && timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_${v}_$tag -o p -- python $GRAFT_REPO_ROOT/tools/gemm_one.py $v 50432 2304 768 > /dev/null 2>&1
+    cd /tmp && timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_${v}_$tag -o p -- python $GRAFT_REPO_ROOT/tools/one_gemm.py 50432 2304 768 0 0 $v > /dev/null 2>&1
     f=$(find /tmp/pmc_${v}_$tag -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python3 - "$f" $v <<'PY'
 import csv, sys, collections
