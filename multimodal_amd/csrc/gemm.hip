@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
 // WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
 // SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
   constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -1783,6 +1783,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     mma(xa1, wb1);  // flush the rotated last k-step
 
     // ---------------- epilogue (LDS strips in ring buffer 1; buffer 0 is receiving the next tile) ----------------
+    // fp32 residual: a ring of RD passes of loads in flight, the first RD issued here (before the bias / barrier / first transpose).
+    // Measured (tools/gemm_variant_bench.py --variants 60,61,62,63, r02): depth 1 = 2 (out-proj 100.7 / 100.5 us), depth 3 and 4
+    // LOSE (115 / 133 us: 21 spilled registers and more loads queued per CU) -- the residual's latency is not what the fp32
+    // epilogue waits for; the default stays 1.
+    constexpr int RD = OUT_F32 ? RES_DEPTH : 1;
+    const int nw0 = n0 + wn * TN;
+    const int rrow = lane >> 3, rc = (lane & 7) * 4;  // fp32 read-back: 8 rows x 128 B per wave-instruction
+    f32x4 rq[RD][4];
+    auto res_load = [&](int pass, f32x4 (&dst)[4]) __attribute__((always_inline)) {  // pass = mi * NI + ni
+      const int mi = pass / NI, ni = pass - mi * NI;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
+        dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+      }
+    };
+    if constexpr (OUT_F32) {
+      if (p.R != nullptr) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) res_load(d, rq[d]);
+      }
+    }
     bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT, FOLD == 1>(acc, p, m0, n0, wm, wn, lane, smem + 2 * STAGE);
     if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
 #pragma unroll
@@ -1794,22 +1817,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     }
     constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
     char* strip = smem + STAGE + wave * (32 * ROWB);
-    const int nw0 = n0 + wn * TN;
     __syncthreads();  // every wave has finished reading the last K-tile out of ring buffer 1
     if constexpr (OUT_F32) {
       const bool has_res = p.R != nullptr;
-      const int rrow = lane >> 3, rc = (lane & 7) * 4;  // read-back: 8 rows x 128 B per wave-instruction
-      f32x4 rr[4], rn[4];
-      auto res_load = [&](int pass, f32x4 (&dst)[4]) {  // pass = mi * NI + ni
-        const int mi = pass / NI, ni = pass - mi * NI;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
-          dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
-        }
-      };
-      if (has_res) res_load(0, rr);
       float fs1[4], fs2[4];  // LN fold (producer): row partials of the 4 rows this lane touches per pass, over the wave's TN columns
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -1833,7 +1843,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
           f32x4 vv[4];
 #pragma unroll
           for (int it = 0; it < 4; ++it) vv[it] = *reinterpret_cast<const f32x4*>(strip + (it * 8 + rrow) * ROWB + rc * 4);
-          if (has_res && pass + 1 < MI * NI) res_load(pass + 1, rn);
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
@@ -1842,7 +1851,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
             if (ok) {
               if (has_res) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += rr[it][j];
+                for (int j = 0; j < 4; ++j) v[j] += rq[pass % RD][it][j];
               }
               store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
             }
@@ -1855,8 +1864,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
               }
             }
           }
-#pragma unroll
-          for (int it = 0; it < 4; ++it) rr[it] = rn[it];
+          if (has_res && pass + RD < MI * NI) res_load(pass + RD, rq[pass % RD]);  // refill the slot this pass just consumed
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else {
@@ -1909,8 +1917,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   }
 }
 
+#ifdef MMAMD_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------
-// "W" kernel: TWO workgroups per CU.  The lock-step kernels above stop the matrix pipe for the whole per-tile epilogue (22-55 % of a
+// "W" kernel (experiment, r02: correct, bit-equal to the production kernels, and SLOWER -- qkv 200 vs 160 us, MLP-up 277 vs 252,
+// MLP-down 316 vs 270; PMC profiles/r02_pmc_gemm_w.txt: MFMA pipe 41 % busy vs 53 %, 57 % of wave cycles in issue stalls;
+// six DMA pieces per 16 MFMAs per wave against eight per 32 in the 8-wave kernels): TWO workgroups per CU.  The lock-step kernels above stop the matrix pipe for the whole per-tile epilogue (22-55 % of a
 // tile's time at K = 768: bias / activation VALU, the LDS transpose, the stores) because all eight waves of the CU's one workgroup are
 // in it together.  Here a workgroup is 4 waves (one per SIMD) on a 256 x 128 tile (2 x 2 waves of 128 x 64, the same wave tile and
 // fragment traffic as above) with a 3-stage BK = 32 LDS-DMA ring (72 KiB), so two workgroups are resident per CU with independent
@@ -2063,6 +2074,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel_w(const GemmArgs p
   gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
 }
 
+#endif  // MMAMD_EXPERIMENTS
+
 // plain one-thread-per-output kernel: on-device cross-check for the MFMA kernels (tests / debugging)
 template <bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmArgs p) {
@@ -2150,12 +2163,12 @@ static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
 
 #endif  // MMAMD_EXPERIMENTS
 
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true, FOLD>(p, st);
   constexpr int smem = 2 * 512 * 128 + (FOLD == 1 ? 256 * 16 * 8 : 0);  // + the tile's row statistics (nslot <= 16: K <= 1024)
   if (FOLD == 1 && p.nslot_in > 16) return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, GM, 0, true, FOLD>(p, st);
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD>;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD, RES_DEPTH>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
@@ -2167,6 +2180,7 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_pp");
 }
 
+#ifdef MMAMD_EXPERIMENTS
 template <bool OUT_F32, int ACT, int GM, int SCH = 0>
 static int launch_tiled_w(GemmArgs& p, hipStream_t st) {
   constexpr int smem = 3 * (256 + 128) * 64;
@@ -2178,6 +2192,8 @@ static int launch_tiled_w(GemmArgs& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), smem, st, p, tiles_m);
   return launch_status("gemm_bf16_w");
 }
+
+#endif  // MMAMD_EXPERIMENTS
 
 template <bool OUT_F32, int ACT, int FOLD = 0>
 static int dispatch_variant(GemmArgs& p, hipStream_t st) {
@@ -2248,9 +2264,15 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       // bf16 C tiles are stored non-temporal (measured +6-7 % on the qkv / MLP-up GEMMs: the 128 KiB a block writes per
       // tile no longer competes with the operand panels for the XCD's L2); the in-place fp32 residual update stays plain
       case 18: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(p, st);
+#ifdef MMAMD_EXPERIMENTS
+      case 60: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 1>(p, st);  // fp32 residual prefetch ring depth 1 .. 4
+      case 61: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 2>(p, st);
+      case 62: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 3>(p, st);
+      case 63: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 4>(p, st);
       case 50: return launch_tiled_w<OUT_F32, ACT, 8>(p, st);   // two workgroups per CU, 256 x 128 tiles, BK = 32 ring of 3
       case 51: return launch_tiled_w<OUT_F32, ACT, 8, 1>(p, st);
       case 52: return launch_tiled_w<OUT_F32, ACT, 8, 2>(p, st);
+#endif
 #ifdef MMAMD_EXPERIMENTS
       case 20: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 1>(p, st);  // C stores sc1 (write-through, not kept in L2)
       case 21: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 2>(p, st);  // C stores nt
