@@ -253,6 +253,10 @@ int mmamd_pool_ln_proj(const float* x, int S, int d, const int64_t* ids, const f
 /* F.normalize(x, p=2, dim=1, eps) on [rows,d]  (models/clip/model.py:72-73). */
 int mmamd_l2_normalize(const void* x, int x_dtype, void* y, int y_dtype, int rows, int d, float eps,
                        mmamd_stream_t stream);
+/* Same with an output row stride ldy >= d (elements): CLIP.forward normalises both towers straight into the two halves of the packed
+ * [B, 2E] block the loss all-gathers (modules/losses/contrastive_loss_with_temperature.py:35-36: gather of a, gather of b). */
+int mmamd_l2_normalize_ld(const void* x, int x_dtype, void* y, int y_dtype, int ldy, int rows, int d, float eps,
+                          mmamd_stream_t stream);
 
 /* --- K13: in-place clamp of the 0-dim logit_scale parameter ----------------------------------
  * (modules/losses/contrastive_loss_with_temperature.py:193). */
@@ -270,6 +274,13 @@ int mmamd_contrastive_fwd(const float* a, const float* b, const float* a_all, co
                           int label_offset, const uint8_t* row_mask, float label_smoothing,
                           int reduction, float* logits_a, float* logits_b, float* out3, float* ws,
                           mmamd_stream_t stream);
+
+/* Same with a row stride for the LOCAL features (ld_local >= E): a / b may be the two halves of the packed [B, 2E] block that
+ * CLIP.forward normalised into and the all-gather sent (no unpacking copies anywhere between the towers and the loss). */
+int mmamd_contrastive_fwd_ld(const float* a, const float* b, int ld_local, const float* a_all, const float* b_all, int ld_all,
+                             const float* logit_scale, int B, int WB, int E, int label_offset, const uint8_t* row_mask,
+                             float label_smoothing, int reduction, float* logits_a, float* logits_b, float* out3, float* ws,
+                             mmamd_stream_t stream);
 
 /* --- backward of the contrastive loss (autograd of modules/losses/contrastive_loss_with_temperature.py:81-107; the
  * reference relies on torch autograd through matmul / cross_entropy / exp and, for BackpropType.GLOBAL, on the all-gather's

@@ -91,10 +91,15 @@ PROTOTYPES = {
     "mmamd_embed_tokens": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_pool_ln_proj": (_i, [_vp, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mmamd_l2_normalize": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp]),
+    "mmamd_l2_normalize_ld": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_clamp_scalar": (_i, [_vp, _i, _f, _i, _f, _vp]),
     "mmamd_contrastive_fwd": (
         _i,
         [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "mmamd_contrastive_fwd_ld": (
+        _i,
+        [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
     ),
     "mmamd_convert": (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     "mmamd_timer_create": (_vp, []),

@@ -14,10 +14,10 @@ namespace mmamd {
 __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                      const float* __restrict__ a_all, const float* __restrict__ b_all,
                                                      int ld_all, const float* __restrict__ logit_scale, int B, int WB,
-                                                     int E, float* __restrict__ logits_a, float* __restrict__ logits_b) {
+                                                     int E, float* __restrict__ logits_a, float* __restrict__ logits_b, int ld_loc) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int dir = blockIdx.z;
-  const float* L = dir == 0 ? a : b;          // [B,E], row stride E
+  const float* L = dir == 0 ? a : b;          // [B,E], row stride ld_loc (E, or 2E when a / b are halves of the packed block)
   const float* R = dir == 0 ? b_all : a_all;  // [WB,E], row stride ld_all
   float* out = dir == 0 ? logits_a : logits_b;
   const int i0 = blockIdx.y * 32;
@@ -26,9 +26,9 @@ __global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ a
   const int half = lane >> 5;
   int ri = i0 + (lane & 31); ri = ri < B ? ri : B - 1;
   int rj = j0 + (lane & 31); rj = rj < WB ? rj : WB - 1;
-  const float* lp = L + (size_t)ri * E;
+  const float* lp = L + (size_t)ri * ld_loc;
   const float* rp = R + (size_t)rj * ld_all;
-  const bool vec = ((E & 3) == 0) && ((ld_all & 3) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) &&
+  const bool vec = ((E & 3) == 0) && ((ld_all & 3) == 0) && ((ld_loc & 3) == 0) && ((reinterpret_cast<uintptr_t>(L) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(R) & 15) == 0);
   f32x16 acc;
 #pragma unroll
@@ -365,17 +365,25 @@ extern "C" int mmamd_contrastive_fwd(const float* a, const float* b, const float
                                      int ld_all, const float* logit_scale, int B, int WB, int E, int label_offset,
                                      const uint8_t* row_mask, float label_smoothing, int reduction, float* logits_a,
                                      float* logits_b, float* out3, float* ws, mmamd_stream_t stream) {
+  return mmamd_contrastive_fwd_ld(a, b, E, a_all, b_all, ld_all, logit_scale, B, WB, E, label_offset, row_mask, label_smoothing, reduction,
+                                  logits_a, logits_b, out3, ws, stream);
+}
+
+extern "C" int mmamd_contrastive_fwd_ld(const float* a, const float* b, int ld_local, const float* a_all, const float* b_all,
+                                        int ld_all, const float* logit_scale, int B, int WB, int E, int label_offset,
+                                        const uint8_t* row_mask, float label_smoothing, int reduction, float* logits_a,
+                                        float* logits_b, float* out3, float* ws, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(a && b && a_all && b_all && logit_scale && logits_a && logits_b && out3 && ws, MMAMD_E_BADARG,
                   "contrastive_fwd: null pointer");
-  MMAMD_CHECK_ARG(B > 0 && WB >= B && E > 0 && ld_all >= E, MMAMD_E_BADARG,
-                  "contrastive_fwd: bad sizes B=%d WB=%d E=%d ld_all=%d", B, WB, E, ld_all);
+  MMAMD_CHECK_ARG(B > 0 && WB >= B && E > 0 && ld_all >= E && ld_local >= E, MMAMD_E_BADARG,
+                  "contrastive_fwd: bad sizes B=%d WB=%d E=%d ld_all=%d ld_local=%d", B, WB, E, ld_all, ld_local);
   MMAMD_CHECK_ARG(label_offset >= 0 && label_offset + B <= WB, MMAMD_E_BADARG,
                   "contrastive_fwd: labels %d..%d outside [0,%d)", label_offset, label_offset + B, WB);
   MMAMD_CHECK_ARG(reduction == MMAMD_REDUCE_MEAN || reduction == MMAMD_REDUCE_SUM, MMAMD_E_UNSUPPORTED,
                   "contrastive_fwd: reduction must be mean or sum");
   hipStream_t st = (hipStream_t)stream;
   const dim3 g1((WB + 127) / 128, (B + 31) / 32, 2);
-  hipLaunchKernelGGL(logits_kernel, g1, dim3(256), 0, st, a, b, a_all, b_all, ld_all, logit_scale, B, WB, E, logits_a, logits_b);
+  hipLaunchKernelGGL(logits_kernel, g1, dim3(256), 0, st, a, b, a_all, b_all, ld_all, logit_scale, B, WB, E, logits_a, logits_b, ld_local);
   hipLaunchKernelGGL(ce_rows_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, st, logits_a, logits_b, B, WB, label_offset,
                      row_mask, label_smoothing, ws);
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, st, ws, B, row_mask, reduction, out3);

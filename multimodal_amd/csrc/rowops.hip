@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void coca_text_mask_kernel(const void* __restr
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void l2_normalize_kernel(const TI* __restrict__ x, TO* __restrict__ y,
-                                                           int rows, int d, float eps) {
+                                                           int rows, int d, float eps, int ldy) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const TI* __restrict_
   float ss = 0.f;
   for (int k = lane; k < d; k += 64) { const float v = to_f32(xr[k]); ss += v * v; }
   const float sc = 1.0f / fmaxf(sqrtf(wave_sum(ss)), eps);
-  TO* yr = y + (size_t)row * d;
+  TO* yr = y + (size_t)row * ldy;  // ldy > d: the rows land in one half of the packed [B, 2E] gather block
   for (int k = lane; k < d; k += 64) yr[k] = (TO)(to_f32(xr[k]) * sc);
 }
 
@@ -833,23 +833,28 @@ extern "C" int mmamd_pool_ln_proj(const float* x, int S, int d, const int64_t* i
   return launch_status("pool_ln_proj");
 }
 
-extern "C" int mmamd_l2_normalize(const void* x, int x_dtype, void* y, int y_dtype, int rows, int d, float eps,
-                                  mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(x && y && rows >= 0 && d > 0, MMAMD_E_BADARG, "l2_normalize: bad argument");
+extern "C" int mmamd_l2_normalize_ld(const void* x, int x_dtype, void* y, int y_dtype, int ldy, int rows, int d, float eps,
+                                     mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && y && rows >= 0 && d > 0 && ldy >= d, MMAMD_E_BADARG, "l2_normalize: bad argument");
   if (rows == 0) return 0;
   const dim3 grid((rows + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_F32)
-    hipLaunchKernelGGL((l2_normalize_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)y, rows, d, eps);
+    hipLaunchKernelGGL((l2_normalize_kernel<float, float>), grid, block, 0, st, (const float*)x, (float*)y, rows, d, eps, ldy);
   else if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_BF16)
-    hipLaunchKernelGGL((l2_normalize_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)x, (bf16*)y, rows, d, eps);
+    hipLaunchKernelGGL((l2_normalize_kernel<bf16, bf16>), grid, block, 0, st, (const bf16*)x, (bf16*)y, rows, d, eps, ldy);
   else if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_F32)
-    hipLaunchKernelGGL((l2_normalize_kernel<bf16, float>), grid, block, 0, st, (const bf16*)x, (float*)y, rows, d, eps);
+    hipLaunchKernelGGL((l2_normalize_kernel<bf16, float>), grid, block, 0, st, (const bf16*)x, (float*)y, rows, d, eps, ldy);
   else if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_BF16)
-    hipLaunchKernelGGL((l2_normalize_kernel<float, bf16>), grid, block, 0, st, (const float*)x, (bf16*)y, rows, d, eps);
+    hipLaunchKernelGGL((l2_normalize_kernel<float, bf16>), grid, block, 0, st, (const float*)x, (bf16*)y, rows, d, eps, ldy);
   else
     MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "l2_normalize: bad dtype code");
   return launch_status("l2_normalize");
+}
+
+extern "C" int mmamd_l2_normalize(const void* x, int x_dtype, void* y, int y_dtype, int rows, int d, float eps,
+                                  mmamd_stream_t stream) {
+  return mmamd_l2_normalize_ld(x, x_dtype, y, y_dtype, d, rows, d, eps, stream);
 }
 
 extern "C" int mmamd_clamp_scalar(float* p, int has_min, float lo, int has_max, float hi, mmamd_stream_t stream) {

@@ -119,9 +119,15 @@ class CLIP(PackedModeMixin, nn.Module):
             embeddings_a = tower_a(features_a)
             main.wait_stream(side)
             embeddings_b.record_stream(main)
-        embeddings_a = ops.l2_normalize(embeddings_a.detach().contiguous(), eps=1e-12)
-        embeddings_b = ops.l2_normalize(embeddings_b.detach().contiguous(), eps=1e-12)
-        return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
+        ea, eb = embeddings_a.detach().contiguous(), embeddings_b.detach().contiguous()
+        if ea.dim() == 2 and ea.shape == eb.shape and ea.dtype == eb.dtype:
+            # both outputs are views of ONE [B, 2E] block = the message of the loss's packed all-gather
+            # (utils.distributed.gather_packed_features recognises the layout and gathers it without packing copies)
+            E = ea.shape[1]
+            packed = torch.empty((ea.shape[0], 2 * E), dtype=ea.dtype, device=ea.device)
+            return CLIPOutput(embeddings_a=ops.l2_normalize(ea, eps=1e-12, out=packed[:, :E]),
+                              embeddings_b=ops.l2_normalize(eb, eps=1e-12, out=packed[:, E:]))
+        return CLIPOutput(embeddings_a=ops.l2_normalize(ea, eps=1e-12), embeddings_b=ops.l2_normalize(eb, eps=1e-12))
 
     @torch.jit.unused
     def _cu_partition(self, ref):

@@ -31,8 +31,10 @@ class ContrastiveLossOutput(OrderedDict):
 _SUPPORTED_CE_KWARGS = {"label_smoothing", "reduction"}
 
 
-def _as_f32(t: Tensor) -> Tensor:
+def _as_f32(t: Tensor, keep_row_stride: bool = False) -> Tensor:
     t = t.detach()
+    if keep_row_stride and t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t  # a half of CLIP.forward's packed [B, 2E] block: read in place (row stride 2E), gathered without packing copies
     t = t if t.is_contiguous() else t.contiguous()
     return t if t.dtype == torch.float32 else ops.convert(t, torch.float32)
 
@@ -76,7 +78,8 @@ def contrastive_loss_with_temperature(
     if needs_grad:
         out3, logits_a, logits_b = _ContrastiveFn.apply(embeddings_a, embeddings_b, logit_scale, mask, backprop_type, smoothing, red_code)
     else:
-        out3, logits_a, logits_b, _ = _contrastive_forward(embeddings_a, embeddings_b, logit_scale, mask, smoothing, red_code)
+        out3, logits_a, logits_b, _ = _contrastive_forward(embeddings_a, embeddings_b, logit_scale, mask, smoothing, red_code,
+                                                           for_backward=False)
     if mask is not None:  # reference …:97-100 returns only the kept rows (data-dependent shape)
         logits_a, logits_b = logits_a[mask], logits_b[mask]
     out_dtype = embeddings_a.dtype
@@ -87,10 +90,12 @@ def contrastive_loss_with_temperature(
 
 
 def _contrastive_forward(embeddings_a: Tensor, embeddings_b: Tensor, logit_scale: Tensor, mask: Optional[Tensor], smoothing: float,
-                         red_code: int):
+                         red_code: int, for_backward: bool = True):
     """gather + logits + cross entropy.  Returns (out3, logits_a, logits_b, saved-for-backward tuple)."""
-    a = _as_f32(embeddings_a)
-    b = _as_f32(embeddings_b)
+    a = _as_f32(embeddings_a, keep_row_stride=not for_backward)  # (the backward kernels take contiguous local features)
+    b = _as_f32(embeddings_b, keep_row_stride=not for_backward)
+    if a.stride(0) != b.stride(0):
+        a, b = a.contiguous(), b.contiguous()
     B, E = a.shape
     buf, rank, world = gather_packed_features(a, b)  # [W*B, 2E]; W=1 without a process group
     a_all, b_all = buf[:, :E], buf[:, E:]

@@ -721,13 +721,17 @@ def pool_ln_proj(x: torch.Tensor, B: int, S: int, ids: Optional[torch.Tensor], g
     return out
 
 
-def l2_normalize(x: torch.Tensor, eps: float = 1e-12, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.normalize(x, dim=1).  `out` may be a [rows, d] column slice of a wider row-major buffer (unit inner stride)."""
     _chk(x, "x")
     if x.dim() != 2:
         raise MmamdError("l2_normalize expects a [rows, d] tensor")
-    out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
-    check(_lib.lib().mmamd_l2_normalize(x.data_ptr(), _dt(x), out.data_ptr(), _dt(out), x.shape[0], x.shape[1],
-                                        float(eps), _stream()), "mmamd_l2_normalize")
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    elif not (out.is_cuda and out.shape == x.shape and out.stride(1) == 1 and out.stride(0) >= x.shape[1]):
+        raise MmamdError("l2_normalize: out must be a [rows, d] HIP view with unit inner stride")
+    check(_lib.lib().mmamd_l2_normalize_ld(x.data_ptr(), _dt(x), out.data_ptr(), _dt(out), out.stride(0), x.shape[0], x.shape[1],
+                                           float(eps), _stream()), "mmamd_l2_normalize_ld")
     return out
 
 
@@ -744,10 +748,12 @@ def contrastive_fwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
                     label_smoothing: float = 0.0, reduction: int = _lib.REDUCE_MEAN
                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Returns (out3 = [loss, loss_a, loss_b], logits_a [B,WB], logits_b [B,WB]), all fp32."""
-    _chk(a, "a", torch.float32); _chk(b, "b", torch.float32); _chk(logit_scale, "logit_scale", torch.float32)
-    for n, t in (("a_all", a_all), ("b_all", b_all)):
-        if not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
-            raise MmamdError(f"{n} must be an fp32 HIP tensor with unit inner stride")
+    _chk(logit_scale, "logit_scale", torch.float32)
+    for n, t in (("a", a), ("b", b), ("a_all", a_all), ("b_all", b_all)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(-1) == 1):
+            raise MmamdError(f"{n} must be a 2-D fp32 HIP tensor with unit inner stride")
+    if a.shape != b.shape or a.stride(0) != b.stride(0) or a.device.index != torch.cuda.current_device():
+        raise MmamdError("contrastive_fwd: a and b must have the same shape / row stride and live on the current device")
     B, E = a.shape
     WB = a_all.shape[0]
     if row_mask is not None:
@@ -757,11 +763,11 @@ def contrastive_fwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
     logits_b = torch.empty((B, WB), dtype=torch.float32, device=dev)
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     ws = torch.empty(2 * B, dtype=torch.float32, device=dev)
-    check(_lib.lib().mmamd_contrastive_fwd(a.data_ptr(), b.data_ptr(), a_all.data_ptr(), b_all.data_ptr(), int(ld_all),
-                                           logit_scale.data_ptr(), B, WB, E, int(label_offset), _ptr(row_mask),
-                                           float(label_smoothing), int(reduction), logits_a.data_ptr(),
-                                           logits_b.data_ptr(), out3.data_ptr(), ws.data_ptr(), _stream()),
-          "mmamd_contrastive_fwd")
+    check(_lib.lib().mmamd_contrastive_fwd_ld(a.data_ptr(), b.data_ptr(), a.stride(0), a_all.data_ptr(), b_all.data_ptr(), int(ld_all),
+                                              logit_scale.data_ptr(), B, WB, E, int(label_offset), _ptr(row_mask),
+                                              float(label_smoothing), int(reduction), logits_a.data_ptr(),
+                                              logits_b.data_ptr(), out3.data_ptr(), ws.data_ptr(), _stream()),
+          "mmamd_contrastive_fwd_ld")
     return out3, logits_a, logits_b
 
 

@@ -72,9 +72,15 @@ def gather_packed_features(a: Tensor, b: Tensor) -> Tuple[Tensor, int, int]:
     if a.shape != b.shape or a.dim() != 2:
         raise ValueError(f"expected two [B,E] tensors of equal shape, got {tuple(a.shape)} and {tuple(b.shape)}")
     B, E = a.shape
-    packed = torch.empty((B, 2 * E), dtype=a.dtype, device=a.device)
-    packed[:, :E].copy_(a)  # device memcpy: packing the message, not compute
-    packed[:, E:].copy_(b)
+    if (a.dtype == b.dtype and a.device == b.device and a.stride() == (2 * E, 1) and b.stride() == (2 * E, 1)
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and b.storage_offset() == a.storage_offset() + E
+            and a.untyped_storage().nbytes() >= (a.storage_offset() + B * 2 * E) * a.element_size()):
+        # a and b already ARE the two halves of one packed [B, 2E] block (CLIP.forward normalises straight into it): no packing copies
+        packed = a.as_strided((B, 2 * E), (2 * E, 1), a.storage_offset())
+    else:
+        packed = torch.empty((B, 2 * E), dtype=a.dtype, device=a.device)
+        packed[:, :E].copy_(a)  # device memcpy: packing the message, not compute
+        packed[:, E:].copy_(b)
     if not _dist_ready():
         return packed, 0, 1
     world = torch.distributed.get_world_size()

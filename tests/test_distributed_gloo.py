@@ -87,3 +87,19 @@ def test_packed_gather_without_process_group():
     assert (r, w) == (0, 1) and torch.equal(buf[:, :4], a) and torch.equal(buf[:, 4:], b)
     with pytest.raises(ValueError):
         gather_packed_features(a, torch.randn(2, 4))
+
+
+def test_packed_gather_recognises_the_two_halves_of_one_block():
+    """CLIP.forward normalises both towers into ONE [B, 2E] buffer and returns its halves: the gather must send that buffer as is (same
+    storage, no packing copies) and anything else through the packing path."""
+    from multimodal_amd.utils.distributed import gather_packed_features
+
+    block = torch.randn(5, 12)
+    a, b = block[:, :6], block[:, 6:]
+    buf, r, w = gather_packed_features(a, b)
+    assert (r, w) == (0, 1) and buf.data_ptr() == block.data_ptr() and torch.equal(buf, block)
+    buf2, _, _ = gather_packed_features(b, a)  # swapped halves are NOT the packed layout: copied into the right order
+    assert buf2.data_ptr() != block.data_ptr() and torch.equal(buf2[:, :6], b) and torch.equal(buf2[:, 6:], a)
+    wide = torch.randn(5, 20)
+    buf3, _, _ = gather_packed_features(wide[:, :6], wide[:, 6:12])  # row stride 20 != 2E
+    assert buf3.shape == (5, 12) and torch.equal(buf3[:, 6:], wide[:, 6:12])
