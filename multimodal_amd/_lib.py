@@ -29,6 +29,7 @@ PROTOTYPES = {
     "mmamd_clear_last_hip_error": (_i, []),
     "mmamd_set_gemm_variant": (_i, [_i]),
     "mmamd_get_gemm_variant": (_i, []),
+    "mmamd_debug_set_gemm_stagger": (_i, [_i]),
     "mmamd_debug_set_gemm_trace": (_i, [_vp]),
     "mmamd_debug_set_attn_variant": (_i, [_i]),
     "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

@@ -77,6 +77,9 @@ struct GemmArgs {
   int nslot_in = 0;
   const float* c1 = nullptr;     // [N] row sums of the gamma-scaled bf16 weight
   float inv_d = 0.f, ln_eps = 0.f;
+  // persistent kernel: workgroups that walk one tile fewer than the others (the last round of tiles is partial) start up to `stagger`
+  // clock ticks late, spread evenly, so that the CUs stop draining their C tiles in lock-step (0 = off)
+  int stagger = 0;
 };
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
@@ -145,9 +148,11 @@ __device__ __forceinline__ void store_act_copy(const GemmArgs& p, uint4 v, int m
 // (tools/ln_fold_numerics.py); var = E[x^2] - mu^2 in fp32.  Parity at the headline size: tests/test_gpu_headline_parity.py.
 // ---------------------------------------------------------------------------------------------------------
 // st_lds (FOLD == 1, persistent kernel): the statistics of the tile's rows, [BM][nslot][2] floats, DMA'd into LDS during the K loop
+// bias_lds (persistent kernel, FOLD == 0): the tile's 256 bias values, DMA'd into LDS during the K loop (the eight 16-byte global loads
+// per lane at the head of the epilogue were an exposed L2 round trip per tile)
 template <int MI, int NI, int TM, int TN, int FOLD, int ACT, bool STLDS = false>
 __device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn, int lane,
-                                               const char* st_lds = nullptr) {
+                                               const char* st_lds = nullptr, const char* bias_lds = nullptr) {
   const int l31 = lane & 31, half = lane >> 5;
   if constexpr (FOLD == 1) {
     // the 128 accumulators leave ~100 VGPRs to this code: statistics first (2 * MI live values), then one column group at a time with
@@ -210,7 +215,8 @@ __device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const Gemm
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) bv = load4(p.bias + n);
+        if (bias_lds != nullptr) bv = *reinterpret_cast<const f32x4*>(bias_lds + (wn * TN + ni * 32 + 4 * half + 8 * g) * 4);  // block-uniform
+        else if (n + 3 < p.N) bv = load4(p.bias + n);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -234,6 +240,9 @@ __device__ __forceinline__ void lnfold_butterfly8(float& a, float& b) {  // part
 }
 
 static int g_gemm_variant = 0;
+// per cent of a tile time; measured (tools/gemm_variant_bench.py --staggers 0,30,60,90,120, profiles/r02_gemm_stagger.txt): 60 is the best or
+// within 1 % of it on every shape whose last round of tiles is partial (ViT MLP-up -3.6 %, out-proj -8 %, text MLP-up -10.6 %, patch -7.6 %)
+static int g_gemm_stagger = 60;
 static unsigned long long* g_gemm_trace = nullptr;
 
 // Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
@@ -1586,7 +1595,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
 // WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
 // SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
   constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -1726,6 +1735,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   tile_offsets(tm, tn, a_off, b_off);
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) issue_piece(0, 0, i);
+  if (p.stagger > 0) {
+    const int heavy = ntiles % (int)gridDim.x;  // workgroups 0 .. heavy-1 walk one tile more: they start at once
+    if (heavy > 0 && (int)blockIdx.x >= heavy) {
+      const long long delay = (long long)p.stagger * ((int)blockIdx.x - heavy + 1) / ((int)gridDim.x - heavy);
+      const long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
+    }
+  }
 
   while (true) {
     const int m0 = tm * BM, n0 = tn * BN;
@@ -1769,6 +1786,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
           }
         }
       }
+      if constexpr (BLDS && FOLD != 1) {
+        // the tile's 256 bias values (1 KiB = one DMA piece, issued by wave 0) land in LDS behind the ring while the K loop runs;
+        // same hazards as the statistics above: issued after the tile's first barrier, waited for by the next sync_tile
+        if (kt == 0 && wave == 0 && p.bias != nullptr) {
+          const uint32_t limit = (uint32_t)(p.N - n0) * 4u - 16u;
+          uint32_t off = lane * 16u;
+          off = off < limit ? off : limit;  // columns past N (never stored) re-read the last valid 16 bytes
+          dma_piece_s(reinterpret_cast<const char*>(p.bias) + (size_t)n0 * 4u, off, lds0 + 2 * STAGE);
+        }
+      }
       tile_body(B0{}, kt + 1, true);
       const bool last = kt + 2 >= KT;
       if (last && more) {  // this tile's loads are all issued: switch the DMA source to the next tile's first K-tile
@@ -1806,7 +1833,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
         for (int d = 0; d < RD; ++d) res_load(d, rq[d]);
       }
     }
-    bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT, FOLD == 1>(acc, p, m0, n0, wm, wn, lane, smem + 2 * STAGE);
+    bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT, FOLD == 1>(acc, p, m0, n0, wm, wn, lane, smem + 2 * STAGE,
+                                                         (BLDS && FOLD != 1) ? smem + 2 * STAGE : nullptr);
     if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -2163,12 +2191,12 @@ static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
 
 #endif  // MMAMD_EXPERIMENTS
 
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true, FOLD>(p, st);
-  constexpr int smem = 2 * 512 * 128 + (FOLD == 1 ? 256 * 16 * 8 : 0);  // + the tile's row statistics (nslot <= 16: K <= 1024)
+  constexpr int smem = 2 * 512 * 128 + (FOLD == 1 ? 256 * 16 * 8 : (BLDS ? 1024 : 0));  // + the tile's row statistics (nslot <= 16: K <= 1024) / bias
   if (FOLD == 1 && p.nslot_in > 16) return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, GM, 0, true, FOLD>(p, st);
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD, RES_DEPTH>;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD, RES_DEPTH, BLDS>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
@@ -2264,6 +2292,7 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       // bf16 C tiles are stored non-temporal (measured +6-7 % on the qkv / MLP-up GEMMs: the 128 KiB a block writes per
       // tile no longer competes with the operand panels for the XCD's L2); the in-place fp32 residual update stays plain
       case 18: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(p, st);
+      case 70: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 1, true>(p, st);  // bias through LDS (DMA'd during the K loop)
 #ifdef MMAMD_EXPERIMENTS
       case 60: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 1>(p, st);  // fp32 residual prefetch ring depth 1 .. 4
       case 61: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 2>(p, st);
@@ -2354,6 +2383,10 @@ extern "C" int mmamd_set_gemm_variant(int variant) {
   return 0;
 }
 extern "C" int mmamd_get_gemm_variant(void) { return g_gemm_variant; }
+extern "C" int mmamd_debug_set_gemm_stagger(int percent) {
+  g_gemm_stagger = percent < 0 ? 0 : percent;
+  return 0;
+}
 
 extern "C" int mmamd_debug_set_gemm_trace(void* buf) {
   g_gemm_trace = reinterpret_cast<unsigned long long*>(buf);
@@ -2426,6 +2459,13 @@ static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.act = act; p.tiles_n = 0;
   p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0;
   p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.split_flat = 0;
+  {
+    // start-up stagger of the persistent kernel as a fraction (g_gemm_stagger, per cent) of the estimated tile time in shader ticks:
+    // ~3500 ticks per 64-deep K-tile + the epilogue (bf16 tile ~8k, + QuickGELU / erf-GELU ~8k, fp32 + residual ~27k)
+    const long long t_tile = (long long)(K / 64) * 3500 + (out_dtype == MMAMD_F32 ? 27000 : 8000) +
+                             ((act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF) ? 8000 : 0);
+    p.stagger = (int)(t_tile * g_gemm_stagger / 100);
+  }
   if (lf != nullptr) {
     p.Xh = (bf16*)lf->xh; p.ldxh = lf->ldxh; p.st_out = lf->st_out; p.nslot_out = N / 64;
     p.st_in = lf->st_in; p.nslot_in = lf->nslot_in; p.c1 = lf->c1; p.inv_d = 1.0f / (float)K; p.ln_eps = lf->eps;

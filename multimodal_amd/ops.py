@@ -99,6 +99,11 @@ def cu_census(blocks: int = 2048, spin_ticks: int = 200000) -> torch.Tensor:
     return out
 
 
+def set_gemm_stagger(ticks: int) -> None:
+    """Experiment hook: see mmamd_debug_set_gemm_stagger."""
+    _lib.lib().mmamd_debug_set_gemm_stagger(int(ticks))
+
+
 def set_gemm_variant(v: int) -> None:
     _lib.lib().mmamd_set_gemm_variant(int(v))
 

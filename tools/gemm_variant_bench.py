@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--variants", default="0,50,51,52")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--only", default="", help="comma-separated shape-name substrings")
+    ap.add_argument("--staggers", default="", help="comma-separated stagger tick counts: sweeps them on variant 0 instead of the variants")
     args = ap.parse_args()
     from multimodal_amd import build, ops
 
@@ -40,8 +41,10 @@ def main():
         x0 = rnd(M, N, dtype=torch.float32) if res else None
         ref = None
         line = f"{name:10s} [{M}x{N}x{K}]"
-        for v in variants:
+        sweep = [(0, int(x)) for x in args.staggers.split(",")] if args.staggers else [(v, 0) for v in variants]
+        for v, stg in sweep:
             ops.set_gemm_variant(v)
+            ops.set_gemm_stagger(stg)
             out = x0.clone() if res else torch.empty(M, N, dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")
 
             def run():
@@ -60,8 +63,9 @@ def main():
             else:
                 same = "==" if torch.equal(out_first, ref) else f"!= (max {float((out_first.float() - ref.float()).abs().max()):.3g})"
             best = min(timeit(run, 10) for _ in range(args.rounds))
-            line += f" | v{v}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:5.0f} TF/s {same}"
+            line += f" | v{v}{'/s' + str(stg) if stg else ''}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:5.0f} TF/s {same}"
         ops.set_gemm_variant(0)
+        ops.set_gemm_stagger(0)
         print(line, flush=True)
 
 
