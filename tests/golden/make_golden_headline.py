@@ -1,12 +1,14 @@
 """Headline-size parity fixtures from the REFERENCE itself (mechanism: make_golden.py).  Build container only:
 
-    python -m tests.golden.make_golden_headline [b16] [l14] [coca]
+    python -m tests.golden.make_golden_headline [b16] [l14] [coca] [flava]
 
   clip_b16_b256.npz   cfg 2 AT FULL SIZE: reference clip_vit_b16 (seed-0 default init), the SURVEY 8d batch of 256 pairs, CPU fp32:
                       emb_a / emb_b [256,512], both [256,256] logit blocks, the loss; and the reference's OWN bf16-CPU run
                       (model.to(bfloat16), bf16 images): its logits and its argmax agreement with its fp32 run — the rate the HIP path
                       is compared with ("report the unfiltered agreement rate next to the reference's own bf16-CPU rate")
   clip_l14_b32.npz    cfg 3 model (clip_vit_l14) at B = 32: same fields
+  flava_full_b16.npz  cfg 4 model (flava_model(), 241 M parameters) at B = 16: FLAVAModel.forward with a patch mask and masked / padded text
+                      (projected embeddings, CLS rows of all five encoders' outputs, multimodal pooler) + the global contrastive loss
   coca_l14_b8.npz     cfg 5 model (coca_vit with the coca_vit_l_14 arguments and cascaded_pooler=False: the parallel pooler, SURVEY 8a
                       note) at B = 8 with padded captions: pooled embeddings, both losses of CoCaForPretraining, and of the
                       [8,76,49408] vocabulary logits (120 MB) a strided column sample, the per-row argmax / max / logsumexp and the
@@ -138,6 +140,49 @@ def coca_case(timing):
     print("coca_l14_b8", timing["coca_l14_b8"], flush=True)
 
 
+def flava_case(timing):
+    """cfg 4 model at B = 16: flava_model() (seed 0), patch mask + masked / padded text, the whole FLAVAModel.forward + ITC loss."""
+    from torchmultimodal.models.flava.model import flava_model
+    from torchmultimodal.modules.losses.flava import FLAVAGlobalContrastiveLoss
+
+    from multimodal_amd.models.flava.model import flava_model as my_flava_model
+
+    B = 16
+    seed(0)
+    model = flava_model().eval()
+    seed(0)
+    mine = my_flava_model()
+    rs, ms = model.state_dict(), mine.state_dict()
+    assert list(rs.keys()) == list(ms.keys()) and all(torch.equal(rs[k], ms[k]) for k in rs), "flava init"
+    del mine, ms
+    g = torch.Generator().manual_seed(2024)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    text = torch.randint(1, 30500, (B, 77), generator=g)
+    for i, n in enumerate([77, 60, 41, 77, 23, 9, 77, 52] * 2):
+        text[i, n:] = 0
+    text_masked = text.clone()
+    text_masked[torch.rand(B, 77, generator=g) < 0.15] = 103
+    text_masked[text == 0] = 0
+    patches_mask = torch.randint(0, 2, (B, 196), generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out = model(image, text, image_patches_mask=patches_mask, text_masked=text_masked, skip_unmasked_mm_encoder=True)
+        t_fwd = time.perf_counter() - t0
+        lo = FLAVAGlobalContrastiveLoss().eval()(out.projected_image_embeddings, out.projected_text_embeddings, torch.ones(B, dtype=torch.bool))
+    k, s, a = checksums(model)
+    st = dict(text=text.numpy(), text_masked=text_masked.numpy(), patches_mask=patches_mask.numpy(), image_sum=float(image.double().sum()),
+              proj_image=tnp(out.projected_image_embeddings), proj_text=tnp(out.projected_text_embeddings),
+              image_cls=tnp(out.image.last_hidden_state[:, 0]), text_cls=tnp(out.text.last_hidden_state[:, 0]),
+              image_masked_cls=tnp(out.image_masked.last_hidden_state[:, 0]), text_masked_cls=tnp(out.text_masked.last_hidden_state[:, 0]),
+              mm_masked_cls=tnp(out.multimodal_masked.last_hidden_state[:, 0]), mm_masked_pooler=tnp(out.multimodal_masked.pooler_output),
+              mm_masked_hidden_mean=float(out.multimodal_masked.last_hidden_state.double().mean()),
+              itc_loss=tnp(lo.loss), itc_image_logits=tnp(lo.image_logits), itc_text_logits=tnp(lo.text_logits), keys=k, sums=s, asums=a)
+    np.savez_compressed(OUT / "flava_full_b16.npz", **st)
+    timing["flava_full_b16"] = {"model": "flava_model()", "batch": B, "dtype": "fp32", "threads": torch.get_num_threads(), "cores": os.cpu_count(),
+                                "model_forward_s": round(t_fwd, 3), "samples_per_s": round(B / t_fwd, 3), "itc_loss": float(lo.loss)}
+    print("flava_full_b16", timing["flava_full_b16"], flush=True)
+
+
 def main():
     assert _ref_shim.reference_available(), "needs /root/reference"
     _ref_shim.install()
@@ -146,7 +191,7 @@ def main():
     from multimodal_amd.models.clip import clip_vit_b16, clip_vit_l14
 
     torch.set_num_threads(8)
-    which = set(sys.argv[1:]) or {"b16", "l14", "coca"}
+    which = set(sys.argv[1:]) or {"b16", "l14", "coca", "flava"}
     path = ROOT / "profiles" / "r02_reference_cpu.json"
     timing = json.loads(path.read_text()) if path.exists() else {}
     timing["_host"] = {"cpu": "build container", "os_cpu_count": os.cpu_count(), "torch_threads": 8, "torch": torch.__version__,
@@ -158,6 +203,8 @@ def main():
         clip_case("clip_l14_b32", ref_l14, clip_vit_l14, 32, timing)
     if "coca" in which:
         coca_case(timing)
+    if "flava" in which:
+        flava_case(timing)
     path.write_text(json.dumps(timing, indent=1) + "\n")
     print("written", path)
 
