@@ -87,9 +87,10 @@ def test_scripted_and_compiled_clip_equal_eager():
         assert torch.equal(scripted.embeddings_a, eager.embeddings_a) and torch.equal(scripted.embeddings_b, eager.embeddings_b)
         # torch.compile: dynamo traces the module into ONE graph of torch.ops.mmamd.* calls (fullgraph: no graph break, i.e. no opaque
         # ctypes call was hit), FakeTensor propagation runs on the Meta kernels of the shim; aot_eager executes the real ops
-        compiled = torch.compile(clip, backend="aot_eager", fullgraph=True)
-        got = compiled(images, ids)
-        assert torch.equal(got.embeddings_a, eager.embeddings_a) and torch.equal(got.embeddings_b, eager.embeddings_b)
+        for backend in ("aot_eager", "inductor"):  # inductor (torch.compile's default) emits the custom ops as extern calls
+            torch._dynamo.reset()
+            got = torch.compile(clip, backend=backend, fullgraph=True)(images, ids)
+            assert torch.equal(got.embeddings_a, eager.embeddings_a) and torch.equal(got.embeddings_b, eager.embeddings_b), backend
         x = torch.randn(7, 33, device="cuda")
         assert torch.equal(torch.jit.script(SiLU())(x), SiLU()(x))
 
