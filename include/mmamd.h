@@ -85,6 +85,22 @@ int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float*
                     const void* residual, int ldr, void* C, int ldc, int out_dtype, int M, int N,
                     int K, int act, mmamd_stream_t stream);
 
+/* GROUPED form of mmamd_gemm_bf16: up to two problems that share out_dtype and the activation but not the shapes — the same projection
+ * of the two towers of the dual encoder (models/clip/model.py:63-75 runs encoder_a then encoder_b; the layers of image_encoder.py:108
+ * and text_encoder.py:121 are independent until the loss) — in ONE persistent launch whose workgroups walk the concatenated tile list.
+ * Each problem: C = act(A W^T + bias) (+ R, dtype = out_dtype, may alias C).  Results are bit-identical to one mmamd_gemm_bf16 call per
+ * problem; problems the persistent kernel cannot take (K % 128 != 0, too few tiles, a non-default GEMM variant) run as exactly those calls. */
+typedef struct {
+  const void* A;      /* bf16 [M, lda] */
+  const void* W;      /* bf16 [N, ldw] */
+  const float* bias;  /* fp32 [N] or NULL */
+  const void* R;      /* residual [M, ldr] or NULL */
+  void* C;            /* [M, ldc] */
+  int M, N, K;
+  int lda, ldw, ldr, ldc;
+} mmamd_gemm_problem;
+int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int nprob, int out_dtype, int act, mmamd_stream_t stream);
+
 /* Training forward of an MLP's first linear (linear1 of the encoder layers, modules/layers/mlp.py:60-79 under autograd): ONE pass
  * writes the pre-activation U = A W^T + bias (bf16 [M, ldu], kept for the backward) and G = act(U) (bf16 [M, ldg], the input of the
  * second linear), act = MMAMD_ACT_QUICKGELU or MMAMD_ACT_GELU_ERF applied to the bf16-rounded U (exactly what mmamd_act_fwd on U

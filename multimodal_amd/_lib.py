@@ -34,6 +34,7 @@ PROTOTYPES = {
     "mmamd_debug_set_attn_variant": (_i, [_i]),
     "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mmamd_gemm_bf16_grouped": (_i, [_vp, _i, _i, _i, _vp]),
     "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_attention_fwd_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_gemm_bf16_splitk": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

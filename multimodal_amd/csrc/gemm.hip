@@ -1945,6 +1945,372 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// GROUPED persistent kernel ("PPG"): the persistent kernel above walking the CONCATENATED tile lists of up to two GEMM problems that
+// share the epilogue kind (activation, output type) but not the shapes -- the same projection of the two towers of the dual encoder
+// (ViT [50432 x N x 768] and text [19712 x N' x 512] at cfg 2).  One launch instead of two on two streams: the second problem's tiles
+// fill the partial last round of the first (a persistent workgroup owns its CU for the whole launch, so a second stream's kernels could
+// only run in whatever the first one's tail left over -- in-bench every ViT kernel ran 17-60 % slower than alone and the text tower's
+// 24-50 us GEMMs took 150 us on average).  Per tile the problem's fields are (re)loaded from the kernel argument segment (scalar loads);
+// K, the leading dimensions, the operand bases and the epilogue pointers all change at a problem boundary, and the first K-tile of the NEXT
+// tile -- possibly of the other problem -- is DMA'd behind the last K-tile of the current one exactly as in the single-problem kernel.
+struct GemmProblem {
+  const bf16* A;
+  const bf16* W;
+  const float* bias;
+  const void* R;
+  void* C;
+  int M, N, K;
+  int lda, ldw, ldr, ldc;
+  int tiles_m, tiles_n;
+};
+struct GemmGroupArgs {
+  GemmProblem prob[2];
+  int nprob;
+  int tile_start[3];  // tile_start[i] = first tile id of problem i; tile_start[nprob] = total
+  int stagger;
+};
+
+template <bool OUT_F32, int ACT, int GM>
+__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupArgs g) {
+  constexpr int WM = 2, WN = 4, STP = OUT_F32 ? 0 : 2, RDP = 0;
+  constexpr int BM = 256, BN = 256, NW = WM * WN;
+  const int ntiles = g.tile_start[g.nprob];
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW, NDMA = A_INSTR + B_INSTR, NF = NI + MI, NM = NI * MI;
+  static_assert(NM >= NDMA && NM >= NF && NW % 4 == 0, "interleave needs one MFMA per DMA piece / fragment read");
+  constexpr int CH = TN / 64;  // 128-byte column chunks of a wave tile row in bf16
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // virtual block id -> (problem, tile): the XCD-contiguous remap runs over the CONCATENATED tile list, the GM-grouped order inside
+  // each problem's own tile grid
+  auto tile_of = [&](int vb, int& sel, int& tm, int& tn) __attribute__((always_inline)) {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, loc = vb >> 3;
+    int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    sel = (g.nprob > 1 && id >= g.tile_start[1]) ? 1 : 0;
+    id -= g.tile_start[sel];
+    const int tiles_m = g.prob[sel].tiles_m;
+    const int per_group = GM * g.prob[sel].tiles_n;
+    const int grp = id / per_group, within = id - grp * per_group;
+    const int gm0 = grp * GM;
+    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    tn = within / rows;
+    tm = gm0 + (within - tn * rows);
+  };
+
+  // DMA source offsets of this lane (see kernel above for the swizzle): depend on the tile, not on K
+  const int sw = (4 * (wave & 3) + (lane >> 4)) & 15;
+  const int slot = (lane & 15) ^ sw;
+  const int row8 = 2 * (lane >> 4) + (slot >> 3);
+  const int chunk = slot & 7;
+  auto tile_offsets = [&](const GemmProblem& p, int tm, int tn, uint32_t (&ao)[A_INSTR], uint32_t (&bo)[B_INSTR]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      int r = tm * BM + 8 * (wave + NW * j) + row8;
+      r = r < p.M ? r : p.M - 1;
+      ao[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      int r = tn * BN + 8 * (wave + NW * j) + row8;
+      r = r < p.N ? r : p.N - 1;
+      bo[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
+    }
+  };
+  int vb = blockIdx.x, sel = 0;
+  int tm, tn;
+  tile_of(vb, sel, tm, tn);
+  GemmProblem p = g.prob[sel];  // the CURRENT tile's problem (scalar loads from the kernel argument segment, refreshed per tile)
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Wb = reinterpret_cast<const char*>(p.W);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
+  uint32_t a_off[A_INSTR], b_off[B_INSTR], a_nxt[A_INSTR], b_nxt[B_INSTR];
+  auto issue_piece = [&](int buf, int kt, int i) __attribute__((always_inline)) {
+    const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
+    if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
+    else dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
+  };
+
+  const int hsw = l31 >> 1;
+  uint32_t ra[2][4], rb[2][4];
+#pragma unroll
+  for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
+      ra[bf][t] = lds0 + bf * STAGE + (wm * TM) * 128 + ro;
+      rb[bf][t] = lds0 + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
+    }
+  typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
+
+  f32x16 acc[NI][MI];
+  bf16x8 xa0[MI], wb0[NI], xa1[MI], wb1[NI];
+  auto load_frags = [&](auto bufc, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+    constexpr int BF = decltype(bufc)::value;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + ni * 32 * 128));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + mi * 32 * 128));
+  };
+  auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
+  };
+  auto mma_one = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI], int i) {
+    acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
+  };
+  // one K-tile out of ring buffer BF; behind the first MFMA group one DMA piece each of (ktsrc -> buffer BF^1)
+  auto tile_body = [&](auto bufc, int ktsrc, const bool issue) __attribute__((always_inline)) {
+    constexpr int BF = decltype(bufc)::value;
+    load_frags(bufc, 0, xa0, wb0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      mma_one(xa1, wb1, i);
+      if (issue && i < NDMA) issue_piece(BF ^ 1, ktsrc, i);  // wave-uniform scalar branch
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_frags(bufc, 1, xa1, wb1);
+    mma(xa0, wb0);
+    load_frags(bufc, 2, xa0, wb0);
+    mma(xa1, wb1);
+    load_frags(bufc, 3, xa1, wb1);
+    mma(xa0, wb0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if constexpr (RDP == 0) {         // one read of the next k-step behind each of the first NF MFMAs
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+      } else if constexpr (RDP == 1) {  // all NF reads in one burst behind the first MFMA (maximum cover)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 1, 0);
+      } else {                          // two reads behind each of the first NF/2 MFMAs
+#pragma unroll
+        for (int i = 0; i < NF / 2; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NF / 2, 0);
+      }
+    }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  auto sync_tile = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  int KT = p.K >> 6;  // even (launcher), per problem
+  tile_offsets(p, tm, tn, a_off, b_off);
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) issue_piece(0, 0, i);
+  if (g.stagger > 0) {
+    const int heavy = ntiles % (int)gridDim.x;  // workgroups 0 .. heavy-1 walk one tile more: they start at once
+    if (heavy > 0 && (int)blockIdx.x >= heavy) {
+      const long long delay = (long long)g.stagger * ((int)blockIdx.x - heavy + 1) / ((int)gridDim.x - heavy);
+      const long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+
+  while (true) {
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nvb = vb + gridDim.x;
+    const bool more = nvb < ntiles;
+    int ntm = 0, ntn = 0, nsel = sel;
+    const char *Abn = Ab, *Wbn = Wb;
+    if (more) {
+      tile_of(nvb, nsel, ntm, ntn);
+      tile_offsets(g.prob[nsel], ntm, ntn, a_nxt, b_nxt);
+      Abn = reinterpret_cast<const char*>(g.prob[nsel].A);
+      Wbn = reinterpret_cast<const char*>(g.prob[nsel].W);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xa1[mi][j] = (bf16)0.f;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
+
+#pragma unroll 1
+    for (int kt = 0; kt < KT; kt += 2) {
+      sync_tile();
+      tile_body(B0{}, kt + 1, true);
+      const bool last = kt + 2 >= KT;
+      if (last && more) {  // this tile's loads are all issued: switch the DMA source to the next tile's first K-tile
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) a_off[j] = a_nxt[j];
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j) b_off[j] = b_nxt[j];
+        Ab = Abn;  // ... which may belong to the other problem
+        Wb = Wbn;
+      }
+      sync_tile();
+      tile_body(B1{}, last ? 0 : kt + 2, !last || more);
+    }
+    mma(xa1, wb1);  // flush the rotated last k-step
+
+    // ---------------- epilogue (LDS strips in ring buffer 1; buffer 0 is receiving the next tile) ----------------
+    // fp32 residual: a ring of RD passes of loads in flight, the first RD issued here (before the bias / barrier / first transpose).
+    // Measured (tools/gemm_variant_bench.py --variants 60,61,62,63, r02): depth 1 = 2 (out-proj 100.7 / 100.5 us), depth 3 and 4
+    // LOSE (115 / 133 us: 21 spilled registers and more loads queued per CU) -- the residual's latency is not what the fp32
+    // epilogue waits for; the default stays 1.
+    constexpr int RD = 1;
+    const int nw0 = n0 + wn * TN;
+    const int rrow = lane >> 3, rc = (lane & 7) * 4;  // fp32 read-back: 8 rows x 128 B per wave-instruction
+    f32x4 rq[RD][4];
+    auto res_load = [&](int pass, f32x4 (&dst)[4]) __attribute__((always_inline)) {  // pass = mi * NI + ni
+      const int mi = pass / NI, ni = pass - mi * NI;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
+        dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+      }
+    };
+    if constexpr (OUT_F32) {
+      if (p.R != nullptr) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) res_load(d, rq[d]);
+      }
+    }
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g4;
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (n + 3 < p.N) bv = load4(p.bias + n);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g4 + j] += bv[j];
+        }
+    }
+    if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ni][mi][r] = quick_gelu(acc[ni][mi][r]);
+    }
+    constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
+    char* strip = smem + STAGE + wave * (32 * ROWB);
+    __syncthreads();  // every wave has finished reading the last K-tile out of ring buffer 1
+    if constexpr (OUT_F32) {
+      const bool has_res = p.R != nullptr;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int pass = mi * NI + ni;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = ACT == MMAMD_ACT_GELU_ERF ? gelu_erf(acc[ni][mi][4 * g4 + j]) : acc[ni][mi][4 * g4 + j];
+            *reinterpret_cast<f32x4*>(strip + l31 * ROWB + (8 * g4 + 4 * half) * 4) = t;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          f32x4 vv[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) vv[it] = *reinterpret_cast<const f32x4*>(strip + (it * 8 + rrow) * ROWB + rc * 4);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
+            const bool ok = m < p.M && n + 3 < p.N;
+            f32x4 v = vv[it];
+            if (ok) {
+              if (has_res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rq[pass % RD][it][j];
+              }
+              store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
+            }
+          }
+          if (has_res && pass + RD < MI * NI) res_load(pass + RD, rq[pass % RD]);  // refill the slot this pass just consumed
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {  // 64 columns (128 B of bf16) per pass
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4 += 2) {
+              const int ni = 2 * ch + nn;
+              bf16x4 pa, pb;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float va = acc[ni][mi][4 * g4 + j], vb2 = acc[ni][mi][4 * (g4 + 1) + j];
+                if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb2 = gelu_erf(vb2); }
+                pa[j] = (bf16)va; pb[j] = (bf16)vb2;
+              }
+              uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+              auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+              auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+              *reinterpret_cast<uint4*>(strip + l31 * ROWB + (nn * 32 + 8 * (g4 + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
+            const int row = it * 8 + (lane >> 3), c = lane & 7;
+            uint4 v = *reinterpret_cast<const uint4*>(strip + row * ROWB + c * 16);
+            const int m = m0 + wm * TM + mi * 32 + row, n = nw0 + ch * 64 + c * 8;
+            if (m < p.M && n + 7 < p.N) {
+              if (p.R != nullptr) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+                bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
+                v = __builtin_bit_cast(uint4, a8);
+              }
+              store16<STP>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v);
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    if (!more) break;
+    vb = nvb;
+    tm = ntm;
+    tn = ntn;
+    if (nsel != sel) {  // wave-uniform: the walk crossed into the next problem
+      sel = nsel;
+      p = g.prob[sel];
+    }
+    KT = p.K >> 6;
+  }
+}
+
+
 #ifdef MMAMD_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------
 // "W" kernel (experiment, r02: correct, bit-equal to the production kernels, and SLOWER -- qkv 200 vs 160 us, MLP-up 277 vs 252,
@@ -2208,6 +2574,19 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_pp");
 }
 
+template <bool OUT_F32, int ACT>
+static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
+  constexpr int smem = 2 * 512 * 128;
+  auto kern = gemm_bf16_nt_kernel_ppg<OUT_F32, ACT, 8>;
+  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
+  const int ntiles = g.tile_start[g.nprob];
+  const int cus = stream_cus(st);
+  const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g);
+  return launch_status("gemm_bf16_grouped");
+}
+
 #ifdef MMAMD_EXPERIMENTS
 template <bool OUT_F32, int ACT, int GM, int SCH = 0>
 static int launch_tiled_w(GemmArgs& p, hipStream_t st) {
@@ -2428,6 +2807,67 @@ extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, c
                                int ldr, void* C, int ldc, int out_dtype, int M, int N, int K, int act,
                                mmamd_stream_t stream) {
   return gemm_bf16_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, out_dtype, M, N, K, act, nullptr, 0, 0, stream);
+}
+
+extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int nprob, int out_dtype, int act, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(probs != nullptr && nprob >= 1 && nprob <= 2, MMAMD_E_BADARG, "gemm_grouped: 1 or 2 problems, got %d", nprob);
+  MMAMD_CHECK_ARG(out_dtype == MMAMD_F32 || out_dtype == MMAMD_BF16, MMAMD_E_BADARG, "gemm_grouped: bad out_dtype %d", out_dtype);
+  MMAMD_CHECK_ARG(act == MMAMD_ACT_NONE || act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF, MMAMD_E_BADARG, "gemm_grouped: bad activation code %d", act);
+  // one persistent launch needs every problem on the persistent kernel's K granularity (two 64-deep K-tiles per loop trip) and enough tiles
+  // in total to give each CU more than one; anything else runs as the separate launches the grouped call stands for (same results: a tile's
+  // arithmetic does not depend on which launch computes it -- tests/test_gpu_grouped_gemm.py)
+  bool group = nprob == 2 && g_gemm_variant == 0;
+  long tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const mmamd_gemm_problem& q = probs[i];
+    MMAMD_CHECK_ARG(q.A && q.W && q.C && q.M >= 0 && q.N > 0 && q.K > 0, MMAMD_E_BADARG, "gemm_grouped: problem %d: bad argument", i);
+    if ((q.K & 127) != 0 || q.M == 0) group = false;
+    tiles += (long)((q.M + 255) / 256) * ((q.N + 255) / 256);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (!group || tiles < 2L * stream_cus(st)) {
+    for (int i = 0; i < nprob; ++i) {
+      const mmamd_gemm_problem& q = probs[i];
+      if (int rc = gemm_bf16_impl(q.A, q.lda, q.W, q.ldw, q.bias, q.R, q.ldr, q.C, q.ldc, out_dtype, q.M, q.N, q.K, act, nullptr, 0, 0, stream)) return rc;
+    }
+    return 0;
+  }
+  GemmGroupArgs g;
+  g.nprob = nprob;
+  g.tile_start[0] = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const mmamd_gemm_problem& q = probs[i];
+    MMAMD_CHECK_ARG(q.N % 8 == 0, MMAMD_E_UNSUPPORTED, "gemm_grouped: N=%d must be a multiple of 8", q.N);
+    MMAMD_CHECK_ARG(q.lda >= q.K && q.ldw >= q.K && q.ldc >= q.N && (!q.R || q.ldr >= q.N), MMAMD_E_BADARG, "gemm_grouped: leading dimension too small");
+    MMAMD_CHECK_ARG(q.lda % 8 == 0 && q.ldw % 8 == 0 && q.ldc % 8 == 0 && (!q.R || q.ldr % 8 == 0), MMAMD_E_ALIGN,
+                    "gemm_grouped: leading dimensions must be multiples of 8 elements");
+    MMAMD_CHECK_ARG(aligned16(q.A) && aligned16(q.W) && aligned16(q.C) && aligned16(q.R) && aligned16(q.bias), MMAMD_E_ALIGN,
+                    "gemm_grouped: base pointers must be 16-byte aligned");
+    MMAMD_CHECK_ARG((uint64_t)q.M * (uint64_t)q.lda * 2u < (1ull << 32) && (uint64_t)q.N * (uint64_t)q.ldw * 2u < (1ull << 32),
+                    MMAMD_E_UNSUPPORTED, "gemm_grouped: operand exceeds the 4 GiB 32-bit DMA offset range");
+    GemmProblem& d = g.prob[i];
+    d.A = (const bf16*)q.A; d.W = (const bf16*)q.W; d.bias = q.bias; d.R = q.R; d.C = q.C;
+    d.M = q.M; d.N = q.N; d.K = q.K; d.lda = q.lda; d.ldw = q.ldw; d.ldr = q.ldr; d.ldc = q.ldc;
+    d.tiles_m = (q.M + 255) / 256; d.tiles_n = (q.N + 255) / 256;
+    g.tile_start[i + 1] = g.tile_start[i] + d.tiles_m * d.tiles_n;
+  }
+  for (int i = nprob; i < 2; ++i) { g.prob[i] = g.prob[0]; g.tile_start[i + 1] = g.tile_start[nprob]; }
+  {
+    const long long t_tile = (long long)(probs[0].K / 64) * 3500 + (out_dtype == MMAMD_F32 ? 27000 : 8000) + (act != MMAMD_ACT_NONE ? 8000 : 0);
+    g.stagger = (int)(t_tile * g_gemm_stagger / 100);
+  }
+  if (out_dtype == MMAMD_F32) {
+    switch (act) {
+      case MMAMD_ACT_NONE: return launch_grouped<true, MMAMD_ACT_NONE>(g, st);
+      case MMAMD_ACT_QUICKGELU: return launch_grouped<true, MMAMD_ACT_QUICKGELU>(g, st);
+      default: return launch_grouped<true, MMAMD_ACT_GELU_ERF>(g, st);
+    }
+  }
+  switch (act) {
+    case MMAMD_ACT_NONE: return launch_grouped<false, MMAMD_ACT_NONE>(g, st);
+    case MMAMD_ACT_QUICKGELU: return launch_grouped<false, MMAMD_ACT_QUICKGELU>(g, st);
+    default: return launch_grouped<false, MMAMD_ACT_GELU_ERF>(g, st);
+  }
 }
 
 extern "C" int mmamd_gemm_bf16_dual(const void* A, int lda, const void* W, int ldw, const float* bias, void* U, int ldu, void* G,

@@ -88,8 +88,8 @@ class TransformerStack(nn.Module):
         return x
 
     @torch.jit.unused
-    def run(self, x: torch.Tensor, B: int, S: int, causal: bool) -> torch.Tensor:
-        """x: fp32 [B*S, d] residual stream (updated in place and returned)."""
+    def run(self, x: torch.Tensor, B: int, S: int, causal: bool, first: int = 0) -> torch.Tensor:
+        """x: fp32 [B*S, d] residual stream (updated in place and returned); layers [first:] only."""
         d, H = self.d_model, self.nhead
         if d // H != HEAD_DIM:
             raise ops.MmamdError(f"the MI355X attention kernel is built for head dim 64, got {d // H}")
@@ -106,12 +106,13 @@ class TransformerStack(nn.Module):
         # B = 256: consumers 193 / 284 us vs LayerNorm 35 + GEMM 163 / 254; producers 138 / 297 vs 98 / 269 — the per-tile epilogue is the
         # exposed part of these kernels and the streaming LayerNorm kernel runs at 6.6 TB/s; profiles/r02_lnfold_bench.txt).
         # Opt-in for experiments: MMAMD_LN_FOLD=1.
-        if not bf16_stream and d % 128 == 0 and os.environ.get("MMAMD_LN_FOLD", "0") == "1":
+        if first == 0 and not bf16_stream and d % 128 == 0 and os.environ.get("MMAMD_LN_FOLD", "0") == "1":
             return self._run_ln_folded(x, B, S, causal, qkv, att, up)
         x_f32 = x
         if bf16_stream:
             x = ops.convert(x, bf)
-        for layer in self.layers:
+        for li in range(first, len(self.layers)):
+            layer = self.layers[li]
             sa = layer.self_attn
             ops.layernorm(x, pk(layer.norm1.weight, f32), pk(layer.norm1.bias, f32), layer.norm1.eps, out=hn)
             ops.gemm_bf16(hn, pk(sa.in_proj_weight, bf), pk(sa.in_proj_bias, f32), out=qkv)
@@ -123,6 +124,52 @@ class TransformerStack(nn.Module):
         if bf16_stream:
             x = ops.convert(x, f32)
         return x
+
+
+def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, causal_a: bool, sb: TransformerStack, xb: torch.Tensor, Bb: int,
+                   Sb: int, causal_b: bool):
+    """Both towers of a dual encoder, layer-locked on ONE stream: layer i of tower A and layer i of tower B are independent until the loss
+    (reference models/clip/model.py:63-75 simply runs one encoder after the other), so each of the four projections of a layer is ONE
+    grouped persistent GEMM over both towers' tiles (ops.gemm_bf16_grouped): the short tower's tiles fill the partial last round of the
+    long one's instead of competing with it from a second stream.  Same kernels' arithmetic, bit-identical results to TransformerStack.run
+    per tower.  Layers beyond the shorter stack's depth (CLIP L/14: 24 vision, 12 text) run alone.  xa / xb are updated in place."""
+    for st in (sa, sb):
+        if st.d_model // st.nhead != HEAD_DIM:
+            raise ops.MmamdError(f"the MI355X attention kernel is built for head dim 64, got {st.d_model // st.nhead}")
+    bf, f32 = torch.bfloat16, torch.float32
+    dev = xa.device
+    Ma, Mb = Ba * Sa, Bb * Sb
+    pa, pb = sa._packed.get, sb._packed.get
+
+    def bufs(M, st):
+        return (torch.empty((M, st.d_model), dtype=bf, device=dev), torch.empty((M, 3 * st.d_model), dtype=bf, device=dev),
+                torch.empty((M, st.d_model), dtype=bf, device=dev), torch.empty((M, st.dim_feedforward), dtype=bf, device=dev))
+
+    hna, qkva, atta, upa = bufs(Ma, sa)
+    hnb, qkvb, attb, upb = bufs(Mb, sb)
+    n = min(len(sa.layers), len(sb.layers))
+    for li in range(n):
+        la, lb = sa.layers[li], sb.layers[li]
+        aa, ab = la.self_attn, lb.self_attn
+        ops.layernorm(xa, pa(la.norm1.weight, f32), pa(la.norm1.bias, f32), la.norm1.eps, out=hna)
+        ops.layernorm(xb, pb(lb.norm1.weight, f32), pb(lb.norm1.bias, f32), lb.norm1.eps, out=hnb)
+        ops.gemm_bf16_grouped([(hna, pa(aa.in_proj_weight, bf), pa(aa.in_proj_bias, f32), None, qkva),
+                               (hnb, pb(ab.in_proj_weight, bf), pb(ab.in_proj_bias, f32), None, qkvb)])
+        ops.attention_fwd(qkva, Ba, Sa, sa.nhead, causal_a, out=atta)
+        ops.attention_fwd(qkvb, Bb, Sb, sb.nhead, causal_b, out=attb)
+        ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), xa, xa),
+                               (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), xb, xb)], out_dtype=f32)
+        ops.layernorm(xa, pa(la.norm2.weight, f32), pa(la.norm2.bias, f32), la.norm2.eps, out=hna)
+        ops.layernorm(xb, pb(lb.norm2.weight, f32), pb(lb.norm2.bias, f32), lb.norm2.eps, out=hnb)
+        ops.gemm_bf16_grouped([(hna, pa(la.linear1.weight, bf), pa(la.linear1.bias, f32), None, upa),
+                               (hnb, pb(lb.linear1.weight, bf), pb(lb.linear1.bias, f32), None, upb)], act=ops.ACT_QUICKGELU)
+        ops.gemm_bf16_grouped([(upa, pa(la.linear2.weight, bf), pa(la.linear2.bias, f32), xa, xa),
+                               (upb, pb(lb.linear2.weight, bf), pb(lb.linear2.bias, f32), xb, xb)], out_dtype=f32)
+    if len(sa.layers) > n:
+        sa.run(xa, Ba, Sa, causal_a, first=n)
+    if len(sb.layers) > n:
+        sb.run(xb, Bb, Sb, causal_b, first=n)
+    return xa, xb
 
 
 def _run_ln_folded(self, x, B, S, causal, qkv, att, up):

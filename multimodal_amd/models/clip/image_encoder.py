@@ -103,38 +103,56 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
                 raise NotImplementedError("CLIPViTEncoder: the gradient with respect to the input image is not implemented on the "
                                           "MI355X path (parameters are differentiable; detach the image or run under torch.no_grad())")
             return self._forward_train(x)
-        f32 = torch.float32
-        pk = self._packed.get
-        B = x.size(0)
-        g = self.image_size // self.patch_size
-        G2 = g * g
-        K = 3 * self.patch_size * self.patch_size
-        kpad = (K + 63) // 64 * 64
-        xc = x if x.is_contiguous() else x.contiguous()
         # K1: patch embedding = GEMM over non-overlapping patches (conv has no bias in CLIP), fp32 result
-        return self.forward_patches(ops.patchify(xc, self.patch_size, kpad))
+        h, B, S = self._stem(x)
+        h = self.encoder.run(h, B, S, causal=False)
+        return self._head(h, B, S)
 
     @torch.jit.unused
     def forward_patches(self, patches: Tensor) -> Tensor:
         """Inference entry for a device-side loader (extension; transforms.clip_transform.CLIPImageTransform.patches): bf16 im2col
         rows [B*G2, Kpad] (column (c*P+py)*P+px, Kpad = 3*P*P rounded up to 64) instead of the fp32 image -- the same rows
         `forward` builds with mmamd_patchify, so the result is identical."""
-        f32 = torch.float32
-        pk = self._packed.get
+        self._check_patches(patches)
+        h, B, S = self._stem_patches(patches)
+        h = self.encoder.run(h, B, S, causal=False)
+        return self._head(h, B, S)
+
+    @torch.jit.unused
+    def _check_patches(self, patches: Tensor) -> None:
         g = self.image_size // self.patch_size
         G2 = g * g
         K = 3 * self.patch_size * self.patch_size
         kpad = (K + 63) // 64 * 64
         if patches.dim() != 2 or patches.shape[1] != kpad or patches.shape[0] % G2 != 0 or patches.dtype != torch.bfloat16:
             raise ValueError(f"Expected bf16 patch rows [B*{G2}, {kpad}], found {patches.dtype} {tuple(patches.shape)}")
+
+    @torch.jit.unused
+    def _stem(self, x: Tensor):
+        """fp32 image -> (residual stream fp32 [B*S, w], B, S): the part of the inference forward in front of the layer stack."""
+        K = 3 * self.patch_size * self.patch_size
+        xc = x if x.is_contiguous() else x.contiguous()
+        return self._stem_patches(ops.patchify(xc, self.patch_size, (K + 63) // 64 * 64))
+
+    @torch.jit.unused
+    def _stem_patches(self, patches: Tensor):
+        f32 = torch.float32
+        pk = self._packed.get
+        g = self.image_size // self.patch_size
+        G2 = g * g
         B = patches.shape[0] // G2
-        pe = ops.gemm_bf16(patches, self._conv_weight_bf16(kpad), out_dtype=f32)
+        pe = ops.gemm_bf16(patches, self._conv_weight_bf16(patches.shape[1]), out_dtype=f32)
         # prepend CLS, + positional embedding, ln_pre  -> fp32 residual stream [B*S, w]
         h = ops.vit_assemble_ln(pe, pk(self.cls_token_embedding, f32), pk(self.positional_embedding, f32),
                                 pk(self.ln_pre.weight, f32), pk(self.ln_pre.bias, f32), self.ln_pre.eps, B, G2)
-        h = self.encoder.run(h, B, G2 + 1, causal=False)
-        # K7: ln_post(CLS) @ projection
-        out = ops.pool_ln_proj(h, B, G2 + 1, None, pk(self.ln_post.weight, f32), pk(self.ln_post.bias, f32),
+        return h, B, G2 + 1
+
+    @torch.jit.unused
+    def _head(self, h: Tensor, B: int, S: int) -> Tensor:
+        """K7: ln_post(CLS) @ projection -- the part behind the layer stack."""
+        f32 = torch.float32
+        pk = self._packed.get
+        out = ops.pool_ln_proj(h, B, S, None, pk(self.ln_post.weight, f32), pk(self.ln_post.bias, f32),
                                self.ln_post.eps, pk(self.projection, f32), proj_is_linear_weight=False)
         return out if self.projection.dtype == f32 else ops.convert(out, self.projection.dtype)
 

@@ -16,6 +16,7 @@ from ...utils.common import load_module_from_url
 from . import _train
 from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
+from ._transformer import run_two_stacks
 
 
 _torch_ops.try_load()
@@ -91,6 +92,39 @@ class CLIP(PackedModeMixin, nn.Module):
             embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
             embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))
             return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
+        if self._grouped_towers(tower_a, features_a, features_b):
+            embeddings_a, embeddings_b = self._towers_grouped(tower_a, features_a, features_b)
+        else:
+            embeddings_a, embeddings_b = self._towers_streams(tower_a, features_a, features_b)
+        ea, eb = embeddings_a.detach().contiguous(), embeddings_b.detach().contiguous()
+        if ea.dim() == 2 and ea.shape == eb.shape and ea.dtype == eb.dtype:
+            # both outputs are views of ONE [B, 2E] block = the message of the loss's packed all-gather
+            # (utils.distributed.gather_packed_features recognises the layout and gathers it without packing copies)
+            E = ea.shape[1]
+            packed = torch.empty((ea.shape[0], 2 * E), dtype=ea.dtype, device=ea.device)
+            return CLIPOutput(embeddings_a=ops.l2_normalize(ea, eps=1e-12, out=packed[:, :E]),
+                              embeddings_b=ops.l2_normalize(eb, eps=1e-12, out=packed[:, E:]))
+        return CLIPOutput(embeddings_a=ops.l2_normalize(ea, eps=1e-12), embeddings_b=ops.l2_normalize(eb, eps=1e-12))
+
+    @torch.jit.unused
+    def _towers_grouped(self, tower_a, features_a, features_b):
+        """Both towers layer-locked on one stream, each projection ONE grouped persistent GEMM over both towers' tiles
+        (_transformer.run_two_stacks)."""
+        va, tb = self.encoder_a, self.encoder_b
+        from_patches = tower_a is not va
+        if from_patches:
+            va._check_patches(features_a)
+        ids = features_b if (features_b.dtype == torch.int64 and features_b.is_contiguous()) else features_b.to(torch.int64).contiguous()
+        ha, Ba, Sa = va._stem_patches(features_a) if from_patches else va._stem(features_a)
+        hb = tb._stem(ids)
+        Bb, Sb = ids.shape
+        run_two_stacks(va.encoder, ha, Ba, Sa, False, tb.encoder, hb, Bb, Sb, True)
+        return va._head(ha, Ba, Sa), tb._head(hb, Bb, Sb, ids)
+
+    @torch.jit.unused
+    def _towers_streams(self, tower_a, features_a, features_b):
+        """Tower-agnostic schedule: tower B on a side HIP stream (or each tower on its own CU partition), forked from / joined to the
+        caller's stream.  MMAMD_SINGLE_STREAM=1: one after the other."""
         side = self._side_stream(features_a)
         part = self._cu_partition(features_a) if side is not None else None
         if side is None:
@@ -119,15 +153,30 @@ class CLIP(PackedModeMixin, nn.Module):
             embeddings_a = tower_a(features_a)
             main.wait_stream(side)
             embeddings_b.record_stream(main)
-        ea, eb = embeddings_a.detach().contiguous(), embeddings_b.detach().contiguous()
-        if ea.dim() == 2 and ea.shape == eb.shape and ea.dtype == eb.dtype:
-            # both outputs are views of ONE [B, 2E] block = the message of the loss's packed all-gather
-            # (utils.distributed.gather_packed_features recognises the layout and gathers it without packing copies)
-            E = ea.shape[1]
-            packed = torch.empty((ea.shape[0], 2 * E), dtype=ea.dtype, device=ea.device)
-            return CLIPOutput(embeddings_a=ops.l2_normalize(ea, eps=1e-12, out=packed[:, :E]),
-                              embeddings_b=ops.l2_normalize(eb, eps=1e-12, out=packed[:, E:]))
-        return CLIPOutput(embeddings_a=ops.l2_normalize(ea, eps=1e-12), embeddings_b=ops.l2_normalize(eb, eps=1e-12))
+        return embeddings_a, embeddings_b
+
+    @torch.jit.unused
+    def _grouped_towers(self, tower_a, features_a, features_b) -> bool:
+        """The grouped two-tower schedule applies to the CLIP pair of this package (ViT + text transformer) in inference; any other
+        encoder pair keeps the tower-agnostic path.  MMAMD_TWO_TOWER=streams selects the two-stream schedule instead."""
+        import os
+
+        if os.environ.get("MMAMD_TWO_TOWER", "grouped") != "grouped":
+            return False
+        if type(self.encoder_a) is not CLIPViTEncoder or type(self.encoder_b) is not CLIPTextEncoder:
+            return False
+        if not (isinstance(features_a, torch.Tensor) and isinstance(features_b, torch.Tensor) and features_a.is_cuda and features_b.is_cuda):
+            return False
+        if features_b.dim() != 2 or os.environ.get("MMAMD_RESIDUAL", "fp32") != "fp32" or os.environ.get("MMAMD_LN_FOLD", "0") == "1":
+            return False
+        va, tb = self.encoder_a, self.encoder_b
+        if va._forward_hooks or va._forward_pre_hooks or tb._forward_hooks or tb._forward_pre_hooks:
+            return False  # hooks observe the encoders' own forward calls
+        if features_b.size(1) != tb.context_length:
+            return False  # (the encoder's forward raises the reference's error)
+        if tower_a is va:
+            return features_a.dim() == 4 and features_a.size(1) == 3 and features_a.size(2) == va.image_size and features_a.size(3) == va.image_size
+        return tower_a == va.forward_patches
 
     @torch.jit.unused
     def _cu_partition(self, ref):

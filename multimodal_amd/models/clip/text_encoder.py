@@ -111,12 +111,22 @@ class CLIPTextEncoder(PackedModeMixin, nn.Module):
             eot_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=ids.device) + ids.argmax(dim=-1)  # index bookkeeping
             return _train.PooledHeadFn.apply(h, eot_rows, self.ln_final.weight, self.ln_final.bias, self.projection.weight,
                                              self.ln_final.eps, True)
+        h = self._stem(ids)
+        h = self.encoder.run(h, B, S, causal=True)
+        return self._head(h, B, S, ids, return_hidden_state)
+
+    @torch.jit.unused
+    def _stem(self, ids: Tensor) -> Tensor:
+        """K8: gather + positional embedding -> fp32 residual stream [B*S, w] (ids: contiguous int64 [B, S])."""
         table = self.token_embedding.weight.detach()
         if table.dtype not in (torch.float32, torch.bfloat16):
             raise ops.MmamdError(f"token_embedding dtype {table.dtype} unsupported")
-        # K8: gather + positional embedding -> fp32 residual stream [B*S, w]
-        h = ops.embed_tokens(ids, table.contiguous(), pk(self.positional_embedding, f32))
-        h = self.encoder.run(h, B, S, causal=True)
+        return ops.embed_tokens(ids, table.contiguous(), self._packed.get(self.positional_embedding, torch.float32))
+
+    @torch.jit.unused
+    def _head(self, h: Tensor, B: int, S: int, ids: Tensor, return_hidden_state: bool = False) -> Tensor:
+        f32 = torch.float32
+        pk = self._packed.get
         out_dtype = self.projection.weight.dtype
         if return_hidden_state:
             hs = ops.layernorm(h, pk(self.ln_final.weight, f32), pk(self.ln_final.bias, f32), self.ln_final.eps,

@@ -23,7 +23,7 @@ __all__ = [
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
-    "attention_x_bwd", "image_resample", "group_mean_normalize", "scale_normalize", "target_rank",
+    "attention_x_bwd", "gemm_bf16_grouped", "image_resample", "group_mean_normalize", "scale_normalize", "target_rank",
 ]
 
 
@@ -145,6 +145,48 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     if timer is not None:
         timer.stop()
     return out
+
+
+class _GemmProblem(C.Structure):  # mmamd_gemm_problem (include/mmamd.h)
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldw", C.c_int), ("ldr", C.c_int), ("ldc", C.c_int)]
+
+
+def gemm_bf16_grouped(problems, act: int = ACT_NONE, out_dtype: torch.dtype = torch.bfloat16):
+    """One persistent launch for up to two GEMMs that share the epilogue kind: problems = [(a, w, bias, residual, out), ...] with the
+    operand meaning of gemm_bf16 (residual / out may be None; residual may alias out).  Returns the list of outputs.  Bit-identical to one
+    gemm_bf16 call per problem (mmamd_gemm_bf16_grouped)."""
+    n = len(problems)
+    if not 1 <= n <= 2:
+        raise MmamdError(f"gemm_bf16_grouped: 1 or 2 problems, got {n}")
+    arr = (_GemmProblem * n)()
+    outs = []
+    for i, (a, w, bias, residual, out) in enumerate(problems):
+        _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16)
+        M, K = a.shape
+        N, K2 = w.shape
+        if K != K2:
+            raise MmamdError(f"gemm_grouped: inner dims differ ({K} vs {K2})")
+        if bias is not None:
+            _chk(bias, "bias", torch.float32)
+        if out is None:
+            out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        _chk(out, "out", out_dtype)
+        if residual is not None:
+            _chk(residual, "residual", out_dtype)
+        q = arr[i]
+        q.A, q.W, q.bias, q.R, q.C = a.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr()
+        q.M, q.N, q.K, q.lda, q.ldw, q.ldr, q.ldc = M, N, K, K, K, N, N
+        outs.append(out)
+    probe = _GEMM_PROBE
+    timer = probe._timer_for(arr[0].M, arr[0].N, arr[0].K) if probe is not None else None
+    if timer is not None:
+        probe.companion = (arr[1].M, arr[1].N, arr[1].K) if n == 2 else None  # the launch also computes this problem
+        timer.start()
+    check(_lib.lib().mmamd_gemm_bf16_grouped(C.cast(arr, C.c_void_p), n, BF16 if out_dtype == torch.bfloat16 else F32, int(act), _stream()), "mmamd_gemm_bf16_grouped")
+    if timer is not None:
+        timer.stop()
+    return outs
 
 
 def lnfold_pack(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor]):
@@ -975,6 +1017,7 @@ class GemmProbe:
     def __init__(self, M: int, N: int, K: int, max_samples: int = 4096) -> None:
         self.shape = (M, N, K)
         self.max_samples = max_samples
+        self.companion = None  # second problem of the grouped launches that were timed (gemm_bf16_grouped), if any
         self._timers = []
 
     def _timer_for(self, M: int, N: int, K: int):
