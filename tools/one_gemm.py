@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Run ONE GEMM problem a few times (for rocprofv3 --pmc passes):  python tools/one_gemm.py M N K act res variant [iters]"""
+"""Run ONE GEMM launch a few times (for rocprofv3 --pmc passes):  python tools/one_gemm.py M N K act res variant [iters [M2 N2 K2]]
+(M2 N2 K2: a second problem of the same epilogue kind -> one GROUPED launch, ops.gemm_bf16_grouped)"""
 import sys
 from pathlib import Path
 
@@ -17,6 +18,15 @@ w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
 bias = torch.randn(N, generator=g).to(dev)
 out = torch.zeros((M, N), dtype=torch.float32 if res else torch.bfloat16, device=dev)
 ops.set_gemm_variant(variant)
-for _ in range(iters):
-    ops.gemm_bf16(a, w, bias, act=act, residual=out if res else None, out=out)
+if len(sys.argv) > 10:
+    M2, N2, K2 = (int(x) for x in sys.argv[8:11])
+    a2 = torch.randn(M2, K2, generator=g).to(dev).to(torch.bfloat16)
+    w2 = (torch.randn(N2, K2, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    bias2 = torch.randn(N2, generator=g).to(dev)
+    out2 = torch.zeros((M2, N2), dtype=out.dtype, device=dev)
+    for _ in range(iters):
+        ops.gemm_bf16_grouped([(a, w, bias, out if res else None, out), (a2, w2, bias2, out2 if res else None, out2)], act=act, out_dtype=out.dtype)
+else:
+    for _ in range(iters):
+        ops.gemm_bf16(a, w, bias, act=act, residual=out if res else None, out=out)
 torch.cuda.synchronize()
