@@ -60,7 +60,9 @@ int mmamd_set_gemm_variant(int variant);
 int mmamd_get_gemm_variant(void);
 /* Start-up stagger of the persistent GEMM, in per cent of the estimated time of one tile (default 60; 0 = off): the workgroups that walk one tile
  * fewer than the others (the last round of tiles is partial) start up to that much later, spread evenly — it de-synchronises the
- * C-tile store bursts of the 256 CUs and is free as long as it stays below one tile time.  Results do not change. */
+ * C-tile store bursts of the 256 CUs and is free as long as it stays below one tile time.  Results do not change.
+ * 1000 + percent (experiment, single-problem persistent kernel only): EVERY workgroup is delayed, the 32 of an XCD spread over 0 .. percent of a tile
+ * time — measured to cost as much makespan as the spread-out bursts save. */
 int mmamd_debug_set_gemm_stagger(int percent);
 /* Diagnostic: device buffer of 64*2*256 uint64 that GEMM variant 14 fills with s_memtime stamps (NULL = off). */
 int mmamd_debug_set_gemm_trace(void* buf);

@@ -1742,6 +1742,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
       const long long t0 = __builtin_readcyclecounter();
       while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
     }
+  } else if (p.stagger < 0) {
+    // experiment (mmamd_debug_set_gemm_stagger(1000 + percent)): EVERY workgroup is delayed, the 32 of an XCD spread evenly over
+    // [0, |stagger|) -- de-synchronises the chip-wide store bursts at the price of up to |stagger| of makespan
+    const long long delay = (long long)(-p.stagger) * ((int)blockIdx.x >> 3) / (((int)gridDim.x + 7) >> 3);
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
   }
 
   while (true) {
@@ -2854,7 +2860,7 @@ extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int npro
   for (int i = nprob; i < 2; ++i) { g.prob[i] = g.prob[0]; g.tile_start[i + 1] = g.tile_start[nprob]; }
   {
     const long long t_tile = (long long)(probs[0].K / 64) * 3500 + (out_dtype == MMAMD_F32 ? 27000 : 8000) + (act != MMAMD_ACT_NONE ? 8000 : 0);
-    g.stagger = (int)(t_tile * g_gemm_stagger / 100);
+    g.stagger = (int)(t_tile * (g_gemm_stagger % 1000) / 100);
   }
   if (out_dtype == MMAMD_F32) {
     switch (act) {
@@ -2904,7 +2910,7 @@ static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const 
     // ~3500 ticks per 64-deep K-tile + the epilogue (bf16 tile ~8k, + QuickGELU / erf-GELU ~8k, fp32 + residual ~27k)
     const long long t_tile = (long long)(K / 64) * 3500 + (out_dtype == MMAMD_F32 ? 27000 : 8000) +
                              ((act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF) ? 8000 : 0);
-    p.stagger = (int)(t_tile * g_gemm_stagger / 100);
+    p.stagger = g_gemm_stagger >= 1000 ? -(int)(t_tile * (g_gemm_stagger - 1000) / 100) : (int)(t_tile * g_gemm_stagger / 100);
   }
   if (lf != nullptr) {
     p.Xh = (bf16*)lf->xh; p.ldxh = lf->ldxh; p.st_out = lf->st_out; p.nslot_out = N / 64;
