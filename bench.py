@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-probe", action="store_true", help="do not bracket the dominant GEMM with events")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" IS RCCL on ROCm; gloo only with --dry-run')
     ap.add_argument("--dry-run", action="store_true", help="CPU control-flow run of the multi-rank path (no towers, no measurement)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with ONE rank: the N > 1 code path (communicator, packed all-gather, rank-offset "
+                         "labels, fences, max-over-ranks) on a single-GPU box")
     return ap.parse_args(argv)
 
 
@@ -190,6 +193,12 @@ def main() -> None:
     if args.backend != "nccl":
         raise SystemExit("the measured path runs over RCCL (--backend nccl); gloo is for --dry-run")
 
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 from here on (RCCL prints its library path
+    # through C stdio, flushed at exit, i.e. AFTER the record) goes to stderr; the record is written to the saved descriptor
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     if not torch.cuda.is_available():
@@ -202,8 +211,13 @@ def main() -> None:
     import torch.distributed as dist
 
     ranks_seen = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # --force-dist without a launcher
+            os.environ["MASTER_PORT"] = str(free_port())
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm; intra-node transport = xGMI
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
@@ -213,7 +227,7 @@ def main() -> None:
 
     if local_rank == 0:
         build.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     from multimodal_amd import ops
@@ -241,7 +255,7 @@ def main() -> None:
     with torch.no_grad():
         for _ in range(args.warmup):
             loss = step()
-        fence(dev, dist, world)
+        fence(dev, dist, 2 if use_dist else 1)
         t0 = time.perf_counter()
         marks[0].record()
         if args.no_probe:
@@ -253,7 +267,7 @@ def main() -> None:
                 for i in range(args.steps):
                     loss = step()
                     marks[i + 1].record()
-        fence(dev, dist, world)
+        fence(dev, dist, 2 if use_dist else 1)
         dt = time.perf_counter() - t0
     loss_val = float(loss)
     if not math.isfinite(loss_val):
@@ -262,7 +276,7 @@ def main() -> None:
     median_ms = per_step[len(per_step) // 2] if per_step else float("nan")
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t)
     pairs_per_s = world * B * args.steps / dt_max
@@ -331,7 +345,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "CLIP ViT-B/16 + text transformer forward + ContrastiveLossWithTemperature "
-                                   f"({'local' if world == 1 else 'global, packed RCCL all-gather'}), random-init weights",
+                                   f"({'global, packed RCCL all-gather' if use_dist else 'local'}), random-init weights",
                        "per_gpu_batch": B, "global_batch": world * B, "seq_img": S_img, "seq_txt": 77,
                        "parallelism": f"dp{world}", "gemm_variant": args.gemm_variant},
             "loss": round(loss_val, 5),
@@ -340,8 +354,9 @@ def main() -> None:
         }
         if ranks_seen is not None:
             line["rccl_ranks_seen"] = ranks_seen
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(record_fd, (json.dumps(line) + "\n").encode())
+    os.close(record_fd)
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -70,3 +70,19 @@ def test_world_size_mismatch_is_refused():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo"], cwd=str(ROOT), env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=4" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_force_dist_runs_the_rccl_path_with_one_rank():
+    """`--force-dist`: the N > 1 code path of bench.py on ONE MI355X — RCCL communicator, ranks-seen all-reduce, the packed
+    all_gather_into_tensor of the [B, 2E] block, rank-offset labels, barrier fences, max over ranks.  Same loss as the local run."""
+    lines = {}
+    for tag, extra in (("local", []), ("rccl", ["--force-dist"])):
+        p = run_bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "64", "--cpu-sample", "0", "--no-probe", *extra)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = p.stdout.strip().splitlines()
+        assert len(out) == 1, out  # stdout is the record and nothing else (RCCL's own chatter must not land there)
+        lines[tag] = json.loads(out[0])
+    assert lines["rccl"]["rccl_ranks_seen"] == 1 and "rccl_ranks_seen" not in lines["local"]
+    assert "RCCL all-gather" in lines["rccl"]["config"]["workload"]
+    assert lines["rccl"]["loss"] == lines["local"]["loss"]
