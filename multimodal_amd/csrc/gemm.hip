@@ -2679,6 +2679,10 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       case 18: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(p, st);
       case 70: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 1, true>(p, st);  // bias through LDS (DMA'd during the K loop)
 #ifdef MMAMD_EXPERIMENTS
+      // one wave per SIMD (4 waves, ONE workgroup per CU by LDS: 96 KiB ring), the 8-wave kernels' 128 x 64 wave tile: what a kernel with a
+      // second accumulator set (512 registers per wave) would have as its main loop
+      case 81: return launch_tiled<256, 128, 2, 2, OUT_F32, ACT, true>(p, st);
+      case 82: return launch_tiled<128, 256, 1, 4, OUT_F32, ACT, true>(p, st);
       case 60: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 1>(p, st);  // fp32 residual prefetch ring depth 1 .. 4
       case 61: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 2>(p, st);
       case 62: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 3>(p, st);
