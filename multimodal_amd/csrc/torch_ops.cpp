@@ -291,6 +291,134 @@ std::tuple<Tensor, Tensor, Tensor> contrastive_fwd_meta(const Tensor& a, const T
   return std::make_tuple(at::empty({3}, a.options()), at::empty({a.size(0), a_all.size(0)}, a.options()), at::empty({a.size(0), a_all.size(0)}, a.options()));
 }
 
+// ---- CoCa / encoder-decoder building blocks (modules/layers/{patch_embedding,multi_head_attention,attention_pooler}.py,
+//      models/coca/text_decoder.py of the reference) ------------------------------------------------------------------------------
+
+// Conv2d(kernel = stride = patch, with bias) + optional CLS row + position embeddings -> fp32 [B*(G2 (+1)), d]
+Tensor image_embed_impl(const Tensor& img, const Tensor& conv_w, const Tensor& conv_b, const optional<Tensor>& cls, const Tensor& pos, int64_t patch) {
+  chk(img, "image");
+  TORCH_CHECK(img.dim() == 4 && conv_w.dim() == 4 && img.size(2) == img.size(3), "mmamd::image_embed: square image [B,C,H,H] and conv weight [d,C,p,p] expected");
+  const int64_t B = img.size(0), C = img.size(1), HW = img.size(2), g = HW / patch, G2 = g * g, d = conv_w.size(0);
+  const int64_t K = C * patch * patch, kpad = (K + 63) / 64 * 64;
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(img.device());
+  mmamd_stream_t st = cur_stream(img);
+  Tensor cols = at::empty({B * G2, kpad}, img.options().dtype(at::kBFloat16));
+  check_status(mmamd_patchify(img.data_ptr(), dt_code(img.scalar_type()), cols.data_ptr(), (int)B, (int)C, (int)HW, (int)patch, (int)kpad, st),
+               "mmamd_patchify");
+  Tensor wk = bf16w(conv_w).view({d, K});
+  if (kpad != K) {
+    Tensor padded = at::zeros({d, kpad}, wk.options());
+    padded.narrow(1, 0, K).copy_(wk);
+    wk = padded;
+  }
+  const Tensor bias = f32v(conv_b), p = f32v(pos);
+  Tensor pe = at::empty({B * G2, d}, img.options().dtype(at::kFloat));
+  check_status(mmamd_gemm_bf16(cols.data_ptr(), (int)kpad, wk.data_ptr(), (int)kpad, bias.data_ptr<float>(), nullptr, 0, pe.data_ptr(), (int)d,
+                               MMAMD_F32, (int)(B * G2), (int)d, (int)kpad, MMAMD_ACT_NONE, st), "mmamd_gemm_bf16");
+  Tensor c;
+  if (cls.has_value()) c = f32v(*cls);
+  Tensor x = at::empty({B * (G2 + (c.defined() ? 1 : 0)), d}, pe.options());
+  check_status(mmamd_flava_image_embed(pe.data_ptr<float>(), c.defined() ? c.data_ptr<float>() : nullptr, p.data_ptr<float>(), nullptr, nullptr,
+                                       x.data_ptr<float>(), (int)B, (int)G2, (int)d, st), "mmamd_flava_image_embed");
+  return x;
+}
+Tensor image_embed_meta(const Tensor& img, const Tensor& conv_w, const Tensor&, const optional<Tensor>& cls, const Tensor&, int64_t patch) {
+  const int64_t g = img.size(2) / patch;
+  return at::empty({img.size(0) * (g * g + (cls.has_value() ? 1 : 0)), conv_w.size(0)}, img.options().dtype(at::kFloat));
+}
+
+// general attention: q [B*Sq (or Sq when shared_q), H*hd], k / v [B*Sk, H*hd] bf16, possibly column slices of wider matrices;
+// key_mask uint8 [B,Sk], full_mask uint8 [B or 1, Sq, Sk] (0 = masked) -> bf16 [B*Sq, H*hd]
+Tensor attn_x_impl(const Tensor& q, const Tensor& k, const Tensor& v, int64_t B, int64_t Sq, int64_t Sk, int64_t H, int64_t hd, bool causal,
+                   const optional<Tensor>& key_mask, const optional<Tensor>& full_mask, bool shared_q) {
+  for (const Tensor* t : {&q, &k, &v})
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kBFloat16 && t->dim() == 2 && t->stride(1) == 1 && t->size(1) == H * hd,
+                "mmamd::attn_x: q / k / v must be bf16 HIP matrices (views) with unit inner stride and H*head_dim columns");
+  TORCH_CHECK(q.size(0) == (shared_q ? Sq : B * Sq) && k.size(0) == B * Sk && v.size(0) == B * Sk, "mmamd::attn_x: row counts do not match B, Sq, Sk");
+  const uint8_t *km = nullptr, *fm = nullptr;
+  int64_t fm_bs = 0;
+  if (key_mask.has_value()) {
+    chk(*key_mask, "key_mask", at::kByte);
+    TORCH_CHECK(key_mask->numel() == B * Sk, "mmamd::attn_x: key_mask must be [B, Sk]");
+    km = key_mask->data_ptr<uint8_t>();
+  }
+  if (full_mask.has_value()) {
+    chk(*full_mask, "full mask", at::kByte);
+    TORCH_CHECK(full_mask->numel() == Sq * Sk || full_mask->numel() == B * Sq * Sk, "mmamd::attn_x: full mask must be [B or 1, Sq, Sk]");
+    fm = full_mask->data_ptr<uint8_t>();
+    fm_bs = (full_mask->numel() == B * Sq * Sk && B > 1) ? Sq * Sk : 0;
+  }
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(q.device());
+  Tensor out = at::empty({B * Sq, H * hd}, q.options());
+  check_status(mmamd_attention_x_fwd(q.data_ptr(), (int)q.stride(0), shared_q ? 0 : Sq * q.stride(0), k.data_ptr(), v.data_ptr(), (int)k.stride(0),
+                                     (int)v.stride(0), Sk * k.stride(0), km, fm, fm_bs, causal ? 1 : 0, out.data_ptr(), (int)(H * hd), nullptr, MMAMD_F32,
+                                     nullptr, (int)B, (int)Sq, (int)Sk, (int)H, (int)hd, 1.0f / std::sqrt((float)hd), cur_stream(q)),
+               "mmamd_attention_x_fwd");
+  return out;
+}
+Tensor attn_x_meta(const Tensor& q, const Tensor&, const Tensor&, int64_t B, int64_t Sq, int64_t, int64_t H, int64_t hd, bool, const optional<Tensor>&,
+                   const optional<Tensor>&, bool) {
+  return at::empty({B * Sq, H * hd}, q.options());
+}
+
+// CoCaTextEmbeddings: table[ids] + pos (+ the CLS row cls + pos[S]) -> fp32 [B*(S (+1)), d]
+Tensor coca_text_embed_impl(const Tensor& ids, const Tensor& table, const Tensor& pos, const optional<Tensor>& cls) {
+  chk(ids, "ids", at::kLong);
+  TORCH_CHECK(ids.dim() == 2 && table.dim() == 2, "mmamd::coca_text_embed: ids [B,S] and table [vocab,d] expected");
+  const Tensor tb = f32v(table), p = f32v(pos);
+  Tensor c;
+  if (cls.has_value()) c = f32v(*cls);
+  const int64_t B = ids.size(0), S = ids.size(1), d = tb.size(1);
+  TORCH_CHECK(p.numel() >= (S + (c.defined() ? 1 : 0)) * d, "mmamd::coca_text_embed: fewer position rows than tokens");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(ids.device());
+  Tensor x = at::empty({B * (S + (c.defined() ? 1 : 0)), d}, tb.options());
+  check_status(mmamd_coca_text_embed(ids.data_ptr<int64_t>(), tb.data_ptr<float>(), p.data_ptr<float>(), c.defined() ? c.data_ptr<float>() : nullptr,
+                                     x.data_ptr<float>(), (int)B, (int)S, (int)d, (int)tb.size(0), cur_stream(ids)), "mmamd_coca_text_embed");
+  return x;
+}
+Tensor coca_text_embed_meta(const Tensor& ids, const Tensor& table, const Tensor&, const optional<Tensor>& cls) {
+  return at::empty({ids.size(0) * (ids.size(1) + (cls.has_value() ? 1 : 0)), table.size(1)}, table.options().dtype(at::kFloat));
+}
+
+// CoCaTextDecoder.build_mask as uint8 [B, S+1, S+1]: src = int64 token ids (use_pad_id: keep = id != pad_id) or a padding mask (keep = value != 0)
+Tensor coca_text_mask_impl(const Tensor& src, bool use_pad_id, int64_t pad_id) {
+  chk(src, "mask source");
+  TORCH_CHECK(src.dim() == 2, "mmamd::coca_text_mask: [B, S] ids or padding mask expected");
+  int kind = 0;
+  if (use_pad_id) {
+    TORCH_CHECK(src.scalar_type() == at::kLong, "mmamd::coca_text_mask: token ids must be int64");
+  } else {
+    const auto t = src.scalar_type();
+    kind = t == at::kFloat ? 1 : t == at::kLong ? 2 : (t == at::kByte || t == at::kBool) ? 3 : -1;
+    TORCH_CHECK(kind > 0, "mmamd::coca_text_mask: unsupported mask dtype ", t);
+  }
+  const int64_t B = src.size(0), S = src.size(1);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(src.device());
+  Tensor out = at::empty({B, S + 1, S + 1}, src.options().dtype(at::kByte));
+  check_status(mmamd_coca_text_mask(src.data_ptr(), kind, use_pad_id ? pad_id : 0, out.data_ptr<uint8_t>(), (int)B, (int)S, cur_stream(src)),
+               "mmamd_coca_text_mask");
+  return out;
+}
+Tensor coca_text_mask_meta(const Tensor& src, bool, int64_t) {
+  return at::empty({src.size(0), src.size(1) + 1, src.size(1) + 1}, src.options().dtype(at::kByte));
+}
+
+// exact-fp32 rows @ W^T + bias (pooled projections: one row per sample)
+Tensor rows_linear_f32_impl(const Tensor& x, const Tensor& weight, const optional<Tensor>& bias) {
+  chk(x, "x", at::kFloat);
+  TORCH_CHECK(x.dim() == 2 && weight.dim() == 2 && x.size(1) == weight.size(1), "mmamd::rows_linear_f32: x [B,d] and weight [E,d] expected");
+  const Tensor w = f32v(weight);
+  Tensor b;
+  if (bias.has_value()) b = f32v(*bias);
+  const int64_t B = x.size(0), d = x.size(1), E = w.size(0);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+  Tensor out = at::empty({B, E}, x.options());
+  check_status(mmamd_rows_linear_f32(x.data_ptr<float>(), d, w.data_ptr<float>(), b.defined() ? b.data_ptr<float>() : nullptr, 0, out.data_ptr<float>(),
+                                     (int)B, (int)d, (int)E, cur_stream(x)), "mmamd_rows_linear_f32");
+  return out;
+}
+Tensor rows_linear_f32_meta(const Tensor& x, const Tensor& weight, const optional<Tensor>&) { return at::empty({x.size(0), weight.size(0)}, x.options()); }
+
 int64_t abi_version_impl() { return mmamd_abi_version(); }
 
 }  // namespace
@@ -309,6 +437,12 @@ TORCH_LIBRARY(mmamd, m) {
   m.def("l2_normalize(Tensor x, float eps) -> Tensor");
   m.def("clamp_scalar_(Tensor(a!) p, float? lo, float? hi) -> ()");
   m.def("activation(Tensor x, int act) -> Tensor");
+  m.def("image_embed(Tensor img, Tensor conv_w, Tensor conv_b, Tensor? cls, Tensor pos, int patch) -> Tensor");
+  m.def("attn_x(Tensor q, Tensor k, Tensor v, int B, int Sq, int Sk, int H, int head_dim, bool causal, Tensor? key_mask, Tensor? full_mask, "
+        "bool shared_q) -> Tensor");
+  m.def("coca_text_embed(Tensor ids, Tensor table, Tensor pos, Tensor? cls) -> Tensor");
+  m.def("coca_text_mask(Tensor src, bool use_pad_id, int pad_id) -> Tensor");
+  m.def("rows_linear_f32(Tensor x, Tensor weight, Tensor? bias) -> Tensor");
   m.def("contrastive_fwd(Tensor a, Tensor b, Tensor a_all, Tensor b_all, Tensor logit_scale, int label_offset, Tensor? mask, "
         "float label_smoothing, int reduction) -> (Tensor, Tensor, Tensor)");
 }
@@ -325,6 +459,11 @@ TORCH_LIBRARY_IMPL(mmamd, CUDA, m) {  // the "CUDA" dispatch key is the HIP devi
   m.impl("l2_normalize", l2_normalize_impl);
   m.impl("clamp_scalar_", clamp_scalar_impl);
   m.impl("activation", activation_impl);
+  m.impl("image_embed", image_embed_impl);
+  m.impl("attn_x", attn_x_impl);
+  m.impl("coca_text_embed", coca_text_embed_impl);
+  m.impl("coca_text_mask", coca_text_mask_impl);
+  m.impl("rows_linear_f32", rows_linear_f32_impl);
   m.impl("contrastive_fwd", contrastive_fwd_impl);
 }
 
@@ -340,5 +479,10 @@ TORCH_LIBRARY_IMPL(mmamd, Meta, m) {
   m.impl("l2_normalize", same_meta);
   m.impl("clamp_scalar_", clamp_scalar_meta);
   m.impl("activation", activation_meta);
+  m.impl("image_embed", image_embed_meta);
+  m.impl("attn_x", attn_x_meta);
+  m.impl("coca_text_embed", coca_text_embed_meta);
+  m.impl("coca_text_mask", coca_text_mask_meta);
+  m.impl("rows_linear_f32", rows_linear_f32_meta);
   m.impl("contrastive_fwd", contrastive_fwd_meta);
 }

@@ -6,7 +6,6 @@ MI355X execution: ViT (no CLS row) -> attention pooler(s) (batch-shared learned 
 L2 normalise; causal text decoder with the padding-aware CLS mask on a second HIP stream; multimodal decoder with
 cross-attention; vocabulary GEMM; captioning cross entropy (ignore_index = pad) and the contrastive loss kernels.
 """
-from __future__ import annotations
 
 import math
 from functools import partial
@@ -15,7 +14,7 @@ from typing import Any, Callable, Dict, List, NamedTuple, Optional, Tuple, Union
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedCache, PackedModeMixin
 from ...modules.encoders.vision_transformer import vision_transformer
 from ...modules.layers.attention_pooler import AttentionPooler, CascadedAttentionPooler
@@ -25,6 +24,9 @@ from ...modules.losses.flava import cls_linear
 from ..._autograd import CrossEntropyFn, L2NormalizeFn, wants_grad
 from .multimodal_decoder import CoCaMultimodalDecoder
 from .text_decoder import CoCaTextDecoder
+
+
+_torch_ops.try_load()
 
 
 class MultimodalOutput(NamedTuple):
@@ -56,6 +58,38 @@ class CoCaModel(PackedModeMixin, nn.Module):
         self._packed = PackedCache()
 
     def forward(self, images: Tensor, texts: Tensor, text_padding_mask: Optional[Tensor] = None) -> MultimodalOutput:
+        if torch.jit.is_scripting():
+            return self._forward_ops(images, texts, text_padding_mask)
+        else:
+            return self._forward_host(images, texts, text_padding_mask)
+
+    def _forward_ops(self, images: Tensor, texts: Tensor, text_padding_mask: Optional[Tensor]) -> MultimodalOutput:
+        """The forward through the dispatcher ops (torch.ops.mmamd.*, csrc/torch_ops.cpp) — what torch.jit.script sees (reference:
+        tests/models/coca/test_coca_model.py:146-154 scripts the model) and what torch.compile traces.  Inference, one stream; the same
+        kernels as the eager forward (the stacked q|k|v projections of the decoders run as three GEMMs)."""
+        pooled_text_embeddings, text_tokens = self.text_decoder(texts, text_padding_mask)
+        contrastive_text_embeddings = torch.ops.mmamd.l2_normalize(pooled_text_embeddings, 1e-12)
+        image_embeddings = self.vision_encoder(images).last_hidden_state
+        assert image_embeddings is not None, "Image embeddings must be Tensor"
+        pooled_outputs = self.vision_pooler(image_embeddings)
+        if isinstance(pooled_outputs, list):
+            assert len(pooled_outputs) == 2
+            captioning_image_embeddings, contrastive = pooled_outputs[0], pooled_outputs[1]
+            B, nq, D = contrastive.size(0), contrastive.size(1), contrastive.size(2)
+            proj = torch.ops.mmamd.rows_linear_f32(contrastive.contiguous().view(B * nq, D), self.vision_proj.weight, self.vision_proj.bias)
+            contrastive_image_embeddings = torch.ops.mmamd.l2_normalize(proj, 1e-12).view(B, nq, -1)
+        else:
+            assert isinstance(pooled_outputs, Tensor), "Pooled image embeddings must be Tensor"
+            captioning_image_embeddings = pooled_outputs[:, 1:]
+            proj = torch.ops.mmamd.rows_linear_f32(pooled_outputs[:, 0].contiguous(), self.vision_proj.weight, self.vision_proj.bias)
+            contrastive_image_embeddings = torch.ops.mmamd.l2_normalize(proj, 1e-12)
+        multimodal_embeddings = self.multimodal_decoder(text_tokens, captioning_image_embeddings)
+        return MultimodalOutput(contrastive_image_embeddings, contrastive_text_embeddings, multimodal_embeddings)
+
+    @torch.jit.unused
+    def _forward_host(self, images: Tensor, texts: Tensor, text_padding_mask: Optional[Tensor] = None) -> MultimodalOutput:
+        if torch.compiler.is_compiling() and not wants_grad(self):
+            return self._forward_ops(images, texts, text_padding_mask)
         training = wants_grad(self)
         l2n = L2NormalizeFn.apply if training else ops.l2_normalize
         dev = images.device

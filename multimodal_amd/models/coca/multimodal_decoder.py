@@ -1,17 +1,19 @@
 """Host-side mirror of torchmultimodal/models/coca/multimodal_decoder.py:14-108 (CoCaMultimodalDecoder): causal transformer
 decoder over the text tokens that cross-attends to the captioning image embeddings, then the (vocabulary) output projection —
 one bf16 MFMA GEMM with fp32 logits."""
-from __future__ import annotations
 
 from typing import Callable, Optional
 
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedCache
 from ...modules.layers.transformer import TransformerDecoder
 from ...utils.attention import get_causal_attention_mask
+
+
+_torch_ops.try_load()
 
 
 class CoCaMultimodalDecoder(nn.Module):
@@ -32,6 +34,31 @@ class CoCaMultimodalDecoder(nn.Module):
         self._packed = PackedCache()
 
     def forward(self, texts: Tensor, images: Tensor) -> Tensor:
+        if torch.jit.is_scripting():
+            return self._forward_ops(texts, images)
+        else:
+            return self._forward_host(texts, images)
+
+    def _forward_ops(self, texts: Tensor, images: Tensor) -> Tensor:
+        """The forward through the dispatcher ops — what torch.jit.script / torch.compile see (inference)."""
+        seq_len = texts.size(1)
+        assert self.causal_mask.size(0) == seq_len and self.causal_mask.size(1) == seq_len
+        hidden_states = self.transformer_decoder._forward_ops(texts, images, True, None, False).last_hidden_state
+        assert hidden_states is not None, "hidden states must not be None"
+        proj = self.output_projection
+        if proj is None:
+            return hidden_states
+        B, S, d = hidden_states.size(0), hidden_states.size(1), hidden_states.size(2)
+        V = proj.weight.size(0)
+        if V % 8 != 0:
+            raise RuntimeError("scripted CoCaMultimodalDecoder on the MI355X path: output_dim must be a multiple of 8 (the eager forward pads it)")
+        h = torch.ops.mmamd.convert(hidden_states.contiguous().view(B * S, d), 1)
+        return torch.ops.mmamd.gemm_bf16(h, proj.weight, None, None, 0, 0).view(B, S, V)
+
+    @torch.jit.unused
+    def _forward_host(self, texts: Tensor, images: Tensor) -> Tensor:
+        if torch.compiler.is_compiling() and not torch.is_grad_enabled() and (self.output_projection is None or self.output_projection.out_features % 8 == 0):
+            return self._forward_ops(texts, images)
         seq_len = texts.shape[1]
         assert self.causal_mask.shape == (seq_len, seq_len)
         # the registered causal_mask buffer IS lower-triangular: the kernel's causal flag skips the key tiles above the diagonal

@@ -2,17 +2,19 @@
 
 Token gather + CLS row + position add is one kernel (coca_text_embed_kernel); the padding-aware causal mask of
 `build_mask` is produced directly as the uint8 [B, S, S] mask the attention kernel reads (coca_text_mask_kernel)."""
-from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedCache
 from ...modules.layers.transformer import TransformerDecoder
 from ...utils.attention import get_causal_attention_mask
+
+
+_torch_ops.try_load()
 
 
 class CoCaTextEmbedFn(torch.autograd.Function):
@@ -69,7 +71,28 @@ class CoCaTextEmbeddings(nn.Module):
             nn.init.constant_(self.cls_embedding, 0.01)
 
     def forward(self, input_ids: Tensor) -> Tensor:
+        if torch.jit.is_scripting():
+            return self._forward_ops(input_ids)
+        else:
+            return self._forward_host(input_ids)
+
+    def _forward_ops(self, input_ids: Tensor) -> Tensor:
+        """The forward through the dispatcher op (torch.ops.mmamd.coca_text_embed) — what torch.jit.script / torch.compile see."""
+        B = input_ids.size(0)
+        cls: Optional[Tensor] = None
+        T = self.num_positions
+        if self.cls_embedding is not None:
+            cls = self.cls_embedding
+            T = self.num_positions - 1
+        assert input_ids.size(1) == T
+        x = torch.ops.mmamd.coca_text_embed(input_ids.contiguous(), self.token_embeddings.weight, self.position_embeddings, cls)
+        return x.view(B, -1, x.size(1))
+
+    @torch.jit.unused
+    def _forward_host(self, input_ids: Tensor) -> Tensor:
         assert input_ids.shape[1] == (self.num_positions if self.cls_embedding is None else self.num_positions - 1)
+        if torch.compiler.is_compiling() and not (self.training and torch.is_grad_enabled() and self.token_embeddings.weight.requires_grad):
+            return self._forward_ops(input_ids)
         pk, f32 = self._packed.get, torch.float32
         ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
         if self.training and torch.is_grad_enabled() and self.token_embeddings.weight.requires_grad:
@@ -96,6 +119,7 @@ class CoCaTextDecoder(nn.Module):
                                                       layer_norm_eps=layer_norm_eps, norm_first=norm_first, use_cross_attention=False)
         if final_layer_norm_eps is not None:
             self.ln_final = nn.LayerNorm(normalized_shape=embedding_dim, eps=final_layer_norm_eps)
+        self._ln_final_eps: float = final_layer_norm_eps if final_layer_norm_eps is not None else 0.0
         self.text_projection = nn.Linear(embedding_dim, output_dim, bias=False)
         self.register_buffer("causal_mask", get_causal_attention_mask(num_positions).to(dtype=torch.bool), persistent=False)
         self.init_parameters(embedding_dim, n_layer)
@@ -127,6 +151,44 @@ class CoCaTextDecoder(nn.Module):
         return ops.AttnMask(full=full)
 
     def forward(self, input_ids: Tensor, padding_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if torch.jit.is_scripting():
+            return self._forward_ops(input_ids, padding_mask)
+        else:
+            return self._forward_host(input_ids, padding_mask)
+
+    def _forward_ops(self, input_ids: Tensor, padding_mask: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+        """The forward through the dispatcher ops — what torch.jit.script / torch.compile see (inference; embed_cls decoders)."""
+        if not self.embed_cls:
+            raise RuntimeError("CoCaTextDecoder(embed_cls=False) is not implemented on the MI355X path")
+        if input_ids.size(1) == self.num_positions:
+            input_ids = input_ids[:, :-1]
+        if padding_mask is not None:
+            if padding_mask.size(1) == self.num_positions:
+                padding_mask = padding_mask[:, :-1]
+        assert input_ids.size(1) == self.num_positions - 1
+        ids = input_ids.contiguous()
+        embeddings = self.embeddings(ids)
+        full: Optional[Tensor] = None
+        pad_idx = self.pad_idx
+        if pad_idx is not None:  # the padding-aware causal mask of build_mask (uint8 [B, S+1, S+1]); else plain causal
+            if padding_mask is None:
+                full = torch.ops.mmamd.coca_text_mask(ids, True, pad_idx)
+            else:
+                full = torch.ops.mmamd.coca_text_mask(padding_mask.contiguous(), False, 0)
+        hidden_states = self.transformer_decoder._forward_ops(embeddings, None, full is None, full, False).last_hidden_state
+        assert hidden_states is not None, "hidden states must not be None"
+        B, S, d = hidden_states.size(0), hidden_states.size(1), hidden_states.size(2)
+        tokens = hidden_states[:, :-1]
+        pooled = hidden_states[:, S - 1].contiguous()  # the B CLS rows (data movement)
+        if hasattr(self, "ln_final"):
+            pooled = torch.ops.mmamd.layernorm(pooled, self.ln_final.weight, self.ln_final.bias, self._ln_final_eps, 0)
+        pooled = torch.ops.mmamd.rows_linear_f32(pooled, self.text_projection.weight, None)
+        return pooled, tokens
+
+    @torch.jit.unused
+    def _forward_host(self, input_ids: Tensor, padding_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if torch.compiler.is_compiling() and self.embed_cls and not torch.is_grad_enabled():
+            return self._forward_ops(input_ids, padding_mask)
         if self.embed_cls:
             if input_ids.shape[1] == self.num_positions:
                 input_ids = input_ids[:, :-1]

@@ -1,6 +1,5 @@
 """Host-side mirror of torchmultimodal/modules/encoders/vision_transformer.py:19-263 (VisionTransformer, GlobalAveragePooler,
 vision_transformer and the vit_* factories) — CoCa's image tower."""
-from __future__ import annotations
 
 from typing import Any, Callable, Optional, Tuple, Union
 

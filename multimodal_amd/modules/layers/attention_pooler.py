@@ -2,15 +2,16 @@
 
 The learned queries are the same for every sample: LayerNorm and the q projection run ONCE on [n_queries, d] and the attention
 kernel reads them with batch stride 0 (the reference materialises `query.repeat(batch, 1, 1)` and projects B copies)."""
-from __future__ import annotations
 
 from typing import List
 
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedCache
+
+_torch_ops.try_load()
 from .multi_head_attention import MultiHeadAttentionWithCache
 
 
@@ -22,11 +23,33 @@ class AttentionPooler(nn.Module):
         self.ln_q = nn.LayerNorm(output_embed_dim, layer_norm_eps)
         self.ln_k = nn.LayerNorm(input_embed_dim, layer_norm_eps)
         self.ln_post = nn.LayerNorm(output_embed_dim, layer_norm_eps)
+        self._ln_eps: float = layer_norm_eps  # (nn.LayerNorm.eps is a TorchScript constant of the LayerNorm, not readable from here)
         self._packed = PackedCache()
 
     def forward(self, x: Tensor) -> Tensor:
+        if torch.jit.is_scripting():
+            return self._forward_ops(x)
+        else:
+            return self._forward_host(x)
+
+    def _forward_ops(self, x: Tensor) -> Tensor:
+        """The forward through the dispatcher ops — what torch.jit.script / torch.compile see (inference)."""
+        if x.dim() != 3 or x.dtype != torch.float32:
+            raise RuntimeError("AttentionPooler on the MI355X path takes fp32 [batch, seq_len, input_embed_dim] tensors")
+        B, S, din = x.size(0), x.size(1), x.size(2)
+        nq, dout = self.query.size(0), self.query.size(1)
+        k = torch.ops.mmamd.layernorm(x.contiguous().view(B * S, din), self.ln_k.weight, self.ln_k.bias, self._ln_eps, 1)
+        q = torch.ops.mmamd.layernorm(torch.ops.mmamd.packed(self.query, 0), self.ln_q.weight, self.ln_q.bias, self._ln_eps, 1)
+        out = self.attn._run_ops(q, k, k, B, nq, S, False, None, None, True)
+        out = torch.ops.mmamd.layernorm(out, self.ln_post.weight, self.ln_post.bias, self._ln_eps, 0)
+        return out.view(B, nq, dout)
+
+    @torch.jit.unused
+    def _forward_host(self, x: Tensor) -> Tensor:
         if x.dim() != 3 or x.dtype != torch.float32:
             raise ops.MmamdError("AttentionPooler on the MI355X path takes fp32 [batch, seq_len, input_embed_dim] tensors")
+        if torch.compiler.is_compiling() and not (torch.is_grad_enabled() and (x.requires_grad or (self.training and self.query.requires_grad))):
+            return self._forward_ops(x)
         B, S, din = x.shape
         if torch.is_grad_enabled() and (x.requires_grad or (self.training and self.query.requires_grad)):
             # differentiable path: LayerNorm / cross-attention nodes with HIP forward and backward (queries shared by the batch)

@@ -4,16 +4,17 @@ Same constructor, same `model` nn.Sequential (so state_dict keys are `model.0.we
 construction consumes the RNG identically).  forward() does not run the Sequential: every Linear is one bf16 MFMA GEMM
 (csrc/gemm.hip) with the bias and the FOLLOWING activation fused into its epilogue.
 """
-from __future__ import annotations
 
 from typing import Callable, List, Optional, Union
 
 import torch
 from torch import nn
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedCache
 from .activation import SiLU
+
+_torch_ops.try_load()
 
 
 ACT_RELU_EXACT = -1  # plan() code of nn.ReLU: no GEMM epilogue has it; MLPs that use it (classifier heads) run the exact-fp32 row path
@@ -57,6 +58,11 @@ class MLP(nn.Module):
         layers.append(nn.Linear(in_dim, out_dim))
         self.model = nn.Sequential(*layers)
         self._packed = PackedCache()
+        # what the scripted forward needs to know statically: the GEMM-epilogue code of the activation (-2: none of the kernels', -1: nn.ReLU
+        # = exact-fp32 row path, eager only; -3: a normalization inside the MLP) and the number of Linear layers
+        code = fused_activation_code(activation()) if len(hidden_dims) > 0 else ops.ACT_NONE
+        self._act_code: int = -3 if normalization else (-2 if code is None else int(code))
+        self._n_linear: int = len(hidden_dims) + 1
 
     def plan(self):
         """[(linear, activation code)] — raises for module sequences the GEMM epilogues cannot express."""
@@ -103,6 +109,36 @@ class MLP(nn.Module):
     EXACT_ROWS_MAX = 8192
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.jit.is_scripting():
+            return self._forward_ops(x)
+        else:
+            return self._forward_host(x)
+
+    def _run_ops(self, h: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
+        """run() through the dispatcher ops (torch.ops.mmamd.*): h bf16 [M, in_dim] -> fp32 [M, out_dim] (+ residual)."""
+        if self._act_code < 0:
+            raise RuntimeError("scripted MLP on the MI355X path: nn.GELU / SiLU MLPs without normalization only (nn.ReLU heads use the eager forward)")
+        i = 0
+        for m in self.model:
+            if hasattr(m, "weight"):  # the Linear layers (statically resolved per module of the Sequential)
+                i += 1
+                if i < self._n_linear:
+                    h = torch.ops.mmamd.gemm_bf16(h, m.weight, m.bias, None, self._act_code, 1)
+                else:
+                    h = torch.ops.mmamd.gemm_bf16(h, m.weight, m.bias, residual, 0, 0)
+        return h
+
+    def _forward_ops(self, x: torch.Tensor) -> torch.Tensor:
+        d = x.size(-1)
+        h = torch.ops.mmamd.convert(x.contiguous().view(-1, d), 1)
+        y = self._run_ops(h, None)
+        shape = x.size()[:-1] + [y.size(1)]
+        return y.view(shape)
+
+    @torch.jit.unused
+    def _forward_host(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.compiler.is_compiling() and self._act_code >= 0 and not (torch.is_grad_enabled() and x.requires_grad):
+            return self._forward_ops(x)
         steps = self.plan()
         xc = x if x.is_contiguous() else x.contiguous()
         rows = xc.view(-1, xc.shape[-1])

@@ -6,7 +6,6 @@ the MI355X: one GEMM for the stacked projections (q|k|v for self-attention, k|v 
 the general MFMA attention kernel (csrc/attention.hip: attention_x_kernel — Sq != Sk, 64- or 96-wide heads, causal / padding /
 full boolean masks, batch-shared queries), one GEMM for the output projection with the residual add in its epilogue.
 """
-from __future__ import annotations
 
 from typing import NamedTuple, Optional, Tuple, Union
 
@@ -101,13 +100,22 @@ class MultiHeadSelfAttention(nn.Module):
         if query.dim() != 3:
             raise RuntimeError("MultiHeadSelfAttention takes bsz x seq_len x embed_dim inputs")
         B, S, d = query.size(0), query.size(1), query.size(2)
-        if d != 64 * self.num_heads:
-            raise RuntimeError("scripted MultiHeadSelfAttention on the MI355X path is built for 64-wide heads")
+        if d != 64 * self.num_heads and d != 96 * self.num_heads:
+            raise RuntimeError("the MI355X attention kernels are built for 64- and 96-wide heads")
         x = torch.ops.mmamd.convert(query.contiguous().view(B * S, d), 1)
-        qkv = torch.ops.mmamd.gemm_bf16(x, self.input_proj.weight, self.input_proj.bias, None, 0, 1)
-        att = torch.ops.mmamd.attn_fwd(qkv, B, S, self.num_heads, is_causal)
-        out = torch.ops.mmamd.gemm_bf16(att, self.output_proj.weight, self.output_proj.bias, None, 0, 0)
-        return out.view(B, S, d)
+        return self._run_ops(x, B, S, is_causal, None).view(B, S, d)
+
+    def _run_ops(self, hn: Tensor, B: int, S: int, is_causal: bool, residual: Optional[Tensor]) -> Tensor:
+        """run() through the dispatcher ops: hn bf16 [B*S, d] -> fp32 [B*S, d] = output_proj(attention) (+ residual)."""
+        d = self.output_proj.in_features
+        H = self.num_heads
+        hd = d // H
+        qkv = torch.ops.mmamd.gemm_bf16(hn, self.input_proj.weight, self.input_proj.bias, None, 0, 1)
+        if hd == 64:
+            att = torch.ops.mmamd.attn_fwd(qkv, B, S, H, is_causal)
+        else:
+            att = torch.ops.mmamd.attn_x(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, is_causal, None, None, False)
+        return torch.ops.mmamd.gemm_bf16(att, self.output_proj.weight, self.output_proj.bias, residual, 0, 0)
 
     @torch.jit.unused
     def _forward_host(self, query: Tensor, attn_mask: Optional[Tensor] = None, is_causal: bool = False) -> Tensor:
@@ -187,6 +195,53 @@ class MultiHeadAttentionWithCache(nn.Module):
     def forward(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor] = None,
                 past_key_value: Optional[Tuple[Tensor, Tensor]] = None, is_causal: bool = False, use_cache: bool = False
                 ) -> Union[Tensor, MHAWithCacheOutput]:
+        if torch.jit.is_scripting():
+            return self._forward_ops(query, key, value, attn_mask, past_key_value, is_causal, use_cache)
+        else:
+            return self._forward_host(query, key, value, attn_mask, past_key_value, is_causal, use_cache)
+
+    def _run_ops(self, q_in: Tensor, k_in: Tensor, v_in: Tensor, B: int, Sq: int, Sk: int, is_causal: bool, full_mask: Optional[Tensor],
+                 residual: Optional[Tensor], shared_q: bool) -> Tensor:
+        """run() through the dispatcher ops (no key/value cache): q_in bf16 [B*Sq, dq] ([Sq, dq] when shared_q), k_in / v_in bf16 [B*Sk, dkv]
+        -> fp32 [B*Sq, dq] = output_proj(attention) (+ residual).  Three projection GEMMs instead of the eager path's stacked one: the same
+        arithmetic per output element."""
+        dq = self.q_proj.out_features
+        H = self.num_heads
+        hd = dq // H
+        if hd * H != dq or (hd != 64 and hd != 96):
+            raise RuntimeError("the MI355X attention kernels are built for 64- and 96-wide heads")
+        q = torch.ops.mmamd.gemm_bf16(q_in, self.q_proj.weight, self.q_proj.bias, None, 0, 1)
+        k = torch.ops.mmamd.gemm_bf16(k_in, self.k_proj.weight, self.k_proj.bias, None, 0, 1)
+        v = torch.ops.mmamd.gemm_bf16(v_in, self.v_proj.weight, self.v_proj.bias, None, 0, 1)
+        att = torch.ops.mmamd.attn_x(q, k, v, B, Sq, Sk, H, hd, is_causal, None, full_mask, shared_q)
+        return torch.ops.mmamd.gemm_bf16(att, self.output_proj.weight, self.output_proj.bias, residual, 0, 0)
+
+    def _forward_ops(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor], past_key_value: Optional[Tuple[Tensor, Tensor]],
+                     is_causal: bool, use_cache: bool) -> Tensor:
+        """The forward through the dispatcher ops — what torch.jit.script sees.  Boolean [Sq,Sk] / [B,Sq,Sk] masks (True = attend) or
+        is_causal; incremental decoding (past_key_value / use_cache) needs the eager forward."""
+        if past_key_value is not None or use_cache:
+            raise RuntimeError("scripted MultiHeadAttentionWithCache on the MI355X path has no key/value cache (use the eager forward)")
+        if query.dim() != 3 or key.dim() != 3 or value.dim() != 3 or key.size(0) != query.size(0) or key.size(1) != value.size(1):
+            raise RuntimeError("MultiHeadAttentionWithCache takes bsz x seq_len x dim tensors with a common bsz")
+        B, Sq, dq = query.size(0), query.size(1), query.size(2)
+        Sk = key.size(1)
+        full: Optional[Tensor] = None
+        if attn_mask is not None:
+            if is_causal:
+                raise RuntimeError("attn_mask must be None when is_causal=True")
+            if attn_mask.dtype != torch.bool or attn_mask.numel() not in (Sq * Sk, B * Sq * Sk):
+                raise RuntimeError("attention masks on the MI355X path are boolean [Sq,Sk] / [B,Sq,Sk] (True = attend)")
+            full = attn_mask.contiguous().to(torch.uint8)  # mask plumbing
+        q_in = torch.ops.mmamd.convert(query.contiguous().view(B * Sq, dq), 1)
+        k_in = torch.ops.mmamd.convert(key.contiguous().view(B * Sk, key.size(2)), 1)
+        v_in = torch.ops.mmamd.convert(value.contiguous().view(B * Sk, value.size(2)), 1)
+        return self._run_ops(q_in, k_in, v_in, B, Sq, Sk, is_causal, full, None, False).view(B, Sq, dq)
+
+    @torch.jit.unused
+    def _forward_host(self, query: Tensor, key: Tensor, value: Tensor, attn_mask: Optional[Tensor] = None,
+                      past_key_value: Optional[Tuple[Tensor, Tensor]] = None, is_causal: bool = False, use_cache: bool = False
+                      ) -> Union[Tensor, MHAWithCacheOutput]:
         if key is not value:
             raise ops.MmamdError("key and value must be the same tensor on the MI355X path (self- or cross-attention)")
         if key.size(0) != query.size(0):

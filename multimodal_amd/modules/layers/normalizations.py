@@ -25,6 +25,11 @@ class Fp32LayerNorm(nn.LayerNorm):
         else:
             return self._forward_host(x)
 
+    def _ln_ops(self, x: Tensor, out_dtype: int) -> Tensor:
+        """LayerNorm of fp32 / bf16 rows through the dispatcher op with an explicit output dtype code (0 = fp32, 1 = bf16: the operand of
+        the next GEMM) — for the scripted forwards of the enclosing layers (`eps` is a TorchScript constant of THIS module)."""
+        return torch.ops.mmamd.layernorm(x, self.weight, self.bias, self.eps, out_dtype)
+
     @torch.jit.unused
     def _forward_host(self, x: Tensor) -> Tensor:
         if self.weight is None or self.bias is None or len(self.normalized_shape) != 1:

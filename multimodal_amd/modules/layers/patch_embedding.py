@@ -1,7 +1,6 @@
 """Host-side mirror of torchmultimodal/modules/layers/patch_embedding.py:17-152 (PatchEmbeddings, PatchEmbeddingsOutput).
 Conv2d(kernel = stride = patch) = im2col (patchify_kernel) + one MFMA GEMM with the conv bias; mask-token blend, optional CLS
 row and position embeddings are one row kernel (flava_image_embed_kernel)."""
-from __future__ import annotations
 
 import math
 import warnings
@@ -10,8 +9,10 @@ from typing import NamedTuple, Optional, Tuple, Union
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._packing import PackedCache
+
+_torch_ops.try_load()
 
 
 class PatchEmbeddingsOutput(NamedTuple):
@@ -46,6 +47,7 @@ class PatchEmbeddings(nn.Module):
         else:
             self.mask_token = None
         self.patch_drop_rate = patch_drop_rate
+        self._patch: int = patch_size
         self._packed = PackedCache()
 
     def _init_conv_weights(self) -> None:
@@ -55,6 +57,34 @@ class PatchEmbeddings(nn.Module):
         nn.init.zeros_(self.conv_projection.bias)
 
     def forward(self, pixel_values: Tensor, image_patches_mask: Optional[Tensor] = None) -> PatchEmbeddingsOutput:
+        if torch.jit.is_scripting():
+            return self._forward_ops(pixel_values, image_patches_mask)
+        else:
+            return self._forward_host(pixel_values, image_patches_mask)
+
+    def _forward_ops(self, pixel_values: Tensor, image_patches_mask: Optional[Tensor]) -> PatchEmbeddingsOutput:
+        """The forward through the dispatcher ops (torch.ops.mmamd.image_embed: im2col + GEMM with the conv bias + CLS row + position
+        embeddings) — what torch.jit.script / torch.compile see.  Inference, no patch masking."""
+        if image_patches_mask is not None:
+            raise RuntimeError("scripted PatchEmbeddings on the MI355X path takes no image_patches_mask (use the eager forward)")
+        if pixel_values.dim() != 4 or pixel_values.size(2) != self.image_size[0] or pixel_values.size(3) != self.image_size[1]:
+            raise ValueError("Input image size doesn't match the image size expected by model")
+        if self.image_size[0] != self.image_size[1]:
+            raise RuntimeError("non-square images are not implemented on the MI355X path")
+        B = pixel_values.size(0)
+        cls: Optional[Tensor] = None
+        if hasattr(self, "cls_token"):  # (resolved when the module is scripted: the parameter exists only with include_cls_embed)
+            cls = self.cls_token
+        conv_bias = self.conv_projection.bias
+        assert conv_bias is not None
+        x = torch.ops.mmamd.image_embed(pixel_values.contiguous(), self.conv_projection.weight, conv_bias, cls, self.position_embeddings,
+                                        self._patch)
+        return PatchEmbeddingsOutput(embeddings=x.view(B, -1, x.size(1)))
+
+    @torch.jit.unused
+    def _forward_host(self, pixel_values: Tensor, image_patches_mask: Optional[Tensor] = None) -> PatchEmbeddingsOutput:
+        if torch.compiler.is_compiling() and image_patches_mask is None and not (self.training and torch.is_grad_enabled()):
+            return self._forward_ops(pixel_values, image_patches_mask)
         batch_size, num_channels, height, width = pixel_values.shape
         if height != self.image_size[0] or width != self.image_size[1]:
             raise ValueError(f"Input image size ({height}*{width}) doesn't match image size "

@@ -12,12 +12,15 @@ from typing import Callable, List, NamedTuple, Optional, Tuple
 import torch
 from torch import nn, Tensor
 
-from ... import ops
+from ... import _torch_ops, ops
 from ..._autograd import wants_grad
 from ..._packing import PackedCache
 from .mlp import MLP
 from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask
 from .normalizations import Fp32LayerNorm
+
+
+_torch_ops.try_load()
 
 
 class TransformerOutput(NamedTuple):
@@ -75,6 +78,29 @@ class TransformerEncoderLayer(nn.Module):
         return _ln(pc, self.feedforward_layernorm, ff, f32)
 
     def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
+        if torch.jit.is_scripting():
+            return self._forward_ops(hidden_states, attention_mask)
+        else:
+            return self._forward_host(hidden_states, attention_mask)
+
+    def _layer_ops(self, x: Tensor, B: int, S: int) -> Tensor:
+        """run() through the dispatcher ops (torch.ops.mmamd.*; pre-norm layers, no mask): x fp32 [B*S, d] -> new fp32 [B*S, d]."""
+        if not self.norm_first:
+            raise RuntimeError("scripted TransformerEncoderLayer on the MI355X path: pre-norm layers only (post-norm uses the eager forward)")
+        hn = self.attention_layernorm._ln_ops(x, 1)
+        x1 = self.attention._run_ops(hn, B, S, False, x)
+        return self.feedforward._run_ops(self.feedforward_layernorm._ln_ops(x1, 1), x1)
+
+    def _forward_ops(self, hidden_states: Tensor, attention_mask: Optional[Tensor]) -> Tensor:
+        if attention_mask is not None:
+            raise RuntimeError("scripted TransformerEncoderLayer on the MI355X path takes no attention_mask (use the eager forward)")
+        if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
+            raise RuntimeError("TransformerEncoderLayer on the MI355X path takes fp32 [bsz, seq_len, d_model] tensors")
+        B, S, d = hidden_states.size(0), hidden_states.size(1), hidden_states.size(2)
+        return self._layer_ops(hidden_states.contiguous().view(B * S, d), B, S).view(B, S, d)
+
+    @torch.jit.unused
+    def _forward_host(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
         _forbid_training(self)
         B, S, d = hidden_states.shape
         y = self.run(_f32_rows(hidden_states, "TransformerEncoderLayer"), B, S, to_attn_mask(attention_mask, False, B, S, S))
@@ -98,9 +124,41 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, return_hidden_states: bool = False
                 ) -> TransformerOutput:
+        if torch.jit.is_scripting():
+            return self._forward_ops(hidden_states, attention_mask, return_hidden_states)
+        else:
+            return self._forward_host(hidden_states, attention_mask, return_hidden_states)
+
+    def _forward_ops(self, hidden_states: Tensor, attention_mask: Optional[Tensor], return_hidden_states: bool) -> TransformerOutput:
+        """The forward through the dispatcher ops — what torch.jit.script / torch.compile see (inference, pre-norm, no mask)."""
+        if attention_mask is not None:
+            raise RuntimeError("scripted TransformerEncoder on the MI355X path takes no attention_mask (use the eager forward)")
+        if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
+            raise RuntimeError("TransformerEncoder on the MI355X path takes fp32 [bsz, seq_len, d_model] tensors")
+        B, S, d = hidden_states.size(0), hidden_states.size(1), hidden_states.size(2)
+        x = hidden_states.contiguous().view(B * S, d)
+        all_hidden_states: List[Tensor] = []
+        for layer_module in self.layer:
+            if return_hidden_states:
+                all_hidden_states.append(x.view(B, S, d))
+            x = layer_module._layer_ops(x, B, S)
+        y = x.view(B, S, d)
+        hs: Optional[List[Tensor]] = None
+        if return_hidden_states:
+            all_hidden_states.append(y)
+            hs = all_hidden_states
+        if self.final_layer_norm is not None:
+            y = self.final_layer_norm(y)
+        return TransformerOutput(last_hidden_state=y, hidden_states=hs)
+
+    @torch.jit.unused
+    def _forward_host(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, return_hidden_states: bool = False
+                      ) -> TransformerOutput:
         B, S, d = hidden_states.shape
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
             return self._forward_train(hidden_states, attention_mask, return_hidden_states)
+        if torch.compiler.is_compiling():
+            return self._forward_ops(hidden_states, attention_mask, return_hidden_states)
         x = _f32_rows(hidden_states, "TransformerEncoder")
         mask = to_attn_mask(attention_mask, False, B, S, S)
         all_hidden_states = []
@@ -215,6 +273,52 @@ class TransformerDecoderLayer(nn.Module):
     def forward(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cross_attention_mask: Optional[Tensor] = None, past_key_value: Optional[Tuple[Tensor, Tensor]] = None,
                 use_cache: bool = False) -> Tuple[Tensor, Optional[Tuple[Tensor, Tensor]]]:
+        if torch.jit.is_scripting():
+            return self._forward_ops(hidden_states, encoder_hidden_states, attention_mask, cross_attention_mask, past_key_value, use_cache)
+        else:
+            return self._forward_host(hidden_states, encoder_hidden_states, attention_mask, cross_attention_mask, past_key_value, use_cache)
+
+    def _layer_ops(self, x: Tensor, B: int, S: int, is_causal: bool, full_mask: Optional[Tensor], enc: Optional[Tensor], Sk: int) -> Tensor:
+        """run() through the dispatcher ops (pre-norm, no cache): x fp32 [B*S, d]; full_mask uint8 [B or 1, S, S] (0 = masked) or is_causal;
+        enc bf16 [B*Sk, dim_kv] encoder states or None -> new fp32 [B*S, d]."""
+        if not self.norm_first:
+            raise RuntimeError("scripted TransformerDecoderLayer on the MI355X path: pre-norm layers only (post-norm uses the eager forward)")
+        hn = self.attention_layernorm._ln_ops(x, 1)
+        a = self.attention._run_ops(hn, hn, hn, B, S, S, is_causal, full_mask, x, False)
+        if self.cross_attention is not None:
+            if enc is not None:
+                hc = self.cross_attention_layernorm._ln_ops(a, 1)
+                a = self.cross_attention._run_ops(hc, enc, enc, B, S, Sk, False, None, a, False)
+        return self.feedforward._run_ops(self.feedforward_layernorm._ln_ops(a, 1), a)
+
+    def _forward_ops(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor], attention_mask: Optional[Tensor],
+                     cross_attention_mask: Optional[Tensor], past_key_value: Optional[Tuple[Tensor, Tensor]], use_cache: bool
+                     ) -> Tuple[Tensor, Optional[Tuple[Tensor, Tensor]]]:
+        if past_key_value is not None or use_cache:
+            raise RuntimeError("scripted TransformerDecoderLayer on the MI355X path has no key/value cache (use the eager forward)")
+        if cross_attention_mask is not None:
+            raise RuntimeError("scripted TransformerDecoderLayer on the MI355X path takes no cross_attention_mask")
+        if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
+            raise RuntimeError("TransformerDecoderLayer on the MI355X path takes fp32 [bsz, seq_len, d_model] tensors")
+        B, S, d = hidden_states.size(0), hidden_states.size(1), hidden_states.size(2)
+        enc: Optional[Tensor] = None
+        Sk = 0
+        if encoder_hidden_states is not None:
+            Sk = encoder_hidden_states.size(1)
+            enc = torch.ops.mmamd.convert(encoder_hidden_states.contiguous().view(B * Sk, encoder_hidden_states.size(2)), 1)
+        full: Optional[Tensor] = None
+        if attention_mask is not None:
+            if attention_mask.dtype != torch.bool or attention_mask.numel() not in (S * S, B * S * S):
+                raise RuntimeError("attention masks on the MI355X path are boolean [S,S] / [B,S,S] (True = attend)")
+            full = attention_mask.contiguous().to(torch.uint8)  # mask plumbing
+        y = self._layer_ops(hidden_states.contiguous().view(B * S, d), B, S, False, full, enc, Sk)
+        none_kv: Optional[Tuple[Tensor, Tensor]] = None
+        return y.view(B, S, d), none_kv
+
+    @torch.jit.unused
+    def _forward_host(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
+                      cross_attention_mask: Optional[Tensor] = None, past_key_value: Optional[Tuple[Tensor, Tensor]] = None,
+                      use_cache: bool = False) -> Tuple[Tensor, Optional[Tuple[Tensor, Tensor]]]:
         _forbid_training(self)
         B, S, d = hidden_states.shape
         enc, Sk = None, 0
@@ -247,6 +351,51 @@ class TransformerDecoder(nn.Module):
     def forward(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cross_attention_mask: Optional[Tensor] = None, past_key_values: Optional[List[Tuple[Tensor, Tensor]]] = None,
                 use_cache: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
+        if torch.jit.is_scripting():
+            if past_key_values is not None or use_cache:
+                raise RuntimeError("scripted TransformerDecoder on the MI355X path has no key/value cache (use the eager forward)")
+            full: Optional[Tensor] = None
+            if attention_mask is not None:
+                if attention_mask.dtype != torch.bool:
+                    raise RuntimeError("attention masks on the MI355X path are boolean (True = attend)")
+                full = attention_mask.contiguous().to(torch.uint8)  # mask plumbing
+            return self._forward_ops(hidden_states, encoder_hidden_states, False, full, return_hidden_states)
+        else:
+            return self._forward_host(hidden_states, encoder_hidden_states, attention_mask, cross_attention_mask, past_key_values, use_cache,
+                                      return_hidden_states)
+
+    def _forward_ops(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor], is_causal: bool, full_mask: Optional[Tensor],
+                     return_hidden_states: bool) -> TransformerOutput:
+        """The forward through the dispatcher ops (inference, pre-norm, no cache): self-attention mask = is_causal or a uint8
+        [B or 1, S, S] mask (0 = masked), as CoCa's decoders build them."""
+        if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
+            raise RuntimeError("TransformerDecoder on the MI355X path takes fp32 [bsz, seq_len, d_model] tensors")
+        B, S, d = hidden_states.size(0), hidden_states.size(1), hidden_states.size(2)
+        x = hidden_states.contiguous().view(B * S, d)
+        enc: Optional[Tensor] = None
+        Sk = 0
+        if encoder_hidden_states is not None:
+            if encoder_hidden_states.dim() != 3 or encoder_hidden_states.dtype != torch.float32:
+                raise RuntimeError("TransformerDecoder on the MI355X path takes fp32 [bsz, seq_len, dim_kv] encoder states")
+            Sk = encoder_hidden_states.size(1)
+            enc = torch.ops.mmamd.convert(encoder_hidden_states.contiguous().view(B * Sk, encoder_hidden_states.size(2)), 1)  # once for all layers
+        all_hidden_states: List[Tensor] = []
+        for layer_module in self.layer:
+            if return_hidden_states:
+                all_hidden_states.append(x.view(B, S, d))
+            x = layer_module._layer_ops(x, B, S, is_causal, full_mask, enc, Sk)
+        y = x.view(B, S, d)
+        if return_hidden_states:
+            all_hidden_states.append(y)
+        if self.final_layer_norm is not None:
+            y = self.final_layer_norm(y)
+        kv: List[Tuple[Tensor, Tensor]] = []
+        return TransformerOutput(last_hidden_state=y, hidden_states=all_hidden_states, current_key_values=kv)
+
+    @torch.jit.unused
+    def _forward_host(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
+                      cross_attention_mask: Optional[Tensor] = None, past_key_values: Optional[List[Tuple[Tensor, Tensor]]] = None,
+                      use_cache: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
         B, S, d = hidden_states.shape
         caching = past_key_values is not None or use_cache
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):

@@ -67,6 +67,42 @@ def test_reference_scripted_modules_compile_and_keep_their_errors(ns):
     with pytest.raises((ValueError, torch.jit.Error), match="Expected 3 channels"):
         sv(torch.zeros(1, 1, 32, 32))
     assert "ops.mmamd.l2_normalize" in torch.jit.script(CLIP(vit, txt)).code
-    assert "ops.mmamd.attn_fwd" in torch.jit.script(MultiHeadSelfAttention(128, 2))._forward_ops.code  # reference test_multi_head_attention.py:50-57
+    assert "ops.mmamd.attn_fwd" in torch.jit.script(MultiHeadSelfAttention(128, 2))._run_ops.code  # reference test_multi_head_attention.py:50-57
     assert "ops.mmamd.activation" in torch.jit.script(SiLU()).code
     assert "ops.mmamd.layernorm" in torch.jit.script(Fp32LayerNorm(16)).code
+
+
+def test_coca_model_scripts_through_the_dispatcher_ops(ns):
+    """reference tests/models/coca/test_coca_model.py:146-154 scripts the CoCa model.  Here (no GPU): the whole module tree — ViT, attention
+    pooler(s), text decoder with the padding-aware mask, multimodal decoder with cross-attention — compiles, the graph computes through
+    torch.ops.mmamd.* only, and the Meta kernels carry the reference's output shapes (parallel pooler [B,D], cascaded [B,1,D])."""
+    from multimodal_amd.models.coca.coca_model import coca_vit
+    from tests.golden.make_golden_coca import POOL96, SMALL
+
+    for kw, cascaded in ((SMALL, False), (SMALL, True), (POOL96, False)):
+        scripted = torch.jit.script(coca_vit(**kw, cascaded_pooler=cascaded).eval())
+        assert isinstance(scripted, torch.jit.ScriptModule)
+        graph = str(scripted.inlined_graph)  # every call inlined: the whole forward as one graph
+        for op in ("image_embed", "coca_text_embed", "coca_text_mask", "attn_x", "gemm_bf16", "rows_linear_f32", "l2_normalize", "layernorm"):
+            assert f"mmamd::{op}" in graph, op
+        assert "aten::matmul" not in graph and "aten::linear" not in graph and "aten::softmax" not in graph  # nothing computes outside the kernels
+        m = scripted.to("meta")
+        B, HW, T = 2, kw.get("image_size", 224), kw["num_text_positions"]
+        out = m(torch.empty(B, 3, HW, HW, device="meta"), torch.empty(B, T, dtype=torch.int64, device="meta"))
+        D = kw["pooler_output_embed_dim"]
+        assert out.image_pooled_output.shape == ((B, 1, D) if cascaded else (B, D))
+        assert out.text_pooled_output.shape == (B, kw["text_output_dim"])
+        assert out.multimodal_embeddings.shape == (B, T - 1, kw["multimodal_output_projection_dim"])
+        with pytest.raises(Exception, match="mmamd|CPU|backend"):  # CPU tensors: no kernel for the CPU backend -> loud, no fallback
+            torch.jit.script(coca_vit(**kw, cascaded_pooler=cascaded).eval())(torch.zeros(B, 3, HW, HW), torch.zeros(B, T, dtype=torch.long))
+
+
+def test_meta_kernels_of_the_coca_ops(ns):
+    m = lambda *s, dtype=torch.float32: torch.empty(*s, dtype=dtype, device="meta")  # noqa: E731
+    bf = torch.bfloat16
+    assert ns.image_embed(m(2, 3, 64, 64), m(128, 3, 16, 16), m(128), None, m(1, 16, 128), 16).shape == (32, 128)
+    assert ns.image_embed(m(2, 3, 64, 64), m(128, 3, 16, 16), m(128), m(1, 1, 128), m(1, 17, 128), 16).shape == (34, 128)
+    assert ns.attn_x(m(8, 192, dtype=bf), m(2 * 16, 192, dtype=bf), m(2 * 16, 192, dtype=bf), 2, 8, 16, 2, 96, False, None, None, True).shape == (16, 192)
+    assert ns.coca_text_embed(m(2, 11, dtype=torch.int64), m(96, 128), m(12, 128), m(128)).shape == (24, 128)
+    assert ns.coca_text_mask(m(2, 11, dtype=torch.int64), True, 0).shape == (2, 12, 12)
+    assert ns.rows_linear_f32(m(4, 128), m(64, 128), None).shape == (4, 64)
