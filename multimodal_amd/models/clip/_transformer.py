@@ -126,6 +126,29 @@ class TransformerStack(nn.Module):
         return x
 
 
+def two_stacks_groupable(sa: TransformerStack, Ma: int, sb: TransformerStack, Mb: int, cus: int = 256) -> bool:
+    """Policy of the layer-locked schedule (measured, sustained runs on one box): towers of equal depth, the first one clearly larger, and
+    EVERY projection pair of a layer qualifies for one grouped persistent launch (mmamd_gemm_bf16_grouped: K % 128 == 0 and at
+    least two 256 x 256 tiles per CU in total).  Otherwise some pairs would run as two launches one after the other on the single stream of
+    run_two_stacks and lose the overlap of the two-stream schedule: measured on ViT-B/32 at B = 256 (out-projection and MLP-down: 304 tiles),
+    6.67 ms grouped vs 5.59 ms two streams."""
+    def tiles(M, N):
+        return ((M + 255) // 256) * ((N + 255) // 256)
+
+    # same depth (the towers stay layer-locked to the end: ViT-L/14's upper 12 layers run alone either way, 52.7 ms grouped vs 52.5 two
+    # streams) and a clearly dominant first tower (comparable towers overlap their LayerNorm / attention kernels better on two streams:
+    # ViT-B/32 at B = 512, every pair grouped, 11.9 vs 10.9 ms) -- profiles/r02_two_tower_ab.txt
+    if len(sa.layers) != len(sb.layers) or Ma * sa.d_model < 2 * Mb * sb.d_model:
+        return False
+
+    for (Na, Ka), (Nb, Kb) in (((3 * sa.d_model, sa.d_model), (3 * sb.d_model, sb.d_model)), ((sa.d_model, sa.d_model), (sb.d_model, sb.d_model)),
+                                 ((sa.dim_feedforward, sa.d_model), (sb.dim_feedforward, sb.d_model)),
+                                 ((sa.d_model, sa.dim_feedforward), (sb.d_model, sb.dim_feedforward))):
+        if Ka % 128 != 0 or Kb % 128 != 0 or tiles(Ma, Na) + tiles(Mb, Nb) < 2 * cus:
+            return False
+    return True
+
+
 def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, causal_a: bool, sb: TransformerStack, xb: torch.Tensor, Bb: int,
                    Sb: int, causal_b: bool):
     """Both towers of a dual encoder, layer-locked on ONE stream: layer i of tower A and layer i of tower B are independent until the loss

@@ -16,7 +16,7 @@ from ...utils.common import load_module_from_url
 from . import _train
 from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
-from ._transformer import run_two_stacks
+from ._transformer import run_two_stacks, two_stacks_groupable
 
 
 _torch_ops.try_load()
@@ -157,11 +157,13 @@ class CLIP(PackedModeMixin, nn.Module):
 
     @torch.jit.unused
     def _grouped_towers(self, tower_a, features_a, features_b) -> bool:
-        """The grouped two-tower schedule applies to the CLIP pair of this package (ViT + text transformer) in inference; any other
-        encoder pair keeps the tower-agnostic path.  MMAMD_TWO_TOWER=streams selects the two-stream schedule instead."""
+        """The grouped two-tower schedule applies to the CLIP pair of this package (ViT + text transformer) in inference, at sizes where every
+        projection pair of a layer qualifies for one grouped launch (ViT-B/16 and L/14 at B = 256; not B/32, not small batches); any other
+        encoder pair or size keeps the tower-agnostic two-stream path.  MMAMD_TWO_TOWER=streams / grouped force one of the two."""
         import os
 
-        if os.environ.get("MMAMD_TWO_TOWER", "grouped") != "grouped":
+        mode = os.environ.get("MMAMD_TWO_TOWER", "auto")  # auto | grouped (whenever the encoder pair allows it) | streams
+        if mode == "streams":
             return False
         if type(self.encoder_a) is not CLIPViTEncoder or type(self.encoder_b) is not CLIPTextEncoder:
             return False
@@ -174,9 +176,19 @@ class CLIP(PackedModeMixin, nn.Module):
             return False  # hooks observe the encoders' own forward calls
         if features_b.size(1) != tb.context_length:
             return False  # (the encoder's forward raises the reference's error)
+        g = va.image_size // va.patch_size
         if tower_a is va:
-            return features_a.dim() == 4 and features_a.size(1) == 3 and features_a.size(2) == va.image_size and features_a.size(3) == va.image_size
-        return tower_a == va.forward_patches
+            if not (features_a.dim() == 4 and features_a.size(1) == 3 and features_a.size(2) == va.image_size and features_a.size(3) == va.image_size):
+                return False
+            Ba = features_a.size(0)
+        elif tower_a == va.forward_patches and features_a.dim() == 2 and features_a.size(0) % (g * g) == 0:
+            Ba = features_a.size(0) // (g * g)
+        else:
+            return False
+        if mode == "grouped":
+            return True
+        # only when every projection pair of a layer becomes ONE persistent launch (else: the two-stream schedule overlaps better)
+        return two_stacks_groupable(va.encoder, Ba * (g * g + 1), tb.encoder, features_b.size(0) * features_b.size(1))
 
     @torch.jit.unused
     def _cu_partition(self, ref):
