@@ -65,6 +65,11 @@ def test_grouped_fallbacks_and_single_problem():
             probs.append((a, w, b, None, None))
         for g, r in zip(ops.gemm_bf16_grouped(probs), want):
             assert torch.equal(g, r)
+    # an empty problem next to a real one (a rank whose text batch is empty): nothing to launch for it, the other one is computed
+    a, w, b = _mk(8192, 1024, 256, 5, dev)
+    e = torch.empty((0, 256), dtype=torch.bfloat16, device=dev)
+    got = ops.gemm_bf16_grouped([(a, w, b, None, None), (e, w, b, None, None)])
+    assert got[1].shape == (0, 1024) and torch.equal(got[0], ops.gemm_bf16(a, w, b))
     a, w, b = _mk(4096, 768, 256, 3, dev)
     (g,) = ops.gemm_bf16_grouped([(a, w, b, None, None)])
     assert torch.equal(g, ops.gemm_bf16(a, w, b))
