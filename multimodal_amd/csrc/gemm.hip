@@ -2830,7 +2830,7 @@ extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int npro
   long tiles = 0;
   for (int i = 0; i < nprob; ++i) {
     const mmamd_gemm_problem& q = probs[i];
-    MMAMD_CHECK_ARG(q.A && q.W && q.C && q.M >= 0 && q.N > 0 && q.K > 0, MMAMD_E_BADARG, "gemm_grouped: problem %d: bad argument", i);
+    MMAMD_CHECK_ARG(q.M >= 0 && q.N > 0 && q.K > 0 && q.W && (q.M == 0 || (q.A && q.C)), MMAMD_E_BADARG, "gemm_grouped: problem %d: bad argument", i);
     if ((q.K & 127) != 0 || q.M == 0) group = false;
     tiles += (long)((q.M + 255) / 256) * ((q.N + 255) / 256);
   }
@@ -2838,6 +2838,7 @@ extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int npro
   if (!group || tiles < 2L * stream_cus(st)) {
     for (int i = 0; i < nprob; ++i) {
       const mmamd_gemm_problem& q = probs[i];
+      if (q.M == 0) continue;  // an empty problem (its pointers may be NULL)
       if (int rc = gemm_bf16_impl(q.A, q.lda, q.W, q.ldw, q.bias, q.R, q.ldr, q.C, q.ldc, out_dtype, q.M, q.N, q.K, act, nullptr, 0, 0, stream)) return rc;
     }
     return 0;
