@@ -2648,7 +2648,9 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
     // (re-measured with warm clocks, tools/kernel_bench.py: the persistent kernel wins from ~400 tiles up at every K — out-proj 625 vs 616 vs
     //  602 TF/s for PP / P / P + split, text MLP-up 691 / 663 / 620, patch embedding 863 / 851 / 838 — and the row-range split only pays
     //  with long K: MLP-down 891 with it, 836-838 without)
-    if (t_eq < 96) {
+    // (half a round of 256 x 256 tiles with a long K: four times as many 128 x 128 tiles balance better -- [9856 x 768 x 3072], the text MLP-down
+    //  of FLAVA / CoCa at B = 128, 117 tiles: 55 us vs 63; profiles/r02_gemm_flava_coca_shapes.txt)
+    if (t_eq < 96 || (t_eq < 128 && p.K >= 2048)) {
       v = 6;
     } else if ((p.K & 127) == 0 && t_eq >= 400) {
       v = 18;  // many tiles per CU: the persistent kernel hides each tile's first-stage load behind the previous epilogue

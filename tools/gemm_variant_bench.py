@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--variants", default="0,50,51,52")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--only", default="", help="comma-separated shape-name substrings")
+    ap.add_argument("--set", default="clip", choices=["clip", "flava", "coca"], help="problem shapes: the cfg-2 CLIP step (default), FLAVA cfg 4, CoCa cfg 5")
     ap.add_argument("--staggers", default="", help="comma-separated stagger tick counts: sweeps them on variant 0 instead of the variants")
     args = ap.parse_args()
     from multimodal_amd import build, ops
@@ -33,6 +34,14 @@ def main():
               ("t.qkv", 19712, 1536, 512, ops.ACT_NONE, False), ("t.mlp_up", 19712, 2048, 512, ops.ACT_QUICKGELU, False),
               ("t.out_proj", 19712, 512, 512, ops.ACT_NONE, True), ("t.mlp_down", 19712, 512, 2048, ops.ACT_NONE, True),
               ("patch", 50176, 768, 768, ops.ACT_NONE, None)]
+    if args.set == "flava":  # cfg 4, B = 128: image tower 197 tokens, text 77, fusion 275 (d = 768, erf-GELU MLPs)
+        shapes = [(f"{t}.{n}", M, N, K, act, res) for t, M in (("i", 25216), ("t", 9856), ("m", 35200))
+                  for n, N, K, act, res in (("qkv", 2304, 768, ops.ACT_NONE, False), ("out", 768, 768, ops.ACT_NONE, True),
+                                            ("up", 3072, 768, ops.ACT_GELU_ERF, False), ("down", 768, 3072, ops.ACT_NONE, True))]
+    elif args.set == "coca":  # cfg 5 per-GPU shape, B = 128: ViT-L/14 256 tokens (d = 1024), text / fusion decoders 77 tokens (d = 768)
+        shapes = [(f"{t}.{n}", M, N, K, act, res) for t, M, d in (("v", 32768, 1024), ("t", 9856, 768))
+                  for n, N, K, act, res in (("qkv", 3 * d, d, ops.ACT_NONE, False), ("out", d, d, ops.ACT_NONE, True),
+                                            ("up", 4 * d, d, ops.ACT_GELU_ERF, False), ("down", d, 4 * d, ops.ACT_NONE, True))]
     for name, M, N, K, act, res in shapes:
         if args.only and not any(t in name for t in args.only.split(",")):
             continue
