@@ -391,7 +391,7 @@ __device__ __forceinline__ void store_probs4(bf16* dst, f32x4 v) {
   for (int j = 0; j < 4; ++j) dst[j] = (bf16)v[j];
 }
 
-template <int NKT, typename TP>
+template <int NKT, typename TP, bool PIPE = true>
 __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __restrict__ qkv, const uint8_t* __restrict__ key_mask,
                                                               bf16* __restrict__ out, TP* __restrict__ probs, int S, int H,
                                                               float scale_log2e) {
@@ -453,12 +453,16 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
       for (int r = 0; r < 16; ++r) st[r] = st[r] * scale_log2e + Mk[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
     };
 
-    // ---- pass 1: running max and sum
-    float m = -INFINITY, lsum = 0.f;
-#pragma unroll 1
-    for (int kt = 0; kt < NKT; ++kt) {
-      f32x16 st;
-      scores(kt, st);
+    float m = -INFINITY, lsum = 0.f, inv = 0.f;
+    f32x16 ot[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
+    TP* pbase = probs + ((size_t)b * H + h) * S * S;
+    // One key tile of pass 1 (row max / sum) and of pass 2 (normalised probabilities out, P.V) on finished scores `st`; the arithmetic
+    // per row is the same sequence of operations in the serial and the pipelined loops (bit-identical results).
+    auto stats_tile = [&](const f32x16& st) {
       float tmax = st[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
@@ -471,21 +475,21 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
       for (int r = 0; r < 16; ++r) ps += (m_new == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(st[r] - m_new);
       lsum = lsum * alpha + ps;
       m = m_new;
-    }
-    lsum += __shfl_xor(lsum, 32);
-    const float inv = 1.0f / lsum;  // all keys masked -> 0 * inf = NaN, as the reference's softmax of an all -inf row
-
-    // ---- pass 2: normalised probabilities out, P.V accumulated
-    f32x16 ot[2];
+    };
+    auto read_vf = [&](int kt, bf16x8 (&vf)[2][2]) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ot[nt][r] = 0.f;
-    TP* pbase = probs + ((size_t)b * H + h) * S * S;
-#pragma unroll 1
-    for (int kt = 0; kt < NKT; ++kt) {
-      f32x16 st;
-      scores(kt, st);
+        for (int nt = 0; nt < 2; ++nt) {
+          const bf16* vrow = Vt + (nt * 32 + l31) * VS + kt * 32 + 16 * jj + 4 * half;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
+          u32x4 vw;
+          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+          vf[jj][nt] = __builtin_bit_cast(bf16x8, vw);
+        }
+    };
+    auto emit_tile = [&](int kt, const f32x16& st, const bf16x8 (&vf)[2][2]) {
       uint32_t pk[8];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -498,8 +502,17 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
         pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
         pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
       }
+      // P.V first: its four MFMAs cover the strip's LDS write -> read round trip (LDS operations of one wave execute in order, so the
+      // reads below see the strip without a wait, and the next tile's strip writes come after them)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        u32x4 pw;
+        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj][nt], pf, ot[nt], 0, 0, 0);
+      }
       if (probs != nullptr) {  // strip -> global: lane = (row lane>>3 of 8, 4 keys at (lane&7)*4); rows are only 4-byte aligned
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
@@ -516,23 +529,82 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
             }
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // strip is rewritten by the next key tile
       }
+    };
+    if constexpr (PIPE) {
+      // Software-pipelined key loops (as in attention_fwd_kernel): the QK^T MFMAs of tile kt+1 are issued before the softmax VALU of
+      // tile kt and the K fragments are read a tile ahead, so the matrix pipe and the LDS work under the VALU instead of in front of it.
+      // Measured (tools/probs_bench.py, B = 128, bit-identical outputs): S = 197 117 us either way (the fp32 probability write, 238 MB, is
+      // what the kernel waits for: 65 us without it), S = 275 267 vs 274 us, 174 vs 181 us without probabilities.
+      auto read_k = [&](int kt, bf16x8 (&kf)[4]) {
+        const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int key0 = kt * 32 + 16 * jj + 4 * half;
-        u32x4 pw;
-        pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(krow + 16 * t);
+      };
+      auto qk = [&](const bf16x8 (&kf)[4]) {
+        f32x16 acc;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const bf16* vrow = Vt + (nt * 32 + l31) * VS + key0;
-          const uint2 v0 = *reinterpret_cast<const uint2*>(vrow);
-          const uint2 v1 = *reinterpret_cast<const uint2*>(vrow + 8);
-          u32x4 vw;
-          vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
-          ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pf, ot[nt], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[t], acc, 0, 0, 0);
+        return acc;
+      };
+      auto mask_scale = [&](int kt, f32x16& st) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(Mk + kt * 32 + 8 * g + 4 * half);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) st[4 * g + j] = st[4 * g + j] * scale_log2e + mk[j];
         }
+      };
+      bf16x8 kf[4];
+      f32x16 st_next;
+      read_k(0, kf);
+      st_next = qk(kf);
+      if constexpr (NKT > 1) read_k(1, kf);
+#pragma unroll 1
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 st = st_next;
+        if (kt + 1 < NKT) {
+          st_next = qk(kf);
+          read_k(kt + 2 < NKT ? kt + 2 : 0, kf);  // (past the end: tile 0 again, for pass 2)
+        }
+        mask_scale(kt, st);
+        stats_tile(st);
+      }
+      lsum += __shfl_xor(lsum, 32);
+      inv = 1.0f / lsum;  // all keys masked -> 0 * inf = NaN, as the reference's softmax of an all -inf row
+      if constexpr (NKT == 1) read_k(0, kf);
+      st_next = qk(kf);  // kf holds tile 0 again
+      if constexpr (NKT > 1) read_k(1, kf);
+#pragma unroll 1
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 st = st_next;
+        bf16x8 vf[2][2];
+        read_vf(kt, vf);
+        if (kt + 1 < NKT) {
+          st_next = qk(kf);
+          read_k(kt + 2 < NKT ? kt + 2 : NKT - 1, kf);
+        }
+        mask_scale(kt, st);
+        emit_tile(kt, st, vf);
+      }
+    } else {
+#pragma unroll 1
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 st;
+        scores(kt, st);
+        stats_tile(st);
+      }
+      lsum += __shfl_xor(lsum, 32);
+      inv = 1.0f / lsum;
+#pragma unroll 1
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 st;
+        scores(kt, st);
+        bf16x8 vf[2][2];
+        read_vf(kt, vf);
+        emit_tile(kt, st, vf);
       }
     }
     if (q < S) {
@@ -550,12 +622,17 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
   }
 }
 
-template <int NKT, typename TP>
+static int g_attn_probs_serial = 0;  // mmamd_debug_set_attn_variant(512): the serial key loops (A/B of the pipelined form; same results)
+
+template <int NKT, typename TP, bool PIPE = true>
 static int launch_attn_probs(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int B, int S, int H, float scale,
                              hipStream_t st) {
+  if constexpr (PIPE) {
+    if (g_attn_probs_serial) return launch_attn_probs<NKT, TP, false>(qkv, key_mask, out, probs, B, S, H, scale, st);
+  }
   constexpr int SP = NKT * 32;
   constexpr int smem = SP * kKStride * 2 + 64 * (SP + 4) * 2 + SP * 4 + 4 * 32 * 36 * 4;
-  auto kern = attention_probs_kernel<NKT, TP>;
+  auto kern = attention_probs_kernel<NKT, TP, PIPE>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), smem, st, (const bf16*)qkv, key_mask, (bf16*)out, (TP*)probs, S, H,
@@ -1263,6 +1340,10 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
 using namespace mmamd;
 
 extern "C" int mmamd_debug_set_attn_variant(int v) {
+  if (v == 512 || v == 513) {  // attention_probs_fwd: 512 = serial key loops, 513 = back to the pipelined default
+    g_attn_probs_serial = v == 512;
+    return 0;
+  }
   g_attn_variant = v;
   return 0;
 }

@@ -293,3 +293,26 @@ def test_contrastive_fwd_reference_kats(golden):
     np.testing.assert_allclose(host(la), z["logits_a"], atol=1e-4)
     out3s, _, _ = ops.contrastive_fwd(a, b, a, b, 5, ls, 0, None, 0.1)
     assert abs(float(out3s[0]) - 10.2524) < 1e-3
+
+
+@torch.no_grad()
+def test_attention_probs_pipelined_equals_serial_key_loops():
+    """attention_probs_fwd: the software-pipelined key loops (default) and the serial ones (mmamd_debug_set_attn_variant(512)) run the same
+    arithmetic per row — outputs and probabilities bit-identical, with and without a key-padding mask, fp32 and bf16 probabilities."""
+    from multimodal_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(11)
+    try:
+        for B, S, H in ((3, 197, 2), (2, 77, 4), (2, 275, 2), (2, 20, 1)):
+            qkv = torch.randn(B * S, 3 * H * 64, generator=g).to(torch.bfloat16).cuda()
+            km = (torch.rand(B, S, generator=g) > 0.3).to(torch.uint8)
+            km[:, 0] = 1
+            for mask in (None, km.cuda()):
+                for dt in (torch.float32, torch.bfloat16):
+                    _lib.lib().mmamd_debug_set_attn_variant(512)
+                    o0, p0 = ops.attention_probs_fwd(qkv, B, S, H, mask, want_probs=True, probs_dtype=dt)
+                    _lib.lib().mmamd_debug_set_attn_variant(513)
+                    o1, p1 = ops.attention_probs_fwd(qkv, B, S, H, mask, want_probs=True, probs_dtype=dt)
+                    assert torch.equal(o0, o1) and torch.equal(p0, p1), (B, S, H, mask is not None, dt)
+    finally:
+        _lib.lib().mmamd_debug_set_attn_variant(513)
