@@ -1981,7 +1981,6 @@ template <bool OUT_F32, int ACT, int GM>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupArgs g) {
   constexpr int WM = 2, WN = 4, STP = OUT_F32 ? 0 : 2, RDP = 0;
   constexpr int BM = 256, BN = 256, NW = WM * WN;
-  const int ntiles = g.tile_start[g.nprob];
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW, NDMA = A_INSTR + B_INSTR, NF = NI + MI, NM = NI * MI;
@@ -1994,13 +1993,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, half = lane >> 5;
 
-  // virtual block id -> (problem, tile): the XCD-contiguous remap runs over the CONCATENATED tile list, the GM-grouped order inside
-  // each problem's own tile grid
-  auto tile_of = [&](int vb, int& sel, int& tm, int& tn) __attribute__((always_inline)) {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, loc = vb >> 3;
-    int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    sel = (g.nprob > 1 && id >= g.tile_start[1]) ? 1 : 0;
-    id -= g.tile_start[sel];
+  // Tile walk.  Workgroup b runs on XCD b & 7 and is the (b >> 3)-th of that XCD's `nwx` workgroups.  Every XCD owns a contiguous slice of
+  // EACH problem's tile list (an eighth of it: operand panels stay in that XCD's L2) and walks its slice of problem 0 first, then its
+  // slice of problem 1 -- so the eight XCDs carry equal WORK, not just equal tile counts (a split of the concatenated list gave the
+  // last XCDs only the second problem's shorter tiles: K = 512 against 768, they idled a quarter of the launch).
+  const int xcd = (int)blockIdx.x & 7, wl = (int)blockIdx.x >> 3;
+  const int nwx = ((int)gridDim.x - xcd + 7) >> 3;
+  int xb0, xc0, xb1 = 0, xc1 = 0;  // this XCD's slice [base, base + count) of problem 0 / 1
+  {
+    const int n0 = g.tile_start[1] - g.tile_start[0], q0 = n0 >> 3, r0 = n0 & 7;
+    xc0 = q0 + (xcd < r0 ? 1 : 0);
+    xb0 = xcd < r0 ? xcd * (q0 + 1) : r0 * (q0 + 1) + (xcd - r0) * q0;
+    if (g.nprob > 1) {
+      const int n1 = g.tile_start[2] - g.tile_start[1], q1 = n1 >> 3, r1 = n1 & 7;
+      xc1 = q1 + (xcd < r1 ? 1 : 0);
+      xb1 = xcd < r1 ? xcd * (q1 + 1) : r1 * (q1 + 1) + (xcd - r1) * q1;
+    }
+  }
+  const int nx = xc0 + xc1;  // tiles of this XCD
+  if (wl >= nx) return;      // (whole workgroup: before any barrier)
+  // XCD-local tile index -> (problem, tile): the GM-grouped order inside each problem's own tile grid
+  auto tile_of = [&](int l, int& sel, int& tm, int& tn) __attribute__((always_inline)) {
+    sel = l >= xc0 ? 1 : 0;
+    const int id = sel ? xb1 + (l - xc0) : xb0 + l;
     const int tiles_m = g.prob[sel].tiles_m;
     const int per_group = GM * g.prob[sel].tiles_n;
     const int grp = id / per_group, within = id - grp * per_group;
@@ -2029,7 +2044,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
       bo[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
     }
   };
-  int vb = blockIdx.x, sel = 0;
+  int vb = wl, sel = 0;  // XCD-local tile index of the current tile
   int tm, tn;
   tile_of(vb, sel, tm, tn);
   GemmProblem p = g.prob[sel];  // the CURRENT tile's problem (scalar loads from the kernel argument segment, refreshed per tile)
@@ -2126,9 +2141,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) issue_piece(0, 0, i);
   if (g.stagger > 0) {
-    const int heavy = ntiles % (int)gridDim.x;  // workgroups 0 .. heavy-1 walk one tile more: they start at once
-    if (heavy > 0 && (int)blockIdx.x >= heavy) {
-      const long long delay = (long long)g.stagger * ((int)blockIdx.x - heavy + 1) / ((int)gridDim.x - heavy);
+    const int heavy = nx % nwx;  // this XCD's workgroups 0 .. heavy-1 walk one tile more: they start at once
+    if (heavy > 0 && wl >= heavy) {
+      const long long delay = (long long)g.stagger * (wl - heavy + 1) / (nwx - heavy);
       const long long t0 = __builtin_readcyclecounter();
       while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
     }
@@ -2136,8 +2151,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
 
   while (true) {
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nvb = vb + gridDim.x;
-    const bool more = nvb < ntiles;
+    const int nvb = vb + nwx;
+    const bool more = nvb < nx;
     int ntm = 0, ntn = 0, nsel = sel;
     const char *Abn = Ab, *Wbn = Wb;
     if (more) {
