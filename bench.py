@@ -281,7 +281,9 @@ def main() -> None:
     dt_max = float(t)
     pairs_per_s = world * B * args.steps / dt_max
 
-    # the same launch alone on the GPU with warm clocks and nothing before or after it: reported next to the in-region figure as "isolated"
+    # the same launch 10 x back to back, nothing else on the GPU: reported next to the in-region figure as "back_to_back" (sustained MFMA load
+    # lowers the clock of this power-limited part: the figure is usually SLOWER than the in-step one, where LayerNorm / attention phases sit
+    # between the GEMMs)
     iso_ms = None
     companion = None if args.no_probe else probe.companion  # grouped launches: the text tower's MLP-up rides in the same kernel
     if not args.no_probe:
@@ -332,7 +334,7 @@ def main() -> None:
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                     "launch_ms": round(mean_ms, 4), "launches_timed": len(durs),
                     "algorithmic_flops_per_launch": flops,
-                    "isolated": {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
+                    "back_to_back": {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
                                  "frac": round(flops / (iso_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}}
 
     cpu_baseline = cpu_baseline_leg(sd_host, images, ids, args.cpu_sample) if sd_host is not None else None
