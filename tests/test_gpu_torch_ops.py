@@ -148,9 +148,12 @@ def test_compiled_coca_model_equals_scripted():
     texts[0, 7:] = 0
     texts = texts.cuda()
     scripted = torch.jit.script(model)
-    compiled = torch.compile(model, backend="aot_eager", fullgraph=True)
     with torch.no_grad():
         want = scripted(images, texts)
-        got = compiled(images, texts)
-    for k in ("image_pooled_output", "text_pooled_output", "multimodal_embeddings"):
-        assert torch.equal(getattr(got, k), getattr(want, k)), k
+    for backend in ("aot_eager", "inductor"):
+        torch._dynamo.reset()
+        compiled = torch.compile(model, backend=backend, fullgraph=True)
+        with torch.no_grad():
+            got = compiled(images, texts)
+        for k in ("image_pooled_output", "text_pooled_output", "multimodal_embeddings"):
+            assert torch.equal(getattr(got, k), getattr(want, k)), (backend, k)
