@@ -119,6 +119,18 @@ int mmamd_gemm_bf16_dual(const void* A, int lda, const void* W, int ldw, const f
 int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                         mmamd_stream_t stream);
 
+/* The attention of BOTH towers of a dual encoder layer (image_encoder.py:108 + text_encoder.py:121) in ONE persistent launch: the
+ * workgroups walk problem 0's (batch, head) items, then problem 1's.  Operands per problem as mmamd_attention_fwd; lse optional
+ * (NULL, or fp32 [B,H,S] as mmamd_attention_fwd_lse).  Bit-identical to one mmamd_attention_fwd call per problem.  Problems the
+ * LDS-DMA ring kernel does not take (S > 224) run as the separate launches this call stands for. */
+typedef struct {
+  const void* qkv;
+  void* out;
+  float* lse;
+  int B, S, H, causal;
+} mmamd_attn_problem;
+int mmamd_attention_fwd_grouped(const mmamd_attn_problem* probs, int nprob, float scale, mmamd_stream_t stream);
+
 /* Backward of mmamd_attention_x_fwd (same operand description; out / dout bf16 [B*Sq, ldo], lse from the forward): writes
  * dq [B, Sq, lddq] (ALWAYS per sample — with batch-shared queries the caller sums over the batch), dk / dv [B*Sk, lddk = lddv]
  * (bf16; they may be column slices of one buffer).  head_dim 96 needs Sk <= 256 (LDS). */

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "mmamd_gemm_bf16_grouped": (_i, [_vp, _i, _i, _i, _vp]),
     "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_attention_fwd_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mmamd_attention_fwd_grouped": (_i, [_vp, _i, _f, _vp]),
     "mmamd_gemm_bf16_splitk": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_gemm_bf16_tn_splitk": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_attention_probs_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -1339,9 +1339,21 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
 
 using namespace mmamd;
 
+namespace mmamd {
+// attention_ring.hip: LDS-DMA ring kernel (S <= 224), up to two problems per launch
+bool attn_ring_supports(int S);
+extern int g_attn_ring_abl;
+int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse, const int* B, const int* S, const int* H, const int* causal,
+                     const float* scale, int nprob, hipStream_t st);
+}  // namespace mmamd
+
 extern "C" int mmamd_debug_set_attn_variant(int v) {
   if (v == 512 || v == 513) {  // attention_probs_fwd: 512 = serial key loops, 513 = back to the pipelined default
     g_attn_probs_serial = v == 512;
+    return 0;
+  }
+  if (v >= 2000 && v < 2032) {  // ring kernel ablations (timing only): 2000 + {1: no DMA, 2: no key loops, 4: no Q loads, 8: no O stores}
+    g_attn_ring_abl = v - 2000;
     return 0;
   }
   g_attn_variant = v;
@@ -1349,6 +1361,7 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
 }
 
 static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream);
+
 
 extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
                                    mmamd_stream_t stream) {
@@ -1369,7 +1382,10 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
   hipStream_t st = (hipStream_t)stream;
   if (S > 288) return launch_attn_long(qkv, nullptr, out, nullptr, MMAMD_F32, B, S, H, causal, scale, st);
   const int nkt = (S + 31) / 32;
-  if (g_attn_variant != 0 && nkt == 7 && !causal) {  // ablations, vision shape only
+  // default for S <= 224: the LDS-DMA ring kernel (attention_ring.hip); mmamd_debug_set_attn_variant(1000) keeps the r02 register-staged kernel (A/B)
+  if (g_attn_variant == 0 && attn_ring_supports(S))
+    return launch_attn_ring(&qkv, &out, &lse, &B, &S, &H, &causal, &scale, 1, st);
+  if (g_attn_variant != 0 && g_attn_variant != 1000 && nkt == 7 && !causal) {  // ablations, vision shape only
     switch (g_attn_variant) {
       case 1: return launch_attn<7, false, 1>(qkv, out, B, S, H, scale, st);
       case 2: return launch_attn<7, false, 2>(qkv, out, B, S, H, scale, st);
@@ -1391,6 +1407,23 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
   }
 #undef ATTN_CASE
   MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention: unsupported S=%d", S);
+}
+
+extern "C" int mmamd_attention_fwd_grouped(const mmamd_attn_problem* probs, int nprob, float scale, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(probs != nullptr && nprob >= 1 && nprob <= 2, MMAMD_E_BADARG, "attention_fwd_grouped: 1 or 2 problems");
+  const void* qkv[2]; void* out[2]; float* lse[2]; int B[2], S[2], H[2], causal[2]; float sc[2];
+  bool ring = g_attn_variant == 0;
+  for (int i = 0; i < nprob; ++i) {
+    const mmamd_attn_problem& p = probs[i];
+    MMAMD_CHECK_ARG(p.qkv && p.out && p.B >= 0 && p.S > 0 && p.H > 0, MMAMD_E_BADARG, "attention_fwd_grouped: bad argument (problem %d)", i);
+    MMAMD_CHECK_ARG(aligned16(p.qkv) && aligned16(p.out), MMAMD_E_ALIGN, "attention_fwd_grouped: pointers must be 16-byte aligned");
+    qkv[i] = p.qkv; out[i] = p.out; lse[i] = p.lse; B[i] = p.B; S[i] = p.S; H[i] = p.H; causal[i] = p.causal; sc[i] = scale;
+    ring = ring && attn_ring_supports(p.S);
+  }
+  if (ring) return launch_attn_ring(qkv, out, lse, B, S, H, causal, sc, nprob, (hipStream_t)stream);
+  for (int i = 0; i < nprob; ++i)  // shapes the ring kernel does not take: the launches this call stands for
+    if (int rc = attention_fwd_impl(qkv[i], out[i], lse[i], B[i], S[i], H[i], causal[i], scale, stream)) return rc;
+  return 0;
 }
 
 extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int probs_dtype,

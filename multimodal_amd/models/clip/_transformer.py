@@ -178,8 +178,7 @@ def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, cau
         ops.layernorm(xb, pb(lb.norm1.weight, f32), pb(lb.norm1.bias, f32), lb.norm1.eps, out=hnb)
         ops.gemm_bf16_grouped([(hna, pa(aa.in_proj_weight, bf), pa(aa.in_proj_bias, f32), None, qkva),
                                (hnb, pb(ab.in_proj_weight, bf), pb(ab.in_proj_bias, f32), None, qkvb)])
-        ops.attention_fwd(qkva, Ba, Sa, sa.nhead, causal_a, out=atta)
-        ops.attention_fwd(qkvb, Bb, Sb, sb.nhead, causal_b, out=attb)
+        ops.attention_fwd_grouped([(qkva, Ba, Sa, sa.nhead, causal_a, atta), (qkvb, Bb, Sb, sb.nhead, causal_b, attb)])
         ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), xa, xa),
                                (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), xb, xb)], out_dtype=f32)
         ops.layernorm(xa, pa(la.norm2.weight, f32), pa(la.norm2.bias, f32), la.norm2.eps, out=hna)

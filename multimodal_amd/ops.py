@@ -17,7 +17,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
                    check)
 
 __all__ = [
-    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "patchify",
+    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "lnfold_pack", "row_stats", "gemm_bf16_res_stats", "gemm_bf16_lnfold", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
@@ -307,6 +307,34 @@ def attention_fwd(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool,
     check(_lib.lib().mmamd_attention_fwd(qkv.data_ptr(), out.data_ptr(), B, S, H, int(bool(causal)),
                                          1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_fwd")
     return out
+
+
+class _AttnProblem(C.Structure):  # mmamd_attn_problem (include/mmamd.h)
+    _fields_ = [("qkv", C.c_void_p), ("out", C.c_void_p), ("lse", C.c_void_p), ("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("causal", C.c_int)]
+
+
+def attention_fwd_grouped(problems):
+    """The attention of both towers of a layer in one persistent launch: problems = [(qkv, B, S, H, causal, out), ...] (1 or 2; `out` may be
+    None).  Returns the outputs.  Bit-identical to one attention_fwd call per problem (mmamd_attention_fwd_grouped)."""
+    n = len(problems)
+    if not 1 <= n <= 2:
+        raise MmamdError(f"attention_fwd_grouped: 1 or 2 problems, got {n}")
+    arr = (_AttnProblem * n)()
+    outs = []
+    for i, (qkv, B, S, H, causal, out) in enumerate(problems):
+        _chk(qkv, "qkv", torch.bfloat16)
+        if tuple(qkv.shape) != (B * S, 3 * H * 64):
+            raise MmamdError(f"attention_fwd_grouped: qkv shape {tuple(qkv.shape)} != {(B * S, 3 * H * 64)}")
+        if out is None:
+            out = torch.empty((B * S, H * 64), dtype=torch.bfloat16, device=qkv.device)
+        _chk(out, "out", torch.bfloat16)
+        if tuple(out.shape) != (B * S, H * 64):
+            raise MmamdError(f"attention_fwd_grouped: out shape {tuple(out.shape)} != {(B * S, H * 64)}")
+        q = arr[i]
+        q.qkv, q.out, q.lse, q.B, q.S, q.H, q.causal = qkv.data_ptr(), out.data_ptr(), None, B, S, H, int(bool(causal))
+        outs.append(out)
+    check(_lib.lib().mmamd_attention_fwd_grouped(C.cast(arr, C.c_void_p), n, 1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_fwd_grouped")
+    return outs
 
 
 def attention_probs_fwd(qkv: torch.Tensor, B: int, S: int, H: int, key_mask: Optional[torch.Tensor] = None,
