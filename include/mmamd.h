@@ -77,6 +77,23 @@ int mmamd_debug_set_attn_variant(int v);
 int mmamd_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
                     int y_dtype, int rows, int d, float eps, mmamd_stream_t stream);
 
+/* The LayerNorms of BOTH towers of a dual-encoder layer in ONE launch, optionally with the residual add in front of them: per problem
+ *   x[r,:] += delta[r,:]   (delta bf16 [rows,d] or NULL; x fp32 [rows,d], updated in place only when delta is given)
+ *   y[r,:]  = LayerNorm(x[r,:]; gamma, beta, eps)   (bf16 [rows,d]; y NULL = add only)
+ * With delta = the bf16 output of the out-projection / MLP-down GEMM (bias included) this is `x = x + sa_block(norm1(x))` followed by
+ * `norm2(x)` of torch's pre-norm TransformerEncoderLayer (models/clip/image_encoder.py:65-73, text_encoder.py:58-65) with the fp32
+ * read-modify-write of the residual stream taken out of the GEMM epilogue. */
+typedef struct {
+  float* x;
+  const void* delta;
+  const float* gamma;
+  const float* beta;
+  void* y;
+  int rows, d;
+  float eps;
+} mmamd_ln_problem;
+int mmamd_add_layernorm_grouped(const mmamd_ln_problem* probs, int nprob, mmamd_stream_t stream);
+
 /* --- K3/K5/K6: C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]) -------------------
  * A, W bf16; fp32 accumulate on MFMA; bias fp32 or NULL; residual (dtype = out_dtype) or NULL, may
  * alias C.  Requires K % 64 == 0, lda/ldw % 8 == 0, ldc/ldr % 4 == 0, 16-byte aligned bases.

@@ -16,13 +16,13 @@ that feeds an MFMA is bf16.
 from __future__ import annotations
 
 import copy
-import os
 
 import torch
 from torch import nn
 
 from ... import _torch_ops, ops
 from ..._packing import PackedCache
+from ...schedule import get_schedule
 
 _torch_ops.try_load()
 
@@ -101,16 +101,6 @@ class TransformerStack(nn.Module):
         qkv = torch.empty((M, 3 * d), dtype=bf, device=dev)
         att = torch.empty((M, d), dtype=bf, device=dev)
         up = torch.empty((M, self.dim_feedforward), dtype=bf, device=dev)
-        bf16_stream = os.environ.get("MMAMD_RESIDUAL", "fp32") == "bf16"  # experiment knob: residual stream dtype
-        # LayerNorm folded into the neighbouring GEMMs: built, parity-tested, and measured SLOWER on this GEMM structure (isolated, ViT-B/16
-        # B = 256: consumers 193 / 284 us vs LayerNorm 35 + GEMM 163 / 254; producers 138 / 297 vs 98 / 269 — the per-tile epilogue is the
-        # exposed part of these kernels and the streaming LayerNorm kernel runs at 6.6 TB/s; profiles/r02_lnfold_bench.txt).
-        # Opt-in for experiments: MMAMD_LN_FOLD=1.
-        if first == 0 and not bf16_stream and d % 128 == 0 and os.environ.get("MMAMD_LN_FOLD", "0") == "1":
-            return self._run_ln_folded(x, B, S, causal, qkv, att, up)
-        x_f32 = x
-        if bf16_stream:
-            x = ops.convert(x, bf)
         for li in range(first, len(self.layers)):
             layer = self.layers[li]
             sa = layer.self_attn
@@ -121,8 +111,6 @@ class TransformerStack(nn.Module):
             ops.layernorm(x, pk(layer.norm2.weight, f32), pk(layer.norm2.bias, f32), layer.norm2.eps, out=hn)
             ops.gemm_bf16(hn, pk(layer.linear1.weight, bf), pk(layer.linear1.bias, f32), act=ops.ACT_QUICKGELU, out=up)
             ops.gemm_bf16(up, pk(layer.linear2.weight, bf), pk(layer.linear2.bias, f32), residual=x, out=x)
-        if bf16_stream:
-            x = ops.convert(x, f32)
         return x
 
 
@@ -171,58 +159,45 @@ def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, cau
     hna, qkva, atta, upa = bufs(Ma, sa)
     hnb, qkvb, attb, upb = bufs(Mb, sb)
     n = min(len(sa.layers), len(sb.layers))
+    delta_ln = get_schedule().residual == "delta_ln"
+    if delta_ln:
+        da, db = torch.empty((Ma, sa.d_model), dtype=bf, device=dev), torch.empty((Mb, sb.d_model), dtype=bf, device=dev)
+
+    def ln(norm_a, norm_b, delta_a=None, delta_b=None):  # both towers' LayerNorms (and, with deltas, the residual adds in front of them) in one launch
+        ops.add_layernorm_grouped([(xa, delta_a, pa(norm_a.weight, f32), pa(norm_a.bias, f32), norm_a.eps, hna),
+                                   (xb, delta_b, pb(norm_b.weight, f32), pb(norm_b.bias, f32), norm_b.eps, hnb)])
+
     for li in range(n):
         la, lb = sa.layers[li], sb.layers[li]
         aa, ab = la.self_attn, lb.self_attn
-        ops.layernorm(xa, pa(la.norm1.weight, f32), pa(la.norm1.bias, f32), la.norm1.eps, out=hna)
-        ops.layernorm(xb, pb(lb.norm1.weight, f32), pb(lb.norm1.bias, f32), lb.norm1.eps, out=hnb)
+        if li == 0 or not delta_ln:
+            ln(la.norm1, lb.norm1)
         ops.gemm_bf16_grouped([(hna, pa(aa.in_proj_weight, bf), pa(aa.in_proj_bias, f32), None, qkva),
                                (hnb, pb(ab.in_proj_weight, bf), pb(ab.in_proj_bias, f32), None, qkvb)])
         ops.attention_fwd_grouped([(qkva, Ba, Sa, sa.nhead, causal_a, atta), (qkvb, Bb, Sb, sb.nhead, causal_b, attb)])
-        ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), xa, xa),
-                               (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), xb, xb)], out_dtype=f32)
-        ops.layernorm(xa, pa(la.norm2.weight, f32), pa(la.norm2.bias, f32), la.norm2.eps, out=hna)
-        ops.layernorm(xb, pb(lb.norm2.weight, f32), pb(lb.norm2.bias, f32), lb.norm2.eps, out=hnb)
+        if delta_ln:
+            # the projections store bf16 deltas (cheap epilogue); x += delta and the next LayerNorm are ONE streaming launch for both towers
+            ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), None, da),
+                                   (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), None, db)])
+            ln(la.norm2, lb.norm2, da, db)
+        else:
+            ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), xa, xa),
+                                   (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), xb, xb)], out_dtype=f32)
+            ln(la.norm2, lb.norm2)
         ops.gemm_bf16_grouped([(hna, pa(la.linear1.weight, bf), pa(la.linear1.bias, f32), None, upa),
                                (hnb, pb(lb.linear1.weight, bf), pb(lb.linear1.bias, f32), None, upb)], act=ops.ACT_QUICKGELU)
-        ops.gemm_bf16_grouped([(upa, pa(la.linear2.weight, bf), pa(la.linear2.bias, f32), xa, xa),
-                               (upb, pb(lb.linear2.weight, bf), pb(lb.linear2.bias, f32), xb, xb)], out_dtype=f32)
+        if delta_ln and li + 1 < n:
+            ops.gemm_bf16_grouped([(upa, pa(la.linear2.weight, bf), pa(la.linear2.bias, f32), None, da),
+                                   (upb, pb(lb.linear2.weight, bf), pb(lb.linear2.bias, f32), None, db)])
+            ln(sa.layers[li + 1].norm1, sb.layers[li + 1].norm1, da, db)
+        else:  # (the last common layer: nothing normalises x behind it here)
+            ops.gemm_bf16_grouped([(upa, pa(la.linear2.weight, bf), pa(la.linear2.bias, f32), xa, xa),
+                                   (upb, pb(lb.linear2.weight, bf), pb(lb.linear2.bias, f32), xb, xb)], out_dtype=f32)
     if len(sa.layers) > n:
         sa.run(xa, Ba, Sa, causal_a, first=n)
     if len(sb.layers) > n:
         sb.run(xb, Bb, Sb, causal_b, first=n)
     return xa, xb
-
-
-def _run_ln_folded(self, x, B, S, causal, qkv, att, up):
-    """The same layers with both LayerNorms folded into the GEMMs around them (csrc/gemm.hip "LN fold"): the GEMM that produces the
-    residual stream x also writes xh = bf16(x) and the per-row block statistics, the GEMM that consumes LN(x) reads xh and applies
-    mu / rstd / gamma / beta in its epilogue — no stand-alone LayerNorm launches, no fp32 re-read of x.  MMAMD_LN_FOLD=0 selects
-    the unfused form above (same arithmetic up to the rounding point of the GEMM operand: xh instead of bf16(LN(x)))."""
-    d, H = self.d_model, self.nhead
-    M = B * S
-    bf, f32 = torch.bfloat16, torch.float32
-    pk, fold = self._packed.get, self._packed.get_lnfold
-    xh = torch.empty((M, d), dtype=bf, device=x.device)
-    stats = torch.empty((M, d // 64, 2), dtype=f32, device=x.device)
-    ops.row_stats(x, xh, stats)
-    last = len(self.layers) - 1
-    for li, layer in enumerate(self.layers):
-        sa = layer.self_attn
-        wg, c1, c2 = fold(sa.in_proj_weight, layer.norm1.weight, layer.norm1.bias, sa.in_proj_bias)
-        ops.gemm_bf16_lnfold(xh, wg, c1, c2, stats, layer.norm1.eps, out=qkv)
-        ops.attention_fwd(qkv, B, S, H, causal, out=att)
-        ops.gemm_bf16_res_stats(att, pk(sa.out_proj.weight, bf), pk(sa.out_proj.bias, f32), x, xh, stats)
-        wg, c1, c2 = fold(layer.linear1.weight, layer.norm2.weight, layer.norm2.bias, layer.linear1.bias)
-        ops.gemm_bf16_lnfold(xh, wg, c1, c2, stats, layer.norm2.eps, act=ops.ACT_QUICKGELU, out=up)
-        if li == last:  # nothing consumes a bf16 copy of the final stream (ln_post / ln_final read the fp32 rows)
-            ops.gemm_bf16(up, pk(layer.linear2.weight, bf), pk(layer.linear2.bias, f32), residual=x, out=x)
-        else:
-            ops.gemm_bf16_res_stats(up, pk(layer.linear2.weight, bf), pk(layer.linear2.bias, f32), x, xh, stats)
-    return x
-
-
-TransformerStack._run_ln_folded = _run_ln_folded
 
 
 def forbid_training_forward(module: nn.Module) -> None:

@@ -16,12 +16,12 @@ from ...utils.common import load_module_from_url
 from . import _train
 from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
+from ...schedule import get_schedule
 from ._transformer import run_two_stacks, two_stacks_groupable
 
 
 _torch_ops.try_load()
 _SIDE_STREAMS = {}
-_PART_STREAMS = {}
 
 
 class CLIPOutput(NamedTuple):
@@ -86,7 +86,7 @@ class CLIP(PackedModeMixin, nn.Module):
         # The two towers are independent until the normalised features meet in the loss: run tower B on a side HIP
         # stream so its small-grid kernels (77-token sequences: 150-600 workgroups per GEMM) fill the CUs that tower
         # A's kernels leave idle in their last, partial wave of workgroups.  Pure stream plumbing: same kernels,
-        # same results.  MMAMD_SINGLE_STREAM=1 disables it.
+        # same results (schedule.side_stream = False disables it).
         if _train.wants_grad(self, features_a, features_b):
             # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward, one stream
             embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
@@ -123,28 +123,12 @@ class CLIP(PackedModeMixin, nn.Module):
 
     @torch.jit.unused
     def _towers_streams(self, tower_a, features_a, features_b):
-        """Tower-agnostic schedule: tower B on a side HIP stream (or each tower on its own CU partition), forked from / joined to the
-        caller's stream.  MMAMD_SINGLE_STREAM=1: one after the other."""
+        """Tower-agnostic schedule: tower B on a side HIP stream, forked from / joined to the caller's stream (schedule.side_stream = False:
+        one after the other).  (Each tower on its own CU partition was measured and rejected: 18.8-23.0 vs 14.4 ms)"""
         side = self._side_stream(features_a)
-        part = self._cu_partition(features_a) if side is not None else None
         if side is None:
             embeddings_a = tower_a(features_a)
             embeddings_b = self.encoder_b(features_b)
-        elif part is not None:
-            # each tower on its own CU partition (hipExtStreamCreateWithCUMask): neither tower's persistent kernels wait for CUs the
-            # other one holds; both streams fork from / join the caller's stream
-            main = torch.cuda.current_stream()
-            sa, sb = part
-            sa.wait_stream(main)
-            sb.wait_stream(main)
-            with torch.cuda.stream(sb):
-                embeddings_b = self.encoder_b(features_b)
-            with torch.cuda.stream(sa):
-                embeddings_a = tower_a(features_a)
-            main.wait_stream(sa)
-            main.wait_stream(sb)
-            embeddings_a.record_stream(main)
-            embeddings_b.record_stream(main)
         else:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
@@ -159,17 +143,15 @@ class CLIP(PackedModeMixin, nn.Module):
     def _grouped_towers(self, tower_a, features_a, features_b) -> bool:
         """The grouped two-tower schedule applies to the CLIP pair of this package (ViT + text transformer) in inference, at sizes where every
         projection pair of a layer qualifies for one grouped launch (ViT-B/16 and L/14 at B = 256; not B/32, not small batches); any other
-        encoder pair or size keeps the tower-agnostic two-stream path.  MMAMD_TWO_TOWER=streams / grouped force one of the two."""
-        import os
-
-        mode = os.environ.get("MMAMD_TWO_TOWER", "auto")  # auto | grouped (whenever the encoder pair allows it) | streams
+        encoder pair or size keeps the tower-agnostic two-stream path.  schedule.two_tower = "streams" / "grouped" force one of the two."""
+        mode = get_schedule().two_tower  # auto | grouped (whenever the encoder pair allows it) | streams
         if mode == "streams":
             return False
         if type(self.encoder_a) is not CLIPViTEncoder or type(self.encoder_b) is not CLIPTextEncoder:
             return False
         if not (isinstance(features_a, torch.Tensor) and isinstance(features_b, torch.Tensor) and features_a.is_cuda and features_b.is_cuda):
             return False
-        if features_b.dim() != 2 or os.environ.get("MMAMD_RESIDUAL", "fp32") != "fp32" or os.environ.get("MMAMD_LN_FOLD", "0") == "1":
+        if features_b.dim() != 2:
             return False
         va, tb = self.encoder_a, self.encoder_b
         if va._forward_hooks or va._forward_pre_hooks or tb._forward_hooks or tb._forward_pre_hooks:
@@ -191,27 +173,8 @@ class CLIP(PackedModeMixin, nn.Module):
         return two_stacks_groupable(va.encoder, Ba * (g * g + 1), tb.encoder, features_b.size(0) * features_b.size(1))
 
     @torch.jit.unused
-    def _cu_partition(self, ref):
-        """(stream of tower A, stream of tower B) confined to complementary CU sets, or None.  MMAMD_CU_SPLIT = CUs per XCD given to
-        tower B (0 / unset = no partition: plain side stream); MMAMD_CU_LAYOUT = interleaved | contiguous (ops.cu_partition_masks)."""
-        import os
-
-        t = int(os.environ.get("MMAMD_CU_SPLIT", "0") or 0)
-        if t <= 0:
-            return None
-        key = (ref.device, t, os.environ.get("MMAMD_CU_LAYOUT", "interleaved"))
-        got = _PART_STREAMS.get(key)
-        if got is None:
-            ma, mb = ops.cu_partition_masks(t, key[2])
-            got = (ops.create_cu_mask_stream(ma, ref.device), ops.create_cu_mask_stream(mb, ref.device))
-            _PART_STREAMS[key] = got
-        return got
-
-    @torch.jit.unused
     def _side_stream(self, ref):
-        import os
-
-        if os.environ.get("MMAMD_SINGLE_STREAM") == "1" or not isinstance(ref, torch.Tensor) or not ref.is_cuda:
+        if not get_schedule().side_stream or not isinstance(ref, torch.Tensor) or not ref.is_cuda:
             return None
         # (during graph capture the fork / join below is captured too: the side stream joins the capture through wait_stream)
         s = _SIDE_STREAMS.get(ref.device)  # process-wide, not a module attribute (modules stay deep-copyable/picklable)

@@ -17,7 +17,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
                    check)
 
 __all__ = [
-    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "patchify",
+    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "lnfold_pack", "row_stats", "gemm_bf16_res_stats", "gemm_bf16_lnfold", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
@@ -145,6 +145,36 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = N
     if timer is not None:
         timer.stop()
     return out
+
+
+class _LnProblem(C.Structure):  # mmamd_ln_problem (include/mmamd.h)
+    _fields_ = [("x", C.c_void_p), ("delta", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("y", C.c_void_p),
+                ("rows", C.c_int), ("d", C.c_int), ("eps", C.c_float)]
+
+
+def add_layernorm_grouped(problems) -> None:
+    """One launch for the LayerNorms of up to two towers: problems = [(x fp32 [rows,d], delta bf16 [rows,d] | None, gamma | None, beta | None,
+    eps, y bf16 [rows,d] | None), ...].  x += delta in place when delta is given; y = LN(x) when y is given (mmamd_add_layernorm_grouped)."""
+    n = len(problems)
+    if not 1 <= n <= 2:
+        raise MmamdError(f"add_layernorm_grouped: 1 or 2 problems, got {n}")
+    arr = (_LnProblem * n)()
+    for i, (x, delta, gamma, beta, eps, y) in enumerate(problems):
+        _chk(x, "x", torch.float32)
+        rows, d = x.shape
+        for t, name, dt in ((delta, "delta", torch.bfloat16), (y, "y", torch.bfloat16)):
+            if t is not None:
+                _chk(t, name, dt)
+                if tuple(t.shape) != (rows, d):
+                    raise MmamdError(f"add_layernorm_grouped: {name} shape {tuple(t.shape)} != {(rows, d)}")
+        for t, name in ((gamma, "gamma"), (beta, "beta")):
+            if t is not None:
+                _chk(t, name, torch.float32)
+                if t.numel() != d:
+                    raise MmamdError(f"add_layernorm_grouped: {name} has {t.numel()} elements, expected {d}")
+        q = arr[i]
+        q.x, q.delta, q.gamma, q.beta, q.y, q.rows, q.d, q.eps = x.data_ptr(), _ptr(delta), _ptr(gamma), _ptr(beta), _ptr(y), rows, d, float(eps)
+    check(_lib.lib().mmamd_add_layernorm_grouped(C.cast(arr, C.c_void_p), n, _stream()), "mmamd_add_layernorm_grouped")
 
 
 class _GemmProblem(C.Structure):  # mmamd_gemm_problem (include/mmamd.h)

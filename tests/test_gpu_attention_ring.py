@@ -123,3 +123,61 @@ def test_ring_log_sum_exp(B, S, H, causal):
     ref, lse_ref = _ref(qkv, B, S, H, causal)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, atol=3e-2, rtol=2e-2)
     np.testing.assert_allclose(lse.cpu().numpy().reshape(B, H, S), lse_ref, atol=2e-3, rtol=1e-4)
+
+
+@torch.no_grad()
+def test_delta_ln_schedule_matches_epilogue_schedule():
+    """schedule.residual = "delta_ln" (bf16 delta GEMMs + ONE fused residual-add + LayerNorm launch for both towers) against the default
+    (fp32 read-modify-write in the GEMM epilogues): the same function up to the bf16 rounding of each projection output."""
+    from multimodal_amd.models.clip import clip_vit_b16
+    from multimodal_amd.schedule import set_schedule
+    from multimodal_amd.utils.synthetic import clip_batch
+
+    torch.manual_seed(0)
+    model = clip_vit_b16().cuda().eval()
+    images, ids = clip_batch(64)
+    images, ids = images.cuda(), ids.cuda()
+    prev = set_schedule(two_tower="grouped", residual="epilogue")
+    try:
+        ref = model(images, ids)
+        set_schedule(residual="delta_ln")
+        got = model(images, ids)
+        again = model(images, ids)
+    finally:
+        set_schedule(two_tower=prev.two_tower, residual=prev.residual)
+    assert torch.equal(got.embeddings_a, again.embeddings_a) and torch.equal(got.embeddings_b, again.embeddings_b)
+    assert (got.embeddings_a - ref.embeddings_a).abs().max().item() <= 2e-3
+    assert (got.embeddings_b - ref.embeddings_b).abs().max().item() <= 2e-3
+
+
+def test_add_layernorm_grouped_vs_float64():
+    from multimodal_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    xa, xb = torch.randn(777, 768, generator=g).cuda(), (torch.randn(130, 512, generator=g) * 3 + 1).cuda()
+    da, db = torch.randn(777, 768, generator=g).bfloat16().cuda(), torch.randn(130, 512, generator=g).bfloat16().cuda()
+    ga, ba = torch.randn(768, generator=g).cuda(), torch.randn(768, generator=g).cuda()
+    gb, bb = torch.randn(512, generator=g).cuda(), torch.randn(512, generator=g).cuda()
+    ya, yb = torch.empty_like(da), torch.empty_like(db)
+
+    def ref(x, d, gm, bt, eps):
+        xn = x.double() + (d.double() if d is not None else 0)
+        mu, var = xn.mean(-1, keepdim=True), xn.var(-1, unbiased=False, keepdim=True)
+        return xn, (xn - mu) / torch.sqrt(var + eps) * gm.double() + bt.double()
+
+    # plain LayerNorm of both problems == two mmamd_layernorm launches, bit for bit; x untouched
+    xa0, xb0 = xa.clone(), xb.clone()
+    ops.add_layernorm_grouped([(xa, None, ga, ba, 1e-5, ya), (xb, None, gb, bb, 1e-6, yb)])
+    assert torch.equal(xa, xa0) and torch.equal(xb, xb0)
+    assert torch.equal(ya, ops.layernorm(xa, ga, ba, 1e-5)) and torch.equal(yb, ops.layernorm(xb, gb, bb, 1e-6))
+    # with deltas: x updated in place, y = LN(x + delta)
+    rxa, rya = ref(xa, da, ga, ba, 1e-5)
+    rxb, ryb = ref(xb, db, gb, bb, 1e-6)
+    ops.add_layernorm_grouped([(xa, da, ga, ba, 1e-5, ya), (xb, db, gb, bb, 1e-6, yb)])
+    assert (xa.double() - rxa).abs().max().item() <= 1e-6 and (xb.double() - rxb).abs().max().item() <= 2e-6
+    np.testing.assert_allclose(ya.double().cpu().numpy(), rya.cpu().numpy(), atol=1e-2, rtol=8e-3)  # bf16 output
+    np.testing.assert_allclose(yb.double().cpu().numpy(), ryb.cpu().numpy(), atol=1e-2, rtol=8e-3)
+    # add only (no LayerNorm output), one problem
+    x1 = xa.clone()
+    ops.add_layernorm_grouped([(x1, da, None, None, 0.0, None)])
+    assert torch.equal(x1, xa + da.float())

@@ -94,10 +94,15 @@ def test_grouped_two_tower_schedule_is_bit_identical_to_the_two_stream_one(facto
     model = getattr(clip_models, factory)().to(dev).eval()
     images, ids = clip_batch(B)
     images, ids = images.to(dev), ids.to(dev)
-    monkeypatch.setenv("MMAMD_TWO_TOWER", "streams")
-    ref = model(images, ids)
-    monkeypatch.setenv("MMAMD_TWO_TOWER", "grouped")
-    got = model(images, ids)
+    from multimodal_amd.schedule import set_schedule
+
+    prev = set_schedule(two_tower="streams")
+    try:
+        ref = model(images, ids)
+        set_schedule(two_tower="grouped")
+        got = model(images, ids)
+    finally:
+        set_schedule(two_tower=prev.two_tower)
     torch.cuda.synchronize()
     assert torch.equal(got.embeddings_a, ref.embeddings_a) and torch.equal(got.embeddings_b, ref.embeddings_b)
     assert torch.isfinite(got.embeddings_a).all() and got.embeddings_a.abs().sum() > 0

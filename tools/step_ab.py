@@ -3,7 +3,7 @@ alternating arms (guide rules 13 / 24).  Each arm is timed three ways: eager wit
 ENQUEUE a step (is the Python thread the limit?), and a HIP-graph replay of the same step (no host in the loop).
 
     python tools/step_ab.py --arms ring,r02attn [--rounds 3] [--steps 20]
-arms: ring (default build), r02attn (register-staged attention kernel, mmamd_debug_set_attn_variant(1000))"""
+arms (joined with +): base, r02attn (register-staged attention kernel), delta_ln (bf16 delta GEMMs + fused add+LayerNorm), streams"""
 import argparse
 import json
 import sys
@@ -36,13 +36,20 @@ def main():
     images, ids = clip_batch(a.batch)
     images, ids = images.to(dev), ids.to(dev)
 
+    from multimodal_amd.schedule import set_schedule
+
     def set_arm(name):
         L.mmamd_debug_set_attn_variant(0)
+        set_schedule(residual="epilogue", two_tower="auto")
         for part in name.split("+"):
             if part in ("ring", "base"):
                 pass
             elif part == "r02attn":
                 L.mmamd_debug_set_attn_variant(1000)
+            elif part == "delta_ln":
+                set_schedule(residual="delta_ln")
+            elif part == "streams":
+                set_schedule(two_tower="streams")
             else:
                 raise SystemExit(f"unknown arm {part}")
 
@@ -53,6 +60,15 @@ def main():
     res = {}
     arms = a.arms.split(",")
     with torch.no_grad():
+        ref = None
+        for arm in arms:  # results of every arm against the first one
+            set_arm(arm)
+            out = model(images, ids)
+            ea, eb = out.embeddings_a.float().clone(), out.embeddings_b.float().clone()
+            if ref is None:
+                ref = (ea, eb)
+            print(f"{arm}: loss {float(loss_fn(out.embeddings_a, out.embeddings_b)):.6f}  max|d emb_a| {float((ea - ref[0]).abs().max()):.3e}  "
+                  f"max|d emb_b| {float((eb - ref[1]).abs().max()):.3e} vs {arms[0]}", flush=True)
         for rnd in range(a.rounds):
             for arm in arms:
                 set_arm(arm)
