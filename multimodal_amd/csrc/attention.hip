@@ -1352,7 +1352,7 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
     g_attn_probs_serial = v == 512;
     return 0;
   }
-  if (v >= 2000 && v < 2032) {  // ring kernel ablations (timing only): 2000 + {1: no DMA, 2: no key loops, 4: no Q loads, 8: no O stores}
+  if (v >= 2000 && v < 2512) {  // ring kernel ablations (timing only): 2000 + {1: no DMA, 2: no key loops, 4: no Q loads, 8: no O stores}
     g_attn_ring_abl = v - 2000;
     return 0;
   }

@@ -100,10 +100,17 @@ __device__ __forceinline__ int ring_f(int row) { return (((row >> 1) & 1) << 2) 
 
 constexpr int kRingWaves = 8;  // 7 compute + 1 loader
 
-// ABL (timing experiments, results WRONG): 1 = no K/V/Q DMA, 2 = no key loops, 8 = no O stores.
+// ABL (timing experiments, results WRONG): 1 = no K/V/Q DMA, 2 = no key loops, 8 = no O stores, 32 = no exp2, 64 = K / V fragments read once per
+// unit instead of per tile, 128 = no MFMA (scores / outputs come from moves), 256 = no cross-half max exchange.  ABL & 4 (results right): phase timers —
+// `lse` of problem 0 receives 8 floats of s_memtime ticks per wave: compute waves {key loops, O transpose + store, barrier wait, total},
+// loader {DMA issue, landing wait, barrier wait, total}.
 // UNR: the key loop of non-causal items with 7 (ViT-B/16, S = 197) or 2 (ViT-B/32, S = 50) key tiles is fully unrolled: tile offsets become
 // ds_read immediates and the score registers of consecutive tiles need no copies (~20 of ~100 VALU instructions per tile)
-template <int ABL, bool UNR>
+// UNR = 2: the unrolled loop in TWO PHASES per key tile — QK^T of tile k+1 beside the exponentials of tile k, then P.V of tile k beside the row sums
+// of tile k and the row maximum / rescale decision of tile k+1 — so that both MFMA groups have independent VALU work to issue between them
+// (r03 ablation: matrix 14.6 us, exp2 9.6 us and the other VALU 28 us of the 52 us compute time were purely additive: the compiler had
+// scheduled each tile's 8 MFMAs in one cluster and ~65 VALU instructions behind it).  Same arithmetic, same order per row.
+template <int ABL, int UNR>
 __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(const AttnRingArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p_r)smem;
@@ -126,6 +133,10 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
     const int Nloc = (int)blockIdx.x < BH ? (BH - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;  // items of this workgroup
     const int R = (Nloc + G - 1) / G;                                                           // rounds
     if (R == 0) continue;
+    constexpr bool TIMED = (ABL & 4) != 0;
+    auto now = [&]() -> uint64_t { if constexpr (TIMED) return __builtin_amdgcn_s_memtime(); else return 0; };
+    uint64_t tacc[4] = {0, 0, 0, 0};
+    const uint64_t t_begin = now();
 
     if (wave == kRingWaves - 1) {
       // ================================================= loader =================================================
@@ -189,10 +200,14 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
       ring_barrier();
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
+        const uint64_t t0 = now();
         if (r > 0 && next_e < R && next_e < r + nring) issue_entry();  // the slot of entry r-1 is free since the last barrier
+        const uint64_t t1 = now();
         if constexpr ((ABL & 1) == 0)
           if (r + 1 < R) ring_wait_vm_le(issued - cum(r + 1));        // entry r+1 landed before anyone starts round r+1
+        const uint64_t t2 = now();
         ring_barrier();
+        if constexpr (TIMED) { tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += now() - t2; }
       }
     } else {
       // ================================================= compute =================================================
@@ -215,6 +230,12 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
       const int ow = l31 * 128 + 8 * half;
       const int orr = (lane >> 3) * 128, oc = lane & 7;
 
+      // Static priority for the younger wave of each SIMD (waves 4-6 share SIMDs with waves 0-2): phase timers showed one wave of every pair
+      // finishing its 7 key tiles in ~70 k ticks and the other in ~97 k whatever the arbitration; with the raise the pair's total drops 3.7 %
+      // (132.9 k vs 138.0 k ticks per launch; alternating the priority per key tile measures the same, 132.6 k).  ABL & 512 switches it off.
+      if constexpr ((ABL & 512) == 0) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+      }
       const int di = wave / nqt, qt = wave - di * nqt;  // this wave's item of the round and its query tile (fixed per problem)
       const bool wactive = wave < G * nqt;
       const int q = qt * 32 + l31;
@@ -224,6 +245,8 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
 #pragma unroll 1
       for (int r = 0; r < R; ++r) {
         const int n = G * r + di;
+        const uint64_t tr0 = now();
+        uint64_t tr1 = tr0, tr2 = tr0;
         if (wactive && n < Nloc) {
           const char* Kb = smem + eslot * entry_bytes + di * slot_bytes;
           const char* Vb = Kb + rows8 * 128;
@@ -240,6 +263,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
             for (int i = 0; i < 16; ++i) ot[nt][i] = 0.f;
 
           auto read_k = [&](int kt, bf16x8 (&kf)[4]) {
+            if constexpr ((ABL & 64) != 0) { if (kt > 1) return; }
             const char* kp = Kb + kt * 4096;
 #pragma unroll
             for (int t = 0; t < 4; ++t) kf[t] = *reinterpret_cast<const bf16x8*>(kp + ko[t]);
@@ -249,7 +273,10 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qcur[t], acc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+              if constexpr ((ABL & 128) != 0) { acc[t] += (float)kf[t][0] * (float)qcur[t][0]; }
+              else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qcur[t], acc, 0, 0, 0);
+            }
             return acc;
           };
           bf16x8 kf[4];
@@ -261,7 +288,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
             const bool csl = NC > 0 ? false : causal;
             f32x16 st = st_next;
             bf16x8 vf[2][2];
-            const char* vp = Vb + kt * 4096;
+            const char* vp = Vb + (((ABL & 64) != 0) ? 0 : kt * 4096);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
 #pragma unroll
             for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, st[i]);
             // (v_permlane32_swap instead of this ds_bpermute measured the same, 73.4 vs 74.0 us; hipcc folds a swap of a register with itself away)
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            if constexpr ((ABL & 256) == 0) tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float ts = tmax * scale_log2e;
             if (__any(ts > m + 8.0f)) {  // deferred max: the reference moves only when some row grew by more than 2^8
               const float m_new = fmaxf(m, ts);
@@ -314,8 +341,11 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
               f32x2 a = {st[2 * g], st[2 * g + 1]};
               a = __builtin_elementwise_fma(a, sc2, nm2);
               f32x2 e;
+              if constexpr ((ABL & 32) != 0) { e = a; }
+              else {
               e[0] = __builtin_amdgcn_exp2f(a[0]);
               e[1] = __builtin_amdgcn_exp2f(a[1]);
+              }
               ps2 += e;
               bf16x2 p;
               p[0] = (bf16)e[0]; p[1] = (bf16)e[1];
@@ -328,7 +358,121 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
               pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
               const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
-              for (int nt = 0; nt < 2; ++nt) ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj][nt], pf, ot[nt], 0, 0, 0);
+              for (int nt = 0; nt < 2; ++nt) {
+                if constexpr ((ABL & 128) != 0) { ot[nt][jj] += (float)vf[jj][nt][0] * (float)pf[0] + (float)vf[jj][nt][7] * (float)pf[7]; }
+                else ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj][nt], pf, ot[nt], 0, 0, 0);
+              }
+            }
+          };
+          auto tiles_phased = [&](auto nc) {
+            constexpr int N = decltype(nc)::value;
+            auto mask_last = [&](f32x16& sc) {  // the last tile holds the padded keys
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const int key = (N - 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                if (key >= S) sc[i] = -INFINITY;
+              }
+            };
+            auto row_max_scaled = [&](const f32x16& sc) {
+              float tmax = sc[0];
+#pragma unroll
+              for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sc[i]);
+              tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+              return tmax * scale_log2e;
+            };
+            read_k(0, kf);
+            f32x16 st = qk(kf);
+            if constexpr (N > 1) read_k(1, kf);
+            if constexpr (N == 1) mask_last(st);
+            {  // tile 0: the reference starts at -inf, so the first tile always sets it (O and the row sum are still zero)
+              const float ts = row_max_scaled(st);
+              m = fmaxf(m, ts);
+            }
+#pragma unroll
+            for (int kt = 0; kt < N; ++kt) {
+              if constexpr ((ABL & 1024) != 0) {  // the two waves of a SIMD take turns at priority 1, one key tile each
+                if ((wave >= 4) == ((kt & 1) != 0)) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+              }
+              bf16x8 vf[2][2];
+              const char* vp = Vb + kt * 4096;
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                  uint2 v0 = ring_tr_b64(vp + jj * 2048 + vo[nt][0]);
+                  uint2 v1 = ring_tr_b64(vp + jj * 2048 + vo[nt][1]);
+                  if (kt == N - 1) {  // keys >= S: their V rows were never staged -> exact zeros
+                    const int key0 = kt * 32 + 16 * jj + 4 * half;
+                    const uint32_t ma = (key0 + 0 < S ? 0x0000ffffu : 0u) | (key0 + 1 < S ? 0xffff0000u : 0u);
+                    const uint32_t mb = (key0 + 2 < S ? 0x0000ffffu : 0u) | (key0 + 3 < S ? 0xffff0000u : 0u);
+                    const uint32_t mc = (key0 + 8 < S ? 0x0000ffffu : 0u) | (key0 + 9 < S ? 0xffff0000u : 0u);
+                    const uint32_t md = (key0 + 10 < S ? 0x0000ffffu : 0u) | (key0 + 11 < S ? 0xffff0000u : 0u);
+                    v0.x &= ma; v0.y &= mb; v1.x &= mc; v1.y &= md;
+                  }
+                  ru32x4 vw;
+                  vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+                  vf[jj][nt] = __builtin_bit_cast(bf16x8, vw);
+                }
+              // ---- phase 1: QK^T of tile kt+1 (matrix pipe) beside the exponentials of tile kt (VALU)
+              f32x16 stn;
+              if (kt + 1 < N) {
+                stn = qk(kf);
+                if (kt + 2 < N) read_k(kt + 2, kf);
+              }
+              uint32_t pk[8];
+              f32x2 ev[8];
+              const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m, -m};
+#pragma unroll
+              for (int g = 0; g < 8; ++g) {
+                f32x2 a = {st[2 * g], st[2 * g + 1]};
+                a = __builtin_elementwise_fma(a, sc2, nm2);
+                ev[g][0] = __builtin_amdgcn_exp2f(a[0]);
+                ev[g][1] = __builtin_amdgcn_exp2f(a[1]);
+                bf16x2 p;
+                p[0] = (bf16)ev[g][0]; p[1] = (bf16)ev[g][1];
+                pk[g] = __builtin_bit_cast(uint32_t, p);
+              }
+              // ---- phase 2: P.V of tile kt (matrix pipe) beside the row sums of tile kt and the row maximum of tile kt+1 (VALU)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                ru32x4 pw;
+                pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[jj][nt], pf, ot[nt], 0, 0, 0);
+              }
+              f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+              for (int g = 0; g < 8; ++g) ps2 += ev[g];
+              lsum += ps2[0] + ps2[1];
+              if (kt + 1 < N) {
+                if (kt + 1 == N - 1) mask_last(stn);
+                const float ts = row_max_scaled(stn);
+                if constexpr (UNR == 3) {  // interleave hints: one MFMA, then its share of the VALU work, per phase
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                  }
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                  }
+                }
+                if (__any(ts > m + 8.0f)) {  // deferred max (after P.V of tile kt: O is rescaled)
+                  const float m_new = fmaxf(m, ts);
+                  const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                  m = m_new;
+                  lsum *= alpha;
+#pragma unroll
+                  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ot[nt][i] *= alpha;
+                }
+                st = stn;
+              }
             }
           };
           auto tiles_unrolled = [&](auto nc) {
@@ -341,7 +485,9 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
             body(N - 1, std::true_type{}, nc);
           };
           if constexpr ((ABL & 2) == 0) {
-            if (UNR && !causal && nqt == 7) {
+            if (UNR >= 2 && !causal && nqt == 7) {
+              tiles_phased(std::integral_constant<int, 7>{});
+            } else if (UNR == 1 && !causal && nqt == 7) {
               tiles_unrolled(std::integral_constant<int, 7>{});
             } else if (UNR && !causal && nqt == 2) {
               tiles_unrolled(std::integral_constant<int, 2>{});
@@ -358,11 +504,12 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
           }
 
           // ---- normalise, transpose the O tile through the wave's Q rows, store whole rows
+          tr1 = now();
           lsum += __shfl_xor(lsum, 32);
           const float inv = 1.0f / lsum;
           const int item = (int)blockIdx.x + n * (int)gridDim.x;
           const int b = item / H, h = item - b * H;
-          if (lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __builtin_amdgcn_logf(lsum);
+          if (!TIMED && lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __builtin_amdgcn_logf(lsum);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -381,10 +528,17 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
               if (qt * 32 + row < S) *reinterpret_cast<bf16x8*>(obase + (size_t)row * D) = v;
             }
           }
+          tr2 = now();
         }
         ring_barrier();
+        if constexpr (TIMED) { tacc[0] += tr1 - tr0; tacc[1] += tr2 - tr1; tacc[2] += now() - tr2; }
         eslot = eslot + 1 == nring ? 0 : eslot + 1;
       }
+    }
+    if constexpr (TIMED) {
+      tacc[3] = now() - t_begin;
+      if (pi == 0 && lane == 0 && lse != nullptr)
+        for (int i = 0; i < 4; ++i) lse[((size_t)blockIdx.x * kRingWaves + wave) * 8 + i] = (float)tacc[i];
     }
   }
 }
@@ -419,7 +573,7 @@ bool attn_ring_supports(int S) {
 }
 int g_attn_ring_abl = 0;   // timing experiments: ABL bits of the kernel (1, 2, 8 and their sums), + 16 = runtime key loop for every shape
 
-template <int ABL, bool UNR>
+template <int ABL, int UNR>
 static int launch_ring_t(const AttnRingArgs& a, int grid, int smem, hipStream_t st) {
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to 160 KiB of dynamic LDS (the attribute is a maximum)
   auto kern = attention_ring_kernel<ABL, UNR>;
@@ -447,19 +601,36 @@ int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse
   const int grid = maxbh < cus ? maxbh : cus;
 #ifdef MMAMD_EXPERIMENTS  // ablations for tools/attn_ring_ablate.py (python -m multimodal_amd.build with MMAMD_EXPERIMENTS=1)
   switch (g_attn_ring_abl) {
-    case 1: return launch_ring_t<1, true>(a, grid, smem, st);
-    case 2: return launch_ring_t<2, true>(a, grid, smem, st);
-    case 3: return launch_ring_t<3, true>(a, grid, smem, st);
-    case 8: return launch_ring_t<8, true>(a, grid, smem, st);
-    case 9: return launch_ring_t<9, true>(a, grid, smem, st);
-    case 10: return launch_ring_t<10, true>(a, grid, smem, st);
-    case 11: return launch_ring_t<11, true>(a, grid, smem, st);
-    case 16: return launch_ring_t<0, false>(a, grid, smem, st);
-    case 17: return launch_ring_t<1, false>(a, grid, smem, st);
-    case 25: return launch_ring_t<9, false>(a, grid, smem, st);
+    case 1: return launch_ring_t<1, 1>(a, grid, smem, st);
+    case 2: return launch_ring_t<2, 1>(a, grid, smem, st);
+    case 3: return launch_ring_t<3, 1>(a, grid, smem, st);
+    case 8: return launch_ring_t<8, 1>(a, grid, smem, st);
+    case 9: return launch_ring_t<9, 1>(a, grid, smem, st);
+    case 10: return launch_ring_t<10, 1>(a, grid, smem, st);
+    case 11: return launch_ring_t<11, 1>(a, grid, smem, st);
+    case 4: return launch_ring_t<4, 1>(a, grid, smem, st);
+    case 300: return launch_ring_t<0, 1>(a, grid, smem, st);
+    case 301: return launch_ring_t<0, 3>(a, grid, smem, st);
+    case 309: return launch_ring_t<9, 2>(a, grid, smem, st);
+    case 310: return launch_ring_t<9, 3>(a, grid, smem, st);
+    case 304: return launch_ring_t<4, 2>(a, grid, smem, st);
+    case 302: return launch_ring_t<512, 2>(a, grid, smem, st);
+    case 303: return launch_ring_t<1024, 2>(a, grid, smem, st);
+    case 305: return launch_ring_t<512 + 4, 2>(a, grid, smem, st);
+    case 306: return launch_ring_t<1024 + 4, 2>(a, grid, smem, st);
+    case 41: return launch_ring_t<9 + 32, 1>(a, grid, smem, st);
+    case 73: return launch_ring_t<9 + 64, 1>(a, grid, smem, st);
+    case 137: return launch_ring_t<9 + 128, 1>(a, grid, smem, st);
+    case 265: return launch_ring_t<9 + 256, 1>(a, grid, smem, st);
+    case 105: return launch_ring_t<9 + 32 + 64, 1>(a, grid, smem, st);
+    case 233: return launch_ring_t<9 + 32 + 64 + 128, 1>(a, grid, smem, st);
+    case 201: return launch_ring_t<9 + 64 + 128, 1>(a, grid, smem, st);
+    case 16: return launch_ring_t<0, 0>(a, grid, smem, st);
+    case 17: return launch_ring_t<1, 0>(a, grid, smem, st);
+    case 25: return launch_ring_t<9, 0>(a, grid, smem, st);
   }
 #endif
-  return launch_ring_t<0, true>(a, grid, smem, st);
+  return launch_ring_t<0, 2>(a, grid, smem, st);
 }
 
 }  // namespace mmamd

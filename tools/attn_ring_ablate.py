@@ -1,5 +1,6 @@
 """Ablations / A-B of the attention kernels timed as HIP-graph replays (20 launches per graph: the Python + ctypes call costs ~90 us,
 more than the kernel, so eager loops measure the host).   python tools/attn_ring_ablate.py"""
+import os
 import sys
 from pathlib import Path
 
@@ -40,7 +41,7 @@ def main():
     for name, (B, S, H, c) in shapes.items():
         torch.manual_seed(0)
         bufs[name] = (torch.randn(B * S, 3 * H * 64).to(torch.bfloat16).cuda(), torch.empty((B * S, H * 64), dtype=torch.bfloat16, device="cuda"))
-    for rnd in range(2):
+    for rnd in range(0 if os.environ.get("ABLS") else 2):
         for name, (B, S, H, c) in shapes.items():
             qkv, out = bufs[name]
             for var, tag in ((0, "ring"), (1000, "r02")):
@@ -54,10 +55,12 @@ def main():
         print(f"vit+text   grouped {us:7.1f} us", flush=True)
     B, S, H, c = shapes["vit-b16"]
     qkv, out = bufs["vit-b16"]
-    for abl in (0, 16, 9, 25, 1, 17, 2, 8, 0, 16):
+    abls = [int(x) for x in os.environ.get("ABLS", "0,16,9,25,1,17,2,8,0,16").split(",")]
+    for abl in abls:
         L.mmamd_debug_set_attn_variant(2000 + abl)
         us = graph_time(lambda: ops.attention_fwd(qkv, B, S, H, c, out=out))
-        print(f"ring abl={abl:2d} (noDMA={abl & 1} noKeyLoop={(abl >> 1) & 1} noOstore={(abl >> 3) & 1} runtimeLoop={(abl >> 4) & 1}): {us:7.1f} us", flush=True)
+        print(f"ring abl={abl:3d} (noDMA={abl & 1} noKeyLoop={(abl >> 1) & 1} noOstore={(abl >> 3) & 1} runtimeLoop={(abl >> 4) & 1} noExp={(abl >> 5) & 1} "
+              f"noLdsReads={(abl >> 6) & 1} noMfma={(abl >> 7) & 1} noXchg={(abl >> 8) & 1}): {us:7.1f} us", flush=True)
     L.mmamd_debug_set_attn_variant(2000)
 
 

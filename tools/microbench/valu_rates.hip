@@ -8,10 +8,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-enum { FMA, EXP, MAX3, CVT, PKFMA, PKADD, MOV, MIX_EXP_FMA3, MIX_EXP_FMA1, MFMA_ONLY, MFMA_EXP2, MFMA_FMA4, ROLE_EXP_FMA, ADD, MUL, NKIND };
+enum { FMA, EXP, MAX3, CVT, PKFMA, PKADD, MOV, MIX_EXP_FMA3, MIX_EXP_FMA1, MFMA_ONLY, MFMA_EXP2, MFMA_FMA4, ROLE_EXP_FMA, ADD, MUL, ROLE_MFMA_FMA, ROLE_MFMA_EXP, MFMA_DEP_FMA8, NKIND };
 static const char* kNames[] = {"v_fma_f32", "v_exp_f32", "v_max3_f32", "v_cvt_pk_bf16_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_mov_b32",
                                "1 exp + 3 fma (per 4 instr)", "1 exp + 1 fma (per 2 instr)", "mfma 32x32x16 only (per mfma)",
-                               "mfma + 2 exp (per group)", "mfma + 4 fma (per group)", "roles: even waves exp, odd waves fma", "v_add_f32", "v_mul_f32"};
+                               "mfma + 2 exp (per group)", "mfma + 4 fma (per group)", "roles: even waves exp, odd waves fma", "v_add_f32", "v_mul_f32", "roles: waves 0-3 mfma, waves 4-7 fma", "roles: waves 0-3 mfma, waves 4-7 exp", "mfma + 8 fma (per group, dependent mfma chain)"};
 
 template <int KIND>
 __global__ void burn(int iters, float* sink, float seed) {
@@ -83,6 +83,28 @@ __global__ void burn(int iters, float* sink, float seed) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5"
                      : "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "v"(c), "v"(p[0]));
+      } else if constexpr (KIND == ROLE_MFMA_FMA || KIND == ROLE_MFMA_EXP) {
+        if (wave < 4) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        } else if constexpr (KIND == ROLE_MFMA_FMA) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "v"(p[i]));
+          REP8(X) REP8(X)
+#undef X
+        } else {
+#define X(i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+          REP8(X)
+#undef X
+        }
+      } else if constexpr (KIND == MFMA_DEP_FMA8) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "v"(p[i]));
+        REP8(X)
+#undef X
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(c), "v"(p[i]));
+        REP8(X)
+#undef X
       } else if constexpr (KIND == ROLE_EXP_FMA) {
         // waves 0-3 (first on each SIMD) run exp, waves 4-7 run fma: does a SIMD overlap one wave's transcendentals with the other's VALU?
         if (wave < 4) {
@@ -119,7 +141,7 @@ int main() {
   float* sink; hipMalloc(&sink, 16);
   const int iters = 20000;
   // per-kind: instructions (or groups) per loop iteration per wave
-  const double per_iter[NKIND] = {32, 32, 32, 32, 32, 32, 32, 8 /*groups of 4 -> 8 instr: count instr*/ * 4, 8 * 4, 8, 8, 8, 32, 32, 32};
+  const double per_iter[NKIND] = {32, 32, 32, 32, 32, 32, 32, 8 /*groups of 4 -> 8 instr: count instr*/ * 4, 8 * 4, 8, 8, 8, 32, 32, 32, 8, 8, 8};
   double ns_fma2 = run<FMA>(512, iters, sink);
   const double clk = (2.0 * iters * 32 * 2.0) / ns_fma2;  // GHz if v_fma_f32 = 2 cycles per instruction per SIMD, 2 waves per SIMD
   printf("calibration: v_fma_f32, 2 waves/SIMD: %.1f us -> %.2f GHz if 2 cycles per wave-instruction\n", ns_fma2 / 1e3, clk);
@@ -130,6 +152,13 @@ int main() {
            ns * clk / (w * iters * per_iter[K]));                                                                           \
   }
   RUN(FMA) RUN(ADD) RUN(MUL) RUN(EXP) RUN(MAX3) RUN(CVT) RUN(PKFMA) RUN(PKADD) RUN(MOV) RUN(MIX_EXP_FMA3) RUN(MIX_EXP_FMA1) RUN(MFMA_ONLY) RUN(MFMA_EXP2) RUN(MFMA_FMA4)
+  RUN(MFMA_DEP_FMA8)
+  {
+    const double ns = run<ROLE_MFMA_FMA>(512, iters, sink);
+    printf("%-40s 2 wave(s)/SIMD: %8.1f us  (per iteration: 8 mfma in waves 0-3, 64 fma in waves 4-7; mfma alone / fma alone at 1 wave per SIMD above)\n", kNames[ROLE_MFMA_FMA], ns / 1e3);
+    const double ns2 = run<ROLE_MFMA_EXP>(512, iters, sink);
+    printf("%-40s 2 wave(s)/SIMD: %8.1f us  (per iteration: 8 mfma in waves 0-3, 32 exp in waves 4-7)\n", kNames[ROLE_MFMA_EXP], ns2 / 1e3);
+  }
   {
     const double ns = run<ROLE_EXP_FMA>(512, iters, sink);
     printf("%-40s 2 wave(s)/SIMD: %8.1f us  (exp alone at 1 wave/SIMD and fma alone at 1 wave/SIMD above)\n", kNames[ROLE_EXP_FMA], ns / 1e3);
