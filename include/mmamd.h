@@ -212,6 +212,17 @@ int mmamd_vit_assemble_ln(const void* patch_emb, int pe_dtype, const float* cls,
                           const float* gamma, const float* beta, float eps, float* x, int B, int G2,
                           int d, mmamd_stream_t stream);
 
+/* Fused ViT stem (image_encoder.py:91-106 without the im2col copy and without a second pass over the tokens):
+ * mmamd_patch_embed_gemm: x[b*(g*g+1) + 1 + i, :] = conv(patch i of image b) + pos[1 + i, :]  (fp32), the patch rows gathered straight from
+ *   the bf16 image [B,3,image_size,image_size] by the GEMM's LDS-DMA (16-byte pieces = 8 pixels of one image row; patch 16 or 32), W = conv.weight
+ *   viewed [width, 3*patch*patch] (bf16, row pitch ldw), pos fp32 [g*g+1, width].  Row 0 of every image (the CLS token) is not touched.
+ * mmamd_vit_cls_lnpre_ln: x[b,0,:] = cls + pos0 (pos0 = pos[0,:]); x = ln_pre(x) in place (fp32); hn (optional, bf16 [B*S, d]) =
+ *   LayerNorm(x; gamma1, beta1, eps1) = norm1 of the first encoder layer, same pass. */
+int mmamd_patch_embed_gemm(const void* image, const void* W, int ldw, const float* pos, float* x, int B, int patch, int image_size,
+                           int width, mmamd_stream_t stream);
+int mmamd_vit_cls_lnpre_ln(float* x, const float* cls, const float* pos0, const float* gamma, const float* beta, float eps,
+                           const float* gamma1, const float* beta1, float eps1, void* hn, int B, int S, int d, mmamd_stream_t stream);
+
 /* --- K8: token embedding gather + positional embedding ----------------------------------------
  * x[b,s,:] = table[ids[b,s],:] + pos[s,:]  (fp32 out).  Returns the launch status only; ids are
  * range-clamped on device (out-of-range ids are a caller error, as with nn.Embedding).

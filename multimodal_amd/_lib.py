@@ -34,6 +34,8 @@ PROTOTYPES = {
     "mmamd_debug_set_attn_variant": (_i, [_i]),
     "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_add_layernorm_grouped": (_i, [_vp, _i, _vp]),
+    "mmamd_patch_embed_gemm": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mmamd_vit_cls_lnpre_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mmamd_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmamd_gemm_bf16_grouped": (_i, [_vp, _i, _i, _i, _vp]),
     "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -80,6 +80,14 @@ struct GemmArgs {
   // persistent kernel: workgroups that walk one tile fewer than the others (the last round of tiles is partial) start up to `stagger`
   // clock ticks late, spread evenly, so that the CUs stop draining their C tiles in lock-step (0 = off)
   int stagger = 0;
+  // patch-embedding mode of the persistent kernel (A_MODE = 1): A is a bf16 IMAGE [B,3,hw,hw]; the row m = b*g2 + gy*g + gx of the im2col
+  // matrix and its K index (c*p + py)*p + px are resolved by the LDS-DMA source addresses (16-byte pieces = 8 pixels of one image row),
+  // the output row is b*(g2+1) + 1 + (m - b*g2) (row 0 of every image is the CLS token, written elsewhere) and R = positional embedding
+  // rows 1..g2 (row index (m mod g2) + 1), models/clip/image_encoder.py:91-106
+  int i2c_g2 = 0, i2c_g = 0, i2c_p = 0, i2c_hw = 0;
+  int i2c_lcr = 0;   // log2(16-byte chunks per patch row) = log2(p / 8)
+  int i2c_ltpc = 0;  // log2(K-tiles per channel) = log2(p*p / 64)
+  int i2c_rpk = 0;   // image rows per K-tile = 64 / p
 };
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
@@ -1595,7 +1603,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
 // WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
 // SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
   constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -1631,7 +1639,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     for (int j = 0; j < A_INSTR; ++j) {
       int r = tm * BM + 8 * (wave + NW * j) + row8;
       r = r < p.M ? r : p.M - 1;
-      ao[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+      if constexpr (A_MODE == 1) {  // patch row r = (b, gy, gx); this lane's 16-byte chunk = 8 pixels of patch row py_l of the K-tile
+        const int b = r / p.i2c_g2, t = r - b * p.i2c_g2;
+        const int gy = t / p.i2c_g, gx = t - gy * p.i2c_g;
+        const int py_l = chunk >> p.i2c_lcr, px0 = (chunk & ((1 << p.i2c_lcr) - 1)) * 8;
+        ao[j] = ((uint32_t)((b * 3 * p.i2c_hw + gy * p.i2c_p + py_l) * p.i2c_hw) + (uint32_t)(gx * p.i2c_p + px0)) * 2u;
+      } else {
+        ao[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
@@ -1646,9 +1661,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   uint32_t a_off[A_INSTR], b_off[B_INSTR], a_nxt[A_INSTR], b_nxt[B_INSTR];
   auto issue_piece = [&](int buf, int kt, int i) __attribute__((always_inline)) {
     const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
-    if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
-    else dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
+    if (i < A_INSTR) {
+      if constexpr (A_MODE == 1) {  // K-tile kt = channel kt >> ltpc, image rows (kt & mask) * rpk .. + rpk - 1 of every patch
+        const size_t koff = ((size_t)(kt >> p.i2c_ltpc) * p.i2c_hw * p.i2c_hw + (size_t)(kt & ((1 << p.i2c_ltpc) - 1)) * p.i2c_rpk * p.i2c_hw) * 2u;
+        dma_piece_s(Ab + koff, a_off[i], dst);
+      } else {
+        dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
+      }
+    } else {
+      dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
+    }
   };
+  // output / residual row of GEMM row m (A_MODE = 1: the token row behind its image's CLS row; positional-embedding row of the patch)
+  auto c_row = [&](int m) -> size_t { if constexpr (A_MODE == 1) return (size_t)m + (size_t)(m / p.i2c_g2) + 1; else return (size_t)m; };
+  auto r_row = [&](int m) -> size_t { if constexpr (A_MODE == 1) return (size_t)(m % p.i2c_g2) + 1; else return (size_t)m; };
 
   const int hsw = l31 >> 1;
   uint32_t ra[2][4], rb[2][4];
@@ -1830,7 +1856,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
       for (int it = 0; it < 4; ++it) {
         const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
         dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+        if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + r_row(m) * p.ldr + n);
       }
     };
     if constexpr (OUT_F32) {
@@ -1887,7 +1913,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += rq[pass % RD][it][j];
               }
-              store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
+              store16<STP>(reinterpret_cast<float*>(p.C) + c_row(m) * p.ldc + n, __builtin_bit_cast(uint4, v));
             }
             if constexpr (FOLD == 2) {  // 8 lanes hold 32 columns of row m in this pass
               lnfold_store_acc(p, v, m, n, ok, fs1[it], fs2[it]);  // lane c = lane & 7: quad c of pass 0, quad c + 8 of pass 1
@@ -2578,12 +2604,14 @@ static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
 
 #endif  // MMAMD_EXPERIMENTS
 
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
-  if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true, FOLD>(p, st);
+  if constexpr (A_MODE == 0) {
+    if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true, FOLD>(p, st);
+  }
   constexpr int smem = 2 * 512 * 128 + (FOLD == 1 ? 256 * 16 * 8 : (BLDS ? 1024 : 0));  // + the tile's row statistics (nslot <= 16: K <= 1024) / bias
   if (FOLD == 1 && p.nslot_in > 16) return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, GM, 0, true, FOLD>(p, st);
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD, RES_DEPTH, BLDS>;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD, RES_DEPTH, BLDS, A_MODE>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
@@ -2834,6 +2862,26 @@ extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, c
                                int ldr, void* C, int ldc, int out_dtype, int M, int N, int K, int act,
                                mmamd_stream_t stream) {
   return gemm_bf16_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, out_dtype, M, N, K, act, nullptr, 0, 0, stream);
+}
+
+extern "C" int mmamd_patch_embed_gemm(const void* image, const void* W, int ldw, const float* pos, float* x, int B, int patch, int image_size,
+                                      int width, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(image && W && pos && x && B >= 0 && width > 0, MMAMD_E_BADARG, "patch_embed_gemm: bad argument");
+  MMAMD_CHECK_ARG((patch == 16 || patch == 32) && image_size > 0 && image_size % patch == 0 && image_size % 8 == 0, MMAMD_E_UNSUPPORTED,
+                  "patch_embed_gemm: patch %d / image %d (16- and 32-pixel patches of an image side that is a multiple of 8)", patch, image_size);
+  MMAMD_CHECK_ARG(width % 8 == 0 && ldw >= 3 * patch * patch && ldw % 8 == 0, MMAMD_E_UNSUPPORTED, "patch_embed_gemm: width %d / ldw %d", width, ldw);
+  MMAMD_CHECK_ARG(aligned16(image) && aligned16(W) && aligned16(pos) && aligned16(x), MMAMD_E_ALIGN, "patch_embed_gemm: pointers must be 16-byte aligned");
+  const int g = image_size / patch;
+  MMAMD_CHECK_ARG((uint64_t)B * 3u * image_size * image_size * 2u < (1ull << 32) && (uint64_t)width * ldw * 2u < (1ull << 32), MMAMD_E_UNSUPPORTED,
+                  "patch_embed_gemm: operand exceeds the 4 GiB 32-bit DMA offset range");
+  if (B == 0) return 0;
+  GemmArgs p;
+  p.A = (const bf16*)image; p.W = (const bf16*)W; p.bias = nullptr; p.R = pos; p.C = x;
+  p.M = B * g * g; p.N = width; p.K = 3 * patch * patch; p.lda = p.K; p.ldw = ldw; p.ldr = width; p.ldc = width; p.act = MMAMD_ACT_NONE; p.tiles_n = 0;
+  p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0; p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0; p.split_flat = 0; p.stagger = 0;
+  p.i2c_g2 = g * g; p.i2c_g = g; p.i2c_p = patch; p.i2c_hw = image_size;
+  p.i2c_lcr = patch == 16 ? 1 : 2; p.i2c_ltpc = patch == 16 ? 2 : 4; p.i2c_rpk = 64 / patch;
+  return launch_tiled_pp<true, MMAMD_ACT_NONE, 8, 2, 4, 0, 0, 0, 1, false, 1>(p, (hipStream_t)stream);
 }
 
 extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int nprob, int out_dtype, int act, mmamd_stream_t stream) {

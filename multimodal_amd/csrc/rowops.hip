@@ -296,6 +296,89 @@ __global__ __launch_bounds__(256) void vit_assemble_ln_kernel(const TPE* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// ViT stem behind the fused patch-embedding GEMM (mmamd_patch_embed_gemm wrote x[b,1+i] = conv(patch i) + pos[1+i] in place):
+// x[b,0] = cls + pos[0]; x = ln_pre(x) (fp32, in place) and, when asked, hn = LayerNorm(x; gamma1, beta1) (bf16) = norm1 of the first
+// encoder layer in the same pass — the row never leaves the registers between the two normalisations.  Same arithmetic, same
+// summation order as vit_assemble_ln_kernel / layernorm_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void vit_cls_lnpre_ln_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos0,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               const float* __restrict__ gamma1, const float* __restrict__ beta1, float eps1,
+                                                               bf16* __restrict__ hn, int rows, int S, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int s = row % S;
+  const int d4 = d >> 2;
+  float* xr = x + (size_t)row * d;
+  f32x4 v[MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) {
+      f32x4 t;
+      if (s == 0) {
+        t = load4(cls + 4 * c);
+        const f32x4 p = load4(pos0 + 4 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] += p[j];
+      } else {
+        t = load4(xr + 4 * c);
+      }
+      v[i] = t;
+      sum += (t[0] + t[1]) + (t[2] + t[3]);
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  auto normalise = [&](const float* g_, const float* b_, float e_) {  // v = LN(v) (rows beyond d4 stay zero)
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(sm) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = v[i][j] - mean;
+          q += t * t;
+        }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + e_);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) {
+        const f32x4 g = load4(g_ + 4 * c), bb = load4(b_ + 4 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+      }
+    }
+  };
+  (void)sum;
+  normalise(gamma, beta, eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) store4(xr + 4 * c, v[i]);
+  }
+  if (hn == nullptr) return;
+  normalise(gamma1, beta1, eps1);
+  bf16* hr = hn + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d4) store4(hr + 4 * c, v[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // token embedding gather + positional embedding  -> fp32
 // ---------------------------------------------------------------------------------------------
 template <typename TT>
@@ -918,6 +1001,25 @@ extern "C" int mmamd_vit_assemble_ln(const void* pe, int pe_dtype, const float* 
   }
 #undef LAUNCH_ASM
   return launch_status("vit_assemble_ln");
+}
+
+extern "C" int mmamd_vit_cls_lnpre_ln(float* x, const float* cls, const float* pos0, const float* gamma, const float* beta, float eps,
+                                      const float* gamma1, const float* beta1, float eps1, void* hn, int B, int S, int d, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && cls && pos0 && gamma && beta && B >= 0 && S > 0 && d > 0 && (hn == nullptr || (gamma1 && beta1)), MMAMD_E_BADARG,
+                  "vit_cls_lnpre_ln: bad argument");
+  MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "vit_cls_lnpre_ln: d=%d must be a multiple of 4 and <= 2048", d);
+  MMAMD_CHECK_ARG(aligned16(x) && aligned16(cls) && aligned16(pos0) && aligned16(gamma) && aligned16(beta) && aligned16(gamma1) && aligned16(beta1) &&
+                      aligned16(hn) && (d * 2) % 16 == 0,
+                  MMAMD_E_ALIGN, "vit_cls_lnpre_ln: rows must be 16-byte aligned");
+  if (B == 0) return 0;
+  const int rows = B * S;
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int d4 = d / 4;
+#define LAUNCH_VCL(MV) hipLaunchKernelGGL((vit_cls_lnpre_ln_kernel<MV>), grid, block, 0, st, x, cls, pos0, gamma, beta, eps, gamma1, beta1, eps1, (bf16*)hn, rows, S, d)
+  if (d4 <= 128) LAUNCH_VCL(2); else if (d4 <= 192) LAUNCH_VCL(3); else if (d4 <= 256) LAUNCH_VCL(4); else LAUNCH_VCL(8);
+#undef LAUNCH_VCL
+  return launch_status("vit_cls_lnpre_ln");
 }
 
 extern "C" int mmamd_embed_tokens(const int64_t* ids, const void* table, int table_dtype, const float* pos,

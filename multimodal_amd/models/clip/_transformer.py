@@ -88,8 +88,9 @@ class TransformerStack(nn.Module):
         return x
 
     @torch.jit.unused
-    def run(self, x: torch.Tensor, B: int, S: int, causal: bool, first: int = 0) -> torch.Tensor:
-        """x: fp32 [B*S, d] residual stream (updated in place and returned); layers [first:] only."""
+    def run(self, x: torch.Tensor, B: int, S: int, causal: bool, first: int = 0, hn0: torch.Tensor = None) -> torch.Tensor:
+        """x: fp32 [B*S, d] residual stream (updated in place and returned); layers [first:] only.  hn0 (optional, bf16 [B*S, d]): norm1 of layer
+        `first` already applied to x by the producer of x (the fused ViT stem)."""
         d, H = self.d_model, self.nhead
         if d // H != HEAD_DIM:
             raise ops.MmamdError(f"the MI355X attention kernel is built for head dim 64, got {d // H}")
@@ -97,14 +98,15 @@ class TransformerStack(nn.Module):
         dev = x.device
         pk = self._packed.get
         bf, f32 = torch.bfloat16, torch.float32
-        hn = torch.empty((M, d), dtype=bf, device=dev)
+        hn = hn0 if hn0 is not None else torch.empty((M, d), dtype=bf, device=dev)
         qkv = torch.empty((M, 3 * d), dtype=bf, device=dev)
         att = torch.empty((M, d), dtype=bf, device=dev)
         up = torch.empty((M, self.dim_feedforward), dtype=bf, device=dev)
         for li in range(first, len(self.layers)):
             layer = self.layers[li]
             sa = layer.self_attn
-            ops.layernorm(x, pk(layer.norm1.weight, f32), pk(layer.norm1.bias, f32), layer.norm1.eps, out=hn)
+            if li != first or hn0 is None:
+                ops.layernorm(x, pk(layer.norm1.weight, f32), pk(layer.norm1.bias, f32), layer.norm1.eps, out=hn)
             ops.gemm_bf16(hn, pk(sa.in_proj_weight, bf), pk(sa.in_proj_bias, f32), out=qkv)
             ops.attention_fwd(qkv, B, S, H, causal, out=att)
             ops.gemm_bf16(att, pk(sa.out_proj.weight, bf), pk(sa.out_proj.bias, f32), residual=x, out=x)
@@ -138,7 +140,7 @@ def two_stacks_groupable(sa: TransformerStack, Ma: int, sb: TransformerStack, Mb
 
 
 def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, causal_a: bool, sb: TransformerStack, xb: torch.Tensor, Bb: int,
-                   Sb: int, causal_b: bool):
+                   Sb: int, causal_b: bool, hn0_a: torch.Tensor = None):
     """Both towers of a dual encoder, layer-locked on ONE stream: layer i of tower A and layer i of tower B are independent until the loss
     (reference models/clip/model.py:63-75 simply runs one encoder after the other), so each of the four projections of a layer is ONE
     grouped persistent GEMM over both towers' tiles (ops.gemm_bf16_grouped): the short tower's tiles fill the partial last round of the
@@ -158,6 +160,8 @@ def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, cau
 
     hna, qkva, atta, upa = bufs(Ma, sa)
     hnb, qkvb, attb, upb = bufs(Mb, sb)
+    if hn0_a is not None:  # norm1 of tower A's first layer came with its stem (fused ViT stem): only tower B's is left to do
+        hna = hn0_a
     n = min(len(sa.layers), len(sb.layers))
     delta_ln = get_schedule().residual == "delta_ln"
     if delta_ln:
@@ -170,7 +174,9 @@ def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, cau
     for li in range(n):
         la, lb = sa.layers[li], sb.layers[li]
         aa, ab = la.self_attn, lb.self_attn
-        if li == 0 or not delta_ln:
+        if li == 0 and hn0_a is not None:
+            ops.add_layernorm_grouped([(xb, None, pb(lb.norm1.weight, f32), pb(lb.norm1.bias, f32), lb.norm1.eps, hnb)])
+        elif li == 0 or not delta_ln:
             ln(la.norm1, lb.norm1)
         ops.gemm_bf16_grouped([(hna, pa(aa.in_proj_weight, bf), pa(aa.in_proj_bias, f32), None, qkva),
                                (hnb, pb(ab.in_proj_weight, bf), pb(ab.in_proj_bias, f32), None, qkvb)])

@@ -104,8 +104,8 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
                                           "MI355X path (parameters are differentiable; detach the image or run under torch.no_grad())")
             return self._forward_train(x)
         # K1: patch embedding = GEMM over non-overlapping patches (conv has no bias in CLIP), fp32 result
-        h, B, S = self._stem(x)
-        h = self.encoder.run(h, B, S, causal=False)
+        h, B, S, hn0 = self._stem(x, want_hn0=True)
+        h = self.encoder.run(h, B, S, causal=False, hn0=hn0)
         return self._head(h, B, S)
 
     @torch.jit.unused
@@ -128,11 +128,33 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
             raise ValueError(f"Expected bf16 patch rows [B*{G2}, {kpad}], found {patches.dtype} {tuple(patches.shape)}")
 
     @torch.jit.unused
-    def _stem(self, x: Tensor):
-        """fp32 image -> (residual stream fp32 [B*S, w], B, S): the part of the inference forward in front of the layer stack."""
-        K = 3 * self.patch_size * self.patch_size
+    def _stem(self, x: Tensor, want_hn0: bool = False):
+        """image (fp32 or bf16) -> (residual stream fp32 [B*S, w], B, S[, hn0]): the part of the inference forward in front of the layer stack.
+        16- and 32-pixel patches take the fused stem: the patch-embedding GEMM gathers the patch rows from the bf16 image itself (LDS-DMA source
+        addresses: no im2col matrix in HBM) and adds the positional embedding in its epilogue; ONE row kernel then writes the CLS rows, applies
+        ln_pre and — `want_hn0` — also norm1 of the first encoder layer (`hn0`, bf16).  Bit-identical to the patchify / GEMM / assemble path
+        (tests/test_gpu_fused_stem.py).  14-pixel patches (28-byte runs, not DMA-able) keep that path."""
+        P = self.patch_size
+        K = 3 * P * P
         xc = x if x.is_contiguous() else x.contiguous()
-        return self._stem_patches(ops.patchify(xc, self.patch_size, (K + 63) // 64 * 64))
+        if P in (16, 32) and self.image_size % 8 == 0 and self.width % 8 == 0 and xc.numel() * 2 < 2**32:
+            f32, bf = torch.float32, torch.bfloat16
+            pk = self._packed.get
+            B = xc.shape[0]
+            g = self.image_size // P
+            S = g * g + 1
+            img = xc if xc.dtype == bf else ops.convert(xc, bf)  # (the im2col rows were bf16 on the other path too: same rounding)
+            pos = pk(self.positional_embedding, f32)
+            h = ops.patch_embed_fused(img, self._conv_weight_bf16(K), pos, P)
+            ln1 = None
+            if want_hn0:
+                n1 = self.encoder.layers[0].norm1
+                ln1 = (self.encoder._packed.get(n1.weight, f32), self.encoder._packed.get(n1.bias, f32), n1.eps)
+            hn0 = ops.vit_cls_lnpre_ln(h, pk(self.cls_token_embedding, f32), pos, pk(self.ln_pre.weight, f32), pk(self.ln_pre.bias, f32),
+                                       self.ln_pre.eps, B, S, ln1)
+            return (h, B, S, hn0) if want_hn0 else (h, B, S)
+        res = self._stem_patches(ops.patchify(xc, P, (K + 63) // 64 * 64))
+        return (*res, None) if want_hn0 else res
 
     @torch.jit.unused
     def _stem_patches(self, patches: Tensor):

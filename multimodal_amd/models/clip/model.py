@@ -115,10 +115,14 @@ class CLIP(PackedModeMixin, nn.Module):
         if from_patches:
             va._check_patches(features_a)
         ids = features_b if (features_b.dtype == torch.int64 and features_b.is_contiguous()) else features_b.to(torch.int64).contiguous()
-        ha, Ba, Sa = va._stem_patches(features_a) if from_patches else va._stem(features_a)
+        if from_patches:
+            ha, Ba, Sa = va._stem_patches(features_a)
+            hn0 = None
+        else:
+            ha, Ba, Sa, hn0 = va._stem(features_a, want_hn0=True)
         hb = tb._stem(ids)
         Bb, Sb = ids.shape
-        run_two_stacks(va.encoder, ha, Ba, Sa, False, tb.encoder, hb, Bb, Sb, True)
+        run_two_stacks(va.encoder, ha, Ba, Sa, False, tb.encoder, hb, Bb, Sb, True, hn0_a=hn0)
         return va._head(ha, Ba, Sa), tb._head(hb, Bb, Sb, ids)
 
     @torch.jit.unused

@@ -17,7 +17,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
                    check)
 
 __all__ = [
-    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patchify",
+    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "lnfold_pack", "row_stats", "gemm_bf16_res_stats", "gemm_bf16_lnfold", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
@@ -793,6 +793,42 @@ def vit_assemble_ln(patch_emb: torch.Tensor, cls: torch.Tensor, pos: torch.Tenso
                                            gamma.data_ptr(), beta.data_ptr(), float(eps), x.data_ptr(), B, G2, d,
                                            _stream()), "mmamd_vit_assemble_ln")
     return x
+
+
+def patch_embed_fused(image: torch.Tensor, w: torch.Tensor, pos: torch.Tensor, patch: int) -> torch.Tensor:
+    """Fused ViT patch embedding: image bf16 [B,3,HW,HW], w bf16 [width, 3*patch*patch] (conv.weight viewed as a GEMM weight), pos fp32
+    [g*g+1, width] -> x fp32 [B*(g*g+1), width] with x[b,1+i] = conv(patch i) + pos[1+i]; the CLS rows x[b,0] are left for vit_cls_lnpre_ln.
+    The im2col gather happens in the GEMM's LDS-DMA source addresses (mmamd_patch_embed_gemm): no patch matrix in HBM."""
+    _chk(image, "image", torch.bfloat16); _chk(w, "w", torch.bfloat16); _chk(pos, "pos", torch.float32)
+    B, C, H, W_ = image.shape
+    width, K = w.shape
+    g = H // patch
+    if C != 3 or H != W_ or K != 3 * patch * patch or tuple(pos.shape) != (g * g + 1, width):
+        raise MmamdError(f"patch_embed_fused: image {tuple(image.shape)}, w {tuple(w.shape)}, pos {tuple(pos.shape)}, patch {patch} do not match")
+    x = torch.empty((B * (g * g + 1), width), dtype=torch.float32, device=image.device)
+    check(_lib.lib().mmamd_patch_embed_gemm(image.data_ptr(), w.data_ptr(), K, pos.data_ptr(), x.data_ptr(), B, patch, H, width, _stream()),
+          "mmamd_patch_embed_gemm")
+    return x
+
+
+def vit_cls_lnpre_ln(x: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, B: int, S: int,
+                     ln1: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> Optional[torch.Tensor]:
+    """x fp32 [B*S, d] in place: CLS rows = cls + pos[0], then ln_pre; with ln1 = (gamma1, beta1, eps1) also returns bf16 LayerNorm(x) — norm1
+    of the first encoder layer, computed in the same pass (mmamd_vit_cls_lnpre_ln)."""
+    _chk(x, "x", torch.float32)
+    for n, t in (("cls", cls), ("pos", pos), ("gamma", gamma), ("beta", beta)):
+        _chk(t, n, torch.float32)
+    d = x.shape[1]
+    hn = None
+    g1 = b1 = None
+    e1 = 0.0
+    if ln1 is not None:
+        g1, b1, e1 = ln1
+        _chk(g1, "gamma1", torch.float32); _chk(b1, "beta1", torch.float32)
+        hn = torch.empty((B * S, d), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmamd_vit_cls_lnpre_ln(x.data_ptr(), cls.data_ptr(), pos.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(g1),
+                                            _ptr(b1), float(e1), _ptr(hn), B, S, d, _stream()), "mmamd_vit_cls_lnpre_ln")
+    return hn
 
 
 def embed_tokens(ids: torch.Tensor, table: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
