@@ -248,30 +248,54 @@ def grad_requested(module, *inputs) -> bool:
     return any(p.requires_grad for p in module.parameters())
 
 
-_EVAL_GRAD_MSG = ("{name}: forward in eval mode with autograd enabled would return outputs that are detached from the graph (the "
-                  "differentiable MI355X path of this module runs in train mode and returns no attention probabilities); call it under "
-                  "torch.no_grad() / with requires_grad_(False) parameters for inference, or .train() to differentiate")
+_EVAL_GRAD_MSG = ("{name}: this eval-mode forward has no differentiable path on the MI355X kernels (the differentiable path of the module runs "
+                  "in train mode and returns no attention probabilities) and an INPUT requires grad, so the caller expects gradients to flow: "
+                  "detach the input / run under torch.no_grad() for inference, or call .train() to differentiate")
+_warned_detached = set()
+
+
+def _inputs_want_grad(*inputs) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs)
+
+
+def _warn_detached_once(module) -> None:
+    """The default state of a freshly built model — eval(), grad mode on, parameters with requires_grad=True — is plain inference in the
+    reference's tests and examples: serve it (outputs carry no graph), and say so once per module class instead of refusing the call."""
+    name = type(module).__name__
+    if name not in _warned_detached:
+        _warned_detached.add(name)
+        import warnings
+
+        warnings.warn(f"{name}: eval-mode forward with grad mode on returns outputs that are NOT attached to the autograd graph on the MI355X "
+                      "path (inference); use torch.no_grad() to silence this, or .train() for the differentiable path", stacklevel=3)
 
 
 def wants_grad(module, *inputs) -> bool:
     """True: take the differentiable (autograd-node) path.  Modules whose differentiable path changes what they return (FLAVA /
-    CoCa: no attention probabilities, only the last hidden state attached) take it in train mode only; an eval-mode forward
-    that autograd would have recorded raises instead of silently detaching its outputs."""
+    CoCa: no attention probabilities, only the last hidden state attached) take it in train mode only.  In eval mode the forward is
+    inference: it raises only when an input tensor requires grad (the caller is asking for gradients this path cannot give), and warns
+    once when merely the parameters do (the default state of any freshly constructed model, in which the reference's tests and examples
+    call eval-mode forwards without torch.no_grad())."""
     if not grad_requested(module, *inputs):
         return False
     if module.training:
         return True
-    raise NotImplementedError(_EVAL_GRAD_MSG.format(name=type(module).__name__))
+    if _inputs_want_grad(*inputs):
+        raise NotImplementedError(_EVAL_GRAD_MSG.format(name=type(module).__name__))
+    _warn_detached_once(module)
+    return False
 
 
 def forbid_detached_forward(module, *inputs) -> None:
     """Stand-alone layer forwards (one attention module, one MLP called outside its stack) have no differentiable path of their own:
-    training runs through the stack-level autograd nodes.  Where the reference would have recorded the call (grad mode on and a
-    parameter or an input requires grad, train OR eval mode), refuse loudly instead of returning detached tensors."""
-    if grad_requested(module, *inputs):
+    training runs through the stack-level autograd nodes.  Refuse when an INPUT requires grad (gradients are expected to flow through
+    this call); with only parameters requiring grad (every freshly built module) serve the call as inference and warn once."""
+    if _inputs_want_grad(*inputs):
         raise NotImplementedError(
             f"{type(module).__name__}: this stand-alone forward has no differentiable path on the MI355X kernels (training goes "
-            "through the enclosing encoder / model); call it under torch.no_grad(), or freeze its parameters and detach its inputs")
+            "through the enclosing encoder / model); call it under torch.no_grad(), or detach its inputs")
+    if grad_requested(module, *inputs):
+        _warn_detached_once(module)
 
 
 class CrossEntropyFn(torch.autograd.Function):

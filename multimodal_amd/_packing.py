@@ -30,6 +30,18 @@ def invalidate_packed(model=None) -> None:
     parameter edits that bypass torch's version counter (`.data` writes); cheap — copies are rebuilt on the next forward."""
     global _EPOCH
     _EPOCH += 1
+    try:  # the scripted / compiled forwards keep their own C++ cache (csrc/torch_ops.cpp): drop it too
+        from . import _torch_ops
+
+        if _torch_ops.loaded():
+            torch.ops.mmamd.clear_packed()
+    except Exception:
+        pass
+
+
+def packed_epoch() -> int:
+    """Counter bumped by invalidate_packed(): caches outside PackedCache compare it on lookup."""
+    return _EPOCH
 
 
 class PackedModeMixin:

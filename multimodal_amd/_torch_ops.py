@@ -23,6 +23,11 @@ def try_load() -> bool:
         return False
 
 
+def loaded() -> bool:
+    """True once the shim has been registered in this process."""
+    return bool(_LOADED)
+
+
 def load():
     """Register the ops (once) and return the `torch.ops.mmamd` namespace."""
     global _LOADED

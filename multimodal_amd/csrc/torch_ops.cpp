@@ -16,6 +16,8 @@
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/core/dispatch/Dispatcher.h>
+#include <torch/csrc/autograd/autograd_not_implemented_fallback.h>
 #include <torch/library.h>
 
 #include <cmath>
@@ -419,17 +421,67 @@ Tensor rows_linear_f32_impl(const Tensor& x, const Tensor& weight, const optiona
 }
 Tensor rows_linear_f32_meta(const Tensor& x, const Tensor& weight, const optional<Tensor>&) { return at::empty({x.size(0), weight.size(0)}, x.options()); }
 
+// FLAVA's attention (modules/layers/attention.py:185-241): output + the normalised probabilities [B,H,S,S], key-padding mask honoured
+std::tuple<Tensor, Tensor> attn_probs_impl(const Tensor& qkv, int64_t B, int64_t S, int64_t H, const optional<Tensor>& key_mask, bool write_probs,
+                                           int64_t probs_dtype) {
+  chk(qkv, "qkv", at::kBFloat16);
+  TORCH_CHECK(qkv.dim() == 2 && qkv.size(0) == B * S && qkv.size(1) == 3 * H * 64, "mmamd::attn_probs: qkv must be [B*S, 3*H*64]");
+  TORCH_CHECK(probs_dtype == MMAMD_F32 || probs_dtype == MMAMD_BF16, "mmamd::attn_probs: probs_dtype must be 0 (fp32) or 1 (bf16)");
+  const uint8_t* km = nullptr;
+  if (key_mask.has_value()) {
+    chk(*key_mask, "key_mask", at::kByte);
+    TORCH_CHECK(key_mask->dim() == 2 && key_mask->size(0) == B && key_mask->size(1) == S, "mmamd::attn_probs: key_mask must be uint8 [B, S]");
+    km = key_mask->data_ptr<uint8_t>();
+  }
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
+  Tensor out = at::empty({B * S, H * 64}, qkv.options());
+  Tensor probs = write_probs ? at::empty({B, H, S, S}, qkv.options().dtype(probs_dtype == MMAMD_F32 ? at::kFloat : at::kBFloat16))
+                             : at::empty({0}, qkv.options().dtype(at::kFloat));
+  check_status(mmamd_attention_probs_fwd(qkv.data_ptr(), km, out.data_ptr(), write_probs ? probs.data_ptr() : nullptr, (int)probs_dtype, (int)B, (int)S,
+                                         (int)H, 1.0f / std::sqrt(64.0f), cur_stream(qkv)), "mmamd_attention_probs_fwd");
+  return std::make_tuple(out, probs);
+}
+std::tuple<Tensor, Tensor> attn_probs_meta(const Tensor& qkv, int64_t B, int64_t S, int64_t H, const optional<Tensor>&, bool write_probs,
+                                           int64_t probs_dtype) {
+  return std::make_tuple(at::empty({B * S, H * 64}, qkv.options()),
+                         write_probs ? at::empty({B, H, S, S}, qkv.options().dtype(probs_dtype == MMAMD_F32 ? at::kFloat : at::kBFloat16))
+                                     : at::empty({0}, qkv.options().dtype(at::kFloat)));
+}
+
+// The loss's ONE collective as a dispatcher op (modules/losses/contrastive_loss_with_temperature.py:26-47 does two list all-gathers + two
+// concats): the packed [B, 2E] block of a rank -> [W*B, 2E].  Backend-agnostic (it only calls c10d's functional collective through the
+// dispatcher: RCCL for HIP tensors, gloo for CPU tensors), traceable; group_size <= 1 returns a copy.
+Tensor allgather_packed_impl(const Tensor& buf, std::string group_name, int64_t group_size) {
+  TORCH_CHECK(buf.dim() == 2, "mmamd::allgather_packed: [B, 2E] block expected");
+  if (group_size <= 1) return buf.clone();
+  static auto gather = c10::Dispatcher::singleton()
+                           .findSchemaOrThrow("_c10d_functional::all_gather_into_tensor", "")
+                           .typed<Tensor(const Tensor&, int64_t, std::string)>();
+  static auto wait = c10::Dispatcher::singleton().findSchemaOrThrow("_c10d_functional::wait_tensor", "").typed<Tensor(const Tensor&)>();
+  return wait.call(gather.call(buf.contiguous(), group_size, std::move(group_name)));
+}
+
 int64_t abi_version_impl() { return mmamd_abi_version(); }
+
+// drops every kernel-ready parameter copy this shim holds (multimodal_amd._packing.invalidate_packed() calls it: `.data` writes do not
+// bump torch's version counter, so a stale copy could otherwise survive in scripted / compiled forwards)
+void clear_packed_impl() {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  g_pack.clear();
+}
 
 }  // namespace
 
 TORCH_LIBRARY(mmamd, m) {
   m.def("abi_version() -> int", abi_version_impl);
+  m.def("clear_packed() -> ()", clear_packed_impl);
   m.def("packed(Tensor p, int dtype) -> Tensor");
   m.def("convert(Tensor x, int dtype) -> Tensor");
   m.def("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps, int out_dtype) -> Tensor");
   m.def("gemm_bf16(Tensor a, Tensor w, Tensor? bias, Tensor? residual, int act, int out_dtype) -> Tensor");
   m.def("attn_fwd(Tensor qkv, int B, int S, int H, bool causal) -> Tensor");
+  m.def("attn_probs(Tensor qkv, int B, int S, int H, Tensor? key_mask, bool write_probs, int probs_dtype) -> (Tensor, Tensor)");
+  m.def("allgather_packed(Tensor buf, str group_name, int group_size) -> Tensor");
   m.def("patch_embed(Tensor img, Tensor conv_w, Tensor cls, Tensor pos, Tensor ln_w, Tensor ln_b, float eps, int patch) -> Tensor");
   m.def("embed_tokens(Tensor ids, Tensor table, Tensor pos) -> Tensor");
   m.def("pool_proj_normalize(Tensor h, int B, int S, Tensor? ids, Tensor ln_w, Tensor ln_b, float eps, Tensor proj, bool proj_is_linear_weight, "
@@ -453,6 +505,7 @@ TORCH_LIBRARY_IMPL(mmamd, CUDA, m) {  // the "CUDA" dispatch key is the HIP devi
   m.impl("layernorm", layernorm_impl);
   m.impl("gemm_bf16", gemm_impl);
   m.impl("attn_fwd", attn_fwd_impl);
+  m.impl("attn_probs", attn_probs_impl);
   m.impl("patch_embed", patch_embed_impl);
   m.impl("embed_tokens", embed_tokens_impl);
   m.impl("pool_proj_normalize", pool_proj_normalize_impl);
@@ -473,6 +526,7 @@ TORCH_LIBRARY_IMPL(mmamd, Meta, m) {
   m.impl("layernorm", layernorm_meta);
   m.impl("gemm_bf16", gemm_meta);
   m.impl("attn_fwd", attn_fwd_meta);
+  m.impl("attn_probs", attn_probs_meta);
   m.impl("patch_embed", patch_embed_meta);
   m.impl("embed_tokens", embed_tokens_meta);
   m.impl("pool_proj_normalize", pool_proj_normalize_meta);
@@ -485,4 +539,16 @@ TORCH_LIBRARY_IMPL(mmamd, Meta, m) {
   m.impl("coca_text_mask", coca_text_mask_meta);
   m.impl("rows_linear_f32", rows_linear_f32_meta);
   m.impl("contrastive_fwd", contrastive_fwd_meta);
+}
+
+TORCH_LIBRARY_IMPL(mmamd, CompositeExplicitAutograd, m) { m.impl("allgather_packed", allgather_packed_impl); }
+
+// No derivative formulas are registered for these ops (training runs through the autograd.Function nodes of multimodal_amd/_autograd.py,
+// whose forward AND backward are C-ABI kernels).  Without an Autograd kernel a scripted / compiled module called with grad mode on would
+// return outputs that are silently cut from the graph; with this fallback, differentiating through any mmamd op RAISES
+// ("derivative for mmamd::... is not implemented"), and inference under no_grad / with frozen parameters is unaffected.
+TORCH_LIBRARY_IMPL(mmamd, Autograd, m) {
+  for (const char* name : {"packed", "convert", "layernorm", "gemm_bf16", "attn_fwd", "attn_probs", "patch_embed", "embed_tokens", "pool_proj_normalize",
+                           "l2_normalize", "activation", "image_embed", "attn_x", "coca_text_embed", "rows_linear_f32", "contrastive_fwd"})
+    m.impl(name, torch::autograd::autogradNotImplementedFallback());
 }

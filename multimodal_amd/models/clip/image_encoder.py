@@ -53,7 +53,7 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
         self.ln_post = Fp32LayerNorm(width)
         self.projection = nn.Parameter(scale * torch.randn(width, embedding_dim))
         self._packed = PackedCache()
-        self._conv_w_cache = None  # (ptr, version, device, packed [width, Kpad] bf16)
+        self._conv_w_cache = None  # (ptr, version, device, packed [width, Kpad] bf16, invalidate_packed() epoch)
 
     @torch.jit.unused
     def _conv_weight_bf16(self, kpad: int) -> Tensor:
@@ -62,12 +62,14 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
         K = w.shape[1] * w.shape[2] * w.shape[3]
         if K == kpad:
             return self._packed.get(self.conv.weight, torch.bfloat16).view(w.shape[0], K)
+        from ..._packing import packed_epoch
+
         c = self._conv_w_cache
-        if c is not None and c[0] == w.data_ptr() and c[1] == self.conv.weight._version and c[2] == w.device:
+        if c is not None and c[0] == w.data_ptr() and c[1] == self.conv.weight._version and c[2] == w.device and c[4] == packed_epoch():
             return c[3]
         packed = torch.zeros((w.shape[0], kpad), dtype=torch.bfloat16, device=w.device)  # one-time pack
         packed[:, :K].copy_(self._packed.get(self.conv.weight, torch.bfloat16).view(w.shape[0], K))
-        self._conv_w_cache = (w.data_ptr(), self.conv.weight._version, w.device, packed)
+        self._conv_w_cache = (w.data_ptr(), self.conv.weight._version, w.device, packed, packed_epoch())
         return packed
 
     def forward(self, x: Tensor) -> Tensor:

@@ -25,6 +25,15 @@ _SIDE_STREAMS = {}
 
 
 class CLIPOutput(NamedTuple):
+    """L2-normalised embeddings of the two modalities (reference: models/clip/model.py:19-21).
+
+    Layout note (inference forwards of this package): when both towers produce [B, E] outputs of one dtype, `embeddings_a` and
+    `embeddings_b` are the two column halves of ONE [B, 2E] buffer — row stride 2E, i.e. NOT contiguous.  That block is exactly the message
+    of the contrastive loss's packed all-gather (utils.distributed.gather_packed_features sends it without packing copies) and the loss
+    kernels read the halves in place.  Values, shapes and dtypes are the reference's; code that needs a flat view should call
+    `.contiguous()` first (`.reshape(-1)` works, `.view(-1)` does not).  The scripted / compiled and the training forwards return ordinary
+    contiguous tensors."""
+
     embeddings_a: torch.Tensor
     embeddings_b: torch.Tensor
 

@@ -90,7 +90,7 @@ class CoCaModel(PackedModeMixin, nn.Module):
     def _forward_host(self, images: Tensor, texts: Tensor, text_padding_mask: Optional[Tensor] = None) -> MultimodalOutput:
         if torch.compiler.is_compiling() and not wants_grad(self):
             return self._forward_ops(images, texts, text_padding_mask)
-        training = wants_grad(self)
+        training = wants_grad(self, images)
         l2n = L2NormalizeFn.apply if training else ops.l2_normalize
         dev = images.device
         side = None

@@ -105,7 +105,7 @@ class ImageEmbeddings(nn.Module):
         if self.training and self.dropout.p > 0:
             raise ops.MmamdError("embedding dropout > 0 in training mode is not implemented on the MI355X path")
         B = pixel_values.shape[0]
-        if wants_grad(self):
+        if wants_grad(self, pixel_values):
             if interpolate_pos_encoding:
                 raise ops.MmamdError("training on the MI355X path: interpolate_pos_encoding is not implemented")
             if image_patches_mask is not None and self.mask_token is None:

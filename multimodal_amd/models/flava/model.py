@@ -115,7 +115,7 @@ class FLAVAModel(PackedModeMixin, nn.Module):
         required_embedding: Optional[EMBEDDING_OPTIONS] = None,
         skip_unmasked_mm_encoder: bool = True,
     ) -> FLAVAOutput:
-        training = wants_grad(self)
+        training = wants_grad(self, image)
         if required_embedding is None:
             if image is not None and text is not None:
                 required_embedding = "mm"

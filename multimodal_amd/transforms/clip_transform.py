@@ -65,7 +65,10 @@ def _open_text(path: str) -> str:
 
         cache = os.path.join(torch.hub.get_dir(), "checkpoints")
         os.makedirs(cache, exist_ok=True)
-        local = os.path.join(cache, os.path.basename(path))
+        import hashlib
+
+        # keyed on the FULL url (two different urls ending in merges.txt / vocab.txt must not resolve to whichever was fetched first)
+        local = os.path.join(cache, hashlib.sha1(path.encode()).hexdigest()[:8] + "_" + os.path.basename(path))
         if not os.path.exists(local):
             try:
                 torch.hub.download_url_to_file(path, local, progress=False)

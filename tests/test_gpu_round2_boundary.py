@@ -64,27 +64,38 @@ def test_clip_in_eval_mode_is_differentiable_like_the_reference():
     assert (out.embeddings_a.detach() - ref.embeddings_a).abs().max() < 2e-3
 
 
-def test_standalone_forwards_refuse_to_detach():
+def test_standalone_forwards_serve_inference_and_refuse_only_when_an_input_wants_grad():
+    """a freshly built module (parameters require grad, grad mode on) called in eval OR train mode is plain inference in the
+    reference's tests and examples — it must work (with one warning that the outputs carry no graph); only an INPUT that requires grad makes
+    the call an error (gradients would be cut off silently)."""
+    import warnings
+
+    from multimodal_amd import _autograd
     from multimodal_amd.modules.layers.mlp import MLP
     from multimodal_amd.modules.layers.multi_head_attention import MultiHeadSelfAttention
 
+    _autograd._warned_detached.clear()
     mha = MultiHeadSelfAttention(128, 2).cuda()
     q = torch.randn(2, 5, 128, device="cuda")
-    for mode in (mha.train, mha.eval):  # train OR eval: parameters require grad and grad mode is on
-        mode()
-        with pytest.raises(NotImplementedError, match="no differentiable path"):
-            mha(q)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for mode in (mha.train, mha.eval):
+            mode()
+            out = mha(q)
+            assert out.shape == (2, 5, 128) and out.grad_fn is None
+    assert sum("NOT attached to the autograd graph" in str(x.message) for x in w) == 1  # once per module class
     with torch.no_grad():
         assert mha(q).shape == (2, 5, 128)
     mha.requires_grad_(False)
     assert mha(q).shape == (2, 5, 128)  # frozen parameters, plain input: nothing to record
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError, match="no differentiable path"):
         mha(q.clone().requires_grad_(True))  # ... but an input that requires grad would be cut off
     mlp = MLP(128, 128, 256, dropout=0.0, activation=torch.nn.GELU).cuda().eval()
-    with pytest.raises(NotImplementedError, match="no differentiable path"):
-        mlp(torch.randn(3, 128, device="cuda"))
-    with torch.no_grad():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
         assert mlp(torch.randn(3, 128, device="cuda")).shape == (3, 128)
+    with pytest.raises(NotImplementedError, match="no differentiable path"):
+        mlp(torch.randn(3, 128, device="cuda", requires_grad=True))
 
 
 def test_packed_copies_follow_data_writes_after_invalidate_or_mode_change():

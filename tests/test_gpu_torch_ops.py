@@ -157,3 +157,38 @@ def test_compiled_coca_model_equals_scripted():
             got = compiled(images, texts)
         for k in ("image_pooled_output", "text_pooled_output", "multimodal_embeddings"):
             assert torch.equal(getattr(got, k), getattr(want, k)), (backend, k)
+
+
+@torch.no_grad()
+def test_attn_probs_op_equals_the_eager_kernel_call():
+    """torch.ops.mmamd.attn_probs (attn_fwd(..., write_probs)) == ops.attention_probs_fwd: FLAVA's attention with the probabilities."""
+    from multimodal_amd import _torch_ops, ops
+
+    ns = _torch_ops.load()
+    g = torch.Generator().manual_seed(2)
+    B, S, H = 3, 197, 2
+    qkv = torch.randn(B * S, 3 * H * 64, generator=g).to(torch.bfloat16).cuda()
+    km = (torch.rand(B, S, generator=g) > 0.2).to(torch.uint8)
+    km[:, 0] = 1
+    km = km.cuda()
+    for mask in (None, km):
+        for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+            o_ref, p_ref = ops.attention_probs_fwd(qkv, B, S, H, mask, want_probs=True, probs_dtype=dt)
+            o, p = ns.attn_probs(qkv, B, S, H, mask, True, code)
+            assert torch.equal(o, o_ref) and torch.equal(p, p_ref) and p.dtype == dt
+    o, p = ns.attn_probs(qkv, B, S, H, None, False, 0)
+    assert torch.equal(o, ops.attention_probs_fwd(qkv, B, S, H, None, want_probs=False)[0]) and p.numel() == 0
+
+
+def test_invalidate_packed_reaches_the_shim_cache():
+    """`.data` writes + invalidate_packed() must also refresh the C++ packed-parameter cache behind the scripted forwards."""
+    from multimodal_amd import _torch_ops
+    from multimodal_amd._packing import invalidate_packed
+
+    ns = _torch_ops.load()
+    w = torch.nn.Parameter(torch.randn(8, 64, device="cuda"))
+    a = ns.packed(w, 1).clone()
+    w.data.mul_(2.0)  # no version bump
+    assert torch.equal(ns.packed(w, 1), a)  # stale by construction ...
+    invalidate_packed()
+    assert torch.equal(ns.packed(w, 1), (w.detach()).to(torch.bfloat16))  # ... until invalidated

@@ -60,9 +60,15 @@ def test_coca_records_and_loud_failures():
     m = coca_vit(**SMALL, cascaded_pooler=False).eval()
     with pytest.raises(ops.MmamdError, match="no CPU"), torch.no_grad():
         m(torch.randn(1, 3, 64, 64), torch.randint(1, 96, (1, 13)))
-    # eval mode + autograd recording: the reference would return differentiable outputs; refuse instead of detaching silently
-    with pytest.raises(NotImplementedError, match="eval mode with autograd enabled"), torch.enable_grad():
+    from multimodal_amd import _autograd
+
+    _autograd._warned_detached.clear()
+    # eval mode + grad mode on: inference like the reference's own tests run it -> reaches the device check, not a refusal;
+    # an INPUT that requires grad is refused (its gradient would be cut off silently)
+    with pytest.raises(ops.MmamdError, match="no CPU"), torch.enable_grad(), pytest.warns(UserWarning, match="NOT attached"):
         m(torch.randn(1, 3, 64, 64), torch.randint(1, 96, (1, 13)))
+    with pytest.raises(NotImplementedError, match="INPUT requires grad"), torch.enable_grad():
+        m(torch.randn(1, 3, 64, 64, requires_grad=True), torch.randint(1, 96, (1, 13)))
     with pytest.raises(ValueError, match="doesn't match image size"):
         m.vision_encoder(torch.randn(1, 3, 32, 32))
     with pytest.raises(AssertionError):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 OPS = ["abi_version", "packed", "convert", "layernorm", "gemm_bf16", "attn_fwd", "patch_embed", "embed_tokens", "pool_proj_normalize",
-       "l2_normalize", "clamp_scalar_", "activation", "contrastive_fwd"]
+       "l2_normalize", "clamp_scalar_", "activation", "contrastive_fwd", "attn_probs", "allgather_packed"]
 
 
 @pytest.fixture(scope="module")
@@ -106,3 +106,55 @@ def test_meta_kernels_of_the_coca_ops(ns):
     assert ns.coca_text_embed(m(2, 11, dtype=torch.int64), m(96, 128), m(12, 128), m(128)).shape == (24, 128)
     assert ns.coca_text_mask(m(2, 11, dtype=torch.int64), True, 0).shape == (2, 12, 12)
     assert ns.rows_linear_f32(m(4, 128), m(64, 128), None).shape == (4, 64)
+
+
+def test_attn_probs_meta_and_schema(ns):
+    bf = torch.bfloat16
+    q = torch.empty(2 * 50, 3 * 128, dtype=bf, device="meta")
+    out, probs = ns.attn_probs(q, 2, 50, 2, None, True, 0)
+    assert out.shape == (100, 128) and out.dtype == bf and probs.shape == (2, 2, 50, 50) and probs.dtype == torch.float32
+    out, probs = ns.attn_probs(q, 2, 50, 2, torch.empty(2, 50, dtype=torch.uint8, device="meta"), True, 1)
+    assert probs.dtype == bf
+    out, probs = ns.attn_probs(q, 2, 50, 2, None, False, 0)
+    assert probs.numel() == 0
+    assert "Tensor? key_mask, bool write_probs, int probs_dtype" in str(torch.ops.mmamd.attn_probs.default._schema)
+
+
+def test_differentiating_through_an_op_raises_instead_of_detaching(ns):
+    """no Autograd kernel used to mean that a scripted / compiled module called with grad mode on returned outputs silently cut from
+    the graph.  The Autograd key now carries autogradNotImplementedFallback: the output requires grad and backward raises."""
+    x = torch.empty(6, 128, device="meta", requires_grad=True)
+    g, b = torch.empty(128, device="meta", requires_grad=True), torch.empty(128, device="meta")
+    y = ns.layernorm(x, g, b, 1e-5, 0)
+    assert y.requires_grad
+    with pytest.raises(RuntimeError, match="not implemented"):
+        y.sum().backward()
+    with torch.no_grad():  # inference is unaffected
+        assert not ns.layernorm(x, g, b, 1e-5, 0).requires_grad
+
+
+def _allgather_worker(rank, world, sync):
+    import torch.distributed as dist
+
+    from multimodal_amd import _torch_ops
+
+    dist.init_process_group("gloo", init_method=f"file://{sync}", world_size=world, rank=rank)
+    ns_ = _torch_ops.load()
+    B, E = 3, 8
+    buf = torch.arange(B * 2 * E, dtype=torch.float32).reshape(B, 2 * E) + 1000 * rank
+    name = dist.distributed_c10d._get_default_group().group_name
+    got = ns_.allgather_packed(buf, name, world)
+    ref = torch.empty(world * B, 2 * E)
+    dist.all_gather_into_tensor(ref, buf)
+    assert torch.equal(got, ref)
+    assert torch.equal(got[rank * B:(rank + 1) * B], buf)
+    dist.destroy_process_group()
+
+
+def test_allgather_packed_op_equals_the_collective_it_wraps(ns, tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_allgather_worker, (2, str(tmp_path / "sync")), nprocs=2)
+    one = torch.randn(4, 6)
+    out = ns.allgather_packed(one, "", 1)  # no process group: a copy of the block
+    assert torch.equal(out, one) and out.data_ptr() != one.data_ptr()
