@@ -63,6 +63,11 @@ def parse_args(argv=None):
     ap.add_argument("--fp32-images", action="store_true", help="feed fp32 images (the stem then converts them to bf16 inside the timed step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" IS RCCL on ROCm; gloo only with --dry-run')
     ap.add_argument("--dry-run", action="store_true", help="CPU control-flow run of the multi-rank path (no towers, no measurement)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step (both towers, loss, and for N > 1 the packed all-gather) in ONE HIP graph and time K replays: no Python "
+                         "between the kernels, so host jitter cannot skew N lock-stepped ranks; falls back to eager launches (and says so) when "
+                         "the capture fails")
+    ap.add_argument("--no-affinity", action="store_true", help="do not pin each rank to the CPUs next to its GPU")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with ONE rank: the N > 1 code path (communicator, packed all-gather, rank-offset "
                          "labels, fences, max-over-ranks) on a single-GPU box")
@@ -83,6 +88,42 @@ def relaunch(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_rank_to_local_cpus(local_rank: int, world: int, bdf=None):
+    """One process per GPU: keep each rank's Python thread (and its helper threads) on its own slice of the CPUs of the NUMA node its GPU
+    hangs off (/sys/bus/pci/devices/<bdf>/local_cpulist), so that 8 launch loops do not migrate across sockets or share cores.  Returns a
+    description for the JSON line; never fatal."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        local = avail
+        where = "all"
+        if bdf:
+            path = f"/sys/bus/pci/devices/{bdf}/local_cpulist"
+            if os.path.exists(path):
+                near = [c for c in _parse_cpulist(open(path).read()) if c in set(avail)]
+                if near:
+                    local, where = near, f"numa-local to {bdf}"
+        per = max(1, len(local) // max(world, 1))
+        lo = (local_rank * per) % len(local)
+        mine = local[lo:lo + per] or local
+        os.sched_setaffinity(0, mine)
+        return {"cpus": f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine)),
+                "count": len(mine), "policy": where}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
 
 
 def fence(dev, dist, world):
@@ -109,6 +150,7 @@ def dry_main(args, rank, world) -> None:
     ones = torch.ones(1)
     if world > 1:
         dist.all_reduce(ones)
+    affinity = None if args.no_affinity else pin_rank_to_local_cpus(int(os.environ.get("LOCAL_RANK", "0")), world)
     B, E = args.batch, 512
     g = torch.Generator().manual_seed(1234 + rank)
     a = torch.nn.functional.normalize(torch.randn(B, E, generator=g))
@@ -124,13 +166,18 @@ def dry_main(args, rank, world) -> None:
     assert (r, w) == (rank, world) and buf.shape == (world * B, 2 * E)
     assert torch.equal(buf[rank * B:(rank + 1) * B, :E], a) and torch.equal(buf[rank * B:(rank + 1) * B, E:], b)
     t = torch.tensor([dt], dtype=torch.float64)
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     if world > 1:
+        dist.all_gather(per_rank, t.clone())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    else:
+        per_rank = [t.clone()]
     if rank == 0:
         print(json.dumps({"metric": METRIC, "dry_run": True, "value": None, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(float(t) / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "backend": args.backend,
-                          "ranks_seen": int(ones.item()),
+                          "ranks_seen": int(ones.item()), "cpu_affinity_rank0": affinity,
+                          "per_rank_ms_per_step": [round(float(x) / max(args.steps, 1) * 1e3, 3) for x in per_rank],
                           "config": {"workload": "control flow of the multi-rank path on CPU tensors (no towers)", "per_gpu_batch": B,
                                      "global_batch": world * B, "parallelism": f"dp{world}"}}), flush=True)
     if world > 1:
@@ -208,6 +255,15 @@ def main() -> None:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible); one process per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = None
+    if not args.no_affinity and world > 1:
+        bdf = None
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001
+            bdf = None
+        affinity = pin_rank_to_local_cpus(local_rank, world, bdf)
 
     import torch.distributed as dist
 
@@ -257,13 +313,35 @@ def main() -> None:
     S_img = 197
     probe = ops.GemmProbe(B * S_img, 3072, 768)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    graph, graph_note = None, None
     with torch.no_grad():
         for _ in range(args.warmup):
             loss = step()
+        if args.graph:
+            # ONE HIP graph for the whole step (the C-ABI neither allocates nor synchronises; the packed all-gather of N > 1 is captured
+            # with it): K replays are timed, the loss is read from the graph's output buffer afterwards
+            try:
+                cap = torch.cuda.Stream(device=dev)
+                cap.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(cap):
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=cap):
+                        loss = step()
+                torch.cuda.current_stream(dev).wait_stream(cap)
+                for _ in range(2):
+                    graph.replay()
+            except Exception as e:  # noqa: BLE001
+                graph, graph_note = None, f"capture failed, eager launches timed instead: {type(e).__name__}: {e}"
+                torch.cuda.synchronize(dev)
+                loss = step()
         fence(dev, dist, 2 if use_dist else 1)
         t0 = time.perf_counter()
         marks[0].record()
-        if args.no_probe:
+        if graph is not None:
+            for i in range(args.steps):
+                graph.replay()
+                marks[i + 1].record()
+        elif args.no_probe:
             for i in range(args.steps):
                 loss = step()
                 marks[i + 1].record()
@@ -272,8 +350,26 @@ def main() -> None:
                 for i in range(args.steps):
                     loss = step()
                     marks[i + 1].record()
+        t_enqueued = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        dt_local = time.perf_counter() - t0   # this rank's own K steps, before it waits for the others
         fence(dev, dist, 2 if use_dist else 1)
         dt = time.perf_counter() - t0
+        # the loss's ONE collective on its own (N > 1): the packed [B, 2E] all-gather, HIP-event timed on this rank, outside the timed region
+        allgather_ms = None
+        if use_dist:
+            from multimodal_amd.utils.distributed import gather_packed_features
+
+            out = model(images_d, ids_d)
+            for _ in range(3):
+                gather_packed_features(out.embeddings_a, out.embeddings_b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                gather_packed_features(out.embeddings_a, out.embeddings_b)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            allgather_ms = e0.elapsed_time(e1) / 20
     loss_val = float(loss)
     if not math.isfinite(loss_val):
         raise SystemExit(f"non-finite loss {loss_val}")
@@ -281,8 +377,12 @@ def main() -> None:
     median_ms = per_step[len(per_step) // 2] if per_step else float("nan")
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = torch.tensor([dt_local, t_enqueued, allgather_ms or 0.0], dtype=torch.float64, device=dev)
+    per_rank_all = [per_rank]
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank_all = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(per_rank_all, per_rank)
     dt_max = float(t)
     pairs_per_s = world * B * args.steps / dt_max
 
@@ -337,6 +437,9 @@ def main() -> None:
         roofline = {"bound": "mfma", "kernel": label,
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/pmc_dominant_kernel.json: HBM bytes per launch from separate rocprofv3 --pmc "
+                                                                    "passes of this command (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); "
+                                                                    "a stored figure, not measured in this run",
                     "launch_ms": round(mean_ms, 4), "launches_timed": len(durs),
                     "algorithmic_flops_per_launch": flops,
                     "back_to_back": {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
@@ -359,8 +462,18 @@ def main() -> None:
             "step_mfma_frac": round(pairs_per_s / world * GF_PER_PAIR * 1e9 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        # diagnosability of the N > 1 runs: each rank's own time for its K steps (before the closing barrier), its host time to enqueue them,
+        # and the all-gather alone; `value` above is computed from the max-over-ranks fenced wall time as the contract says
+        line["per_rank_ms_per_step"] = [round(float(x[0]) / args.steps * 1e3, 3) for x in per_rank_all]
+        line["per_rank_host_enqueue_ms_per_step"] = [round(float(x[1]) / args.steps * 1e3, 3) for x in per_rank_all]
+        line["graph"] = graph is not None
+        if graph_note:
+            line["graph_note"] = graph_note
+        if affinity is not None:
+            line["cpu_affinity_rank0"] = affinity
         if ranks_seen is not None:
             line["rccl_ranks_seen"] = ranks_seen
+            line["allgather_ms"] = [round(float(x[2]), 4) for x in per_rank_all]
         os.write(record_fd, (json.dumps(line) + "\n").encode())
     os.close(record_fd)
     if use_dist:

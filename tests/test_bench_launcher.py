@@ -86,3 +86,33 @@ def test_force_dist_runs_the_rccl_path_with_one_rank():
     assert lines["rccl"]["rccl_ranks_seen"] == 1 and "rccl_ranks_seen" not in lines["local"]
     assert "RCCL all-gather" in lines["rccl"]["config"]["workload"]
     assert lines["rccl"]["loss"] == lines["local"]["loss"]
+
+
+def test_self_launch_eight_ranks_gloo_dry_run():
+    """W = 8 — the size of the SCALE run: eight self-launched ranks through the same control flow (rendezvous, ranks-seen all-reduce, packed
+    gather with its layout check, per-rank CPU pinning, per-rank times gathered to rank 0, ONE JSON line)."""
+    p = run_bench("--gpus", "8", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "1", "--batch", "4", timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    (line,) = json_lines(p.stdout)
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["config"]["global_batch"] == 32 and line["config"]["parallelism"] == "dp8"
+    assert len(line["per_rank_ms_per_step"]) == 8 and all(x > 0 for x in line["per_rank_ms_per_step"])
+    assert max(line["per_rank_ms_per_step"]) <= line["ms_per_step"] * 1.5 + 1.0
+    aff = line["cpu_affinity_rank0"]
+    assert aff is None or "error" in aff or aff["count"] >= 1
+
+
+def test_cpu_pinning_helper_splits_the_visible_cpus():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    before = os.sched_getaffinity(0)
+    try:
+        got = b.pin_rank_to_local_cpus(1, 2)
+        assert got["count"] >= 1 and set(os.sched_getaffinity(0)) <= set(before)
+        if len(before) >= 2:
+            assert len(os.sched_getaffinity(0)) == len(before) // 2
+    finally:
+        os.sched_setaffinity(0, before)
