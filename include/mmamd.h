@@ -374,23 +374,6 @@ int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int 
 /* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(1024, rows) * n floats. */
 int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */
-/* LayerNorm folded into the GEMMs either side of it (pre-norm transformer blocks: torch TransformerEncoderLayer norm_first,
- * torch/nn/modules/transformer.py:946-950, called from models/clip/image_encoder.py:108 and text_encoder.py:121):
- *   y = LN(x; gamma, beta, eps) W^T + b  ==  rstd_m (xh W'^T - mu_m c1) + c2,   xh = bf16(x), W' = bf16(gamma (.) W),
- *   c1[n] = sum_k W'[n][k], c2[n] = b[n] + sum_k beta[k] W[n][k].
- * mmamd_lnfold_pack        one-time packing of (W [N,K] fp32|bf16, gamma, beta, bias|NULL) into (Wg bf16 [N,K], c1 [N], c2 [N]).
- * mmamd_gemm_bf16_res_stats the PRODUCER of x: C (fp32, may alias residual) = A W^T + bias + residual, plus Xh = bf16(C) and
- *                          stats[m][N/64][2] = (sum, sum of squares) of every 64-column block of row m.  N % 128 == 0.
- * mmamd_gemm_bf16_lnfold   the CONSUMER: C (bf16) = act(rstd_m (Xh Wg^T - mu_m c1) + c2), mu / rstd finished in the epilogue from the
- *                          nslot = K/64 partials of each row (fixed order).
- * mmamd_row_stats          Xh and stats (block 0 = whole row, other blocks 0) of a residual stream no GEMM produced (layer 0 input). */
-int mmamd_lnfold_pack(const void* W, int w_dtype, const float* gamma, const float* beta, const float* bias, void* Wg, float* c1,
-                      float* c2, int N, int K, mmamd_stream_t stream);
-int mmamd_gemm_bf16_res_stats(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr,
-                              float* C, int ldc, void* Xh, int ldxh, float* stats, int M, int N, int K, mmamd_stream_t stream);
-int mmamd_gemm_bf16_lnfold(const void* Xh, int lda, const void* Wg, int ldw, const float* c1, const float* c2, const float* stats,
-                           int nslot, float eps, void* C, int ldc, int M, int N, int K, int act, mmamd_stream_t stream);
-int mmamd_row_stats(const float* x, void* xh, float* stats, int rows, int d, int nslot, mmamd_stream_t stream);
 /* Streams confined to a subset of the CUs (hipExtStreamCreateWithCUMask): the two towers of the dual encoder are independent until
  * the loss (reference models/clip/model.py:70-71 runs them one after the other); here each gets its own CU partition so that neither
  * tower's persistent kernels queue behind the other's.  mask: `words` 32-bit words, bit i = CU i in the runtime's CU numbering.

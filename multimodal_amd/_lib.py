@@ -63,10 +63,6 @@ PROTOTYPES = {
     "mmamd_dalle_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_row_softmax_": (_i, [_vp, _i64, _i, _vp]),
     "mmamd_dalle_pack": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "mmamd_lnfold_pack": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "mmamd_gemm_bf16_res_stats": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
-    "mmamd_gemm_bf16_lnfold": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _vp]),
-    "mmamd_row_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "mmamd_stream_create_cu_mask": (_i, [_vp, _i, _vp]),
     "mmamd_stream_destroy": (_i, [_vp]),
     "mmamd_stream_cus": (_i, [_vp]),

@@ -105,29 +105,6 @@ class PackedCache:
         self._cat[key] = (sig, buf)
         return buf
 
-    def get_lnfold(self, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias) -> tuple:
-        """(Wg bf16, c1, c2) of a Linear(w, bias) fed by LayerNorm(gamma, beta), for the LN-folded GEMM (ops.lnfold_pack); cached like
-        every other kernel-ready copy."""
-        self._sync_epoch()
-        params = [w, gamma, beta] + ([bias] if bias is not None else [])
-        ts = [p.detach() for p in params]
-        for t in ts:
-            if not t.is_cuda:
-                raise ops.MmamdError(
-                    f"parameter lives on {t.device}: move the module to a HIP device (.to('cuda')); there is no CPU path")
-        key = (("lnfold",) + tuple(id(p) for p in params), torch.bfloat16)
-        sig = tuple((t.data_ptr(), p._version) for t, p in zip(ts, params))
-        hit = self._cat.get(key)
-        if hit is not None and hit[0] == sig:
-            return hit[1]
-        f32 = torch.float32
-        wt = ts[0] if ts[0].is_contiguous() else ts[0].contiguous()
-        if wt.dtype not in (f32, torch.bfloat16):
-            raise ops.MmamdError(f"unsupported weight dtype {wt.dtype}")
-        packed = ops.lnfold_pack(wt, self.get(gamma, f32), self.get(beta, f32), self.get(bias, f32) if bias is not None else None)
-        self._cat[key] = (sig, packed)
-        return packed
-
     def get_padded_rows(self, p: torch.Tensor, dtype: torch.dtype, multiple: int) -> torch.Tensor:
         """`p` ([rows, ...]) with its row count rounded up to `multiple` (zero rows appended) — e.g. a [30522, d] vocabulary
         projection padded to the GEMM's N % 8 == 0."""

@@ -66,17 +66,6 @@ struct GemmArgs {
   int split_flat;           // split-K with the split index folded into blockIdx.x (1-D grid of tiles * splits, split-major): 0 = blockIdx.y
   void* C2;                 // training forward of the MLP: second bf16 output act2(bf16(C)) next to the pre-activation C (NULL = none)
   int ldc2, act2;
-  // LayerNorm folded into the GEMMs either side of it (file header of the "LN fold" section below).
-  // producer (fp32 residual GEMM): bf16 copy of the output rows + per-row partial (sum, sum of squares) of every 64-column block
-  bf16* Xh = nullptr;
-  int ldxh = 0;
-  float* st_out = nullptr;  // [M][nslot_out][2]
-  int nslot_out = 0;
-  // consumer (A = that bf16 copy, W = gamma-scaled weight): C = rstd_m (acc - mu_m c1[n]) + bias[n], then the activation
-  const float* st_in = nullptr;  // [M][nslot_in][2]
-  int nslot_in = 0;
-  const float* c1 = nullptr;     // [N] row sums of the gamma-scaled bf16 weight
-  float inv_d = 0.f, ln_eps = 0.f;
   // persistent kernel: workgroups that walk one tile fewer than the others (the last round of tiles is partial) start up to `stagger`
   // clock ticks late, spread evenly, so that the CUs stop draining their C tiles in lock-step (0 = off)
   int stagger = 0;
@@ -144,79 +133,12 @@ __device__ __forceinline__ void store_act_copy(const GemmArgs& p, uint4 v, int m
   *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C2) + (size_t)m * p.ldc2 + n) = __builtin_bit_cast(uint4, a8);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// LN fold.  A pre-norm block computes  y = LN(x) W^T + b  with  LN(x) = (x - mu) rstd gamma + beta  per token row.  Algebra:
-//     y[m][n] = rstd_m ( sum_k x[m][k] (gamma_k W[n][k])  -  mu_m sum_k gamma_k W[n][k] )  +  ( sum_k beta_k W[n][k] + b[n] )
-//             = rstd_m ( acc[m][n] - mu_m c1[n] ) + c2[n]          acc = xh . W'^T,  xh = bf16(x),  W' = bf16(gamma (.) W)
-// so the LayerNorm pass (a 155 MB fp32 read + 77 MB bf16 write per call at ViT-B/16, B = 256) disappears: the GEMM that PRODUCES x
-// (attention out-projection / MLP down-projection with the fp32 residual) also writes xh and, per row and 64-column block, the
-// partial sums (sum x, sum x^2) of the fp32 values; the GEMM that CONSUMES LN(x) reads xh as its A operand and finishes the
-// statistics (mu, rstd from the N/64 partials of its rows, fixed summation order -> bit-reproducible) in its epilogue.
-// Numerics: x instead of LN(x) is rounded to bf16, which scales the operand rounding error of a token by sqrt(1 + mu^2/sigma^2)
-// (tools/ln_fold_numerics.py); var = E[x^2] - mu^2 in fp32.  Parity at the headline size: tests/test_gpu_headline_parity.py.
-// ---------------------------------------------------------------------------------------------------------
-// st_lds (FOLD == 1, persistent kernel): the statistics of the tile's rows, [BM][nslot][2] floats, DMA'd into LDS during the K loop
-// bias_lds (persistent kernel, FOLD == 0): the tile's 256 bias values, DMA'd into LDS during the K loop (the eight 16-byte global loads
-// per lane at the head of the epilogue were an exposed L2 round trip per tile)
-template <int MI, int NI, int TM, int TN, int FOLD, int ACT, bool STLDS = false>
-__device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn, int lane,
-                                               const char* st_lds = nullptr, const char* bias_lds = nullptr) {
-  const int l31 = lane & 31, half = lane >> 5;
-  if constexpr (FOLD == 1) {
-    // the 128 accumulators leave ~100 VGPRs to this code: statistics first (2 * MI live values), then one column group at a time with
-    // a scheduling fence between groups (hipcc otherwise hoists the c1 / c2 loads of all 8 groups to the top: 64 more live registers)
-    float rs[MI], nmr[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      float s1 = 0.f, s2 = 0.f;
-      if constexpr (STLDS) {
-        const float* s = reinterpret_cast<const float*>(st_lds) + (size_t)(wm * TM + mi * 32 + l31) * (size_t)(2 * p.nslot_in);
-        for (int k = 0; k < p.nslot_in; k += 2) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(s + 2 * k);
-          s1 += v[0]; s2 += v[1];
-          s1 += v[2]; s2 += v[3];
-        }
-      } else {
-        int m = m0 + wm * TM + mi * 32 + l31;
-        m = m < p.M ? m : p.M - 1;
-        const float* s = p.st_in + (size_t)m * (size_t)(2 * p.nslot_in);
-#pragma unroll 4
-        for (int k = 0; k < p.nslot_in; k += 2) {  // nslot is even (host check); fixed order: block 0, 1, 2, ...
-          const f32x4 v = load4(s + 2 * k);
-          s1 += v[0]; s2 += v[1];
-          s1 += v[2]; s2 += v[3];
-        }
-      }
-      const float mean = s1 * p.inv_d;
-      rs[mi] = __builtin_amdgcn_rsqf(fmaxf(fmaf(s2, p.inv_d, -mean * mean), 0.f) + p.ln_eps);
-      nmr[mi] = -mean * rs[mi];  // acc' = rs acc + (-mu rs) c1 + c2
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // one 32-column half (4 column groups) at a time: its 8 c1 / c2 loads are issued together (ONE L2 round trip per half; a fence
-    // per group made it one per group: +10 % on the ViT MLP-up GEMM, 2 x on the text tower's), 32 live registers
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      f32x4 cv[4], bv[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * TN + ni * 32 + 4 * half + 8 * g;
-        cv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n + 3 < p.N) { cv[g] = load4(p.c1 + n); bv[g] = load4(p.bias + n); }
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float v = fmaf(rs[mi], acc[ni][mi][4 * g + j], fmaf(nmr[mi], cv[g][j], bv[g][j]));
-            // QuickGELU right here (the callers skip their own pass when FOLD == 1)
-            acc[ni][mi][4 * g + j] = ACT == MMAMD_ACT_QUICKGELU ? quick_gelu(v) : v;
-          }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else if (p.bias != nullptr) {
+// bias add of the epilogues (depends on the column only).  bias_lds (persistent kernel): the tile's 256 bias values, DMA'd into LDS during the K
+// loop (the eight 16-byte global loads per lane at the head of the epilogue were an exposed L2 round trip per tile)
+template <int MI, int NI, int TM, int TN>
+__device__ __forceinline__ void add_bias(f32x16 (&acc)[NI][MI], const GemmArgs& p, int n0, int wn, int lane, const char* bias_lds = nullptr) {
+  const int half = lane >> 5;
+  if (p.bias != nullptr) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -233,20 +155,6 @@ __device__ __forceinline__ void bias_or_lnfold(f32x16 (&acc)[NI][MI], const Gemm
   }
 }
 
-// producer side.  CANONICAL summation order of a row's 64-column block (every epilogue reproduces it, so a row's statistics are
-// bit-identical whichever kernel the dispatcher picks for a batch size): column quads q_c = (v0 + v1) + (v2 + v3), c = 0..15;
-// u_c = q_c + q_(c+8), c = 0..7 (the two 32-column halves); then a butterfly over c with partners c^1, c^2, c^4.  Sum of squares alike
-// with quads fma(v0, v0, v1 v1) + fma(v2, v2, v3 v3).
-__device__ __forceinline__ void lnfold_store_acc(const GemmArgs& p, f32x4 v, int m, int n, bool ok, float& s1, float& s2) {
-  if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, v);  // bf16 copy of the 4 values
-  s1 += (v[0] + v[1]) + (v[2] + v[3]);
-  s2 += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
-}
-__device__ __forceinline__ void lnfold_butterfly8(float& a, float& b) {  // partners c^1, c^2, c^4 = lanes ^1, ^2, ^4
-#pragma unroll
-  for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-}
-
 static int g_gemm_variant = 0;
 // per cent of a tile time; measured (tools/gemm_variant_bench.py --staggers 0,30,60,90,120, profiles/r02_gemm_stagger.txt): 60 is the best or
 // within 1 % of it on every shape whose last round of tiles is partial (ViT MLP-up -3.6 %, out-proj -8 %, text MLP-up -10.6 %, patch -7.6 %)
@@ -255,13 +163,13 @@ static unsigned long long* g_gemm_trace = nullptr;
 
 // Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
 // n = .. + 8g + 4*(lane>>5) + {0..3}.
-template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT, int FOLD = 0>
+template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm, int wn,
                                               int lane) {
   const int l31 = lane & 31, half = lane >> 5;
   // pass 1: bias (depends on n only) or the folded LayerNorm.  pass 2: activation behind ONE uniform branch.  pass 3: residual + store.
-  bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT>(acc, p, m0, n0, wm, wn, lane);
-  if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
+  add_bias<MI, NI, TM, TN>(acc, p, n0, wn, lane);
+  if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -287,9 +195,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * TM + mi * 32 + l31;
     const bool mok = m < p.M;
-    // LN fold (producer): the canonical order (lnfold_store_acc) in this layout: quad c = 2 g + half of 32-column half ni, so
-    // u_c = ua[g] (sum over ni, in-lane), partner c^1 = the other lane half, partners c^2 / c^4 = accumulator groups g^1 / g^2
-    float ua[4] = {0.f, 0.f, 0.f, 0.f}, ub[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int nb = n0 + wn * TN + ni * 32 + 4 * half;
@@ -310,11 +215,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
         }
         if constexpr (OUT_F32) {
           if (ok) store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, t);
-          if constexpr (FOLD == 2) {
-            if (ok) store4(p.Xh + (size_t)m * p.ldxh + n, t);
-            ua[g] += (t[0] + t[1]) + (t[2] + t[3]);
-            ub[g] += fmaf(t[0], t[0], t[1] * t[1]) + fmaf(t[2], t[2], t[3] * t[3]);
-          }
         }
         v[g] = t;
       }
@@ -339,20 +239,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
         }
       }
     }
-    if constexpr (OUT_F32 && FOLD == 2) {
-      {  // TN == 64: the wave's columns are ONE 64-column block
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          ua[g] += __shfl_xor(ua[g], 32);
-          ub[g] += __shfl_xor(ub[g], 32);
-        }
-        const float ls1 = (ua[0] + ua[1]) + (ua[2] + ua[3]), ls2 = (ub[0] + ub[1]) + (ub[2] + ub[3]);
-        if (mok && half == 0) {
-          const int slot = (n0 + wn * TN) >> 6;
-          *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + slot) * 2) = f32x2{ls1, ls2};
-        }
-      }
-    }
   }
 }
 
@@ -361,13 +247,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
 // at 30-50 % of the kernel time.  Here every wave transposes its sub-tile through a private LDS strip, 32 rows at a
 // time, and then stores/loads FULL rows: one wave-instruction covers 8 rows x 128 B (bf16) or 4 rows x 256 B (fp32),
 // i.e. whole cache lines; the fp32 residual is read with the same row-contiguous pattern.
-template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT, int ABL = 0, int FOLD = 0>
+template <int MI, int NI, int TM, int TN, bool OUT_F32, int ACT, int ABL = 0>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const GemmArgs& p, int m0, int n0, int wm,
                                                   int wn, int lane, int wave, char* smem) {
   static_assert(TN == 64, "row strip below is laid out for 64-column wave tiles");
   const int l31 = lane & 31, half = lane >> 5;
-  bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT>(acc, p, m0, n0, wm, wn, lane);
-  if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
+  add_bias<MI, NI, TM, TN>(acc, p, n0, wn, lane);
+  if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -429,15 +315,6 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
             for (int j = 0; j < 4; ++j) v[j] += rr[it][j];
           }
           store4(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
-        }
-        if constexpr (FOLD == 2) {  // LN fold (producer): 16 lanes hold the 64 columns of row m
-          float s1 = 0.f, s2 = 0.f;
-          lnfold_store_acc(p, v, m, n, ok, s1, s2);  // lane c = lane & 15 holds quad c
-          s1 += __shfl_xor(s1, 8);                   // u_c = q_c + q_(c+8)
-          s2 += __shfl_xor(s2, 8);
-          lnfold_butterfly8(s1, s2);
-          if (m < p.M && (lane & 15) == 0)
-            *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{s1, s2};
         }
       }
 #pragma unroll
@@ -514,7 +391,7 @@ __device__ __forceinline__ void store16(void* ptr, uint4 v) {
 }
 
 // BM x BN block tile, WM x WN waves, BK = 64
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB, int FOLD = 0>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -634,7 +511,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
     }
   }
 
-  gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT, FOLD>(acc, p, m0, n0, wm, wn, lane);
+  gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane);
 }
 
 
@@ -656,7 +533,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 // K-tile is then [64 t][256 cols], stored as 256-byte units of [4 t][32 cols] (two [4][16] blocks) in [t/4][cols/32] order — the
 // DMA lays it out through its per-lane source addresses — and every MFMA operand is two ds_read_b64_tr_b16 (4 + 4 contraction
 // indices of one column per lane; the two 16-lane groups of a half-wave read one contiguous 256-byte unit: conflict-free).
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0, int FOLD = 0>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m,
                                                                         unsigned long long* trace = nullptr) {
   static_assert(!TNM || (BM == 256 && BN == 256), "TN image below is laid out for 256-column operand tiles");
@@ -944,15 +821,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     if (ssum == 1.2345678e33f) reinterpret_cast<float*>(p.C)[0] = ssum;
     return;
   }
-  if constexpr (FOLD != 0) {  // never split-K: the kernel argument is used as is (a local copy of the enlarged struct is not promoted to SGPRs)
-    if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL, FOLD>(acc, p, m0, n0, wm, wn, lane, wave, smem);
-    else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT, FOLD>(acc, p, m0, n0, wm, wn, lane);
-  } else {
-    GemmArgs pe = p;
-    if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)split * (size_t)p.c_split_stride;
-    if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL, 0>(acc, pe, m0, n0, wm, wn, lane, wave, smem);
-    else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT, 0>(acc, pe, m0, n0, wm, wn, lane);
-  }
+  GemmArgs pe = p;
+  if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)split * (size_t)p.c_split_stride;
+  if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, pe, m0, n0, wm, wn, lane, wave, smem);
+  else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, pe, m0, n0, wm, wn, lane);
   if constexpr ((ABL & 64) != 0) {
     stamp();                                           // stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores retired
@@ -964,634 +836,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 
 
 #ifdef MMAMD_EXPERIMENTS
-// ---------------------------------------------------------------------------------------------------------
-// Ping-pong kernel ("G"): 256 x 256 tile, BK = 64, 2-stage LDS ring, 8 waves (2 x 4), 128 x 64 per wave — same tile, LDS image,
-// DMA pieces and epilogue as "P", different time structure.
-//
-// Why: in "P" every wave interleaves its fragment reads and DMA issue 1:1 with its own MFMAs, and the two waves of a SIMD
-// do the same thing at the same time: the ablations put MFMA + DMA at 1613 TF/s-equivalent and MFMA + DMA + ds_read at 1190 —
-// the reads steal issue slots from the matrix pipe.  Here the two waves of a SIMD (wave w and w + 4, i.e. wm = 0 / wm = 1) run
-// ONE BARRIER APART: while one group issues an uninterrupted burst of 8 MFMAs at raised priority, the other one issues its
-// ds_reads and DMA pieces, then they swap.  Each K-tile is four phases (one 64 x 32 quadrant of the wave tile x all of K = 64):
-//
-//     phase : LOAD  { fragment reads of this phase; 2 DMA pieces }  s_barrier  MFMA { 8 x mfma_32x32x16 }  s_barrier
-//     quadrants (m-half, n-block): (0,0) (0,1) (1,1) (1,0)  ->  A fragments are read in phases 0 and 2, W fragments in 0 and 1
-//                                                               (both W sets stay in registers; phase 3 reads nothing)
-//
-// Because the W units of a stage are dead after phase 1 and the A units after phase 2, the DMA stream runs a whole K-tile
-// ahead inside a 2-stage ring.  Units (2 pieces per wave each): W-lo/W-hi = weight rows 0-127 / 128-255 of the tile,
-// A-lo/A-hi = activation rows 0-127 (read only by group 0) / 128-255 (only by group 1).  Issue schedule, tile t in stage t&1:
-//     phase 0(t): W-hi(t+1)   phase 1(t): A-lo(t+1)   phase 2(t): A-hi(t+1)   phase 3(t): W-lo(t+2)
-// Slots (= barrier intervals): group 0 reads tile t in slots 8t, 8t+2, 8t+4 and group 1 in 8t+1, 8t+3, 8t+5; a read issued in
-// slot L is retired by its wave's lgkmcnt(0) at the start of slot L+1, i.e. before the barrier that ends L+1: a unit may be
-// restaged from slot L+2 on.  W (last read 8t+3) -> restaged in slots 8t+6.. (phase 3) ok; A-lo (8t+4) -> 8t+10..; A-hi (8t+5)
-// -> 8t+12.. ok.
-// MEASURED (MI355X, qkv shape, TF/s-equivalent): full 1007 (P 1043, PP 1088); without epilogue 1197 (P 1320); MFMA + barriers 1758;
-// MFMA + reads 1345; MFMA + DMA 1625; loads only 1932.  The fragment reads cost the same ~25 % as in P even though another wave
-// issues them: not an issue-slot effect.  Kept as an experiment (variants 30/31/34-38).
-// RAW: every wave waits `vmcnt(2)` (its two youngest pieces = W-lo(t+2) may stay in flight) at the end of
-// slot 8t+7 — the end of the MFMA section of phase 3 for group 0, of the LOAD section of phase 3 for group 1 — and tile t+1 is
-// first read in slot 8t+8, behind the barrier.  Never vmcnt(0) in the loop except at the tail where phase 3 issues nothing.
-template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_g(const GemmArgs p, const int tiles_m, unsigned long long* trace) {
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
-  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;  // 128 x 64 per wave: MI 4, NI 2
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;             // 32 KiB + 32 KiB
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  int tm, tn;
-  {
-    const int per_group = GM * p.tiles_n;
-    const int grp = bid / per_group, within = bid - grp * per_group;
-    const int gm0 = grp * GM;
-    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
-    tn = within / rows;
-    tm = gm0 + (within - tn * rows);
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // wm is also the ping-pong group: waves w and w+4 share a SIMD
-
-  // DMA source offsets (same image as "P": bank swizzle applied on the source side)
-  const int sw = (4 * (wave & 3) + (lane >> 4)) & 15;
-  const int slot = (lane & 15) ^ sw;
-  const int row8 = 2 * (lane >> 4) + (slot >> 3);
-  const int chunk = slot & 7;
-  uint32_t a_off[4], b_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int r = m0 + 8 * (wave + NW * j) + row8;
-    r = r < p.M ? r : p.M - 1;
-    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
-    int c = n0 + 8 * (wave + NW * j) + row8;
-    c = c < p.N ? c : p.N - 1;
-    b_off[j] = ((uint32_t)c * (uint32_t)p.ldw + chunk * 8) * 2u;
-  }
-  const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  // unit u of K-tile kt into stage buf: 0 = A-lo, 1 = A-hi, 2 = W-lo, 3 = W-hi (pieces j = 2(u&1), 2(u&1)+1 of the operand)
-  auto issue_unit = [&](int buf, int kt, int u) __attribute__((always_inline)) {
-    if constexpr ((ABL & 1) != 0) { if (kt > 0) return; }  // ablation: no DMA after the prologue
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int j = 2 * (u & 1) + e;
-      if (u < 2) dma_piece_s(Ab + (size_t)kt * 128, a_off[j], lds0 + buf * STAGE + (wave + NW * j) * 1024);
-      else dma_piece_s(Wb + (size_t)kt * 128, b_off[j], lds0 + buf * STAGE + A_BYTES + (wave + NW * j) * 1024);
-    }
-  };
-
-  const int l31 = lane & 31, half = lane >> 5;
-  const int hsw = l31 >> 1;
-  uint32_t ra[2][4], rb[2][4];
-#pragma unroll
-  for (int bf = 0; bf < 2; ++bf)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
-      ra[bf][t] = lds0 + bf * STAGE + (wm * TM) * 128 + ro;
-      rb[bf][t] = lds0 + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
-    }
-  typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
-
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-  bf16x8 xa[2][4], w0[4], w1[4];  // A fragments of the current m-half (2 row blocks x 4 k-steps); both W column blocks
-
-  auto bar = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  const int KT = p.K >> 6;  // even (checked by the launcher)
-  int tix = 0;
-  unsigned long long* tr = nullptr;
-  if constexpr (TRACE) {
-    if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
-  }
-  auto stamp = [&]() __attribute__((always_inline)) {
-    if constexpr (TRACE) {
-      if (tr != nullptr && tix < 255) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if (lane == 0) tr[1 + tix] = t;
-        ++tix;
-      }
-    }
-  };
-
-  // one phase.  BF: stage of the current K-tile (compile-time), PH: phase 0..3, kt: current K-tile
-  auto phase = [&](auto bufc, auto phc, int kt) __attribute__((always_inline)) {
-    constexpr int BF = decltype(bufc)::value, PH = decltype(phc)::value;
-    constexpr int MH = (PH >= 2) ? 1 : 0;             // m-half of the wave tile
-    constexpr int NB = (PH == 1 || PH == 2) ? 1 : 0;  // n-block
-    // ---- LOAD section
-    if constexpr (PH == 0 && (ABL & 8) == 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) w0[t] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t]));
-    }
-    if constexpr (PH == 1 && (ABL & 8) == 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) w1[t] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + 32 * 128));
-    }
-    if constexpr ((PH == 0 || PH == 2) && (ABL & 8) == 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) xa[mi][t] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + (2 * MH + mi) * 32 * 128));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    bool issued_ahead = true;
-    if constexpr (PH == 0) { if (kt + 1 < KT) issue_unit(BF ^ 1, kt + 1, 3); }
-    if constexpr (PH == 1) { if (kt + 1 < KT) issue_unit(BF ^ 1, kt + 1, 0); }
-    if constexpr (PH == 2) { if (kt + 1 < KT) issue_unit(BF ^ 1, kt + 1, 1); }
-    if constexpr (PH == 3) {
-      issued_ahead = kt + 2 < KT;
-      if (issued_ahead) issue_unit(BF, kt + 2, 2);
-      if (wm == 1) {  // group 1: this LOAD section is slot 8t+7
-        if (issued_ahead) __builtin_amdgcn_s_waitcnt(0x0F72 | 0x0000);  // vmcnt(2)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
-      }
-    }
-    stamp();
-    bar();
-    stamp();
-    // ---- MFMA section
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this phase's (and older) fragment reads
-    stamp();
-    __builtin_amdgcn_s_setprio(1);
-    if constexpr ((ABL & 2) == 0) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          acc[NB][2 * MH + mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NB ? w1[t] : w0[t], xa[mi][t], acc[NB][2 * MH + mi], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { asm volatile("" ::"v"(NB ? w1[t] : w0[t])); asm volatile("" ::"v"(xa[0][t])); asm volatile("" ::"v"(xa[1][t])); }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if constexpr (PH == 3) {
-      if (wm == 0) {  // group 0: this MFMA section is slot 8t+7
-        if (issued_ahead) __builtin_amdgcn_s_waitcnt(0x0F72);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-      }
-    }
-    stamp();
-    bar();
-    stamp();
-  };
-
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, 1>;
-  using P2 = std::integral_constant<int, 2>;
-  using P3 = std::integral_constant<int, 3>;
-
-  stamp();
-  // prologue: all of tile 0, W-lo of tile 1
-  issue_unit(0, 0, 2);
-  issue_unit(0, 0, 3);
-  issue_unit(0, 0, 0);
-  issue_unit(0, 0, 1);
-  if (KT > 1) {
-    issue_unit(1, 1, 2);
-    __builtin_amdgcn_s_waitcnt(0x0F72);
-  } else {
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-  }
-  bar();
-  if (wm == 1) bar();  // group 1 runs one slot behind
-#pragma unroll 1
-  for (int kt = 0; kt < KT; kt += 2) {
-    phase(B0{}, P0{}, kt);
-    phase(B0{}, P1{}, kt);
-    phase(B0{}, P2{}, kt);
-    phase(B0{}, P3{}, kt);
-    phase(B1{}, P0{}, kt + 1);
-    phase(B1{}, P1{}, kt + 1);
-    phase(B1{}, P2{}, kt + 1);
-    phase(B1{}, P3{}, kt + 1);
-  }
-  if (wm == 0) bar();  // barrier counts of the two groups match again
-  stamp();
-  if constexpr ((ABL & 4) != 0) {
-    float ssum = 0.f;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ssum += acc[ni][mi][r];
-    if (ssum == 1.2345678e33f) reinterpret_cast<float*>(p.C)[0] = ssum;
-    return;
-  }
-  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
-  if constexpr (TRACE) {
-    stamp();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamp();
-    if (tr != nullptr && lane == 0) tr[0] = (unsigned long long)tix;
-  }
-}
-
-#endif  // MMAMD_EXPERIMENTS
-
-// ---------------------------------------------------------------------------------------------------------
-// Deep-ring kernel ("Q"): 256 x 256 tile, BK = 32, FOUR-stage LDS ring (4 x 32 KiB), 8 waves.
-// Why: with a 2-stage ring the DMA for K-tile k+1 is issued at the barrier of tile k and drained (vmcnt(0)) at the
-// barrier of tile k+1, so at most one tile is in flight and the L2->LDS stream stops between tiles; measured, the
-// load skeleton alone (no MFMA) ran at ~24 B/clk/CU and barely overlapped the matrix work.  Here three 32-wide
-// stages (96 KiB per CU) are ALWAYS in flight: stage s+3 is issued right after the barrier that retires stage s-1,
-// and the wait before the next barrier is a COUNTED vmcnt (8 = the pieces of the two younger stages), never 0.
-// One raw s_barrier per stage; fragment reads are software-pipelined one k16-step deep ACROSS the barrier.
-// Stage image: tile row = 64 B (4 chunks of 16 B), 4 rows per 256-B bank row, slot' = slot ^ (bankrow & 3)
-// (conflict-free for ds_read_b128 lane groups; applied on the DMA source address, undone on the read).
-template <bool OUT_F32, int ACT, int GM, int SCHED = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_q(const GemmArgs p, const int tiles_m) {
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
-  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;  // 128 x 64 per wave: MI 4, NI 2
-  constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;               // 16 KiB + 16 KiB
-  constexpr int NF = NI + MI, NM = NI * MI;                              // 6 fragment reads, 8 MFMAs per k16-step
-  extern __shared__ __attribute__((aligned(16))) char smem[];            // 4 * STAGE = 128 KiB
-
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  int tm, tn;
-  {
-    const int per_group = GM * p.tiles_n;
-    const int grp = bid / per_group, within = bid - grp * per_group;
-    const int gm0 = grp * GM;
-    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
-    tn = within / rows;
-    tm = gm0 + (within - tn * rows);
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave / WN, wn = wave - wm * WN;
-
-  // DMA: a 1-KiB piece = 16 tile rows; piece i of the A (or W) half covers rows 16i..16i+15; wave w moves pieces
-  // w and w+8 of each half.  LDS position of lane: bank row 4i + (lane>>4), slot' = lane&15.
-  const int slot = (lane & 15) ^ (lane >> 4);          // (bank row & 3) == lane>>4
-  const int row16 = 4 * (lane >> 4) + (slot >> 2);     // row inside the 16-row piece
-  const int chunk = slot & 3;                          // 16-byte chunk inside the 64-byte row
-  uint32_t a_off[2], b_off[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int r = m0 + 16 * (wave + NW * j) + row16;
-    r = r < p.M ? r : p.M - 1;
-    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
-    int rn = n0 + 16 * (wave + NW * j) + row16;
-    rn = rn < p.N ? rn : p.N - 1;
-    b_off[j] = ((uint32_t)rn * (uint32_t)p.ldw + chunk * 8) * 2u;
-  }
-  const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W);
-  auto issue_stage = [&](int st) __attribute__((always_inline)) {
-    char* sbase = smem + (st & 3) * STAGE;
-    const uint32_t kbytes = (uint32_t)st * 64u;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Ab + a_off[j] + kbytes), (lds_u32p)(sbase + (wave + NW * j) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Wb + b_off[j] + kbytes),
-                                       (lds_u32p)(sbase + A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
-  };
-
-  // fragment read: row l31 of a 32-row block (8 bank rows), chunk 2t + half; bank row & 3 == (l31 >> 2) & 3
-  const int l31 = lane & 31, half = lane >> 5;
-  int roff[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-    roff[t] = (l31 >> 2) * 256 + (((((l31 & 3) << 2) | (2 * t + half)) ^ ((l31 >> 2) & 3)) << 4);
-
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-  bf16x8 xa0[MI], wb0[NI], xa1[MI], wb1[NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xa1[mi][j] = (bf16)0.f;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
-
-  auto load_frags = [&](const char* sa, const char* sb, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 32 * 64 + roff[t]);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 32 * 64 + roff[t]);
-  };
-  auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
-  };
-  // one 32-wide stage between two barriers.  On entry (xa1, wb1) = 2nd k16-step of the previous stage (or zeros).
-  auto mma_range = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI], int i0, int i1) {
-#pragma unroll
-    for (int i = 0; i < NM; ++i)
-      if (i >= i0 && i < i1)
-        acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
-  };
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  auto stage_body = [&](int st, auto issue_next) __attribute__((always_inline)) {
-    const char* sa = smem + (st & 3) * STAGE + (wm * TM) * 64;
-    const char* sb = smem + (st & 3) * STAGE + A_BYTES + (wn * TN) * 64;
-    if constexpr (SCHED == 1) {
-      // k16-step = [1 MFMA | all 6 fragment reads of the NEXT step (front-loaded: 7 MFMAs of cover) | MFMA | DMA piece |
-      // 3 MFMA | DMA piece | 3 MFMA]; the 4 DMA pieces of stage st+3 are spread over the whole stage instead of bursting
-      constexpr bool ISS = decltype(issue_next)::value;
-      const uint32_t dst = lds0 + ((st + 3) & 3) * STAGE + wave * 1024;
-      const uint32_t kb = (uint32_t)(st + 3) * 64u;
-      mma_range(xa1, wb1, 0, 1);
-      __builtin_amdgcn_sched_barrier(0);  // the wait for THIS step's fragments stays in front of the new reads
-      load_frags(sa, sb, 0, xa0, wb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_range(xa1, wb1, 1, 2);
-      if constexpr (ISS) dma_piece(Ab + a_off[0] + kb, dst);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_range(xa1, wb1, 2, 5);
-      if constexpr (ISS) dma_piece(Ab + a_off[1] + kb, dst + NW * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_range(xa1, wb1, 5, 8);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_range(xa0, wb0, 0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frags(sa, sb, 1, xa1, wb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_range(xa0, wb0, 1, 2);
-      if constexpr (ISS) dma_piece(Wb + b_off[0] + kb, dst + A_BYTES);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_range(xa0, wb0, 2, 5);
-      if constexpr (ISS) dma_piece(Wb + b_off[1] + kb, dst + A_BYTES + NW * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_range(xa0, wb0, 5, 8);
-      return;
-    }
-    // program order: DMA pieces BEFORE the fragment reads (an LDS-DMA issued behind pending ds_reads makes hipcc
-    // drain lgkmcnt first), then everything is re-interleaved behind the previous stage's last MFMA group
-    if constexpr (decltype(issue_next)::value) issue_stage(st + 3);
-    load_frags(sa, sb, 0, xa0, wb0);
-    mma(xa1, wb1);
-    load_frags(sa, sb, 1, xa1, wb1);
-    mma(xa0, wb0);
-    if constexpr (decltype(issue_next)::value) {
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, NM - 3, 0);
-    } else {
-      __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
-  };
-
-  const int NS = p.K >> 5;  // stages (>= 2 since K % 64 == 0)
-#pragma unroll 1
-  for (int st = 0; st < 3 && st < NS; ++st) issue_stage(st);
-  // steady state: two younger stages (8 pieces of this wave) stay in flight across the barrier
-  int st = 0;
-#pragma unroll 1
-  for (; st + 3 < NS; ++st) {
-    __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8) lgkmcnt(0) (gfx9 encoding: vm[3:0] | exp<<4 | lgkm<<8 | vm[5:4]<<14)
-    __builtin_amdgcn_s_barrier();
-    stage_body(st, std::true_type{});
-  }
-  // drain: the last three stages, nothing left to issue
-#pragma unroll 1
-  for (; st < NS; ++st) {
-    const int younger = NS - 1 - st;
-    if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0078);       // vmcnt(8) lgkmcnt(0)
-    else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0074);  // vmcnt(4) lgkmcnt(0)
-    else __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    stage_body(st, std::false_type{});
-  }
-  mma(xa1, wb1);
-  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------
-// Staggered kernel ("S"): the Q kernel's geometry (256 x 256 tile, BK = 32, 4-stage 128 KiB ring, 8 waves = 2 per
-// SIMD) with the two wave halves running HALF A PERIOD APART.  Ablations of the lock-step kernels showed the MFMA
-// loop alone sustains 77 % of peak but drops to 40 % as soon as fragment reads + DMA are added: both waves of a SIMD
-// hit their LDS waits at the same time (matrix pipe idle) and then fight for the pipe at the same time.  Here every
-// stage is split into a LOAD section (4 DMA pieces of stage s+3, the 12 fragment reads of stage s, counted vmcnt +
-// lgkmcnt drain) and a MATRIX section (16 MFMAs under s_setprio 1), separated by raw s_barriers; waves 4-7 execute
-// one extra barrier up front, so on each SIMD one wave is always in its matrix section while its partner loads:
-//        interval:   0      1      2      3      4
-//        waves 0-3:  L(0)   M(0)   L(1)   M(1)   L(2) ...
-//        waves 4-7:  -      L(0)   M(0)   L(1)   M(1) ...
-// Hazards (s = stage, buffer = s & 3, all barriers are whole-workgroup):
-//   RAW  stage x is first read in L(x); its pieces were issued in L(x-3) and are waited for (vmcnt(8) = the two
-//        younger stages may stay in flight) in L(x-1), which ends with a barrier BEFORE any L(x) starts.
-//   WAR  the DMA for stage x (issued in L(x-3)) overwrites stage x-4, whose last reads (other half's L(x-4)) were
-//        drained (lgkmcnt(0)) before the barrier that ends that interval, i.e. before L(x-3) of either half starts.
-// TRACE: waves 0 and 4 of the first 64 blocks stamp s_memtime at every section boundary into `trace`
-// ([block][2 waves][256] u64) — diagnostic variant 14, see tools/gemm_trace.py
-template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, const int tiles_m, unsigned long long* trace = nullptr) {
-  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8;
-  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  int tm, tn;
-  {
-    const int per_group = GM * p.tiles_n;
-    const int grp = bid / per_group, within = bid - grp * per_group;
-    const int gm0 = grp * GM;
-    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
-    tn = within / rows;
-    tm = gm0 + (within - tn * rows);
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave / WN, wn = wave - wm * WN;
-
-  const int slot = (lane & 15) ^ (lane >> 4);
-  const int row16 = 4 * (lane >> 4) + (slot >> 2);
-  const int chunk = slot & 3;
-  uint32_t a_off[2], b_off[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int r = m0 + 16 * (wave + NW * j) + row16;
-    r = r < p.M ? r : p.M - 1;
-    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
-    int rn = n0 + 16 * (wave + NW * j) + row16;
-    rn = rn < p.N ? rn : p.N - 1;
-    b_off[j] = ((uint32_t)rn * (uint32_t)p.ldw + chunk * 8) * 2u;
-  }
-  const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W);
-  auto issue_stage = [&](int st) __attribute__((always_inline)) {
-    char* sbase = smem + (st & 3) * STAGE;
-    const uint32_t kbytes = (uint32_t)st * 64u;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Ab + a_off[j] + kbytes), (lds_u32p)(sbase + (wave + NW * j) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((glb_u32p)(Wb + b_off[j] + kbytes),
-                                       (lds_u32p)(sbase + A_BYTES + (wave + NW * j) * 1024), 16, 0, 0);
-  };
-
-  const int l31 = lane & 31, half = lane >> 5;
-  int roff[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-    roff[t] = (l31 >> 2) * 256 + (((((l31 & 3) << 2) | (2 * t + half)) ^ ((l31 >> 2) & 3)) << 4);
-
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-  bf16x8 xa[2][MI], wb[2][NI];  // both k16-steps of one stage
-  int tix = 0;
-  unsigned long long* tr = nullptr;
-  if constexpr (TRACE) {
-    if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
-  }
-  auto stamp = [&]() __attribute__((always_inline)) {
-    if constexpr (TRACE) {
-      if (tr != nullptr && tix < 255) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if (lane == 0) tr[1 + tix] = t;
-        ++tix;
-      }
-    }
-  };
-
-  // LOAD section of stage st: DMA of stage st+3 first (an LDS-DMA behind pending ds_reads would make hipcc drain them)
-  auto load_section = [&](int st, auto issue_next, auto waitcode) __attribute__((always_inline)) {
-    if constexpr (decltype(issue_next)::value && (ABL & 1) == 0) issue_stage(st + 3);
-    if constexpr (TRACE) { __builtin_amdgcn_sched_barrier(0); stamp(); }
-    const char* sa = smem + (st & 3) * STAGE + (wm * TM) * 64;
-    const char* sb = smem + (st & 3) * STAGE + A_BYTES + (wn * TN) * 64;
-    if constexpr ((ABL & 8) == 0) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) wb[t][ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 32 * 64 + roff[t]);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) xa[t][mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 32 * 64 + roff[t]);
-      }
-    }
-    if constexpr (TRACE) {
-      __builtin_amdgcn_sched_barrier(0); stamp();
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-      __builtin_amdgcn_sched_barrier(0); stamp();
-    }
-    __builtin_amdgcn_s_waitcnt(decltype(waitcode)::value);  // fragments in registers; next stage's own pieces landed
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto matrix_section = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[t][ni], xa[t][mi], acc[ni][mi], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  using W8 = std::integral_constant<int, 0x0078>;  // vmcnt(8) lgkmcnt(0)
-  using W4 = std::integral_constant<int, 0x0074>;  // vmcnt(4) lgkmcnt(0)
-  using W0 = std::integral_constant<int, 0x0070>;  // vmcnt(0) lgkmcnt(0)
-
-  stamp();
-  const int NS = p.K >> 5;
-#pragma unroll 1
-  for (int st = 0; st < 3 && st < NS; ++st) issue_stage(st);
-  // stage 0 visible to everyone before the first load section
-  if (NS >= 3) __builtin_amdgcn_s_waitcnt(0x0078); else if (NS == 2) __builtin_amdgcn_s_waitcnt(0x0074); else __builtin_amdgcn_s_waitcnt(0x0070);
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();  // the stagger: waves 4-7 run one interval behind
-  stamp();
-
-  int st = 0;
-#pragma unroll 1
-  for (; st + 3 < NS; ++st) {
-    load_section(st, std::true_type{}, W8{});
-    stamp();
-    __builtin_amdgcn_s_barrier();
-    stamp();
-    matrix_section();
-    stamp();
-    __builtin_amdgcn_s_barrier();
-    stamp();
-  }
-#pragma unroll 1
-  for (; st < NS; ++st) {
-    const int younger = NS - 2 - st;  // issued stages younger than st+1
-    if (younger >= 2) load_section(st, std::false_type{}, W8{});
-    else if (younger == 1) load_section(st, std::false_type{}, W4{});
-    else load_section(st, std::false_type{}, W0{});
-    __builtin_amdgcn_s_barrier();
-    matrix_section();
-    __builtin_amdgcn_s_barrier();
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
-  stamp();
-  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
-  stamp();
-  if constexpr (TRACE) {
-    if (tr != nullptr && lane == 0) tr[0] = (unsigned long long)tix;
-  }
-}
-
+#include "experiments/gemm_kernels_gqs.inc"  // schedule experiments G / Q / S (not faster: DESIGN.md 4.1)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // Persistent pipelined kernel ("PP", the production kernel): the P schedule, but ONE workgroup per CU walks the tiles
@@ -1603,7 +849,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_s(const GemmArgs p, c
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
 // WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
 // SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
   constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -1803,22 +1049,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll 1
     for (int kt = 0; kt < KT; kt += 2) {
       sync_tile();
-      if constexpr (FOLD == 1) {
-        // LN fold (consumer): the block statistics of this tile's 256 rows ([256][nslot][2] floats, one contiguous 256 * nslot * 8 B
-        // block of p.st_in) go to LDS behind the ring by LDS-DMA, issued after the first barrier of the tile (every wave has left the
-        // previous tile's epilogue, which read the previous statistics) and waited for by the next sync_tile: the epilogue finds
-        // them in LDS instead of paying nslot/2 dependent L2 round trips per row
-        if (kt == 0) {
-          const uint32_t total = (uint32_t)p.nslot_in * (BM * 8u), limit = (uint32_t)(p.M - m0) * (uint32_t)p.nslot_in * 8u - 16u;
-          const char* sbase = reinterpret_cast<const char*>(p.st_in) + (size_t)m0 * (size_t)p.nslot_in * 8u;
-          for (uint32_t pc = wave; pc * 1024u < total; pc += NW) {
-            uint32_t off = pc * 1024u + lane * 16u;
-            off = off < limit ? off : limit;  // rows past M (last tile) read the last valid 16 bytes: never stored anyway
-            dma_piece_s(sbase, off, lds0 + 2 * STAGE + pc * 1024u);
-          }
-        }
-      }
-      if constexpr (BLDS && FOLD != 1) {
+      if constexpr (BLDS) {
         // the tile's 256 bias values (1 KiB = one DMA piece, issued by wave 0) land in LDS behind the ring while the K loop runs;
         // same hazards as the statistics above: issued after the tile's first barrier, waited for by the next sync_tile
         if (kt == 0 && wave == 0 && p.bias != nullptr) {
@@ -1865,9 +1096,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
         for (int d = 0; d < RD; ++d) res_load(d, rq[d]);
       }
     }
-    bias_or_lnfold<MI, NI, TM, TN, FOLD, ACT, FOLD == 1>(acc, p, m0, n0, wm, wn, lane, smem + 2 * STAGE,
-                                                         (BLDS && FOLD != 1) ? smem + 2 * STAGE : nullptr);
-    if constexpr (ACT == MMAMD_ACT_QUICKGELU && FOLD != 1) {
+    add_bias<MI, NI, TM, TN>(acc, p, n0, wn, lane, BLDS ? smem + 2 * STAGE : nullptr);
+    if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -1886,12 +1116,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int pass = mi * NI + ni;
-          if constexpr (FOLD == 2) {
-            if (ni == 0) {
-#pragma unroll
-              for (int it = 0; it < 4; ++it) fs1[it] = fs2[it] = 0.f;
-            }
-          }
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             f32x4 t;
@@ -1914,14 +1138,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
                 for (int j = 0; j < 4; ++j) v[j] += rq[pass % RD][it][j];
               }
               store16<STP>(reinterpret_cast<float*>(p.C) + c_row(m) * p.ldc + n, __builtin_bit_cast(uint4, v));
-            }
-            if constexpr (FOLD == 2) {  // 8 lanes hold 32 columns of row m in this pass
-              lnfold_store_acc(p, v, m, n, ok, fs1[it], fs2[it]);  // lane c = lane & 7: quad c of pass 0, quad c + 8 of pass 1
-              if (ni == NI - 1) {
-                lnfold_butterfly8(fs1[it], fs2[it]);
-                if (m < p.M && (lane & 7) == 0)
-                  *reinterpret_cast<f32x2*>(p.st_out + ((size_t)m * p.nslot_out + (nw0 >> 6)) * 2) = f32x2{fs1[it], fs2[it]};
-              }
             }
           }
           if (has_res && pass + RD < MI * NI) res_load(pass + RD, rq[pass % RD]);  // refill the slot this pass just consumed
@@ -2359,163 +1575,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
 
 
 #ifdef MMAMD_EXPERIMENTS
-// ---------------------------------------------------------------------------------------------------------
-// "W" kernel (experiment, r02: correct, bit-equal to the production kernels, and SLOWER -- qkv 200 vs 160 us, MLP-up 277 vs 252,
-// MLP-down 316 vs 270; PMC profiles/r02_pmc_gemm_w.txt: MFMA pipe 41 % busy vs 53 %, 57 % of wave cycles in issue stalls;
-// six DMA pieces per 16 MFMAs per wave against eight per 32 in the 8-wave kernels): TWO workgroups per CU.  The lock-step kernels above stop the matrix pipe for the whole per-tile epilogue (22-55 % of a
-// tile's time at K = 768: bias / activation VALU, the LDS transpose, the stores) because all eight waves of the CU's one workgroup are
-// in it together.  Here a workgroup is 4 waves (one per SIMD) on a 256 x 128 tile (2 x 2 waves of 128 x 64, the same wave tile and
-// fragment traffic as above) with a 3-stage BK = 32 LDS-DMA ring (72 KiB), so two workgroups are resident per CU with independent
-// barriers: they drift out of phase, and while one is in its prologue / epilogue the other one's K loop owns the matrix pipe.
-//   LDS image of a K-tile: 64-byte rows (32 bf16), 4 rows per 256-byte bank row = 16 slots of 16 B; logical slot s = 4 (r & 3) + c
-//   (c = 16-byte chunk) is stored at s ^ (R & 15), R = r >> 2 -- the permutation is applied to the DMA SOURCE address (the LDS
-//   destination of a piece is lane-linear) and undone by the ds_read_b128 address: the 16 lanes of every read group hit 16 slots.
-//   RAW: tile kt's pieces (issued two iterations earlier) are waited with vmcnt(6) (tile kt+1's six may stay in flight) + barrier.
-//   WAR: tile kt+2 goes into the stage read during iteration kt-1; every wave has passed iteration kt's barrier by then.
-// SCH 0: DMA burst behind the barrier, then reads, then MFMAs.  SCH 1: one DMA piece behind each of the first six MFMAs (the burst is
-// ~6 x 60-100 cycles in front of a 512-cycle MFMA block).  SCH 2: SCH 1 + raised priority over the MFMA block.
-template <bool OUT_F32, int ACT, int GM, int SCH = 0>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel_w(const GemmArgs p, const int tiles_m) {
-  constexpr int BM = 256, BN = 128, WN = 2, NW = 4, TM = 128, TN = 64, MI = 4, NI = 2;
-  constexpr int A_BYTES = BM * 64, STAGE = (BM + BN) * 64, A_INSTR = 4, B_INSTR = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  int tm, tn;
-  {
-    const int per_group = GM * p.tiles_n;
-    const int grp = bid / per_group, within = bid - grp * per_group;
-    const int gm0 = grp * GM;
-    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
-    tn = within / rows;
-    tm = gm0 + (within - tn * rows);
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int l31 = lane & 31, half = lane >> 5;
-
-  // DMA source offsets: piece q = wave + 4 j covers image rows 16 q .. 16 q + 15; lane -> bank row R = 4 q + (lane >> 4), stored
-  // slot lane & 15 holds logical slot s = (lane & 15) ^ (R & 15); (R & 15) = (4 wave + (lane >> 4)) & 15 for every j
-  const int sxr = (4 * wave + (lane >> 4)) & 15;
-  const int ls = (lane & 15) ^ sxr;
-  const int prow = 4 * (lane >> 4) + (ls >> 2), pchunk = ls & 3;
-  uint32_t a_off[A_INSTR], b_off[B_INSTR];
-#pragma unroll
-  for (int j = 0; j < A_INSTR; ++j) {
-    int r = m0 + 16 * (wave + NW * j) + prow;
-    r = r < p.M ? r : p.M - 1;
-    a_off[j] = ((uint32_t)r * (uint32_t)p.lda + pchunk * 8) * 2u;
-  }
-#pragma unroll
-  for (int j = 0; j < B_INSTR; ++j) {
-    int r = n0 + 16 * (wave + NW * j) + prow;
-    r = r < p.N ? r : p.N - 1;
-    b_off[j] = ((uint32_t)r * (uint32_t)p.ldw + pchunk * 8) * 2u;
-  }
-  const char* Ab = reinterpret_cast<const char*>(p.A);
-  const char* Wb = reinterpret_cast<const char*>(p.W);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  auto issue_tile = [&](int stage, int kt) __attribute__((always_inline)) {
-    const uint32_t dst = lds0 + stage * STAGE + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) dma_piece_s(Ab + (size_t)kt * 64, a_off[j], dst + NW * j * 1024);
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) dma_piece_s(Wb + (size_t)kt * 64, b_off[j], dst + A_BYTES + NW * j * 1024);
-  };
-
-  // fragment read offsets inside a stage: operand row r, k-step t -> chunk c = 2 t + half
-  uint32_t ra[MI][2], rb[NI][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int r = wm * TM + mi * 32 + l31, R = r >> 2;
-      ra[mi][t] = R * 256 + (((((r & 3) << 2) | (2 * t + half)) ^ (R & 15)) << 4);
-    }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int r = wn * TN + ni * 32 + l31, R = r >> 2;
-      rb[ni][t] = A_BYTES + R * 256 + (((((r & 3) << 2) | (2 * t + half)) ^ (R & 15)) << 4);
-    }
-  }
-
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-
-  const int KT = p.K >> 5;  // >= 2 (K % 64 == 0)
-  issue_tile(0, 0);
-  issue_tile(1, 1);
-  auto body = [&](auto stagec, int kt) __attribute__((always_inline)) {
-    constexpr int ST = decltype(stagec)::value;
-    if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt landed; tile kt+1's six pieces may be in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const bool issue = kt + 2 < KT;
-    if constexpr (SCH == 0) {
-      if (issue) issue_tile((ST + 2) % 3, kt + 2);
-    }
-    const char* sb = smem + ST * STAGE;
-    bf16x8 xa[2][MI], wb[2][NI];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wb[t][ni] = *reinterpret_cast<const bf16x8*>(sb + rb[ni][t]);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xa[t][mi] = *reinterpret_cast<const bf16x8*>(sb + ra[mi][t]);
-    }
-    if constexpr (SCH == 0) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[t][ni], xa[t][mi], acc[ni][mi], 0, 0, 0);
-    } else {
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SCH == 2) __builtin_amdgcn_s_setprio(1);
-      const uint32_t dst = lds0 + ((ST + 2) % 3) * STAGE + wave * 1024;
-#pragma unroll
-      for (int i = 0; i < NI * MI; ++i) {
-        acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[0][i / MI], xa[0][i % MI], acc[i / MI][i % MI], 0, 0, 0);
-        if (issue && i < A_INSTR + B_INSTR) {  // wave-uniform scalar branch
-          if (i < A_INSTR) dma_piece_s(Ab + (size_t)(kt + 2) * 64, a_off[i], dst + NW * i * 1024);
-          else dma_piece_s(Wb + (size_t)(kt + 2) * 64, b_off[i - A_INSTR], dst + A_BYTES + NW * (i - A_INSTR) * 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[1][ni], xa[1][mi], acc[ni][mi], 0, 0, 0);
-      if constexpr (SCH == 2) __builtin_amdgcn_s_setprio(0);
-    }
-  };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  using S2 = std::integral_constant<int, 2>;
-#pragma unroll 1
-  for (int kt = 0; kt < KT; kt += 3) {
-    body(S0{}, kt);
-    if (kt + 1 < KT) body(S1{}, kt + 1);
-    if (kt + 2 < KT) body(S2{}, kt + 2);
-  }
-  gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT>(acc, p, m0, n0, wm, wn, lane, wave, smem);
-}
-
-#endif  // MMAMD_EXPERIMENTS
+#include "experiments/gemm_kernel_w.inc"  // two-workgroups-per-CU experiment (slower: DESIGN.md 4.1)
+#endif
 
 // plain one-thread-per-output kernel: on-device cross-check for the MFMA kernels (tests / debugging)
 template <bool OUT_F32>
@@ -2537,10 +1598,10 @@ __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB, int FOLD = 0>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, bool SGB>
 static int launch_tiled(GemmArgs& p, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, OUT_F32, ACT, SGB, FOLD>;
+  auto kern = gemm_bf16_nt_kernel<BM, BN, WM, WN, OUT_F32, ACT, SGB>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -2549,12 +1610,12 @@ static int launch_tiled(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16");
 }
 
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, int FOLD = 0>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true>
 static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
   // the pipelined kernel walks the K-tiles in pairs (compile-time buffer index): odd tile counts take the plain kernel
-  if (((p.K >> 6) & 1) != 0) return launch_tiled<BM, BN, WM, WN, OUT_F32, ACT, true, FOLD>(p, st);
+  if (((p.K >> 6) & 1) != 0) return launch_tiled<BM, BN, WM, WN, OUT_F32, ACT, true>(p, st);
   constexpr int smem = 2 * (BM + BN) * 128;
-  auto kern = gemm_bf16_nt_kernel_p<BM, BN, WM, WN, OUT_F32, ACT, GM, ABL, LDSEPI, false, 0, FOLD>;
+  auto kern = gemm_bf16_nt_kernel_p<BM, BN, WM, WN, OUT_F32, ACT, GM, ABL, LDSEPI, false, 0>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -2564,54 +1625,17 @@ static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_p");
 }
 
-template <bool OUT_F32, int ACT, int GM, int SCHED = 0>
-static int launch_tiled_q(GemmArgs& p, hipStream_t st) {
-  constexpr int smem = 4 * 512 * 64;
-  auto kern = gemm_bf16_nt_kernel_q<OUT_F32, ACT, GM, SCHED>;
-  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
-  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
-  const int tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m);
-  return launch_status("gemm_bf16_q");
-}
-
-template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
-static int launch_tiled_s(GemmArgs& p, hipStream_t st) {
-  constexpr int smem = 4 * 512 * 64;
-  auto kern = gemm_bf16_nt_kernel_s<OUT_F32, ACT, GM, TRACE, ABL>;
-  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
-  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
-  const int tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m, TRACE ? g_gemm_trace : nullptr);
-  return launch_status("gemm_bf16_s");
-}
-
 #ifdef MMAMD_EXPERIMENTS
-template <bool OUT_F32, int ACT, int GM, bool TRACE = false, int ABL = 0>
-static int launch_tiled_g(GemmArgs& p, hipStream_t st) {
-  if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
-  constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_g<OUT_F32, ACT, GM, TRACE, ABL>;
-  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
-  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
-  const int tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(512), smem, st, p, tiles_m, TRACE ? g_gemm_trace : nullptr);
-  return launch_status("gemm_bf16_g");
-}
+#include "experiments/gemm_launchers.inc"
+#endif
 
-#endif  // MMAMD_EXPERIMENTS
-
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int FOLD = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if constexpr (A_MODE == 0) {
-    if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true, FOLD>(p, st);
+    if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
   }
-  constexpr int smem = 2 * 512 * 128 + (FOLD == 1 ? 256 * 16 * 8 : (BLDS ? 1024 : 0));  // + the tile's row statistics (nslot <= 16: K <= 1024) / bias
-  if (FOLD == 1 && p.nslot_in > 16) return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, GM, 0, true, FOLD>(p, st);
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, FOLD, RES_DEPTH, BLDS, A_MODE>;
+  constexpr int smem = 2 * 512 * 128 + (BLDS ? 1024 : 0);  // + the tile's bias values
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, RES_DEPTH, BLDS, A_MODE>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
@@ -2636,24 +1660,10 @@ static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
   return launch_status("gemm_bf16_grouped");
 }
 
-#ifdef MMAMD_EXPERIMENTS
-template <bool OUT_F32, int ACT, int GM, int SCH = 0>
-static int launch_tiled_w(GemmArgs& p, hipStream_t st) {
-  constexpr int smem = 3 * (256 + 128) * 64;
-  auto kern = gemm_bf16_nt_kernel_w<OUT_F32, ACT, GM, SCH>;
-  static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
-  if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
-  const int tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 127) / 128;
-  hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n), dim3(256), smem, st, p, tiles_m);
-  return launch_status("gemm_bf16_w");
-}
 
-#endif  // MMAMD_EXPERIMENTS
-
-template <bool OUT_F32, int ACT, int FOLD = 0>
+template <bool OUT_F32, int ACT>
 static int dispatch_variant(GemmArgs& p, hipStream_t st) {
-  int v = FOLD != 0 ? 0 : g_gemm_variant;  // the LN-fold epilogues exist in the default-policy kernels only
+  int v = g_gemm_variant;
   if (v == 0) {
     // Default policy (measured per shape with tools/kernel_bench.py):
     //  * the pipelined 256x256 kernel whenever its grid reaches a good fraction of the 256 CUs, else 128x128 tiles;
@@ -2681,11 +1691,8 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       b.C = reinterpret_cast<char*>(p.C) + rows * p.ldc * esz;
       if (p.R != nullptr) b.R = reinterpret_cast<const char*>(p.R) + rows * p.ldr * esz;
       if (p.C2 != nullptr) b.C2 = reinterpret_cast<char*>(p.C2) + rows * p.ldc2 * 2;
-      if (p.Xh != nullptr) b.Xh = p.Xh + rows * p.ldxh;
-      if (p.st_out != nullptr) b.st_out = p.st_out + rows * (size_t)(2 * p.nslot_out);
-      if (p.st_in != nullptr) b.st_in = p.st_in + rows * (size_t)(2 * p.nslot_in);
-      rc = big_pp ? launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, FOLD>(a, st) : launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, true, FOLD>(a, st);
-      if (rc == 0) rc = launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true, FOLD>(b, st);
+      rc = big_pp ? launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(a, st) : launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(a, st);
+      if (rc == 0) rc = launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(b, st);
       return true;
     };
     // (re-measured with warm clocks, tools/kernel_bench.py: the persistent kernel wins from ~400 tiles up at every K — out-proj 625 vs 616 vs
@@ -2700,87 +1707,26 @@ static int dispatch_variant(GemmArgs& p, hipStream_t st) {
       if (p.K >= 2048 && try_split(true)) return rc;
       // the large-M and the small-M launches get different instantiations (tile-order group 8 / 4: equal speed), so that a kernel name in a
       // rocprof summary is ONE shape class — the bench's dominant kernel, gemm_bf16_nt_kernel_pp<false, QuickGELU, 8, ...>, is the ViT MLP-up only
-      if (p.M < 32768) return launch_tiled_pp<OUT_F32, ACT, 4, 2, 4, OUT_F32 ? 0 : 2, 0, FOLD>(p, st);
+      if (p.M < 32768) return launch_tiled_pp<OUT_F32, ACT, 4, 2, 4, OUT_F32 ? 0 : 2>(p, st);
     } else {
       v = 7;
       if (p.K >= 2048 && try_split(false)) return rc;
     }
   }
-  if constexpr (FOLD != 0) {
-    switch (v) {
-      case 6: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true, FOLD>(p, st);
-      case 7: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, true, FOLD>(p, st);
-      default: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, FOLD>(p, st);
-    }
-  } else {
-    switch (v) {
-      case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);
-      case 2: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, false>(p, st);
-      case 5: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
-      case 6: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(p, st);
-      case 7: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(p, st);
-      // bf16 C tiles are stored non-temporal (measured +6-7 % on the qkv / MLP-up GEMMs: the 128 KiB a block writes per
-      // tile no longer competes with the operand panels for the XCD's L2); the in-place fp32 residual update stays plain
-      case 18: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(p, st);
-      case 70: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 1, true>(p, st);  // bias through LDS (DMA'd during the K loop)
+  switch (v) {
+    case 1: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, false>(p, st);
+    case 2: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, false>(p, st);
+    case 5: return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
+    case 6: return launch_tiled<128, 128, 2, 2, OUT_F32, ACT, true>(p, st);
+    case 7: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8>(p, st);
+    // bf16 C tiles are stored non-temporal (measured +6-7 % on the qkv / MLP-up GEMMs: the 128 KiB a block writes per
+    // tile no longer competes with the operand panels for the XCD's L2); the in-place fp32 residual update stays plain
+    case 18: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2>(p, st);
+    case 70: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 1, true>(p, st);  // bias through LDS (DMA'd during the K loop)
 #ifdef MMAMD_EXPERIMENTS
-      // one wave per SIMD (4 waves, ONE workgroup per CU by LDS: 96 KiB ring), the 8-wave kernels' 128 x 64 wave tile: what a kernel with a
-      // second accumulator set (512 registers per wave) would have as its main loop
-      case 81: return launch_tiled<256, 128, 2, 2, OUT_F32, ACT, true>(p, st);
-      case 82: return launch_tiled<128, 256, 1, 4, OUT_F32, ACT, true>(p, st);
-      case 60: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 1>(p, st);  // fp32 residual prefetch ring depth 1 .. 4
-      case 61: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 2>(p, st);
-      case 62: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 3>(p, st);
-      case 63: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 0, 0, 4>(p, st);
-      case 50: return launch_tiled_w<OUT_F32, ACT, 8>(p, st);   // two workgroups per CU, 256 x 128 tiles, BK = 32 ring of 3
-      case 51: return launch_tiled_w<OUT_F32, ACT, 8, 1>(p, st);
-      case 52: return launch_tiled_w<OUT_F32, ACT, 8, 2>(p, st);
+#include "experiments/gemm_dispatch_cases.inc"
 #endif
-#ifdef MMAMD_EXPERIMENTS
-      case 20: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 1>(p, st);  // C stores sc1 (write-through, not kept in L2)
-      case 21: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 2>(p, st);  // C stores nt
-      case 22: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, 0>(p, st);  // C stores plain
-      case 23: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 1>(p, st);  // fragment reads in one burst
-      case 24: return launch_tiled_pp<OUT_F32, ACT, 8, 2, 4, OUT_F32 ? 0 : 2, 2>(p, st);  // fragment reads 2 per MFMA
-      case 25: return launch_tiled_pp<OUT_F32, ACT, 4, 2, 4, OUT_F32 ? 0 : 2>(p, st);   // tile-order group of 4 row panels
-      case 26: return launch_tiled_pp<OUT_F32, ACT, 16, 2, 4, OUT_F32 ? 0 : 2>(p, st);  // ... 16
-      case 27: return launch_tiled_pp<OUT_F32, ACT, 2, 2, 4, OUT_F32 ? 0 : 2>(p, st);   // ... 2
-#endif
-#ifdef MMAMD_EXPERIMENTS  // schedule experiments, ablations (WRONG results for 1xx except 132/164) and traces: see DESIGN.md 4.1
-      case 30: return launch_tiled_g<OUT_F32, ACT, 8>(p, st);        // ping-pong kernel "G" (measured: not faster than P/PP)
-      case 31: return launch_tiled_g<OUT_F32, ACT, 8, true>(p, st);  // ping-pong kernel with s_memtime stamps
-      case 34: return launch_tiled_g<OUT_F32, ACT, 8, false, 4>(p, st);   // G ablations: no epilogue
-      case 35: return launch_tiled_g<OUT_F32, ACT, 8, false, 5>(p, st);   //   no epilogue, no DMA
-      case 36: return launch_tiled_g<OUT_F32, ACT, 8, false, 12>(p, st);  //   no epilogue, no fragment reads
-      case 37: return launch_tiled_g<OUT_F32, ACT, 8, false, 6>(p, st);   //   no epilogue, no MFMA
-      case 38: return launch_tiled_g<OUT_F32, ACT, 8, false, 13>(p, st);  //   MFMA + barriers only
-      // (tried and removed: the same kernel as 4 waves x (128 x 128) — one wave per SIMD, 256 AGPR accumulators, a third less LDS read
-      //  traffic per MFMA: its main loop alone ran at 1187 TF/s-equivalent against 1300 for the 8-wave form on the qkv shape)
-      case 3: return launch_tiled<256, 128, 4, 2, OUT_F32, ACT, false>(p, st);
-      case 4: return launch_tiled<128, 256, 2, 4, OUT_F32, ACT, false>(p, st);
-      case 9: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 0, false>(p, st);  // direct-store epilogue
-      case 10: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 1>(p, st);
-      case 11: return launch_tiled_q<OUT_F32, ACT, 8>(p, st);
-      case 12: return launch_tiled_q<OUT_F32, ACT, 8, 1>(p, st);
-      case 13: return launch_tiled_s<OUT_F32, ACT, 8>(p, st);
-      case 14: return launch_tiled_s<OUT_F32, ACT, 8, true>(p, st);
-      case 15: return launch_tiled_s<OUT_F32, ACT, 8, true, 1>(p, st);
-      case 16: return launch_tiled_s<OUT_F32, ACT, 8, true, 8>(p, st);
-      case 101: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 1>(p, st);
-      case 102: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 2>(p, st);
-      case 104: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 4>(p, st);
-      case 105: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 5>(p, st);
-      case 106: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 6>(p, st);
-      case 108: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 8>(p, st);
-      case 112: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 12>(p, st);
-      case 113: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 13>(p, st);
-      case 114: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 14>(p, st);
-      case 116: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 16>(p, st);
-      case 132: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 32>(p, st);
-      case 164: return launch_tiled_p<256, 256, 2, 4, OUT_F32, ACT, 8, 64>(p, st);
-#endif
-      default: set_error("gemm: unknown variant %d (experimental variants need -DMMAMD_EXPERIMENTS)", v); return MMAMD_E_BADARG;
-    }
+    default: set_error("gemm: unknown variant %d (experimental variants need -DMMAMD_EXPERIMENTS)", v); return MMAMD_E_BADARG;
   }
 }
 
@@ -2789,17 +1735,6 @@ static int dispatch(GemmArgs& p, hipStream_t st) {
   if (g_gemm_variant == 99) {
     hipLaunchKernelGGL((gemm_naive_kernel<OUT_F32>), dim3((p.N + 63) / 64, (p.M + 3) / 4), dim3(256), 0, st, p);
     return launch_status("gemm_naive");
-  }
-  if constexpr (OUT_F32) {
-    if (p.Xh != nullptr) return dispatch_variant<true, MMAMD_ACT_NONE, 2>(p, st);  // LN fold, producer (host: act == NONE)
-  } else {
-    if (p.st_in != nullptr) {  // LN fold, consumer
-      switch (p.act) {
-        case MMAMD_ACT_NONE: return dispatch_variant<false, MMAMD_ACT_NONE, 1>(p, st);
-        case MMAMD_ACT_QUICKGELU: return dispatch_variant<false, MMAMD_ACT_QUICKGELU, 1>(p, st);
-        default: return dispatch_variant<false, MMAMD_ACT_GELU_ERF, 1>(p, st);
-      }
-    }
   }
   switch (p.act) {
     case MMAMD_ACT_NONE: return dispatch_variant<OUT_F32, MMAMD_ACT_NONE>(p, st);
@@ -2827,36 +1762,8 @@ extern "C" int mmamd_debug_set_gemm_trace(void* buf) {
   return 0;
 }
 
-struct LnFoldArgs {  // see "LN fold" at the top of this file
-  void* xh = nullptr; int ldxh = 0; float* st_out = nullptr;                         // producer
-  const float* st_in = nullptr; int nslot_in = 0; const float* c1 = nullptr; float eps = 0.f;  // consumer
-};
 static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, void* C,
-                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream,
-                          const LnFoldArgs* lf = nullptr);
-
-extern "C" int mmamd_gemm_bf16_res_stats(const void* A, int lda, const void* W, int ldw, const float* bias, const float* residual, int ldr,
-                                         float* C, int ldc, void* Xh, int ldxh, float* stats, int M, int N, int K, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(Xh && stats, MMAMD_E_BADARG, "gemm_res_stats: null output");
-  MMAMD_CHECK_ARG(N % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_res_stats: N=%d must be a multiple of 128 (whole 64-column statistic blocks, even count)", N);
-  MMAMD_CHECK_ARG(ldxh >= N && ldxh % 4 == 0 && (reinterpret_cast<uintptr_t>(Xh) & 7) == 0 && (reinterpret_cast<uintptr_t>(stats) & 15) == 0,
-                  MMAMD_E_ALIGN, "gemm_res_stats: bf16 copy needs 8-byte aligned rows, the statistics 16-byte alignment");
-  LnFoldArgs lf;
-  lf.xh = Xh; lf.ldxh = ldxh; lf.st_out = stats;
-  return gemm_bf16_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, MMAMD_F32, M, N, K, MMAMD_ACT_NONE, nullptr, 0, 0, stream, &lf);
-}
-
-extern "C" int mmamd_gemm_bf16_lnfold(const void* Xh, int lda, const void* Wg, int ldw, const float* c1, const float* c2, const float* stats,
-                                      int nslot, float eps, void* C, int ldc, int M, int N, int K, int act, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(c1 && c2 && stats, MMAMD_E_BADARG, "gemm_lnfold: null argument");
-  MMAMD_CHECK_ARG(nslot > 0 && nslot % 2 == 0 && nslot * 64 == K, MMAMD_E_BADARG,
-                  "gemm_lnfold: %d statistic blocks of 64 columns do not cover the normalised width K=%d", nslot, K);
-  MMAMD_CHECK_ARG(aligned16(c1) && aligned16(stats), MMAMD_E_ALIGN, "gemm_lnfold: c1 / stats must be 16-byte aligned");
-  MMAMD_CHECK_ARG(act == MMAMD_ACT_NONE || act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF, MMAMD_E_BADARG, "gemm_lnfold: bad activation code %d", act);
-  LnFoldArgs lf;
-  lf.st_in = stats; lf.nslot_in = nslot; lf.c1 = c1; lf.eps = eps;
-  return gemm_bf16_impl(Xh, lda, Wg, ldw, c2, nullptr, 0, C, ldc, MMAMD_BF16, M, N, K, act, nullptr, 0, 0, stream, &lf);
-}
+                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream);
 
 extern "C" int mmamd_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual,
                                int ldr, void* C, int ldc, int out_dtype, int M, int N, int K, int act,
@@ -2881,7 +1788,7 @@ extern "C" int mmamd_patch_embed_gemm(const void* image, const void* W, int ldw,
   p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0; p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0; p.split_flat = 0; p.stagger = 0;
   p.i2c_g2 = g * g; p.i2c_g = g; p.i2c_p = patch; p.i2c_hw = image_size;
   p.i2c_lcr = patch == 16 ? 1 : 2; p.i2c_ltpc = patch == 16 ? 2 : 4; p.i2c_rpk = 64 / patch;
-  return launch_tiled_pp<true, MMAMD_ACT_NONE, 8, 2, 4, 0, 0, 0, 1, false, 1>(p, (hipStream_t)stream);
+  return launch_tiled_pp<true, MMAMD_ACT_NONE, 8, 2, 4, 0, 0, 1, false, 1>(p, (hipStream_t)stream);
 }
 
 extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int nprob, int out_dtype, int act, mmamd_stream_t stream) {
@@ -2955,8 +1862,7 @@ extern "C" int mmamd_gemm_bf16_dual(const void* A, int lda, const void* W, int l
 }
 
 static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldr, void* C,
-                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream,
-                          const LnFoldArgs* lf) {
+                          int ldc, int out_dtype, int M, int N, int K, int act, void* C2, int ldc2, int act2, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(A && W && C, MMAMD_E_BADARG, "gemm: null pointer");
   MMAMD_CHECK_ARG(M >= 0 && N > 0 && K > 0, MMAMD_E_BADARG, "gemm: bad sizes M=%d N=%d K=%d", M, N, K);
   MMAMD_CHECK_ARG(K % 64 == 0, MMAMD_E_UNSUPPORTED, "gemm: K=%d must be a multiple of 64 (pad the operands)", K);
@@ -2981,10 +1887,6 @@ static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const 
     const long long t_tile = (long long)(K / 64) * 3500 + (out_dtype == MMAMD_F32 ? 27000 : 8000) +
                              ((act == MMAMD_ACT_QUICKGELU || act == MMAMD_ACT_GELU_ERF) ? 8000 : 0);
     p.stagger = g_gemm_stagger >= 1000 ? -(int)(t_tile * (g_gemm_stagger - 1000) / 100) : (int)(t_tile * g_gemm_stagger / 100);
-  }
-  if (lf != nullptr) {
-    p.Xh = (bf16*)lf->xh; p.ldxh = lf->ldxh; p.st_out = lf->st_out; p.nslot_out = N / 64;
-    p.st_in = lf->st_in; p.nslot_in = lf->nslot_in; p.c1 = lf->c1; p.inv_d = 1.0f / (float)K; p.ln_eps = lf->eps;
   }
   if (act == MMAMD_ACT_MUL_QUICKGELU_GRAD || act == MMAMD_ACT_MUL_GELU_GRAD) {
     MMAMD_CHECK_ARG(out_dtype == MMAMD_BF16 && residual != nullptr, MMAMD_E_BADARG,

@@ -178,63 +178,6 @@ __global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const LnGrou
 }
 
 // ---------------------------------------------------------------------------------------------
-// LN fold helpers (gemm.hip "LN fold"): one-time weight packing, and the statistics + bf16 copy of a residual stream that no GEMM
-// produced (the first layer's input).
-// ---------------------------------------------------------------------------------------------
-// Wg[n][k] = bf16(gamma[k] W[n][k]);  c1[n] = sum_k float(Wg[n][k]) (the values the MFMA multiplies);  c2[n] = bias[n] + sum_k beta[k] W[n][k]
-template <typename TW>
-__global__ __launch_bounds__(256) void lnfold_pack_kernel(const TW* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ bias, bf16* __restrict__ Wg, float* __restrict__ c1,
-                                                          float* __restrict__ c2, int N, int K) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int k = 4 * lane; k < K; k += 256) {
-    const f32x4 w = load4(W + (size_t)n * K + k), g = load4(gamma + k), b = load4(beta + k);
-    bf16x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o[j] = (bf16)(g[j] * w[j]);
-      s1 += (float)o[j];
-      s2 = fmaf(b[j], w[j], s2);
-    }
-    *reinterpret_cast<bf16x4*>(Wg + (size_t)n * K + k) = o;
-  }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if (lane == 0) {
-    c1[n] = s1;
-    c2[n] = s2 + (bias != nullptr ? bias[n] : 0.f);
-  }
-}
-
-// xh = bf16(x);  stats[row][0] = (sum x, sum x^2), stats[row][1 .. nslot) = 0
-template <int MAXV>
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, bf16* __restrict__ xh, float* __restrict__ stats, int rows,
-                                                        int d, int nslot) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int d4 = d >> 2;
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < d4) {
-      const f32x4 v = load4(x + (size_t)row * d + 4 * c);
-      store4(xh + (size_t)row * d + 4 * c, v);
-      s1 += (v[0] + v[1]) + (v[2] + v[3]);
-      s2 += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
-    }
-  }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  float* st = stats + (size_t)row * (2 * nslot);
-  for (int k = lane; k < 2 * nslot; k += 64) st[k] = k == 0 ? s1 : (k == 1 ? s2 : 0.f);
-}
-
-// ---------------------------------------------------------------------------------------------
 // ViT assemble: x[b,0]=cls+pos[0]; x[b,1+i]=patch_emb[b,i]+pos[1+i]; then ln_pre  -> fp32
 // ---------------------------------------------------------------------------------------------
 template <typename TPE, int MAXV>
@@ -954,31 +897,6 @@ extern "C" int mmamd_layernorm(const void* x, int x_dtype, const float* gamma, c
   if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_BF16) return launch_layernorm<bf16, bf16>(x, gamma, beta, y, rows, d, eps, st);
   if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_F32) return launch_layernorm<bf16, float>(x, gamma, beta, y, rows, d, eps, st);
   MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "layernorm: bad dtype code");
-}
-
-extern "C" int mmamd_lnfold_pack(const void* W, int w_dtype, const float* gamma, const float* beta, const float* bias, void* Wg, float* c1,
-                                 float* c2, int N, int K, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(W && gamma && beta && Wg && c1 && c2 && N > 0 && K > 0, MMAMD_E_BADARG, "lnfold_pack: bad argument");
-  MMAMD_CHECK_ARG(K % 4 == 0 && aligned16(W) && aligned16(gamma) && aligned16(beta) && (reinterpret_cast<uintptr_t>(Wg) & 7) == 0, MMAMD_E_ALIGN,
-                  "lnfold_pack: K %% 4 == 0 and 16-byte aligned operands");
-  const dim3 grid((N + 3) / 4), block(256);
-  if (w_dtype == MMAMD_F32) hipLaunchKernelGGL((lnfold_pack_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)W, gamma, beta, bias, (bf16*)Wg, c1, c2, N, K);
-  else if (w_dtype == MMAMD_BF16) hipLaunchKernelGGL((lnfold_pack_kernel<bf16>), grid, block, 0, (hipStream_t)stream, (const bf16*)W, gamma, beta, bias, (bf16*)Wg, c1, c2, N, K);
-  else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "lnfold_pack: bad weight dtype");
-  return launch_status("lnfold_pack");
-}
-
-extern "C" int mmamd_row_stats(const float* x, void* xh, float* stats, int rows, int d, int nslot, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(x && xh && stats && rows >= 0 && d > 0 && nslot > 0, MMAMD_E_BADARG, "row_stats: bad argument");
-  MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048 && aligned16(x), MMAMD_E_UNSUPPORTED, "row_stats: d=%d must be a multiple of 4 and <= 2048", d);
-  if (rows == 0) return 0;
-  const dim3 grid((rows + 3) / 4), block(256);
-  const int d4 = d / 4;
-  hipStream_t st = (hipStream_t)stream;
-  if (d4 <= 128) hipLaunchKernelGGL((row_stats_kernel<2>), grid, block, 0, st, x, (bf16*)xh, stats, rows, d, nslot);
-  else if (d4 <= 256) hipLaunchKernelGGL((row_stats_kernel<4>), grid, block, 0, st, x, (bf16*)xh, stats, rows, d, nslot);
-  else hipLaunchKernelGGL((row_stats_kernel<8>), grid, block, 0, st, x, (bf16*)xh, stats, rows, d, nslot);
-  return launch_status("row_stats");
 }
 
 extern "C" int mmamd_vit_assemble_ln(const void* pe, int pe_dtype, const float* cls, const float* pos,

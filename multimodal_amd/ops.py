@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "lnfold_pack", "row_stats", "gemm_bf16_res_stats", "gemm_bf16_lnfold", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -217,64 +217,6 @@ def gemm_bf16_grouped(problems, act: int = ACT_NONE, out_dtype: torch.dtype = to
     if timer is not None:
         timer.stop()
     return outs
-
-
-def lnfold_pack(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor]):
-    """(Wg bf16 [N,K], c1 [N], c2 [N]) of a Linear(W, bias) that consumes LayerNorm(gamma, beta): see mmamd_lnfold_pack."""
-    _chk(w, "w"); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
-    if bias is not None:
-        _chk(bias, "bias", torch.float32)
-    N, K = w.shape
-    wg = torch.empty((N, K), dtype=torch.bfloat16, device=w.device)
-    c1 = torch.empty(N, dtype=torch.float32, device=w.device)
-    c2 = torch.empty(N, dtype=torch.float32, device=w.device)
-    check(_lib.lib().mmamd_lnfold_pack(w.data_ptr(), _dt(w), gamma.data_ptr(), beta.data_ptr(), _ptr(bias), wg.data_ptr(), c1.data_ptr(),
-                                       c2.data_ptr(), N, K, _stream()), "mmamd_lnfold_pack")
-    return wg, c1, c2
-
-
-def row_stats(x: torch.Tensor, xh: torch.Tensor, stats: torch.Tensor) -> None:
-    """xh = bf16(x), stats[row] = [(sum, sum sq), 0, ...]: LN-fold inputs of a residual stream that no GEMM produced."""
-    _chk(x, "x", torch.float32); _chk(xh, "xh", torch.bfloat16); _chk(stats, "stats", torch.float32)
-    rows, d = x.shape
-    check(_lib.lib().mmamd_row_stats(x.data_ptr(), xh.data_ptr(), stats.data_ptr(), rows, d, stats.shape[1], _stream()), "mmamd_row_stats")
-
-
-def gemm_bf16_res_stats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], x: torch.Tensor, xh: torch.Tensor,
-                        stats: torch.Tensor) -> torch.Tensor:
-    """x (fp32 [M,N], in place) += a @ w^T + bias; also writes xh = bf16(x) and the per-row block statistics [M, N/64, 2]."""
-    _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16); _chk(x, "x", torch.float32); _chk(xh, "xh", torch.bfloat16)
-    _chk(stats, "stats", torch.float32)
-    M, K = a.shape
-    N = w.shape[0]
-    if w.shape[1] != K or x.shape != (M, N) or xh.shape != (M, N) or stats.shape != (M, N // 64, 2):
-        raise MmamdError("gemm_bf16_res_stats: shape mismatch")
-    if bias is not None:
-        _chk(bias, "bias", torch.float32)
-    check(_lib.lib().mmamd_gemm_bf16_res_stats(a.data_ptr(), K, w.data_ptr(), K, _ptr(bias), x.data_ptr(), N, x.data_ptr(), N, xh.data_ptr(), N,
-                                               stats.data_ptr(), M, N, K, _stream()), "mmamd_gemm_bf16_res_stats")
-    return x
-
-
-def gemm_bf16_lnfold(xh: torch.Tensor, wg: torch.Tensor, c1: torch.Tensor, c2: torch.Tensor, stats: torch.Tensor, eps: float,
-                     act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out (bf16 [M,N]) = act(LayerNorm(x) @ W^T + b) from the packed (wg, c1, c2), xh = bf16(x) and x's block statistics."""
-    _chk(xh, "xh", torch.bfloat16); _chk(wg, "wg", torch.bfloat16); _chk(c1, "c1", torch.float32); _chk(c2, "c2", torch.float32)
-    _chk(stats, "stats", torch.float32)
-    M, K = xh.shape
-    N = wg.shape[0]
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=xh.device)
-    _chk(out, "out", torch.bfloat16)
-    probe = _GEMM_PROBE
-    timer = probe._timer_for(M, N, K) if probe is not None else None
-    if timer is not None:
-        timer.start()
-    check(_lib.lib().mmamd_gemm_bf16_lnfold(xh.data_ptr(), K, wg.data_ptr(), K, c1.data_ptr(), c2.data_ptr(), stats.data_ptr(), stats.shape[1],
-                                            float(eps), out.data_ptr(), N, M, N, K, int(act), _stream()), "mmamd_gemm_bf16_lnfold")
-    if timer is not None:
-        timer.stop()
-    return out
 
 
 def gemm_bf16_dual(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int) -> Tuple[torch.Tensor, torch.Tensor]:
