@@ -26,6 +26,7 @@ from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.flava import cls_linear, Pooler
 from ...utils.common import load_module_from_url
 from ..._autograd import wants_grad
+from ...schedule import get_schedule
 from ._dalle import DalleConv2d, DalleEncoder, DalleEncoderBlock, DalleVAEEncoder  # noqa: F401  (reference :583-744)
 from .image_encoder import flava_image_encoder
 from .text_encoder import flava_text_encoder
@@ -141,17 +142,35 @@ class FLAVAModel(PackedModeMixin, nn.Module):
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
             side.wait_stream(main)
+        # The unmasked and the masked pass of a tower share its weights and are independent per sample: in inference they run as ONE pass
+        # over a 2B batch (the GEMMs see M = 2 B S rows: persistent 256 x 256 kernels at full rounds instead of 1.5 rounds / 128 x 128 tiles),
+        # and the outputs are split back into the two TransformerOutputs as views.  Bit-identical to two passes (every kernel's per-row
+        # arithmetic is independent of the row's position in the batch: tests/test_gpu_bench_size_parity.py; a patch mask of zeros blends
+        # nothing: csrc/rowops.hip::flava_image_embed_kernel).  Encoders with forward hooks, and training, keep the two calls.
+        batched = not training and get_schedule().flava_batched_passes
         ctx = torch.cuda.stream(side) if side is not None else _Null()
         with ctx:
-            if want_text:
-                text_outputs, projected_text_embeddings = self.encode_text(text, projection=True)
-            if want_text_masked:
-                text_masked_outputs = self.encode_text(text_masked)
-        if want_image:
-            image_outputs, projected_image_embeddings = self.encode_image(image, projection=True)
-            if image_patches_mask is None:
-                image_masked_outputs = image_outputs  # identical inputs, deterministic kernels: same values
+            if (batched and want_text and want_text_masked and _plain_call(self.text_encoder) and text.shape == text_masked.shape
+                    and text.dtype == text_masked.dtype):
+                both = self.encode_text(torch.cat([text, text_masked]))
+                text_outputs, text_masked_outputs = _split_batch(both, text.shape[0])
+                projected_text_embeddings = cls_linear(text_outputs.last_hidden_state, self.text_projection, self._packed)
             else:
+                if want_text:
+                    text_outputs, projected_text_embeddings = self.encode_text(text, projection=True)
+                if want_text_masked:
+                    text_masked_outputs = self.encode_text(text_masked)
+        if want_image:
+            if image_patches_mask is None:
+                image_outputs, projected_image_embeddings = self.encode_image(image, projection=True)
+                image_masked_outputs = image_outputs  # identical inputs, deterministic kernels: same values
+            elif batched and _plain_call(self.image_encoder) and image_patches_mask.shape[0] == image.shape[0]:
+                m = image_patches_mask.reshape(image.shape[0], -1)
+                both = self.encode_image(torch.cat([image, image]), image_patches_mask=torch.cat([torch.zeros_like(m), m]))
+                image_outputs, image_masked_outputs = _split_batch(both, image.shape[0])
+                projected_image_embeddings = cls_linear(image_outputs.last_hidden_state, self.image_projection, self._packed)
+            else:
+                image_outputs, projected_image_embeddings = self.encode_image(image, projection=True)
                 image_masked_outputs = self.encode_image(image, image_patches_mask=image_patches_mask)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
@@ -230,6 +249,24 @@ class FLAVAModel(PackedModeMixin, nn.Module):
         self._token_linear(image_embedding, self.image_to_mm_projection, fused_state[:, :Si])
         self._token_linear(text_embedding, self.text_to_mm_projection, fused_state[:, Si:])
         return self.mm_encoder(fused_state)
+
+
+def _plain_call(enc: nn.Module) -> bool:
+    """no forward hooks on the encoder: merging two calls into one would change what a hook observes"""
+    return not (enc._forward_hooks or enc._forward_pre_hooks)
+
+
+def _split_batch(o: TransformerOutput, B: int) -> Tuple[TransformerOutput, TransformerOutput]:
+    """the two halves of a 2B-batch TransformerOutput (views, no copies)"""
+    def half(t, k):
+        return None if t is None else t[k * B:(k + 1) * B]
+
+    def halves(k):
+        return TransformerOutput(last_hidden_state=half(o.last_hidden_state, k), pooler_output=half(o.pooler_output, k),
+                                 hidden_states=None if o.hidden_states is None else [half(t, k) for t in o.hidden_states],
+                                 attentions=None if o.attentions is None else [half(t, k) for t in o.attentions])
+
+    return halves(0), halves(1)
 
 
 class _Null:

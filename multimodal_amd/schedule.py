@@ -8,6 +8,7 @@ Every choice is between paths that compute the same function; the defaults are t
     residual    "epilogue" | "delta_ln"           x += proj(...) inside the GEMM epilogue (fp32 read-modify-write per tile), or the GEMM
                                                   stores a bf16 delta and ONE streaming kernel does x += delta; hn = LN(x) for both towers
     side_stream  True | False                     tower-agnostic path: second tower on a side stream (False = one stream)
+    flava_batched_passes  True | False            FLAVA inference: the unmasked and the masked pass of a tower as ONE pass over a 2B batch
 
 Environment (read once): MMAMD_TWO_TOWER, MMAMD_RESIDUAL (epilogue | delta_ln), MMAMD_SINGLE_STREAM=1.
 """
@@ -25,6 +26,7 @@ class Schedule:
     two_tower: str = "auto"
     residual: str = "epilogue"
     side_stream: bool = True
+    flava_batched_passes: bool = True
 
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:

@@ -637,3 +637,44 @@ def test_offset_position_ids_like_reference():
         a = emb2(big.cuda())
         b = emb2(big.cuda(), position_ids=want.cuda())
     assert torch.equal(a, b)
+
+
+@torch.no_grad()
+def test_batched_passes_equal_two_passes_bit_for_bit(golden):
+    """schedule.flava_batched_passes (r03, default): the unmasked and the masked pass of the image tower — and of the text tower — run as ONE
+    pass over a 2B batch and are split back as views.  Every field of FLAVAOutput must equal the two-pass result exactly; a forward hook on
+    an encoder switches the merge off (the hook must see both calls)."""
+    from multimodal_amd.schedule import get_schedule, set_schedule
+
+    z = golden("flava_small.npz")
+    model = _small_model(z)
+    image, text = torch.from_numpy(z["image"]).cuda(), torch.from_numpy(z["text"]).cuda()
+    pm, tm = torch.from_numpy(z["patches_mask"]).cuda(), torch.from_numpy(z["text_masked"]).cuda()
+
+    def run():
+        return model(image, text, image_patches_mask=pm, text_masked=tm, skip_unmasked_mm_encoder=False)
+
+    prev = get_schedule().flava_batched_passes
+    try:
+        set_schedule(flava_batched_passes=False)
+        ref = run()
+        set_schedule(flava_batched_passes=True)
+        got = run()
+        calls = []
+        h = model.image_encoder.register_forward_hook(lambda m, i, o: calls.append(1))
+        hooked = run()
+        h.remove()
+    finally:
+        set_schedule(flava_batched_passes=prev)
+    assert len(calls) == 2  # hooks observe the reference's two calls
+    for out in (got, hooked):
+        assert torch.equal(out.projected_image_embeddings, ref.projected_image_embeddings)
+        assert torch.equal(out.projected_text_embeddings, ref.projected_text_embeddings)
+        for part in ("image", "text", "image_masked", "text_masked", "multimodal", "multimodal_masked"):
+            a, b = getattr(out, part), getattr(ref, part)
+            assert torch.equal(a.last_hidden_state, b.last_hidden_state), part
+            assert (a.pooler_output is None) == (b.pooler_output is None)
+            if a.pooler_output is not None:
+                assert torch.equal(a.pooler_output, b.pooler_output), part
+            assert len(a.hidden_states) == len(b.hidden_states) and all(torch.equal(p, q) for p, q in zip(a.hidden_states, b.hidden_states)), part
+            assert len(a.attentions) == len(b.attentions) and all(torch.equal(p, q) for p, q in zip(a.attentions, b.attentions)), part
