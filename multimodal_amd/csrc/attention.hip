@@ -1343,6 +1343,8 @@ namespace mmamd {
 // attention_ring.hip: LDS-DMA ring kernel (S <= 224), up to two problems per launch
 bool attn_ring_supports(int S);
 extern int g_attn_ring_abl;
+extern int g_attn_ring_depth_cap;
+int g_ln_nt_policy = 0;  // mmamd_debug_set_attn_variant(3100 + p): LayerNorm x loads 0 = by size (default), 1 = never non-temporal, 2 = always (A/B)
 int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse, const int* B, const int* S, const int* H, const int* causal,
                      const float* scale, int nprob, hipStream_t st);
 }  // namespace mmamd
@@ -1352,8 +1354,16 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
     g_attn_probs_serial = v == 512;
     return 0;
   }
-  if (v >= 2000 && v < 2512) {  // ring kernel ablations (timing only): 2000 + {1: no DMA, 2: no key loops, 4: no Q loads, 8: no O stores}
+  if (v >= 2000 && v < 3000) {  // ring kernel ablations (timing only): 2000 + {1: no DMA, 2: no key loops, 4: no Q loads, 8: no O stores}
     g_attn_ring_abl = v - 2000;
+    return 0;
+  }
+  if (v >= 3100 && v < 3103) {
+    g_ln_nt_policy = v - 3100;
+    return 0;
+  }
+  if (v >= 3000 && v < 3008) {  // ring kernel: cap of the ring depth (0 = none), timing A/B only
+    g_attn_ring_depth_cap = v - 3000;
     return 0;
   }
   g_attn_variant = v;

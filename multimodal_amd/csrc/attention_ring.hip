@@ -67,8 +67,10 @@ struct AttnRingArgs {
 
 // 1 KiB LDS-DMA piece: lane l writes 16 B at lds_dst + 16 l from sbase + voff (scalar base + 32-bit per-lane offset: no VALU).
 // M0 is written and consumed inside the statement; nothing else in this kernel uses M0.
+template <int NT = 0>
 __device__ __forceinline__ void ring_dma_piece(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  if constexpr (NT != 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 // wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; rounded DOWN to a multiple of 8,
@@ -100,6 +102,10 @@ __device__ __forceinline__ int ring_f(int row) { return (((row >> 1) & 1) << 2) 
 
 constexpr int kRingWaves = 8;  // 7 compute + 1 loader
 
+// ABL, results right: 4096 / 8192 = O rows stored non-temporal / sc1, 16384 = K / V / Q loaded non-temporal (profiles/r03_cache_policy_ab.txt: non-temporal O
+// stores take the isolated kernel from 77 to 67-70 us and cost the out-projection that reads O next just as much: 13.69 vs 13.66 ms per step).
+// 2048 (results wrong) = no Q rows in the ring entry, which makes room for a third entry: 58.4 vs 57.7 us without O stores, 66.4 vs 65.6 with - a deeper
+// ring does not pay (tools/attn_ring_depth.py).
 // ABL (timing experiments, results WRONG): 1 = no K/V/Q DMA, 2 = no key loops, 8 = no O stores, 32 = no exp2, 64 = K / V fragments read once per
 // unit instead of per tile, 128 = no MFMA (scores / outputs come from moves), 256 = no cross-half max exchange.  ABL & 4 (results right): phase timers —
 // `lse` of problem 0 receives 8 floats of s_memtime ticks per wave: compute waves {key loops, O transpose + store, barrier wait, total},
@@ -143,7 +149,9 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
       const int np = rows8 >> 3;            // 1 KiB pieces per K (and per V) image
       const int npq = nqt * 4;              // pieces of the Q image (32 * nqt rows)
       const int nfull = S >> 3;             // pieces whose 8 rows all exist
-      const int E1 = 2 * np + npq;          // pieces per item
+      constexpr int DNT = (ABL & 16384) ? 1 : 0;  // non-temporal K / V / Q loads
+      constexpr bool NOQ = (ABL & 2048) != 0;  // timing experiment: no Q rows in the ring (the compute waves read K rows as their Q)
+      const int E1 = 2 * np + (NOQ ? 0 : npq);  // pieces per item
       const int E = G * E1;                 // pieces of a full entry
       const int lr8 = lane >> 3, c8 = lane & 7;
       // full pieces: lane offset relative to the piece's first row; the swizzle term of row 8p + lr8 is ring_f(lr8) ^ (2 (p & 1))
@@ -160,20 +168,20 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
         int p = 0;
 #pragma unroll 1
         for (; p + 1 < nfull; p += 2) {
-          ring_dma_piece(sp, vo_even, d);
-          ring_dma_piece(sp + step, vo_odd, d + 1024);
+          ring_dma_piece<DNT>(sp, vo_even, d);
+          ring_dma_piece<DNT>(sp + step, vo_odd, d + 1024);
           sp += 2 * step;
           d += 2048;
         }
         if (p < nfull) {
-          ring_dma_piece(sp, vo_even, d);
+          ring_dma_piece<DNT>(sp, vo_even, d);
           ++p;
         }
 #pragma unroll 1
         for (; p < npieces; ++p) {  // rows >= S: the source row is clamped to S - 1 (K / V: never used; Q: as the register-staged kernel did)
           const int row = 8 * p + lr8;
           const int srow = row < S ? row : S - 1;
-          ring_dma_piece(sb, (uint32_t)(srow * rsb + ((c8 ^ ring_f(row)) << 4)), d0 + (uint32_t)(p * 1024));
+          ring_dma_piece<DNT>(sb, (uint32_t)(srow * rsb + ((c8 ^ ring_f(row)) << 4)), d0 + (uint32_t)(p * 1024));
         }
       };
       auto issue_entry = [&]() {
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
           const char* src = reinterpret_cast<const char*>(qkv + ((size_t)b * S * 3 * D + (size_t)h * 64));
           const uint32_t dst = ebase + (uint32_t)(gi * slot_bytes);
           if constexpr ((ABL & 1) == 0) {
-            issue_image(src, dst + (uint32_t)(2 * rows8 * 128), npq);           // Q (read first by the compute waves)
+            if constexpr (!NOQ) issue_image(src, dst + (uint32_t)(2 * rows8 * 128), npq);  // Q (read first by the compute waves)
             issue_image(src + (size_t)D * 2, dst, np);                         // K
             issue_image(src + (size_t)D * 4, dst + (uint32_t)(rows8 * 128), np);  // V
           }
@@ -250,7 +258,8 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
         if (wactive && n < Nloc) {
           const char* Kb = smem + eslot * entry_bytes + di * slot_bytes;
           const char* Vb = Kb + rows8 * 128;
-          char* Qb = const_cast<char*>(Vb) + rows8 * 128 + qt * 4096;  // this wave's 32 Q rows; later its O tile
+          char* Qb = (ABL & 2048) ? const_cast<char*>(Kb) + (qt < 6 ? qt : 5) * 4096
+                                  : const_cast<char*>(Vb) + rows8 * 128 + qt * 4096;  // this wave's 32 Q rows; later its O tile
           bf16x8 qcur[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) qcur[t] = *reinterpret_cast<const bf16x8*>(Qb + ko[t]);
@@ -525,7 +534,17 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
             for (int j = 0; j < 4; ++j) {
               const int row = (lane >> 3) + 8 * j;
               const bf16x8 v = *reinterpret_cast<const bf16x8*>(Qb + orr + j * 1024 + ((oc ^ ring_f(row)) << 4));
-              if (qt * 32 + row < S) *reinterpret_cast<bf16x8*>(obase + (size_t)row * D) = v;
+              if (qt * 32 + row < S) {
+                if constexpr ((ABL & 4096) != 0) {
+                  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+                  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(obase + (size_t)row * D), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
+                } else if constexpr ((ABL & 8192) != 0) {
+                  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+                  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(obase + (size_t)row * D), "v"(__builtin_bit_cast(u32x4_t, v)) : "memory");
+                } else {
+                  *reinterpret_cast<bf16x8*>(obase + (size_t)row * D) = v;
+                }
+              }
             }
           }
           tr2 = now();
@@ -544,6 +563,8 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
 }
 
 // host side ----------------------------------------------------------------------------------------------------------------
+int g_attn_ring_abl = 0;
+int g_attn_ring_depth_cap = 0;  // mmamd_debug_set_attn_variant(3000 + n): at most n ring entries (0 = as many as fit)
 static bool ring_prob_setup(AttnRingProb& p, const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, int& smem) {
   const int nqt = (S + 31) / 32;
   if (nqt > 7 || S < 1) return false;
@@ -553,14 +574,21 @@ static bool ring_prob_setup(AttnRingProb& p, const void* qkv, void* out, float* 
   p.nqt = nqt; p.rows8 = rows8;
   p.G = 7 / nqt;
   p.slot_bytes = (2 * rows8 + 32 * nqt) * 128;  // K rows, V rows, Q rows (the V over-read of the last key tile ends inside the Q rows)
+#ifdef MMAMD_EXPERIMENTS
+  if (g_attn_ring_abl == 400 || g_attn_ring_abl == 401) p.slot_bytes = 2 * rows8 * 128;  // "no Q rows" timing experiment
+#endif
   p.entry_bytes = p.G * p.slot_bytes;
   int nring = (160 * 1024) / p.entry_bytes;
   if (nring > 4) nring = 4;
+  if (g_attn_ring_depth_cap >= 2 && nring > g_attn_ring_depth_cap) nring = g_attn_ring_depth_cap;  // A/B of the ring depth (tools/attn_ring_depth.py)
   if (nring < 2) return false;
   p.nring = nring;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.pad_ = 0;
-  const int need = nring * p.entry_bytes;
+  int need = nring * p.entry_bytes;
+#ifdef MMAMD_EXPERIMENTS
+  if (g_attn_ring_abl == 400 || g_attn_ring_abl == 401) need += 4096;  // the V over-read of the last entry
+#endif
   if (need > smem) smem = need;
   return true;
 }
@@ -571,7 +599,7 @@ bool attn_ring_supports(int S) {
   const int nqt = (S + 31) / 32, rows8 = (S + 7) & ~7;
   return 2 * (7 / nqt) * (2 * rows8 + 32 * nqt) * 128 <= 160 * 1024;
 }
-int g_attn_ring_abl = 0;   // timing experiments: ABL bits of the kernel (1, 2, 8 and their sums), + 16 = runtime key loop for every shape
+// (defined above ring_prob_setup) timing experiments: ABL bits of the kernel (1, 2, 8 and their sums), + 16 = runtime key loop for every shape
 
 template <int ABL, int UNR>
 static int launch_ring_t(const AttnRingArgs& a, int grid, int smem, hipStream_t st) {
@@ -625,6 +653,13 @@ int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse
     case 105: return launch_ring_t<9 + 32 + 64, 1>(a, grid, smem, st);
     case 233: return launch_ring_t<9 + 32 + 64 + 128, 1>(a, grid, smem, st);
     case 201: return launch_ring_t<9 + 64 + 128, 1>(a, grid, smem, st);
+    case 410: return launch_ring_t<4096, 2>(a, grid, smem, st);
+    case 412: return launch_ring_t<16384, 2>(a, grid, smem, st);
+    case 413: return launch_ring_t<4096 + 16384, 2>(a, grid, smem, st);
+    case 411: return launch_ring_t<8192, 2>(a, grid, smem, st);
+    case 400: return launch_ring_t<2048 + 8, 2>(a, grid, smem, st);
+    case 401: return launch_ring_t<2048, 2>(a, grid, smem, st);
+    case 402: return launch_ring_t<8, 2>(a, grid, smem, st);
     case 16: return launch_ring_t<0, 0>(a, grid, smem, st);
     case 17: return launch_ring_t<1, 0>(a, grid, smem, st);
     case 25: return launch_ring_t<9, 0>(a, grid, smem, st);

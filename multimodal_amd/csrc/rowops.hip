@@ -3,14 +3,25 @@
 //   pooled-row LN + projection (+L2 normalize), L2 normalize, scalar clamp, dtype convert.
 // All are one-wave-per-row (64 lanes, 16-byte vector accesses) unless noted; none reshapes work
 // into a GEMM — the roofline that bounds them is HBM bandwidth.
+#include <type_traits>
+
 #include "common.h"
 
 namespace mmamd {
+extern int g_ln_nt_policy;  // attention.hip (mmamd_debug_set_attn_variant(3100 + p)): 0 = by size, 1 = never, 2 = always
+// LayerNorm reads its fp32 input NON-TEMPORALLY when the tensor is larger than what the 256 MiB MALL keeps next to the bf16 output: the input rows then
+// stream through without evicting the output rows the next GEMM is about to read.  Measured per step, same-box alternating A/B
+// (profiles/r03_cache_policy_ab.txt): ViT-B/16 B = 256 (148 + 38 MiB) 13.66 -> 13.43 ms, ViT-L/14 (257 MiB) -1.0 %, FLAVA (148 MiB) -0.8 %;
+// ViT-B/32 (37 MiB: the input is still cached from the GEMM that wrote it) +0.7 %, CoCa B = 128 (128 MiB) +0.3 %.
+static bool ln_nontemporal(size_t x_bytes) {
+  if (g_ln_nt_policy != 0) return g_ln_nt_policy == 2;
+  return x_bytes >= ((size_t)144 << 20);
+}
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row cached in registers (MAXV float4 per lane), two-pass statistics
 // ---------------------------------------------------------------------------------------------
-template <typename TIN, typename TOUT, int MAXV>
+template <typename TIN, typename TOUT, int MAXV, int NT = 0>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
@@ -27,7 +38,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + 64 * i;
     if (c < d4) {
-      v[i] = load4(xr + 4 * c);
+      if constexpr (NT != 0 && std::is_same<TIN, float>::value) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * c));
+      else v[i] = load4(xr + 4 * c);
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     } else {
       v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -66,6 +78,15 @@ static int launch_layernorm(const void* x, const float* g, const float* b, void*
                             float eps, hipStream_t st) {
   const int d4 = d / 4;
   const dim3 grid((rows + 3) / 4), block(256);
+  if (std::is_same<TIN, float>::value && ln_nontemporal((size_t)rows * d * 4)) {
+    if (d4 <= 128)
+      hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 2, 1>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
+    else if (d4 <= 256)
+      hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 4, 1>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
+    else
+      hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 8, 1>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
+    return launch_status("layernorm");
+  }
   if (d4 <= 128)
     hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 2>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
   else if (d4 <= 256)
@@ -96,7 +117,7 @@ struct LnGroupArgs {
   int blocks0;  // blocks (4 rows each) of problem 0
 };
 
-template <int MAXV, bool HAS_DELTA>
+template <int MAXV, bool HAS_DELTA, int NT = 0>
 __global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const LnGroupArgs a) {
   const int lane = threadIdx.x & 63;
   int blk = blockIdx.x, pi = 0;
@@ -141,7 +162,8 @@ __global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const LnGrou
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + 64 * i;
       if (c < d4) {
-        v[i] = load4(xr + 4 * c);
+        if constexpr (NT != 0) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + 4 * c));
+        else v[i] = load4(xr + 4 * c);
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
       } else {
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -871,9 +893,13 @@ extern "C" int mmamd_add_layernorm_grouped(const mmamd_ln_problem* probs, int np
   hipStream_t st = (hipStream_t)stream;
   bool has_delta = false;
   for (int i = 0; i < a.nprob; ++i) has_delta = has_delta || a.p[i].delta != nullptr;
+  size_t xbytes = 0;
+  for (int i = 0; i < a.nprob; ++i) xbytes += (size_t)a.p[i].rows * a.p[i].d * 4;
+  const bool ntp = ln_nontemporal(xbytes);
 #define LN_LAUNCH(MV)                                                                                                  \
   do {                                                                                                                 \
     if (has_delta) hipLaunchKernelGGL((add_layernorm_grouped_kernel<MV, true>), dim3(total), dim3(256), 0, st, a);     \
+    else if (ntp) hipLaunchKernelGGL((add_layernorm_grouped_kernel<MV, false, 1>), dim3(total), dim3(256), 0, st, a);  \
     else hipLaunchKernelGGL((add_layernorm_grouped_kernel<MV, false>), dim3(total), dim3(256), 0, st, a);              \
   } while (0)
   if (dmax <= 512) LN_LAUNCH(2);

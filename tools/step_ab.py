@@ -3,7 +3,8 @@ alternating arms (guide rules 13 / 24).  Each arm is timed three ways: eager wit
 ENQUEUE a step (is the Python thread the limit?), and a HIP-graph replay of the same step (no host in the loop).
 
     python tools/step_ab.py --arms ring,r02attn [--rounds 3] [--steps 20]
-arms (joined with +): base, r02attn (register-staged attention kernel), delta_ln (bf16 delta GEMMs + fused add+LayerNorm), streams"""
+arms (joined with +): base, r02attn (register-staged attention kernel), delta_ln (bf16 delta GEMMs + fused add+LayerNorm), streams,
+ln_cached (LayerNorm input loads never non-temporal)"""
 import argparse
 import json
 import sys
@@ -43,6 +44,7 @@ def main():
 
     def set_arm(name):
         L.mmamd_debug_set_attn_variant(0)
+        L.mmamd_debug_set_attn_variant(3100)
         set_schedule(residual="epilogue", two_tower="auto")
         for part in name.split("+"):
             if part in ("ring", "base"):
@@ -53,6 +55,8 @@ def main():
                 set_schedule(residual="delta_ln")
             elif part == "streams":
                 set_schedule(two_tower="streams")
+            elif part == "ln_cached":  # LayerNorm input loads never non-temporal (the r02 behaviour)
+                L.mmamd_debug_set_attn_variant(3101)
             else:
                 raise SystemExit(f"unknown arm {part}")
 
