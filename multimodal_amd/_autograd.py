@@ -71,74 +71,132 @@ class StackConfig:
         self.hidden: List[Tensor] = []  # inputs of every layer (detached), filled by the forward when keep_hidden
 
 
+def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: int, causal: bool, act: int, eps1: List[float],
+                    eps2: List[float], key_mask: Optional[Tensor]) -> List[Tensor]:
+    """Forward of N pre-norm layers.  params: the 12 canonical fp32 tensors per layer.  Returns [x_L] + per layer
+    [h1, qkv, att, lse, x_mid, h2, u, g] + the inputs of layers 1 .. N-1 (layer 0's input is x0 itself)."""
+    H = n_head
+    n_layers = len(params) // 12
+    saved: List[Tensor] = []
+    inputs: List[Tensor] = []
+    x = x0
+    for li in range(n_layers):
+        Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+        if li > 0:
+            inputs.append(x)
+        h1 = ops.layernorm(x, g1, be1, eps1[li], out_dtype=bf)
+        qkv = ops.gemm_bf16(h1, ops.convert(Wqkv, bf), bqkv)
+        att, lse = ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
+        x_mid = ops.gemm_bf16(att, ops.convert(Wo, bf), bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
+        h2 = ops.layernorm(x_mid, g2, be2, eps2[li], out_dtype=bf)
+        u, g = ops.gemm_bf16_dual(h2, ops.convert(W1, bf), b1, act)  # pre-activation (kept for the backward) + activation
+        x_out = ops.gemm_bf16(g, ops.convert(W2, bf), b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
+        saved += [h1, qkv, att, lse, x_mid, h2, u, g]
+        x = x_out
+    return [x] + saved + inputs
+
+
+def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask):
+    n_layers = len(params) // 12
+    M, d = x0.shape
+    saved, inputs = [], []
+    for li in range(n_layers):
+        ff = params[12 * li + 4].shape[0]
+        if li > 0:
+            inputs.append(x0.new_empty((M, d)))
+        saved += [x0.new_empty((M, d), dtype=bf), x0.new_empty((M, 3 * d), dtype=bf), x0.new_empty((M, d), dtype=bf),
+                  x0.new_empty((B, n_head, S)), x0.new_empty((M, d)), x0.new_empty((M, d), dtype=bf), x0.new_empty((M, ff), dtype=bf),
+                  x0.new_empty((M, ff), dtype=bf)]
+    return [x0.new_empty((M, d))] + saved + inputs
+
+
 _ACT_GRAD = {ops.ACT_QUICKGELU: ops.ACT_MUL_QUICKGELU_GRAD, ops.ACT_GELU_ERF: ops.ACT_MUL_GELU_GRAD}
+
+
+def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: List[Tensor], n_head: int, B: int, S: int, causal: bool,
+                    act: int, eps1: List[float], eps2: List[float], key_mask: Optional[Tensor]) -> List[Tensor]:
+    """Backward of _stack_fwd_impl: saved = its outputs [1:].  Returns [dX0] + the 12 canonical gradients per layer."""
+    H = n_head
+    n_layers = len(params) // 12
+    inputs = [x0] + list(saved[8 * n_layers:])
+    dX = dx_out
+    grads: List[Tensor] = [dX] * (12 * n_layers)
+    dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
+    dXsum = None  # ... and its column sums (= the bias gradient of this layer's second MLP Linear) from the same kernel
+    for li in reversed(range(n_layers)):
+        h1, qkv, att, lse, x_mid, h2, u, g = saved[8 * li:8 * li + 8]
+        x = inputs[li]
+        Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+        if dXb is None:
+            dXb = ops.convert(dX, bf)
+        # x_out = x_mid + g W2^T + b2;  g = act(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
+        du = dgrad(dXb, W2, bf, _ACT_GRAD[act], u)
+        if dXsum is None:
+            dW2, db2 = wgrad(dXb, g, bias=True)
+        else:
+            dW2, db2 = wgrad(dXb, g), dXsum
+        # u = h2 W1^T + b1
+        dh2 = dgrad(du, W1, f32)
+        dW1, db1 = wgrad(du, h2, bias=True)
+        dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True)
+        # x_mid = x + att Wo^T + bo
+        datt = dgrad(dxmb, Wo, bf)
+        dWo = wgrad(dxmb, att)
+        dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal, key_mask)
+        # qkv = h1 Wqkv^T + bqkv
+        dh1 = dgrad(dqkv, Wqkv, f32)
+        dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
+        dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
+        grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
+    return [dX] + grads
+
+
+def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask):
+    return [torch.empty_like(x0)] + [torch.empty_like(p) for p in params]
+
+
+from ._custom_op import define as _define  # noqa: E402
+
+_STACK_SCALARS = "int n_head, int B, int S, bool causal, int act, float[] eps1, float[] eps2, Tensor? key_mask"
+stack_fwd_op = _define("encoder_stack_fwd", f"(Tensor x0, Tensor[] params, {_STACK_SCALARS}) -> Tensor[]", _stack_fwd_impl, _stack_fwd_fake)
+stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}) -> Tensor[]",
+                       _stack_bwd_impl, _stack_bwd_fake)
 
 
 class EncoderStackFn(torch.autograd.Function):
     """x0 fp32 [B*S, d] -> x_L.  Per layer (tensors kept for backward in brackets):
-        [x] -LN-> [h1] -GEMM-> [qkv] -attention-> [att, lse] -GEMM(+x)-> [x_mid] -LN-> [h2] -GEMM-> [u] -act-> [g] -GEMM(+x_mid)-> x'"""
+        [x] -LN-> [h1] -GEMM-> [qkv] -attention-> [att, lse] -GEMM(+x)-> [x_mid] -LN-> [h2] -GEMM-> [u] -act-> [g] -GEMM(+x_mid)-> x'
+    Forward and backward are ONE dispatcher op each (torch.ops.mmamd_train.encoder_stack_fwd / _bwd, multimodal_amd/_custom_op.py)."""
 
     @staticmethod
     def forward(ctx, x0: Tensor, cfg: StackConfig, *params: Tensor):
-        B, S, H = cfg.B, cfg.S, cfg.n_head
-        saved: List[Tensor] = []
         x = x0.detach()
         x = x if x.is_contiguous() else x.contiguous()
+        canon: List[Tensor] = []
         for li in range(cfg.n_layers):
-            Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]])
-            if cfg.keep_hidden:
-                cfg.hidden.append(x)
-            h1 = ops.layernorm(x, g1, be1, cfg.eps1[li], out_dtype=bf)
-            qkv = ops.gemm_bf16(h1, ops.convert(Wqkv, bf), bqkv)
-            att, lse = ops.attention_fwd_train(qkv, B, S, H, cfg.causal, cfg.key_mask)
-            x_mid = ops.gemm_bf16(att, ops.convert(Wo, bf), bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
-            h2 = ops.layernorm(x_mid, g2, be2, cfg.eps2[li], out_dtype=bf)
-            u, g = ops.gemm_bf16_dual(h2, ops.convert(W1, bf), b1, cfg.act)  # pre-activation (kept for the backward) + activation
-            x_out = ops.gemm_bf16(g, ops.convert(W2, bf), b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
-            saved += [x, h1, qkv, att, lse, x_mid, h2, u, g]
-            x = x_out
+            canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
+        outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask)
         if cfg.keep_hidden:
-            cfg.hidden.append(x)
-        ctx.save_for_backward(*saved, *params)
+            cfg.hidden.extend([x] + list(outs[1 + 8 * cfg.n_layers:]) + [outs[0]])
+        ctx.save_for_backward(x, *outs[1:], *params)
         ctx.cfg, ctx.nparam = cfg, len(params)
-        return x
+        return outs[0]
 
     @staticmethod
     def backward(ctx, dx_out: Tensor):
         cfg, nparam = ctx.cfg, ctx.nparam
         tensors = ctx.saved_tensors
-        saved, params = tensors[:len(tensors) - nparam], tensors[len(tensors) - nparam:]
-        B, S, H = cfg.B, cfg.S, cfg.n_head
+        x0, saved, params = tensors[0], tensors[1:len(tensors) - nparam], tensors[len(tensors) - nparam:]
         dX = dx_out.detach()
         dX = dX if dX.is_contiguous() else dX.contiguous()
+        canon: List[Tensor] = []
+        for li in range(cfg.n_layers):
+            canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
+        outs = stack_bwd_op(dX, x0, list(saved), canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask)
         grads: List[Optional[Tensor]] = [None] * nparam
-        dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
-        dXsum = None  # ... and its column sums (= the bias gradient of this layer's second MLP Linear) from the same kernel
-        for li in reversed(range(cfg.n_layers)):
-            x, h1, qkv, att, lse, x_mid, h2, u, g = saved[9 * li:9 * li + 9]
-            Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]])
-            if dXb is None:
-                dXb = ops.convert(dX, bf)
-            # x_out = x_mid + g W2^T + b2;  g = act(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
-            du = dgrad(dXb, W2, bf, _ACT_GRAD[cfg.act], u)
-            if dXsum is None:
-                dW2, db2 = wgrad(dXb, g, bias=True)
-            else:
-                dW2, db2 = wgrad(dXb, g), dXsum
-            # u = h2 W1^T + b1
-            dh2 = dgrad(du, W1, f32)
-            dW1, db1 = wgrad(du, h2, bias=True)
-            dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, cfg.eps2[li], add=dX, want_bf16=True, want_colsum=True)
-            # x_mid = x + att Wo^T + bo
-            datt = dgrad(dxmb, Wo, bf)
-            dWo = wgrad(dxmb, att)
-            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, cfg.causal, cfg.key_mask)
-            # qkv = h1 Wqkv^T + bqkv
-            dh1 = dgrad(dqkv, Wqkv, f32)
-            dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
-            dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, cfg.eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
-            grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical([dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2])
-        return (dX, None, *grads)
+        for li in range(cfg.n_layers):
+            grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical(list(outs[1 + 12 * li:13 + 12 * li]))
+        return (outs[0], None, *grads)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -226,17 +284,22 @@ class SmallLinearF32Fn(torch.autograd.Function):
         return dx, dW, db, None
 
 
+l2norm_fwd_op = _define("l2_normalize_fwd", "(Tensor x) -> Tensor", lambda x: ops.l2_normalize(x), lambda x: torch.empty_like(x))
+l2norm_bwd_op = _define("l2_normalize_bwd", "(Tensor x, Tensor dy) -> Tensor", lambda x, dy: ops.l2_normalize_bwd(x, dy),
+                        lambda x, dy: torch.empty_like(x))
+
+
 class L2NormalizeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         xc = c32(x)
         ctx.save_for_backward(xc)
-        return ops.l2_normalize(xc)
+        return l2norm_fwd_op(xc)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return ops.l2_normalize_bwd(x, dy.contiguous())
+        return l2norm_bwd_op(x, dy.contiguous())
 
 
 def grad_requested(module, *inputs) -> bool:

@@ -1,0 +1,56 @@
+"""torch.compile(fullgraph=True) traces the CLIP TRAINING step (both towers, contrastive loss, backward): every autograd node of the path
+is a torch.autograd.Function whose forward and backward bodies are single dispatcher ops (torch.ops.mmamd_train.*,
+multimodal_amd/_custom_op.py) with fake implementations, so dynamo + AOT autograd meet no ctypes call and no graph break.  Runs on meta
+tensors: shapes only, no GPU (the numerical twin is tests/test_gpu_compile_train.py)."""
+import pytest
+import torch
+
+
+def _small_clip():
+    from multimodal_amd.models.clip import CLIPTextEncoder, CLIPViTEncoder
+    from multimodal_amd.models.clip.model import CLIP
+    from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
+
+    vit = CLIPViTEncoder(embedding_dim=64, heads=2, layers=2, patch_size=16, image_size=32, width=128)
+    txt = CLIPTextEncoder(embedding_dim=64, context_length=8, vocab_size=64, width=128, heads=2, layers=2)
+    return CLIP(vit, txt).train(), ContrastiveLossWithTemperature()
+
+
+@pytest.mark.parametrize("backend", ["eager", "aot_eager"])
+def test_training_step_traces_without_graph_breaks(backend):
+    from multimodal_amd import _torch_ops
+
+    if not _torch_ops.try_load():
+        pytest.skip("libmmamd_torch.so is not built")
+    torch._dynamo.reset()
+    with torch.device("meta"):
+        model, loss_fn = _small_clip()
+        images = torch.zeros(4, 3, 32, 32)
+        ids = torch.zeros(4, 8, dtype=torch.long)
+
+    def step(images, ids):
+        out = model(images, ids)
+        return loss_fn(out.embeddings_a, out.embeddings_b)
+
+    loss = torch.compile(step, backend=backend, fullgraph=True)(images, ids)
+    assert loss.shape == () and loss.requires_grad
+    loss.backward()
+    missing = [n for n, p in list(model.named_parameters()) + list(loss_fn.named_parameters()) if p.grad is None or p.grad.shape != p.shape]
+    assert not missing, missing
+
+
+def test_training_ops_are_registered_with_fake_implementations():
+    import multimodal_amd.models.clip._train  # noqa: F401  (registers the ops)
+    import multimodal_amd.modules.losses.contrastive_loss_with_temperature  # noqa: F401
+
+    names = ["encoder_stack_fwd", "encoder_stack_bwd", "l2_normalize_fwd", "l2_normalize_bwd", "clip_vision_embed_fwd", "clip_vision_embed_bwd",
+             "clip_text_embed_fwd", "clip_text_embed_bwd", "clip_pooled_head_fwd", "clip_pooled_head_bwd", "contrastive_fwd", "contrastive_bwd"]
+    for n in names:
+        assert hasattr(torch.ops.mmamd_train, n), n
+    x = torch.zeros(6, 16, device="meta")
+    assert torch.ops.mmamd_train.l2_normalize_fwd(x).shape == (6, 16)
+    # host tensors are refused by the one implementation there is (no CPU fallback)
+    from multimodal_amd import ops
+
+    with pytest.raises(ops.MmamdError):
+        torch.ops.mmamd_train.l2_normalize_fwd(torch.zeros(6, 16))

@@ -1,0 +1,95 @@
+"""The compiled CLIP training step (torch.compile(fullgraph=True): dynamo + AOT autograd over the torch.ops.mmamd_train.* ops) against the
+eager one: same kernels in the same order, so loss and every parameter gradient are BIT-IDENTICAL.  Needs an MI355X."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    from multimodal_amd import build
+
+    build.build()
+
+
+def _models():
+    from multimodal_amd.models.clip import CLIPTextEncoder, CLIPViTEncoder
+    from multimodal_amd.models.clip.model import CLIP
+    from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
+
+    torch.manual_seed(0)
+    vit = CLIPViTEncoder(embedding_dim=128, heads=2, layers=2, patch_size=16, image_size=64, width=128)
+    txt = CLIPTextEncoder(embedding_dim=128, context_length=16, vocab_size=512, width=128, heads=2, layers=2)
+    return CLIP(vit, txt).cuda().train(), ContrastiveLossWithTemperature().cuda()
+
+
+@pytest.mark.parametrize("backend", ["aot_eager", "inductor"])
+def test_compiled_training_step_equals_eager_bit_for_bit(backend):
+    torch._dynamo.reset()
+    model, loss_fn = _models()
+    model_c, loss_c = copy.deepcopy(model), copy.deepcopy(loss_fn)
+    g = torch.Generator().manual_seed(1)
+    images = torch.randn(8, 3, 64, 64, generator=g).cuda()
+    ids = torch.randint(1, 500, (8, 16), generator=g)
+    ids[:, -1] = 511  # EOT = the largest id
+    ids = ids.cuda()
+
+    def make_step(m, l):
+        def step(images, ids):
+            out = m(images, ids)
+            return l(out.embeddings_a, out.embeddings_b)
+        return step
+
+    loss_e = make_step(model, loss_fn)(images, ids)
+    loss_e.backward()
+    cstep = torch.compile(make_step(model_c, loss_c), backend=backend, fullgraph=True)
+    for it in range(2):  # the second call replays the compiled graph (no retrace); gradients accumulate like eager's would
+        for p in list(model_c.parameters()) + list(loss_c.parameters()):
+            p.grad = None
+        loss_k = cstep(images, ids)
+        loss_k.backward()
+        assert torch.equal(loss_k.detach(), loss_e.detach()), (it, float(loss_k), float(loss_e))
+        for (n, p), (_, q) in zip(list(model.named_parameters()) + list(loss_fn.named_parameters()),
+                                  list(model_c.named_parameters()) + list(loss_c.named_parameters())):
+            assert q.grad is not None, n
+            if n.endswith("token_embedding.weight"):  # scatter-add of colliding token rows: fp32 atomics, order not fixed
+                torch.testing.assert_close(q.grad, p.grad, rtol=1e-5, atol=1e-6)
+            else:
+                assert torch.equal(p.grad, q.grad), (it, n)
+
+
+def test_compiled_step_trains():
+    """three SGD steps through the compiled step: the loss falls and equals the eager run's step by step"""
+    torch._dynamo.reset()
+    model, loss_fn = _models()
+    model_c, loss_c = copy.deepcopy(model), copy.deepcopy(loss_fn)
+    g = torch.Generator().manual_seed(2)
+    images = torch.randn(8, 3, 64, 64, generator=g).cuda()
+    ids = torch.randint(1, 500, (8, 16), generator=g)
+    ids[:, -1] = 511
+    ids = ids.cuda()
+    runs = []
+    for m, l, compiled in ((model, loss_fn, False), (model_c, loss_c, True)):
+        opt = torch.optim.SGD(list(m.parameters()) + list(l.parameters()), lr=1e-2)
+
+        def step(images, ids, m=m, l=l):
+            out = m(images, ids)
+            return l(out.embeddings_a, out.embeddings_b)
+
+        fn = torch.compile(step, backend="aot_eager", fullgraph=True) if compiled else step
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = fn(images, ids)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        runs.append(losses)
+    # the first step is bit-identical; later ones see the token-embedding update, whose fp32 atomics are order-dependent — a last-bit
+    # difference there flips bf16 roundings of the re-packed weights (two eager runs differ the same way)
+    assert runs[0][0] == runs[1][0], runs
+    assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(runs[0], runs[1])), runs
+    assert runs[0][-1] < runs[0][0]
