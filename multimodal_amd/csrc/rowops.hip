@@ -12,10 +12,11 @@ extern int g_ln_nt_policy;  // attention.hip (mmamd_debug_set_attn_variant(3100 
 // LayerNorm reads its fp32 input NON-TEMPORALLY when the tensor is larger than what the 256 MiB MALL keeps next to the bf16 output: the input rows then
 // stream through without evicting the output rows the next GEMM is about to read.  Measured per step, same-box alternating A/B
 // (profiles/r03_cache_policy_ab.txt): ViT-B/16 B = 256 (148 + 38 MiB) 13.66 -> 13.43 ms, ViT-L/14 (257 MiB) -1.0 %, FLAVA (148 MiB) -0.8 %;
-// ViT-B/32 (37 MiB: the input is still cached from the GEMM that wrote it) +0.7 %, CoCa B = 128 (128 MiB) +0.3 %.
+// ViT-B/32 (37 MiB: the input is still cached from the GEMM that wrote it) +0.7 %, CoCa B = 128 (128 MiB) +0.3 % with one row per wave and -0.4 % with
+// the two-rows-per-wave kernel these inputs now take (layernorm_grouped_rows_kernel) — hence the 128 MiB threshold.
 static bool ln_nontemporal(size_t x_bytes) {
   if (g_ln_nt_policy != 0) return g_ln_nt_policy == 2;
-  return x_bytes >= ((size_t)144 << 20);
+  return x_bytes >= ((size_t)128 << 20);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -195,6 +196,66 @@ __global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const LnGrou
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
       store4(yr + 4 * c, o);
+    }
+  }
+}
+
+// The grouped LayerNorm for LARGE inputs (non-temporal loads, see ln_nontemporal): RPW rows per wave, the loads of all of them in flight before
+// the first reduction (twice the bytes in flight per wave of the one-row kernel).  Same arithmetic per row: bit-identical results.  Same-box
+// alternating A/B of the headline step (profiles/r03_cache_policy_ab.txt): 2 rows per wave -0.05 ... -0.12 ms, 3 and 4 rows no better than 1.
+template <int MAXV, int RPW>
+__global__ __launch_bounds__(256) void layernorm_grouped_rows_kernel(const LnGroupArgs a) {
+  const int lane = threadIdx.x & 63;
+  int blk = blockIdx.x, pi = 0;
+  const int b0 = (a.p[0].rows + 4 * RPW - 1) / (4 * RPW);
+  if (blk >= b0) { blk -= b0; pi = 1; }
+  const float* __restrict__ x = a.p[pi].x;
+  const float* __restrict__ gamma = a.p[pi].gamma;
+  const float* __restrict__ beta = a.p[pi].beta;
+  bf16* __restrict__ y = a.p[pi].y;
+  const int rows = a.p[pi].rows, d = a.p[pi].d;
+  const float eps = a.p[pi].eps;
+  const int row0 = blk * (4 * RPW) + (threadIdx.x >> 6) * RPW;
+  if (row0 >= rows) return;
+  const int d4 = d >> 2;
+  f32x4 v[RPW][MAXV];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      v[r][i] = (row0 + r < rows && c < d4) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (size_t)(row0 + r) * d + 4 * c)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    if (row0 + r >= rows) break;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (lane + 64 * i < d4) s += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (lane + 64 * i < d4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = v[r][i][j] - mean;
+          q += t * t;
+        }
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    bf16* yr = y + (size_t)(row0 + r) * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d4) {
+        const f32x4 g = load4(gamma + 4 * c), b = load4(beta + 4 * c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[r][i][j] - mean) * rstd * g[j] + b[j];
+        store4(yr + 4 * c, o);
+      }
     }
   }
 }
@@ -896,6 +957,17 @@ extern "C" int mmamd_add_layernorm_grouped(const mmamd_ln_problem* probs, int np
   size_t xbytes = 0;
   for (int i = 0; i < a.nprob; ++i) xbytes += (size_t)a.p[i].rows * a.p[i].d * 4;
   const bool ntp = ln_nontemporal(xbytes);
+  bool all_y = true;
+  for (int i = 0; i < a.nprob; ++i) all_y = all_y && a.p[i].y != nullptr;
+  if (ntp && !has_delta && all_y) {  // large inputs: two rows per wave
+    int tot2 = 0;
+    for (int i = 0; i < a.nprob; ++i) tot2 += (a.p[i].rows + 7) / 8;
+    if (dmax <= 512) hipLaunchKernelGGL((layernorm_grouped_rows_kernel<2, 2>), dim3(tot2), dim3(256), 0, st, a);
+    else if (dmax <= 768) hipLaunchKernelGGL((layernorm_grouped_rows_kernel<3, 2>), dim3(tot2), dim3(256), 0, st, a);
+    else if (dmax <= 1024) hipLaunchKernelGGL((layernorm_grouped_rows_kernel<4, 2>), dim3(tot2), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((layernorm_grouped_rows_kernel<8, 2>), dim3(tot2), dim3(256), 0, st, a);
+    return launch_status("add_layernorm_grouped");
+  }
 #define LN_LAUNCH(MV)                                                                                                  \
   do {                                                                                                                 \
     if (has_delta) hipLaunchKernelGGL((add_layernorm_grouped_kernel<MV, true>), dim3(total), dim3(256), 0, st, a);     \
@@ -918,7 +990,14 @@ extern "C" int mmamd_layernorm(const void* x, int x_dtype, const float* gamma, c
                   MMAMD_E_ALIGN, "layernorm: pointers must be 16-byte aligned");
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_BF16) return launch_layernorm<float, bf16>(x, gamma, beta, y, rows, d, eps, st);
+  if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_BF16) {
+    if (d <= 2048 && (d * 2) % 16 == 0 && ln_nontemporal((size_t)rows * d * 4)) {  // large input: the two-rows-per-wave kernel (same arithmetic)
+      mmamd_ln_problem q;
+      q.x = const_cast<float*>(reinterpret_cast<const float*>(x)); q.delta = nullptr; q.gamma = gamma; q.beta = beta; q.y = y; q.rows = rows; q.d = d; q.eps = eps;
+      return mmamd_add_layernorm_grouped(&q, 1, stream);
+    }
+    return launch_layernorm<float, bf16>(x, gamma, beta, y, rows, d, eps, st);
+  }
   if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_F32) return launch_layernorm<float, float>(x, gamma, beta, y, rows, d, eps, st);
   if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_BF16) return launch_layernorm<bf16, bf16>(x, gamma, beta, y, rows, d, eps, st);
   if (x_dtype == MMAMD_BF16 && y_dtype == MMAMD_F32) return launch_layernorm<bf16, float>(x, gamma, beta, y, rows, d, eps, st);
