@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // out[c] = sum_g part[g][c]  (second stage of every column reduction).  Block = 32 columns (8 threads x 4 columns, 16-byte loads) x 32
 // partial-row groups, the loop unrolled by four so each thread keeps 4 independent loads in flight: the first form (thread per
 // column, 8 groups) was latency-bound — 22 us average over the 596 calls of a CLIP training step, 4 % of the step.
-__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out) {
+// (out1 / out2 / seg: the result is split into segments of `seg` columns that go to up to three separate arrays — the LayerNorm backward's
+// dgamma | dbeta | column sums of dx; out1 == NULL: one array)
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out,
+                                                            float* __restrict__ out1 = nullptr, float* __restrict__ out2 = nullptr, int seg = 0) {
   __shared__ f32x4 red[32][8];
   const int cq = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const int c = blockIdx.x * 32 + cq * 4;
@@ -139,7 +142,14 @@ __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restr
   }
   if (grp == 0)
     for (int j = 0; j < 4; ++j)
-      if (c + j < n) out[c + j] = red[0][cq][j];
+      if (c + j < n) {
+        if (out1 == nullptr) {
+          out[c + j] = red[0][cq][j];
+        } else {
+          const int which = (c + j) / seg, cc = (c + j) - which * seg;
+          (which == 0 ? out : which == 1 ? out1 : out2)[cc] = red[0][cq][j];
+        }
+      }
 }
 
 // column sums of x [rows, n] (bias gradients): stage 1.  Workgroup g owns rows [g*rpb, (g+1)*rpb); a thread owns one 16-byte column
@@ -354,11 +364,9 @@ extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const voi
   else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "layernorm_bwd: bad dy dtype");
 #undef LNB
   // part layout [G][ns][d] = G rows of width ns*d: dgamma | dbeta | (column sums of dx)
-  float* res = ws + (size_t)G * ns * d;
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((ns * d + 31) / 32), dim3(256), 0, st, ws, G, ns * d, res);
-  hipMemcpyAsync(dgamma, res, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(dbeta, res + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
-  if (cs) hipMemcpyAsync(dx_colsum, res + 2 * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st);
+  // (the three results go straight to their arrays: the three 3 KB device-to-device copies this used to end with were 150 of the 182
+  //  copies of a CLIP training step, 0.7 ms of serialised 5 us operations)
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((ns * d + 31) / 32), dim3(256), 0, st, ws, G, ns * d, dgamma, dbeta, dx_colsum, d);
   return launch_status("layernorm_bwd");
 }
 
