@@ -158,8 +158,12 @@ def _contrastive_bwd_impl(g3: Tensor, a: Tensor, b: Tensor, buf: Tensor, scale32
     elif mode == 1:
         _, _, g_all, _ = ops.contrastive_bwd(a, b, a_all, b_all, 2 * E, scale32, logits_a, logits_b, B * rank, row_mask, smoothing,
                                              red_code, g3, None, (0, world * B))
-        add = torch.empty((B, 2 * E), dtype=torch.float32, device=a.device)
-        torch.distributed.reduce_scatter_tensor(add, g_all)
+        if torch.distributed.get_backend() == "nccl":  # RCCL
+            add = torch.empty((B, 2 * E), dtype=torch.float32, device=a.device)
+            torch.distributed.reduce_scatter_tensor(add, g_all)
+        else:  # gloo has no reduce-scatter (tests: two processes on one device): all-reduce, keep the own block
+            torch.distributed.all_reduce(g_all)
+            add = g_all[B * rank:B * (rank + 1)].contiguous()
     elif mode == 2:
         all_rows, add_all = (B * rank, B), True  # own block only (world == 1: that is everything), no communication
     ga, gb, _, gs = ops.contrastive_bwd(a, b, a_all, b_all, 2 * E, scale32, logits_a, logits_b, B * rank, row_mask, smoothing,
