@@ -116,9 +116,12 @@ def pin_rank_to_local_cpus(local_rank: int, world: int, bdf=None):
                 near = [c for c in _parse_cpulist(open(path).read()) if c in set(avail)]
                 if near:
                     local, where = near, f"numa-local to {bdf}"
-        per = max(1, len(local) // max(world, 1))
-        lo = (local_rank * per) % len(local)
-        mine = local[lo:lo + per] or local
+        per = len(local) // max(world, 1)
+        if per < 4:  # too few cores for a private slice (the launch thread, the HIP runtime's and RCCL's helpers need several): share the list
+            mine, where = local, where + ", shared"
+        else:
+            lo = (local_rank * per) % len(local)
+            mine = local[lo:lo + per] or local
         os.sched_setaffinity(0, mine)
         return {"cpus": f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine)),
                 "count": len(mine), "policy": where}

@@ -112,7 +112,11 @@ def test_cpu_pinning_helper_splits_the_visible_cpus():
     try:
         got = b.pin_rank_to_local_cpus(1, 2)
         assert got["count"] >= 1 and set(os.sched_getaffinity(0)) <= set(before)
-        if len(before) >= 2:
+        if len(before) >= 8:
             assert len(os.sched_getaffinity(0)) == len(before) // 2
+        os.sched_setaffinity(0, before)
+        if len(before) < 32:  # fewer than 4 cores per rank at W = 8: no private slices, the ranks share the (NUMA-local) list
+            got8 = b.pin_rank_to_local_cpus(3, 8)
+            assert "shared" in got8["policy"] and set(os.sched_getaffinity(0)) == set(before)
     finally:
         os.sched_setaffinity(0, before)
