@@ -4,7 +4,7 @@ ENQUEUE a step (is the Python thread the limit?), and a HIP-graph replay of the 
 
     python tools/step_ab.py --arms ring,r02attn [--rounds 3] [--steps 20]
 arms (joined with +): base, r02attn (register-staged attention kernel), delta_ln (bf16 delta GEMMs + fused add+LayerNorm), streams,
-ln_cached (LayerNorm input loads never non-temporal)"""
+ln_cached (LayerNorm input loads never non-temporal), stagger<percent>"""
 import argparse
 import json
 import sys
@@ -45,6 +45,7 @@ def main():
     def set_arm(name):
         L.mmamd_debug_set_attn_variant(0)
         L.mmamd_debug_set_attn_variant(3100)
+        L.mmamd_debug_set_gemm_stagger(60)
         set_schedule(residual="epilogue", two_tower="auto")
         for part in name.split("+"):
             if part in ("ring", "base"):
@@ -55,6 +56,8 @@ def main():
                 set_schedule(residual="delta_ln")
             elif part == "streams":
                 set_schedule(two_tower="streams")
+            elif part.startswith("stagger"):  # start-up stagger of the persistent GEMMs, per cent of a tile time (default 60)
+                L.mmamd_debug_set_gemm_stagger(int(part[7:]))
             elif part == "ln_cached":  # LayerNorm input loads never non-temporal (the r02 behaviour)
                 L.mmamd_debug_set_attn_variant(3101)
             else:
