@@ -1,4 +1,4 @@
-// attention_ring.hip — multi-head self-attention forward for short sequences (S <= 224, head dim 64) built around
+// attention_ring.hip — multi-head self-attention forward for short sequences (S <= 208, head dim 64) built around
 // LDS-DMA staging: a dedicated LOADER wave streams K / V of the coming (batch, head) items into a ring of LDS slots
 // with `global_load_lds_dwordx4` (no VGPR round trip, no ds_write, no prefetch registers) while the other seven waves
 // of the workgroup compute out of slots that have landed.  One workgroup (8 waves) per CU, persistent.

@@ -1,4 +1,4 @@
-"""LDS-DMA ring attention kernel (csrc/attention_ring.hip, the default of mmamd_attention_fwd for S <= 224) against float64 math, against
+"""LDS-DMA ring attention kernel (csrc/attention_ring.hip, the default of mmamd_attention_fwd for S <= 208) against float64 math, against
 the r02 register-staged kernel it replaces (bit for bit on non-causal problems: same arithmetic in the same order), in grouped
 two-problem launches, with many more items than workgroups (ring wrap-around) and with the log-sum-exp output.  Needs an MI355X."""
 import numpy as np
