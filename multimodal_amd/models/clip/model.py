@@ -23,6 +23,35 @@ from ._transformer import run_two_stacks, two_stacks_groupable
 _torch_ops.try_load()
 _SIDE_STREAMS = {}
 
+# torch.compile of an INFERENCE forward: the whole pair forward is one dispatcher op whose implementation is the eager forward (grouped two-tower
+# launches, fused stem, packed output), so a compiled model runs the same schedule at the same speed as the eager one (the per-op dispatcher path
+# of csrc/torch_ops.cpp runs the towers one after the other: 14.7 vs 13.3 ms at B = 256, tools/compiled_vs_eager.py).  The op finds its model
+# through a weak registry keyed by an integer the module carries; the parameters ride along as inputs so the graph depends on them.
+import itertools
+import weakref
+
+from ..._custom_op import define as _define
+
+_PAIR_MODELS = weakref.WeakValueDictionary()
+_PAIR_KEYS = itertools.count(1)
+
+
+def _pair_fwd_impl(features_a, features_b, params, key: int, E: int):
+    model = _PAIR_MODELS.get(key)
+    if model is None:
+        raise ops.MmamdError("clip_pair_fwd: the model this compiled graph was traced from is gone")
+    with torch.no_grad():
+        out = model._forward(model.encoder_a, features_a, features_b)
+    a, b = out.embeddings_a, out.embeddings_b
+    base = a._base if a._base is not None else None
+    if base is not None and base.shape == (a.shape[0], 2 * E) and b._base is base:
+        return base  # the packed [B, 2E] block both outputs are views of
+    return torch.cat([a, b], 1)
+
+
+pair_fwd_op = _define("clip_pair_fwd", "(Tensor features_a, Tensor features_b, Tensor[] params, int key, int E) -> Tensor", _pair_fwd_impl,
+                      lambda fa, fb, params, key, E: params[0].new_empty((fa.shape[0], 2 * E), dtype=torch.float32))
+
 
 class CLIPOutput(NamedTuple):
     """L2-normalised embeddings of the two modalities (reference: models/clip/model.py:19-21).
@@ -60,6 +89,16 @@ class CLIP(PackedModeMixin, nn.Module):
         torch._C._log_api_usage_once(f"torchmultimodal.{self.__class__.__name__}")
         self.encoder_a = encoder_a
         self.encoder_b = encoder_b
+        self._register_pair()
+
+    @torch.jit.unused
+    def _register_pair(self) -> None:
+        self._pair_key = next(_PAIR_KEYS)
+        _PAIR_MODELS[self._pair_key] = self
+
+    def __setstate__(self, state):  # (copy.deepcopy / unpickling: the copy is another model -> its own key)
+        super().__setstate__(state)
+        self._register_pair()
 
     def forward(self, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
         if torch.jit.is_scripting():  # dispatcher ops (csrc/torch_ops.cpp); one stream, inference only
@@ -73,6 +112,12 @@ class CLIP(PackedModeMixin, nn.Module):
     @torch.jit.unused
     def _forward_host(self, features_a: torch.Tensor, features_b: torch.Tensor) -> CLIPOutput:
         if torch.compiler.is_compiling() and not _train.wants_grad(self, features_a, features_b):
+            if (type(self.encoder_a) is CLIPViTEncoder and type(self.encoder_b) is CLIPTextEncoder and self.encoder_a.projection.dtype == torch.float32
+                    and self.encoder_b.projection.weight.dtype == torch.float32
+                    and self.encoder_a.projection.shape[1] == self.encoder_b.projection.weight.shape[0]):
+                E = self.encoder_b.projection.weight.shape[0]
+                packed = pair_fwd_op(features_a, features_b, list(self.parameters()), self._pair_key, E)
+                return CLIPOutput(embeddings_a=packed[:, :E], embeddings_b=packed[:, E:])
             a = self.encoder_a(features_a)
             b = self.encoder_b(features_b)
             return CLIPOutput(embeddings_a=torch.ops.mmamd.l2_normalize(a.contiguous(), 1e-12),

@@ -54,3 +54,33 @@ def test_training_ops_are_registered_with_fake_implementations():
 
     with pytest.raises(ops.MmamdError):
         torch.ops.mmamd_train.l2_normalize_fwd(torch.zeros(6, 16))
+
+
+def test_compiled_inference_is_one_pair_op_with_the_eager_output_layout():
+    """torch.compile of the CLIP pair in inference: ONE dispatcher op (clip_pair_fwd) whose implementation is the eager forward, so the compiled
+    model runs the grouped two-tower schedule; the outputs are the two halves of one packed [B, 2E] block, as in eager mode; a deep copy of the
+    model registers under its own key."""
+    import copy
+
+    from multimodal_amd import _torch_ops
+
+    if not _torch_ops.try_load():
+        pytest.skip("libmmamd_torch.so is not built")
+    torch._dynamo.reset()
+    with torch.device("meta"):
+        model, _ = _small_clip()
+        model = model.eval()
+        images = torch.zeros(4, 3, 32, 32)
+        ids = torch.zeros(4, 8, dtype=torch.long)
+    seen = []
+
+    def backend(gm, example_inputs):
+        seen.extend(str(n.target) for n in gm.graph.nodes if n.op == "call_function")
+        return gm.forward
+
+    with torch.no_grad():
+        out = torch.compile(model, backend=backend, fullgraph=True)(images, ids)
+    assert any("clip_pair_fwd" in t for t in seen), seen
+    assert not any("mmamd.gemm_bf16" in t or "mmamd.attn_fwd" in t for t in seen), seen
+    assert out.embeddings_a.shape == (4, 64) and out.embeddings_a.stride() == (128, 1) and out.embeddings_b.storage_offset() == 64
+    assert copy.deepcopy(model)._pair_key != model._pair_key
