@@ -858,7 +858,7 @@ static int dispatch_attn_x(const AttnX& p, int B, hipStream_t st) {
 //   CU, built with 2-byte scattered stores) and ran the vision shape in 317 + 415 us against the forward's 108.
 // ---------------------------------------------------------------------------------------------------------
 template <int NKT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+__global__ __launch_bounds__(512, 2) void attention_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                                const bf16* __restrict__ dO, const float* __restrict__ lse,
                                                                bf16* __restrict__ dqkv, int S, int H, float scale,
                                                                const uint8_t* __restrict__ key_mask) {
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
   const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int r = tid >> 3; r < SP; r += 32) {
+  for (int r = tid >> 3; r < SP; r += (int)(blockDim.x >> 3)) {
     const int c = tid & 7;
     bf16x8 kv, vv;
 #pragma unroll
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
   const float c2 = scale * 1.4426950408889634f;
   const int nqt = (S + 31) >> 5;
   const bf16* ktr = Ks + tr_off(lane, kKStride);  // K^T fragments by transpose reads of the row-major K image
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += (int)(blockDim.x >> 6)) {
     const int q = qt * 32 + l31;
     const int qc = q < S ? q : S - 1;
     bf16x8 qf[4], dof[4];
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16* __res
 }
 
 template <int NKT, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+__global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                                 const bf16* __restrict__ dO, const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, int S, int H, float scale,
                                                                 const uint8_t* __restrict__ key_mask) {
@@ -995,9 +995,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
   const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int k = tid; k < SP; k += 256) { L2s[k] = INFINITY; Dqs[k] = 0.f; }
+  for (int k = tid; k < SP; k += (int)blockDim.x) { L2s[k] = INFINITY; Dqs[k] = 0.f; }
   __syncthreads();
-  for (int r = tid >> 3; r < SP; r += 32) {
+  for (int r = tid >> 3; r < SP; r += (int)(blockDim.x >> 3)) {
     const int c = tid & 7;
     bf16x8 qv, dv, ov;
 #pragma unroll
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16* __re
   const int nkt = (S + 31) >> 5;
   const bf16* qtr = Qs + tr_off(lane, kKStride);   // Q^T / dO^T fragments by transpose reads of the row-major images
   const bf16* dotr = dOs + tr_off(lane, kKStride);
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += (int)(blockDim.x >> 6)) {
     const int key = kt * 32 + l31;
     const int kc = key < S ? key : S - 1;
     const bool key_live = key < S && (key_mask == nullptr || key_mask[(size_t)b * S + kc] != 0);  // a masked key has P = 0: dK = dV = 0
@@ -1111,6 +1111,9 @@ template <int NKT>
 static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
                            float scale, hipStream_t st, const uint8_t* key_mask) {
   constexpr int SP = NKT * 32;
+  // the kernels take any multiple of 64 threads (tiles are dealt round-robin to the waves): 8 waves per workgroup from 5 tiles up (ViT-B/16: 7 tiles in
+  // one round, 16 waves per CU instead of 8: 365-391 us vs 398-405 us for both kernels at B = 256), 4 below (text S = 77: 67 vs 71 us); same results
+  constexpr int kThreads = NKT >= 5 ? 512 : 256;
   constexpr int smem1 = 2 * SP * kKStride * 2;               // K, V rows (two workgroups per CU up to S = 256)
   constexpr int smem2 = 2 * SP * kKStride * 2 + 2 * SP * 4;  // Q, dO rows + lse / Dq
   auto k1c = attention_bwd_dq_kernel<NKT, true>;
@@ -1123,11 +1126,11 @@ static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const
   if (int rc_attr = opt_in_lds((const void*)k2c, smem2, m2c)) return rc_attr;
   if (int rc_attr = opt_in_lds((const void*)k2n, smem2, m2n)) return rc_attr;
   if (causal) {
-    hipLaunchKernelGGL(k1c, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
-    hipLaunchKernelGGL(k2c, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
+    hipLaunchKernelGGL(k1c, dim3(B * H), dim3(kThreads), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
+    hipLaunchKernelGGL(k2c, dim3(B * H), dim3(kThreads), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
   } else {
-    hipLaunchKernelGGL(k1n, dim3(B * H), dim3(256), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
-    hipLaunchKernelGGL(k2n, dim3(B * H), dim3(256), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
+    hipLaunchKernelGGL(k1n, dim3(B * H), dim3(kThreads), smem1, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
+    hipLaunchKernelGGL(k2n, dim3(B * H), dim3(kThreads), smem2, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, scale, key_mask);
   }
   return launch_status("attention_bwd");
 }
