@@ -27,7 +27,7 @@ Extra objects on the JSON line:
   cpu_baseline  rank 0, N=1 only: the reference's CPU path on this box's host cores, on a bounded sample (B=32, 1 warm-up +
                 3 timed passes) of the same batch.  /root/reference does not exist on the GPU box, so what is timed here is
                 oracle/torch_cpu_clip.py — the reference's module composition restated on the same torch.nn modules, i.e. the
-                same ATen CPU kernels ("kind": "reference-restatement"); the figure of the reference ITSELF, measured in the
+                same ATen CPU kernels ("kind": "port" in the contract's vocabulary, "kind_detail" says what it is); the figure of the reference ITSELF, measured in the
                 build container by tests/golden/make_golden_headline.py, is carried next to it ("reference_itself").
   rccl_ranks_seen  N > 1: all_reduce(SUM) of a one per rank over the bench's process group (RCCL for --backend nccl).
 """
@@ -222,7 +222,8 @@ def cpu_baseline_leg(sd_host, images, ids, n):
         except Exception:
             ref_itself = None
     return {"value": round(n / med, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "host_logical_cpus": os.cpu_count(),
-            "kind": "reference-restatement", "thread_sweep_s": {str(k): round(v, 2) for k, v in sweep.items()},
+            "kind": "port", "kind_detail": "oracle/torch_cpu_clip.py: the reference's module composition restated on the same torch.nn CPU modules",
+            "thread_sweep_s": {str(k): round(v, 2) for k, v in sweep.items()},
             "sample": f"first {n} pairs of the same synthetic ViT-B/16 batch, fp32, torch {torch.__version__} CPU kernels through "
                       f"nn.TransformerEncoder (oracle/torch_cpu_clip.py), one warm-up pass per thread count then 3 timed passes at "
                       f"{best_t} threads, median {med:.2f} s",

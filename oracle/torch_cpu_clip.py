@@ -5,7 +5,7 @@ composes — nn.TransformerEncoder(nn.TransformerEncoderLayer(norm_first=True)),
 F.layer_norm, F.normalize, F.cross_entropy — so that, timed on a host's cores, it dispatches to the same ATen kernels as the
 reference itself (reference call sites: models/clip/image_encoder.py:65-77,91-113, models/clip/text_encoder.py:58-66,113-134,
 models/clip/model.py:65-74, modules/losses/contrastive_loss_with_temperature.py:81-107).  It exists because /root/reference is
-absent on the GPU box: bench.py's `cpu_baseline` leg times THIS there ("kind": "reference-restatement"), next to the figure of
+absent on the GPU box: bench.py's `cpu_baseline` leg times THIS there ("kind": "port", kind_detail: the restatement on torch.nn CPU modules), next to the figure of
 the reference itself measured in the build container (profiles/r02_reference_cpu.json).
 
 Pinned: tests/test_oracle_golden.py::test_torch_cpu_restatement_matches_reference_fixtures compares it with the outputs of the
