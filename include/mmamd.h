@@ -395,6 +395,17 @@ int mmamd_activation(const void* x, const void* dy, void* out, int dtype, int64_
  * pass; ws: ceil(ld_dst/64) * cols floats when colsum is given. */
 int mmamd_transpose_to_bf16(const void* src, int src_dtype, int64_t ld_src, void* dst, int rows, int cols, int ld_dst,
                             float* colsum, float* ws, mmamd_stream_t stream);
+/* Weight pack of a training step (what autograd's saved bf16 operands are in the reference's autocast run: torch re-casts every nn.Linear weight per step,
+ * modules/layers/mlp.py:60-79, nn.MultiheadAttention's in / out projections): up to 64 fp32 [rows, cols] matrices -> their bf16 copies (nt, [rows, cols]) and /
+ * or their bf16 transposes (tr, [cols, ld_t], columns >= rows zero-filled: the operand of dX = dY W as an NT GEMM) in ONE launch.  Bit-identical to
+ * mmamd_convert / mmamd_transpose_to_bf16 per tensor. */
+typedef struct {
+  const float* src;
+  void* nt;   /* bf16 [rows, cols] or NULL */
+  void* tr;   /* bf16 [cols, ld_t] or NULL */
+  int rows, cols, ld_t;
+} mmamd_pack_desc;
+int mmamd_pack_weights(const mmamd_pack_desc* descs, int n, mmamd_stream_t stream);
 /* F.normalize backward (fp32): dx = (dy - y (y.dy)) / max(|x|, eps). */
 int mmamd_l2_normalize_bwd(const float* x, const float* dy, float* dx, int rows, int d, float eps, mmamd_stream_t stream);
 /* dst[idx[i], :] += src[i, :] with fp32 atomics (embedding-table gradient; pooled-row gradient into the sequence). */

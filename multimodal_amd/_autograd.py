@@ -40,6 +40,15 @@ def dgrad(dy: Tensor, w: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act: Op
     return ops.gemm_bf16(dy, wT, None, act=act, residual=pre_act, out_dtype=out_dtype)
 
 
+def dgrad_t(dy: Tensor, wT: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act: Optional[Tensor] = None) -> Tensor:
+    """dgrad with the bf16 transpose of W already made (ops.pack_weights: one launch per stack and step instead of one transpose per GEMM)."""
+    if wT.shape[1] != dy.shape[1]:
+        pad = torch.zeros((dy.shape[0], wT.shape[1]), dtype=bf, device=dy.device)
+        pad[:, :dy.shape[1]].copy_(dy)
+        dy = pad
+    return ops.gemm_bf16(dy, wT, None, act=act, residual=pre_act, out_dtype=out_dtype)
+
+
 def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
     """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens.  bias=True also returns
     db[N] = column sums of the bf16-rounded dY.  Token counts that are multiples of 128 (every full-size batch) go straight from the
@@ -71,6 +80,9 @@ class StackConfig:
         self.hidden: List[Tensor] = []  # inputs of every layer (detached), filled by the forward when keep_hidden
 
 
+_PACK_WEIGHTS = True  # tools/train_pack_ab.py flips it for the A/B
+
+
 def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: int, causal: bool, act: int, eps1: List[float],
                     eps2: List[float], key_mask: Optional[Tensor]) -> List[Tensor]:
     """Forward of N pre-norm layers.  params: the 12 canonical fp32 tensors per layer.  Returns [x_L] + per layer
@@ -79,21 +91,28 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
     n_layers = len(params) // 12
     saved: List[Tensor] = []
     inputs: List[Tensor] = []
+    # every Linear weight of the stack -> bf16 (forward operand) and bf16 transpose (dgrad operand, kept for the backward): one launch per 64
+    ws = [params[12 * li + k] for li in range(n_layers) for k in (0, 2, 4, 6)]
+    if _PACK_WEIGHTS:
+        wb, wt = ops.pack_weights(ws)
+    else:  # (A/B: one convert and one transpose launch per weight, as before r03)
+        wb, wt = [ops.convert(w, bf) for w in ws], [ops.transpose_to_bf16(w, pad_to=64) for w in ws]
     x = x0
     for li in range(n_layers):
-        Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+        _, bqkv, _, bo, _, b1, _, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+        Wqkv, Wo, W1, W2 = wb[4 * li:4 * li + 4]
         if li > 0:
             inputs.append(x)
         h1 = ops.layernorm(x, g1, be1, eps1[li], out_dtype=bf)
-        qkv = ops.gemm_bf16(h1, ops.convert(Wqkv, bf), bqkv)
+        qkv = ops.gemm_bf16(h1, Wqkv, bqkv)
         att, lse = ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
-        x_mid = ops.gemm_bf16(att, ops.convert(Wo, bf), bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
+        x_mid = ops.gemm_bf16(att, Wo, bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
         h2 = ops.layernorm(x_mid, g2, be2, eps2[li], out_dtype=bf)
-        u, g = ops.gemm_bf16_dual(h2, ops.convert(W1, bf), b1, act)  # pre-activation (kept for the backward) + activation
-        x_out = ops.gemm_bf16(g, ops.convert(W2, bf), b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
+        u, g = ops.gemm_bf16_dual(h2, W1, b1, act)  # pre-activation (kept for the backward) + activation
+        x_out = ops.gemm_bf16(g, W2, b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
         saved += [h1, qkv, att, lse, x_mid, h2, u, g]
         x = x_out
-    return [x] + saved + inputs
+    return [x] + saved + inputs + wt
 
 
 def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask):
@@ -107,7 +126,12 @@ def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask)
         saved += [x0.new_empty((M, d), dtype=bf), x0.new_empty((M, 3 * d), dtype=bf), x0.new_empty((M, d), dtype=bf),
                   x0.new_empty((B, n_head, S)), x0.new_empty((M, d)), x0.new_empty((M, d), dtype=bf), x0.new_empty((M, ff), dtype=bf),
                   x0.new_empty((M, ff), dtype=bf)]
-    return [x0.new_empty((M, d))] + saved + inputs
+    wt = []
+    for li in range(n_layers):
+        for k in (0, 2, 4, 6):
+            N, K = params[12 * li + k].shape
+            wt.append(x0.new_empty((K, (N + 63) // 64 * 64), dtype=bf))
+    return [x0.new_empty((M, d))] + saved + inputs + wt
 
 
 _ACT_GRAD = {ops.ACT_QUICKGELU: ops.ACT_MUL_QUICKGELU_GRAD, ops.ACT_GELU_ERF: ops.ACT_MUL_GELU_GRAD}
@@ -118,7 +142,8 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
     """Backward of _stack_fwd_impl: saved = its outputs [1:].  Returns [dX0] + the 12 canonical gradients per layer."""
     H = n_head
     n_layers = len(params) // 12
-    inputs = [x0] + list(saved[8 * n_layers:])
+    inputs = [x0] + list(saved[8 * n_layers:9 * n_layers - 1])
+    wt = saved[9 * n_layers - 1:]  # bf16 transposes of (Wqkv, Wo, W1, W2) per layer, made by the forward's weight pack
     dX = dx_out
     grads: List[Tensor] = [dX] * (12 * n_layers)
     dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
@@ -130,21 +155,22 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         if dXb is None:
             dXb = ops.convert(dX, bf)
         # x_out = x_mid + g W2^T + b2;  g = act(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
-        du = dgrad(dXb, W2, bf, _ACT_GRAD[act], u)
+        WqkvT, WoT, W1T, W2T = wt[4 * li:4 * li + 4]
+        du = dgrad_t(dXb, W2T, bf, _ACT_GRAD[act], u)
         if dXsum is None:
             dW2, db2 = wgrad(dXb, g, bias=True)
         else:
             dW2, db2 = wgrad(dXb, g), dXsum
         # u = h2 W1^T + b1
-        dh2 = dgrad(du, W1, f32)
+        dh2 = dgrad_t(du, W1T, f32)
         dW1, db1 = wgrad(du, h2, bias=True)
         dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True)
         # x_mid = x + att Wo^T + bo
-        datt = dgrad(dxmb, Wo, bf)
+        datt = dgrad_t(dxmb, WoT, bf)
         dWo = wgrad(dxmb, att)
         dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal, key_mask)
         # qkv = h1 Wqkv^T + bqkv
-        dh1 = dgrad(dqkv, Wqkv, f32)
+        dh1 = dgrad_t(dqkv, WqkvT, f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
         dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
         grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
@@ -177,7 +203,7 @@ class EncoderStackFn(torch.autograd.Function):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
         outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask)
         if cfg.keep_hidden:
-            cfg.hidden.extend([x] + list(outs[1 + 8 * cfg.n_layers:]) + [outs[0]])
+            cfg.hidden.extend([x] + list(outs[1 + 8 * cfg.n_layers:9 * cfg.n_layers]) + [outs[0]])
         ctx.save_for_backward(x, *outs[1:], *params)
         ctx.cfg, ctx.nparam = cfg, len(params)
         return outs[0]

@@ -316,6 +316,79 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const TS* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight pack for a training step: up to 64 fp32 [rows, cols] matrices (the Linear weights of a layer stack) -> their bf16 copies [rows, cols]
+// (the forward GEMMs' W operand) AND their bf16 transposes [cols, ld_t] (the dgrad GEMMs' operand: dX = dY W = gemm(dY, W^T)), ONE launch instead
+// of a convert and a transpose launch per weight per step (the 99 + 96 five-microsecond launches of a CLIP ViT-B/16 training step).
+// A workgroup owns one 64 x 64 tile; tensor / tile from the prefix table in the kernel arguments.  Same rounding as mmamd_convert /
+// mmamd_transpose_to_bf16 (one fp32 -> bf16 conversion per element): bit-identical copies.
+// ---------------------------------------------------------------------------------------------
+struct PackDesc {
+  const float* src;
+  bf16* nt;   // [rows, cols] or NULL
+  bf16* tr;   // [cols, ld_t] (columns >= rows zero-filled up to ld_t) or NULL
+  int rows, cols, ld_t;
+  int tile0;  // first tile id of this tensor
+};
+struct PackArgs {
+  PackDesc d[64];
+  int n, total;
+};
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+  __shared__ bf16 tile[64][68];
+  int ti = 0;
+  {
+    int lo = 0, hi = a.n - 1;  // last tensor whose tile0 <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (a.d[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    ti = lo;
+  }
+  const PackDesc& p = a.d[ti];
+  const int tiles_c = (p.cols + 63) >> 6;
+  const int tid_ = (int)blockIdx.x - p.tile0;
+  const int r0 = (tid_ / tiles_c) * 64, c0 = (tid_ - (tid_ / tiles_c) * tiles_c) * 64;
+  const int t = threadIdx.x;
+  const int lr = t >> 4, lc = (t & 15) * 4;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int r = r0 + ps * 16 + lr;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < p.rows) {
+      if (c0 + lc + 3 < p.cols && (p.cols & 3) == 0) v = *reinterpret_cast<const f32x4*>(p.src + (size_t)r * p.cols + c0 + lc);
+      else
+        for (int j = 0; j < 4; ++j)
+          if (c0 + lc + j < p.cols) v[j] = p.src[(size_t)r * p.cols + c0 + lc + j];
+    }
+    bf16x4 b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = (bf16)v[j];
+    *reinterpret_cast<bf16x4*>(&tile[ps * 16 + lr][lc]) = b;
+    if (p.nt != nullptr && r < p.rows) {
+      if (c0 + lc + 3 < p.cols && (p.cols & 3) == 0) *reinterpret_cast<bf16x4*>(p.nt + (size_t)r * p.cols + c0 + lc) = b;
+      else
+        for (int j = 0; j < 4; ++j)
+          if (c0 + lc + j < p.cols) p.nt[(size_t)r * p.cols + c0 + lc + j] = b[j];
+    }
+  }
+  if (p.tr == nullptr) return;
+  __syncthreads();
+  const int sc = t >> 4, sr = (t & 15) * 4;  // dst row = source column sc (+16 ps), 4 consecutive dst columns = source rows sr..sr+3
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int c = c0 + ps * 16 + sc, r = r0 + sr;
+    if (c < p.cols && r < p.ld_t) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = tile[sr + j][ps * 16 + sc];  // rows >= p.rows were staged as zeros
+      if (r + 3 < p.ld_t) *reinterpret_cast<bf16x4*>(p.tr + (size_t)c * p.ld_t + r) = o;
+      else
+        for (int j = 0; j < 4 && r + j < p.ld_t; ++j) p.tr[(size_t)c * p.ld_t + r + j] = o[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // F.normalize backward: y = x / max(|x|, eps);  dx = (dy - y (y . dy)) / max(|x|, eps)      (wave per row, fp32)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2_normalize_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -432,6 +505,26 @@ extern "C" int mmamd_transpose_to_bf16(const void* src, int src_dtype, int64_t l
   else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "transpose: bad dtype");
   if (colsum != nullptr) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, ws, (int)grid.y, cols, colsum);
   return launch_status("transpose_to_bf16");
+}
+
+extern "C" int mmamd_pack_weights(const mmamd_pack_desc* descs, int n, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(descs != nullptr && n >= 1 && n <= 64, MMAMD_E_BADARG, "pack_weights: 1 .. 64 tensors per call, got %d", n);
+  PackArgs a;
+  a.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const mmamd_pack_desc& q = descs[i];
+    MMAMD_CHECK_ARG(q.src && q.rows > 0 && q.cols > 0 && (q.nt || q.tr), MMAMD_E_BADARG, "pack_weights: tensor %d: bad argument", i);
+    MMAMD_CHECK_ARG(q.tr == nullptr || (q.ld_t >= q.rows && q.ld_t % 4 == 0), MMAMD_E_BADARG, "pack_weights: tensor %d: ld_t must be >= rows and a multiple of 4", i);
+    MMAMD_CHECK_ARG(aligned16(q.src) && ((uintptr_t)q.nt & 7) == 0 && ((uintptr_t)q.tr & 7) == 0, MMAMD_E_ALIGN, "pack_weights: tensor %d: alignment", i);
+    PackDesc& d = a.d[i];
+    d.src = q.src; d.nt = (bf16*)q.nt; d.tr = (bf16*)q.tr; d.rows = q.rows; d.cols = q.cols; d.ld_t = q.tr ? q.ld_t : 0; d.tile0 = tiles;
+    const int rows_t = q.tr ? (q.ld_t > q.rows ? q.ld_t : q.rows) : q.rows;  // the zero tail of the transposes is written too
+    tiles += ((rows_t + 63) / 64) * ((q.cols + 63) / 64);
+  }
+  a.total = tiles;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status("pack_weights");
 }
 
 extern "C" int mmamd_l2_normalize_bwd(const float* x, const float* dy, float* dx, int rows, int d, float eps, mmamd_stream_t stream) {

@@ -972,6 +972,37 @@ def transpose_to_bf16(src: torch.Tensor, pad_to: int = 128, with_colsum: bool = 
     return (dst, cs) if with_colsum else dst
 
 
+class _PackDesc(C.Structure):  # mmamd_pack_desc (include/mmamd.h)
+    _fields_ = [("src", C.c_void_p), ("nt", C.c_void_p), ("tr", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld_t", C.c_int)]
+
+
+def pack_weights(weights, want_nt: bool = True, want_tr: bool = True, pad_to: int = 64):
+    """bf16 copies and / or bf16 transposes of a list of contiguous fp32 [rows, cols] matrices, 64 tensors per launch (mmamd_pack_weights).
+    Returns (nt list or None, tr list or None); tr[i] is [cols, rows rounded up to pad_to] with a zero tail — what transpose_to_bf16 gives."""
+    nts, trs = ([] if want_nt else None), ([] if want_tr else None)
+    for w in weights:
+        _chk(w, "weight", torch.float32)
+        if w.dim() != 2:
+            raise MmamdError("pack_weights: 2-D matrices only")
+        rows, cols = w.shape
+        if want_nt:
+            nts.append(torch.empty((rows, cols), dtype=torch.bfloat16, device=w.device))
+        if want_tr:
+            trs.append(torch.empty((cols, (rows + pad_to - 1) // pad_to * pad_to), dtype=torch.bfloat16, device=w.device))
+    for i0 in range(0, len(weights), 64):
+        chunk = weights[i0:i0 + 64]
+        arr = (_PackDesc * len(chunk))()
+        for j, w in enumerate(chunk):
+            q = arr[j]
+            q.src = w.data_ptr()
+            q.nt = nts[i0 + j].data_ptr() if want_nt else None
+            q.tr = trs[i0 + j].data_ptr() if want_tr else None
+            q.rows, q.cols = w.shape
+            q.ld_t = trs[i0 + j].shape[1] if want_tr else 0
+        check(_lib.lib().mmamd_pack_weights(C.cast(arr, C.c_void_p), len(chunk), _stream()), "mmamd_pack_weights")
+    return nts, trs
+
+
 def l2_normalize_bwd(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
     _chk(x, "x", torch.float32); _chk(dy, "dy", torch.float32)
     dx = torch.empty_like(x)

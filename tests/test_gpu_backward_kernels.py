@@ -558,3 +558,19 @@ def test_small_fp32_linear_with_relu_backward():
         assert np.abs(host(y) - yd.detach().numpy()).max() <= 1e-5
         for got, ref in ((xg.grad, xd.grad), (wg.grad, wd.grad), (bg.grad, bd.grad)):
             assert np.abs(host(got) - ref.numpy()).max() <= 1e-5 * max(1.0, float(ref.abs().max())), relu
+
+
+def test_pack_weights_equals_convert_and_transpose_per_tensor():
+    """mmamd_pack_weights: the bf16 copies and bf16 transposes of many fp32 matrices in one launch == mmamd_convert / mmamd_transpose_to_bf16 per
+    tensor, bit for bit (ragged shapes, a zero tail in the transposes, more than 64 tensors = two launches)."""
+    from multimodal_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (96, 40), (130, 68), (64, 64), (1, 4)] + [(128, 256)] * 60
+    ws = [torch.randn(r, c, generator=g).cuda() for r, c in shapes]
+    nts, trs = ops.pack_weights(ws)
+    for w, nt, tr in zip(ws, nts, trs):
+        assert torch.equal(nt, ops.convert(w, torch.bfloat16))
+        assert torch.equal(tr, ops.transpose_to_bf16(w, pad_to=64))
+    only_t = ops.pack_weights(ws[:5], want_nt=False)
+    assert only_t[0] is None and all(torch.equal(a, b) for a, b in zip(only_t[1], trs[:5]))
