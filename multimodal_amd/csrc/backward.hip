@@ -170,7 +170,18 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     if (ch < nch && rl < rpar) {
-      for (int r = r0 + rl; r < r1; r += rpar) {
+      int r = r0 + rl;
+      if constexpr (sizeof(T) == 2) {  // four rows in flight per thread (the dependent-looking accumulate loop kept one)
+        for (; r + 3 * rpar < r1; r += 4 * rpar) {
+          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(x + (size_t)r * n + ch * VEC);
+          const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(x + (size_t)(r + rpar) * n + ch * VEC);
+          const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(x + (size_t)(r + 2 * rpar) * n + ch * VEC);
+          const bf16x8 v3 = *reinterpret_cast<const bf16x8*>(x + (size_t)(r + 3 * rpar) * n + ch * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { acc[j] += (float)v0[j]; acc[j] += (float)v1[j]; acc[j] += (float)v2[j]; acc[j] += (float)v3[j]; }
+        }
+      }
+      for (; r < r1; r += rpar) {
         if constexpr (sizeof(T) == 2) {
           const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (size_t)r * n + ch * VEC);
 #pragma unroll
