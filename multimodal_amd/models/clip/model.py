@@ -142,9 +142,19 @@ class CLIP(PackedModeMixin, nn.Module):
         # A's kernels leave idle in their last, partial wave of workgroups.  Pure stream plumbing: same kernels,
         # same results (schedule.side_stream = False disables it).
         if _train.wants_grad(self, features_a, features_b):
-            # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward, one stream
-            embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
-            embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))
+            # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward
+            side = self._side_stream(features_a) if (get_schedule().train_side_stream and not torch.compiler.is_compiling()) else None
+            if side is None:
+                embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
+                embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))
+            else:  # tower B (forward AND, through autograd's stream bookkeeping, backward) on the side stream
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))
+                embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
+                main.wait_stream(side)
+                embeddings_b.record_stream(main)
             return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
         if self._grouped_towers(tower_a, features_a, features_b):
             embeddings_a, embeddings_b = self._towers_grouped(tower_a, features_a, features_b)

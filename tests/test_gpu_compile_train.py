@@ -93,3 +93,39 @@ def test_compiled_step_trains():
     assert runs[0][0] == runs[1][0], runs
     assert all(abs(a - b) <= 1e-3 * abs(a) for a, b in zip(runs[0], runs[1])), runs
     assert runs[0][-1] < runs[0][0]
+
+
+def test_training_step_with_the_text_tower_on_a_side_stream_equals_one_stream():
+    """schedule.train_side_stream: tower B's forward (and, through autograd's stream bookkeeping, its backward) on a side HIP stream — the same
+    kernels, so loss and gradients equal the one-stream step bit for bit (token embedding: fp32 atomics, tolerance), over several steps."""
+    from multimodal_amd.schedule import set_schedule
+
+    model, loss_fn = _models()
+    model_s, loss_s = copy.deepcopy(model), copy.deepcopy(loss_fn)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(8, 3, 64, 64, generator=g).cuda()
+    ids = torch.randint(1, 500, (8, 16), generator=g)
+    ids[:, -1] = 511
+    ids = ids.cuda()
+    prev = set_schedule(train_side_stream=False)
+    try:
+        for it in range(3):
+            results = []
+            for m, l, side in ((model, loss_fn, False), (model_s, loss_s, True)):
+                set_schedule(train_side_stream=side)
+                for p in list(m.parameters()) + list(l.parameters()):
+                    p.grad = None
+                out = m(images, ids)
+                loss = l(out.embeddings_a, out.embeddings_b)
+                loss.backward()
+                torch.cuda.synchronize()
+                results.append((loss.detach().clone(), [(n, p.grad.clone()) for n, p in list(m.named_parameters()) + list(l.named_parameters())]))
+            (le, ge), (ls, gs) = results
+            assert torch.equal(le, ls), (it, float(le), float(ls))
+            for (n, a), (_, b) in zip(ge, gs):
+                if n.endswith("token_embedding.weight"):
+                    torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
+                else:
+                    assert torch.equal(a, b), (it, n)
+    finally:
+        set_schedule(train_side_stream=prev.train_side_stream)
