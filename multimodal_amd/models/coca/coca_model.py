@@ -21,6 +21,7 @@ from ...modules.layers.attention_pooler import AttentionPooler, CascadedAttentio
 from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
 from ...modules.losses.flava import cls_linear
+from ...schedule import get_schedule
 from ..._autograd import CrossEntropyFn, L2NormalizeFn, wants_grad
 from .multimodal_decoder import CoCaMultimodalDecoder
 from .text_decoder import CoCaTextDecoder
@@ -94,16 +95,17 @@ class CoCaModel(PackedModeMixin, nn.Module):
         l2n = L2NormalizeFn.apply if training else ops.l2_normalize
         dev = images.device
         side = None
-        if training:  # differentiable path: autograd nodes with HIP forward and backward, one stream
+        if training and not get_schedule().train_side_stream:  # differentiable path on one stream
             pooled_text_embeddings, text_tokens = self.text_decoder(texts, text_padding_mask)
             contrastive_text_embeddings = l2n(pooled_text_embeddings)
-        elif dev.type == "cuda":  # text decoder on a side stream: its small grids fill the CUs the ViT leaves idle
+        elif dev.type == "cuda":  # text decoder on a side stream: its small grids fill the CUs the ViT leaves idle (in training the autograd
+            # engine runs the decoder's backward on that stream too: schedule.train_side_stream)
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 pooled_text_embeddings, text_tokens = self.text_decoder(texts, text_padding_mask)
-                contrastive_text_embeddings = ops.l2_normalize(pooled_text_embeddings)
+                contrastive_text_embeddings = l2n(pooled_text_embeddings)
         else:
             pooled_text_embeddings, text_tokens = self.text_decoder(texts, text_padding_mask)  # raises: no CPU path
             contrastive_text_embeddings = ops.l2_normalize(pooled_text_embeddings)
