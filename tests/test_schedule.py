@@ -1,0 +1,43 @@
+"""The schedule object (multimodal_amd/schedule.py): one frozen settings record, validated, read from the environment once, changed only through
+set_schedule (which returns the previous record).  CPU-only."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_defaults_and_validation():
+    from multimodal_amd.schedule import Schedule, get_schedule, set_schedule
+
+    s = Schedule()
+    assert (s.two_tower, s.residual, s.side_stream, s.flava_batched_passes, s.train_side_stream) == ("auto", "epilogue", True, True, True)
+    with pytest.raises(ValueError):
+        Schedule(two_tower="both")
+    with pytest.raises(ValueError):
+        Schedule(residual="bf16")
+    with pytest.raises(Exception):
+        s.two_tower = "streams"  # frozen
+    prev = set_schedule(two_tower="streams", train_side_stream=False)
+    try:
+        assert get_schedule().two_tower == "streams" and get_schedule().train_side_stream is False
+        assert prev.two_tower in ("auto", "grouped", "streams")
+        with pytest.raises(ValueError):
+            set_schedule(residual="nope")
+        assert get_schedule().two_tower == "streams"  # a rejected change leaves the record as it was
+    finally:
+        set_schedule(two_tower=prev.two_tower, train_side_stream=prev.train_side_stream)
+    assert get_schedule() == prev
+
+
+def test_environment_is_read_once_at_import():
+    code = "from multimodal_amd.schedule import get_schedule as g; s = g(); print(s.two_tower, s.residual, s.side_stream)"
+    env = dict(os.environ, MMAMD_TWO_TOWER="grouped", MMAMD_RESIDUAL="delta_ln", MMAMD_SINGLE_STREAM="1", PYTHONPATH=str(ROOT))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["grouped", "delta_ln", "False"]
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(env, MMAMD_TWO_TOWER="sideways"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "two_tower" in bad.stderr
