@@ -138,7 +138,7 @@ class FLAVAModel(PackedModeMixin, nn.Module):
         # text tower(s) on the side stream, image tower(s) on the caller's stream
         side = None
         dev = (image if image is not None else text).device
-        if want_image and (want_text or want_text_masked) and dev.type == "cuda" and (not training or get_schedule().train_side_stream):
+        if want_image and (want_text or want_text_masked) and dev.type == "cuda" and (not training or (get_schedule().train_side_stream and not torch.compiler.is_compiling())):
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
             side.wait_stream(main)
