@@ -64,6 +64,9 @@ int mmamd_get_gemm_variant(void);
  * 1000 + percent (experiment, single-problem persistent kernel only): EVERY workgroup is delayed, the 32 of an XCD spread over 0 .. percent of a tile
  * time — measured to cost as much makespan as the spread-out bursts save. */
 int mmamd_debug_set_gemm_stagger(int percent);
+/* Experiment knobs of the GEMM launchers (results never change; knob 0: tile-order group of the grouped persistent kernel -- 0 = by the stream's
+ * CU budget, 4, 8;  knob 1: start-up stagger policy of the grouped kernel -- 0 = light workgroups only, 1 = every workgroup by its slack). */
+int mmamd_debug_set_gemm_knob(int knob, int value);
 /* Diagnostic: device buffer of 64*2*256 uint64 that GEMM variant 14 fills with s_memtime stamps (NULL = off). */
 int mmamd_debug_set_gemm_trace(void* buf);
 /* Diagnostic: attention ablation variant (timing experiments; non-zero values compute WRONG results). */
@@ -382,6 +385,12 @@ int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* w
 int mmamd_stream_create_cu_mask(const uint32_t* mask, int words, mmamd_stream_t* out);
 int mmamd_stream_destroy(mmamd_stream_t stream);
 int mmamd_stream_cus(mmamd_stream_t stream);
+/* CU BUDGET of an ordinary stream (no mask): persistent kernels launched on it use `cus` workgroups (a multiple of 8; 0 or >= 256 clears it)
+ * instead of one per CU of the chip.  Two streams with a budget of 128 each run their persistent GEMM / attention kernels side by side on
+ * disjoint CUs, and a phase shift between the two lets one stream's HBM-bound kernels (LayerNorm, attention, residual epilogues) run while the
+ * other's matrix-bound main loops leave the memory system idle: the phased half-batch schedule of the dual encoder (each half-batch of
+ * reference models/clip/model.py:65-74 is independent of the other until the loss).  Host-side state, read when a launch is enqueued. */
+int mmamd_stream_set_cus(mmamd_stream_t stream, int cus);
 int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks, mmamd_stream_t stream);
 int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream);
 int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n, int act, mmamd_stream_t stream);

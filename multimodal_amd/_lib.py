@@ -31,6 +31,7 @@ PROTOTYPES = {
     "mmamd_get_gemm_variant": (_i, []),
     "mmamd_debug_set_gemm_stagger": (_i, [_i]),
     "mmamd_debug_set_gemm_trace": (_i, [_vp]),
+    "mmamd_debug_set_gemm_knob": (_i, [_i, _i]),
     "mmamd_debug_set_attn_variant": (_i, [_i]),
     "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_add_layernorm_grouped": (_i, [_vp, _i, _vp]),
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "mmamd_stream_create_cu_mask": (_i, [_vp, _i, _vp]),
     "mmamd_stream_destroy": (_i, [_vp]),
     "mmamd_stream_cus": (_i, [_vp]),
+    "mmamd_stream_set_cus": (_i, [_vp, _i]),
     "mmamd_debug_cu_census": (_i, [_vp, _i, C.c_longlong, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),

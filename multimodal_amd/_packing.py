@@ -53,9 +53,39 @@ class PackedModeMixin:
         return super().train(mode)
 
 
+class _Ready:
+    """Stream-safety of a cached copy: the conversion kernel runs on the stream that first asked for the copy; a forward that drives SEVERAL
+    streams from one host thread (second tower on a side stream, the phased half-batch schedule) may look the copy up from another stream
+    before that kernel has run.  The producer records an event; a lookup from a different stream waits for it (stream-side, no host sync);
+    once the event has completed the guard is dropped, so the steady-state lookup costs one attribute test."""
+
+    __slots__ = ("event", "stream")
+
+    def __init__(self) -> None:
+        self.stream = torch.cuda.current_stream()
+        self.event = None
+        if not torch.cuda.is_current_stream_capturing():
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+
+    def guard(self) -> None:
+        ev = self.event
+        if ev is None:
+            return
+        cur = torch.cuda.current_stream()
+        if cur == self.stream:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            cur.wait_event(ev)
+        elif ev.query():
+            self.event = None
+        else:
+            cur.wait_event(ev)
+
+
 class PackedCache:
     def __init__(self) -> None:
-        self._store: Dict[Tuple[int, torch.dtype], Tuple[int, int, torch.device, torch.Tensor]] = {}
+        self._store: Dict[Tuple[int, torch.dtype], tuple] = {}
         self._cat: Dict[tuple, tuple] = {}
         self._epoch = _EPOCH
 
@@ -75,10 +105,12 @@ class PackedCache:
         key = (id(p), dtype)
         hit = self._store.get(key)
         if hit is not None and hit[0] == t.data_ptr() and hit[1] == p._version and hit[2] == t.device:
+            if hit[4].event is not None:
+                hit[4].guard()
             return hit[3]
         src = t if t.is_contiguous() else t.contiguous()
         conv = ops.convert(src, dtype)
-        self._store[key] = (t.data_ptr(), p._version, t.device, conv)
+        self._store[key] = (t.data_ptr(), p._version, t.device, conv, _Ready())
         return conv
 
     def get_cat(self, params: Sequence[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
@@ -94,6 +126,8 @@ class PackedCache:
         sig = tuple((t.data_ptr(), p._version) for t, p in zip(ts, params))
         hit = self._cat.get(key)
         if hit is not None and hit[0] == sig:
+            if hit[2].event is not None:
+                hit[2].guard()
             return hit[1]
         rows = sum(t.shape[0] for t in ts)
         buf = torch.empty((rows, *ts[0].shape[1:]), dtype=dtype, device=ts[0].device)
@@ -102,7 +136,7 @@ class PackedCache:
             src = t if t.is_contiguous() else t.contiguous()
             ops.convert(src, dtype, out=buf[r0:r0 + t.shape[0]])
             r0 += t.shape[0]
-        self._cat[key] = (sig, buf)
+        self._cat[key] = (sig, buf, _Ready())
         return buf
 
     def get_padded_rows(self, p: torch.Tensor, dtype: torch.dtype, multiple: int) -> torch.Tensor:
@@ -121,10 +155,12 @@ class PackedCache:
         sig = ((t.data_ptr(), p._version),)
         hit = self._cat.get(key)
         if hit is not None and hit[0] == sig:
+            if hit[2].event is not None:
+                hit[2].guard()
             return hit[1]
         buf = torch.zeros((padded, *t.shape[1:]), dtype=dtype, device=t.device)  # zero fill = memset, not arithmetic
         ops.convert(t if t.is_contiguous() else t.contiguous(), dtype, out=buf[:rows])
-        self._cat[key] = (sig, buf)
+        self._cat[key] = (sig, buf, _Ready())
         return buf
 
     def clear(self) -> None:

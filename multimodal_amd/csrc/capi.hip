@@ -107,6 +107,17 @@ extern "C" int mmamd_stream_destroy(mmamd_stream_t stream) {
   return (int)hipStreamDestroy((hipStream_t)stream);
 }
 extern "C" int mmamd_stream_cus(mmamd_stream_t stream) { return mmamd::stream_cus((hipStream_t)stream); }
+// CU BUDGET of an ordinary (unmasked) stream: the persistent kernels launched on it size their grids to `cus` workgroups instead of one per CU
+// of the chip, so that the persistent kernels of ANOTHER stream find the remaining CUs free and the two streams' phases interleave (the phased
+// half-batch schedule).  Nothing confines the stream's other kernels; 0 / >= 256 clears the budget.
+extern "C" int mmamd_stream_set_cus(mmamd_stream_t stream, int cus) {
+  MMAMD_CHECK_ARG(cus >= 0, MMAMD_E_BADARG, "stream_set_cus: negative CU budget");
+  MMAMD_CHECK_ARG(cus == 0 || cus % 8 == 0, MMAMD_E_BADARG, "stream_set_cus: the budget must be a multiple of 8 (whole XCD slices), got %d", cus);
+  std::lock_guard<std::mutex> lk(mmamd::g_stream_mu);
+  if (cus == 0 || cus >= mmamd::kChipCUs) mmamd::g_stream_cus.erase((void*)stream);
+  else mmamd::g_stream_cus[(void*)stream] = cus;
+  return 0;
+}
 extern "C" int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(out && blocks > 0, MMAMD_E_BADARG, "cu_census: bad argument");
   hipLaunchKernelGGL(mmamd::cu_census_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, out, spin_ticks);

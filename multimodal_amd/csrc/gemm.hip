@@ -159,6 +159,8 @@ static int g_gemm_variant = 0;
 // per cent of a tile time; measured (tools/gemm_variant_bench.py --staggers 0,30,60,90,120, profiles/r02_gemm_stagger.txt): 60 is the best or
 // within 1 % of it on every shape whose last round of tiles is partial (ViT MLP-up -3.6 %, out-proj -8 %, text MLP-up -10.6 %, patch -7.6 %)
 static int g_gemm_stagger = 60;
+// experiment knobs (mmamd_debug_set_gemm_knob): [0] tile-order group of the grouped kernel (0 = by CU budget, 4, 8); [1] slack-aware stagger, per cent
+static int g_gemm_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static unsigned long long* g_gemm_trace = nullptr;
 
 // Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
@@ -1217,6 +1219,10 @@ struct GemmGroupArgs {
   int nprob;
   int tile_start[3];  // tile_start[i] = first tile id of problem i; tile_start[nprob] = total
   int stagger;
+  // slack-aware start-up stagger (experiment knob 1 = per cent, 0 = off): estimated ticks of one tile of problem 0 / 1; a workgroup whose tile
+  // list is shorter than its XCD's longest starts late by a share of the difference, so the chip's epilogue bursts spread without adding makespan
+  int slack_pct;
+  int tile_ticks[2];
 };
 
 template <bool OUT_F32, int ACT, int GM>
@@ -1382,7 +1388,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
   tile_offsets(p, tm, tn, a_off, b_off);
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) issue_piece(0, 0, i);
-  if (g.stagger > 0) {
+  if (g.slack_pct > 0) {
+    // work of workgroup w of this XCD = its tiles of problem 0 and 1 times their estimated tile times (all scalar arithmetic)
+    auto work_of = [&](int w) -> long long {
+      const int ct = (nx - w + nwx - 1) / nwx;
+      const int c0 = w < xc0 ? (xc0 - w + nwx - 1) / nwx : 0;
+      return (long long)c0 * g.tile_ticks[0] + (long long)(ct - c0) * g.tile_ticks[1];
+    };
+    long long wmax = 0;
+    for (int w = 0; w < nwx && w < nx; ++w) {
+      const long long t = work_of(w);
+      wmax = t > wmax ? t : wmax;
+    }
+    const long long slack = wmax - work_of(wl);
+    const long long delay = slack * (((wl * 7) % nwx) + 1) / nwx * g.slack_pct / 100;  // shares 1/nwx .. 1 of the slack, scattered over the workgroups
+    if (delay > 0) {
+      const long long t0 = __builtin_readcyclecounter();
+      while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(32);
+    }
+  } else if (g.stagger > 0) {
     const int heavy = nx % nwx;  // this XCD's workgroups 0 .. heavy-1 walk one tile more: they start at once
     if (heavy > 0 && wl >= heavy) {
       const long long delay = (long long)g.stagger * (wl - heavy + 1) / (nwx - heavy);
@@ -1647,10 +1671,10 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   return launch_status("gemm_bf16_pp");
 }
 
-template <bool OUT_F32, int ACT>
-static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
+template <bool OUT_F32, int ACT, int GM>
+static int launch_grouped_gm(GemmGroupArgs& g, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_ppg<OUT_F32, ACT, 8>;
+  auto kern = gemm_bf16_nt_kernel_ppg<OUT_F32, ACT, GM>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int ntiles = g.tile_start[g.nprob];
@@ -1658,6 +1682,15 @@ static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
   const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g);
   return launch_status("gemm_bf16_grouped");
+}
+
+// tile-order group: the workgroups an XCD runs concurrently share GM activation row panels and (their count / GM) weight tiles in its L2.  32 per
+// XCD on the whole chip -> 8 x 4; a stream with half the chip's CUs as its budget (16 per XCD, the other stream's 16 beside them) -> 4 x 4
+template <bool OUT_F32, int ACT>
+static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
+  const int gm = g_gemm_knob[0] != 0 ? g_gemm_knob[0] : (stream_cus(st) <= 160 ? 4 : 8);
+  if (gm == 4) return launch_grouped_gm<OUT_F32, ACT, 4>(g, st);
+  return launch_grouped_gm<OUT_F32, ACT, 8>(g, st);
 }
 
 
@@ -1757,6 +1790,12 @@ extern "C" int mmamd_debug_set_gemm_stagger(int percent) {
   return 0;
 }
 
+extern "C" int mmamd_debug_set_gemm_knob(int knob, int value) {
+  MMAMD_CHECK_ARG(knob >= 0 && knob < 8, MMAMD_E_BADARG, "debug_set_gemm_knob: knob %d out of range", knob);
+  g_gemm_knob[knob] = value;
+  return 0;
+}
+
 extern "C" int mmamd_debug_set_gemm_trace(void* buf) {
   g_gemm_trace = reinterpret_cast<unsigned long long*>(buf);
   return 0;
@@ -1836,8 +1875,11 @@ extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int npro
   }
   for (int i = nprob; i < 2; ++i) { g.prob[i] = g.prob[0]; g.tile_start[i + 1] = g.tile_start[nprob]; }
   {
-    const long long t_tile = (long long)(probs[0].K / 64) * 3500 + (out_dtype == MMAMD_F32 ? 27000 : 8000) + (act != MMAMD_ACT_NONE ? 8000 : 0);
+    const long long t_epi = (out_dtype == MMAMD_F32 ? 27000 : 8000) + (act != MMAMD_ACT_NONE ? 8000 : 0);
+    const long long t_tile = (long long)(probs[0].K / 64) * 3500 + t_epi;
     g.stagger = (int)(t_tile * (g_gemm_stagger % 1000) / 100);
+    g.slack_pct = g_gemm_knob[1];
+    for (int i = 0; i < 2; ++i) g.tile_ticks[i] = (int)((long long)(g.prob[i].K / 64) * 3500 + t_epi);
   }
   if (out_dtype == MMAMD_F32) {
     switch (act) {

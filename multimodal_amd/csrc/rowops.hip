@@ -14,9 +14,11 @@ extern int g_ln_nt_policy;  // attention.hip (mmamd_debug_set_attn_variant(3100 
 // (profiles/r03_cache_policy_ab.txt): ViT-B/16 B = 256 (148 + 38 MiB) 13.66 -> 13.43 ms, ViT-L/14 (257 MiB) -1.0 %, FLAVA (148 MiB) -0.8 %;
 // ViT-B/32 (37 MiB: the input is still cached from the GEMM that wrote it) +0.7 %, CoCa B = 128 (128 MiB) +0.3 % with one row per wave and -0.4 % with
 // the two-rows-per-wave kernel these inputs now take (layernorm_grouped_rows_kernel) — hence the 128 MiB threshold.
-static bool ln_nontemporal(size_t x_bytes) {
+// A stream with a CU budget (mmamd_stream_set_cus) shares the chip -- and the MALL -- with the other half's stream: its tensors count for the
+// whole chip's worth (a half-batch of 74 MiB beside another half-batch of 74 MiB streams the same 148 MiB past the MALL).
+static bool ln_nontemporal(size_t x_bytes, hipStream_t st) {
   if (g_ln_nt_policy != 0) return g_ln_nt_policy == 2;
-  return x_bytes >= ((size_t)128 << 20);
+  return x_bytes * (size_t)kChipCUs / (size_t)stream_cus(st) >= ((size_t)128 << 20);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -79,7 +81,7 @@ static int launch_layernorm(const void* x, const float* g, const float* b, void*
                             float eps, hipStream_t st) {
   const int d4 = d / 4;
   const dim3 grid((rows + 3) / 4), block(256);
-  if (std::is_same<TIN, float>::value && ln_nontemporal((size_t)rows * d * 4)) {
+  if (std::is_same<TIN, float>::value && ln_nontemporal((size_t)rows * d * 4, st)) {
     if (d4 <= 128)
       hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, 2, 1>), grid, block, 0, st, (const TIN*)x, g, b, (TOUT*)y, rows, d, eps);
     else if (d4 <= 256)
@@ -956,7 +958,7 @@ extern "C" int mmamd_add_layernorm_grouped(const mmamd_ln_problem* probs, int np
   for (int i = 0; i < a.nprob; ++i) has_delta = has_delta || a.p[i].delta != nullptr;
   size_t xbytes = 0;
   for (int i = 0; i < a.nprob; ++i) xbytes += (size_t)a.p[i].rows * a.p[i].d * 4;
-  const bool ntp = ln_nontemporal(xbytes);
+  const bool ntp = ln_nontemporal(xbytes, st);
   bool all_y = true;
   for (int i = 0; i < a.nprob; ++i) all_y = all_y && a.p[i].y != nullptr;
   if (ntp && !has_delta && all_y) {  // large inputs: two rows per wave
@@ -991,7 +993,7 @@ extern "C" int mmamd_layernorm(const void* x, int x_dtype, const float* gamma, c
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == MMAMD_F32 && y_dtype == MMAMD_BF16) {
-    if (d <= 2048 && (d * 2) % 16 == 0 && ln_nontemporal((size_t)rows * d * 4)) {  // large input: the two-rows-per-wave kernel (same arithmetic)
+    if (d <= 2048 && (d * 2) % 16 == 0 && ln_nontemporal((size_t)rows * d * 4, st)) {  // large input: the two-rows-per-wave kernel (same arithmetic)
       mmamd_ln_problem q;
       q.x = const_cast<float*>(reinterpret_cast<const float*>(x)); q.delta = nullptr; q.gamma = gamma; q.beta = beta; q.y = y; q.rows = rows; q.d = d; q.eps = eps;
       return mmamd_add_layernorm_grouped(&q, 1, stream);

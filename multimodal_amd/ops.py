@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -90,6 +90,16 @@ def create_cu_mask_stream(mask_words, device=None) -> "torch.cuda.Stream":
 def stream_cus(stream: Optional["torch.cuda.Stream"] = None) -> int:
     s = torch.cuda.current_stream() if stream is None else stream
     return int(_lib.lib().mmamd_stream_cus(s.cuda_stream))
+
+
+def chip_cus() -> int:
+    """Compute units of the chip the kernels are built for (MI355X: 8 XCDs x 32)."""
+    return 256
+
+
+def stream_set_cus(stream: "torch.cuda.Stream", cus: int) -> None:
+    """CU budget of an ordinary stream: its persistent kernels use `cus` workgroups instead of one per CU (0 clears); mmamd_stream_set_cus."""
+    check(_lib.lib().mmamd_stream_set_cus(stream.cuda_stream, int(cus)), "mmamd_stream_set_cus")
 
 
 def cu_census(blocks: int = 2048, spin_ticks: int = 200000) -> torch.Tensor:

@@ -7,12 +7,18 @@ Every choice is between paths that compute the same function; the defaults are t
                                                   (auto: grouped only where it measured faster, _transformer.two_stacks_groupable)
     residual    "epilogue" | "delta_ln"           x += proj(...) inside the GEMM epilogue (fp32 read-modify-write per tile), or the GEMM
                                                   stores a bf16 delta and ONE streaming kernel does x += delta; hn = LN(x) for both towers
+                                                  (delta_ln applies to the GROUPED two-tower schedule only: TransformerStack.run and the
+                                                  two-stream path always use the epilogue form)
     side_stream  True | False                     tower-agnostic path: second tower on a side stream (False = one stream)
     flava_batched_passes  True | False            FLAVA inference: the unmasked and the masked pass of a tower as ONE pass over a 2B batch
     train_side_stream  True | False               CLIP training step: the text tower's forward (and, through autograd, backward) on a side stream
                                                   (same kernels, bit-identical step; -1.3 ... -4 ms of 54 depending on the box)
 
-Environment (read once): MMAMD_TWO_TOWER, MMAMD_RESIDUAL (epilogue | delta_ln), MMAMD_SINGLE_STREAM=1.
+    phases      1 | 2                              CLIP pair, grouped schedule: the batch as ONE launch list on the whole chip, or as two half-batches
+                                                  on two streams with half the chip's CUs each, the second `phase_lead` launches behind the first, so
+                                                  that one half's HBM-bound kernels run beside the other's matrix-bound ones
+
+Environment (read once): MMAMD_TWO_TOWER, MMAMD_RESIDUAL (epilogue | delta_ln), MMAMD_SINGLE_STREAM=1, MMAMD_PHASES (1 | 2).
 """
 from __future__ import annotations
 
@@ -30,17 +36,38 @@ class Schedule:
     side_stream: bool = True
     flava_batched_passes: bool = True
     train_side_stream: bool = True
+    phases: int = 1
+    phase_lead: int = 4
 
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:
             raise ValueError(f"two_tower must be one of {_TWO_TOWER}, got {self.two_tower!r}")
         if self.residual not in _RESIDUAL:
             raise ValueError(f"residual must be one of {_RESIDUAL}, got {self.residual!r}")
+        if self.phases not in (1, 2):
+            raise ValueError(f"phases must be 1 or 2, got {self.phases!r}")
+        if self.phase_lead < 0:
+            raise ValueError(f"phase_lead must be >= 0, got {self.phase_lead!r}")
 
 
 def _from_env() -> Schedule:
-    return Schedule(two_tower=os.environ.get("MMAMD_TWO_TOWER", "auto"), residual=os.environ.get("MMAMD_RESIDUAL", "epilogue"),
-                    side_stream=os.environ.get("MMAMD_SINGLE_STREAM") != "1")
+    """The environment is advisory: an unknown value warns and falls back to the default instead of failing `import multimodal_amd`
+    (MMAMD_RESIDUAL=fp32 / bf16 were round-2 spellings: fp32 is today's "epilogue", the bf16 residual stream is gone)."""
+    import warnings
+
+    def pick(var, allowed, default, legacy=()):
+        v = os.environ.get(var)
+        if v is None or v == "":
+            return default
+        v = dict(legacy).get(v, v)
+        if v not in allowed:
+            warnings.warn(f"{var}={os.environ[var]!r} is not one of {allowed}: using {default!r}", RuntimeWarning, stacklevel=3)
+            return default
+        return v
+
+    phases = pick("MMAMD_PHASES", ("1", "2"), "1")
+    return Schedule(two_tower=pick("MMAMD_TWO_TOWER", _TWO_TOWER, "auto"), residual=pick("MMAMD_RESIDUAL", _RESIDUAL, "epilogue", legacy=(("fp32", "epilogue"),)),
+                    side_stream=os.environ.get("MMAMD_SINGLE_STREAM") != "1", phases=int(phases))
 
 
 _current = _from_env()

@@ -39,5 +39,21 @@ def test_environment_is_read_once_at_import():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split() == ["grouped", "delta_ln", "False"]
-    bad = subprocess.run([sys.executable, "-c", code], env=dict(env, MMAMD_TWO_TOWER="sideways"), capture_output=True, text=True, timeout=120)
-    assert bad.returncode != 0 and "two_tower" in bad.stderr
+    # the environment is advisory: an unknown value warns and falls back to the default, a round-2 spelling is mapped -- the import never fails
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(env, MMAMD_TWO_TOWER="sideways", MMAMD_RESIDUAL="fp32"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 0, bad.stderr[-2000:]
+    assert bad.stdout.split() == ["auto", "epilogue", "False"] and "MMAMD_TWO_TOWER" in bad.stderr
+    ph = subprocess.run([sys.executable, "-c", "from multimodal_amd.schedule import get_schedule as g; print(g().phases, g().phase_lead)"],
+                        env=dict(env, MMAMD_PHASES="2"), capture_output=True, text=True, timeout=120)
+    assert ph.returncode == 0 and ph.stdout.split() == ["2", "4"], ph.stderr[-2000:]
+
+
+def test_phases_fields():
+    from multimodal_amd.schedule import Schedule
+
+    assert Schedule().phases == 1
+    assert Schedule(phases=2, phase_lead=6).phase_lead == 6
+    with pytest.raises(ValueError):
+        Schedule(phases=3)
+    with pytest.raises(ValueError):
+        Schedule(phase_lead=-1)
