@@ -19,10 +19,15 @@ One "step" = one such pass over one batch that is already resident in HBM.  Weak
 own 256 pairs; `value` = N*256*K / max-over-ranks wall time of the K timed steps (warm-up 10, 50 timed steps by
 default; `ms_per_step_median` = the median of the per-step HIP-event durations of rank 0, reported next to the mean).
 
+Inputs are what the reference's transform hands over: fp32 images and int64 ids, resident in HBM; the fp32 -> bf16 cast of the image batch is
+part of the timed step (`--bf16-images` feeds an already-cast batch instead; the line carries that figure too, as `bf16_resident_images`).
+
 Extra objects on the JSON line:
-  roofline      the dominant kernel = the MLP-up GEMM of the vision tower ([50432 x 3072 x 768], 238 GFLOP per launch,
-                12 launches per step): algorithmic FLOPs / its mean launch duration, measured with HIP events on the
-                launch stream inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  roofline      the dominant kernel = the one with the LARGEST SHARE of the step: gemm_bf16_nt_kernel_ppg<true,0,*>, the grouped fp32-residual
+                GEMM of both towers (out-projection [B*197 x 768 x 768] and MLP-down [B*197 x 768 x 3072] + the text tower's, 24 launches per
+                step, ~37 % of it): algorithmic FLOPs of the timed launches / their summed duration, measured with HIP events on the launch
+                stream(s) inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak; `by_shape` splits the two shapes;
+                `other_kernels` carries the MLP-up (+QuickGELU) and qkv grouped GEMMs, timed the same way in a few extra steps AFTER the region.
   step_mfma_frac  whole-step figure: pairs/s x 41.09 GFLOP/pair / 2.5 PFLOP/s.
   cpu_baseline  rank 0, N=1 only: the reference's CPU path on this box's host cores, on a bounded sample (B=32, 1 warm-up +
                 3 timed passes) of the same batch.  /root/reference does not exist on the GPU box, so what is timed here is
@@ -60,7 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=32, help="batch of the CPU-baseline sample; 0 = skip")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--no-probe", action="store_true", help="do not bracket the dominant GEMM with events")
-    ap.add_argument("--fp32-images", action="store_true", help="feed fp32 images (the stem then converts them to bf16 inside the timed step)")
+    ap.add_argument("--fp32-images", action="store_true", help="(default since r04) feed fp32 images: the stem converts them to bf16 inside the timed step")
+    ap.add_argument("--bf16-images", action="store_true", help="feed an already-cast bf16 image batch (the r03 default): the cast is then outside the timed step")
+    ap.add_argument("--phases", type=int, default=0, choices=[0, 1, 2], help="override schedule.phases (0 = the library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" IS RCCL on ROCm; gloo only with --dry-run')
     ap.add_argument("--dry-run", action="store_true", help="CPU control-flow run of the multi-rank path (no towers, no measurement)")
     ap.add_argument("--graph", action="store_true",
@@ -304,18 +311,23 @@ def main() -> None:
     loss_fn = ContrastiveLossWithTemperature().to(dev)
     B = args.batch
     images, ids = clip_batch(B, rank=rank)
-    # resident inputs as SURVEY 8d prescribes them: the synthetic fp32 images cast to bf16 once, outside the timed region (the patch
-    # rows were bf16 MFMA operands on the fp32-image path too: same rounding, same results; --fp32-images feeds the fp32 tensor instead)
+    # resident inputs as the reference's transform hands them over: fp32 images, int64 ids (the cast to bf16 belongs to the step;
+    # --bf16-images restores the r03 form, where the batch was cast once outside the timed region -- same rounding, same results)
     images_d, ids_d = images.to(dev), ids.to(dev)
-    if not args.fp32_images:
-        images_d = images_d.to(torch.bfloat16)
+    images_bf16 = images_d.to(torch.bfloat16)
+    if args.bf16_images:
+        images_d = images_bf16
+    if args.phases:
+        from multimodal_amd.schedule import set_schedule
+
+        set_schedule(phases=args.phases)
 
     def step():
         out = model(images_d, ids_d)
         return loss_fn(out.embeddings_a, out.embeddings_b)
 
     S_img = 197
-    probe = ops.GemmProbe(B * S_img, 3072, 768)
+    probe = ops.GemmProbe(shapes=[(768, 768), (768, 3072)])  # (N, K) of the fp32-residual GEMMs: out-projection and MLP-down, any M
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     graph, graph_note = None, None
     with torch.no_grad():
@@ -390,66 +402,83 @@ def main() -> None:
     dt_max = float(t)
     pairs_per_s = world * B * args.steps / dt_max
 
-    # the same launch 10 x back to back, nothing else on the GPU: reported next to the in-region figure as "back_to_back" (sustained MFMA load
-    # lowers the clock of this power-limited part: the figure is usually SLOWER than the in-step one, where LayerNorm / attention phases sit
-    # between the GEMMs)
-    iso_ms = None
-    companion = None if args.no_probe else probe.companion  # grouped launches: the text tower's MLP-up rides in the same kernel
-    if not args.no_probe:
-        def operands(M, N, K):
-            return (torch.randn(M, K, device=dev).to(torch.bfloat16), (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16),
-                    torch.randn(N, device=dev), None, torch.empty((M, N), dtype=torch.bfloat16, device=dev))
-
-        probs = [operands(*probe.shape)] + ([operands(*companion)] if companion else [])
-
-        def launch():
-            if companion:
-                ops.gemm_bf16_grouped(probs, act=ops.ACT_QUICKGELU)
-            else:
-                a_, w_, b_, _, o_ = probs[0]
-                ops.gemm_bf16(a_, w_, b_, act=ops.ACT_QUICKGELU, out=o_)
-
-        for _ in range(3):
-            launch()
-        torch.cuda.synchronize(dev)
-        tm = ops.StreamTimer()
-        tm.start()
-        for _ in range(10):
-            launch()
-        tm.stop()
-        iso_ms = tm.elapsed_ms() / 10
-        del probs
+    def family(samples):
+        """Σ algorithmic FLOPs / Σ duration of a list of timed launches (each possibly a grouped launch of two problems)."""
+        fl = sum(2.0 * m * n * k + (2.0 * c[0] * c[1] * c[2] if c else 0.0) for _, (m, n, k), c in samples)
+        ms = sum(d for d, _, _ in samples)
+        return fl, ms
 
     roofline = None
-    durs = [] if args.no_probe else probe.durations_ms()
-    if durs:
-        mean_ms = sum(durs) / len(durs)
-        flops = 2.0 * (B * S_img) * 3072 * 768
-        label = f"gemm_bf16_nt MLP-up [{B * S_img}x3072x768] (+bias, QuickGELU)"
-        if companion:
-            flops += 2.0 * companion[0] * companion[1] * companion[2]
-            label = (f"gemm_bf16_nt_kernel_ppg: grouped MLP-up of both towers, ViT [{B * S_img}x3072x768] + text "
-                     f"[{companion[0]}x{companion[1]}x{companion[2]}] (+bias, QuickGELU)")
-        achieved = flops / (mean_ms * 1e-3) / 1e12
+    other_kernels = None
+    bf16_resident = None
+    samples = [] if args.no_probe else probe.samples()
+    if samples:
+        with torch.no_grad():
+            # secondary kernels (MLP-up + QuickGELU, qkv) timed the same way in 3 extra steps AFTER the timed region
+            probe2 = ops.GemmProbe(shapes=[(3072, 768), (2304, 768)])
+            with probe2:
+                for _ in range(3):
+                    step()
+            torch.cuda.synchronize(dev)
+            # the r03 input form (bf16-resident image batch), 10 steps, for continuity with BENCH_r03
+            if not args.bf16_images:
+                keep = images_d
+                images_d = images_bf16
+                for _ in range(3):
+                    step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    step()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                images_d = keep
+                bf16_resident = {"ms_per_step": round(e0.elapsed_time(e1) / 10, 3), "steps": 10,
+                                 "note": "image batch cast to bf16 once outside the timed steps (the r03 bench default); this rank only"}
+        s2 = probe2.samples()
+        other_kernels = []
+        for (n_, k_), name in (((3072, 768), "grouped MLP-up (+bias, QuickGELU)"), ((2304, 768), "grouped qkv (+bias)")):
+            sub = [x for x in s2 if x[1][1:] == (n_, k_)]
+            if sub:
+                fl, ms = family(sub)
+                other_kernels.append({"kernel": f"gemm_bf16_nt_kernel_ppg<false,{1 if n_ == 3072 else 0},*>: {name}", "launches_timed": len(sub),
+                                      "launch_ms": round(ms / len(sub), 4), "achieved": round(fl / (ms * 1e-3) / 1e12, 2),
+                                      "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "where": "3 extra steps after the timed region"})
+        fl, ms = family(samples)
+        achieved = fl / (ms * 1e-3) / 1e12
+        by_shape = {}
+        for (n_, k_), name in (((768, 768), "out_projection"), ((768, 3072), "mlp_down")):
+            sub = [x for x in samples if x[1][1:] == (n_, k_)]
+            if sub:
+                f2, m2 = family(sub)
+                by_shape[name] = {"launches_timed": len(sub), "launch_ms": round(m2 / len(sub), 4), "achieved": round(f2 / (m2 * 1e-3) / 1e12, 2),
+                                  "frac": round(f2 / (m2 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "first_problem_MNK": list(sub[0][1]),
+                                  "companion_MNK": list(sub[0][2]) if sub[0][2] else None}
         traffic = None
-        pmc = ROOT / "profiles" / "pmc_dominant_kernel.json"
+        pmc = ROOT / "profiles" / "pmc_residual_kernel.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+                z = json.loads(pmc.read_text())["shapes"]
+                traffic = int(sum(v["hbm_bytes_per_launch"] for v in z.values()) / len(z))
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": label,
+        roofline = {"bound": "mfma",
+                    "kernel": "gemm_bf16_nt_kernel_ppg<true,0,*>: grouped out-projection / MLP-down of both towers (+bias, fp32 residual read-modify-write); "
+                              "the kernel with the largest share of the step",
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/pmc_dominant_kernel.json: HBM bytes per launch from separate rocprofv3 --pmc "
-                                                                    "passes of this command (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); "
-                                                                    "a stored figure, not measured in this run",
-                    "launch_ms": round(mean_ms, 4), "launches_timed": len(durs),
-                    "algorithmic_flops_per_launch": flops,
-                    "back_to_back": {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
-                                 "frac": round(flops / (iso_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}}
+                    "traffic_source": None if traffic is None else "profiles/pmc_residual_kernel.json: HBM bytes per launch (mean of the two shapes) from separate "
+                                                                    "rocprofv3 --pmc passes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); a stored "
+                                                                    "figure from whole-chip launches, not measured in this run",
+                    "launch_ms": round(ms / len(samples), 4), "launches_timed": len(samples),
+                    "share_of_step": round(ms / args.steps / (dt_local / args.steps * 1e3), 4),
+                    "algorithmic_flops_per_launch": fl / len(samples), "by_shape": by_shape, "other_kernels": other_kernels}
 
     cpu_baseline = cpu_baseline_leg(sd_host, images, ids, args.cpu_sample) if sd_host is not None else None
+    from multimodal_amd.schedule import get_schedule
+
+    sch = get_schedule()
+    schedule_desc = {"two_tower": sch.two_tower, "residual": sch.residual, "phases": sch.phases, "phase_lead": sch.phase_lead}
 
     if rank == 0:
         line = {
@@ -460,12 +489,14 @@ def main() -> None:
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "CLIP ViT-B/16 + text transformer forward + ContrastiveLossWithTemperature "
                                    f"({'global, packed RCCL all-gather' if use_dist else 'local'}), random-init weights",
-                       "per_gpu_batch": B, "global_batch": world * B, "seq_img": S_img, "seq_txt": 77, "image_dtype": "fp32" if args.fp32_images else "bf16",
-                       "parallelism": f"dp{world}", "gemm_variant": args.gemm_variant},
+                       "per_gpu_batch": B, "global_batch": world * B, "seq_img": S_img, "seq_txt": 77, "image_dtype": "bf16" if args.bf16_images else "fp32",
+                       "parallelism": f"dp{world}", "gemm_variant": args.gemm_variant, "schedule": schedule_desc},
             "loss": round(loss_val, 5),
             "step_mfma_frac": round(pairs_per_s / world * GF_PER_PAIR * 1e9 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if bf16_resident is not None:
+            line["bf16_resident_images"] = bf16_resident
         # diagnosability of the N > 1 runs: each rank's own time for its K steps (before the closing barrier), its host time to enqueue them,
         # and the all-gather alone; `value` above is computed from the max-over-ranks fenced wall time as the contract says
         line["per_rank_ms_per_step"] = [round(float(x[0]) / args.steps * 1e3, 3) for x in per_rank_all]

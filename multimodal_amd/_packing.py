@@ -89,6 +89,17 @@ class PackedCache:
         self._cat: Dict[tuple, tuple] = {}
         self._epoch = _EPOCH
 
+    # the cache is DERIVED data keyed by the identity of the owning module's parameters: a copy of the module (copy.deepcopy, pickle) has other
+    # parameters and starts with an empty cache (the entries also hold HIP events, which neither copy nor pickle)
+    def __deepcopy__(self, memo):
+        return PackedCache()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
     def _sync_epoch(self) -> None:
         if self._epoch != _EPOCH:
             self.clear()

@@ -219,9 +219,10 @@ def gemm_bf16_grouped(problems, act: int = ACT_NONE, out_dtype: torch.dtype = to
         q.M, q.N, q.K, q.lda, q.ldw, q.ldr, q.ldc = M, N, K, K, K, N, N
         outs.append(out)
     probe = _GEMM_PROBE
-    timer = probe._timer_for(arr[0].M, arr[0].N, arr[0].K) if probe is not None else None
+    comp = (arr[1].M, arr[1].N, arr[1].K) if n == 2 else None  # the launch also computes this problem
+    timer = probe._timer_for(arr[0].M, arr[0].N, arr[0].K, comp) if probe is not None else None
     if timer is not None:
-        probe.companion = (arr[1].M, arr[1].N, arr[1].K) if n == 2 else None  # the launch also computes this problem
+        probe.companion = comp
         timer.start()
     check(_lib.lib().mmamd_gemm_bf16_grouped(C.cast(arr, C.c_void_p), n, BF16 if out_dtype == torch.bfloat16 else F32, int(act), _stream()), "mmamd_gemm_bf16_grouped")
     if timer is not None:
@@ -1088,20 +1089,23 @@ _GEMM_PROBE = None
 
 
 class GemmProbe:
-    """Measurement hook for bench.py: brackets every gemm_bf16 launch of ONE problem shape with a pair of HIP
-    events on the launch stream, so the dominant kernel's duration is measured live inside the timed region."""
+    """Measurement hook for bench.py: brackets every gemm_bf16 / gemm_bf16_grouped launch whose FIRST problem has one of the given (N, K)
+    shapes (any M: the phased schedule launches half-batches) with a pair of HIP events on the launch stream, so a kernel's duration is
+    measured live inside the timed region.  `GemmProbe(M, N, K)` (one exact shape) is the round-1 form and still works."""
 
-    def __init__(self, M: int, N: int, K: int, max_samples: int = 4096) -> None:
+    def __init__(self, M=None, N: int = None, K: int = None, max_samples: int = 4096, shapes=None) -> None:
+        self.exact_m = M
+        self.shapes = [tuple(x) for x in shapes] if shapes is not None else [(N, K)]
         self.shape = (M, N, K)
         self.max_samples = max_samples
-        self.companion = None  # second problem of the grouped launches that were timed (gemm_bf16_grouped), if any
-        self._timers = []
+        self.companion = None  # second problem of the LAST grouped launch that was timed (gemm_bf16_grouped), if any
+        self._timers = []      # (timer, (M, N, K), companion (M, N, K) | None)
 
-    def _timer_for(self, M: int, N: int, K: int):
-        if (M, N, K) != self.shape or len(self._timers) >= self.max_samples:
+    def _timer_for(self, M: int, N: int, K: int, companion=None):
+        if (N, K) not in self.shapes or (self.exact_m is not None and M != self.exact_m) or len(self._timers) >= self.max_samples:
             return None
         t = StreamTimer()
-        self._timers.append(t)
+        self._timers.append((t, (M, N, K), companion))
         return t
 
     def __enter__(self):
@@ -1114,7 +1118,11 @@ class GemmProbe:
         _GEMM_PROBE = None
 
     def durations_ms(self):
-        return [t.elapsed_ms() for t in self._timers]
+        return [t.elapsed_ms() for t, _, _ in self._timers]
+
+    def samples(self):
+        """[(ms, (M, N, K), companion | None)] of every timed launch."""
+        return [(t.elapsed_ms(), shp, comp) for t, shp, comp in self._timers]
 
     def reset(self):
         self._timers = []

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--fp32-images", action="store_true")
+    ap.add_argument("--bf16-images", action="store_true", help="feed an already-cast bf16 batch (default: fp32 images like bench.py; the cast is part of the step)")
     a = ap.parse_args()
     from multimodal_amd.models.clip import clip_vit_b16
     from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
@@ -38,7 +38,7 @@ def main():
     loss_fn = ContrastiveLossWithTemperature().to(dev)
     images, ids = clip_batch(a.batch)
     images, ids = images.to(dev), ids.to(dev)
-    if not a.fp32_images:
+    if a.bf16_images:
         images = images.to(torch.bfloat16)
 
     from multimodal_amd.schedule import set_schedule
