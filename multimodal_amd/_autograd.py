@@ -112,6 +112,8 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
         x_out = ops.gemm_bf16(g, W2, b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
         saved += [h1, qkv, att, lse, x_mid, h2, u, g]
         x = x_out
+    if n_layers == 0:
+        x = x0.clone()  # a custom op (mutates_args = ()) must not return an alias of its input
     return [x] + saved + inputs + wt
 
 
@@ -174,6 +176,8 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
         dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
         grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
+    if n_layers == 0:
+        dX = dx_out.clone()  # (no alias of an input, see _stack_fwd_impl)
     return [dX] + grads
 
 

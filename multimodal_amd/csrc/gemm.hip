@@ -159,7 +159,7 @@ static int g_gemm_variant = 0;
 // per cent of a tile time; measured (tools/gemm_variant_bench.py --staggers 0,30,60,90,120, profiles/r02_gemm_stagger.txt): 60 is the best or
 // within 1 % of it on every shape whose last round of tiles is partial (ViT MLP-up -3.6 %, out-proj -8 %, text MLP-up -10.6 %, patch -7.6 %)
 static int g_gemm_stagger = 60;
-// experiment knobs (mmamd_debug_set_gemm_knob): [0] tile-order group of the grouped kernel (0 = by CU budget, 4, 8); [1] slack-aware stagger, per cent
+// experiment knobs (mmamd_debug_set_gemm_knob): [0] tile-order group of the grouped kernel (0 = by CU budget, 4, 8); [1] slack-aware stagger, per cent; [2] walk order of the grouped kernel's two problems
 static int g_gemm_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static unsigned long long* g_gemm_trace = nullptr;
 
@@ -1223,6 +1223,7 @@ struct GemmGroupArgs {
   // list is shorter than its XCD's longest starts late by a share of the difference, so the chip's epilogue bursts spread without adding makespan
   int slack_pct;
   int tile_ticks[2];
+  int order;  // experiment knob 2: walk order of the two problems' tiles inside an XCD's slice (0 = first problem, then second)
 };
 
 template <bool OUT_F32, int ACT, int GM>
@@ -1262,8 +1263,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
   if (wl >= nx) return;      // (whole workgroup: before any barrier)
   // XCD-local tile index -> (problem, tile): the GM-grouped order inside each problem's own tile grid
   auto tile_of = [&](int l, int& sel, int& tm, int& tn) __attribute__((always_inline)) {
-    sel = l >= xc0 ? 1 : 0;
-    const int id = sel ? xb1 + (l - xc0) : xb0 + l;
+    int id;
+    if (g.order == 1) {         // experiment: the second problem's tiles first
+      sel = l < xc1 ? 1 : 0;
+      id = sel ? xb1 + l : xb0 + (l - xc1);
+    } else if (g.order == 2 && nwx <= xc0) {  // experiment: one round of the first problem, then the second problem's tiles, then the rest
+      sel = (l >= nwx && l < nwx + xc1) ? 1 : 0;
+      id = sel ? xb1 + (l - nwx) : xb0 + (l < nwx ? l : l - xc1);
+    } else {
+      sel = l >= xc0 ? 1 : 0;
+      id = sel ? xb1 + (l - xc0) : xb0 + l;
+    }
     const int tiles_m = g.prob[sel].tiles_m;
     const int per_group = GM * g.prob[sel].tiles_n;
     const int grp = id / per_group, within = id - grp * per_group;
@@ -1879,6 +1889,7 @@ extern "C" int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int npro
     const long long t_tile = (long long)(probs[0].K / 64) * 3500 + t_epi;
     g.stagger = (int)(t_tile * (g_gemm_stagger % 1000) / 100);
     g.slack_pct = g_gemm_knob[1];
+    g.order = g_gemm_knob[2];
     for (int i = 0; i < 2; ++i) g.tile_ticks[i] = (int)((long long)(g.prob[i].K / 64) * 3500 + t_epi);
   }
   if (out_dtype == MMAMD_F32) {

@@ -139,7 +139,10 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
         P = self.patch_size
         K = 3 * P * P
         xc = x if x.is_contiguous() else x.contiguous()
-        if P in (16, 32) and self.image_size % 8 == 0 and self.width % 8 == 0 and xc.numel() * 2 < 2**32:
+        # (other shapes -- an image side that is not a whole number of patches, where nn.Conv2d(stride = P) floors the grid; a stack without
+        #  layers -- keep the patchify / assemble path)
+        if (P in (16, 32) and self.image_size % 8 == 0 and self.image_size % P == 0 and self.width % 8 == 0 and xc.numel() * 2 < 2**32
+                and (not want_hn0 or len(self.encoder.layers) > 0)):
             f32, bf = torch.float32, torch.bfloat16
             pk = self._packed.get
             B = xc.shape[0]

@@ -16,7 +16,7 @@ from ...utils.common import load_module_from_url
 from . import _train
 from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
-from ...schedule import get_schedule
+from ...schedule import get_schedule, train_side_stream_now
 from ._transformer import run_two_stacks, two_stacks_groupable, two_stacks_steps
 
 
@@ -40,6 +40,12 @@ def _pair_fwd_impl(features_a, features_b, params, key: int, E: int):
     model = _PAIR_MODELS.get(key)
     if model is None:
         raise ops.MmamdError("clip_pair_fwd: the model this compiled graph was traced from is gone")
+    # the op runs the LIVE module: the `params` inputs only make the graph depend on them.  A graph replayed with substituted parameters
+    # (torch.func.functional_call, export with swapped weights) would silently compute with the registered module's own: refuse instead.
+    own = list(model.parameters())
+    if len(own) != len(params) or any(p.data_ptr() != q.data_ptr() for p, q in zip(own, params)):
+        raise ops.MmamdError("clip_pair_fwd: the parameters passed to the compiled graph are not the registered model's own (functional / substituted "
+                             "parameters are not supported by this op: run the eager forward, or the per-op dispatcher path)")
     with torch.no_grad():
         out = model._forward(model.encoder_a, features_a, features_b)
     a, b = out.embeddings_a, out.embeddings_b
@@ -143,7 +149,9 @@ class CLIP(PackedModeMixin, nn.Module):
         # same results (schedule.side_stream = False disables it).
         if _train.wants_grad(self, features_a, features_b):
             # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward
-            side = self._side_stream(features_a) if (get_schedule().train_side_stream and not torch.compiler.is_compiling()) else None
+            # (not under a process group: DistributedDataParallel stashes its AccumulateGrad hooks on the stream it was constructed on, so a tower
+            #  whose backward runs on a side stream pays extra syncs there and cannot be captured in a HIP graph -- ADVICE r03)
+            side = self._side_stream(features_a) if train_side_stream_now() else None
             if side is None:
                 embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
                 embeddings_b = _train.L2NormalizeFn.apply(self.encoder_b(features_b))

@@ -21,7 +21,7 @@ from ...modules.layers.attention_pooler import AttentionPooler, CascadedAttentio
 from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
 from ...modules.losses.flava import cls_linear
-from ...schedule import get_schedule
+from ...schedule import get_schedule, train_side_stream_now
 from ..._autograd import CrossEntropyFn, L2NormalizeFn, wants_grad
 from .multimodal_decoder import CoCaMultimodalDecoder
 from .text_decoder import CoCaTextDecoder
@@ -95,7 +95,7 @@ class CoCaModel(PackedModeMixin, nn.Module):
         l2n = L2NormalizeFn.apply if training else ops.l2_normalize
         dev = images.device
         side = None
-        if training and (not get_schedule().train_side_stream or torch.compiler.is_compiling()):  # differentiable path on one stream
+        if training and not train_side_stream_now():  # differentiable path on one stream
             pooled_text_embeddings, text_tokens = self.text_decoder(texts, text_padding_mask)
             contrastive_text_embeddings = l2n(pooled_text_embeddings)
         elif dev.type == "cuda":  # text decoder on a side stream: its small grids fill the CUs the ViT leaves idle (in training the autograd

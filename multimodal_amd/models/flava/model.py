@@ -26,7 +26,7 @@ from ...modules.layers.transformer import TransformerOutput
 from ...modules.losses.flava import cls_linear, Pooler
 from ...utils.common import load_module_from_url
 from ..._autograd import wants_grad
-from ...schedule import get_schedule
+from ...schedule import get_schedule, train_side_stream_now
 from ._dalle import DalleConv2d, DalleEncoder, DalleEncoderBlock, DalleVAEEncoder  # noqa: F401  (reference :583-744)
 from .image_encoder import flava_image_encoder
 from .text_encoder import flava_text_encoder
@@ -138,7 +138,7 @@ class FLAVAModel(PackedModeMixin, nn.Module):
         # text tower(s) on the side stream, image tower(s) on the caller's stream
         side = None
         dev = (image if image is not None else text).device
-        if want_image and (want_text or want_text_masked) and dev.type == "cuda" and (not training or (get_schedule().train_side_stream and not torch.compiler.is_compiling())):
+        if want_image and (want_text or want_text_masked) and dev.type == "cuda" and (not training or train_side_stream_now()):
             main = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
             side.wait_stream(main)

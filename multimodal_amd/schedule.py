@@ -77,6 +77,18 @@ def get_schedule() -> Schedule:
     return _current
 
 
+def train_side_stream_now() -> bool:
+    """Whether a TRAINING forward may put its second tower on the side stream right now: schedule.train_side_stream, and neither a torch.compile
+    trace in progress (eager-mode schedule) nor an initialised process group (DistributedDataParallel keeps its gradient-accumulation hooks on the
+    stream it was constructed on: a tower whose backward runs elsewhere pays extra syncs there -- the 'AccumulateGrad node's stream does not
+    match' warning -- and a HIP-graph capture of the DDP step can break)."""
+    import torch
+
+    if not _current.train_side_stream or torch.compiler.is_compiling():
+        return False
+    return not (torch.distributed.is_available() and torch.distributed.is_initialized())
+
+
 def set_schedule(**changes) -> Schedule:
     """Replace fields of the process-wide schedule (tools / tests: A-B runs in one process).  Returns the previous schedule."""
     global _current
