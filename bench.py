@@ -23,7 +23,7 @@ Inputs are what the reference's transform hands over: fp32 images and int64 ids,
 part of the timed step (`--bf16-images` feeds an already-cast batch instead; the line carries that figure too, as `bf16_resident_images`).
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel = the one with the LARGEST SHARE of the step: gemm_bf16_nt_kernel_ppg<true,0,*>, the grouped fp32-residual
+  roofline      the dominant kernel = the one with the LARGEST SHARE of the step: gemm_bf16_nt_kernel_ppg<true,0>, the grouped fp32-residual
                 GEMM of both towers (out-projection [B*197 x 768 x 768] and MLP-down [B*197 x 768 x 3072] + the text tower's, 24 launches per
                 step, ~37 % of it): algorithmic FLOPs of the timed launches / their summed duration, measured with HIP events on the launch
                 stream(s) inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak; `by_shape` splits the two shapes;
@@ -441,7 +441,7 @@ def main() -> None:
             sub = [x for x in s2 if x[1][1:] == (n_, k_)]
             if sub:
                 fl, ms = family(sub)
-                other_kernels.append({"kernel": f"gemm_bf16_nt_kernel_ppg<false,{1 if n_ == 3072 else 0},*>: {name}", "launches_timed": len(sub),
+                other_kernels.append({"kernel": f"gemm_bf16_nt_kernel_ppg<false,{1 if n_ == 3072 else 0}>: {name}", "launches_timed": len(sub),
                                       "launch_ms": round(ms / len(sub), 4), "achieved": round(fl / (ms * 1e-3) / 1e12, 2),
                                       "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "where": "3 extra steps after the timed region"})
         fl, ms = family(samples)
@@ -463,7 +463,7 @@ def main() -> None:
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma",
-                    "kernel": "gemm_bf16_nt_kernel_ppg<true,0,*>: grouped out-projection / MLP-down of both towers (+bias, fp32 residual read-modify-write); "
+                    "kernel": "gemm_bf16_nt_kernel_ppg<true,0>: grouped out-projection / MLP-down of both towers (+bias, fp32 residual read-modify-write); "
                               "the kernel with the largest share of the step",
                     "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,

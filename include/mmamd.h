@@ -392,6 +392,14 @@ int mmamd_stream_cus(mmamd_stream_t stream);
  * reference models/clip/model.py:65-74 is independent of the other until the loss).  Host-side state, read when a launch is enqueued. */
 int mmamd_stream_set_cus(mmamd_stream_t stream, int cus);
 int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks, mmamd_stream_t stream);
+/* Training-time dropout / stochastic depth (reference: nn.Dropout at modules/layers/mlp.py:59-60, modules/layers/transformer.py:69-70,86-93;
+ * torchvision StochasticDepth(mode="row") at transformer.py:64-67):  out[i] = (residual ? residual[i] : 0) + x[i] * keep(i) / (1 - p).
+ * keep() is Philox4x32-10 keyed by `seed` with counter (index group, site): a pure function of (seed, site, i), so the backward calls the same
+ * entry on the incoming gradient (residual = NULL) instead of storing masks.  group = 0: one decision per element; group > 0: one decision per
+ * sample of `group` consecutive elements (drop path).  x / out: fp32 or bf16 (may alias); residual: fp32; mask_out (optional, tests): uint8 [n].
+ * n % 4 == 0.  oracle/philox.py restates the generator. */
+int mmamd_dropout(const void* x, int x_dtype, const float* residual, void* out, int out_dtype, uint8_t* mask_out, int64_t n, int64_t group,
+                  float p, uint64_t seed, uint32_t site, mmamd_stream_t stream);
 int mmamd_act_fwd(const void* u, void* g, int64_t n, int act, mmamd_stream_t stream);
 int mmamd_act_bwd(const void* u, const void* dg, void* du, int64_t n, int act, mmamd_stream_t stream);
 /* The activation MODULE called on its own (reference: modules/layers/activation.py:24-25, SiLU.forward = x * sigmoid(1.702 x); KAT

@@ -72,19 +72,106 @@ class StackConfig:
 
     def __init__(self, n_layers: int, n_head: int, B: int, S: int, causal: bool, act: int, eps1: Sequence[float], eps2: Sequence[float],
                  params_per_layer: int, to_canonical: Callable, from_canonical: Callable, key_mask: Optional[Tensor] = None,
-                 keep_hidden: bool = False):
+                 keep_hidden: bool = False, drop: Optional[Sequence[float]] = None, seed: int = 0):
         self.n_layers, self.n_head, self.B, self.S, self.causal, self.act = n_layers, n_head, B, S, causal, act
+        # training-time dropout (stack_drop_spec): [] = none, else [p_branch, p_mlp, p_attn] + one stochastic-depth rate per layer (-1 = none)
+        self.drop, self.seed = [float(v) for v in (drop or [])], int(seed)
         self.eps1, self.eps2, self.ppl = list(eps1), list(eps2), params_per_layer
         self.to_canonical, self.from_canonical, self.key_mask = to_canonical, from_canonical, key_mask
         self.keep_hidden = keep_hidden
         self.hidden: List[Tensor] = []  # inputs of every layer (detached), filled by the forward when keep_hidden
 
 
+def draw_seed() -> int:
+    """A fresh 62-bit Philox key for the dropout masks of ONE forward, drawn on the host from torch's CPU generator (reproducible under
+    torch.manual_seed); the backward regenerates its masks from the same key, nothing is stored.  Not under graph capture / torch.compile:
+    the key would be baked into the graph and every replay would drop the same elements."""
+    if torch.compiler.is_compiling():
+        raise ops.MmamdError("training-time dropout on the MI355X path is an eager-mode feature (torch.compile would bake the mask key into the graph)")
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise ops.MmamdError("training-time dropout cannot be captured in a HIP graph (the mask key is drawn on the host per step)")
+    return int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+
+
+def branch_rates(mod) -> Tuple[float, float]:
+    """(dropout p, stochastic-depth rate or -1) of a residual-branch module: nn.Dropout or StochasticDepth (modules/layers/stochastic_depth.py)."""
+    from .modules.layers.stochastic_depth import StochasticDepth
+
+    if isinstance(mod, StochasticDepth):
+        if mod.mode != "row":
+            raise ops.MmamdError("stochastic depth inside a layer stack: mode='row' only (what the reference's layers use)")
+        return 0.0, float(mod.p)
+    return float(getattr(mod, "p", 0.0)), -1.0
+
+
+def stack_drop_spec(layers, attn_p: Callable = None) -> Tuple[List[float], int]:
+    """Dropout description of a stack of pre-norm layers whose members follow the reference's naming (attention_dropout, feedforward_dropout,
+    feedforward = MLP): ([], 0) when every rate is zero, else ([p_branch, p_mlp, p_attn] + per-layer stochastic-depth rates, fresh seed).
+    One p_branch / p_mlp / p_attn per stack (the reference builds all layers of a stack from one `dropout` value; transformer.py:175-200)."""
+    pb, pm, pa, path = set(), set(), set(), []
+    for layer in layers:
+        p1, r1 = branch_rates(layer.attention_dropout)
+        p2, r2 = branch_rates(layer.feedforward_dropout)
+        if (p1, r1) != (p2, r2):
+            raise ops.MmamdError("training: attention_dropout and feedforward_dropout of a layer must have the same rate")
+        pb.add(p1)
+        path.append(r1)
+        pm.add(layer.feedforward.hidden_dropout_p())
+        pa.add(float(attn_p(layer)) if attn_p is not None else 0.0)
+    if len(pb) > 1 or len(pm) > 1 or len(pa) > 1:
+        raise ops.MmamdError("training: all layers of a stack must share their dropout rates")
+    p_branch, p_mlp, p_attn = pb.pop(), pm.pop(), pa.pop()
+    if p_attn > 0:
+        raise ops.MmamdError("training: dropout on the attention PROBABILITIES (attn_dropout > 0) is not implemented on the MI355X path "
+                             "(residual-branch dropout, MLP dropout, embedding dropout and stochastic depth are)")
+    if p_branch == 0 and p_mlp == 0 and all(r <= 0 for r in path):
+        return [], 0
+    if all(r < 0 for r in path):
+        path = []
+    return [p_branch, p_mlp, p_attn] + [max(r, -1.0) for r in path], draw_seed()
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = x * keep / (1 - p) (mmamd_dropout; group > 0: one decision per sample of `group` elements = stochastic depth, mode 'row').  The
+    backward is the same kernel on the incoming gradient: the mask is a function of (seed, site, index)."""
+
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int, site: int, group: int):
+        xc = x.detach()
+        xc = xc if xc.is_contiguous() else xc.contiguous()
+        ctx.meta = (p, seed, site, group)
+        return ops.dropout(xc, p, seed, site, group=group)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, site, group = ctx.meta
+        d = dy.detach()
+        return ops.dropout(d if d.is_contiguous() else d.contiguous(), p, seed, site, group=group), None, None, None, None
+
+
+def dropout_train(x: Tensor, p: float, site: int = 0, group: int = 0) -> Tensor:
+    """nn.Dropout(p) / StochasticDepth(p) of a TRAINING forward on a contiguous fp32 / bf16 tensor whose element count is a multiple of 4."""
+    if p <= 0:
+        return x
+    if x.numel() % 4 != 0:
+        raise ops.MmamdError(f"dropout on the MI355X path needs a multiple of 4 elements, got {tuple(x.shape)}")
+    return DropoutFn.apply(x, float(p), draw_seed(), site, group)
+
+
 _PACK_WEIGHTS = True  # tools/train_pack_ab.py flips it for the A/B
 
 
+def _drop_of(drop: List[float], li: int, S: int, d: int) -> Tuple[float, float, int]:
+    """(p of the two residual branches of layer li, p of the MLP's hidden dropout, elements per sample or 0): a stochastic-depth rate
+    replaces the branch dropout of its layer (reference transformer.py:64-70)."""
+    if not drop:
+        return 0.0, 0.0, 0
+    path = drop[3 + li] if len(drop) > 3 else -1.0
+    return (path, drop[1], S * d) if path >= 0 else (drop[0], drop[1], 0)
+
+
 def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: int, causal: bool, act: int, eps1: List[float],
-                    eps2: List[float], key_mask: Optional[Tensor]) -> List[Tensor]:
+                    eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int) -> List[Tensor]:
     """Forward of N pre-norm layers.  params: the 12 canonical fp32 tensors per layer.  Returns [x_L] + per layer
     [h1, qkv, att, lse, x_mid, h2, u, g] + the inputs of layers 1 .. N-1 (layer 0's input is x0 itself)."""
     H = n_head
@@ -106,10 +193,19 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
         h1 = ops.layernorm(x, g1, be1, eps1[li], out_dtype=bf)
         qkv = ops.gemm_bf16(h1, Wqkv, bqkv)
         att, lse = ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
-        x_mid = ops.gemm_bf16(att, Wo, bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
+        pb, pm, grp = _drop_of(drop, li, S, x.shape[1])
+        if pb > 0:  # x_mid = x + drop(att Wo^T + bo): the projection without the residual, then ONE pass: mask, scale, add
+            x_mid = ops.dropout(ops.gemm_bf16(att, Wo, bo, out_dtype=f32), pb, seed, 16 * li, residual=x, group=grp)
+        else:
+            x_mid = ops.gemm_bf16(att, Wo, bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
         h2 = ops.layernorm(x_mid, g2, be2, eps2[li], out_dtype=bf)
         u, g = ops.gemm_bf16_dual(h2, W1, b1, act)  # pre-activation (kept for the backward) + activation
-        x_out = ops.gemm_bf16(g, W2, b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
+        if pm > 0:
+            ops.dropout(g, pm, seed, 16 * li + 1, out=g)  # the MLP's hidden dropout, in place: the dropped g feeds W2 and its gradient
+        if pb > 0:
+            x_out = ops.dropout(ops.gemm_bf16(g, W2, b2, out_dtype=f32), pb, seed, 16 * li + 2, residual=x_mid, group=grp)
+        else:
+            x_out = ops.gemm_bf16(g, W2, b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
         saved += [h1, qkv, att, lse, x_mid, h2, u, g]
         x = x_out
     if n_layers == 0:
@@ -117,7 +213,7 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
     return [x] + saved + inputs + wt
 
 
-def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask):
+def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed):
     n_layers = len(params) // 12
     M, d = x0.shape
     saved, inputs = [], []
@@ -140,7 +236,7 @@ _ACT_GRAD = {ops.ACT_QUICKGELU: ops.ACT_MUL_QUICKGELU_GRAD, ops.ACT_GELU_ERF: op
 
 
 def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: List[Tensor], n_head: int, B: int, S: int, causal: bool,
-                    act: int, eps1: List[float], eps2: List[float], key_mask: Optional[Tensor]) -> List[Tensor]:
+                    act: int, eps1: List[float], eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int) -> List[Tensor]:
     """Backward of _stack_fwd_impl: saved = its outputs [1:].  Returns [dX0] + the 12 canonical gradients per layer."""
     H = n_head
     n_layers = len(params) // 12
@@ -154,11 +250,16 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         h1, qkv, att, lse, x_mid, h2, u, g = saved[8 * li:8 * li + 8]
         x = inputs[li]
         Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
-        if dXb is None:
+        pb, pm, grp = _drop_of(drop, li, S, x.shape[1])
+        if pb > 0:  # x_out = x_mid + drop(delta): the branch gradient is the masked, scaled dX (bf16 for the GEMMs); x_mid's share stays dX
+            dXb, dXsum = ops.dropout(dX, pb, seed, 16 * li + 2, group=grp, out_dtype=bf), None
+        elif dXb is None:
             dXb = ops.convert(dX, bf)
         # x_out = x_mid + g W2^T + b2;  g = act(u): du = (dX W2) * act'(u) in the dgrad GEMM's epilogue
         WqkvT, WoT, W1T, W2T = wt[4 * li:4 * li + 4]
         du = dgrad_t(dXb, W2T, bf, _ACT_GRAD[act], u)
+        if pm > 0:
+            ops.dropout(du, pm, seed, 16 * li + 1, out=du)  # g' = g * m / (1 - p): the mask commutes with the activation's derivative
         if dXsum is None:
             dW2, db2 = wgrad(dXb, g, bias=True)
         else:
@@ -167,6 +268,9 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         dh2 = dgrad_t(du, W1T, f32)
         dW1, db1 = wgrad(du, h2, bias=True)
         dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True)
+        if pb > 0:  # x_mid = x + drop(att Wo^T + bo)
+            dxmb = ops.dropout(dx_mid, pb, seed, 16 * li, group=grp, out_dtype=bf)
+            dbo = ops.colsum(dxmb)
         # x_mid = x + att Wo^T + bo
         datt = dgrad_t(dxmb, WoT, bf)
         dWo = wgrad(dxmb, att)
@@ -181,13 +285,13 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
     return [dX] + grads
 
 
-def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask):
+def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed):
     return [torch.empty_like(x0)] + [torch.empty_like(p) for p in params]
 
 
 from ._custom_op import define as _define  # noqa: E402
 
-_STACK_SCALARS = "int n_head, int B, int S, bool causal, int act, float[] eps1, float[] eps2, Tensor? key_mask"
+_STACK_SCALARS = "int n_head, int B, int S, bool causal, int act, float[] eps1, float[] eps2, Tensor? key_mask, float[] drop, int seed"
 stack_fwd_op = _define("encoder_stack_fwd", f"(Tensor x0, Tensor[] params, {_STACK_SCALARS}) -> Tensor[]", _stack_fwd_impl, _stack_fwd_fake)
 stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}) -> Tensor[]",
                        _stack_bwd_impl, _stack_bwd_fake)
@@ -205,7 +309,7 @@ class EncoderStackFn(torch.autograd.Function):
         canon: List[Tensor] = []
         for li in range(cfg.n_layers):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
-        outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask)
+        outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop, cfg.seed)
         if cfg.keep_hidden:
             cfg.hidden.extend([x] + list(outs[1 + 8 * cfg.n_layers:9 * cfg.n_layers]) + [outs[0]])
         ctx.save_for_backward(x, *outs[1:], *params)
@@ -222,7 +326,8 @@ class EncoderStackFn(torch.autograd.Function):
         canon: List[Tensor] = []
         for li in range(cfg.n_layers):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
-        outs = stack_bwd_op(dX, x0, list(saved), canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask)
+        outs = stack_bwd_op(dX, x0, list(saved), canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop,
+                            cfg.seed)
         grads: List[Optional[Tensor]] = [None] * nparam
         for li in range(cfg.n_layers):
             grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical(list(outs[1 + 12 * li:13 + 12 * li]))

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "mmamd_stream_cus": (_i, [_vp]),
     "mmamd_stream_set_cus": (_i, [_vp, _i]),
     "mmamd_debug_cu_census": (_i, [_vp, _i, C.c_longlong, _vp]),
+    "mmamd_dropout": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i64, _i64, _f, C.c_uint64, C.c_uint32, _vp]),
     "mmamd_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mmamd_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mmamd_activation": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp]),

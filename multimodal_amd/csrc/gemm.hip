@@ -77,6 +77,7 @@ struct GemmArgs {
   int i2c_lcr = 0;   // log2(16-byte chunks per patch row) = log2(p / 8)
   int i2c_ltpc = 0;  // log2(K-tiles per channel) = log2(p*p / 64)
   int i2c_rpk = 0;   // image rows per K-tile = 64 / p
+  int gm = 0;        // persistent kernel: tile-order group at run time (0 = the kernel's template value); pick_gm()
 };
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
@@ -161,6 +162,16 @@ static int g_gemm_variant = 0;
 static int g_gemm_stagger = 60;
 // experiment knobs (mmamd_debug_set_gemm_knob): [0] tile-order group of the grouped kernel (0 = by CU budget, 4, 8); [1] slack-aware stagger, per cent; [2] walk order of the grouped kernel's two problems
 static int g_gemm_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+// tile-order group (GemmGroupArgs::gm).  Column tiles <= 4 (N <= 1024: out-projection, MLP-down, the dgrad of qkv / MLP-up): row-major, all
+// column tiles of a row panel at once.  Otherwise the 32 workgroups an XCD runs share 8 row panels x 4 column tiles (16 per XCD on a stream
+// with half the chip as its CU budget: 4 x 4).
+static int pick_gm(int tiles_n, int cus) {
+  if (g_gemm_knob[0] != 0) return g_gemm_knob[0];
+  if (tiles_n <= 4) return 1;
+  return cus <= 160 ? 4 : 8;
+}
+
 static unsigned long long* g_gemm_trace = nullptr;
 
 // Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
@@ -866,13 +877,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   const int wm = wave / WN, wn = wave - wm * WN;
   const int l31 = lane & 31, half = lane >> 5;
 
+  const int GMr = p.gm > 0 ? p.gm : GM;  // (row-major, gm = 1, for few column tiles: see pick_gm)
   auto tile_of = [&](int vb, int& tm, int& tn) __attribute__((always_inline)) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, loc = vb >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int per_group = GM * p.tiles_n;
+    const int per_group = GMr * p.tiles_n;
     const int grp = id / per_group, within = id - grp * per_group;
-    const int gm0 = grp * GM;
-    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
+    const int gm0 = grp * GMr;
+    const int rows = (tiles_m - gm0) < GMr ? (tiles_m - gm0) : GMr;
     tn = within / rows;
     tm = gm0 + (within - tn * rows);
   };
@@ -1224,9 +1236,14 @@ struct GemmGroupArgs {
   int slack_pct;
   int tile_ticks[2];
   int order;  // experiment knob 2: walk order of the two problems' tiles inside an XCD's slice (0 = first problem, then second)
+  // tile-order group per problem: the workgroups an XCD runs concurrently walk gm row panels x all column tiles, column tile slowest inside a
+  // group.  gm = 1 is row-major: ALL column tiles of a row panel run at the same time, in lock-step, so every K-slice of the panel is fetched
+  // into the XCD's L2 once -- what a GEMM with FEW column tiles and a LONG K wants (MLP-down: 3 column tiles, a 1.5 MiB panel per 256 rows
+  // that no cache level keeps between rounds; r04: HBM bytes per launch 1254 -> ... MB, profiles/r04_pmc_residual_kernel.json)
+  int gm[2];
 };
 
-template <bool OUT_F32, int ACT, int GM>
+template <bool OUT_F32, int ACT>
 __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupArgs g) {
   constexpr int WM = 2, WN = 4, STP = OUT_F32 ? 0 : 2, RDP = 0;
   constexpr int BM = 256, BN = 256, NW = WM * WN;
@@ -1275,6 +1292,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
       id = sel ? xb1 + (l - xc0) : xb0 + l;
     }
     const int tiles_m = g.prob[sel].tiles_m;
+    const int GM = g.gm[sel];
     const int per_group = GM * g.prob[sel].tiles_n;
     const int grp = id / per_group, within = id - grp * per_group;
     const int gm0 = grp * GM;
@@ -1677,30 +1695,23 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   const int ntiles = tiles_m * p.tiles_n;
   const int cus = stream_cus(st);                   // 256, or the CU partition of a masked stream (multiple of 8: whole XCD slices)
   const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
+  p.gm = (g_gemm_knob[0] != 0) ? g_gemm_knob[0] : (p.tiles_n <= 4 ? 1 : 0);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, st, p, tiles_m, ntiles);
   return launch_status("gemm_bf16_pp");
 }
 
-template <bool OUT_F32, int ACT, int GM>
-static int launch_grouped_gm(GemmGroupArgs& g, hipStream_t st) {
+template <bool OUT_F32, int ACT>
+static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_ppg<OUT_F32, ACT, GM>;
+  auto kern = gemm_bf16_nt_kernel_ppg<OUT_F32, ACT>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int ntiles = g.tile_start[g.nprob];
   const int cus = stream_cus(st);
+  for (int i = 0; i < 2; ++i) g.gm[i] = pick_gm(g.prob[i].tiles_n, cus);
   const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g);
   return launch_status("gemm_bf16_grouped");
-}
-
-// tile-order group: the workgroups an XCD runs concurrently share GM activation row panels and (their count / GM) weight tiles in its L2.  32 per
-// XCD on the whole chip -> 8 x 4; a stream with half the chip's CUs as its budget (16 per XCD, the other stream's 16 beside them) -> 4 x 4
-template <bool OUT_F32, int ACT>
-static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
-  const int gm = g_gemm_knob[0] != 0 ? g_gemm_knob[0] : (stream_cus(st) <= 160 ? 4 : 8);
-  if (gm == 4) return launch_grouped_gm<OUT_F32, ACT, 4>(g, st);
-  return launch_grouped_gm<OUT_F32, ACT, 8>(g, st);
 }
 
 

@@ -13,7 +13,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
-from ..._autograd import EncoderStackFn, StackConfig, c32, dgrad, wgrad
+from ..._autograd import EncoderStackFn, StackConfig, c32, dgrad, stack_drop_spec, wgrad
 
 bf, f32 = torch.bfloat16, torch.float32
 
@@ -160,8 +160,6 @@ def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: boo
     for layer in encoder.layer:
         if not layer.norm_first:
             raise ops.MmamdError("training on the MI355X path implements pre-norm (norm_first=True) encoder layers")
-        if layer.attention_dropout.p > 0 or layer.feedforward_dropout.p > 0:
-            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
         steps = layer.feedforward.plan()
         if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
             raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
@@ -175,8 +173,11 @@ def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: boo
                    layer.feedforward_layernorm.bias]
         eps1.append(layer.attention_layernorm.eps)
         eps2.append(layer.feedforward_layernorm.eps)
+    # training-time dropout (reference flava/transformer.py: attention_dropout / feedforward_dropout on the branches, the MLP's hidden dropout;
+    # dropout on the attention probabilities -- SelfAttention(attn_dropout) -- is refused by stack_drop_spec)
+    drop, seed = stack_drop_spec(encoder.layer, attn_p=lambda l: l.attention.attn.attn_dropout)
     cfg = StackConfig(len(encoder.layer), encoder.layer[0].attention.n_head, B, S, False, act, eps1, eps2, 16, _to_canonical,
-                      _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden)
+                      _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden, drop=drop, seed=seed)
     xc = x if x.is_contiguous() else x.contiguous()
     y = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)
     hidden = [h.view(B, S, d) for h in cfg.hidden] if keep_hidden else None

@@ -102,8 +102,6 @@ class ImageEmbeddings(nn.Module):
 
     def forward(self, pixel_values: Tensor, image_patches_mask: Optional[Tensor] = None,
                 interpolate_pos_encoding: bool = False) -> Tensor:
-        if self.training and self.dropout.p > 0:
-            raise ops.MmamdError("embedding dropout > 0 in training mode is not implemented on the MI355X path")
         B = pixel_values.shape[0]
         if wants_grad(self, pixel_values):
             if interpolate_pos_encoding:
@@ -117,9 +115,14 @@ class ImageEmbeddings(nn.Module):
                                  f"({pe_mod.image_size[0]}*{pe_mod.image_size[1]}).")
             from ._train import FlavaImageEmbedFn
 
-            return FlavaImageEmbedFn.apply(pixel_values, pe_mod.projection.weight, pe_mod.projection.bias, self.cls_token,
-                                           self.position_embeddings, pe_mod.patch_size[0], image_patches_mask,
-                                           self.mask_token if image_patches_mask is not None else None)
+            from ..._autograd import dropout_train
+
+            emb = FlavaImageEmbedFn.apply(pixel_values, pe_mod.projection.weight, pe_mod.projection.bias, self.cls_token,
+                                          self.position_embeddings, pe_mod.patch_size[0], image_patches_mask,
+                                          self.mask_token if image_patches_mask is not None else None)
+            return dropout_train(emb, self.dropout.p)  # reference flava/image_encoder.py:165: dropout on the assembled embeddings
+        if self.training and self.dropout.p > 0:
+            raise ops.MmamdError("embedding dropout applies on the differentiable (train mode, grad enabled) forward only: call .eval() for inference")
         pe = self.patch_embeddings(pixel_values, interpolate_pos_encoding=interpolate_pos_encoding)
         G2 = pe.shape[1]
         pk, f32 = self._packed.get, torch.float32

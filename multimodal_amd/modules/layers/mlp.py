@@ -82,12 +82,17 @@ class MLP(nn.Module):
                                          "(nn.GELU and the CLIP SiLU/QuickGELU are GEMM epilogues, nn.ReLU runs on the exact-fp32 row path)")
                 act = code
                 i += 1
-            if i < len(mods) and isinstance(mods[i], nn.Dropout):
-                if self.training and mods[i].p > 0:
-                    raise ops.MmamdError("MLP on the MI355X path: dropout > 0 in training mode is not implemented")
+            if i < len(mods) and isinstance(mods[i], nn.Dropout):  # applied by the training paths (hidden_dropout_p); identity in eval mode
                 i += 1
             steps.append((lin, act))
         return steps
+
+    def hidden_dropout_p(self) -> float:
+        """p of the nn.Dropout behind every hidden activation (reference mlp.py:59-60; one value per MLP), 0.0 if there is none."""
+        ps = {float(m.p) for m in self.model if isinstance(m, nn.Dropout)}
+        if len(ps) > 1:
+            raise ops.MmamdError("MLP on the MI355X path: one dropout rate per MLP")
+        return ps.pop() if ps else 0.0
 
     def run(self, h: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """h: bf16 [M, in_dim].  Returns fp32 [M, out_dim] (+ residual, which may alias out)."""
@@ -148,12 +153,15 @@ class MLP(nn.Module):
                                      f"rows, got {rows.shape[0]}); token-level MLPs use nn.GELU / SiLU (fused GEMM epilogues)")
             if rows.dtype != torch.float32:
                 raise ops.MmamdError("MLP (exact-fp32 row path) takes fp32 activations")
-            from ..._autograd import SmallLinearF32Fn, wants_grad
+            from ..._autograd import SmallLinearF32Fn, dropout_train, wants_grad
 
             h = rows
             if wants_grad(self) or (torch.is_grad_enabled() and x.requires_grad):
-                for lin, act in steps:
+                pdrop = self.hidden_dropout_p() if self.training else 0.0
+                for n, (lin, act) in enumerate(steps):
                     h = SmallLinearF32Fn.apply(h, lin.weight, lin.bias, act == ACT_RELU_EXACT)
+                    if pdrop > 0 and n + 1 < len(steps):  # Linear -> activation -> Dropout per hidden layer (reference mlp.py:52-61)
+                        h = dropout_train(h, pdrop, site=n)
             else:
                 pk = self._packed.get
                 for lin, act in steps:

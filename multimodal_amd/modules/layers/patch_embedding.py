@@ -91,8 +91,8 @@ class PatchEmbeddings(nn.Module):
                              f"{self.image_size[0]}*{self.image_size[1]} expected by model")
         if height != width:
             raise ops.MmamdError("non-square images are not implemented on the MI355X path")
-        if self.training and (self.patch_drop_rate is not None or self.dropout.p > 0):
-            raise ops.MmamdError("patch dropping / dropout in training mode are not implemented on the MI355X path")
+        if self.training and self.patch_drop_rate is not None:
+            raise ops.MmamdError("patch dropping (patch_drop_rate) in training mode is not implemented on the MI355X path")
         P = self.conv_projection.kernel_size[0]
         if self.training and torch.is_grad_enabled() and self.conv_projection.weight.requires_grad:
             from ...models.flava._train import FlavaImageEmbedFn  # differentiable path (conv + bias, optional CLS / mask token, + pos)
@@ -100,10 +100,14 @@ class PatchEmbeddings(nn.Module):
             if image_patches_mask is not None and self.mask_token is None:
                 warnings.warn("image_patches_mask passed but use_image_masking in init was false. Ignoring.")
                 image_patches_mask = None
+            from ..._autograd import dropout_train
+
             x = FlavaImageEmbedFn.apply(pixel_values, self.conv_projection.weight, self.conv_projection.bias,
                                         self.cls_token if self.include_cls_embed else None, self.position_embeddings, P,
                                         image_patches_mask, self.mask_token if image_patches_mask is not None else None)
-            return PatchEmbeddingsOutput(embeddings=x)
+            return PatchEmbeddingsOutput(embeddings=dropout_train(x, self.dropout.p))  # reference :150: dropout on the assembled embeddings
+        if self.training and self.dropout.p > 0:
+            raise ops.MmamdError("embedding dropout applies on the differentiable (train mode, grad enabled) forward only: call .eval() for inference")
         w = self.conv_projection.weight
         k = num_channels * P * P
         kpad = (k + 63) // 64 * 64

@@ -53,8 +53,6 @@ class BERTTextEmbeddings(nn.Module):
             raise ops.MmamdError("inputs_embeds is not implemented on the MI355X path (pass input_ids)")
         if self.offset_pos_ids and position_ids is None:
             position_ids = self.create_position_ids_from_input_ids(input_ids)  # reference :88-89
-        if self.training and self.dropout.p > 0:
-            raise ops.MmamdError("embedding dropout > 0 in training mode is not implemented on the MI355X path")
         B, S = input_ids.shape
         if position_ids is not None and position_ids.shape != input_ids.shape:
             position_ids = position_ids.expand(B, S).contiguous()
@@ -62,9 +60,14 @@ class BERTTextEmbeddings(nn.Module):
         if self.training and torch.is_grad_enabled() and self.word_embeddings.weight.requires_grad:
             from ...models.flava._train import BertEmbedFn  # differentiable path
 
-            return BertEmbedFn.apply(ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
-                                     self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, token_type_ids, position_ids,
-                                     self.word_embeddings.padding_idx)
+            from ..._autograd import dropout_train
+
+            emb = BertEmbedFn.apply(ids, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
+                                    self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, token_type_ids, position_ids,
+                                    self.word_embeddings.padding_idx)
+            return dropout_train(emb, self.dropout.p)  # reference :102-103: LayerNorm, then dropout
+        if self.training and self.dropout.p > 0:
+            raise ops.MmamdError("embedding dropout applies on the differentiable (train mode, grad enabled) forward only: call .eval() for inference")
         pk, f32 = self._packed.get, torch.float32
         x = ops.bert_embed_ln(input_ids if input_ids.is_contiguous() else input_ids.contiguous(),
                               pk(self.word_embeddings.weight, f32), pk(self.position_embeddings.weight, f32),

@@ -18,6 +18,7 @@ from ..._packing import PackedCache
 from .mlp import MLP
 from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask
 from .normalizations import Fp32LayerNorm
+from .stochastic_depth import StochasticDepth
 
 
 _torch_ops.try_load()
@@ -53,11 +54,12 @@ class TransformerEncoderLayer(nn.Module):
                  activation: Callable[..., nn.Module] = nn.ReLU, layer_norm_eps: float = 1e-12, norm_first: bool = False,
                  drop_path_rate: Optional[float] = None) -> None:
         super().__init__()
-        if drop_path_rate is not None:
-            raise ops.MmamdError("stochastic depth (drop_path_rate) is a training-time feature not implemented on the MI355X path")
         self.attention = MultiHeadSelfAttention(embed_dim=d_model, num_heads=n_head)
-        self.attention_dropout = nn.Dropout(dropout)
-        self.feedforward_dropout = nn.Dropout(dropout)
+        if drop_path_rate is not None:  # reference :64-67: ONE StochasticDepth(mode="row") serves both residual branches
+            self.attention_dropout = self.feedforward_dropout = StochasticDepth(drop_path_rate, mode="row")
+        else:
+            self.attention_dropout = nn.Dropout(dropout)
+            self.feedforward_dropout = nn.Dropout(dropout)
         self.feedforward = MLP(d_model, d_model, dim_feedforward, dropout=dropout, activation=activation)
         self.attention_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
         self.feedforward_layernorm = Fp32LayerNorm(d_model, eps=layer_norm_eps)
@@ -65,9 +67,12 @@ class TransformerEncoderLayer(nn.Module):
         self._packed = PackedCache()
 
     def run(self, x: Tensor, B: int, S: int, mask: ops.AttnMask) -> Tensor:
-        """x: fp32 [B*S, d] (left untouched) -> new fp32 [B*S, d]."""
-        if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
-            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
+        """x: fp32 [B*S, d] (left untouched) -> new fp32 [B*S, d].  INFERENCE form (no dropout / stochastic depth): the training forward of the
+        enclosing TransformerEncoder applies them (_encoder_forward_train); a train-mode module with non-zero rates must not land here."""
+        if self.training and (getattr(self.attention_dropout, "p", 0.0) > 0 or getattr(self.feedforward_dropout, "p", 0.0) > 0
+                              or self.feedforward.hidden_dropout_p() > 0):
+            raise ops.MmamdError("this non-differentiable forward applies no dropout / stochastic depth: call .eval() for inference (training goes "
+                                 "through TransformerEncoder's differentiable forward, which does apply them)")
         bf, f32, pc = torch.bfloat16, torch.float32, self._packed
         if self.norm_first:  # reference :96-116
             x1 = self.attention.run(_ln(pc, self.attention_layernorm, x, bf), B, S, mask, residual=x)
@@ -112,11 +117,13 @@ class TransformerEncoder(nn.Module):
                  activation: Callable[..., nn.Module] = nn.ReLU, layer_norm_eps: float = 1e-12, norm_first: bool = False,
                  final_layer_norm_eps: Optional[float] = None, drop_path_rate: Optional[float] = None):
         super().__init__()
-        if drop_path_rate is not None:
-            raise ops.MmamdError("stochastic depth (drop_path_rate) is a training-time feature not implemented on the MI355X path")
+        if drop_path_rate is not None:  # reference :190-193: the rate grows linearly with depth
+            drop_rate = [x.item() for x in torch.linspace(0, drop_path_rate, n_layer)]
+        else:
+            drop_rate = [None for _ in range(n_layer)]
         self.layer = nn.ModuleList([
-            TransformerEncoderLayer(d_model, n_head, dim_feedforward, dropout, activation, layer_norm_eps, norm_first, None)
-            for _ in range(n_layer)
+            TransformerEncoderLayer(d_model, n_head, dim_feedforward, dropout, activation, layer_norm_eps, norm_first, drop_rate[i])
+            for i in range(n_layer)
         ])
         self.final_layer_norm = None
         if final_layer_norm_eps:
@@ -176,7 +183,7 @@ class TransformerEncoder(nn.Module):
 
 def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_hidden_states: bool) -> TransformerOutput:
     """Differentiable TransformerEncoder.forward: the packed input_proj layout is the canonical one of EncoderStackFn."""
-    from ..._autograd import EncoderStackFn, StackConfig
+    from ..._autograd import EncoderStackFn, StackConfig, stack_drop_spec
     from .mlp import fused_activation_code  # noqa: F401
 
     B, S, d = hidden_states.shape
@@ -184,8 +191,8 @@ def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_h
         raise ops.MmamdError("training on the MI355X path: TransformerEncoder attention masks are not implemented")
     params, eps1, eps2, act = [], [], [], None
     for layer in self.layer:
-        if not layer.norm_first or layer.attention_dropout.p > 0 or layer.feedforward_dropout.p > 0:
-            raise ops.MmamdError("training on the MI355X path implements pre-norm layers without dropout")
+        if not layer.norm_first:
+            raise ops.MmamdError("training on the MI355X path implements pre-norm layers")
         steps = layer.feedforward.plan()
         if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
             raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
@@ -197,8 +204,11 @@ def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_h
         eps1.append(layer.attention_layernorm.eps)
         eps2.append(layer.feedforward_layernorm.eps)
     ident = lambda t: t
+    # training-time dropout / stochastic depth of the residual branches and the MLP's hidden dropout (reference :64-93); MultiHeadSelfAttention is
+    # built without attention-probability dropout (:60-63)
+    drop, seed = stack_drop_spec(self.layer)
     cfg = StackConfig(len(self.layer), self.layer[0].attention.num_heads, B, S, False, act, eps1, eps2, 12, ident, ident,
-                      keep_hidden=return_hidden_states)
+                      keep_hidden=return_hidden_states, drop=drop, seed=seed)
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
     x = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params).view(B, S, d)
     hidden = None
@@ -443,7 +453,10 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
     layers, params = [], []
     for layer in self.layer:
         if not layer.norm_first or layer.attention_dropout.p > 0 or layer.feedforward_dropout.p > 0:
-            raise ops.MmamdError("training on the MI355X path implements pre-norm layers without dropout")
+            # (the decoder's MultiHeadAttentionWithCache also drops attention PROBABILITIES at the same rate, reference :262-266 -- the part of
+            #  training-time dropout that is not implemented; the encoder stacks, whose attention has none, do train with dropout)
+            raise ops.MmamdError("training on the MI355X path implements pre-norm decoder layers without dropout (attention-probability dropout "
+                                 "is not implemented)")
         steps = layer.feedforward.plan()
         if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
             raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")

@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -1126,6 +1126,26 @@ class GemmProbe:
 
     def reset(self):
         self._timers = []
+
+
+def dropout(x: torch.Tensor, p: float, seed: int, site: int, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            out_dtype: Optional[torch.dtype] = None, group: int = 0, want_mask: bool = False):
+    """out = (residual or 0) + x * keep / (1 - p) with the Philox mask of (seed, site) (mmamd_dropout); group > 0: one decision per sample of
+    `group` consecutive elements (stochastic depth).  `out` may be `x`.  The gradient of x is the same call on the incoming gradient.
+    want_mask: also return the uint8 keep mask (tests)."""
+    _chk(x, "x")
+    n = x.numel()
+    if residual is not None:
+        _chk(residual, "residual", torch.float32)
+        if residual.numel() != n:
+            raise MmamdError("dropout: residual must have the shape of x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype or (torch.float32 if residual is not None else x.dtype), device=x.device)
+    _chk(out, "out")
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_mask else None
+    check(_lib.lib().mmamd_dropout(x.data_ptr(), _dt(x), _ptr(residual), out.data_ptr(), _dt(out), _ptr(mask), n, int(group), float(p),
+                                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(site) & 0xFFFFFFFF, _stream()), "mmamd_dropout")
+    return (out, mask) if want_mask else out
 
 
 def image_resample(desc: torch.Tensor, tables: torch.Tensor, tmp: torch.Tensor, B: int, crop_h: int, crop_w: int, max_rows: int,

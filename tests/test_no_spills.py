@@ -23,7 +23,7 @@ def test_hot_kernels_do_not_spill():
     # instantiations that exist for API completeness but that no model path dispatches, and whose scratch use is known and accepted:
     #   * fp32 output WITH an activation (`<true, 1|2, ...>`: every activation on the path feeds a bf16 operand),
     #   * the plain (non-pipelined) 256 x 256 kernel: only the fallback for an odd number of 64-wide K-tiles
-    cold = ("gemm_bf16_nt_kernel<256, 256, 2, 4,", "gemm_bf16_nt_kernel_ppg<true, 1,", "gemm_bf16_nt_kernel_ppg<true, 2,",
+    cold = ("gemm_bf16_nt_kernel<256, 256, 2, 4,", "gemm_bf16_nt_kernel_ppg<true, 1>", "gemm_bf16_nt_kernel_ppg<true, 2>",
             "gemm_bf16_nt_kernel_pp<true, 1,", "gemm_bf16_nt_kernel_pp<true, 2,")
     for name, rc, rows in results:
         assert rc == 0, name
@@ -34,7 +34,7 @@ def test_hot_kernels_do_not_spill():
         assert all(r[1] <= 256 for r in rows), name  # unified VGPR/AGPR budget of a 2-waves-per-SIMD kernel
     # the kernels of the headline step must be among the checked ones (and clean)
     names = [demangle(r[0]) for r in results[0][2]]
-    for must in ("gemm_bf16_nt_kernel_ppg<true, 0, 8>", "gemm_bf16_nt_kernel_ppg<false, 0, 8>", "gemm_bf16_nt_kernel_ppg<false, 1, 8>",
+    for must in ("gemm_bf16_nt_kernel_ppg<true, 0>", "gemm_bf16_nt_kernel_ppg<false, 0>", "gemm_bf16_nt_kernel_ppg<false, 1>",
                  "gemm_bf16_nt_kernel_pp<true, 0, 8, 2, 4, 0, 0, 1, false, 1>"):
         assert any(must in n for n in names), must
 
