@@ -163,13 +163,15 @@ static int g_gemm_stagger = 60;
 // experiment knobs (mmamd_debug_set_gemm_knob): [0] tile-order group of the grouped kernel (0 = by CU budget, 4, 8); [1] slack-aware stagger, per cent; [2] walk order of the grouped kernel's two problems
 static int g_gemm_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-// tile-order group (GemmGroupArgs::gm).  Column tiles <= 4 (N <= 1024: out-projection, MLP-down, the dgrad of qkv / MLP-up): row-major, all
-// column tiles of a row panel at once.  Otherwise the 32 workgroups an XCD runs share 8 row panels x 4 column tiles (16 per XCD on a stream
-// with half the chip as its CU budget: 4 x 4).
+// tile-order group (GemmGroupArgs::gm / GemmArgs::gm): the workgroups an XCD runs concurrently walk gm row panels x all column tiles.  Measured
+// on MI355X (r04, profiles/r04_tile_order_ab.txt): gm = 2 is the best or within 0.5 % of it on all four projection pairs of the headline step
+// (step 13.39 ms with the r03 value 8, 13.30 with row-major order for N <= 1024 only, 13.25 with 2 everywhere): with few row panels per group
+// the column tiles of a panel run at the same time, in lock-step, and every K-slice of the panel is fetched into the XCD's L2 once -- MLP-down
+// (3 column tiles, a 1.5 MiB panel per 256 rows that no cache level keeps between rounds) 311 -> 301 us, the vision out-projection alone 93.6 -> 86.5 us.
 static int pick_gm(int tiles_n, int cus) {
   if (g_gemm_knob[0] != 0) return g_gemm_knob[0];
-  if (tiles_n <= 4) return 1;
-  return cus <= 160 ? 4 : 8;
+  (void)cus;
+  return tiles_n <= 4 ? 1 : 2;
 }
 
 static unsigned long long* g_gemm_trace = nullptr;
@@ -1695,7 +1697,7 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   const int ntiles = tiles_m * p.tiles_n;
   const int cus = stream_cus(st);                   // 256, or the CU partition of a masked stream (multiple of 8: whole XCD slices)
   const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
-  p.gm = (g_gemm_knob[0] != 0) ? g_gemm_knob[0] : (p.tiles_n <= 4 ? 1 : 0);
+  p.gm = pick_gm(p.tiles_n, cus);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, st, p, tiles_m, ntiles);
   return launch_status("gemm_bf16_pp");
 }

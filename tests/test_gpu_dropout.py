@@ -1,0 +1,161 @@
+"""Training-time dropout / stochastic depth on the MI355X path (csrc/dropout.hip, _autograd.py).  The reference draws its masks from torch's
+generator, so parity is stated per mask:
+  (i)   p = 0 is the unchanged path;  (ii) every mask equals the numpy Philox restatement BIT FOR BIT, keep-rate and the 1 / (1 - p) scaling exact;
+  (iii) with the masks known, forward and every gradient of an encoder stack equal the reference arithmetic applied with the same masks;
+  (iv)  the reference's default fine-tuning model (flava_model_for_classification: classifier_dropout = 0.5) runs a train-mode step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dropout_layers, philox
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,p,group", [(4096, 0.5, 0), (1 << 20, 0.1, 0), (12 * 4 * 64, 0.25, 4 * 64), (64, 0.0, 0), (1 << 16, 0.9, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_kernel_mask_equals_oracle(n, p, group, dtype):
+    from multimodal_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randn(n, device="cuda").to(dtype)
+    seed, site = 0x1234_5678_9ABC_DEF, 37
+    y, m = ops.dropout(x, p, seed, site, group=group, want_mask=True)
+    want = philox.dropout_mask(n, p, seed, site, group)
+    assert np.array_equal(m.cpu().numpy(), want)
+    ref = philox.dropout_apply(x.float().cpu().numpy(), want, p)
+    if dtype == torch.bfloat16:
+        ref = torch.from_numpy(ref).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(y.float().cpu().numpy(), ref)
+    if p > 0 and group == 0 and n >= 1 << 16:
+        assert abs(float(m.float().mean()) - (1 - p)) < 5 * np.sqrt(p * (1 - p) / n)
+    # residual form and the in-place form
+    r = torch.randn(n, device="cuda")
+    out = ops.dropout(x, p, seed, site, residual=r, group=group)
+    assert np.array_equal(out.cpu().numpy(), (r.cpu().numpy() + philox.dropout_apply(x.float().cpu().numpy(), want, p)).astype(np.float32))
+    x2 = x.clone()
+    ops.dropout(x2, p, seed, site, group=group, out=x2)
+    assert torch.equal(x2, y)
+
+
+def test_dropout_fn_backward_uses_the_same_mask():
+    from multimodal_amd._autograd import DropoutFn
+
+    x = torch.randn(8, 96, device="cuda", requires_grad=True)
+    y = DropoutFn.apply(x, 0.3, 99, 5, 0)
+    g = torch.randn_like(y)
+    y.backward(g)
+    m = torch.from_numpy(philox.dropout_mask(x.numel(), 0.3, 99, 5).reshape(8, 96)).cuda().float()
+    scale = float(np.float32(1) / (np.float32(1) - np.float32(0.3)))
+    assert torch.equal(x.grad, torch.where(m != 0, g * scale, torch.zeros_like(g)))
+
+
+def _encoder_pair(dropout, drop_path, n_layer=2, d=128, heads=2, ff=256):
+    from multimodal_amd.modules.layers.transformer import TransformerEncoder
+
+    torch.manual_seed(3)
+    enc = TransformerEncoder(n_layer, d, heads, ff, dropout=dropout, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True,
+                             drop_path_rate=drop_path).cuda().train()
+    layers = []
+    for layer in enc.layer:
+        lin1, lin2 = layer.feedforward.model[0], layer.feedforward.model[-1]
+        f = lambda t: t.detach().cpu().clone().requires_grad_(True)  # noqa: E731
+        layers.append({"Wqkv": f(layer.attention.input_proj.weight), "bqkv": f(layer.attention.input_proj.bias),
+                       "Wo": f(layer.attention.output_proj.weight), "bo": f(layer.attention.output_proj.bias), "W1": f(lin1.weight),
+                       "b1": f(lin1.bias), "W2": f(lin2.weight), "b2": f(lin2.bias), "g1": f(layer.attention_layernorm.weight),
+                       "be1": f(layer.attention_layernorm.bias), "g2": f(layer.feedforward_layernorm.weight),
+                       "be2": f(layer.feedforward_layernorm.bias), "eps1": layer.attention_layernorm.eps, "eps2": layer.feedforward_layernorm.eps})
+    return enc, layers
+
+
+@pytest.mark.parametrize("dropout,drop_path", [(0.1, None), (0.0, 0.4), (0.25, 0.3)])
+def test_encoder_stack_with_known_masks(dropout, drop_path):
+    enc, layers = _encoder_pair(dropout, drop_path)
+    B, S, d = 8, 16, 128
+    torch.manual_seed(11)
+    x = torch.randn(B, S, d)
+    gout = torch.randn(B, S, d)
+    # the seed the forward will draw: same generator state, same draw (multimodal_amd/_autograd.py::draw_seed)
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    torch.manual_seed(77)
+    xg = x.cuda().requires_grad_(True)
+    y = enc(xg).last_hidden_state
+    y.backward(gout.cuda())
+    rates = None if drop_path is None else [float(v) for v in torch.linspace(0, drop_path, len(layers))]
+    # a layer whose stochastic-depth rate is 0 keeps every sample (p = 0 -> identity); its branch dropout is replaced all the same
+    xr = x.clone().requires_grad_(True)
+    yr = dropout_layers.encoder_forward(xr, layers, 2, 0.0 if drop_path is not None else dropout, dropout, rates, seed)
+    yr.backward(gout)
+    scale = float(yr.abs().max())
+    assert float((y.detach().cpu() - yr.detach()).abs().max()) < 2e-2 * scale
+    gscale = float(xr.grad.abs().max())
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 4e-2 * gscale
+    for li, layer in enumerate(enc.layer):
+        got = {"Wqkv": layer.attention.input_proj.weight.grad, "Wo": layer.attention.output_proj.weight.grad,
+               "W1": layer.feedforward.model[0].weight.grad, "W2": layer.feedforward.model[-1].weight.grad,
+               "b2": layer.feedforward.model[-1].bias.grad, "bo": layer.attention.output_proj.bias.grad, "g2": layer.feedforward_layernorm.weight.grad}
+        for k, gten in got.items():
+            ref = layers[li][k].grad
+            assert float((gten.cpu() - ref).abs().max()) < 5e-2 * float(ref.abs().max()) + 1e-6, (li, k)
+    # dropped samples / elements really are dropped: with p_branch > 0 the forward differs from the no-dropout forward
+    enc.eval()
+    with torch.no_grad():
+        y0 = enc(x.cuda()).last_hidden_state
+    assert float((y0 - y.detach()).abs().max()) > 1e-3
+
+
+def test_zero_rates_take_the_unchanged_path():
+    from multimodal_amd._autograd import stack_drop_spec
+
+    enc, _ = _encoder_pair(0.0, None)
+    assert stack_drop_spec(enc.layer) == ([], 0)
+    enc2, _ = _encoder_pair(0.0, 0.0)  # stochastic depth with rate 0 everywhere
+    assert stack_drop_spec(enc2.layer) == ([], 0)
+
+
+def test_stochastic_depth_module_row_mode():
+    from multimodal_amd.modules.layers.stochastic_depth import StochasticDepth
+
+    sd = StochasticDepth(0.5, "row").cuda()
+    x = torch.randn(64, 8, 32, device="cuda")
+    sd.eval()
+    assert sd(x) is x
+    sd.train()
+    y = sd(x)
+    per_sample = (y.reshape(64, -1).abs().sum(1) == 0)
+    assert 10 < int(per_sample.sum()) < 54                      # about half of the samples dropped ...
+    kept = ~per_sample
+    assert torch.equal(y[kept], x[kept] * 2.0)                  # ... survivors scaled by 1 / (1 - p), whole samples at a time
+    with pytest.raises(ValueError):
+        StochasticDepth(0.5, "column")
+
+
+def test_flava_classification_default_model_trains():
+    """reference models/flava/model.py:551: classifier_dropout = 0.5 is the DEFAULT of flava_model_for_classification."""
+    from multimodal_amd.models.flava.model import flava_model_for_classification
+
+    torch.manual_seed(0)
+    model = flava_model_for_classification(num_classes=3, image_num_hidden_layers=1, image_num_attention_heads=2, image_hidden_size=128,
+                                           image_intermediate_size=256, text_num_hidden_layers=1, text_num_attention_heads=2,
+                                           text_hidden_size=128, text_intermediate_size=256, multimodal_num_hidden_layers=1,
+                                           multimodal_num_attention_heads=2, multimodal_hidden_size=128, multimodal_intermediate_size=256,
+                                           image_size=32, patch_size=16, classifier_in_dim=128, classifier_hidden_sizes=(64,)).cuda().train()
+    assert model.classifier.hidden_dropout_p() == 0.5
+    image = torch.randn(4, 3, 32, 32, device="cuda")
+    text = torch.randint(1, 1000, (4, 16), device="cuda")
+    labels = torch.tensor([0, 1, 2, 1], device="cuda")
+    out = model(image=image, text=text, required_embedding="mm", labels=labels)
+    out.loss.backward()
+    grads = [p.grad for p in model.classifier.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+    assert any(float(g.abs().max()) > 0 for g in grads)
+    # two train-mode forwards differ (fresh masks), eval-mode forwards do not
+    l1 = float(model(image=image, text=text, required_embedding="mm", labels=labels).loss)
+    l2 = float(model(image=image, text=text, required_embedding="mm", labels=labels).loss)
+    assert l1 != l2
+    model.eval()
+    with torch.no_grad():
+        e1 = float(model(image=image, text=text, required_embedding="mm", labels=labels).loss)
+        e2 = float(model(image=image, text=text, required_embedding="mm", labels=labels).loss)
+    assert e1 == e2

@@ -78,8 +78,17 @@ def test_coca_records_and_loud_failures():
     m.eval()
     with pytest.raises(ValueError, match="divisible by patch size"):
         PatchEmbeddings(image_size=30, patch_size=16)
-    with pytest.raises(ops.MmamdError, match="drop_path_rate"):
-        TransformerEncoder(1, 128, 2, 256, drop_path_rate=0.1)
+    # stochastic depth is built like the reference builds it (transformer.py:64-67,190-193): ONE StochasticDepth(mode="row") on both residual
+    # branches of a layer, the rate growing linearly with depth; no parameters, so the state_dict is the dropout-free one
+    from multimodal_amd.modules.layers.stochastic_depth import StochasticDepth
+
+    sd_enc = TransformerEncoder(3, 128, 2, 256, drop_path_rate=0.2)
+    assert [l.attention_dropout.p for l in sd_enc.layer] == pytest.approx([0.0, 0.1, 0.2])
+    assert all(isinstance(l.attention_dropout, StochasticDepth) and l.attention_dropout is l.feedforward_dropout and l.attention_dropout.mode == "row"
+               for l in sd_enc.layer)
+    assert set(sd_enc.state_dict()) == set(TransformerEncoder(3, 128, 2, 256).state_dict())
+    x_cpu = torch.randn(2, 3, 8)
+    assert StochasticDepth(0.5, "row").eval()(x_cpu) is x_cpu and StochasticDepth(0.0, "row").train()(x_cpu) is x_cpu
     with pytest.raises(ops.MmamdError, match="boolean"):
         to_attn_mask(torch.zeros(2, 4, 4), False, 2, 4, 4)
     with pytest.raises(ops.MmamdError, match="per-head"):
