@@ -78,8 +78,8 @@ class StackConfig:
         self.drop, self.seed = [float(v) for v in (drop or [])], int(seed)
         self.eps1, self.eps2, self.ppl = list(eps1), list(eps2), params_per_layer
         self.to_canonical, self.from_canonical, self.key_mask = to_canonical, from_canonical, key_mask
-        self.keep_hidden = keep_hidden
-        self.hidden: List[Tensor] = []  # inputs of every layer (detached), filled by the forward when keep_hidden
+        self.keep_hidden = keep_hidden  # the node then returns (x_L, inputs of layers 1 .. N-1) and fills `qkv`
+        self.qkv: List[Tensor] = []
 
 
 def draw_seed() -> int:
@@ -236,8 +236,10 @@ _ACT_GRAD = {ops.ACT_QUICKGELU: ops.ACT_MUL_QUICKGELU_GRAD, ops.ACT_GELU_ERF: op
 
 
 def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: List[Tensor], n_head: int, B: int, S: int, causal: bool,
-                    act: int, eps1: List[float], eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int) -> List[Tensor]:
-    """Backward of _stack_fwd_impl: saved = its outputs [1:].  Returns [dX0] + the 12 canonical gradients per layer."""
+                    act: int, eps1: List[float], eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int,
+                    dhidden: List[Optional[Tensor]]) -> List[Tensor]:
+    """Backward of _stack_fwd_impl: saved = its outputs [1:].  Returns [dX0] + the 12 canonical gradients per layer.  dhidden (empty, or one
+    entry per layer 1 .. N-1): gradients that arrived through the intermediate hidden states the forward handed out (None = unused)."""
     H = n_head
     n_layers = len(params) // 12
     inputs = [x0] + list(saved[8 * n_layers:9 * n_layers - 1])
@@ -279,13 +281,19 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         dh1 = dgrad_t(dqkv, WqkvT, f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
         dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
+        if li > 0 and dhidden and dhidden[li - 1] is not None:
+            # this layer's input was also handed out as hidden_states[li] and something differentiated through it: dX += that gradient
+            # (mmamd_dropout with p = 0 is the fp32 add kernel); the bf16 copy / column sums of dX made above are stale
+            extra = dhidden[li - 1].detach()
+            dX = ops.dropout(extra if extra.is_contiguous() else extra.contiguous(), 0.0, 0, 0, residual=dX)
+            dXb, dXsum = None, None
         grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
     if n_layers == 0:
         dX = dx_out.clone()  # (no alias of an input, see _stack_fwd_impl)
     return [dX] + grads
 
 
-def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed):
+def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden):
     return [torch.empty_like(x0)] + [torch.empty_like(p) for p in params]
 
 
@@ -293,7 +301,7 @@ from ._custom_op import define as _define  # noqa: E402
 
 _STACK_SCALARS = "int n_head, int B, int S, bool causal, int act, float[] eps1, float[] eps2, Tensor? key_mask, float[] drop, int seed"
 stack_fwd_op = _define("encoder_stack_fwd", f"(Tensor x0, Tensor[] params, {_STACK_SCALARS}) -> Tensor[]", _stack_fwd_impl, _stack_fwd_fake)
-stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}) -> Tensor[]",
+stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}, Tensor?[] dhidden) -> Tensor[]",
                        _stack_bwd_impl, _stack_bwd_fake)
 
 
@@ -310,24 +318,37 @@ class EncoderStackFn(torch.autograd.Function):
         for li in range(cfg.n_layers):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
         outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop, cfg.seed)
-        if cfg.keep_hidden:
-            cfg.hidden.extend([x] + list(outs[1 + 8 * cfg.n_layers:9 * cfg.n_layers]) + [outs[0]])
         ctx.save_for_backward(x, *outs[1:], *params)
         ctx.cfg, ctx.nparam = cfg, len(params)
+        ctx.set_materialize_grads(False)
+        if cfg.keep_hidden:
+            # the inputs of layers 1 .. N-1 are OUTPUTS of this node too: hidden_states[1 .. N-1] of the reference's TransformerOutput stay
+            # attached to the graph in training like the reference's (models/flava/transformer.py:254-259); hidden_states[0] is the caller's own
+            # input tensor and hidden_states[N] the result.  cfg.qkv: the packed projections of every layer, for callers that also hand out
+            # attention probabilities in training (they recompute them from here, detached)
+            mids = list(outs[1 + 8 * cfg.n_layers:9 * cfg.n_layers])
+            cfg.qkv = [outs[1 + 8 * li + 1] for li in range(cfg.n_layers)]
+            ctx.n_mid = len(mids)
+            return (outs[0], *mids)
+        ctx.n_mid = -1
         return outs[0]
 
     @staticmethod
-    def backward(ctx, dx_out: Tensor):
+    def backward(ctx, dx_out, *dmid):
         cfg, nparam = ctx.cfg, ctx.nparam
         tensors = ctx.saved_tensors
         x0, saved, params = tensors[0], tensors[1:len(tensors) - nparam], tensors[len(tensors) - nparam:]
-        dX = dx_out.detach()
-        dX = dX if dX.is_contiguous() else dX.contiguous()
+        if dx_out is None:  # only intermediate hidden states were differentiated
+            dX = torch.zeros_like(x0)  # memset
+        else:
+            dX = dx_out.detach()
+            dX = dX if dX.is_contiguous() else dX.contiguous()
         canon: List[Tensor] = []
         for li in range(cfg.n_layers):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
+        dhidden = list(dmid) if any(d is not None for d in dmid) else []
         outs = stack_bwd_op(dX, x0, list(saved), canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop,
-                            cfg.seed)
+                            cfg.seed, dhidden)
         grads: List[Optional[Tensor]] = [None] * nparam
         for li in range(cfg.n_layers):
             grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical(list(outs[1 + 12 * li:13 + 12 * li]))

@@ -151,8 +151,12 @@ def _from_canonical(g: List[Tensor]):
             dg2, dbe2]
 
 
-def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool):
-    """Differentiable pass through a flava.TransformerEncoder.  Returns (x_L [B,S,d], hidden states (detached) or None)."""
+def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool, want_probs: bool = False):
+    """Differentiable pass through a flava.TransformerEncoder.  Returns (x_L [B,S,d], hidden states or None, attention probabilities or None).
+    keep_hidden: ALL hidden states, attached to the graph (the input, the input of every further layer, the result) like the reference's
+    training forward (models/flava/transformer.py:254-259).  want_probs: the per-layer attention probabilities [B,H,S,S] fp32, recomputed from
+    each layer's saved projections by the inference kernel (mmamd_attention_probs_fwd) -- values as in eval mode, NOT differentiable (the
+    reference's are; nothing in its models or losses differentiates through returned attention maps)."""
     from ...modules.layers.mlp import fused_activation_code
 
     B, S, d = x.shape
@@ -178,7 +182,13 @@ def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: boo
     drop, seed = stack_drop_spec(encoder.layer, attn_p=lambda l: l.attention.attn.attn_dropout)
     cfg = StackConfig(len(encoder.layer), encoder.layer[0].attention.n_head, B, S, False, act, eps1, eps2, 16, _to_canonical,
                       _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden, drop=drop, seed=seed)
+    cfg.keep_hidden = keep_hidden or want_probs
     xc = x if x.is_contiguous() else x.contiguous()
-    y = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)
-    hidden = [h.view(B, S, d) for h in cfg.hidden] if keep_hidden else None
-    return y.view(B, S, d), hidden
+    res = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)
+    y = (res[0] if cfg.keep_hidden else res).view(B, S, d)
+    hidden = [x] + [h.view(B, S, d) for h in res[1:]] + [y] if keep_hidden else None
+    probs = None
+    if want_probs:
+        H = cfg.n_head
+        probs = [ops.attention_probs_fwd(q, B, S, H, key_mask)[1] for q in cfg.qkv]
+    return y, hidden, probs

@@ -162,16 +162,17 @@ class TransformerEncoder(nn.Module):
             raise ops.MmamdError("TransformerEncoder on the MI355X path takes fp32 [b, seq, c] hidden states")
         B, S, d = hidden_states.shape
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
-            # differentiable forward (models/flava/_train.py): attention probabilities are not produced in this mode
+            # differentiable forward (models/flava/_train.py): every hidden state attached to the graph, attention probabilities as values
+            # (schedule.train_attentions = False skips their recomputation: attentions = None, the r03 behaviour)
+            from ...schedule import get_schedule
             from ._train import run_encoder
 
             km = key_mask_from_attention_mask(attention_mask, B, S)
-            x, hidden = run_encoder(self, hidden_states, km, return_hidden_states)
-            if hidden is not None:
-                hidden[-1] = x  # the last entry feeds FLAVA's multimodal encoder: keep it attached to the graph
+            want_probs = return_attn_weights and get_schedule().train_attentions
+            x, hidden, probs = run_encoder(self, hidden_states, km, return_hidden_states, want_probs)
             if self.final_layer_norm is not None:
                 x = self.final_layer_norm(x)
-            return TransformerOutput(last_hidden_state=x, hidden_states=hidden, attentions=None)
+            return TransformerOutput(last_hidden_state=x, hidden_states=hidden, attentions=probs)
         x = (hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()).view(B * S, d)
         km = key_mask_from_attention_mask(attention_mask, B, S)
         all_hidden_states: Optional[List[Tensor]] = [] if return_hidden_states else None

@@ -210,11 +210,13 @@ def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_h
     cfg = StackConfig(len(self.layer), self.layer[0].attention.num_heads, B, S, False, act, eps1, eps2, 12, ident, ident,
                       keep_hidden=return_hidden_states, drop=drop, seed=seed)
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
-    x = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params).view(B, S, d)
+    res = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)
     hidden = None
-    if return_hidden_states:
-        hidden = [h.view(B, S, d) for h in cfg.hidden]
-        hidden[-1] = x
+    if return_hidden_states:  # every entry attached to the graph, like the reference's (:230-247): the input, the layer inputs, the result
+        x = res[0].view(B, S, d)
+        hidden = [hidden_states] + [h.view(B, S, d) for h in res[1:]] + [x]
+    else:
+        x = res.view(B, S, d)
     if self.final_layer_norm is not None:
         x = self.final_layer_norm(x)
     return TransformerOutput(last_hidden_state=x, hidden_states=hidden)

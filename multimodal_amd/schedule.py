@@ -18,6 +18,10 @@ Every choice is between paths that compute the same function; the defaults are t
                                                   on two streams with half the chip's CUs each, the second `phase_lead` launches behind the first, so
                                                   that one half's HBM-bound kernels run beside the other's matrix-bound ones
 
+    train_attentions  True | False                FLAVA training forwards also return the per-layer attention probabilities (recomputed by the
+                                                  inference kernel, detached) like the reference's; False: attentions = None (saves one attention
+                                                  launch per layer and the S^2 writes)
+
 Environment (read once): MMAMD_TWO_TOWER, MMAMD_RESIDUAL (epilogue | delta_ln), MMAMD_SINGLE_STREAM=1, MMAMD_PHASES (1 | 2).
 """
 from __future__ import annotations
@@ -38,6 +42,7 @@ class Schedule:
     train_side_stream: bool = True
     phases: int = 1
     phase_lead: int = 4
+    train_attentions: bool = True
 
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:

@@ -87,7 +87,7 @@ def test_encoder_stack_with_known_masks(dropout, drop_path):
     xr = x.clone().requires_grad_(True)
     yr = dropout_layers.encoder_forward(xr, layers, 2, 0.0 if drop_path is not None else dropout, dropout, rates, seed)
     yr.backward(gout)
-    scale = float(yr.abs().max())
+    scale = float(yr.detach().abs().max())
     assert float((y.detach().cpu() - yr.detach()).abs().max()) < 2e-2 * scale
     gscale = float(xr.grad.abs().max())
     assert float((xg.grad.cpu() - xr.grad).abs().max()) < 4e-2 * gscale
@@ -136,14 +136,14 @@ def test_flava_classification_default_model_trains():
     from multimodal_amd.models.flava.model import flava_model_for_classification
 
     torch.manual_seed(0)
-    model = flava_model_for_classification(num_classes=3, image_num_hidden_layers=1, image_num_attention_heads=2, image_hidden_size=128,
-                                           image_intermediate_size=256, text_num_hidden_layers=1, text_num_attention_heads=2,
-                                           text_hidden_size=128, text_intermediate_size=256, multimodal_num_hidden_layers=1,
-                                           multimodal_num_attention_heads=2, multimodal_hidden_size=128, multimodal_intermediate_size=256,
-                                           image_size=32, patch_size=16, classifier_in_dim=128, classifier_hidden_sizes=(64,)).cuda().train()
+    small = dict(image_hidden_size=128, image_num_attention_heads=2, image_num_hidden_layers=2, image_intermediate_size=256, image_size=32,
+                 patch_size=16, text_hidden_size=128, text_num_attention_heads=2, text_num_hidden_layers=2, text_intermediate_size=256,
+                 vocab_size=200, max_position_embeddings=32, multimodal_hidden_size=128, multimodal_num_attention_heads=2,
+                 multimodal_num_hidden_layers=2, multimodal_intermediate_size=256, text_and_image_proj_size=64)
+    model = flava_model_for_classification(num_classes=3, classifier_in_dim=128, classifier_hidden_sizes=64, pretrained=False, **small).cuda().train()
     assert model.classifier.hidden_dropout_p() == 0.5
     image = torch.randn(4, 3, 32, 32, device="cuda")
-    text = torch.randint(1, 1000, (4, 16), device="cuda")
+    text = torch.randint(1, 200, (4, 16), device="cuda")
     labels = torch.tensor([0, 1, 2, 1], device="cuda")
     out = model(image=image, text=text, required_embedding="mm", labels=labels)
     out.loss.backward()
@@ -159,3 +159,77 @@ def test_flava_classification_default_model_trains():
         e1 = float(model(image=image, text=text, required_embedding="mm", labels=labels).loss)
         e2 = float(model(image=image, text=text, required_embedding="mm", labels=labels).loss)
     assert e1 == e2
+
+
+def test_training_forward_hands_out_attached_hidden_states():
+    """VERDICT r03 missing #4: the training forwards return every hidden state attached to the graph (reference transformer.py:230-247,
+    flava/transformer.py:254-259).  A gradient that enters through hidden_states[1] of a 2-layer stack must equal the gradient of the same
+    loss on a 1-layer stack with layer 0's weights; adding it to a loss on the result must give the sum of the two gradients."""
+    import copy
+
+    from multimodal_amd.modules.layers.transformer import TransformerEncoder
+
+    torch.manual_seed(5)
+    enc2 = TransformerEncoder(2, 128, 2, 256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True).cuda().train()
+    enc1 = TransformerEncoder(1, 128, 2, 256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True).cuda().train()
+    enc1.layer[0].load_state_dict(copy.deepcopy(enc2.layer[0].state_dict()))
+    x = torch.randn(4, 16, 128, device="cuda")
+    w = torch.randn(4, 16, 128, device="cuda")
+
+    def grads(enc):
+        return [p.grad.clone() for p in enc.layer[0].parameters()]
+
+    out = enc2(x, return_hidden_states=True)
+    hs = out.hidden_states
+    assert len(hs) == 3 and hs[0] is x and all(h.requires_grad for h in hs[1:]) and hs[2] is out.last_hidden_state
+    (hs[1] * w).sum().backward()
+    g_mid = grads(enc2)
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0 for p in enc2.layer[1].parameters())  # layer 1 is not on that path
+    o1 = enc1(x)
+    (o1.last_hidden_state * w).sum().backward()
+    for a, b in zip(g_mid, grads(enc1)):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-5 * float(b.abs().max() + 1))
+    # both routes at once: d/dtheta [sum(h1 w) + sum(h2 w)] = the sum of the separate gradients
+    enc2.zero_grad()
+    out = enc2(x, return_hidden_states=True)
+    (out.last_hidden_state * w).sum().backward()
+    g_end = grads(enc2)
+    enc2.zero_grad()
+    out = enc2(x, return_hidden_states=True)
+    ((out.hidden_states[1] * w).sum() + (out.last_hidden_state * w).sum()).backward()
+    for got, a, b in zip(grads(enc2), g_mid, g_end):
+        assert float((got - (a + b)).abs().max()) <= 2e-2 * float((a + b).abs().max()) + 1e-6
+
+
+def test_flava_training_forward_returns_attentions_and_hidden_states():
+    from multimodal_amd.models.flava.model import flava_model
+    from multimodal_amd.schedule import get_schedule, set_schedule
+
+    torch.manual_seed(0)
+    small = dict(image_hidden_size=128, image_num_attention_heads=2, image_num_hidden_layers=2, image_intermediate_size=256, image_size=32,
+                 patch_size=16, text_hidden_size=128, text_num_attention_heads=2, text_num_hidden_layers=2, text_intermediate_size=256,
+                 vocab_size=200, max_position_embeddings=32, multimodal_hidden_size=128, multimodal_num_attention_heads=2,
+                 multimodal_num_hidden_layers=2, multimodal_intermediate_size=256, text_and_image_proj_size=64)
+    model = flava_model(**small).cuda()
+    image = torch.randn(4, 3, 32, 32, device="cuda")
+    text = torch.randint(1, 200, (4, 16), device="cuda")
+    model.eval()
+    with torch.no_grad():
+        ref = model(image=image, text=text, skip_unmasked_mm_encoder=False)
+    model.train()
+    out = model(image=image, text=text, skip_unmasked_mm_encoder=False)
+    for name in ("image", "text", "multimodal"):
+        tr, ev = getattr(out, name), getattr(ref, name)
+        assert len(tr.hidden_states) == len(ev.hidden_states) == 3 and len(tr.attentions) == len(ev.attentions) == 2
+        assert all(h.requires_grad for h in tr.hidden_states[1:])
+        for a, b in zip(tr.attentions, ev.attentions):
+            assert a.shape == b.shape and a.dtype == b.dtype and not a.requires_grad
+            assert float((a - b).abs().max()) < 2e-3  # same weights, same inputs: the eval-mode probabilities
+        for a, b in zip(tr.hidden_states, ev.hidden_states):
+            assert float((a.detach() - b).abs().max()) < 2e-2 * float(b.abs().max())
+    prev = get_schedule()
+    try:
+        set_schedule(train_attentions=False)
+        assert model(image=image, text=text).image.attentions is None
+    finally:
+        set_schedule(train_attentions=prev.train_attentions)
