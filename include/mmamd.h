@@ -236,6 +236,9 @@ int mmamd_embed_tokens(const int64_t* ids, const void* table, int table_dtype, c
 /* out[i] = 1 where key i may be attended, 0 where it is padding.  kind 0: src = int64 token ids, keep = (id != pad_id);
  * kind 1/2/3: src = float32 / int64 / uint8-bool mask, keep = (value != 0).  Replaces the mask construction of
  * modules/encoders/bert_text_encoder.py:84-91 (+ utils/attention.py:13-52). */
+/* out[b][c] = mean over tokens first .. S-1 of x[b][s][c], x fp32 [B,S,d], d % 4 == 0 (GlobalAveragePooler: reference
+ * modules/encoders/vision_transformer.py:117-127 averages the patch rows and skips the CLS row, first = 1). */
+int mmamd_token_mean(const float* x, float* out, int B, int S, int d, int first, mmamd_stream_t stream);
 int mmamd_key_mask(const void* src, int kind, int64_t pad_id, uint8_t* out, int64_t n, mmamd_stream_t stream);
 
 /* CoCa text embeddings: x[b,s] = table[ids[b,s]] + pos[s] (s < S_ids); x[b,S_ids] = cls + pos[S_ids] when cls != NULL.

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "mmamd_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_coca_text_embed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_coca_text_mask": (_i, [_vp, _i, _i64, _vp, _i, _i, _vp]),
+    "mmamd_token_mean": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_key_mask": (_i, [_vp, _i, _i64, _vp, _i64, _vp]),
     "mmamd_bert_embed_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmamd_flava_image_embed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

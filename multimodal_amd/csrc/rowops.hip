@@ -1149,6 +1149,36 @@ extern "C" int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_
   return launch_status("convert");
 }
 
+// ---------------------------------------------------------------------------------------------
+// token mean: out[b][c] = mean over tokens first .. S-1 of x[b][s][c] (GlobalAveragePooler, modules/encoders/vision_transformer.py:117-127:
+// the CLS row is skipped).  One thread per 4 columns of a sample, tokens summed in order (deterministic), coalesced across the row.
+// ---------------------------------------------------------------------------------------------
+namespace mmamd {
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int S, int d, int first) {
+  const int b = blockIdx.y, c4 = blockIdx.x * 256 + threadIdx.x;
+  if (4 * c4 >= d) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* base = x + (size_t)b * S * d + 4 * c4;
+  for (int s = first; s < S; ++s) {
+    const f32x4 v = load4(base + (size_t)s * d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += v[j];
+  }
+  const float inv = 1.0f / (float)(S - first);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] *= inv;
+  store4(out + (size_t)b * d + 4 * c4, acc);
+}
+}  // namespace mmamd
+
+extern "C" int mmamd_token_mean(const float* x, float* out, int B, int S, int d, int first, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(x && out && B >= 0 && S > 0 && d > 0 && first >= 0 && first < S, MMAMD_E_BADARG, "token_mean: bad argument");
+  MMAMD_CHECK_ARG(d % 4 == 0 && aligned16(x) && aligned16(out), MMAMD_E_ALIGN, "token_mean: d %% 4 == 0 and 16-byte aligned pointers");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(mmamd::token_mean_kernel, dim3((d / 4 + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, out, S, d, first);
+  return mmamd::launch_status("token_mean");
+}
+
 extern "C" int mmamd_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const int64_t* pos_ids, const float* word,
                                    const float* pos, const float* type, const float* gamma, const float* beta, float eps, float* x,
                                    int B, int S, int d, int vocab, int max_pos, int n_types, mmamd_stream_t stream) {

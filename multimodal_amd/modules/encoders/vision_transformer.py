@@ -7,6 +7,8 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
+from ..._autograd import forbid_detached_forward
+from ..._packing import PackedCache
 from ...utils.common import load_module_from_url
 from ..layers.patch_embedding import PatchEmbeddings
 from ..layers.transformer import TransformerEncoder, TransformerOutput
@@ -37,8 +39,8 @@ class VisionTransformer(nn.Module):
 
 
 class GlobalAveragePooler(nn.Module):
-    """Mean over the patch rows + LayerNorm + optional head (reference :89-127).  Not on the contrastive path: the parameters
-    are mirrored for checkpoint compatibility, forward raises."""
+    """Mean over the patch rows (the CLS row is skipped) + LayerNorm + optional Linear head (reference :89-127).  Three kernels: the token
+    mean (mmamd_token_mean), the LayerNorm on the B pooled rows, the head in exact fp32 (mmamd_rows_linear_f32).  Inference form."""
 
     def __init__(self, input_dim: int, output_dim: Optional[int] = None, ln_eps: float = 1e-6,
                  init_weights: Optional[Callable] = None) -> None:
@@ -50,9 +52,21 @@ class GlobalAveragePooler(nn.Module):
             self.head = nn.Identity()
         if init_weights is not None:
             self.apply(init_weights)
+        self._packed = PackedCache()
 
     def forward(self, x: Tensor) -> Tensor:
-        raise ops.MmamdError("GlobalAveragePooler is not implemented on the MI355X path (not used by CLIP / FLAVA / CoCa)")
+        forbid_detached_forward(self, x)
+        if x.dim() != 3 or x.dtype != torch.float32:
+            raise ops.MmamdError("GlobalAveragePooler on the MI355X path takes fp32 [bsz, len, input_dim]")
+        if x.shape[1] < 2:
+            raise ops.MmamdError("GlobalAveragePooler averages the rows behind the CLS row: the sequence needs at least 2 rows")
+        pk, f32 = self._packed.get, torch.float32
+        out = ops.token_mean(x if x.is_contiguous() else x.contiguous(), first=1)
+        out = ops.layernorm(out, pk(self.norm.weight, f32), pk(self.norm.bias, f32), self.norm.eps, out_dtype=f32)
+        if isinstance(self.head, nn.Linear):
+            b = pk(self.head.bias, f32) if self.head.bias is not None else None
+            out = ops.rows_linear_f32(out, out.shape[1], out.shape[0], pk(self.head.weight, f32), b)
+        return out
 
 
 def vision_transformer(

@@ -45,12 +45,31 @@ class BERTTextEmbeddings(nn.Module):
         position_ids: Optional[Tensor] = None,
         inputs_embeds: Optional[Tensor] = None,
     ) -> Tensor:
-        if input_ids is None:
-            if inputs_embeds is None:
-                raise ValueError("input_ids or inputs_embeds must not be None")
-            raise ops.MmamdError("inputs_embeds is not implemented on the MI355X path (pass input_ids)")
+        if input_ids is None and inputs_embeds is None:
+            raise ValueError("input_ids or inputs_embeds must not be None")
         if inputs_embeds is not None:
-            raise ops.MmamdError("inputs_embeds is not implemented on the MI355X path (pass input_ids)")
+            # reference :95-101: the caller's embeddings take the place of the word-embedding rows (input_ids, if also given, then only feed the
+            # position ids).  Inference form: the rows are read in place by the embedding kernel (row r of a [B*S, d] "table", id = r).
+            if self.training and torch.is_grad_enabled() and (inputs_embeds.requires_grad or self.word_embeddings.weight.requires_grad):
+                raise ops.MmamdError("inputs_embeds has no differentiable forward on the MI355X path (training takes input_ids); "
+                                     "call .eval() / torch.no_grad() for inference")
+            if inputs_embeds.dim() != 3 or inputs_embeds.dtype != torch.float32 or inputs_embeds.shape[-1] != self.word_embeddings.embedding_dim:
+                raise ops.MmamdError(f"inputs_embeds must be fp32 [bsz, seq_len, {self.word_embeddings.embedding_dim}]")
+            if self.training and self.dropout.p > 0:
+                raise ops.MmamdError("embedding dropout applies on the differentiable (train mode, grad enabled) forward only: call .eval() for inference")
+            B, S, d = inputs_embeds.shape
+            if position_ids is None and self.offset_pos_ids:
+                if input_ids is None:
+                    raise ValueError("offset position ids are derived from input_ids")  # (the reference dereferences None here, :88-89)
+                position_ids = self.create_position_ids_from_input_ids(input_ids)
+            if position_ids is not None and tuple(position_ids.shape) != (B, S):
+                position_ids = position_ids.expand(B, S).contiguous()
+            rows = (inputs_embeds if inputs_embeds.is_contiguous() else inputs_embeds.contiguous()).view(B * S, d)
+            row_ids = torch.arange(B * S, dtype=torch.int64, device=rows.device).view(B, S)  # index bookkeeping: table row of every token
+            pk, f32 = self._packed.get, torch.float32
+            x = ops.bert_embed_ln(row_ids, rows, pk(self.position_embeddings.weight, f32), pk(self.token_type_embeddings.weight, f32),
+                                  pk(self.layer_norm.weight, f32), pk(self.layer_norm.bias, f32), self.layer_norm.eps, token_type_ids, position_ids)
+            return x.view(B, S, -1)
         if self.offset_pos_ids and position_ids is None:
             position_ids = self.create_position_ids_from_input_ids(input_ids)  # reference :88-89
         B, S = input_ids.shape

@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -525,6 +525,17 @@ def bert_embed_ln(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, typ:
                                          x.data_ptr(), B, S, d, word.shape[0], pos.shape[0], typ.shape[0], _stream()),
           "mmamd_bert_embed_ln")
     return x
+
+
+def token_mean(x: torch.Tensor, first: int = 0) -> torch.Tensor:
+    """mean over tokens first .. S-1 of an fp32 [B, S, d] tensor -> fp32 [B, d] (mmamd_token_mean)."""
+    _chk(x, "x", torch.float32)
+    if x.dim() != 3:
+        raise MmamdError("token_mean expects [bsz, seq_len, d]")
+    B, S, d = x.shape
+    out = torch.empty((B, d), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmamd_token_mean(x.data_ptr(), out.data_ptr(), B, S, d, int(first), _stream()), "mmamd_token_mean")
+    return out
 
 
 def flava_image_embed(patch_emb: torch.Tensor, cls: Optional[torch.Tensor], pos: torch.Tensor, B: int, G2: int,

@@ -263,7 +263,8 @@ def test_flava_training_step_gradients_vs_reference_autograd(golden):
     loss_mod = FLAVAGlobalContrastiveLoss().cuda()
     image, text, text_masked = (torch.from_numpy(z[k]).cuda() for k in ("image", "text", "text_masked"))
     out = model(image, text, text_masked=text_masked)
-    assert out.image.attentions is None and len(out.image.hidden_states) == 3  # training mode: no probabilities
+    # training mode hands out what the reference does: every hidden state (attached) and the attention probabilities (values)
+    assert len(out.image.attentions) == 2 and len(out.image.hidden_states) == 3 and out.image.hidden_states[1].requires_grad
     itc = loss_mod(out.projected_image_embeddings, out.projected_text_embeddings, torch.ones(image.shape[0], dtype=torch.bool, device="cuda")).loss
     probe = torch.linspace(-1.0, 1.0, 128, device="cuda")
     mm_term = (out.multimodal_masked.last_hidden_state[:, 0] * probe).sum(-1).mean()
