@@ -87,16 +87,91 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, q: Tensor, kv: Optional[Tensor] = None, return_attn_weights: bool = False, use_cache: bool = False,
                 causal: bool = False, **attn_kwargs: Any) -> Union[Tensor, Tuple[Tensor, Tensor]]:
-        if kv is not None and kv is not q:
-            raise ops.MmamdError("cross-attention is not on the MI355X contrastive path")
-        if use_cache or causal or attn_kwargs.get("head_mask") is not None:
-            raise ops.MmamdError("use_cache / causal / head_mask are not implemented on the MI355X path")
-        if q.dim() != 3:
-            raise ops.MmamdError("MultiHeadAttention on the MI355X path takes [b, seq, c] inputs")
-        forbid_detached_forward(self, q)
-        B, S, d = q.shape
-        qc = q if q.is_contiguous() else q.contiguous()
-        km = key_mask_from_attention_mask(attn_kwargs.get("attention_mask"), B, S)
-        y, probs = self.run(ops.convert(qc.view(B * S, d), torch.bfloat16), B, S, km, return_attn_weights, None)
-        y = y.view(B, S, d)
+        if attn_kwargs.get("head_mask") is not None:
+            raise ops.MmamdError("head_mask is not implemented on the MI355X path")
+        forbid_detached_forward(self, q, kv)
+        am = attn_kwargs.get("attention_mask")
+        pad_form = am is None or (am.dim() == 4 and am.shape[1] == 1 and am.shape[2] == 1) or (am.dim() == 2 and q.dim() == 3 and tuple(am.shape) == (q.shape[0], q.shape[1]) and q.shape[0] != q.shape[1])
+        if q.dim() == 3 and (kv is None or kv is q) and not use_cache and not self.cache and pad_form:
+            # self-attention over [b, seq, c] without a cache (what FLAVA's layers do): one packed in-projection, the flash-style kernels
+            # (`causal` only steers the CACHE in the reference, :159-176: masking comes from attention_mask)
+            B, S, d = q.shape
+            qc = q if q.is_contiguous() else q.contiguous()
+            km = key_mask_from_attention_mask(attn_kwargs.get("attention_mask"), B, S)
+            y, probs = self.run(ops.convert(qc.view(B * S, d), torch.bfloat16), B, S, km, return_attn_weights, None)
+            y = y.view(B, S, d)
+            return (y, probs) if return_attn_weights else y
+        return self._forward_general(q, kv, return_attn_weights, use_cache, causal, attn_kwargs.get("attention_mask"))
+
+    def _forward_general(self, q: Tensor, kv: Optional[Tensor], return_attn_weights: bool, use_cache: bool, causal: bool,
+                         attention_mask: Optional[Tensor]) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        """Cross-attention (kv), n-dimensional token grids, and the key / value cache of the reference's decoding loop (:150-176): q, k, v are
+        projected separately (k and v by one stacked GEMM), the general attention kernel (mmamd_attention_x_fwd: Sq != Sk, 64- / 96-wide heads,
+        key-padding or [Sq, Sk] masks) attends, `self.cache` holds {"k", "v"} in the reference's [b, n_head, seq, c] shape as bf16 views of
+        token-major buffers.  `causal` steers the cache exactly like the reference: with it, new keys are appended to the cached ones; without
+        it a filled cache REPLACES the projections of `kv` (cross-attention to a fixed memory)."""
+        if not isinstance(self.attn, SelfAttention):
+            raise ops.MmamdError(f"attn_module {type(self.attn).__name__} is not implemented on the MI355X path")
+        if self.attn.attn_dropout > 0 and self.training:
+            raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
+        dq, H = self.query.out_features, self.n_head
+        hd = dq // H
+        if hd not in (64, 96):
+            raise ops.MmamdError(f"the MI355X attention kernels are built for 64- and 96-wide heads, got {hd}")
+        bf, f32, pc = torch.bfloat16, torch.float32, self._packed
+        B = q.shape[0]
+        q_shape = q.shape
+        src = q if kv is None else kv
+        Sq = q.numel() // (B * q.shape[-1])
+        Sn = src.numel() // (B * src.shape[-1])
+        qc = (q if q.is_contiguous() else q.contiguous()).view(B * Sq, q.shape[-1])
+        has_b = self.query.bias is not None
+        qp = ops.gemm_bf16(ops.convert(qc, bf), pc.get(self.query.weight, bf), pc.get(self.query.bias, f32) if has_b else None)
+        k_tok = v_tok = None
+        if causal or not self.cache:
+            sc = (src if src.is_contiguous() else src.contiguous()).view(B * Sn, src.shape[-1])
+            wkv = pc.get_cat([self.key.weight, self.value.weight], bf)
+            bkv = pc.get_cat([self.key.bias, self.value.bias], f32) if has_b else None
+            kvp = ops.gemm_bf16(ops.convert(sc, bf) if sc is not qc else ops.convert(qc, bf), wkv, bkv)
+            k_tok, v_tok = kvp[:, :dq].unflatten(0, (B, Sn)), kvp[:, dq:].unflatten(0, (B, Sn))  # [B, Sn, dq] column-slice views
+
+        def as_heads(tok):  # [B, S, dq] token-major -> the reference's [b, n_head, S, c] (a view)
+            return tok.view(B, tok.shape[1], H, hd).transpose(1, 2)
+
+        def as_tokens(t4):  # the inverse, for cache entries (free when they came from as_heads)
+            return t4.transpose(1, 2).reshape(B, t4.shape[2], dq)
+
+        if use_cache:
+            if not self.cache:
+                self.cache = dict(k=as_heads(k_tok.contiguous()), v=as_heads(v_tok.contiguous()))  # (.contiguous(): the reference clones)
+            elif causal:  # append the present keys / values to the past ones (data movement)
+                self.cache["k"] = as_heads(torch.cat([as_tokens(self.cache["k"]), k_tok], dim=1))
+                self.cache["v"] = as_heads(torch.cat([as_tokens(self.cache["v"]), v_tok], dim=1))
+            k_tok, v_tok = as_tokens(self.cache["k"]), as_tokens(self.cache["v"])
+        Sk = k_tok.shape[1]
+        k2 = k_tok.reshape(B * Sk, dq) if k_tok.is_contiguous() else k_tok.flatten(0, 1)
+        v2 = v_tok.reshape(B * Sk, dq) if v_tok.is_contiguous() else v_tok.flatten(0, 1)
+        mask = _general_mask(attention_mask, B, Sq, Sk)
+        att, probs = ops.attention_x_fwd(qp, k2, v2, B, Sq, Sk, H, hd, mask, want_probs=return_attn_weights)
+        y = ops.gemm_bf16(att, pc.get(self.output.weight, bf), pc.get(self.output.bias, f32), out_dtype=f32)
+        y = y.view(*q_shape[:-1], dq)
         return (y, probs) if return_attn_weights else y
+
+
+def _general_mask(attention_mask: Optional[Tensor], B: int, Sq: int, Sk: int) -> ops.AttnMask:
+    """The reference's "0 = do not attend" masks, broadcastable to [b, h, q, k] (:203-206, utils/attention.py): key-padding forms ([B,Sk],
+    [B,1,1,Sk]) become a key mask, head-independent [Sq,Sk] / [B,1,Sq,Sk] / [1,1,Sq,Sk] forms a full uint8 mask; per-head masks raise."""
+    if attention_mask is None:
+        return ops.AttnMask()
+    m = attention_mask
+    if m.dim() > 4:
+        raise ops.MmamdError(f"attention_mask of shape {tuple(m.shape)}: at most 4 dimensions ([b, h, q, k] broadcasting)")
+    m = m.reshape((1,) * (4 - m.dim()) + tuple(m.shape))  # torch broadcasting aligns from the right
+    if m.shape[1] != 1:
+        raise ops.MmamdError("per-head attention masks are not implemented on the MI355X path")
+    if m.shape[0] not in (1, B) or m.shape[3] != Sk or m.shape[2] not in (1, Sq):
+        raise ops.MmamdError(f"attention_mask of shape {tuple(attention_mask.shape)} does not broadcast to [{B}, h, {Sq}, {Sk}]")
+    flags = (m[:, 0] != 0).to(torch.uint8)  # mask plumbing: 0 / 1 flags
+    if m.shape[2] == 1 and Sq != 1:
+        return ops.AttnMask(key_mask=flags[:, 0].expand(B, Sk).contiguous())
+    return ops.AttnMask(full=flags.expand(flags.shape[0], Sq, Sk).contiguous())
