@@ -92,8 +92,9 @@ class TransformerStack(nn.Module):
         """x: fp32 [B*S, d] residual stream (updated in place and returned); layers [first:] only.  hn0 (optional, bf16 [B*S, d]): norm1 of layer
         `first` already applied to x by the producer of x (the fused ViT stem)."""
         d, H = self.d_model, self.nhead
-        if d // H != HEAD_DIM:
-            raise ops.MmamdError(f"the MI355X attention kernel is built for head dim 64, got {d // H}")
+        hd = d // H
+        if hd not in (HEAD_DIM, 96):
+            raise ops.MmamdError(f"the MI355X attention kernels are built for 64- and 96-wide heads, got {hd}")
         M = B * S
         dev = x.device
         pk = self._packed.get
@@ -108,7 +109,10 @@ class TransformerStack(nn.Module):
             if li != first or hn0 is None:
                 ops.layernorm(x, pk(layer.norm1.weight, f32), pk(layer.norm1.bias, f32), layer.norm1.eps, out=hn)
             ops.gemm_bf16(hn, pk(sa.in_proj_weight, bf), pk(sa.in_proj_bias, f32), out=qkv)
-            ops.attention_fwd(qkv, B, S, H, causal, out=att)
+            if hd == HEAD_DIM:
+                ops.attention_fwd(qkv, B, S, H, causal, out=att)
+            else:  # 96-wide heads: the general kernel on the q / k / v column blocks of the packed projection
+                ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, ops.AttnMask(causal=causal), out=att)
             ops.gemm_bf16(att, pk(sa.out_proj.weight, bf), pk(sa.out_proj.bias, f32), residual=x, out=x)
             ops.layernorm(x, pk(layer.norm2.weight, f32), pk(layer.norm2.bias, f32), layer.norm2.eps, out=hn)
             ops.gemm_bf16(hn, pk(layer.linear1.weight, bf), pk(layer.linear1.bias, f32), act=ops.ACT_QUICKGELU, out=up)
@@ -130,6 +134,8 @@ def two_stacks_groupable(sa: TransformerStack, Ma: int, sb: TransformerStack, Mb
     # ViT-B/32 at B = 512, every pair grouped, 11.9 vs 10.9 ms) -- profiles/r02_two_tower_ab.txt
     if len(sa.layers) != len(sb.layers) or Ma * sa.d_model < 2 * Mb * sb.d_model:
         return False
+    if sa.d_model // sa.nhead != HEAD_DIM or sb.d_model // sb.nhead != HEAD_DIM:
+        return False  # (the grouped attention launch is the 64-wide ring kernel)
 
     for (Na, Ka), (Nb, Kb) in (((3 * sa.d_model, sa.d_model), (3 * sb.d_model, sb.d_model)), ((sa.d_model, sa.d_model), (sb.d_model, sb.d_model)),
                                  ((sa.dim_feedforward, sa.d_model), (sb.dim_feedforward, sb.d_model)),
