@@ -159,6 +159,22 @@ int mmamd_attention_x_bwd(const void* q, int ldq, int64_t q_batch_stride, const 
                           int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo, const float* lse,
                           void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim,
                           float scale, mmamd_stream_t stream);
+/* The same two entries with TRAINING-TIME DROPOUT on the normalised probabilities (reference modules/layers/attention.py:234-239: F.dropout on
+ * the softmax output, before the product with V; models/flava/transformer.py:87 builds SelfAttention(dropout)).  keep(b, h, q, key) = word key & 3
+ * of the Philox4x32-10 block with counter ((b H + h) Sq + q) * ceil(Sk / 4) + key / 4 and (site, 0), keyed by `seed` (oracle/philox.py);
+ * survivors are scaled by 1 / (1 - drop_p).  The returned probabilities are the dropped ones, like the reference's; lse is unaffected.  The
+ * backward regenerates the mask from (seed, site). */
+int mmamd_attention_x_fwd_dropout(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                          int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                          int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
+                          float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed,
+                                  uint32_t site, mmamd_stream_t stream);
+int mmamd_attention_x_bwd_dropout(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                          int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                          int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo, const float* lse,
+                          void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim,
+                          float scale, float drop_p, uint64_t seed,
+                                  uint32_t site, mmamd_stream_t stream);
 
 /* mmamd_attention_fwd that also saves the log2-domain log-sum-exp [B,H,S] (fp32) of the scaled scores for mmamd_attention_bwd. */
 int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale,

@@ -121,10 +121,7 @@ def stack_drop_spec(layers, attn_p: Callable = None) -> Tuple[List[float], int]:
     if len(pb) > 1 or len(pm) > 1 or len(pa) > 1:
         raise ops.MmamdError("training: all layers of a stack must share their dropout rates")
     p_branch, p_mlp, p_attn = pb.pop(), pm.pop(), pa.pop()
-    if p_attn > 0:
-        raise ops.MmamdError("training: dropout on the attention PROBABILITIES (attn_dropout > 0) is not implemented on the MI355X path "
-                             "(residual-branch dropout, MLP dropout, embedding dropout and stochastic depth are)")
-    if p_branch == 0 and p_mlp == 0 and all(r <= 0 for r in path):
+    if p_branch == 0 and p_mlp == 0 and p_attn == 0 and all(r <= 0 for r in path):
         return [], 0
     if all(r < 0 for r in path):
         path = []
@@ -192,7 +189,14 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
             inputs.append(x)
         h1 = ops.layernorm(x, g1, be1, eps1[li], out_dtype=bf)
         qkv = ops.gemm_bf16(h1, Wqkv, bqkv)
-        att, lse = ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
+        pa = drop[2] if drop else 0.0
+        if pa > 0:  # dropout on the attention probabilities (FLAVA's SelfAttention(dropout)): the general kernels carry the Philox mask
+            dm = x.shape[1]
+            lse = torch.empty((B, H, S), dtype=f32, device=x.device)
+            att, _ = ops.attention_x_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, S, S, H, dm // H,
+                                         ops.AttnMask(causal=causal, key_mask=key_mask), lse=lse, drop=(pa, seed, 16 * li + 3))
+        else:
+            att, lse = ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
         pb, pm, grp = _drop_of(drop, li, S, x.shape[1])
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo): the projection without the residual, then ONE pass: mask, scale, add
             x_mid = ops.dropout(ops.gemm_bf16(att, Wo, bo, out_dtype=f32), pb, seed, 16 * li, residual=x, group=grp)
@@ -276,7 +280,16 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         # x_mid = x + att Wo^T + bo
         datt = dgrad_t(dxmb, WoT, bf)
         dWo = wgrad(dxmb, att)
-        dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal, key_mask)
+        pa = drop[2] if drop else 0.0
+        if pa > 0:
+            dm = x.shape[1]
+            dq_, dkv_ = ops.attention_x_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], att, datt, lse, B, S, S, H, dm // H,
+                                            ops.AttnMask(causal=causal, key_mask=key_mask), drop=(pa, seed, 16 * li + 3))
+            dqkv = torch.empty((B * S, 3 * dm), dtype=bf, device=x.device)  # [dq | dk | dv]: placement copies of the two kernel outputs
+            dqkv[:, :dm].copy_(dq_)
+            dqkv[:, dm:].copy_(dkv_)
+        else:
+            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal, key_mask)
         # qkv = h1 Wqkv^T + bqkv
         dh1 = dgrad_t(dqkv, WqkvT, f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)

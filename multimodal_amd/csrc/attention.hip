@@ -658,6 +658,7 @@ struct AttnX {
   long long q_bs, kv_bs, fm_bs;
   int ldq, ldk, ldv, ldo, Sq, Sk, H, causal;
   float scale_log2e;
+  AttnDrop drop;  // training-time dropout on the normalised probabilities (thresh = 0: none); common.h
 };
 
 template <int NKT, int DH, typename TP>
@@ -774,6 +775,11 @@ __global__ __launch_bounds__(256) void attention_x_kernel(const AttnX p) {
         float e[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(st[4 * g + j] - m) * inv;
+        if (p.drop.thresh != 0) {  // (uniform) P' = P * keep / (1 - p): what the reference returns and multiplies with V (attention.py:234-239)
+          const Philox4 rr = attn_drop_block(p.drop, ((long long)b * p.H + h) * Sq + qc, (Sk + 3) >> 2, kt * 32 + 8 * g + 4 * half);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = rr.v[j] >= p.drop.thresh ? e[j] * p.drop.scale : 0.f;
+        }
         if (prow != nullptr && q < Sq) {
           const int key = kt * 32 + 8 * g + 4 * half;
 #pragma unroll
@@ -1459,10 +1465,42 @@ extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mas
   MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention_probs: unsupported S=%d", S);
 }
 
+static AttnDrop make_attn_drop(float p, uint64_t seed, uint32_t site) {
+  AttnDrop d;
+  d.thresh = p > 0.f ? dropout_threshold(p) : 0u;
+  if (p > 0.f && d.thresh == 0u) d.thresh = 1u;  // (p below 2^-32 still means "dropout on")
+  d.k0 = (uint32_t)seed; d.k1 = (uint32_t)(seed >> 32); d.site = site;
+  d.scale = 1.0f / (1.0f - p);
+  return d;
+}
+
+static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
+                                int causal, void* out, int ldo, void* probs, int probs_dtype, float* lse, int B, int Sq, int Sk, int H,
+                                int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site, mmamd_stream_t stream);
+
 extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                      int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
                                      int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
                                      float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream) {
+  return attention_x_fwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              ldo, probs, probs_dtype, lse, B, Sq, Sk, H, head_dim, scale, 0.f, 0, 0, stream);
+}
+
+extern "C" int mmamd_attention_x_fwd_dropout(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                             int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                             int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
+                                             float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed,
+                                             uint32_t site, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, MMAMD_E_BADARG, "attention_x: dropout p = %g must be in [0, 1)", (double)drop_p);
+  return attention_x_fwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              ldo, probs, probs_dtype, lse, B, Sq, Sk, H, head_dim, scale, drop_p, seed, site, stream);
+}
+
+static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
+                                int causal, void* out, int ldo, void* probs, int probs_dtype, float* lse, int B, int Sq, int Sk, int H,
+                                int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(q && k && v && out && B >= 0 && Sq > 0 && Sk > 0 && H > 0, MMAMD_E_BADARG, "attention_x: bad argument");
   MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x: head_dim=%d (64 and 96 are built)", head_dim);
   MMAMD_CHECK_ARG(Sk <= 288, MMAMD_E_UNSUPPORTED, "attention_x: Sk=%d > 288 not supported", Sk);
@@ -1479,6 +1517,7 @@ extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_str
   p.q_bs = q_batch_stride; p.kv_bs = kv_batch_stride; p.fm_bs = full_mask_batch_stride;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal ? 1 : 0;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.drop = make_attn_drop(drop_p, seed, site);
   hipStream_t st = (hipStream_t)stream;
   const bool pf32 = probs == nullptr || probs_dtype == MMAMD_F32;
   if (head_dim == 64) return pf32 ? dispatch_attn_x<64, float>(p, B, st) : dispatch_attn_x<64, bf16>(p, B, st);

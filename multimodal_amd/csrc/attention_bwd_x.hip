@@ -20,9 +20,11 @@ struct AttnXB {
   long long q_bs, kv_bs, fm_bs, dq_bs, dkv_bs;
   int ldq, ldk, ldv, ldo, lddq, lddk, lddv, Sq, Sk, H, causal;
   float scale;
+  AttnDrop drop;  // the forward's dropout on the probabilities (thresh = 0: none): O = P' V with P' = P keep / (1 - p), so
+                  // dV = P'^T dO, dP = (dO V^T) keep / (1 - p), dS = P (dP - D) with D = sum dO O (unchanged form)
 };
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p) {
   constexpr int KS = DH + 8;
   constexpr int CPR = DH / 8;
@@ -99,6 +101,8 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float e[4];
+        Philox4 rr = {{0u, 0u, 0u, 0u}};
+        if constexpr (DROP) rr = attn_drop_block(p.drop, ((long long)b * p.H + h) * Sq + qc, (Sk + 3) >> 2, kt * 32 + 8 * g + 4 * half);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
@@ -106,7 +110,9 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
           bool ok = Mk[key] != 0 && (!p.causal || key <= qc);
           if (ok && fm != nullptr) ok = fm[(size_t)qc * Sk + key] != 0;
           const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2) : 0.f;
-          e[j] = pr * (dp[r] - Dq);
+          float dpr = dp[r];
+          if constexpr (DROP) dpr = rr.v[j] >= p.drop.thresh ? dpr * p.drop.scale : 0.f;
+          e[j] = pr * (dpr - Dq);
         }
         bf16x2 p0, p1;
         p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
   }
 }
 
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p) {
   constexpr int KS = DH + 8;
   constexpr int CPR = DH / 8;
@@ -244,8 +250,16 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p
               bool ok = key_live && q < Sq && (!p.causal || key <= q);
               if (ok && fm != nullptr) ok = fm[(size_t)q * Sk + key] != 0;
               const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[ql]) : 0.f;
-              e[j] = pr;
-              f[j] = pr * (dp[r] - Dqs[ql]);
+              float pd = pr, dpr = dp[r];
+              if constexpr (DROP) {  // lane = key: every query of the tile needs its own Philox block (word key & 3)
+                const int qq = q < Sq ? q : Sq - 1;
+                const Philox4 rr = attn_drop_block(p.drop, ((long long)b * p.H + h) * Sq + qq, (Sk + 3) >> 2, kc);
+                const bool keep = rr.v[kc & 3] >= p.drop.thresh;
+                pd = keep ? pr * p.drop.scale : 0.f;
+                dpr = keep ? dpr * p.drop.scale : 0.f;
+              }
+              e[j] = pd;
+              f[j] = pr * (dpr - Dqs[ql]);
             }
             bf16x2 p0, p1, d0, d1;
             p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
@@ -293,14 +307,14 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p
   }
 }
 
-template <int DH>
+template <int DH, bool DROP>
 static int launch_x_bwd(const AttnXB& p, int B, hipStream_t st) {
   const int SP = ((p.Sk + 31) / 32) * 32;
   const int smem1 = 2 * SP * (DH + 8) * 2 + DH * (SP + 4) * 2 + SP;
   constexpr int smem2 = 2 * 128 * (DH + 8) * 2 + 2 * DH * 132 * 2 + 2 * 128 * 4;
   if (smem1 > 160 * 1024) { set_error("attention_x_bwd: Sk=%d with head_dim=%d needs %d B of LDS (> 160 KiB)", p.Sk, DH, smem1); return MMAMD_E_UNSUPPORTED; }
-  auto k1 = attention_x_bwd_dq_kernel<DH>;
-  auto k2 = attention_x_bwd_dkv_kernel<DH>;
+  auto k1 = attention_x_bwd_dq_kernel<DH, DROP>;
+  auto k2 = attention_x_bwd_dkv_kernel<DH, DROP>;
   // per-device opt-in to > 64 KiB dynamic LDS; the dQ kernel's size varies with Sk, so it opts in to the 160 KiB maximum once
   static unsigned long long m1 = 0, m2 = 0;
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(k1), smem1 > 64 * 1024 ? 160 * 1024 : 0, m1)) return rc_attr;
@@ -314,11 +328,37 @@ static int launch_x_bwd(const AttnXB& p, int B, hipStream_t st) {
 
 using namespace mmamd;
 
+static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
+                                int causal, const void* out, const void* dout, int ldo, const float* lse, void* dq, int lddq, void* dk, void* dv,
+                                int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed,
+                                uint32_t site, mmamd_stream_t stream);
+
 extern "C" int mmamd_attention_x_bwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                      int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
                                      int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo,
                                      const float* lse, void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk,
                                      int H, int head_dim, float scale, mmamd_stream_t stream) {
+  return attention_x_bwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              dout, ldo, lse, dq, lddq, dk, dv, lddk, lddv, B, Sq, Sk, H, head_dim, scale, 0.f, 0, 0, stream);
+}
+
+extern "C" int mmamd_attention_x_bwd_dropout(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                             int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                             int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo,
+                                             const float* lse, void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq,
+                                             int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site,
+                                             mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, MMAMD_E_BADARG, "attention_x_bwd: dropout p = %g must be in [0, 1)", (double)drop_p);
+  return attention_x_bwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              dout, ldo, lse, dq, lddq, dk, dv, lddk, lddv, B, Sq, Sk, H, head_dim, scale, drop_p, seed, site, stream);
+}
+
+static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
+                                int causal, const void* out, const void* dout, int ldo, const float* lse, void* dq, int lddq, void* dk, void* dv,
+                                int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed,
+                                uint32_t site, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && B >= 0 && Sq > 0 && Sk > 0 && H > 0, MMAMD_E_BADARG,
                   "attention_x_bwd: bad argument");
   MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x_bwd: head_dim=%d (64 and 96 are built)", head_dim);
@@ -339,7 +379,10 @@ extern "C" int mmamd_attention_x_bwd(const void* q, int ldq, int64_t q_batch_str
   p.dq_bs = (long long)Sq * lddq; p.dkv_bs = (long long)Sk * lddk;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal ? 1 : 0; p.scale = scale;
+  p.drop.thresh = drop_p > 0.f ? (dropout_threshold(drop_p) ? dropout_threshold(drop_p) : 1u) : 0u;
+  p.drop.k0 = (uint32_t)seed; p.drop.k1 = (uint32_t)(seed >> 32); p.drop.site = site; p.drop.scale = 1.0f / (1.0f - drop_p);
   MMAMD_CHECK_ARG(lddk == lddv, MMAMD_E_BADARG, "attention_x_bwd: dk and dv must share their row pitch");
   hipStream_t st = (hipStream_t)stream;
-  return head_dim == 64 ? launch_x_bwd<64>(p, B, st) : launch_x_bwd<96>(p, B, st);
+  if (p.drop.thresh != 0) return head_dim == 64 ? launch_x_bwd<64, true>(p, B, st) : launch_x_bwd<96, true>(p, B, st);
+  return head_dim == 64 ? launch_x_bwd<64, false>(p, B, st) : launch_x_bwd<96, false>(p, B, st);
 }

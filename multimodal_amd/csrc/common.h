@@ -85,6 +85,37 @@ __device__ __forceinline__ f32x4 load4(const bf16* p) {
   return r;
 }
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// Philox4x32-10 (Salmon et al., SC'11; Random123): the counter-based generator behind the training-time dropout masks (csrc/dropout.hip,
+// the attention-probability dropout of the general attention kernels).  oracle/philox.py restates it and is pinned to the Random123 KATs.
+struct Philox4 {
+  uint32_t v[4];
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return Philox4{{c0, c1, c2, c3}};
+}
+// keep <=> r >= floor(p * 2^32): P(keep) = 1 - thresh / 2^32 (integer compare, no float rounding in the decision)
+inline uint32_t dropout_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+}
+// Dropout on attention probabilities: element (b, h, q, key) of a [B, H, Sq, Sk] map uses output word key & 3 of the Philox block with
+// counter ((b H + h) Sq + q) * ceil(Sk / 4) + key / 4 (64-bit) and (site, 0).  drop_thresh = 0: no dropout.
+struct AttnDrop {
+  uint32_t thresh, k0, k1, site;
+  float scale;
+};
+__device__ __forceinline__ Philox4 attn_drop_block(const AttnDrop& d, long long row, int sk4, int key) {
+  const unsigned long long idx = (unsigned long long)row * (unsigned long long)sk4 + (unsigned long long)(key >> 2);
+  return philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), d.site, 0u, d.k0, d.k1);
+}
+
 __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
   bf16x4 r;
   r[0] = (bf16)v[0]; r[1] = (bf16)v[1]; r[2] = (bf16)v[2]; r[3] = (bf16)v[3];

@@ -14,21 +14,6 @@
 
 namespace mmamd {
 
-struct Philox4 {
-  uint32_t v[4];
-};
-
-__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return Philox4{{c0, c1, c2, c3}};
-}
-
 template <typename TX, typename TO, int MODE>
 __global__ __launch_bounds__(256) void dropout_kernel(const TX* __restrict__ x, const float* __restrict__ res, TO* __restrict__ out,
                                                       uint8_t* __restrict__ mask_out, long long n4, long long group, uint32_t thresh,
@@ -74,8 +59,7 @@ extern "C" int mmamd_dropout(const void* x, int x_dtype, const float* residual, 
                       ((uintptr_t)mask_out & 3) == 0, MMAMD_E_ALIGN, "dropout: pointers must be aligned to 4 elements");
   if (n == 0) return 0;
   const long long n4 = n / 4;
-  const double t = (double)p * 4294967296.0;
-  const uint32_t thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;  // keep <=> r >= thresh: P(keep) = 1 - thresh / 2^32
+  const uint32_t thresh = dropout_threshold(p);  // keep <=> r >= thresh: P(keep) = 1 - thresh / 2^32
   const float scale = 1.0f / (1.0f - p);
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const unsigned grid = (unsigned)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);

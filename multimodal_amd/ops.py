@@ -363,10 +363,12 @@ def _mat_view(t: torch.Tensor, name: str) -> torch.Tensor:
 
 def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, Sq: int, Sk: int, H: int, head_dim: int,
                     mask: Optional[AttnMask] = None, shared_q: bool = False, want_probs: bool = False,
-                    out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                    out: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                    drop: Optional[Tuple[float, int, int]] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """General attention (mmamd_attention_x_fwd).  q: bf16 [B*Sq, >=H*hd] (or [Sq, ...] when shared_q: the same queries for
     every sample), k / v: bf16 [B*Sk, >=H*hd]; all may be column-slice views of wider matrices (stride(0) is the row
-    pitch).  Returns (bf16 [B*Sq, H*hd], probabilities fp32 [B,H,Sq,Sk] or None)."""
+    pitch).  Returns (bf16 [B*Sq, H*hd], probabilities fp32 [B,H,Sq,Sk] or None).  drop = (p, seed, site): training-time dropout on the
+    probabilities (mmamd_attention_x_fwd_dropout; the returned probabilities are then the dropped ones)."""
     _mat_view(q, "q"); _mat_view(k, "k"); _mat_view(v, "v")
     D = H * head_dim
     if q.shape[1] != D or k.shape[1] != D or v.shape[1] != D:
@@ -387,10 +389,14 @@ def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, S
     if out is None:
         out = torch.empty((B * Sq, D), dtype=torch.bfloat16, device=q.device)
     probs = torch.empty((B, H, Sq, Sk), dtype=torch.float32, device=q.device) if want_probs else None
-    check(_lib.lib().mmamd_attention_x_fwd(q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(),
-                                           k.stride(0), v.stride(0), Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal),
-                                           out.data_ptr(), out.stride(0), _ptr(probs), F32, _ptr(lse), B, Sq, Sk, H, head_dim,
-                                           1.0 / math.sqrt(float(head_dim)), _stream()), "mmamd_attention_x_fwd")
+    args = (q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
+            Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal), out.data_ptr(), out.stride(0), _ptr(probs), F32, _ptr(lse), B, Sq, Sk, H,
+            head_dim, 1.0 / math.sqrt(float(head_dim)))
+    if drop is not None and drop[0] > 0:
+        check(_lib.lib().mmamd_attention_x_fwd_dropout(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF, _stream()),
+              "mmamd_attention_x_fwd_dropout")
+    else:
+        check(_lib.lib().mmamd_attention_x_fwd(*args, _stream()), "mmamd_attention_x_fwd")
     return out, probs
 
 
@@ -431,8 +437,9 @@ def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse:
 
 
 def attention_x_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int,
-                    Sq: int, Sk: int, H: int, head_dim: int, mask: Optional[AttnMask] = None, shared_q: bool = False):
-    """Backward of attention_x_fwd.  Returns (dq bf16 [B*Sq, D] — per sample even when the queries are shared —, dkv bf16 [B*Sk, 2D]
+                    Sq: int, Sk: int, H: int, head_dim: int, mask: Optional[AttnMask] = None, shared_q: bool = False,
+                    drop: Optional[Tuple[float, int, int]] = None):
+    """Backward of attention_x_fwd (drop: the forward's (p, seed, site)).  Returns (dq bf16 [B*Sq, D] — per sample even when the queries are shared —, dkv bf16 [B*Sk, 2D]
     = [dK | dV])."""
     _mat_view(q, "q"); _mat_view(k, "k"); _mat_view(v, "v"); _mat_view(out, "out"); _mat_view(dout, "dout")
     _chk(lse, "lse", torch.float32)
@@ -445,11 +452,14 @@ def attention_x_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
         raise MmamdError("attention_x_bwd: out and dout must share their row pitch")
     dq = torch.empty((B * Sq, D), dtype=torch.bfloat16, device=q.device)
     dkv = torch.empty((B * Sk, 2 * D), dtype=torch.bfloat16, device=q.device)
-    check(_lib.lib().mmamd_attention_x_bwd(q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(),
-                                           k.stride(0), v.stride(0), Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal),
-                                           out.data_ptr(), dout.data_ptr(), out.stride(0), lse.data_ptr(), dq.data_ptr(), D,
-                                           dkv.data_ptr(), dkv.data_ptr() + 2 * D, 2 * D, 2 * D, B, Sq, Sk, H, head_dim,
-                                           1.0 / math.sqrt(float(head_dim)), _stream()), "mmamd_attention_x_bwd")
+    args = (q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
+            Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal), out.data_ptr(), dout.data_ptr(), out.stride(0), lse.data_ptr(),
+            dq.data_ptr(), D, dkv.data_ptr(), dkv.data_ptr() + 2 * D, 2 * D, 2 * D, B, Sq, Sk, H, head_dim, 1.0 / math.sqrt(float(head_dim)))
+    if drop is not None and drop[0] > 0:
+        check(_lib.lib().mmamd_attention_x_bwd_dropout(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF, _stream()),
+              "mmamd_attention_x_bwd_dropout")
+    else:
+        check(_lib.lib().mmamd_attention_x_bwd(*args, _stream()), "mmamd_attention_x_bwd")
     return dq, dkv
 
 

@@ -233,3 +233,79 @@ def test_flava_training_forward_returns_attentions_and_hidden_states():
         assert model(image=image, text=text).image.attentions is None
     finally:
         set_schedule(train_attentions=prev.train_attentions)
+
+
+def test_attention_probability_dropout_kernels_vs_oracle():
+    """mmamd_attention_x_fwd_dropout / _bwd_dropout: the returned (dropped) probabilities equal softmax * Philox mask / (1 - p) element for
+    element, O = P' V, and dQ / dK / dV equal torch autograd of the same expression with the same mask."""
+    from multimodal_amd import ops
+
+    B, H, S, hd, p, seed, site = 2, 2, 40, 64, 0.2, 4242, 19
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(B * S, H * hd).to(torch.bfloat16) for _ in range(3))
+    km = torch.ones(B, S, dtype=torch.uint8)
+    km[1, 33:] = 0
+    lse = torch.empty((B, H, S), dtype=torch.float32, device="cuda")
+    out, probs = ops.attention_x_fwd(q.cuda(), k.cuda(), v.cuda(), B, S, S, H, hd, ops.AttnMask(key_mask=km.cuda()), want_probs=True, lse=lse,
+                                     drop=(p, seed, site))
+    keep = torch.from_numpy(dropout_layers.attention_mask_bhqk(B, H, S, S, p, seed, site))
+    scale = float(np.float32(1) / (np.float32(1) - np.float32(p)))
+
+    def ref(qf, kf, vf):
+        qh, kh, vh = (t.view(B, S, H, hd).transpose(1, 2) for t in (qf, kf, vf))
+        s = (qh @ kh.transpose(-1, -2)) / 8.0
+        s = s.masked_fill(km[:, None, None, :] == 0, float("-inf"))
+        pr = torch.softmax(s, -1) * keep * scale
+        return pr, (pr @ vh).transpose(1, 2).reshape(B * S, H * hd)
+
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    pr, o = ref(qf, kf, vf)
+    assert float((probs.cpu() - pr.detach()).abs().max()) < 2e-3
+    assert torch.equal(probs.cpu() == 0, pr.detach() == 0) or float(((probs.cpu() == 0) != (pr.detach() == 0)).float().mean()) < 1e-4  # same dropped set
+    assert float((out.float().cpu() - o.detach()).abs().max()) < 3e-2
+    do = torch.randn(B * S, H * hd).to(torch.bfloat16)
+    o.backward(do.float())
+    dq, dkv = ops.attention_x_bwd(q.cuda(), k.cuda(), v.cuda(), out, do.cuda(), lse, B, S, S, H, hd, ops.AttnMask(key_mask=km.cuda()),
+                                  drop=(p, seed, site))
+    D = H * hd
+    for got, want, name in ((dq, qf.grad, "dq"), (dkv[:, :D], kf.grad, "dk"), (dkv[:, D:], vf.grad, "dv")):
+        err = float((got.float().cpu() - want).abs().max())
+        assert err < 4e-2 * float(want.abs().max()) + 1e-3, (name, err)
+
+
+def test_flava_encoder_with_dropout_on_every_site():
+    """FLAVA's encoder built with dropout > 0 (models/flava/transformer.py:87-90 puts the same rate on the attention probabilities, both residual
+    branches and the MLP): forward and gradients vs the reference arithmetic with the Philox masks of the four sites."""
+    from multimodal_amd.models.flava.transformer import TransformerEncoder
+
+    p, d, H = 0.15, 128, 2
+    torch.manual_seed(4)
+    enc = TransformerEncoder(2, d, H, 256, dropout=p, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True).cuda().train()
+    layers = []
+    for layer in enc.layer:
+        at = layer.attention
+        f = lambda t: t.detach().cpu().clone().requires_grad_(True)  # noqa: E731
+        layers.append({"Wqkv": f(torch.cat([at.query.weight, at.key.weight, at.value.weight])), "bqkv": f(torch.cat([at.query.bias, at.key.bias, at.value.bias])),
+                       "Wo": f(at.output.weight), "bo": f(at.output.bias), "W1": f(layer.feedforward.model[0].weight), "b1": f(layer.feedforward.model[0].bias),
+                       "W2": f(layer.feedforward.model[-1].weight), "b2": f(layer.feedforward.model[-1].bias), "g1": f(layer.attention_layernorm.weight),
+                       "be1": f(layer.attention_layernorm.bias), "g2": f(layer.feedforward_layernorm.weight), "be2": f(layer.feedforward_layernorm.bias),
+                       "eps1": layer.attention_layernorm.eps, "eps2": layer.feedforward_layernorm.eps})
+    B, S = 4, 24
+    x, gout = torch.randn(B, S, d), torch.randn(B, S, d)
+    torch.manual_seed(123)
+    seed = int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
+    torch.manual_seed(123)
+    xg = x.cuda().requires_grad_(True)
+    out = enc(xg, return_hidden_states=True)
+    out.last_hidden_state.backward(gout.cuda())
+    xr = x.clone().requires_grad_(True)
+    yr = dropout_layers.flava_encoder_forward(xr, layers, H, p, seed)
+    yr.backward(gout)
+    assert float((out.last_hidden_state.detach().cpu() - yr.detach()).abs().max()) < 2e-2 * float(yr.detach().abs().max())
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) < 5e-2 * float(xr.grad.abs().max())
+    for li, layer in enumerate(enc.layer):
+        d_ = d
+        gq = torch.cat([layer.attention.query.weight.grad, layer.attention.key.weight.grad, layer.attention.value.weight.grad]).cpu()
+        for got, want, name in ((gq, layers[li]["Wqkv"].grad, "Wqkv"), (layer.attention.output.weight.grad.cpu(), layers[li]["Wo"].grad, "Wo"),
+                                (layer.feedforward.model[0].weight.grad.cpu(), layers[li]["W1"].grad, "W1")):
+            assert float((got - want).abs().max()) < 6e-2 * float(want.abs().max()) + 1e-6, (li, name)

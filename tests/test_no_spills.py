@@ -23,8 +23,11 @@ def test_hot_kernels_do_not_spill():
     # instantiations that exist for API completeness but that no model path dispatches, and whose scratch use is known and accepted:
     #   * fp32 output WITH an activation (`<true, 1|2, ...>`: every activation on the path feeds a bf16 operand),
     #   * the plain (non-pipelined) 256 x 256 kernel: only the fallback for an odd number of 64-wide K-tiles
+    #   * the general attention backward WITH dropout on the probabilities (a Philox block per score in the dK/dV kernel: 20 B / lane; only
+    #     models trained with attention dropout > 0 take it -- the dropout-free instantiation `<.., false>` must stay clean)
     cold = ("gemm_bf16_nt_kernel<256, 256, 2, 4,", "gemm_bf16_nt_kernel_ppg<true, 1>", "gemm_bf16_nt_kernel_ppg<true, 2>",
-            "gemm_bf16_nt_kernel_pp<true, 1,", "gemm_bf16_nt_kernel_pp<true, 2,")
+            "gemm_bf16_nt_kernel_pp<true, 1,", "gemm_bf16_nt_kernel_pp<true, 2,", "attention_x_bwd_dkv_kernel<64, true>",
+            "attention_x_bwd_dkv_kernel<96, true>")
     for name, rc, rows in results:
         assert rc == 0, name
         assert len(rows) >= 1, name
