@@ -100,7 +100,7 @@ class TransformerEncoderLayer(nn.Module):
     def run(self, x: Tensor, B: int, S: int, key_mask: Optional[Tensor], want_probs: bool) -> Tuple[Tensor, Optional[Tensor]]:
         """x: fp32 [B*S, d] (left untouched).  Returns (new fp32 [B*S, d], probabilities [B,H,S,S] or None)."""
         if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
-            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
+            raise ops.MmamdError("this non-differentiable (stand-alone / inference) forward applies no dropout: call .eval(); training-time dropout runs inside the encoder / decoder stacks' differentiable forwards")
         bf, f32 = torch.bfloat16, torch.float32
         if self.norm_first:  # reference :155-176
             hn = self._ln(self.attention_layernorm, x, bf)

@@ -18,8 +18,8 @@ HEAD_DIM = 64
 
 
 class SelfAttention(nn.Module):
-    """Marker for "attend over all positions" (reference :13-57).  Dropout on the probabilities is not implemented on the
-    MI355X path (every FLAVA factory builds it with 0.0)."""
+    """Marker for "attend over all positions" (reference :13-57).  `attn_dropout` (dropout on the probabilities) is applied by the training
+    forward of the enclosing encoder stack (the general attention kernels carry the Philox mask: _autograd.py); identity in eval mode."""
 
     def __init__(self, attn_dropout: float = 0.0) -> None:
         super().__init__()
@@ -69,7 +69,7 @@ class MultiHeadAttention(nn.Module):
         if not isinstance(self.attn, SelfAttention):
             raise ops.MmamdError(f"attn_module {type(self.attn).__name__} is not implemented on the MI355X path")
         if self.attn.attn_dropout > 0 and self.training:
-            raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
+            raise ops.MmamdError("this non-differentiable (stand-alone / inference) forward applies no dropout: call .eval(); training-time dropout runs inside the encoder / decoder stacks' differentiable forwards")
         bf, f32 = torch.bfloat16, torch.float32
         w = self._packed.get_cat([self.query.weight, self.key.weight, self.value.weight], bf)
         if self.query.bias is not None:
@@ -113,7 +113,7 @@ class MultiHeadAttention(nn.Module):
         if not isinstance(self.attn, SelfAttention):
             raise ops.MmamdError(f"attn_module {type(self.attn).__name__} is not implemented on the MI355X path")
         if self.attn.attn_dropout > 0 and self.training:
-            raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
+            raise ops.MmamdError("this non-differentiable (stand-alone / inference) forward applies no dropout: call .eval(); training-time dropout runs inside the encoder / decoder stacks' differentiable forwards")
         dq, H = self.query.out_features, self.n_head
         hd = dq // H
         if hd not in (64, 96):

@@ -71,7 +71,7 @@ class MultiHeadSelfAttention(nn.Module):
     def run(self, hn: Tensor, B: int, S: int, mask: AttnMask, residual: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
         """hn: bf16 [B*S, d] -> fp32 [B*S, d] = output_proj(attention) (+ residual)."""
         if self.training and self.dropout > 0:
-            raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
+            raise ops.MmamdError("this non-differentiable (stand-alone / inference) forward applies no dropout: call .eval(); training-time dropout runs inside the encoder / decoder stacks' differentiable forwards")
         d = self.output_proj.in_features
         hd = _check_heads(d, self.num_heads)
         pk, bf, f32 = self._packed.get, torch.bfloat16, torch.float32
@@ -148,7 +148,7 @@ class MultiHeadAttentionWithCache(nn.Module):
         Sk new keys / values (mask then spans Sp + Sk keys); with use_cache the result is (output, (key, value)) — the new cache in the
         reference's [B, H, Sp + Sk, hd] shape, held in bf16 as views of one token-major buffer (feeding it back costs no conversion)."""
         if self.training and self.dropout > 0:
-            raise ops.MmamdError("attention dropout > 0 in training mode is not implemented on the MI355X path")
+            raise ops.MmamdError("this non-differentiable (stand-alone / inference) forward applies no dropout: call .eval(); training-time dropout runs inside the encoder / decoder stacks' differentiable forwards")
         dq = self.q_proj.out_features
         hd = _check_heads(dq, self.num_heads)
         pc, bf, f32 = self._packed, torch.bfloat16, torch.float32

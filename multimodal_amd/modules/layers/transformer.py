@@ -251,7 +251,8 @@ class TransformerDecoderLayer(nn.Module):
         """x: fp32 [B*S, d]; enc: bf16 [B*Sk, dim_kv] encoder states (already converted once per decoder) or None.  With `past` /
         use_cache the self-attention runs over the cached + new keys (reference :336-359) and the result is (y, present)."""
         if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
-            raise ops.MmamdError("dropout > 0 in training mode is not implemented on the MI355X path")
+            raise ops.MmamdError("this non-differentiable forward applies no dropout: call .eval() for inference (training goes through "
+                                 "TransformerDecoder's differentiable forward, which does apply it)")
         bf, f32, pc = torch.bfloat16, torch.float32, self._packed
         cross_mask = cross_mask or ops.AttnMask()
         caching = past is not None or use_cache
@@ -446,19 +447,24 @@ class TransformerDecoder(nn.Module):
 
 def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, attention_mask, return_hidden_states: bool) -> TransformerOutput:
     """Differentiable TransformerDecoder.forward (DecoderStackFn: self-attention with the mask, optional cross-attention, feed-forward)."""
-    from ..._autograd import DecoderStackConfig, DecoderStackFn
+    from ..._autograd import DecoderStackConfig, DecoderStackFn, draw_seed
 
     if return_hidden_states:
         raise ops.MmamdError("training on the MI355X path: return_hidden_states is not implemented for TransformerDecoder")
     B, S, d = hidden_states.shape
     mask = to_attn_mask(attention_mask, False, B, S, S)
     layers, params = [], []
+    drop_rates = set()
     for layer in self.layer:
-        if not layer.norm_first or layer.attention_dropout.p > 0 or layer.feedforward_dropout.p > 0:
-            # (the decoder's MultiHeadAttentionWithCache also drops attention PROBABILITIES at the same rate, reference :262-266 -- the part of
-            #  training-time dropout that is not implemented; the encoder stacks, whose attention has none, do train with dropout)
-            raise ops.MmamdError("training on the MI355X path implements pre-norm decoder layers without dropout (attention-probability dropout "
-                                 "is not implemented)")
+        if not layer.norm_first:
+            raise ops.MmamdError("training on the MI355X path implements pre-norm decoder layers")
+        # training-time dropout: the reference builds every dropout of a decoder layer from ONE value (:262-290) -- attention probabilities
+        # (MultiHeadAttentionWithCache.dropout), the three residual branches, the MLP's hidden dropout
+        rates = {float(layer.attention_dropout.p), float(layer.feedforward_dropout.p), float(layer.feedforward.hidden_dropout_p()),
+                 float(layer.attention.dropout)}
+        if layer.use_cross_attention and layer.cross_attention is not None:
+            rates |= {float(layer.cross_attention_dropout.p), float(layer.cross_attention.dropout)}
+        drop_rates.update(rates)
         steps = layer.feedforward.plan()
         if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
             raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
@@ -483,7 +489,10 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
         Sk = encoder_hidden_states.shape[1]
         e = encoder_hidden_states if encoder_hidden_states.is_contiguous() else encoder_hidden_states.contiguous()
         enc2d = e.view(B * Sk, e.shape[-1])
-    cfg = DecoderStackConfig(B, S, Sk, layers, mask)
+    if len(drop_rates) > 1:
+        raise ops.MmamdError(f"training: all dropout sites of a decoder stack must share one rate, got {sorted(drop_rates)}")
+    drop_p = drop_rates.pop() if drop_rates else 0.0
+    cfg = DecoderStackConfig(B, S, Sk, layers, mask, drop_p=drop_p, seed=draw_seed() if drop_p > 0 else 0)
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
     x = DecoderStackFn.apply(xc.view(B * S, d), enc2d, cfg, *params).view(B, S, d)
     if self.final_layer_norm is not None:

@@ -309,3 +309,47 @@ def test_flava_encoder_with_dropout_on_every_site():
         for got, want, name in ((gq, layers[li]["Wqkv"].grad, "Wqkv"), (layer.attention.output.weight.grad.cpu(), layers[li]["Wo"].grad, "Wo"),
                                 (layer.feedforward.model[0].weight.grad.cpu(), layers[li]["W1"].grad, "W1")):
             assert float((got - want).abs().max()) < 6e-2 * float(want.abs().max()) + 1e-6, (li, name)
+
+
+def test_decoder_stack_trains_with_dropout():
+    """TransformerDecoder (CoCa's text / multimodal decoders) with dropout > 0: all six sites per layer (self- and cross-attention
+    probabilities, three residual branches, the MLP) run; eval == dropout-free; two training forwards differ; p -> 0 converges to the
+    dropout-free gradients (the masks keep everything when p is tiny: same arithmetic through the dropout code path)."""
+    import copy
+
+    from multimodal_amd.modules.layers.transformer import TransformerDecoder
+
+    torch.manual_seed(8)
+    kw = dict(n_layer=2, d_model=128, n_head=2, dim_feedforward=256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True,
+              use_cross_attention=True, dim_kv=128)
+    dec0 = TransformerDecoder(dropout=0.0, **kw).cuda().train()
+    decp = TransformerDecoder(dropout=1e-9, **kw).cuda().train()   # takes the dropout code path, drops (almost surely) nothing
+    decd = TransformerDecoder(dropout=0.3, **kw).cuda().train()
+    sd = copy.deepcopy(dec0.state_dict())
+    for m in (decp, decd):
+        # Dropout modules shift the MLP's Sequential indices: feedforward.model.2 -> .3
+        m.load_state_dict({k.replace("feedforward.model.2.", "feedforward.model.3."): v for k, v in sd.items()}, strict=True)
+    x = torch.randn(3, 12, 128, device="cuda")
+    enc = torch.randn(3, 9, 128, device="cuda")
+    causal = torch.ones(12, 12, dtype=torch.bool, device="cuda").tril()
+    w = torch.randn(3, 12, 128, device="cuda")
+
+    def step(m):
+        m.zero_grad()
+        y = m(x, enc, attention_mask=causal).last_hidden_state
+        (y * w).sum().backward()
+        return y.detach(), [p.grad.clone() for p in m.parameters()]
+
+    y0, g0 = step(dec0)
+    yp, gp = step(decp)
+    assert float((y0 - yp).abs().max()) < 1e-3 * float(y0.abs().max()) + 1e-4
+    for a, b in zip(g0, gp):
+        assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max()) + 1e-5
+    y1, g1 = step(decd)
+    y2, _ = step(decd)
+    assert float((y1 - y2).abs().max()) > 1e-3 and float((y1 - y0).abs().max()) > 1e-3   # fresh masks per forward
+    assert all(torch.isfinite(g).all() for g in g1)
+    decd.eval()
+    with torch.no_grad():
+        ye = decd(x, enc, attention_mask=causal).last_hidden_state
+    assert float((ye - y0).abs().max()) < 2e-2 * float(y0.abs().max())   # eval: dropout is the identity (inference kernels vs training forward)
