@@ -1113,6 +1113,264 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const bf16* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// FUSED attention backward (r04; S <= 256).  The two kernels above each stage half of a head's operands, fetch the other half as
+// fragment-shaped global loads (32 rows x 32 B per wave-instruction) and store their results 8 bytes per lane: ~1 GB of HBM traffic per
+// ViT-B/16 launch pair for 618 MB of operands, at poor coalescing.  Here ONE persistent workgroup per CU walks the (batch, head) items:
+//   * the four row images Q, K, V, dO of the head (+ log-sum-exp, D = sum dO.O, key mask) are staged ONCE, as whole 128-byte row segments;
+//   * wave w runs the dK / dV role for key tile w (lane = key: S^T, dP^T, dV += P^T dO, dK += dS^T Q) and then the dQ role for query tile w
+//     (lane = query: S, dP, dS, dQ += dS K), both out of the same images -- every MFMA operand is an LDS read (row fragments by ds_read_b128,
+//     transposed ones by ds_read_b64_tr_b16), nothing fragment-shaped touches HBM.  (Both roles at once on 16 waves would cap a wave at 128
+//     registers: the dK / dV role needs 162 and spilled 100 of them.)
+//   * the results go back through the dead images (dQ over Q, dK over K, dV over V) and leave as whole rows [dq | dk | dv].
+// Same arithmetic per element as the two-kernel form (the products, their operand roundings and the summation order inside a tile pair are
+// unchanged), so the gradients are bit-identical to it (tests/test_gpu_backward_kernels.py).
+// ---------------------------------------------------------------------------------------------------------
+template <int NKT, bool CAUSAL, int NWH>
+__global__ __launch_bounds__(NWH * 64) void attention_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+                                                                          const bf16* __restrict__ dO, const float* __restrict__ lse,
+                                                                          bf16* __restrict__ dqkv, int S, int H, int BH, float scale,
+                                                                          const uint8_t* __restrict__ key_mask) {
+  static_assert(NKT <= NWH, "one tile per wave and role");
+  constexpr int SP = NKT * 32;
+  constexpr int NT = NWH * 64;  // threads
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qs = reinterpret_cast<bf16*>(smem);
+  bf16* Ks = Qs + SP * kKStride;
+  bf16* Vs = Ks + SP * kKStride;
+  bf16* dOs = Vs + SP * kKStride;
+  float* L2s = reinterpret_cast<float*>(dOs + SP * kKStride);
+  float* Dqs = L2s + SP;
+  uint8_t* Mk = reinterpret_cast<uint8_t*>(Dqs + SP);  // 1 = key may be attended
+  const int D = H * kDh;
+  const size_t row_stride = (size_t)3 * D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const int nt_s = (S + 31) >> 5;  // live tiles (<= NKT)
+
+  for (int item = blockIdx.x; item < BH; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
+    // ---- stage: 8 threads per row, 16 bytes each of q, k, v, dO, O
+    for (int r = tid >> 3; r < SP; r += NT >> 3) {
+      const int c = tid & 7;
+      bf16x8 qv, kv, vv, dv, ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qv[j] = (bf16)0.f; kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; dv[j] = (bf16)0.f; ov[j] = (bf16)0.f; }
+      if (r < S) {
+        const bf16* row = base + (size_t)r * row_stride + c * 8;
+        qv = *reinterpret_cast<const bf16x8*>(row);
+        kv = *reinterpret_cast<const bf16x8*>(row + D);
+        vv = *reinterpret_cast<const bf16x8*>(row + 2 * D);
+        dv = *reinterpret_cast<const bf16x8*>(dO + ((size_t)b * S + r) * D + h * kDh + c * 8);
+        ov = *reinterpret_cast<const bf16x8*>(O + ((size_t)b * S + r) * D + h * kDh + c * 8);
+      }
+      *reinterpret_cast<bf16x8*>(Qs + r * kKStride + c * 8) = qv;
+      *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
+      *reinterpret_cast<bf16x8*>(Vs + r * kKStride + c * 8) = vv;
+      *reinterpret_cast<bf16x8*>(dOs + r * kKStride + c * 8) = dv;
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += (float)dv[j] * (float)ov[j];
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      if (c == 0) {
+        Dqs[r] = r < S ? part : 0.f;
+        L2s[r] = r < S ? lse[((size_t)b * H + h) * S + r] : INFINITY;  // +inf: a padded query has P = exp2(-inf) = 0
+        Mk[r] = (r < S && (key_mask == nullptr || key_mask[(size_t)b * S + r] != 0)) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+
+    f32x16 dq_acc[2], dv_acc[2], dk_acc[2];
+    const int tile = wave;
+    if (tile < nt_s) {
+      {
+        // ---------------- dQ role: lane = query ----------------
+        const int qt = tile;
+        const int q = qt * 32 + l31;
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          qf[t] = *reinterpret_cast<const bf16x8*>(Qs + q * kKStride + 16 * t + 8 * half);
+          dof[t] = *reinterpret_cast<const bf16x8*>(dOs + q * kKStride + 16 * t + 8 * half);
+        }
+        const float Dq = Dqs[q], L2 = L2s[q];
+        const bf16* ktr = Ks + tr_off(lane, kKStride);
+        const int kt_hi = CAUSAL ? (qt + 1 < nt_s ? qt + 1 : nt_s) : nt_s;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dq_acc[nt][r] = 0.f;
+#pragma unroll 1
+        for (int kt = 0; kt < kt_hi; ++kt) {
+          f32x16 st, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+          const bf16* krow = Ks + (kt * 32 + l31) * kKStride + 8 * half;
+          const bf16* vrow = Vs + (kt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow + 16 * t), qf[t], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(vrow + 16 * t), dof[t], dp, 0, 0, 0);
+          }
+          uint32_t pk[8];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t mk4 = *reinterpret_cast<const uint32_t*>(Mk + kt * 32 + 8 * g + 4 * half);  // the 4 keys of this group
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * g + j;
+              const int key = kt * 32 + 8 * g + 4 * half + j;
+              const bool ok = ((mk4 >> (8 * j)) & 1u) != 0 && (!CAUSAL || key <= q);
+              const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2) : 0.f;
+              e[j] = pr * (dp[r] - Dq);
+            }
+            bf16x2 p0, p1;
+            p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+            pk[2 * g] = __builtin_bit_cast(uint32_t, p0);
+            pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            u32x4 pw;
+            pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const bf16* kp = ktr + (kt * 32 + 16 * jj) * kKStride + nt * 32;
+              const uint2 v0 = lds_tr_b64(kp);
+              const uint2 v1 = lds_tr_b64(kp + 8 * kKStride);
+              u32x4 vw;
+              vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+              dq_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), dsf, dq_acc[nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      {
+        // ---------------- dK / dV role: lane = key ----------------
+        const int kt = tile;
+        const int key = kt * 32 + l31;
+        const bool key_live = Mk[key] != 0;  // a masked / padded key has P = 0: dK = dV = 0
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          kf[t] = *reinterpret_cast<const bf16x8*>(Ks + key * kKStride + 16 * t + 8 * half);
+          vf[t] = *reinterpret_cast<const bf16x8*>(Vs + key * kKStride + 16 * t + 8 * half);
+        }
+        const bf16* qtr = Qs + tr_off(lane, kKStride);
+        const bf16* dotr = dOs + tr_off(lane, kKStride);
+        const int qt_lo = CAUSAL ? kt : 0;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { dv_acc[nt][r] = 0.f; dk_acc[nt][r] = 0.f; }
+#pragma unroll 1
+        for (int qt = qt_lo; qt < nt_s; ++qt) {
+          f32x16 st, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+          const bf16* qrow = Qs + (qt * 32 + l31) * kKStride + 8 * half;
+          const bf16* drow = dOs + (qt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qrow + 16 * t), kf[t], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(drow + 16 * t), vf[t], dp, 0, 0, 0);
+          }
+          uint32_t pk[8], dk[8];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float e[4], f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * g + j;
+              const int q = qt * 32 + 8 * g + 4 * half + j;
+              const bool ok = key_live && (!CAUSAL || key <= q);
+              const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;
+              e[j] = pr;
+              f[j] = pr * (dp[r] - Dqs[q]);
+            }
+            bf16x2 p0, p1, d0, d1;
+            p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+            d0[0] = (bf16)f[0]; d0[1] = (bf16)f[1]; d1[0] = (bf16)f[2]; d1[1] = (bf16)f[3];
+            pk[2 * g] = __builtin_bit_cast(uint32_t, p0); pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+            dk[2 * g] = __builtin_bit_cast(uint32_t, d0); dk[2 * g + 1] = __builtin_bit_cast(uint32_t, d1);
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            u32x4 pw, dw;
+            pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+            dw[0] = dk[4 * jj + 0]; dw[1] = dk[4 * jj + 1]; dw[2] = dk[4 * jj + 2]; dw[3] = dk[4 * jj + 3];
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dw);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int toff = (qt * 32 + 16 * jj) * kKStride + nt * 32;
+              const uint2 a0 = lds_tr_b64(dotr + toff), a1 = lds_tr_b64(dotr + toff + 8 * kKStride);
+              const uint2 b0 = lds_tr_b64(qtr + toff), b1 = lds_tr_b64(qtr + toff + 8 * kKStride);
+              u32x4 aw, bw;
+              aw[0] = a0.x; aw[1] = a0.y; aw[2] = a1.x; aw[3] = a1.y;
+              bw[0] = b0.x; bw[1] = b0.y; bw[2] = b1.x; bw[3] = b1.y;
+              dv_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), pf, dv_acc[nt], 0, 0, 0);
+              dk_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), dsf, dk_acc[nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // every role is done reading the images: they become the output staging area
+    if (tile < nt_s) {
+      const int row = tile * 32 + l31;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = nt * 32 + 8 * g + 4 * half;
+          f32x4 a, c, e;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = dq_acc[nt][4 * g + j] * scale; c[j] = dk_acc[nt][4 * g + j] * scale; e[j] = dv_acc[nt][4 * g + j]; }
+          store4(Qs + row * kKStride + col, a);   // dQ over Q
+          store4(Ks + row * kKStride + col, c);   // dK over K
+          store4(Vs + row * kKStride + col, e);   // dV over V
+        }
+    }
+    __syncthreads();
+    // ---- whole rows out: [dq | dk | dv], 8 threads x 16 bytes per 128-byte segment
+    bf16* obase = dqkv + (size_t)b * S * row_stride + h * kDh;
+    for (int r = tid >> 3; r < S; r += NT >> 3) {
+      const int c = tid & 7;
+      bf16* orow = obase + (size_t)r * row_stride + c * 8;
+      *reinterpret_cast<bf16x8*>(orow) = *reinterpret_cast<const bf16x8*>(Qs + r * kKStride + c * 8);
+      *reinterpret_cast<bf16x8*>(orow + D) = *reinterpret_cast<const bf16x8*>(Ks + r * kKStride + c * 8);
+      *reinterpret_cast<bf16x8*>(orow + 2 * D) = *reinterpret_cast<const bf16x8*>(Vs + r * kKStride + c * 8);
+    }
+    __syncthreads();  // the next item's staging overwrites the images
+  }
+}
+
+template <int NKT, int NWH>
+static int launch_attn_bwd_fused(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
+                                 float scale, hipStream_t st, const uint8_t* key_mask) {
+  constexpr int SP = NKT * 32;
+  constexpr int smem = 4 * SP * kKStride * 2 + 2 * SP * 4 + SP;
+  auto kc = attention_bwd_fused_kernel<NKT, true, NWH>;
+  auto kn = attention_bwd_fused_kernel<NKT, false, NWH>;
+  static unsigned long long mc = 0, mn = 0;
+  if (int rc_attr = opt_in_lds((const void*)kc, smem, mc)) return rc_attr;
+  if (int rc_attr = opt_in_lds((const void*)kn, smem, mn)) return rc_attr;
+  const int per_cu = (160 * 1024) / smem >= 2 ? 2 : 1;
+  const int slots = per_cu * stream_cus(st);
+  const int BH = B * H;
+  const int grid = BH < slots ? BH : slots;
+  if (causal) hipLaunchKernelGGL(kc, dim3(grid), dim3(NWH * 64), smem, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, BH, scale, key_mask);
+  else hipLaunchKernelGGL(kn, dim3(grid), dim3(NWH * 64), smem, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, BH, scale, key_mask);
+  return launch_status("attention_bwd_fused");
+}
+
 template <int NKT>
 static int launch_attn_bwd(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
                            float scale, hipStream_t st, const uint8_t* key_mask) {
@@ -1531,6 +1789,19 @@ extern "C" int mmamd_attention_bwd(const void* qkv, const void* out, const void*
   MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), MMAMD_E_ALIGN, "attention_bwd: pointers must be 16-byte aligned");
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (g_attn_variant != 2000) {  // the fused kernel (S <= 256); mmamd_debug_set_attn_variant(2000) keeps the two-kernel form for the A/B
+    switch ((S + 31) / 32) {
+      case 1: return launch_attn_bwd_fused<1, 4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 2: return launch_attn_bwd_fused<2, 4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 3: return launch_attn_bwd_fused<3, 4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 4: return launch_attn_bwd_fused<4, 4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 5: return launch_attn_bwd_fused<5, 8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 6: return launch_attn_bwd_fused<6, 8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 7: return launch_attn_bwd_fused<7, 8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 8: return launch_attn_bwd_fused<8, 8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      default: break;
+    }
+  }
   switch ((S + 31) / 32) {
     case 1: return launch_attn_bwd<1>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
     case 2: return launch_attn_bwd<2>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);

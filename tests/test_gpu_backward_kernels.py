@@ -575,3 +575,31 @@ def test_pack_weights_equals_convert_and_transpose_per_tensor():
         assert torch.equal(tr, ops.transpose_to_bf16(w, pad_to=64))
     only_t = ops.pack_weights(ws[:5], want_nt=False)
     assert only_t[0] is None and all(torch.equal(a, b) for a, b in zip(only_t[1], trs[:5]))
+
+
+@pytest.mark.parametrize("B,S,H,causal,masked", [(3, 197, 12, False, False), (4, 77, 8, True, False), (2, 256, 4, False, True), (2, 50, 2, True, True),
+                                                  (1, 1, 2, False, False), (2, 130, 3, False, True), (5, 33, 2, True, False)])
+def test_fused_attention_backward_equals_the_two_kernel_form(B, S, H, causal, masked):
+    """r04: ONE persistent kernel per launch (four row images of a head in LDS, both roles per wave, whole-row loads and stores) replaces the
+    dQ and dK/dV kernels for S <= 256.  Same products, operand roundings and summation order per tile pair -> the gradients are BIT-identical
+    to the two-kernel form (which stays for 256 < S <= 288 and as mmamd_debug_set_attn_variant(2000))."""
+    from multimodal_amd import _lib, ops
+
+    torch.manual_seed(B * 1000 + S)
+    qkv = torch.randn(B * S, 3 * H * 64).to(torch.bfloat16).cuda()
+    dout = torch.randn(B * S, H * 64).to(torch.bfloat16).cuda()
+    km = None
+    if masked:
+        km = (torch.rand(B, S) > 0.3).to(torch.uint8)
+        km[:, 0] = 1
+        km = km.cuda()
+    out, lse = ops.attention_fwd_train(qkv, B, S, H, causal, km)
+    L = _lib.lib()
+    try:
+        L.mmamd_debug_set_attn_variant(2000)
+        ref = ops.attention_bwd(qkv, out, dout, lse, B, S, H, causal, km)
+    finally:
+        L.mmamd_debug_set_attn_variant(0)
+    got = ops.attention_bwd(qkv, out, dout, lse, B, S, H, causal, km)
+    assert torch.equal(got, ref)
+    assert torch.isfinite(got.float()).all()

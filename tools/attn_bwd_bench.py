@@ -18,7 +18,8 @@ def main():
         out, lse = ops.attention_fwd_train(qkv, B, S, H, causal)
         res = {}
         for rnd in range(2):
-            for code, tag in ((0, "shipped"),):
+            for code, tag in ((0, "fused (shipped)"), (2000, "two kernels (r03)")):
+                L.mmamd_debug_set_attn_variant(code)
                 for _ in range(2):
                     d = ops.attention_bwd(qkv, out, dout, lse, B, S, H, causal)
                 torch.cuda.synchronize()
@@ -30,6 +31,8 @@ def main():
                 torch.cuda.synchronize()
                 res[code] = d
                 print(f"S={S} causal={int(causal)} {tag}: {e0.elapsed_time(e1) * 200:7.1f} us", flush=True)
+        L.mmamd_debug_set_attn_variant(0)
+        print(f"S={S}: fused == two kernels bit for bit: {torch.equal(res[0], res[2000])}", flush=True)
 
 
 if __name__ == "__main__":
