@@ -148,6 +148,9 @@ class FLAVAModel(PackedModeMixin, nn.Module):
         # arithmetic is independent of the row's position in the batch: tests/test_gpu_bench_size_parity.py; a patch mask of zeros blends
         # nothing: csrc/rowops.hip::flava_image_embed_kernel).  Encoders with forward hooks, and training, keep the two calls.
         batched = not training and get_schedule().flava_batched_passes
+        if (batched and get_schedule().flava_grouped and want_image and want_text and want_text_masked and image_patches_mask is not None
+                and self._groupable(image, text, text_masked, image_patches_mask)):
+            return self._forward_grouped(image, text, image_patches_mask, text_masked, required_embedding, skip_unmasked_mm_encoder)
         ctx = torch.cuda.stream(side) if side is not None else _Null()
         with ctx:
             if (batched and want_text and want_text_masked and _plain_call(self.text_encoder) and text.shape == text_masked.shape
@@ -203,6 +206,52 @@ class FLAVAModel(PackedModeMixin, nn.Module):
             projected_image_embeddings=projected_image_embeddings,
             projected_text_embeddings=projected_text_embeddings,
         )
+
+    def _groupable(self, image, text, text_masked, image_patches_mask) -> bool:
+        from ...modules.encoders.bert_text_encoder import BERTTextEncoder
+        from .image_encoder import ImageTransformer
+        from .transformer import TransformerEncoder, two_encoders_groupable
+
+        ie, te = self.image_encoder, self.text_encoder
+        if type(ie) is not ImageTransformer or type(te) is not BERTTextEncoder or not _plain_call(ie) or not _plain_call(te):
+            return False
+        if type(ie.encoder) is not TransformerEncoder or type(te.encoder) is not TransformerEncoder or te.layernorm is None or ie.layernorm is None:
+            return False
+        if text.shape != text_masked.shape or text.dtype != text_masked.dtype or image_patches_mask.shape[0] != image.shape[0] or text.shape[0] != image.shape[0]:
+            return False
+        return two_encoders_groupable(ie.encoder, te.encoder)
+
+    def _forward_grouped(self, image, text, image_patches_mask, text_masked, required_embedding, skip_unmasked_mm_encoder) -> FLAVAOutput:
+        """schedule.flava_grouped: the 2B-batch image pass and the 2B-batch text pass (schedule.flava_batched_passes) LAYER-LOCKED on one stream --
+        stems, models/flava/transformer.py::run_two_encoders, heads; then the multimodal encoder as in forward().  Bit-identical outputs."""
+        from .transformer import run_two_encoders
+
+        B = image.shape[0]
+        ie, te = self.image_encoder, self.text_encoder
+        m = image_patches_mask.reshape(B, -1)
+        xa = ie.embeddings(torch.cat([image, image]), image_patches_mask=torch.cat([torch.zeros_like(m), m]))
+        ids = torch.cat([text, text_masked])
+        ids = ids if ids.is_contiguous() else ids.contiguous()
+        km = ops.key_mask(ids, pad_id=te.embeddings.pad_token_id) if hasattr(te.embeddings, "pad_token_id") else None
+        xb = te.embeddings(input_ids=ids)
+        (ya, ha, pa), (yb, hb, pb) = run_two_encoders(ie.encoder, xa, None, te.encoder, xb, km, want_probs=True)
+        sa = ie.layernorm(ya)
+        both_i = TransformerOutput(last_hidden_state=sa, pooler_output=ie.pooler(sa) if ie.pooler is not None else None, hidden_states=ha, attentions=pa)
+        sb = te.layernorm(yb)
+        both_t = TransformerOutput(last_hidden_state=sb, pooler_output=te.pooler(sb) if te.pooler is not None else None, hidden_states=hb, attentions=pb)
+        image_outputs, image_masked_outputs = _split_batch(both_i, B)
+        text_outputs, text_masked_outputs = _split_batch(both_t, B)
+        projected_image_embeddings = cls_linear(image_outputs.last_hidden_state, self.image_projection, self._packed)
+        projected_text_embeddings = cls_linear(text_outputs.last_hidden_state, self.text_projection, self._packed)
+        multimodal_outputs = TransformerOutput()
+        multimodal_masked_outputs = TransformerOutput()
+        if required_embedding == "mm":
+            if not skip_unmasked_mm_encoder:
+                multimodal_outputs = self.encode_mm(image_outputs.hidden_states[-1], text_outputs.hidden_states[-1])
+            multimodal_masked_outputs = self.encode_mm(image_masked_outputs.hidden_states[-1], text_masked_outputs.hidden_states[-1])
+        return FLAVAOutput(image=image_outputs, image_masked=image_masked_outputs, text=text_outputs, text_masked=text_masked_outputs,
+                           multimodal=multimodal_outputs, multimodal_masked=multimodal_masked_outputs,
+                           projected_image_embeddings=projected_image_embeddings, projected_text_embeddings=projected_text_embeddings)
 
     def encode_image(self, image: Tensor, image_patches_mask: Optional[Tensor] = None, projection: bool = False
                      ) -> Union[Tuple[TransformerOutput, Tensor], Optional[TransformerOutput]]:

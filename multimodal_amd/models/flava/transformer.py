@@ -191,6 +191,91 @@ class TransformerEncoder(nn.Module):
         return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, attentions=all_self_attentions)
 
 
+def two_encoders_groupable(ea: "TransformerEncoder", eb: "TransformerEncoder") -> bool:
+    """run_two_encoders applies: inference, pre-norm layers of equal depth, 64-wide heads, Linear -> GELU / QuickGELU -> Linear feed-forward
+    blocks with the SAME activation (one grouped launch has one epilogue kind), no forward hooks on the layers."""
+    if len(ea.layer) != len(eb.layer) or ea.final_layer_norm is not None or eb.final_layer_norm is not None:
+        return False
+    acts = set()
+    for enc in (ea, eb):
+        for layer in enc.layer:
+            at = layer.attention
+            if (not layer.norm_first or layer._forward_hooks or layer._forward_pre_hooks or at.d_qk != 64 or at.key.in_features != at.query.in_features
+                    or not isinstance(at.attn, SelfAttention) or at.query.bias is None):
+                return False
+            try:
+                steps = layer.feedforward.plan()
+            except ops.MmamdError:
+                return False
+            if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
+                return False
+            acts.add(steps[0][1])
+    return len(acts) == 1
+
+
+def run_two_encoders(ea: "TransformerEncoder", xa: Tensor, km_a: Optional[Tensor], eb: "TransformerEncoder", xb: Tensor, km_b: Optional[Tensor],
+                     want_probs: bool = True):
+    """Both towers of FLAVA's dual encoder LAYER-LOCKED on one stream (reference models/flava/model.py:127-205 runs them one after the other; they
+    are independent until the multimodal encoder): per layer ONE grouped LayerNorm launch, ONE grouped persistent GEMM for each of the four
+    projections over both towers' tiles (mmamd_gemm_bf16_grouped), and the two attention launches (probabilities, key-padding mask).  Same kernels'
+    arithmetic per tower as TransformerEncoder.forward -> bit-identical outputs (tests/test_gpu_bench_size_parity.py).
+    xa / xb: fp32 [B, S, d].  Returns ((x_L, hidden states, probabilities) per tower), every layer writing NEW residual-stream buffers (the hidden
+    states FLAVA hands out are the live buffers, not copies)."""
+    bf, f32 = torch.bfloat16, torch.float32
+    (Ba, Sa, da), (Bb, Sb, db) = xa.shape, xb.shape
+    xa2 = (xa if xa.is_contiguous() else xa.contiguous()).view(Ba * Sa, da)
+    xb2 = (xb if xb.is_contiguous() else xb.contiguous()).view(Bb * Sb, db)
+    dev = xa.device
+    hid_a, hid_b, pr_a, pr_b = [xa2.view(Ba, Sa, da)], [xb2.view(Bb, Sb, db)], [], []
+
+    def ln_pair(la, lb, ua, ub, oa, ob):
+        pa, pb = la._packed.get, lb._packed.get
+        na, nb = ua, ub
+        ops.add_layernorm_grouped([(oa[0], None, pa(na.weight, f32), pa(na.bias, f32), na.eps, oa[1]),
+                                   (ob[0], None, pb(nb.weight, f32), pb(nb.bias, f32), nb.eps, ob[1])])
+
+    hna = torch.empty((Ba * Sa, da), dtype=bf, device=dev)
+    hnb = torch.empty((Bb * Sb, db), dtype=bf, device=dev)
+    qkva = torch.empty((Ba * Sa, 3 * da), dtype=bf, device=dev)
+    qkvb = torch.empty((Bb * Sb, 3 * db), dtype=bf, device=dev)
+    atta, attb = torch.empty_like(hna), torch.empty_like(hnb)
+    ffa = ea.layer[0].feedforward.plan()[0][0].out_features
+    ffb = eb.layer[0].feedforward.plan()[0][0].out_features
+    upa = torch.empty((Ba * Sa, ffa), dtype=bf, device=dev)
+    upb = torch.empty((Bb * Sb, ffb), dtype=bf, device=dev)
+    for la, lb in zip(ea.layer, eb.layer):
+        aa, ab = la.attention, lb.attention
+        ca, cb = aa._packed, ab._packed
+        ln_pair(la, lb, la.attention_layernorm, lb.attention_layernorm, (xa2, hna), (xb2, hnb))
+        ops.gemm_bf16_grouped([(hna, ca.get_cat([aa.query.weight, aa.key.weight, aa.value.weight], bf),
+                                ca.get_cat([aa.query.bias, aa.key.bias, aa.value.bias], f32), None, qkva),
+                               (hnb, cb.get_cat([ab.query.weight, ab.key.weight, ab.value.weight], bf),
+                                cb.get_cat([ab.query.bias, ab.key.bias, ab.value.bias], f32), None, qkvb)])
+        for qkv, B, S, H, km, att, prs in ((qkva, Ba, Sa, aa.n_head, km_a, atta, pr_a), (qkvb, Bb, Sb, ab.n_head, km_b, attb, pr_b)):
+            if want_probs or km is not None:
+                _, probs = ops.attention_probs_fwd(qkv, B, S, H, km, want_probs=want_probs, out=att)
+            else:
+                ops.attention_fwd(qkv, B, S, H, causal=False, out=att)
+                probs = None
+            if want_probs:
+                prs.append(probs)
+        x1a, x1b = torch.empty_like(xa2), torch.empty_like(xb2)
+        ops.gemm_bf16_grouped([(atta, ca.get(aa.output.weight, bf), ca.get(aa.output.bias, f32), xa2, x1a),
+                               (attb, cb.get(ab.output.weight, bf), cb.get(ab.output.bias, f32), xb2, x1b)], out_dtype=f32)
+        ln_pair(la, lb, la.feedforward_layernorm, lb.feedforward_layernorm, (x1a, hna), (x1b, hnb))
+        (l1a, act), (l2a, _) = la.feedforward.plan()
+        (l1b, _), (l2b, _) = lb.feedforward.plan()
+        fa, fb = la.feedforward._packed.get, lb.feedforward._packed.get
+        ops.gemm_bf16_grouped([(hna, fa(l1a.weight, bf), fa(l1a.bias, f32), None, upa), (hnb, fb(l1b.weight, bf), fb(l1b.bias, f32), None, upb)],
+                              act=act)
+        ops.gemm_bf16_grouped([(upa, fa(l2a.weight, bf), fa(l2a.bias, f32), x1a, x1a), (upb, fb(l2b.weight, bf), fb(l2b.bias, f32), x1b, x1b)],
+                              out_dtype=f32)
+        xa2, xb2 = x1a, x1b
+        hid_a.append(xa2.view(Ba, Sa, da))
+        hid_b.append(xb2.view(Bb, Sb, db))
+    return (hid_a[-1], hid_a, pr_a if want_probs else None), (hid_b[-1], hid_b, pr_b if want_probs else None)
+
+
 def init_transformer_weights(module: nn.Module, initializer_range: float) -> None:
     """Initialize the weights (reference :296-310)."""
     if isinstance(module, (nn.Linear, nn.Conv2d)):

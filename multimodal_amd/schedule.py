@@ -18,6 +18,9 @@ Every choice is between paths that compute the same function; the defaults are t
                                                   on two streams with half the chip's CUs each, the second `phase_lead` launches behind the first, so
                                                   that one half's HBM-bound kernels run beside the other's matrix-bound ones
 
+    flava_grouped  True | False                   FLAVA inference with both towers wanted: the image and the text encoder layer-locked on one
+                                                  stream with grouped LayerNorm / GEMM launches (models/flava/transformer.py::run_two_encoders)
+                                                  instead of the text tower on a side stream
     train_attentions  True | False                FLAVA training forwards also return the per-layer attention probabilities (recomputed by the
                                                   inference kernel, detached) like the reference's; False: attentions = None (saves one attention
                                                   launch per layer and the S^2 writes)
@@ -43,6 +46,7 @@ class Schedule:
     phases: int = 1
     phase_lead: int = 4
     train_attentions: bool = True
+    flava_grouped: bool = False
 
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:

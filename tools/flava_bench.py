@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-loss", action="store_true")
     ap.add_argument("--train", action="store_true", help="training step: forward + pre-training loss + backward + SGD")
+    ap.add_argument("--grouped", action="store_true", help="schedule.flava_grouped: image and text towers layer-locked with grouped launches")
     ap.add_argument("--codebook", action="store_true", help="MIM labels from the DALL-E codebook (112x112 images) inside the step instead of synthetic ones")
     a = ap.parse_args()
     from multimodal_amd.models.flava.model import flava_model
@@ -28,6 +29,10 @@ def main():
 
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
+    if a.grouped:
+        from multimodal_amd.schedule import set_schedule
+
+        set_schedule(flava_grouped=True)
     model = flava_model().to(dev)
     loss = FLAVAPretrainingLoss().to(dev)
     model, loss = (model.train(), loss.train()) if a.train else (model.eval(), loss.eval())

@@ -17,7 +17,13 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--attn-variant", type=int, default=0, help="mmamd_debug_set_attn_variant code (2000 = the two-kernel attention backward)")
+    ap.add_argument("--gemm-gm", type=int, default=0, help="mmamd_debug_set_gemm_knob(0, gm): tile-order group (8 = the r03 order)")
     a = ap.parse_args()
+    from multimodal_amd import _lib
+
+    _lib.lib().mmamd_debug_set_attn_variant(a.attn_variant)
+    _lib.lib().mmamd_debug_set_gemm_knob(0, a.gemm_gm)
     from multimodal_amd.models.clip import clip_vit_b16
     from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
     from multimodal_amd.utils.synthetic import clip_batch
