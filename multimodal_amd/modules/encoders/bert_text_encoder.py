@@ -41,12 +41,12 @@ class BERTTextEncoder(nn.Module):
     ) -> TransformerOutput:
         if input_ids is None and inputs_embeds is None:
             raise ValueError("input_ids or inputs_embeds must not be None")
-        if input_ids is None:
-            raise ops.MmamdError("inputs_embeds is not implemented on the MI355X path (pass input_ids)")
-        ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
+        ids = None
+        if input_ids is not None:
+            ids = input_ids if input_ids.is_contiguous() else input_ids.contiguous()
         if attention_mask is None:
-            # only mask out padding tokens if no mask specified (reference :84-88)
-            if hasattr(self.embeddings, "pad_token_id"):
+            # only mask out padding tokens if no mask specified (reference :84-88); with inputs_embeds alone every position is attended (:86-87)
+            if ids is not None and hasattr(self.embeddings, "pad_token_id"):
                 key_mask = ops.key_mask(ids, pad_id=self.embeddings.pad_token_id)
             else:
                 key_mask = None
@@ -54,7 +54,7 @@ class BERTTextEncoder(nn.Module):
             key_mask = ops.key_mask(attention_mask if attention_mask.is_contiguous() else attention_mask.contiguous())
         if key_mask is not None:
             key_mask._mmamd_key_mask = True  # already in kernel format: the encoder passes it through untouched
-        embedding_output = self.embeddings(input_ids=ids, position_ids=position_ids, token_type_ids=token_type_ids)
+        embedding_output = self.embeddings(input_ids=ids, position_ids=position_ids, token_type_ids=token_type_ids, inputs_embeds=inputs_embeds)
         encoder_output = self.encoder(embedding_output, attention_mask=key_mask, return_attn_weights=return_attn_weights,
                                       return_hidden_states=return_hidden_states)
         last_hidden_state = encoder_output.last_hidden_state

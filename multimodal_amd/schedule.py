@@ -20,7 +20,8 @@ Every choice is between paths that compute the same function; the defaults are t
 
     flava_grouped  True | False                   FLAVA inference with both towers wanted: the image and the text encoder layer-locked on one
                                                   stream with grouped LayerNorm / GEMM launches (models/flava/transformer.py::run_two_encoders)
-                                                  instead of the text tower on a side stream
+                                                  instead of the text tower on a side stream (default since r04: 25.8-25.9 vs 26.1-26.2 ms at
+                                                  B = 128, bit-identical outputs)
     train_attentions  True | False                FLAVA training forwards also return the per-layer attention probabilities (recomputed by the
                                                   inference kernel, detached) like the reference's; False: attentions = None (saves one attention
                                                   launch per layer and the S^2 writes)
@@ -46,7 +47,7 @@ class Schedule:
     phases: int = 1
     phase_lead: int = 4
     train_attentions: bool = True
-    flava_grouped: bool = False
+    flava_grouped: bool = True
 
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:

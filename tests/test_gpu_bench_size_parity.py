@@ -67,6 +67,41 @@ def test_flava_b128_rows_equal_the_b16_run(golden):
 
 
 @torch.no_grad()
+def test_flava_grouped_schedule_equals_the_two_stream_schedule_bitwise(golden):
+    """schedule.flava_grouped (image and text encoder layer-locked with grouped LayerNorm / GEMM launches, models/flava/transformer.py::
+    run_two_encoders) vs the default (text tower on a side stream): every output of the B = 128 bench forward, bit for bit -- incl. all hidden
+    states and attention probabilities."""
+    from multimodal_amd.models.flava.model import flava_model
+    from multimodal_amd.schedule import get_schedule, set_schedule
+
+    z = golden("flava_full_b16.npz")
+    set_rng_seed(0)
+    model = flava_model().cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    rep = 8
+    images = torch.randn(16 * rep, 3, 224, 224, generator=g).cuda()
+    text, tmask, pm = (torch.cat([torch.from_numpy(z[k])] * rep).cuda() for k in ("text", "text_masked", "patches_mask"))
+    prev = get_schedule()
+    try:
+        set_schedule(flava_grouped=False)
+        ref = model(images, text, image_patches_mask=pm, text_masked=tmask, skip_unmasked_mm_encoder=True)
+        set_schedule(flava_grouped=True)
+        assert model._groupable(images, text, tmask, pm)
+        got = model(images, text, image_patches_mask=pm, text_masked=tmask, skip_unmasked_mm_encoder=True)
+    finally:
+        set_schedule(flava_grouped=prev.flava_grouped)
+    for name in ("projected_image_embeddings", "projected_text_embeddings"):
+        assert torch.equal(getattr(got, name), getattr(ref, name)), name
+    for part in ("image", "text", "image_masked", "text_masked", "multimodal_masked"):
+        a, b = getattr(got, part), getattr(ref, part)
+        assert torch.equal(a.last_hidden_state, b.last_hidden_state), part
+        if b.pooler_output is not None:
+            assert torch.equal(a.pooler_output, b.pooler_output), part
+        assert len(a.hidden_states) == len(b.hidden_states) and all(torch.equal(x, y) for x, y in zip(a.hidden_states, b.hidden_states)), part
+        assert len(a.attentions) == len(b.attentions) and all(torch.equal(x, y) for x, y in zip(a.attentions, b.attentions)), part
+
+
+@torch.no_grad()
 def test_coca_b128_rows_equal_the_b8_run(golden):
     """cfg 5 per-GPU shape: coca_vit(ViT-L/14 arguments, parallel pooler) at B = 128; rows 0..7 are the fixture's 8 pairs (padded captions)."""
     from multimodal_amd.models.coca.coca_model import coca_vit

@@ -723,3 +723,40 @@ def test_multi_head_attention_general_forward_vs_reference_fixture(golden):
         assert np.abs(host(m0) - z["mem.o0"]).max() <= tol and np.abs(host(m1) - z["mem.o1"]).max() <= tol
         with pytest.raises(ops_error()):
             cross(t("cross.q"), t("cross.kv"), head_mask=torch.ones(2, 2, 5, 9, device="cuda"))
+
+
+@torch.no_grad()
+def test_inputs_embeds_and_global_average_pooler():
+    """VERDICT r03 missing #6.  BERTTextEmbeddings / BERTTextEncoder with `inputs_embeds` (reference modules/layers/text_embedding.py:95-101):
+    feeding the word-embedding rows themselves reproduces the input_ids forward exactly (position ids from input_ids when offset ids are on).
+    GlobalAveragePooler (modules/encoders/vision_transformer.py:117-127): mean over the rows behind CLS -> LayerNorm -> head, vs the same
+    expression in float64."""
+    from multimodal_amd.models.flava.text_encoder import flava_text_encoder
+    from multimodal_amd.modules.encoders.vision_transformer import GlobalAveragePooler
+
+    torch.manual_seed(2)
+    enc = flava_text_encoder(hidden_size=128, num_attention_heads=2, num_hidden_layers=2, intermediate_size=256, vocab_size=300,
+                             max_position_embeddings=40).cuda().eval()
+    ids = torch.randint(1, 300, (3, 20), device="cuda")
+    ref = enc(input_ids=ids, return_hidden_states=True)
+    rows = enc.embeddings.word_embeddings.weight.detach()[ids]  # (index bookkeeping in the test: the rows the lookup would fetch)
+    emb_a = enc.embeddings(input_ids=ids)
+    emb_b = enc.embeddings(inputs_embeds=rows.contiguous())
+    assert torch.equal(emb_a, emb_b)
+    got = enc(inputs_embeds=rows.contiguous(), return_hidden_states=True)
+    assert torch.equal(got.last_hidden_state, ref.last_hidden_state)   # no padding ids in this batch: the default masks agree
+    with pytest.raises(ValueError):
+        enc.embeddings()
+
+    pool = GlobalAveragePooler(128, 32).cuda().eval()
+    torch.nn.init.normal_(pool.norm.weight, 1.0, 0.1)
+    torch.nn.init.normal_(pool.norm.bias, 0.0, 0.1)
+    x = torch.randn(5, 17, 128, device="cuda")
+    y = pool(x)
+    xd = x.double().cpu()
+    m = xd[:, 1:].mean(1)
+    want = torch.nn.functional.layer_norm(m, (128,), pool.norm.weight.double().cpu(), pool.norm.bias.double().cpu(), pool.norm.eps)
+    want = want @ pool.head.weight.double().cpu().t() + pool.head.bias.double().cpu()
+    assert y.shape == (5, 32) and float((y.double().cpu() - want).abs().max()) < 1e-4
+    y2 = GlobalAveragePooler(128).cuda().eval()(x)
+    assert y2.shape == (5, 128)
