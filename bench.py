@@ -327,7 +327,9 @@ def main() -> None:
         return loss_fn(out.embeddings_a, out.embeddings_b)
 
     S_img = 197
-    probe = ops.GemmProbe(shapes=[(768, 768), (768, 3072)])  # (N, K) of the fp32-residual GEMMs: out-projection and MLP-down, any M
+    # (N, K) of the fp32-residual GEMMs: out-projection and MLP-down, any M.  A bracket is two event records on the launch stream (~2 us of
+    # pipeline bubble each: 48 per step measured +0.09 ms): the launches of the first 8 timed steps are bracketed, not all of them
+    probe = ops.GemmProbe(shapes=[(768, 768), (768, 3072)], max_samples=24 * 8)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     graph, graph_note = None, None
     with torch.no_grad():
