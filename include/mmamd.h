@@ -67,6 +67,12 @@ int mmamd_debug_set_gemm_stagger(int percent);
 /* Experiment knobs of the GEMM launchers (results never change; knob 0: tile-order group of the grouped persistent kernel -- 0 = by the stream's
  * CU budget, 4, 8;  knob 1: start-up stagger policy of the grouped kernel -- 0 = light workgroups only, 1 = every workgroup by its slack). */
 int mmamd_debug_set_gemm_knob(int knob, int value);
+/* W [N, K] bf16 row-major (leading dimension ldw) -> MFMA-fragment order for the direct-W GEMM kernels: ceil(N / 32) x (K / 16) blocks of 1 KiB,
+ * block (nb, ks) = 64 lanes x 16 B, lane (l = lane & 31, h = lane >> 5) holds W[32 nb + l][16 ks + 8 h .. + 7] (rows >= N: zeros).  Wp: ceil(N / 32) * 32 * K
+ * bf16.  A layout of the static operand of torch's nn.Linear inside TransformerEncoderLayer (models/clip/image_encoder.py:65-77). */
+int mmamd_pack_w_frag(const void* W, int ldw, int N, int K, void* Wp, mmamd_stream_t stream);
+/* Experiment: fragment-order copy of W used by the direct-W GEMM variants (84, 85) of the following mmamd_gemm_bf16 calls (NULL = none). */
+int mmamd_debug_set_gemm_wp(const void* Wp);
 /* Diagnostic: device buffer of 64*2*256 uint64 that GEMM variant 14 fills with s_memtime stamps (NULL = off). */
 int mmamd_debug_set_gemm_trace(void* buf);
 /* Diagnostic: attention ablation variant (timing experiments; non-zero values compute WRONG results). */

@@ -78,6 +78,9 @@ struct GemmArgs {
   int i2c_ltpc = 0;  // log2(K-tiles per channel) = log2(p*p / 64)
   int i2c_rpk = 0;   // image rows per K-tile = 64 / p
   int gm = 0;        // persistent kernel: tile-order group at run time (0 = the kernel's template value); pick_gm()
+  // BDIR kernels: W in MFMA-fragment order (mmamd_pack_w_frag): block (nb = n / 32, ks = k / 16) = 64 lanes x 16 B, lane (l31, half) holds
+  // W[32 nb + l31][16 ks + 8 half .. + 7] -- the first operand of v_mfma_f32_32x32x16_bf16 as one coalesced 1 KiB buffer load, no LDS
+  const bf16* Wp = nullptr;
 };
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
@@ -175,6 +178,7 @@ static int pick_gm(int tiles_n, int cus) {
 }
 
 static unsigned long long* g_gemm_trace = nullptr;
+static const void* g_gemm_wp = nullptr;  // experiment (mmamd_debug_set_gemm_wp): fragment-order copy of the NEXT gemm call's W (variants 84 / 85)
 
 // Epilogue shared by the tiled kernels.  Lane owns row m = .. + (lane&31); accumulator regs 4g..4g+3 are columns
 // n = .. + 8g + 4*(lane>>5) + {0..3}.
@@ -864,12 +868,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 //   * tile order: same XCD-contiguous, GM-grouped order as P, applied to the virtual block id (gridDim.x % 8 == 0)
 // WM x WN waves: 2 x 4 = eight 128x64 wave tiles (two waves per SIMD), or 2 x 2 = four 128x128 wave tiles (ONE wave per
 // SIMD, 256 accumulator registers in the unified VGPR/AGPR file): 8 instead of 12 fragment reads per 16 MFMAs.
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0,
+          bool BDIR = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const GemmArgs p, const int tiles_m, const int ntiles) {
   constexpr int BM = 256, BN = 256, NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW, NDMA = A_INSTR + B_INSTR, NF = NI + MI, NM = NI * MI;
+  // BDIR: the W fragments never pass through LDS -- every wave loads its own (pre-packed, GemmArgs::Wp) fragments of the NEXT K-tile straight
+  // into registers while it computes this one: a third fewer LDS reads per MFMA in the 8-wave form, half in the 4-wave form, half the DMA pieces
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BDIR ? 0 : BN / 8 / NW, NDMA = A_INSTR + B_INSTR, NF = (BDIR ? 0 : NI) + MI, NM = NI * MI;
+  static_assert(!BDIR || A_MODE == 0, "BDIR: plain A operand only");
   static_assert(NM >= NDMA && NM >= NF && NW % 4 == 0, "interleave needs one MFMA per DMA piece / fragment read");
   constexpr int CH = TN / 64;  // 128-byte column chunks of a wave tile row in bf16
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -896,7 +904,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   const int slot = (lane & 15) ^ sw;
   const int row8 = 2 * (lane >> 4) + (slot >> 3);
   const int chunk = slot & 7;
-  auto tile_offsets = [&](int tm, int tn, uint32_t (&ao)[A_INSTR], uint32_t (&bo)[B_INSTR]) {
+  constexpr int B_ARR = B_INSTR > 0 ? B_INSTR : 1;
+  auto tile_offsets = [&](int tm, int tn, uint32_t (&ao)[A_INSTR], uint32_t (&bo)[B_ARR]) {
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
       int r = tm * BM + 8 * (wave + NW * j) + row8;
@@ -920,7 +929,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  uint32_t a_off[A_INSTR], b_off[B_INSTR], a_nxt[A_INSTR], b_nxt[B_INSTR];
+  uint32_t a_off[A_INSTR], b_off[B_ARR], a_nxt[A_INSTR], b_nxt[B_ARR];
+  // BDIR: per-lane byte offsets of this wave's NI fragment columns in the packed W (block row nb = column / 32, KS blocks of 1 KiB per row)
+  const int KS = p.K >> 4;
+  uint32_t bd_off[NI], bd_nxt[NI];
+  auto bdir_offsets = [&](int tn, uint32_t (&bo)[NI]) {
+    const int nbmax = ((p.N + 31) >> 5) - 1;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      int nb = tn * (BN / 32) + wn * NI + ni;
+      nb = nb < nbmax ? nb : nbmax;  // column blocks past N are never stored
+      bo[ni] = ((uint32_t)nb * (uint32_t)KS * 64u + (uint32_t)lane) * 16u;
+    }
+  };
+  const int32x4 wp_srd = make_srd(BDIR ? p.Wp : p.W, 0x7fffffffu);
+  bf16x8 wbd[4][NI];  // BDIR: W fragments, one slot per k-step of a K-tile (reloaded as soon as its MFMAs are issued)
   auto issue_piece = [&](int buf, int kt, int i) __attribute__((always_inline)) {
     const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
     if (i < A_INSTR) {
@@ -931,8 +954,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
         dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
       }
     } else {
-      dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
+      if constexpr (!BDIR) dma_piece_s(Wb + (size_t)kt * 128, b_off[i - A_INSTR], dst);
     }
+  };
+  // The W loads and every wait on them are inline asm: the compiler's wait insertion does not see the asm DMA pieces and (measured on the ISA)
+  // merges the loop paths into vmcnt(3) / vmcnt(0) waits that land behind the DMA issue of the next K-tile.  The waits are tied to the slot
+  // registers ("+v"), so no MFMA that reads a slot can move above its wait; nothing but v_mfma may read a slot between its load and its wait
+  // (tools/check_bdir_isa.py checks the ISA for that).
+  auto bdir_load = [&](auto tc, int ni, uint32_t voff, int kt) __attribute__((always_inline)) {
+    constexpr int T = decltype(tc)::value;
+    bf16x8& d = wbd[T][ni];  // (asm operands inside a generic lambda must be the lambda's own names)
+    const int32x4 srd = wp_srd;
+    const int soff = (kt * 4 + T) * 1024;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+  };
+  // (a tied wait inside a branch makes the register allocator COPY the slot on the way in -- a read before the data has landed: the tied waits
+  //  are unconditional, the stricter wait of the rare path is an untied statement in front of it)
+  auto bdir_wait_plain = [&](auto nc) __attribute__((always_inline)) {
+    constexpr int N = decltype(nc)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+  };
+  auto bdir_wait = [&](auto tc, auto nc) __attribute__((always_inline)) {  // s_waitcnt vmcnt(N) ahead of the readers of slot T
+    constexpr int T = decltype(tc)::value, N = decltype(nc)::value;
+    static_assert(NI == 2 || NI == 4, "slot width");
+    bf16x8(&w)[NI] = wbd[T];
+    if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
+    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N));
   };
   // output / residual row of GEMM row m (A_MODE = 1: the token row behind its image's CLS row; positional-embedding row of the patch)
   auto c_row = [&](int m) -> size_t { if constexpr (A_MODE == 1) return (size_t)m + (size_t)(m / p.i2c_g2) + 1; else return (size_t)m; };
@@ -1009,10 +1056,73 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
       }
     }
   };
+  // BDIR form of the K-tile kt (in ring buffer BF): A fragments from LDS as above, W fragments from the register slots wbd[t].  Slot t is reloaded
+  // right behind the MFMAs that read it: slot 3 (read by the rotated k-step of K-tile kt - 1 in the first group) <- W(kt, 3), slots 0 .. 2 <- W(ktsrc, t)
+  // -- every load has three to four k-steps (>= 1500 cycles) to land.  `last`: ktsrc belongs to the NEXT output tile (offsets bd_nxt).
+  auto tile_body_bdir = [&](auto bufc, int kt, int ktsrc, const bool issue, const bool last) __attribute__((always_inline)) {
+    constexpr int BF = decltype(bufc)::value;
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
+    // VMEM issue order of a body: DMA x NDMA (if `issue`), slot 3 x NI, slot 0 x NI, slot 1 x NI, slot 2 x NI.  The readers of slot t (loaded one body
+    // ago) may leave everything younger in flight: the rest of that body's reloads + this body's issues so far
+    using W_ISSUE = std::integral_constant<int, 3 * NI + NDMA>;  // step 0: slots 1, 2 of the last body + DMA + slot 3;  steps 1, 2: the same count
+    using W_QUIET = std::integral_constant<int, 3 * NI>;         // ... without DMA pieces in this body (the last K-tile of the last tile)
+    auto load_a = [&](int t, bf16x8 (&xa)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + mi * 32 * 128));
+    };
+    load_a(0, xa0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      mma_one(xa1, wbd[3], i);
+      if (issue && i < NDMA) issue_piece(BF ^ 1, ktsrc, i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bdir_load(T3{}, ni, bd_off[ni], kt);
+    uint32_t bn[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bn[ni] = last ? bd_nxt[ni] : bd_off[ni];  // (bd_nxt == bd_off when there is no next tile)
+    if (!issue) bdir_wait_plain(W_QUIET{});
+    bdir_wait(T0{}, W_ISSUE{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(1, xa1);
+    mma(xa0, wbd[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bdir_load(T0{}, ni, bn[ni], ktsrc);  // unconditional (see above)
+    if (!issue) bdir_wait_plain(W_QUIET{});
+    bdir_wait(T1{}, W_ISSUE{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(2, xa0);
+    mma(xa1, wbd[1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bdir_load(T1{}, ni, bn[ni], ktsrc);
+    if (!issue) bdir_wait_plain(W_QUIET{});
+    bdir_wait(T2{}, W_ISSUE{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(3, xa1);
+    mma(xa0, wbd[2]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bdir_load(T2{}, ni, bn[ni], ktsrc);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  auto sync_tile = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // BDIR, `first` = first K-tile of an output tile: the epilogue's stores are in flight too (they do not retire in order with loads): vmcnt(0).
+  // Otherwise the DMA pieces of this K-tile and slot 3 must have landed; the reloads of slots 0 .. 2 (3 NI loads, the youngest) may stay in flight.
+  auto sync_tile = [&](const bool first = true) __attribute__((always_inline)) {
+    if constexpr (BDIR) {
+      if (first) bdir_wait_plain(std::integral_constant<int, 0>{});
+      bdir_wait(std::integral_constant<int, 3>{}, std::integral_constant<int, 3 * NI>{});
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
   };
 
@@ -1023,6 +1133,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   tile_offsets(tm, tn, a_off, b_off);
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) issue_piece(0, 0, i);
+  if constexpr (BDIR) {
+    bdir_offsets(tn, bd_off);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wbd[3][ni][j] = (bf16)0.f;  // read (times zero) by the first tile's rotated MFMAs
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bdir_load(std::integral_constant<int, 0>{}, ni, bd_off[ni], 0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bdir_load(std::integral_constant<int, 1>{}, ni, bd_off[ni], 0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bdir_load(std::integral_constant<int, 2>{}, ni, bd_off[ni], 0);
+  }
   if (p.stagger > 0) {
     const int heavy = ntiles % (int)gridDim.x;  // workgroups 0 .. heavy-1 walk one tile more: they start at once
     if (heavy > 0 && (int)blockIdx.x >= heavy) {
@@ -1046,6 +1170,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     if (more) {
       tile_of(nvb, ntm, ntn);
       tile_offsets(ntm, ntn, a_nxt, b_nxt);
+      if constexpr (BDIR) bdir_offsets(ntn, bd_nxt);
+    } else if constexpr (BDIR) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bd_nxt[ni] = bd_off[ni];
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -1064,7 +1192,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 
 #pragma unroll 1
     for (int kt = 0; kt < KT; kt += 2) {
-      sync_tile();
+      sync_tile(kt == 0);
       if constexpr (BLDS) {
         // the tile's 256 bias values (1 KiB = one DMA piece, issued by wave 0) land in LDS behind the ring while the K loop runs;
         // same hazards as the statistics above: issued after the tile's first barrier, waited for by the next sync_tile
@@ -1075,7 +1203,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
           dma_piece_s(reinterpret_cast<const char*>(p.bias) + (size_t)n0 * 4u, off, lds0 + 2 * STAGE);
         }
       }
-      tile_body(B0{}, kt + 1, true);
+      if constexpr (BDIR) tile_body_bdir(B0{}, kt, kt + 1, true, false);
+      else tile_body(B0{}, kt + 1, true);
       const bool last = kt + 2 >= KT;
       if (last && more) {  // this tile's loads are all issued: switch the DMA source to the next tile's first K-tile
 #pragma unroll
@@ -1083,10 +1212,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j) b_off[j] = b_nxt[j];
       }
-      sync_tile();
-      tile_body(B1{}, last ? 0 : kt + 2, !last || more);
+      sync_tile(false);
+      if constexpr (BDIR) tile_body_bdir(B1{}, kt + 1, last ? 0 : kt + 2, !last || more, last);
+      else tile_body(B1{}, last ? 0 : kt + 2, !last || more);
     }
-    mma(xa1, wb1);  // flush the rotated last k-step
+    if constexpr (BDIR) {
+      bdir_wait(std::integral_constant<int, 3>{}, std::integral_constant<int, 3 * NI>{});
+      mma(xa1, wbd[3]);  // flush the rotated last k-step
+      // the slot 0 .. 2 reloads of the last body are DEAD after the last tile: the compiler may hand their registers to the epilogue while
+      // the (asm, invisible) loads are still in flight -- every W load has landed before the epilogue starts
+      if (!more) bdir_wait_plain(std::integral_constant<int, 0>{});
+      if (more) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bd_off[ni] = bd_nxt[ni];
+      }
+    } else {
+      mma(xa1, wb1);
+    }
 
     // ---------------- epilogue (LDS strips in ring buffer 1; buffer 0 is receiving the next tile) ----------------
     // fp32 residual: a ring of RD passes of loads in flight, the first RD issued here (before the bias / barrier / first transpose).
@@ -1683,13 +1825,17 @@ static int launch_tiled_p(GemmArgs& p, hipStream_t st) {
 #include "experiments/gemm_launchers.inc"
 #endif
 
-template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0>
+template <bool OUT_F32, int ACT, int GM, int WM = 2, int WN = 4, int STP = 0, int RDP = 0, int RES_DEPTH = 1, bool BLDS = false, int A_MODE = 0,
+          bool BDIR = false>
 static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   if constexpr (A_MODE == 0) {
     if (((p.K >> 6) & 1) != 0) return launch_tiled<256, 256, 2, 4, OUT_F32, ACT, true>(p, st);
   }
+  if constexpr (BDIR) {
+    if (p.Wp == nullptr) { set_error("gemm: the direct-W kernel needs the packed weights (mmamd_pack_w_frag)"); return MMAMD_E_BADARG; }
+  }
   constexpr int smem = 2 * 512 * 128 + (BLDS ? 1024 : 0);  // + the tile's bias values
-  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, RES_DEPTH, BLDS, A_MODE>;
+  auto kern = gemm_bf16_nt_kernel_pp<OUT_F32, ACT, GM, WM, WN, STP, RDP, RES_DEPTH, BLDS, A_MODE, BDIR>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (p.M + 255) / 256;
@@ -1817,6 +1963,38 @@ extern "C" int mmamd_debug_set_gemm_knob(int knob, int value) {
   MMAMD_CHECK_ARG(knob >= 0 && knob < 8, MMAMD_E_BADARG, "debug_set_gemm_knob: knob %d out of range", knob);
   g_gemm_knob[knob] = value;
   return 0;
+}
+
+extern "C" int mmamd_debug_set_gemm_wp(const void* wp) {
+  g_gemm_wp = wp;
+  return 0;
+}
+
+// W [N, K] bf16 row-major -> MFMA-fragment order (GemmArgs::Wp): ceil(N / 32) x (K / 16) blocks of 64 lanes x 16 B; rows past N are zeros
+namespace mmamd {
+__global__ __launch_bounds__(256) void pack_w_frag_kernel(const bf16* __restrict__ W, int ldw, int N, int K, bf16* __restrict__ Wp) {
+  const int KS = K >> 4;
+  const long long total = (long long)((N + 31) >> 5) * KS * 64;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const long long blk = i >> 6;
+    const int ks = (int)(blk % KS), nb = (int)(blk / KS);
+    const int n = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (n < N) v = *reinterpret_cast<const uint4*>(W + (size_t)n * ldw + k);
+    *reinterpret_cast<uint4*>(Wp + i * 8) = v;
+  }
+}
+}  // namespace mmamd
+
+extern "C" int mmamd_pack_w_frag(const void* W, int ldw, int N, int K, void* Wp, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(W && Wp && N > 0 && K > 0, MMAMD_E_BADARG, "pack_w_frag: bad argument");
+  MMAMD_CHECK_ARG(K % 16 == 0 && ldw >= K && ldw % 8 == 0, MMAMD_E_UNSUPPORTED, "pack_w_frag: K=%d must be a multiple of 16, ldw a multiple of 8", K);
+  MMAMD_CHECK_ARG(aligned16(W) && aligned16(Wp), MMAMD_E_ALIGN, "pack_w_frag: pointers must be 16-byte aligned");
+  const long long total = (long long)((N + 31) / 32) * (K / 16) * 64;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(pack_w_frag_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)W, ldw, N, K, (bf16*)Wp);
+  return launch_status("pack_w_frag");
 }
 
 extern "C" int mmamd_debug_set_gemm_trace(void* buf) {
@@ -1947,6 +2125,7 @@ static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldc = ldc; p.act = act; p.tiles_n = 0;
   p.kt_chunk = 0; p.c_split_stride = 0; p.res_mode = 0;
   p.C2 = C2; p.ldc2 = ldc2; p.act2 = act2; p.split_flat = 0;
+  p.Wp = (const bf16*)g_gemm_wp;
   {
     // start-up stagger of the persistent kernel as a fraction (g_gemm_stagger, per cent) of the estimated tile time in shader ticks:
     // ~3500 ticks per 64-deep K-tile + the epilogue (bf16 tile ~8k, + QuickGELU / erf-GELU ~8k, fp32 + residual ~27k)

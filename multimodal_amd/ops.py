@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "pack_w_frag", "debug_set_gemm_wp", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -116,6 +116,20 @@ def set_gemm_stagger(ticks: int) -> None:
 
 def set_gemm_variant(v: int) -> None:
     _lib.lib().mmamd_set_gemm_variant(int(v))
+
+
+def pack_w_frag(w: torch.Tensor) -> torch.Tensor:
+    """bf16 [N, K] weight -> its MFMA-fragment-order copy (mmamd_pack_w_frag): the W operand of the direct-W GEMM kernels."""
+    _chk(w, "w", torch.bfloat16)
+    N, K = w.shape
+    out = torch.empty(((N + 31) // 32 * 32, K), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().mmamd_pack_w_frag(w.data_ptr(), w.stride(0), N, K, out.data_ptr(), _stream()), "mmamd_pack_w_frag")
+    return out
+
+
+def debug_set_gemm_wp(wp: Optional[torch.Tensor]) -> None:
+    """Experiment hook: the packed W of the following gemm_bf16 calls (direct-W variants 84 / 85); None clears it."""
+    _lib.lib().mmamd_debug_set_gemm_wp(wp.data_ptr() if wp is not None else None)
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,

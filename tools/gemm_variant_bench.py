@@ -51,9 +51,12 @@ def main():
         ref = None
         line = f"{name:10s} [{M}x{N}x{K}]"
         sweep = [(0, int(x)) for x in args.staggers.split(",")] if args.staggers else [(v, 0) for v in variants]
+        wp = ops.pack_w_frag(w)  # fragment-order W of the direct-W variants (84 / 85); ignored by the others
+        ops.debug_set_gemm_wp(wp)
         for v, stg in sweep:
             ops.set_gemm_variant(v)
-            ops.set_gemm_stagger(stg)
+            if args.staggers:
+                ops.set_gemm_stagger(stg)
             out = x0.clone() if res else torch.empty(M, N, dtype=torch.float32 if f32out else torch.bfloat16, device="cuda")
 
             def run():
@@ -74,7 +77,9 @@ def main():
             best = min(timeit(run, 10) for _ in range(args.rounds))
             line += f" | v{v}{'/s' + str(stg) if stg else ''}: {best * 1e3:7.1f} us {2.0 * M * N * K / best / 1e9:5.0f} TF/s {same}"
         ops.set_gemm_variant(0)
-        ops.set_gemm_stagger(0)
+        ops.debug_set_gemm_wp(None)
+        if args.staggers:
+            ops.set_gemm_stagger(60)  # the default
         print(line, flush=True)
 
 
