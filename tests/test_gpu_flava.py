@@ -40,6 +40,11 @@ def bf16_round(a):
                                                (2, 77, 12, True, torch.float32), (2, 197, 12, False, torch.float32),
                                                (1, 197, 3, True, torch.bfloat16), (2, 275, 2, True, torch.float32),
                                                (1, 1, 1, False, torch.float32), (1, 33, 1, True, torch.float32),
+                                               # rows that end within 3 elements of a 32-key tile edge (the aligned-store form flushes a carry),
+                                               # every slab / row misalignment against 16 bytes
+                                               (3, 64, 2, False, torch.float32), (2, 63, 3, True, torch.float32), (3, 94, 1, False, torch.float32),
+                                               (2, 224, 2, True, torch.float32), (1, 256, 3, False, torch.float32), (2, 287, 1, False, torch.float32),
+                                               (5, 35, 3, False, torch.float32), (3, 198, 2, False, torch.float32), (2, 199, 2, True, torch.float32),
                                                # S > 288: streaming kernel (512-token BERT inputs, 384-pixel ViT)
                                                (2, 512, 2, True, torch.float32), (1, 577, 3, False, torch.float32),
                                                (1, 300, 1, True, torch.bfloat16)])
@@ -743,8 +748,12 @@ def test_inputs_embeds_and_global_average_pooler():
     emb_a = enc.embeddings(input_ids=ids)
     emb_b = enc.embeddings(inputs_embeds=rows.contiguous())
     assert torch.equal(emb_a, emb_b)
-    got = enc(inputs_embeds=rows.contiguous(), return_hidden_states=True)
-    assert torch.equal(got.last_hidden_state, ref.last_hidden_state)   # no padding ids in this batch: the default masks agree
+    # same key mask (all ones: no padding ids in this batch) -> the same kernels -> the same bits
+    got = enc(inputs_embeds=rows.contiguous(), attention_mask=torch.ones_like(ids), return_hidden_states=True)
+    assert torch.equal(got.last_hidden_state, ref.last_hidden_state)
+    # without a mask every position is attended (reference bert_text_encoder.py:86-87): the unmasked attention kernel, another summation order
+    free = enc(inputs_embeds=rows.contiguous())
+    assert float((free.last_hidden_state - ref.last_hidden_state).abs().max()) < 5e-3
     with pytest.raises(ValueError):
         enc.embeddings()
 
