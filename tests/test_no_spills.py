@@ -38,7 +38,7 @@ def test_hot_kernels_do_not_spill():
     # the kernels of the headline step must be among the checked ones (and clean)
     names = [demangle(r[0]) for r in results[0][2]]
     for must in ("gemm_bf16_nt_kernel_ppg<true, 0>", "gemm_bf16_nt_kernel_ppg<false, 0>", "gemm_bf16_nt_kernel_ppg<false, 1>",
-                 "gemm_bf16_nt_kernel_pp<true, 0, 8, 2, 4, 0, 0, 1, false, 1>"):
+                 "gemm_bf16_nt_kernel_pp<true, 0, 8, 2, 4, 0, 0, 1, false, 1, false>"):
         assert any(must in n for n in names), must
 
 
