@@ -710,8 +710,9 @@ class DecoderStackConfig:
     has_cross; params per layer in the order self q/k/v/o (w, b), attention LN (w, b), [cross q/k/v/o (w, b), cross LN (w, b)],
     ff0 (w, b), ff1 (w, b), feedforward LN (w, b)."""
 
-    def __init__(self, B: int, S: int, Sk: int, layers, mask: Optional[ops.AttnMask], drop_p: float = 0.0, seed: int = 0):
+    def __init__(self, B: int, S: int, Sk: int, layers, mask: Optional[ops.AttnMask], drop_p: float = 0.0, seed: int = 0, layer0: int = 0):
         self.B, self.S, self.Sk, self.layers, self.mask = B, S, Sk, layers, mask or ops.AttnMask()
+        self.layer0 = int(layer0)  # index of layers[0] in the module's stack (a stack run as one node per layer keeps its dropout sites)
         # training-time dropout: ONE rate on the six sites of a layer (self-attention probabilities and branch, cross-attention probabilities and
         # branch, the MLP's hidden dropout, the feed-forward branch), masks from Philox(seed, 16 * layer + site)
         self.drop_p, self.seed = float(drop_p), int(seed)
@@ -742,9 +743,9 @@ class DecoderStackFn(torch.autograd.Function):
             lse = torch.empty((B, H, S), dtype=f32, device=x.device)
             pd, sd = cfg.drop_p, cfg.seed  # ONE rate on every dropout site of a decoder layer (reference transformer.py:262-290)
             att, _ = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, cfg.mask, lse=lse,
-                                         drop=(pd, sd, 16 * li + 3))
+                                         drop=(pd, sd, 16 * (cfg.layer0 + li) + 3))
             if pd > 0:
-                a = ops.dropout(ops.gemm_bf16(att, ops.convert(ow, bf), ob, out_dtype=f32), pd, sd, 16 * li, residual=x)
+                a = ops.dropout(ops.gemm_bf16(att, ops.convert(ow, bf), ob, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li), residual=x)
             else:
                 a = ops.gemm_bf16(att, ops.convert(ow, bf), ob, residual=x, out_dtype=f32, out=torch.empty_like(x))
             rec = [x, h1, qkv, att, lse, a]
@@ -754,9 +755,9 @@ class DecoderStackFn(torch.autograd.Function):
                 qc = ops.gemm_bf16(hc, ops.convert(cqw, bf), cqb)
                 kvc = ops.gemm_bf16(encb, ops.convert(torch.cat([ckw, cvw], 0), bf), torch.cat([ckb, cvb], 0))
                 lsec = torch.empty((B, H, S), dtype=f32, device=x.device)
-                attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, None, lse=lsec, drop=(pd, sd, 16 * li + 5))
+                attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, None, lse=lsec, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
                 if pd > 0:
-                    a2 = ops.dropout(ops.gemm_bf16(attc, ops.convert(cow, bf), cob, out_dtype=f32), pd, sd, 16 * li + 4, residual=a)
+                    a2 = ops.dropout(ops.gemm_bf16(attc, ops.convert(cow, bf), cob, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li) + 4, residual=a)
                 else:
                     a2 = ops.gemm_bf16(attc, ops.convert(cow, bf), cob, residual=a, out_dtype=f32, out=torch.empty_like(x))
                 rec += [hc, qc, kvc, attc, lsec, a2]
@@ -768,8 +769,8 @@ class DecoderStackFn(torch.autograd.Function):
             h2 = ops.layernorm(a2, g2, be2, L["eps2"], out_dtype=bf)
             u, g = ops.gemm_bf16_dual(h2, ops.convert(w1, bf), b1, L["act"])
             if pd > 0:
-                ops.dropout(g, pd, sd, 16 * li + 1, out=g)
-                x_out = ops.dropout(ops.gemm_bf16(g, ops.convert(w2, bf), b2, out_dtype=f32), pd, sd, 16 * li + 2, residual=a2)
+                ops.dropout(g, pd, sd, 16 * (cfg.layer0 + li) + 1, out=g)
+                x_out = ops.dropout(ops.gemm_bf16(g, ops.convert(w2, bf), b2, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li) + 2, residual=a2)
             else:
                 x_out = ops.gemm_bf16(g, ops.convert(w2, bf), b2, residual=a2, out_dtype=f32, out=torch.empty_like(x))
             rec += [h2, u, g]
@@ -820,12 +821,12 @@ class DecoderStackFn(torch.autograd.Function):
                 w1, b1, w2, b2, g2, be2 = pr[10:]
             pd, sd = cfg.drop_p, cfg.seed
             if pd > 0:  # the feed-forward branch's gradient is the masked, scaled dX; the residual path keeps dX
-                dXb = ops.dropout(dX, pd, sd, 16 * li + 2, out_dtype=bf)
+                dXb = ops.dropout(dX, pd, sd, 16 * (cfg.layer0 + li) + 2, out_dtype=bf)
             elif dXb is None:
                 dXb = ops.convert(dX, bf)
             du = dgrad(dXb, w2, bf, _ACT_GRAD[L["act"]], u)
             if pd > 0:
-                ops.dropout(du, pd, sd, 16 * li + 1, out=du)
+                ops.dropout(du, pd, sd, 16 * (cfg.layer0 + li) + 1, out=du)
             dW2, db2 = wgrad(dXb, g, bias=True)
             dh2 = dgrad(du, w1, f32)
             dW1, db1 = wgrad(du, h2, bias=True)
@@ -833,10 +834,10 @@ class DecoderStackFn(torch.autograd.Function):
             gl = [None] * cfg.nparams(li)
             if L["has_cross"]:
                 if pd > 0:
-                    d_a2b = ops.dropout(d_a2, pd, sd, 16 * li + 4, out_dtype=bf)
+                    d_a2b = ops.dropout(d_a2, pd, sd, 16 * (cfg.layer0 + li) + 4, out_dtype=bf)
                 dattc = dgrad(d_a2b, cow, bf)
                 dWco, dbco = wgrad(d_a2b, attc, bias=True)
-                dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, None, drop=(pd, sd, 16 * li + 5))
+                dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, None, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
                 dhc = dgrad(dqc, cqw, f32)
                 dWcq, dbcq = wgrad(dqc, hc, bias=True)
                 wckv = torch.cat([ckw, cvw], 0)
@@ -851,11 +852,11 @@ class DecoderStackFn(torch.autograd.Function):
                 d_a, d_ab = d_a2, d_a2b
                 gl[10:] = [dW1, db1, dW2, db2, dg2, dbe2]
             if pd > 0:
-                d_ab = ops.dropout(d_a, pd, sd, 16 * li, out_dtype=bf)
+                d_ab = ops.dropout(d_a, pd, sd, 16 * (cfg.layer0 + li), out_dtype=bf)
             datt = dgrad(d_ab, ow, bf)
             dWo, dbo = wgrad(d_ab, att, bias=True)
             dq, dkv = ops.attention_x_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, datt, lse, B, S, S, H, hd, cfg.mask,
-                                          drop=(pd, sd, 16 * li + 3))
+                                          drop=(pd, sd, 16 * (cfg.layer0 + li) + 3))
             wqkv = torch.cat([qw, kw, vw], 0)
             # dh1 = dq Wq + [dk | dv] [Wk; Wv]: two GEMMs, the second accumulates onto the first
             dh1 = dgrad(dq, qw, f32)

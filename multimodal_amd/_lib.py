@@ -85,6 +85,8 @@ PROTOTYPES = {
     "mmamd_cross_entropy_bwd": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _i, _i64, _vp, _vp]),
     "mmamd_cross_entropy": (_i, [_vp, _i64, _vp, _i, _i, _i64, _vp, _vp, _vp]),
     "mmamd_attention_x_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "mmamd_attention_x_fwd_head_mask": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f,
+                                             _vp, _i64, _i64, _i64, _i64, _vp]),
     "mmamd_attention_x_fwd_dropout": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f,
                                             C.c_uint64, C.c_uint32, _vp]),
     "mmamd_attention_x_bwd_dropout": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,

@@ -659,6 +659,10 @@ struct AttnX {
   int ldq, ldk, ldv, ldo, Sq, Sk, H, causal;
   float scale_log2e;
   AttnDrop drop;  // training-time dropout on the normalised probabilities (thresh = 0: none); common.h
+  // head_mask of the reference's scaled_dot_product_attention (modules/layers/attention.py:236-237): fp32, multiplied into the probabilities AFTER
+  // softmax and dropout (what is returned and what multiplies V); element strides of its [b, h, q, k] broadcast (0 = broadcast dimension)
+  const float* hmask = nullptr;
+  long long hm_sb = 0, hm_sh = 0, hm_sq = 0, hm_sk = 0;
 };
 
 template <int NKT, int DH, typename TP>
@@ -779,6 +783,12 @@ __global__ __launch_bounds__(256) void attention_x_kernel(const AttnX p) {
           const Philox4 rr = attn_drop_block(p.drop, ((long long)b * p.H + h) * Sq + qc, (Sk + 3) >> 2, kt * 32 + 8 * g + 4 * half);
 #pragma unroll
           for (int j = 0; j < 4; ++j) e[j] = rr.v[j] >= p.drop.thresh ? e[j] * p.drop.scale : 0.f;
+        }
+        if (p.hmask != nullptr) {  // (uniform)
+          const float* hm = p.hmask + (long long)b * p.hm_sb + (long long)h * p.hm_sh + (long long)qc * p.hm_sq;
+          const int key = kt * 32 + 8 * g + 4 * half;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] *= key + j < Sk ? hm[(long long)(key + j) * p.hm_sk] : 0.f;
         }
         if (prow != nullptr && q < Sq) {
           const int key = kt * 32 + 8 * g + 4 * half;
@@ -1735,7 +1745,8 @@ static AttnDrop make_attn_drop(float p, uint64_t seed, uint32_t site) {
 static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                 int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
                                 int causal, void* out, int ldo, void* probs, int probs_dtype, float* lse, int B, int Sq, int Sk, int H,
-                                int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site, mmamd_stream_t stream);
+                                int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site, mmamd_stream_t stream,
+                                const float* head_mask = nullptr, const int64_t* hm_strides = nullptr);
 
 extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                      int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
@@ -1743,6 +1754,19 @@ extern "C" int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_str
                                      float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, mmamd_stream_t stream) {
   return attention_x_fwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
                               ldo, probs, probs_dtype, lse, B, Sq, Sk, H, head_dim, scale, 0.f, 0, 0, stream);
+}
+
+extern "C" int mmamd_attention_x_fwd_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                               int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                               int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
+                                               float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, const float* head_mask,
+                                               int64_t hm_stride_b, int64_t hm_stride_h, int64_t hm_stride_q, int64_t hm_stride_k,
+                                               mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(head_mask != nullptr && hm_stride_b >= 0 && hm_stride_h >= 0 && hm_stride_q >= 0 && hm_stride_k >= 0, MMAMD_E_BADARG,
+                  "attention_x: head_mask must be given with non-negative element strides");
+  const int64_t hms[4] = {hm_stride_b, hm_stride_h, hm_stride_q, hm_stride_k};
+  return attention_x_fwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              ldo, probs, probs_dtype, lse, B, Sq, Sk, H, head_dim, scale, 0.f, 0, 0, stream, head_mask, hms);
 }
 
 extern "C" int mmamd_attention_x_fwd_dropout(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
@@ -1758,7 +1782,8 @@ extern "C" int mmamd_attention_x_fwd_dropout(const void* q, int ldq, int64_t q_b
 static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                 int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
                                 int causal, void* out, int ldo, void* probs, int probs_dtype, float* lse, int B, int Sq, int Sk, int H,
-                                int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site, mmamd_stream_t stream) {
+                                int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site, mmamd_stream_t stream,
+                                const float* head_mask, const int64_t* hm_strides) {
   MMAMD_CHECK_ARG(q && k && v && out && B >= 0 && Sq > 0 && Sk > 0 && H > 0, MMAMD_E_BADARG, "attention_x: bad argument");
   MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x: head_dim=%d (64 and 96 are built)", head_dim);
   MMAMD_CHECK_ARG(Sk <= 288, MMAMD_E_UNSUPPORTED, "attention_x: Sk=%d > 288 not supported", Sk);
@@ -1776,6 +1801,8 @@ static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal ? 1 : 0;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.drop = make_attn_drop(drop_p, seed, site);
+  p.hmask = head_mask;
+  if (head_mask != nullptr) { p.hm_sb = hm_strides[0]; p.hm_sh = hm_strides[1]; p.hm_sq = hm_strides[2]; p.hm_sk = hm_strides[3]; }
   hipStream_t st = (hipStream_t)stream;
   const bool pf32 = probs == nullptr || probs_dtype == MMAMD_F32;
   if (head_dim == 64) return pf32 ? dispatch_attn_x<64, float>(p, B, st) : dispatch_attn_x<64, bf16>(p, B, st);

@@ -97,27 +97,26 @@ class TransformerEncoderLayer(nn.Module):
         pk = self._packed.get
         return ops.layernorm(x, pk(ln.weight, torch.float32), pk(ln.bias, torch.float32), ln.eps, out_dtype=out_dtype)
 
-    def run(self, x: Tensor, B: int, S: int, key_mask: Optional[Tensor], want_probs: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    def run(self, x: Tensor, B: int, S: int, key_mask: Optional[Tensor], want_probs: bool,
+            head_mask: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         """x: fp32 [B*S, d] (left untouched).  Returns (new fp32 [B*S, d], probabilities [B,H,S,S] or None)."""
         if self.training and (self.attention_dropout.p > 0 or self.feedforward_dropout.p > 0):
             raise ops.MmamdError("this non-differentiable (stand-alone / inference) forward applies no dropout: call .eval(); training-time dropout runs inside the encoder / decoder stacks' differentiable forwards")
         bf, f32 = torch.bfloat16, torch.float32
         if self.norm_first:  # reference :155-176
             hn = self._ln(self.attention_layernorm, x, bf)
-            x1, probs = self.attention.run(hn, B, S, key_mask, want_probs, residual=x)
+            x1, probs = self.attention.run(hn, B, S, key_mask, want_probs, residual=x, head_mask=head_mask)
             hn = self._ln(self.feedforward_layernorm, x1, bf)
             y = self.feedforward.run(hn, residual=x1, out=x1)  # x1 is private to this layer: updated in place
             return y, probs
         # post-norm, reference :178-198
-        a, probs = self.attention.run(ops.convert(x, bf), B, S, key_mask, want_probs, residual=x)
+        a, probs = self.attention.run(ops.convert(x, bf), B, S, key_mask, want_probs, residual=x, head_mask=head_mask)
         x1 = self._ln(self.attention_layernorm, a, f32)
         ff = self.feedforward.run(ops.convert(x1, bf), residual=x1, out=a)
         return self._ln(self.feedforward_layernorm, ff, f32), probs
 
     def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None,
                 return_attn_weights: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
-        if head_mask is not None:
-            raise ops.MmamdError("head_mask is not implemented on the MI355X path")
         forbid_training_forward(self)
         shape = hidden_states.shape
         d = shape[-1]
@@ -127,7 +126,7 @@ class TransformerEncoderLayer(nn.Module):
         if xc.dtype != torch.float32:
             raise ops.MmamdError("encoder layers on the MI355X path take fp32 hidden states")
         km = key_mask_from_attention_mask(attention_mask, B, S)
-        y, probs = self.run(xc.view(B * S, d), B, S, km, return_attn_weights)
+        y, probs = self.run(xc.view(B * S, d), B, S, km, return_attn_weights, head_mask)
         y = y.view(shape)
         return (y, probs) if return_attn_weights else y
 
@@ -156,11 +155,11 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None,
                 return_attn_weights: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
-        if head_mask is not None:
-            raise ops.MmamdError("head_mask is not implemented on the MI355X path")
         if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
             raise ops.MmamdError("TransformerEncoder on the MI355X path takes fp32 [b, seq, c] hidden states")
         B, S, d = hidden_states.shape
+        if head_mask is not None and (wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad)):
+            raise ops.MmamdError("head_mask is an inference-time feature on the MI355X path (the attention backward kernels do not carry it): call .eval() / no_grad")
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
             # differentiable forward (models/flava/_train.py): every hidden state attached to the graph, attention probabilities as values
             # (schedule.train_attentions = False skips their recomputation: attentions = None, the r03 behaviour)
@@ -180,7 +179,7 @@ class TransformerEncoder(nn.Module):
         for layer_module in self.layer:
             if return_hidden_states:
                 all_hidden_states.append(x.view(B, S, d))
-            x, probs = layer_module.run(x, B, S, km, return_attn_weights)
+            x, probs = layer_module.run(x, B, S, km, return_attn_weights, head_mask)  # (reference :268-275: the same head_mask for every layer)
             if return_attn_weights:
                 all_self_attentions.append(probs)
         x = x.view(B, S, d)

@@ -60,8 +60,10 @@ class MultiHeadAttention(nn.Module):
         self._packed = PackedCache()
 
     def run(self, hn: Tensor, B: int, S: int, key_mask: Optional[Tensor], want_probs: bool, residual: Optional[Tensor],
-            out: Optional[Tensor] = None, qkv: Optional[Tensor] = None, att: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
-        """hn: bf16 [B*S, d] (already normalised).  Returns (fp32 [B*S, d] = output(attn) + residual, probs or None)."""
+            out: Optional[Tensor] = None, qkv: Optional[Tensor] = None, att: Optional[Tensor] = None,
+            head_mask: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+        """hn: bf16 [B*S, d] (already normalised).  Returns (fp32 [B*S, d] = output(attn) + residual, probs or None).  head_mask (reference
+        attention.py:236-237): multiplied into the probabilities after the softmax -- the general attention kernel carries it."""
         d = self.query.in_features
         if self.key.in_features != d or self.d_qk != HEAD_DIM:
             raise ops.MmamdError("the MI355X attention kernel needs dim_q == dim_kv and 64-wide heads "
@@ -77,7 +79,10 @@ class MultiHeadAttention(nn.Module):
         else:
             b = None
         qkv = ops.gemm_bf16(hn, w, b, out=qkv)
-        if want_probs or key_mask is not None:
+        if head_mask is not None:
+            att, probs = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, self.n_head, HEAD_DIM, ops.AttnMask(key_mask=key_mask),
+                                             want_probs=want_probs, out=att, head_mask=head_mask_f32(head_mask))
+        elif want_probs or key_mask is not None:
             att, probs = ops.attention_probs_fwd(qkv, B, S, self.n_head, key_mask, want_probs=want_probs, out=att)
         else:
             att, probs = ops.attention_fwd(qkv, B, S, self.n_head, causal=False, out=att), None
@@ -87,10 +92,11 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, q: Tensor, kv: Optional[Tensor] = None, return_attn_weights: bool = False, use_cache: bool = False,
                 causal: bool = False, **attn_kwargs: Any) -> Union[Tensor, Tuple[Tensor, Tensor]]:
-        if attn_kwargs.get("head_mask") is not None:
-            raise ops.MmamdError("head_mask is not implemented on the MI355X path")
         forbid_detached_forward(self, q, kv)
         am = attn_kwargs.get("attention_mask")
+        hm = attn_kwargs.get("head_mask")
+        if hm is not None:  # multiplicative post-softmax mask (:236-237): the general kernel, whatever the shapes
+            return self._forward_general(q, kv, return_attn_weights, use_cache, causal, am, head_mask_f32(hm))
         pad_form = am is None or (am.dim() == 4 and am.shape[1] == 1 and am.shape[2] == 1) or (am.dim() == 2 and q.dim() == 3 and tuple(am.shape) == (q.shape[0], q.shape[1]) and q.shape[0] != q.shape[1])
         if q.dim() == 3 and (kv is None or kv is q) and not use_cache and not self.cache and pad_form:
             # self-attention over [b, seq, c] without a cache (what FLAVA's layers do): one packed in-projection, the flash-style kernels
@@ -104,7 +110,7 @@ class MultiHeadAttention(nn.Module):
         return self._forward_general(q, kv, return_attn_weights, use_cache, causal, attn_kwargs.get("attention_mask"))
 
     def _forward_general(self, q: Tensor, kv: Optional[Tensor], return_attn_weights: bool, use_cache: bool, causal: bool,
-                         attention_mask: Optional[Tensor]) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+                         attention_mask: Optional[Tensor], head_mask: Optional[Tensor] = None) -> Union[Tensor, Tuple[Tensor, Tensor]]:
         """Cross-attention (kv), n-dimensional token grids, and the key / value cache of the reference's decoding loop (:150-176): q, k, v are
         projected separately (k and v by one stacked GEMM), the general attention kernel (mmamd_attention_x_fwd: Sq != Sk, 64- / 96-wide heads,
         key-padding or [Sq, Sk] masks) attends, `self.cache` holds {"k", "v"} in the reference's [b, n_head, seq, c] shape as bf16 views of
@@ -152,10 +158,18 @@ class MultiHeadAttention(nn.Module):
         k2 = k_tok.reshape(B * Sk, dq) if k_tok.is_contiguous() else k_tok.flatten(0, 1)
         v2 = v_tok.reshape(B * Sk, dq) if v_tok.is_contiguous() else v_tok.flatten(0, 1)
         mask = _general_mask(attention_mask, B, Sq, Sk)
-        att, probs = ops.attention_x_fwd(qp, k2, v2, B, Sq, Sk, H, hd, mask, want_probs=return_attn_weights)
+        att, probs = ops.attention_x_fwd(qp, k2, v2, B, Sq, Sk, H, hd, mask, want_probs=return_attn_weights, head_mask=head_mask)
         y = ops.gemm_bf16(att, pc.get(self.output.weight, bf), pc.get(self.output.bias, f32), out_dtype=f32)
         y = y.view(*q_shape[:-1], dq)
         return (y, probs) if return_attn_weights else y
+
+
+def head_mask_f32(head_mask: Tensor) -> Tensor:
+    """The reference's head_mask (any dtype, broadcastable to [b, h, q, k]) as the contiguous fp32 device tensor the kernel strides over."""
+    if not head_mask.is_cuda:
+        raise ops.MmamdError("head_mask must live on the HIP device")
+    hm = head_mask.detach().to(torch.float32)
+    return hm if hm.is_contiguous() else hm.contiguous()
 
 
 def _general_mask(attention_mask: Optional[Tensor], B: int, Sq: int, Sk: int) -> ops.AttnMask:

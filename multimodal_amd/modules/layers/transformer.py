@@ -449,11 +449,10 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
     """Differentiable TransformerDecoder.forward (DecoderStackFn: self-attention with the mask, optional cross-attention, feed-forward)."""
     from ..._autograd import DecoderStackConfig, DecoderStackFn, draw_seed
 
-    if return_hidden_states:
-        raise ops.MmamdError("training on the MI355X path: return_hidden_states is not implemented for TransformerDecoder")
     B, S, d = hidden_states.shape
     mask = to_attn_mask(attention_mask, False, B, S, S)
     layers, params = [], []
+    bounds = [0]  # params[bounds[i]:bounds[i + 1]] belong to layer i
     drop_rates = set()
     for layer in self.layer:
         if not layer.norm_first:
@@ -484,6 +483,7 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
         params += [steps[0][0].weight, steps[0][0].bias, steps[1][0].weight, steps[1][0].bias, layer.feedforward_layernorm.weight,
                    layer.feedforward_layernorm.bias]
         layers.append(spec)
+        bounds.append(len(params))
     enc2d, Sk = None, 0
     if encoder_hidden_states is not None:
         Sk = encoder_hidden_states.shape[1]
@@ -492,12 +492,25 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
     if len(drop_rates) > 1:
         raise ops.MmamdError(f"training: all dropout sites of a decoder stack must share one rate, got {sorted(drop_rates)}")
     drop_p = drop_rates.pop() if drop_rates else 0.0
-    cfg = DecoderStackConfig(B, S, Sk, layers, mask, drop_p=drop_p, seed=draw_seed() if drop_p > 0 else 0)
+    seed = draw_seed() if drop_p > 0 else 0
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
-    x = DecoderStackFn.apply(xc.view(B * S, d), enc2d, cfg, *params).view(B, S, d)
+    all_hidden_states = []
+    if return_hidden_states:
+        # every hidden state attached to the graph like the reference's (:606-640): one autograd node per layer (layer0 keeps the dropout sites of the
+        # one-node form, so both forms draw the same masks from the same seed)
+        x = xc.view(B * S, d)
+        for li in range(len(layers)):
+            all_hidden_states.append(x.view(B, S, d))
+            cfg = DecoderStackConfig(B, S, Sk, [layers[li]], mask, drop_p=drop_p, seed=seed, layer0=li)
+            x = DecoderStackFn.apply(x, enc2d, cfg, *params[bounds[li]:bounds[li + 1]])
+        x = x.view(B, S, d)
+        all_hidden_states.append(x)
+    else:
+        cfg = DecoderStackConfig(B, S, Sk, layers, mask, drop_p=drop_p, seed=seed)
+        x = DecoderStackFn.apply(xc.view(B * S, d), enc2d, cfg, *params).view(B, S, d)
     if self.final_layer_norm is not None:
         x = self.final_layer_norm(x)
-    return TransformerOutput(last_hidden_state=x, hidden_states=[], current_key_values=[])
+    return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, current_key_values=[])
 
 
 TransformerDecoder._forward_train = _decoder_forward_train

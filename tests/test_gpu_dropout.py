@@ -353,3 +353,50 @@ def test_decoder_stack_trains_with_dropout():
     with torch.no_grad():
         ye = decd(x, enc, attention_mask=causal).last_hidden_state
     assert float((ye - y0).abs().max()) < 2e-2 * float(y0.abs().max())   # eval: dropout is the identity (inference kernels vs training forward)
+
+
+def test_decoder_training_forward_returns_attached_hidden_states():
+    """TransformerDecoder(..., return_hidden_states=True) in training (reference transformer.py:606-640 returns the input, every layer's output and keeps
+    them in the graph): the per-layer-node form gives the same last state and the same parameter gradients as the one-node form, a loss on an
+    INTERMEDIATE state reaches only the layers below it, and with dropout both forms draw the same masks from the same seed (layer0 keeps the sites)."""
+    from multimodal_amd.modules.layers.transformer import TransformerDecoder
+
+    torch.manual_seed(13)
+    kw = dict(n_layer=3, d_model=128, n_head=2, dim_feedforward=256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True,
+              use_cross_attention=True, dim_kv=128)
+    dec = TransformerDecoder(dropout=0.0, **kw).cuda().train()
+    x = torch.randn(2, 10, 128, device="cuda")
+    enc = torch.randn(2, 7, 128, device="cuda")
+    causal = torch.ones(10, 10, dtype=torch.bool, device="cuda").tril()
+    w = torch.randn(2, 10, 128, device="cuda")
+
+    def grads():
+        return [p.grad.clone() if p.grad is not None else None for p in dec.parameters()]
+
+    dec.zero_grad()
+    one = dec(x, enc, attention_mask=causal)
+    (one.last_hidden_state * w).sum().backward()
+    g_one = grads()
+    assert one.hidden_states == []
+    dec.zero_grad()
+    per = dec(x, enc, attention_mask=causal, return_hidden_states=True)
+    assert len(per.hidden_states) == 4 and all(h.shape == (2, 10, 128) for h in per.hidden_states)
+    assert torch.equal(per.hidden_states[0], x) and torch.equal(per.hidden_states[-1], per.last_hidden_state)
+    assert torch.equal(per.last_hidden_state, one.last_hidden_state)   # the same kernels on the same data
+    assert all(h.requires_grad for h in per.hidden_states[1:])
+    (per.last_hidden_state * w).sum().backward()
+    for a, b in zip(g_one, grads()):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    # a loss on the state after layer 0 reaches layer 0's parameters only
+    dec.zero_grad()
+    per = dec(x, enc, attention_mask=causal, return_hidden_states=True)
+    (per.hidden_states[1] * w).sum().backward()
+    got = {n: p.grad is not None and bool((p.grad != 0).any()) for n, p in dec.named_parameters()}
+    assert all(v for n, v in got.items() if n.startswith("layer.0.")) and not any(v for n, v in got.items() if not n.startswith("layer.0."))
+    # dropout: same seed -> same masks in both forms
+    decd = TransformerDecoder(dropout=0.25, **kw).cuda().train()
+    torch.manual_seed(99)
+    a = decd(x, enc, attention_mask=causal).last_hidden_state.detach()
+    torch.manual_seed(99)
+    b = decd(x, enc, attention_mask=causal, return_hidden_states=True).last_hidden_state.detach()
+    assert torch.equal(a, b)
