@@ -39,6 +39,7 @@ for name, probs in shapes.items():
                  "median_us_under_profiler": med, "tflops_under_profiler": flops / med / 1e6 if med else None,
                  "mfma_busy_frac": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)) if "GRBM_GUI_ACTIVE" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m else None,
                  "tcc_hit_rate": m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]) if "TCC_HIT_sum" in m else None,
+                 "effective_clock_ghz": (m["GRBM_GUI_ACTIVE"] / 8 / med / 1e3) if "GRBM_GUI_ACTIVE" in m and med else None,  # busy cycles per XCD / duration (2.4 nominal)
                  "wait_any_frac": m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in m else None,
                  "wait_inst_frac": m.get("SQ_WAIT_INST_ANY", 0) / m["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in m else None,
                  "active_inst_frac": m.get("SQ_ACTIVE_INST_ANY", 0) / m["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in m else None,
