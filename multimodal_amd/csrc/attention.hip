@@ -1362,6 +1362,234 @@ __global__ __launch_bounds__(NWH * 64) void attention_bwd_fused_kernel(const bf1
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// SINGLE-PASS attention backward (r04, S <= 256): every (query tile, key tile) pair is visited ONCE.  The fused kernel above still computes
+// S, P, dP and dS of a pair twice (once per role: 28 MFMAs and 32 exponentials per pair); here the wave that owns key tile kt computes them once --
+// S^T and dP^T (lane = key), dV_kt += P^T dO, dK_kt += dS^T Q -- and HANDS dS OVER, as a 32 x 32 bf16 tile in an LDS mailbox, to the wave that owns
+// query tile qt, which adds dQ_qt += dS K_kt to its own registers (20 MFMAs and 16 exponentials per pair).  Skewed schedule: in step s wave w produces
+// pair (qt = (w + s) mod T, kt = w) and, behind ONE workgroup barrier, consumes pair (qt = w, kt = (w - s) mod T) -- T = live tiles; every wave
+// produces and consumes exactly one pair per step, no two waves touch the same accumulator, the summation order of every dQ / dK / dV element is
+// fixed (deterministic, no atomics).  Mailboxes are double-buffered over the step parity, so one barrier per step separates writer and reader.
+//   LDS: Q, K, dO row images [SP][72] (V is only ever needed by its key tile's owner: fragments straight from global), log-sum-exp / D / key-mask rows,
+//   2 x T mailboxes of [32 keys][40] bf16 (the consumer reads dS^T fragments by ds_read_b64_tr_b16, exactly like the K^T fragments).  139 KiB at S = 197:
+//   one 8-wave workgroup per CU.  Results leave through the dead images as whole rows, like the fused kernel.
+// Same products, operand roundings and per-pair arithmetic as the other two forms; dQ sums its key tiles in another order (fp32 rounding only).
+// ---------------------------------------------------------------------------------------------------------
+template <int NKT, bool CAUSAL>
+__global__ __launch_bounds__(512) void attention_bwd_sp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O, const bf16* __restrict__ dO,
+                                                               const float* __restrict__ lse, bf16* __restrict__ dqkv, int S, int H, int BH,
+                                                               float scale, const uint8_t* __restrict__ key_mask) {
+  static_assert(NKT <= 8, "one tile per wave");
+  constexpr int SP = NKT * 32, NT = 512, TS = 40;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qs = reinterpret_cast<bf16*>(smem);
+  bf16* Ks = Qs + SP * kKStride;
+  bf16* dOs = Ks + SP * kKStride;
+  float* L2s = reinterpret_cast<float*>(dOs + SP * kKStride);
+  float* Dqs = L2s + SP;
+  uint8_t* Mk = reinterpret_cast<uint8_t*>(Dqs + SP);
+  bf16* mail = reinterpret_cast<bf16*>(smem + 3 * SP * kKStride * 2 + 2 * SP * 4 + ((SP + 15) & ~15));  // [2][NKT][32][TS]
+  const int D = H * kDh;
+  const size_t row_stride = (size_t)3 * D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const int T = (S + 31) >> 5;  // live tiles (<= NKT)
+
+  for (int item = blockIdx.x; item < BH; item += gridDim.x) {
+    const int b = item / H, h = item - b * H;
+    const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
+    for (int r = tid >> 3; r < SP; r += NT >> 3) {
+      const int c = tid & 7;
+      bf16x8 qv, kv, dv, ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qv[j] = (bf16)0.f; kv[j] = (bf16)0.f; dv[j] = (bf16)0.f; ov[j] = (bf16)0.f; }
+      if (r < S) {
+        const bf16* row = base + (size_t)r * row_stride + c * 8;
+        qv = *reinterpret_cast<const bf16x8*>(row);
+        kv = *reinterpret_cast<const bf16x8*>(row + D);
+        dv = *reinterpret_cast<const bf16x8*>(dO + ((size_t)b * S + r) * D + h * kDh + c * 8);
+        ov = *reinterpret_cast<const bf16x8*>(O + ((size_t)b * S + r) * D + h * kDh + c * 8);
+      }
+      *reinterpret_cast<bf16x8*>(Qs + r * kKStride + c * 8) = qv;
+      *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
+      *reinterpret_cast<bf16x8*>(dOs + r * kKStride + c * 8) = dv;
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += (float)dv[j] * (float)ov[j];
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      if (c == 0) {
+        Dqs[r] = r < S ? part : 0.f;
+        L2s[r] = r < S ? lse[((size_t)b * H + h) * S + r] : INFINITY;
+        Mk[r] = (r < S && (key_mask == nullptr || key_mask[(size_t)b * S + r] != 0)) ? 1 : 0;
+      }
+    }
+    const int tile = wave;
+    const bool live = tile < T;
+    // this wave's key tile: K and V fragments (lane = key), V straight from global
+    bf16x8 kf[4], vf[4];
+    {
+      const int key = tile * 32 + l31;
+      const bool in = live && key < S;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kf[t][j] = (bf16)0.f; vf[t][j] = (bf16)0.f; }
+        if (in) {
+          kf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * row_stride + D + 16 * t + 8 * half);
+          vf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * row_stride + 2 * D + 16 * t + 8 * half);
+        }
+      }
+    }
+    __syncthreads();
+    const int key = tile * 32 + l31;
+    const bool key_live = live && Mk[key] != 0;
+    f32x16 dq_acc[2], dv_acc[2], dk_acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dq_acc[nt][r] = 0.f; dv_acc[nt][r] = 0.f; dk_acc[nt][r] = 0.f; }
+    const bf16* qtr = Qs + tr_off(lane, kKStride);
+    const bf16* dotr = dOs + tr_off(lane, kKStride);
+    const bf16* ktr = Ks + tr_off(lane, kKStride);
+    const int trm = tr_off(lane, TS);
+
+#pragma unroll 1
+    for (int s_ = 0; s_ < T; ++s_) {
+      bf16* mbuf = mail + (size_t)(s_ & 1) * NKT * 32 * TS;
+      // ---------------- produce: pair (qt, kt = tile), lane = key ----------------
+      if (live) {
+        int qt = tile + s_;
+        qt = qt >= T ? qt - T : qt;
+        if (!CAUSAL || tile <= qt) {
+          f32x16 st, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+          const bf16* qrow = Qs + (qt * 32 + l31) * kKStride + 8 * half;
+          const bf16* drow = dOs + (qt * 32 + l31) * kKStride + 8 * half;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qrow + 16 * t), kf[t], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(drow + 16 * t), vf[t], dp, 0, 0, 0);
+          }
+          uint32_t pk[8], dk[8];
+          bf16* mrow = mbuf + (size_t)qt * 32 * TS + l31 * TS + 4 * half;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float e[4], f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * g + j;
+              const int q = qt * 32 + 8 * g + 4 * half + j;
+              const bool ok = key_live && (!CAUSAL || key <= q);
+              const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;
+              e[j] = pr;
+              f[j] = pr * (dp[r] - Dqs[q]);
+            }
+            bf16x2 p0, p1, d0, d1;
+            p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
+            d0[0] = (bf16)f[0]; d0[1] = (bf16)f[1]; d1[0] = (bf16)f[2]; d1[1] = (bf16)f[3];
+            pk[2 * g] = __builtin_bit_cast(uint32_t, p0); pk[2 * g + 1] = __builtin_bit_cast(uint32_t, p1);
+            dk[2 * g] = __builtin_bit_cast(uint32_t, d0); dk[2 * g + 1] = __builtin_bit_cast(uint32_t, d1);
+            // dS[q = 8g + 4half + 0..3][key] -> mailbox row `key`, 4 consecutive query columns (8 bytes)
+            *reinterpret_cast<uint2*>(mrow + 8 * g) = make_uint2(dk[2 * g], dk[2 * g + 1]);
+          }
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            u32x4 pw, dw;
+            pw[0] = pk[4 * jj + 0]; pw[1] = pk[4 * jj + 1]; pw[2] = pk[4 * jj + 2]; pw[3] = pk[4 * jj + 3];
+            dw[0] = dk[4 * jj + 0]; dw[1] = dk[4 * jj + 1]; dw[2] = dk[4 * jj + 2]; dw[3] = dk[4 * jj + 3];
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pw), dsf = __builtin_bit_cast(bf16x8, dw);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const int toff = (qt * 32 + 16 * jj) * kKStride + nt * 32;
+              const uint2 a0 = lds_tr_b64(dotr + toff), a1 = lds_tr_b64(dotr + toff + 8 * kKStride);
+              const uint2 b0 = lds_tr_b64(qtr + toff), b1 = lds_tr_b64(qtr + toff + 8 * kKStride);
+              u32x4 aw, bw;
+              aw[0] = a0.x; aw[1] = a0.y; aw[2] = a1.x; aw[3] = a1.y;
+              bw[0] = b0.x; bw[1] = b0.y; bw[2] = b1.x; bw[3] = b1.y;
+              dv_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw), pf, dv_acc[nt], 0, 0, 0);
+              dk_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), dsf, dk_acc[nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      __syncthreads();  // the step's mailboxes are written (and, double-buffered, nobody still reads the ones of two steps ago)
+      // ---------------- consume: pair (qt = tile, kt), lane = query ----------------
+      if (live) {
+        int kt = tile - s_;
+        kt = kt < 0 ? kt + T : kt;
+        if (!CAUSAL || kt <= tile) {
+          const bf16* mt = mbuf + (size_t)tile * 32 * TS + trm;
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const uint2 d0 = lds_tr_b64(mt + (16 * jj) * TS), d1 = lds_tr_b64(mt + (16 * jj + 8) * TS);
+            u32x4 dw;
+            dw[0] = d0.x; dw[1] = d0.y; dw[2] = d1.x; dw[3] = d1.y;
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, dw);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              const bf16* kp = ktr + (kt * 32 + 16 * jj) * kKStride + nt * 32;
+              const uint2 v0 = lds_tr_b64(kp), v1 = lds_tr_b64(kp + 8 * kKStride);
+              u32x4 vw;
+              vw[0] = v0.x; vw[1] = v0.y; vw[2] = v1.x; vw[3] = v1.y;
+              dq_acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), dsf, dq_acc[nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading the images: they become the output staging area
+    if (live) {
+      const int row = tile * 32 + l31;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = nt * 32 + 8 * g + 4 * half;
+          f32x4 a, c, e;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = dq_acc[nt][4 * g + j] * scale; c[j] = dk_acc[nt][4 * g + j] * scale; e[j] = dv_acc[nt][4 * g + j]; }
+          store4(Qs + row * kKStride + col, a);    // dQ over Q
+          store4(Ks + row * kKStride + col, c);    // dK over K
+          store4(dOs + row * kKStride + col, e);   // dV over dO
+        }
+    }
+    __syncthreads();
+    bf16* obase = dqkv + (size_t)b * S * row_stride + h * kDh;
+    for (int r = tid >> 3; r < S; r += NT >> 3) {
+      const int c = tid & 7;
+      bf16* orow = obase + (size_t)r * row_stride + c * 8;
+      *reinterpret_cast<bf16x8*>(orow) = *reinterpret_cast<const bf16x8*>(Qs + r * kKStride + c * 8);
+      *reinterpret_cast<bf16x8*>(orow + D) = *reinterpret_cast<const bf16x8*>(Ks + r * kKStride + c * 8);
+      *reinterpret_cast<bf16x8*>(orow + 2 * D) = *reinterpret_cast<const bf16x8*>(dOs + r * kKStride + c * 8);
+    }
+    __syncthreads();  // the next item's staging overwrites the images
+  }
+}
+
+template <int NKT>
+static int launch_attn_bwd_sp(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
+                              float scale, hipStream_t st, const uint8_t* key_mask) {
+  constexpr int SP = NKT * 32;
+  constexpr int smem = 3 * SP * kKStride * 2 + 2 * SP * 4 + ((SP + 15) & ~15) + 2 * NKT * 32 * 40 * 2;
+  auto kc = attention_bwd_sp_kernel<NKT, true>;
+  auto kn = attention_bwd_sp_kernel<NKT, false>;
+  static unsigned long long mc = 0, mn = 0;
+  if (int rc_attr = opt_in_lds((const void*)kc, smem, mc)) return rc_attr;
+  if (int rc_attr = opt_in_lds((const void*)kn, smem, mn)) return rc_attr;
+  const int per_cu = (160 * 1024) / smem >= 2 ? 2 : 1;
+  const int slots = per_cu * stream_cus(st);
+  const int BH = B * H;
+  const int grid = BH < slots ? BH : slots;
+  if (causal) hipLaunchKernelGGL(kc, dim3(grid), dim3(512), smem, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, BH, scale, key_mask);
+  else hipLaunchKernelGGL(kn, dim3(grid), dim3(512), smem, st, (const bf16*)qkv, (const bf16*)O, (const bf16*)dO, lse, (bf16*)dqkv, S, H, BH, scale, key_mask);
+  return launch_status("attention_bwd_sp");
+}
+
 template <int NKT, int NWH>
 static int launch_attn_bwd_fused(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H, int causal,
                                  float scale, hipStream_t st, const uint8_t* key_mask) {
@@ -1595,6 +1823,7 @@ static int launch_attn_long(const void* qkv, const uint8_t* key_mask, void* out,
 }
 
 static int g_attn_variant = 0;
+static int g_attn_bwd_variant = 0;  // mmamd_debug_set_attn_variant(4000 two kernels | 4001 single pass | 4002 fused two-role | 4003 default): backward form only
 
 template <int NKT, bool CAUSAL, int ABL = 0>
 static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st, float* lse = nullptr) {
@@ -1637,6 +1866,10 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
   }
   if (v >= 3100 && v < 3103) {
     g_ln_nt_policy = v - 3100;
+    return 0;
+  }
+  if (v >= 4000 && v < 4004) {  // attention BACKWARD form (the forward keeps its default)
+    g_attn_bwd_variant = v == 4003 ? 0 : v;
     return 0;
   }
   if (v >= 3000 && v < 3008) {  // ring kernel: cap of the ring depth (0 = none), timing A/B only
@@ -1816,7 +2049,19 @@ extern "C" int mmamd_attention_bwd(const void* qkv, const void* out, const void*
   MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), MMAMD_E_ALIGN, "attention_bwd: pointers must be 16-byte aligned");
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (g_attn_variant != 2000) {  // the fused kernel (S <= 256); mmamd_debug_set_attn_variant(2000) keeps the two-kernel form for the A/B
+  // non-causal heads of five and more tiles (ViT-B/16: 7): the single-pass kernel -- 292-311 us against 308-322 us for the two-role fused kernel and 364-398 us
+  // for the two-kernel form at B = 256 (tools/attn_bwd_bench.py); causal heads keep the fused kernel (the skewed schedule idles on the pairs above the diagonal:
+  // text tower 76 vs 55 us).  mmamd_debug_set_attn_variant(4001) forces it wherever it is built, 4002 the fused kernel, 4000 the two kernels.
+  if (g_attn_bwd_variant == 4001 || (g_attn_bwd_variant == 0 && !causal)) {
+    switch ((S + 31) / 32) {
+      case 3: if (g_attn_bwd_variant == 4001) return launch_attn_bwd_sp<3>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask); break;
+      case 5: return launch_attn_bwd_sp<5>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 6: return launch_attn_bwd_sp<6>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 7: return launch_attn_bwd_sp<7>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+      case 8: return launch_attn_bwd_sp<8>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
+    }
+  }
+  if (g_attn_bwd_variant != 4000) {  // the fused kernel (S <= 256); mmamd_debug_set_attn_variant(4000) keeps the two-kernel form for the A/B (codes 2000-3999 belong to the ring kernel's ablations)
     switch ((S + 31) / 32) {
       case 1: return launch_attn_bwd_fused<1, 4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);
       case 2: return launch_attn_bwd_fused<2, 4>(qkv, out, dout, lse, dqkv, B, S, H, causal, scale, st, key_mask);

@@ -18,7 +18,7 @@ def main():
         out, lse = ops.attention_fwd_train(qkv, B, S, H, causal)
         res = {}
         for rnd in range(2):
-            for code, tag in ((0, "fused (shipped)"), (2000, "two kernels (r03)")):
+            for code, tag in ((4003, "default"), (4000, "two kernels (r03)"), (4001, "single pass"), (4002, "fused (two roles)")):
                 L.mmamd_debug_set_attn_variant(code)
                 for _ in range(2):
                     d = ops.attention_bwd(qkv, out, dout, lse, B, S, H, causal)
@@ -31,8 +31,13 @@ def main():
                 torch.cuda.synchronize()
                 res[code] = d
                 print(f"S={S} causal={int(causal)} {tag}: {e0.elapsed_time(e1) * 200:7.1f} us", flush=True)
-        L.mmamd_debug_set_attn_variant(0)
-        print(f"S={S}: fused == two kernels bit for bit: {torch.equal(res[0], res[2000])}", flush=True)
+        L.mmamd_debug_set_attn_variant(4003)
+        print(f"S={S}: fused == two kernels bit for bit: {torch.equal(res[4002], res[4000])}", flush=True)
+        D = H * 64
+        ref, got = res[4000].float(), res[4001].float()
+        for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+            err = float((got[:, sl] - ref[:, sl]).abs().max())
+            print(f"S={S}: single pass vs two kernels {name}: max |d| {err:.3e} of max |ref| {float(ref[:, sl].abs().max()):.3e}", flush=True)
 
 
 if __name__ == "__main__":

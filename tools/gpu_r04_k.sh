@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_gpu_dropout.py -q -k "decoder" 2>&1 | tail -3
 for i in 1 2; do
   python tools/train_bench.py --steps 8 2>/dev/null | tail -1 | cut -c1-200
-  python tools/train_bench.py --steps 8 --attn-variant 2000 2>/dev/null | tail -1 | cut -c1-200
+  python tools/train_bench.py --steps 8 --attn-variant 4000 2>/dev/null | tail -1 | cut -c1-200
   python tools/train_bench.py --steps 8 --gemm-gm 8 2>/dev/null | tail -1 | cut -c1-200
 done > $O/r04k_train_ab.txt 2>&1; cat $O/r04k_train_ab.txt
 for i in 1 2; do

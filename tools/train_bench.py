@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--attn-variant", type=int, default=0, help="mmamd_debug_set_attn_variant code (2000 = the two-kernel attention backward)")
+    ap.add_argument("--attn-variant", type=int, default=0, help="mmamd_debug_set_attn_variant code (4000 = the two-kernel attention backward, 4001 = single pass, 4002 = fused two-role)")
     ap.add_argument("--gemm-gm", type=int, default=0, help="mmamd_debug_set_gemm_knob(0, gm): tile-order group (8 = the r03 order)")
     a = ap.parse_args()
     from multimodal_amd import _lib
