@@ -473,7 +473,8 @@ def main() -> None:
                                                                     "rocprofv3 --pmc passes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); a stored "
                                                                     "figure from whole-chip launches, not measured in this run",
                     "launch_ms": round(ms / len(samples), 4), "launches_timed": len(samples),
-                    "share_of_step": round(ms / args.steps / (dt_local / args.steps * 1e3), 4),
+                    # (24 launches per step -- 12 layers x 2 shapes -- of which the first 8 timed steps are bracketed)
+                    "share_of_step": round(24 * (ms / len(samples)) / (dt_local / args.steps * 1e3), 4),
                     "algorithmic_flops_per_launch": fl / len(samples), "by_shape": by_shape, "other_kernels": other_kernels}
 
     cpu_baseline = cpu_baseline_leg(sd_host, images, ids, args.cpu_sample) if sd_host is not None else None
