@@ -103,12 +103,25 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
         float e[4];
         Philox4 rr = {{0u, 0u, 0u, 0u}};
         if constexpr (DROP) rr = attn_drop_block(p.drop, ((long long)b * p.H + h) * Sq + qc, (Sk + 3) >> 2, kt * 32 + 8 * g + 4 * half);
+        uint32_t fmw = 0x01010101u;  // the group's 4 consecutive full-mask bytes as one (unaligned) 32-bit load, like the forward kernel
+        if (fm != nullptr) {
+          const int key0 = kt * 32 + 8 * g + 4 * half;
+          const uint8_t* src = fm + (size_t)qc * Sk + key0;
+          if (key0 + 3 < Sk) {
+            __builtin_memcpy(&fmw, src, 4);
+          } else {
+            fmw = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (key0 + j < Sk) fmw |= (uint32_t)src[j] << (8 * j);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const int key = kt * 32 + 8 * g + 4 * half + j;
           bool ok = Mk[key] != 0 && (!p.causal || key <= qc);
-          if (ok && fm != nullptr) ok = fm[(size_t)qc * Sk + key] != 0;
+          ok = ok && ((fmw >> (8 * j)) & 0xffu) != 0;
           const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2) : 0.f;
           float dpr = dp[r];
           if constexpr (DROP) dpr = rr.v[j] >= p.drop.thresh ? dpr * p.drop.scale : 0.f;
