@@ -221,7 +221,9 @@ int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* ou
  * (modules/layers/multi_head_attention.py:69-71,165-167) as CoCa calls them: decoder self-attention with the
  * padding-aware causal mask (models/coca/text_decoder.py:178-194), cross-attention of the multimodal decoder
  * (modules/layers/transformer.py:367-385), AttentionPooler (modules/layers/attention_pooler.py:58-70).
- * lse (optional, [B,H,Sq] fp32): log2-domain log-sum-exp of the scaled masked scores, saved for mmamd_attention_bwd. */
+ * lse (optional, [B,H,Sq] fp32): log2-domain log-sum-exp of the scaled masked scores, saved for mmamd_attention_bwd.  * `causal` is a 2-bit flag: bit 0 = causal (needs Sq == Sk); bit 1 = the key-padding mask binds the LAST query row only — CoCa's text decoder
+ * (models/coca/text_decoder.py:176-194: every row is causal, the CLS query in the last row additionally hides padded tokens), which then needs no
+ * [B, S, S] mask tensor.  The same flag in mmamd_attention_x_bwd. */
 int mmamd_attention_x_fwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                           int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
                           int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,

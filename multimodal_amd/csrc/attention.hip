@@ -657,6 +657,7 @@ struct AttnX {
   float* lse;  // optional [B,H,Sq]: log2-domain log-sum-exp of the scaled scores (saved for the backward kernels)
   long long q_bs, kv_bs, fm_bs;
   int ldq, ldk, ldv, ldo, Sq, Sk, H, causal;
+  int km_last = 0;  // 1: key_mask applies to the last query row only (argument `causal` bit 1)
   float scale_log2e;
   AttnDrop drop;  // training-time dropout on the normalised probabilities (thresh = 0: none); common.h
   // head_mask of the reference's scaled_dot_product_attention (modules/layers/attention.py:236-237): fp32, multiplied into the probabilities AFTER
@@ -745,6 +746,7 @@ __global__ __launch_bounds__(256) void attention_x_kernel(const AttnX p) {
       for (int r = 0; r < 16; ++r) {
         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float add = Mk[key];
+        if (p.km_last && qc != Sq - 1) add = key < Sk ? 0.f : -INFINITY;  // the key-padding mask binds the LAST query row only (CoCa's CLS row)
         if (p.causal && key > qc) add = -INFINITY;
         if (((fmw[r >> 2] >> (8 * (r & 3))) & 0xffu) == 0) add = -INFINITY;
         st[r] = st[r] * p.scale_log2e + add;
@@ -2039,7 +2041,8 @@ static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
   MMAMD_CHECK_ARG(q && k && v && out && B >= 0 && Sq > 0 && Sk > 0 && H > 0, MMAMD_E_BADARG, "attention_x: bad argument");
   MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x: head_dim=%d (64 and 96 are built)", head_dim);
   MMAMD_CHECK_ARG(Sk <= 288, MMAMD_E_UNSUPPORTED, "attention_x: Sk=%d > 288 not supported", Sk);
-  MMAMD_CHECK_ARG(!causal || Sq == Sk, MMAMD_E_BADARG, "attention_x: causal needs Sq == Sk");
+  MMAMD_CHECK_ARG(causal >= 0 && causal <= 3, MMAMD_E_BADARG, "attention_x: causal is a 2-bit flag (1 = causal, 2 = key mask on the last query row only)");
+  MMAMD_CHECK_ARG(!(causal & 1) || Sq == Sk, MMAMD_E_BADARG, "attention_x: causal needs Sq == Sk");
   MMAMD_CHECK_ARG(ldq >= H * head_dim && ldk >= H * head_dim && ldv >= H * head_dim && ldo >= H * head_dim, MMAMD_E_BADARG,
                   "attention_x: leading dimension smaller than H*head_dim");
   MMAMD_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && q_batch_stride % 8 == 0 && kv_batch_stride % 8 == 0 &&
@@ -2050,7 +2053,7 @@ static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.out = (bf16*)out; p.probs = probs;
   p.key_mask = key_mask; p.full_mask = full_mask; p.lse = lse;
   p.q_bs = q_batch_stride; p.kv_bs = kv_batch_stride; p.fm_bs = full_mask_batch_stride;
-  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal ? 1 : 0;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal & 1; p.km_last = (causal >> 1) & 1;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.drop = make_attn_drop(drop_p, seed, site);
   p.hmask = head_mask;

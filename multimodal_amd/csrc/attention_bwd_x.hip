@@ -19,6 +19,7 @@ struct AttnXB {
   const uint8_t *key_mask, *full_mask;
   long long q_bs, kv_bs, fm_bs, dq_bs, dkv_bs;
   int ldq, ldk, ldv, ldo, lddq, lddk, lddv, Sq, Sk, H, causal;
+  int km_last = 0;  // 1: key_mask applies to the last query row only (argument `causal` bit 1), as in the forward
   float scale;
   AttnDrop drop;  // the forward's dropout on the probabilities (thresh = 0: none): O = P' V with P' = P keep / (1 - p), so
                   // dV = P'^T dO, dP = (dO V^T) keep / (1 - p), dS = P (dP - D) with D = sum dO O (unchanged form)
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const int key = kt * 32 + 8 * g + 4 * half + j;
-          bool ok = Mk[key] != 0 && (!p.causal || key <= qc);
+          bool ok = ((p.km_last && qc != Sq - 1) ? key < Sk : Mk[key] != 0) && (!p.causal || key <= qc);
           ok = ok && ((fmw >> (8 * j)) & 0xffu) != 0;
           const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2) : 0.f;
           float dpr = dp[r];
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p
               const int r = 4 * g + j;
               const int ql = qt * 32 + 8 * g + 4 * half + j;  // query index inside the chunk
               const int q = qbase + ql;
-              bool ok = key_live && q < Sq && (!p.causal || key <= q);
+              bool ok = ((p.km_last && q != Sq - 1) ? (active && key < Sk) : key_live) && q < Sq && (!p.causal || key <= q);
               if (ok && fm != nullptr) ok = fm[(size_t)q * Sk + key] != 0;
               const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[ql]) : 0.f;
               float pd = pr, dpr = dp[r];
@@ -376,7 +377,8 @@ static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
                   "attention_x_bwd: bad argument");
   MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x_bwd: head_dim=%d (64 and 96 are built)", head_dim);
   MMAMD_CHECK_ARG(Sk <= 288, MMAMD_E_UNSUPPORTED, "attention_x_bwd: Sk=%d > 288 not supported", Sk);
-  MMAMD_CHECK_ARG(!causal || Sq == Sk, MMAMD_E_BADARG, "attention_x_bwd: causal needs Sq == Sk");
+  MMAMD_CHECK_ARG(causal >= 0 && causal <= 3, MMAMD_E_BADARG, "attention_x_bwd: causal is a 2-bit flag (1 = causal, 2 = key mask on the last query row only)");
+  MMAMD_CHECK_ARG(!(causal & 1) || Sq == Sk, MMAMD_E_BADARG, "attention_x_bwd: causal needs Sq == Sk");
   const int D = H * head_dim;
   MMAMD_CHECK_ARG(ldq >= D && ldk >= D && ldv >= D && ldo >= D && lddq >= D && lddk >= D && lddv >= D, MMAMD_E_BADARG,
                   "attention_x_bwd: leading dimension smaller than H*head_dim");
@@ -391,7 +393,7 @@ static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
   p.q_bs = q_batch_stride; p.kv_bs = kv_batch_stride; p.fm_bs = full_mask_batch_stride;
   p.dq_bs = (long long)Sq * lddq; p.dkv_bs = (long long)Sk * lddk;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
-  p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal ? 1 : 0; p.scale = scale;
+  p.Sq = Sq; p.Sk = Sk; p.H = H; p.causal = causal & 1; p.km_last = (causal >> 1) & 1; p.scale = scale;
   p.drop.thresh = drop_p > 0.f ? (dropout_threshold(drop_p) ? dropout_threshold(drop_p) : 1u) : 0u;
   p.drop.k0 = (uint32_t)seed; p.drop.k1 = (uint32_t)(seed >> 32); p.drop.site = site; p.drop.scale = 1.0f / (1.0f - drop_p);
   MMAMD_CHECK_ARG(lddk == lddv, MMAMD_E_BADARG, "attention_x_bwd: dk and dv must share their row pitch");

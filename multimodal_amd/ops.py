@@ -359,10 +359,18 @@ class AttnMask:
     """Mask description the attention kernels take: causal flag, key-padding mask uint8 [B,Sk], full mask uint8
     [B or 1, Sq, Sk] (0 = masked everywhere)."""
 
-    __slots__ = ("causal", "key_mask", "full")
+    __slots__ = ("causal", "key_mask", "full", "key_mask_last_row")
 
-    def __init__(self, causal: bool = False, key_mask: Optional[torch.Tensor] = None, full: Optional[torch.Tensor] = None):
+    def __init__(self, causal: bool = False, key_mask: Optional[torch.Tensor] = None, full: Optional[torch.Tensor] = None,
+                 key_mask_last_row: bool = False):
         self.causal, self.key_mask, self.full = bool(causal), key_mask, full
+        # the key-padding mask binds the LAST query row only (CoCa's text decoder: causal everywhere, the CLS row also hides padded tokens)
+        self.key_mask_last_row = bool(key_mask_last_row)
+
+    @property
+    def causal_flags(self) -> int:
+        """The 2-bit `causal` argument of mmamd_attention_x_fwd / _bwd."""
+        return int(self.causal) | (2 if self.key_mask_last_row and self.key_mask is not None else 0)
 
     @property
     def empty(self) -> bool:
@@ -406,7 +414,7 @@ def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, S
         out = torch.empty((B * Sq, D), dtype=torch.bfloat16, device=q.device)
     probs = torch.empty((B, H, Sq, Sk), dtype=torch.float32, device=q.device) if want_probs else None
     args = (q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
-            Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal), out.data_ptr(), out.stride(0), _ptr(probs), F32, _ptr(lse), B, Sq, Sk, H,
+            Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, mask.causal_flags, out.data_ptr(), out.stride(0), _ptr(probs), F32, _ptr(lse), B, Sq, Sk, H,
             head_dim, 1.0 / math.sqrt(float(head_dim)))
     if head_mask is not None:
         if drop is not None and drop[0] > 0:
@@ -479,7 +487,7 @@ def attention_x_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
     dq = torch.empty((B * Sq, D), dtype=torch.bfloat16, device=q.device)
     dkv = torch.empty((B * Sk, 2 * D), dtype=torch.bfloat16, device=q.device)
     args = (q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
-            Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, int(mask.causal), out.data_ptr(), dout.data_ptr(), out.stride(0), lse.data_ptr(),
+            Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, mask.causal_flags, out.data_ptr(), dout.data_ptr(), out.stride(0), lse.data_ptr(),
             dq.data_ptr(), D, dkv.data_ptr(), dkv.data_ptr() + 2 * D, 2 * D, 2 * D, B, Sq, Sk, H, head_dim, 1.0 / math.sqrt(float(head_dim)))
     if drop is not None and drop[0] > 0:
         check(_lib.lib().mmamd_attention_x_bwd_dropout(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF, _stream()),
