@@ -19,6 +19,7 @@ from ... import ops
 from ..._packing import PackedCache
 from ...modules.layers.normalizations import Fp32LayerNorm
 from ...modules.layers.transformer import TransformerOutput
+from ...schedule import get_schedule
 from ..._autograd import wants_grad
 from ...modules.losses.flava import Pooler
 from .transformer import init_transformer_weights, TransformerEncoder
@@ -159,7 +160,7 @@ class ImageTransformer(nn.Module):
         if pixel_values is None:
             raise ValueError("You have to specify pixel_values")
         embedding_output = self.embeddings(pixel_values, image_patches_mask=image_patches_mask)
-        encoder_output = self.encoder(embedding_output, attention_mask=attention_mask, return_attn_weights=True,
+        encoder_output = self.encoder(embedding_output, attention_mask=attention_mask, return_attn_weights=get_schedule().flava_attentions,
                                       return_hidden_states=True)
         sequence_output = self.layernorm(encoder_output.last_hidden_state)
         pooled_output = self.pooler(sequence_output) if self.pooler is not None else None

@@ -234,7 +234,7 @@ class FLAVAModel(PackedModeMixin, nn.Module):
         ids = ids if ids.is_contiguous() else ids.contiguous()
         km = ops.key_mask(ids, pad_id=te.embeddings.pad_token_id) if hasattr(te.embeddings, "pad_token_id") else None
         xb = te.embeddings(input_ids=ids)
-        (ya, ha, pa), (yb, hb, pb) = run_two_encoders(ie.encoder, xa, None, te.encoder, xb, km, want_probs=True)
+        (ya, ha, pa), (yb, hb, pb) = run_two_encoders(ie.encoder, xa, None, te.encoder, xb, km, want_probs=get_schedule().flava_attentions)
         sa = ie.layernorm(ya)
         both_i = TransformerOutput(last_hidden_state=sa, pooler_output=ie.pooler(sa) if ie.pooler is not None else None, hidden_states=ha, attentions=pa)
         sb = te.layernorm(yb)
@@ -266,7 +266,7 @@ class FLAVAModel(PackedModeMixin, nn.Module):
 
     def encode_text(self, text: Tensor, text_mask: Optional[Tensor] = None, projection: bool = False
                     ) -> Union[Tuple[TransformerOutput, Tensor], Optional[TransformerOutput]]:
-        encoded_text = self.text_encoder(input_ids=text, attention_mask=text_mask, return_attn_weights=True,
+        encoded_text = self.text_encoder(input_ids=text, attention_mask=text_mask, return_attn_weights=get_schedule().flava_attentions,
                                          return_hidden_states=True)
         if projection:
             projected_embeddings = cls_linear(encoded_text.last_hidden_state, self.text_projection, self._packed)

@@ -64,8 +64,10 @@ class FLAVATransformerWithoutEmbeddings(nn.Module):
             fused[:, 0:1].copy_(cls.to(hidden_states.dtype).expand(B, -1, -1))  # differentiable w.r.t. cls_token in training
             fused[:, 1:].copy_(hidden_states)
             hidden_states = fused
+        from ...schedule import get_schedule
+
         encoder_output = self.encoder(hidden_states, attention_mask=attention_mask, return_hidden_states=True,
-                                      return_attn_weights=True)
+                                      return_attn_weights=get_schedule().flava_attentions)
         sequence_output = self.layernorm(encoder_output.last_hidden_state)
         pooled_output = self.pooler(sequence_output) if self.pooler is not None else None
         return TransformerOutput(last_hidden_state=sequence_output, pooler_output=pooled_output,

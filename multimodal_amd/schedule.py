@@ -25,6 +25,10 @@ Every choice is between paths that compute the same function; the defaults are t
     train_attentions  True | False                FLAVA training forwards also return the per-layer attention probabilities (recomputed by the
                                                   inference kernel, detached) like the reference's; False: attentions = None (saves one attention
                                                   launch per layer and the S^2 writes)
+    flava_attentions  True | False                FLAVA INFERENCE forwards return the per-layer attention probabilities like the reference's (which asks for
+                                                  them unconditionally, models/flava/image_encoder.py:217-222).  False: `attentions = None` -- an opt-out for
+                                                  callers that never read them (the pre-training losses do not): the fp32 [B, H, S, S] tensors are 4.7 GB of
+                                                  writes per forward at B = 128 and a fifth of the step
 
 Environment (read once): MMAMD_TWO_TOWER, MMAMD_RESIDUAL (epilogue | delta_ln), MMAMD_SINGLE_STREAM=1, MMAMD_PHASES (1 | 2).
 """
@@ -48,6 +52,7 @@ class Schedule:
     phase_lead: int = 4
     train_attentions: bool = True
     flava_grouped: bool = True
+    flava_attentions: bool = True
 
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:

@@ -812,3 +812,32 @@ def test_inputs_embeds_and_global_average_pooler():
     assert y.shape == (5, 32) and float((y.double().cpu() - want).abs().max()) < 1e-4
     y2 = GlobalAveragePooler(128).cuda().eval()(x)
     assert y2.shape == (5, 128)
+
+
+@torch.no_grad()
+def test_flava_attentions_opt_out():
+    """schedule.flava_attentions = False: the inference forwards skip the attention-probability outputs (attentions = None on every TransformerOutput) and
+    everything else -- hidden states, pooled rows, projected embeddings, multimodal outputs -- keeps the same values to bf16 rounding (the unmasked image tower then
+    runs the attention kernel without a probability pass)."""
+    from multimodal_amd.models.flava.model import flava_model
+    from multimodal_amd.schedule import set_schedule
+
+    torch.manual_seed(21)
+    kw = dict(image_hidden_size=128, image_num_attention_heads=2, image_num_hidden_layers=2, image_intermediate_size=256, text_hidden_size=128,
+              text_num_attention_heads=2, text_num_hidden_layers=2, text_intermediate_size=256, multimodal_hidden_size=128, multimodal_num_attention_heads=2,
+              multimodal_num_hidden_layers=2, multimodal_intermediate_size=256, text_and_image_proj_size=64, vocab_size=300, image_size=32, patch_size=16, num_channels=3)
+    m = flava_model(**kw).cuda().eval()
+    image = torch.randn(3, 3, 32, 32, device="cuda")
+    text = torch.randint(1, 300, (3, 12), device="cuda")
+    with_p = m(image=image, text=text, skip_unmasked_mm_encoder=False)
+    prev = set_schedule(flava_attentions=False)
+    try:
+        without = m(image=image, text=text, skip_unmasked_mm_encoder=False)
+    finally:
+        set_schedule(flava_attentions=prev.flava_attentions)
+    assert with_p.image.attentions is not None and len(with_p.image.attentions) == 2
+    for part in ("image", "text", "multimodal"):
+        a, b = getattr(with_p, part), getattr(without, part)
+        assert b.attentions is None or len(b.attentions) == 0
+        assert float((a.last_hidden_state - b.last_hidden_state).abs().max()) <= HID_TOL
+        assert len(a.hidden_states) == len(b.hidden_states)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--no-loss", action="store_true")
     ap.add_argument("--train", action="store_true", help="training step: forward + pre-training loss + backward + SGD")
     ap.add_argument("--grouped", action="store_true", help="schedule.flava_grouped: image and text towers layer-locked with grouped launches")
+    ap.add_argument("--no-attentions", action="store_true", help="schedule.flava_attentions = False: the forwards do not produce the attention probabilities (opt-out)")
     ap.add_argument("--codebook", action="store_true", help="MIM labels from the DALL-E codebook (112x112 images) inside the step instead of synthetic ones")
     a = ap.parse_args()
     from multimodal_amd.models.flava.model import flava_model
@@ -29,6 +30,10 @@ def main():
 
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
+    if a.no_attentions:
+        from multimodal_amd.schedule import set_schedule
+
+        set_schedule(flava_attentions=False)
     if a.grouped:
         from multimodal_amd.schedule import set_schedule
 
