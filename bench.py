@@ -462,6 +462,13 @@ def main() -> None:
             try:
                 z = json.loads(pmc.read_text())["shapes"]
                 traffic = int(sum(v["hbm_bytes_per_launch"] for v in z.values()) / len(z))
+                # the stored PMC pass also has the clock the launches ran at (GRBM_GUI_ACTIVE / 8 XCDs / duration; 2.4 GHz nominal): the part clocks down under
+                # MFMA load, so the fraction of what THAT clock allows is reported beside `frac` (which stays against the nominal peak)
+                for key, name in (("outproj", "out_projection"), ("mlpdown", "mlp_down")):
+                    clk = z.get(key, {}).get("effective_clock_ghz")
+                    if clk and name in by_shape:
+                        by_shape[name]["pmc_effective_clock_ghz"] = round(clk, 3)
+                        by_shape[name]["frac_at_that_clock"] = round(by_shape[name]["achieved"] / (MFMA_BF16_PEAK_TFLOPS * clk / 2.4), 4)
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma",
