@@ -57,3 +57,20 @@ def test_phases_fields():
         Schedule(phases=3)
     with pytest.raises(ValueError):
         Schedule(phase_lead=-1)
+
+
+def test_round4_schedule_fields_and_mask_flags():
+    """r04 additions: flava_attentions (default on = the reference's behaviour) and the 2-bit `causal` flag of the general attention kernels."""
+    import torch
+
+    from multimodal_amd import ops
+    from multimodal_amd.schedule import Schedule
+
+    s = Schedule()
+    assert s.flava_attentions is True and s.flava_grouped is True and s.phases == 1 and s.train_attentions is True
+    assert ops.AttnMask().causal_flags == 0 and ops.AttnMask(causal=True).causal_flags == 1
+    km = torch.ones(2, 5, dtype=torch.uint8)
+    assert ops.AttnMask(causal=True, key_mask=km, key_mask_last_row=True).causal_flags == 3
+    assert ops.AttnMask(causal=False, key_mask=km, key_mask_last_row=True).causal_flags == 2
+    assert ops.AttnMask(causal=True, key_mask_last_row=True).causal_flags == 1  # without a key mask the bit has nothing to bind
+    assert ops.AttnMask().empty and not ops.AttnMask(key_mask=km).empty
