@@ -120,3 +120,17 @@ def test_cpu_pinning_helper_splits_the_visible_cpus():
             assert "shared" in got8["policy"] and set(os.sched_getaffinity(0)) == set(before)
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_stored_pmc_pass_has_what_the_bench_line_reads():
+    """bench.py fills roofline.traffic and the per-shape clock fields from profiles/pmc_residual_kernel.json (separate rocprofv3 --pmc passes, tools/gpu_pmc_residual.sh):
+    the file must keep the two shapes with their HBM bytes and effective clocks, or the line silently loses those fields."""
+    import json
+    from pathlib import Path
+
+    z = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "pmc_residual_kernel.json").read_text())["shapes"]
+    assert set(z) >= {"outproj", "mlpdown"}
+    for name, v in z.items():
+        assert v["hbm_bytes_per_launch"] > v["algorithmic_bytes_per_launch"] * 0.9, name   # traffic cannot be (much) below the algorithmic bytes
+        assert 1.0 < v["effective_clock_ghz"] <= 2.45, name                                  # GRBM_GUI_ACTIVE / 8 / duration against the 2.4 GHz nominal clock
+        assert 0.0 < v["mfma_busy_frac"] < 1.0 and 0.0 < v["tcc_hit_rate"] < 1.0, name
