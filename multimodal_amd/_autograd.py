@@ -104,10 +104,14 @@ def branch_rates(mod) -> Tuple[float, float]:
     return float(getattr(mod, "p", 0.0)), -1.0
 
 
-def stack_drop_spec(layers, attn_p: Callable = None) -> Tuple[List[float], int]:
+def stack_drop_spec(layers, attn_p: Callable = None, training: bool = True) -> Tuple[List[float], int]:
     """Dropout description of a stack of pre-norm layers whose members follow the reference's naming (attention_dropout, feedforward_dropout,
     feedforward = MLP): ([], 0) when every rate is zero, else ([p_branch, p_mlp, p_attn] + per-layer stochastic-depth rates, fresh seed).
-    One p_branch / p_mlp / p_attn per stack (the reference builds all layers of a stack from one `dropout` value; transformer.py:175-200)."""
+    One p_branch / p_mlp / p_attn per stack (the reference builds all layers of a stack from one `dropout` value; transformer.py:175-200).
+    training=False (an eval-mode stack on the differentiable path because its INPUT requires grad): ([], 0) -- nn.Dropout and StochasticDepth
+    are the identity in eval mode whatever their rates."""
+    if not training:
+        return [], 0
     pb, pm, pa, path = set(), set(), set(), []
     for layer in layers:
         p1, r1 = branch_rates(layer.attention_dropout)

@@ -15,7 +15,7 @@
 namespace mmamd {
 
 template <typename TX, typename TO, int MODE>
-__global__ __launch_bounds__(256) void dropout_kernel(const TX* __restrict__ x, const float* __restrict__ res, TO* __restrict__ out,
+__global__ __launch_bounds__(256) void dropout_kernel(const TX* x, const float* __restrict__ res, TO* out,  // x and out may alias (in-place form)
                                                       uint8_t* __restrict__ mask_out, long long n4, long long group, uint32_t thresh,
                                                       float scale, uint32_t k0, uint32_t k1, uint32_t site) {
   for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n4; g += (long long)gridDim.x * 256) {

@@ -179,7 +179,7 @@ def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: boo
         eps2.append(layer.feedforward_layernorm.eps)
     # training-time dropout (reference flava/transformer.py: attention_dropout / feedforward_dropout on the branches, the MLP's hidden dropout,
     # and SelfAttention(attn_dropout) on the attention probabilities -- the general attention kernels then carry the Philox mask)
-    drop, seed = stack_drop_spec(encoder.layer, attn_p=lambda l: l.attention.attn.attn_dropout)
+    drop, seed = stack_drop_spec(encoder.layer, attn_p=lambda l: l.attention.attn.attn_dropout, training=encoder.training)
     cfg = StackConfig(len(encoder.layer), encoder.layer[0].attention.n_head, B, S, False, act, eps1, eps2, 16, _to_canonical,
                       _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden, drop=drop, seed=seed)
     cfg.keep_hidden = keep_hidden or want_probs

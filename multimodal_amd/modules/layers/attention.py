@@ -97,7 +97,7 @@ class MultiHeadAttention(nn.Module):
         hm = attn_kwargs.get("head_mask")
         if hm is not None:  # multiplicative post-softmax mask (:236-237): the general kernel, whatever the shapes
             return self._forward_general(q, kv, return_attn_weights, use_cache, causal, am, head_mask_f32(hm))
-        pad_form = am is None or (am.dim() == 4 and am.shape[1] == 1 and am.shape[2] == 1) or (am.dim() == 2 and q.dim() == 3 and tuple(am.shape) == (q.shape[0], q.shape[1]) and q.shape[0] != q.shape[1])
+        pad_form = am is None or (am.dim() == 4 and am.shape[0] == q.shape[0] and am.shape[1] == 1 and am.shape[2] == 1) or (am.dim() == 2 and q.dim() == 3 and tuple(am.shape) == (q.shape[0], q.shape[1]) and q.shape[0] != q.shape[1])
         if q.dim() == 3 and (kv is None or kv is q) and not use_cache and not self.cache and pad_form:
             # self-attention over [b, seq, c] without a cache (what FLAVA's layers do): one packed in-projection, the flash-style kernels
             # (`causal` only steers the CACHE in the reference, :159-176: masking comes from attention_mask)

@@ -206,7 +206,7 @@ def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_h
     ident = lambda t: t
     # training-time dropout / stochastic depth of the residual branches and the MLP's hidden dropout (reference :64-93); MultiHeadSelfAttention is
     # built without attention-probability dropout (:60-63)
-    drop, seed = stack_drop_spec(self.layer)
+    drop, seed = stack_drop_spec(self.layer, training=self.training)
     cfg = StackConfig(len(self.layer), self.layer[0].attention.num_heads, B, S, False, act, eps1, eps2, 12, ident, ident,
                       keep_hidden=return_hidden_states, drop=drop, seed=seed)
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
@@ -489,9 +489,9 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
         Sk = encoder_hidden_states.shape[1]
         e = encoder_hidden_states if encoder_hidden_states.is_contiguous() else encoder_hidden_states.contiguous()
         enc2d = e.view(B * Sk, e.shape[-1])
-    if len(drop_rates) > 1:
+    if self.training and len(drop_rates) > 1:
         raise ops.MmamdError(f"training: all dropout sites of a decoder stack must share one rate, got {sorted(drop_rates)}")
-    drop_p = drop_rates.pop() if drop_rates else 0.0
+    drop_p = drop_rates.pop() if (drop_rates and self.training) else 0.0  # eval mode: every nn.Dropout is the identity
     seed = draw_seed() if drop_p > 0 else 0
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
     all_hidden_states = []
