@@ -115,10 +115,12 @@ class Telemetry:
 
     def sample(self):
         s = {"t": time.perf_counter(), "label": self.label}
+        self._tick = getattr(self, "_tick", 0) + 1
         if self.smi is not None:
             m = self._call("amdsmi_get_gpu_metrics_info")
             if isinstance(m, dict):
                 s["metrics"] = {k: m[k] for k in self.METRIC_KEYS if k in m}
+        if self.smi is not None and self._tick % 8 == 1:  # the slow calls (violation status ~50 ms) on every 8th tick only
             p = self._call("amdsmi_get_power_info")
             if p is not None:
                 s["power_info"] = p
@@ -235,6 +237,34 @@ def summarise(samples, label, skip_s=1.0):
     return out
 
 
+def external(args):
+    """--cmd mode: telemetry around external commands (microbenchmarks), one summary per command."""
+    tel = Telemetry(args.hz)
+    tel.start()
+    time.sleep(1.5)
+    outs = {}
+    for spec in args.cmd:
+        label, _, cmd = spec.partition("=")
+        tel.mark(label)
+        r = subprocess.run(cmd, shell=True, capture_output=True, text=True)
+        tel.mark("gap")
+        outs[label] = {"cmd": cmd, "rc": r.returncode, "stdout": r.stdout[-2000:], "stderr": r.stderr[-500:]}
+        time.sleep(1.0)
+    tel.stop()
+    rec = {"what": "power / clock telemetry around external commands (tools/power_clocks.py --cmd)", "hz_requested": args.hz, "static": {k: v for k, v in tel.static.items() if not k.startswith("cli")},
+           "errors": tel.errors, "workloads": {}}
+    for label, o in outs.items():
+        t = summarise(tel.samples, label, 1.0)
+        if t:
+            t.pop("violation_last", None)
+        rec["workloads"][label] = {"run": o, "telemetry": t}
+        pw = (t or {}).get("socket_power_W(metrics.current_socket_power)")
+        ck = (t or {}).get("gfxclk_MHz(metrics.current_gfxclks mean over XCDs)")
+        print(f"{label:28s} {o['stdout'].strip()[-200:]}\n{'':28s} power {pw} gfxclk {ck} ppt {(t or {}).get('ppt_residency_acc_delta')} / {(t or {}).get('accumulation_counter_delta')}")
+    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(args.out).write_text(json.dumps(rec, indent=1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=5.0)
@@ -242,7 +272,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r05_power_clocks.json"))
     ap.add_argument("--raw", action="store_true", help="also keep every sample in the file")
+    ap.add_argument("--cmd", action="append", default=[], help="LABEL=COMMAND: sample while this external command runs (repeatable) instead of the built-in workloads")
     args = ap.parse_args()
+    if args.cmd:
+        return external(args)
 
     import torch
 
