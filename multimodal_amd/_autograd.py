@@ -72,8 +72,11 @@ class StackConfig:
 
     def __init__(self, n_layers: int, n_head: int, B: int, S: int, causal: bool, act: int, eps1: Sequence[float], eps2: Sequence[float],
                  params_per_layer: int, to_canonical: Callable, from_canonical: Callable, key_mask: Optional[Tensor] = None,
-                 keep_hidden: bool = False, drop: Optional[Sequence[float]] = None, seed: int = 0):
+                 keep_hidden: bool = False, drop: Optional[Sequence[float]] = None, seed: int = 0, norm_first: bool = True,
+                 full_mask: Optional[Tensor] = None):
         self.n_layers, self.n_head, self.B, self.S, self.causal, self.act = n_layers, n_head, B, S, causal, act
+        self.full_mask = full_mask  # uint8 [B or 1, S, S] (0 = masked): arbitrary attention masks go through the general attention kernels
+        self.norm_first = bool(norm_first)  # False: the reference's DEFAULT post-norm layers (modules/layers/transformer.py:56,118-132)
         # training-time dropout (stack_drop_spec): [] = none, else [p_branch, p_mlp, p_attn] + one stochastic-depth rate per layer (-1 = none)
         self.drop, self.seed = [float(v) for v in (drop or [])], int(seed)
         self.eps1, self.eps2, self.ppl = list(eps1), list(eps2), params_per_layer
@@ -171,10 +174,18 @@ def _drop_of(drop: List[float], li: int, S: int, d: int) -> Tuple[float, float, 
     return (path, drop[1], S * d) if path >= 0 else (drop[0], drop[1], 0)
 
 
+def _saved_per_layer(norm_first: bool) -> int:
+    return 8 if norm_first else 9
+
+
 def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: int, causal: bool, act: int, eps1: List[float],
-                    eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int) -> List[Tensor]:
-    """Forward of N pre-norm layers.  params: the 12 canonical fp32 tensors per layer.  Returns [x_L] + per layer
-    [h1, qkv, att, lse, x_mid, h2, u, g] + the inputs of layers 1 .. N-1 (layer 0's input is x0 itself)."""
+                    eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int, norm_first: bool = True,
+                    full_mask: Optional[Tensor] = None) -> List[Tensor]:
+    """Forward of N layers.  params: the 12 canonical fp32 tensors per layer.  Returns [x_L] + per layer
+    [h1, qkv, att, lse, x_mid, h2, u, g] (+ [ff] for post-norm layers) + the inputs of layers 1 .. N-1 (layer 0's input is x0 itself).
+    Pre-norm (reference transformer.py:96-116):  x_mid = x + attn(LN1 x);  x' = x_mid + mlp(LN2 x_mid)
+    Post-norm (:118-132, the reference's default): a = x + attn(x);  x1 = LN1 a;  ff = x1 + mlp(x1);  x' = LN2 ff
+      -- saved under the same names: h1 = bf16(x), x_mid = a, h2 = bf16(x1), and ff (the input of LN2) as a ninth tensor."""
     H = n_head
     n_layers = len(params) // 12
     saved: List[Tensor] = []
@@ -191,37 +202,38 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
         Wqkv, Wo, W1, W2 = wb[4 * li:4 * li + 4]
         if li > 0:
             inputs.append(x)
-        h1 = ops.layernorm(x, g1, be1, eps1[li], out_dtype=bf)
+        h1 = ops.layernorm(x, g1, be1, eps1[li], out_dtype=bf) if norm_first else ops.convert(x, bf)
         qkv = ops.gemm_bf16(h1, Wqkv, bqkv)
-        pa = drop[2] if drop else 0.0
-        if pa > 0:  # dropout on the attention probabilities (FLAVA's SelfAttention(dropout)): the general kernels carry the Philox mask
-            dm = x.shape[1]
-            lse = torch.empty((B, H, S), dtype=f32, device=x.device)
-            att, _ = ops.attention_x_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, S, S, H, dm // H,
-                                         ops.AttnMask(causal=causal, key_mask=key_mask), lse=lse, drop=(pa, seed, 16 * li + 3))
-        else:
-            att, lse = ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
+        att, lse = _attn_fwd_any(qkv, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
         pb, pm, grp = _drop_of(drop, li, S, x.shape[1])
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo): the projection without the residual, then ONE pass: mask, scale, add
             x_mid = ops.dropout(ops.gemm_bf16(att, Wo, bo, out_dtype=f32), pb, seed, 16 * li, residual=x, group=grp)
         else:
             x_mid = ops.gemm_bf16(att, Wo, bo, residual=x, out_dtype=f32, out=torch.empty_like(x))
-        h2 = ops.layernorm(x_mid, g2, be2, eps2[li], out_dtype=bf)
+        if norm_first:
+            res2 = x_mid
+            h2 = ops.layernorm(x_mid, g2, be2, eps2[li], out_dtype=bf)
+        else:  # post-norm: the MLP reads (and adds onto) the NORMALISED sum
+            res2 = ops.layernorm(x_mid, g1, be1, eps1[li], out_dtype=f32)
+            h2 = ops.convert(res2, bf)
         u, g = ops.gemm_bf16_dual(h2, W1, b1, act)  # pre-activation (kept for the backward) + activation
         if pm > 0:
             ops.dropout(g, pm, seed, 16 * li + 1, out=g)  # the MLP's hidden dropout, in place: the dropped g feeds W2 and its gradient
         if pb > 0:
-            x_out = ops.dropout(ops.gemm_bf16(g, W2, b2, out_dtype=f32), pb, seed, 16 * li + 2, residual=x_mid, group=grp)
+            x_out = ops.dropout(ops.gemm_bf16(g, W2, b2, out_dtype=f32), pb, seed, 16 * li + 2, residual=res2, group=grp)
         else:
-            x_out = ops.gemm_bf16(g, W2, b2, residual=x_mid, out_dtype=f32, out=torch.empty_like(x))
+            x_out = ops.gemm_bf16(g, W2, b2, residual=res2, out_dtype=f32, out=torch.empty_like(x))
         saved += [h1, qkv, att, lse, x_mid, h2, u, g]
+        if not norm_first:
+            saved.append(x_out)  # ff: the input of LN2
+            x_out = ops.layernorm(x_out, g2, be2, eps2[li], out_dtype=f32)
         x = x_out
     if n_layers == 0:
         x = x0.clone()  # a custom op (mutates_args = ()) must not return an alias of its input
     return [x] + saved + inputs + wt
 
 
-def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed):
+def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, norm_first=True, full_mask=None):
     n_layers = len(params) // 12
     M, d = x0.shape
     saved, inputs = [], []
@@ -232,6 +244,8 @@ def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask,
         saved += [x0.new_empty((M, d), dtype=bf), x0.new_empty((M, 3 * d), dtype=bf), x0.new_empty((M, d), dtype=bf),
                   x0.new_empty((B, n_head, S)), x0.new_empty((M, d)), x0.new_empty((M, d), dtype=bf), x0.new_empty((M, ff), dtype=bf),
                   x0.new_empty((M, ff), dtype=bf)]
+        if not norm_first:
+            saved.append(x0.new_empty((M, d)))
     wt = []
     for li in range(n_layers):
         for k in (0, 2, 4, 6):
@@ -245,13 +259,16 @@ _ACT_GRAD = {ops.ACT_QUICKGELU: ops.ACT_MUL_QUICKGELU_GRAD, ops.ACT_GELU_ERF: op
 
 def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: List[Tensor], n_head: int, B: int, S: int, causal: bool,
                     act: int, eps1: List[float], eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int,
-                    dhidden: List[Optional[Tensor]]) -> List[Tensor]:
+                    dhidden: List[Optional[Tensor]], norm_first: bool = True, full_mask: Optional[Tensor] = None) -> List[Tensor]:
     """Backward of _stack_fwd_impl: saved = its outputs [1:].  Returns [dX0] + the 12 canonical gradients per layer.  dhidden (empty, or one
     entry per layer 1 .. N-1): gradients that arrived through the intermediate hidden states the forward handed out (None = unused)."""
     H = n_head
     n_layers = len(params) // 12
-    inputs = [x0] + list(saved[8 * n_layers:9 * n_layers - 1])
-    wt = saved[9 * n_layers - 1:]  # bf16 transposes of (Wqkv, Wo, W1, W2) per layer, made by the forward's weight pack
+    ns = _saved_per_layer(norm_first)
+    if not norm_first:
+        return _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, full_mask)
+    inputs = [x0] + list(saved[ns * n_layers:(ns + 1) * n_layers - 1])
+    wt = saved[(ns + 1) * n_layers - 1:]  # bf16 transposes of (Wqkv, Wo, W1, W2) per layer, made by the forward's weight pack
     dX = dx_out
     grads: List[Tensor] = [dX] * (12 * n_layers)
     dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
@@ -284,16 +301,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         # x_mid = x + att Wo^T + bo
         datt = dgrad_t(dxmb, WoT, bf)
         dWo = wgrad(dxmb, att)
-        pa = drop[2] if drop else 0.0
-        if pa > 0:
-            dm = x.shape[1]
-            dq_, dkv_ = ops.attention_x_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], att, datt, lse, B, S, S, H, dm // H,
-                                            ops.AttnMask(causal=causal, key_mask=key_mask), drop=(pa, seed, 16 * li + 3))
-            dqkv = torch.empty((B * S, 3 * dm), dtype=bf, device=x.device)  # [dq | dk | dv]: placement copies of the two kernel outputs
-            dqkv[:, :dm].copy_(dq_)
-            dqkv[:, dm:].copy_(dkv_)
-        else:
-            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal, key_mask)
+        dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
         # qkv = h1 Wqkv^T + bqkv
         dh1 = dgrad_t(dqkv, WqkvT, f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
@@ -310,15 +318,86 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
     return [dX] + grads
 
 
-def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden):
+def _attn_fwd_any(qkv, B, S, H, causal, key_mask, full_mask, pa, seed, site):
+    """(att, lse) of the self-attention of a stack layer: the packed-qkv flash kernels, or the general kernels when the probabilities carry
+    dropout (FLAVA's SelfAttention(dropout): the kernel generates the Philox mask) or the caller gave an arbitrary [Sq, Sk] mask."""
+    if pa > 0 or full_mask is not None:
+        dm = qkv.shape[1] // 3
+        lse = torch.empty((B, H, S), dtype=f32, device=qkv.device)
+        att, _ = ops.attention_x_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, S, S, H, dm // H,
+                                     ops.AttnMask(causal=causal, key_mask=key_mask, full=full_mask), lse=lse,
+                                     drop=(pa, seed, site) if pa > 0 else None)
+        return att, lse
+    return ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
+
+
+def _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, pa, seed, site):
+    """dqkv of _attn_fwd_any."""
+    if pa > 0 or full_mask is not None:
+        dm = att.shape[1]
+        dq_, dkv_ = ops.attention_x_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], att, datt, lse, B, S, S, H, dm // H,
+                                        ops.AttnMask(causal=causal, key_mask=key_mask, full=full_mask),
+                                        drop=(pa, seed, site) if pa > 0 else None)
+        dqkv = torch.empty((B * S, 3 * dm), dtype=bf, device=att.device)  # [dq | dk | dv]: placement copies of the two kernel outputs
+        dqkv[:, :dm].copy_(dq_)
+        dqkv[:, dm:].copy_(dkv_)
+        return dqkv
+    return ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal, key_mask)
+
+
+def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, full_mask=None) -> List[Tensor]:
+    """Backward of the post-norm layers (reference transformer.py:118-132): y = LN2(ff), ff = x1 + mlp(x1), x1 = LN1(a), a = x + attn(x).
+    The same kernels as the pre-norm backward in another order: each LayerNorm backward now sits at the END of its block, and the two
+    residual sums are epilogues of the dgrad GEMMs (dx1 = dff + du W1, dx = da + dqkv Wqkv)."""
+    H = n_head
+    n_layers = len(params) // 12
+    wt = saved[10 * n_layers - 1:]
+    dX = dx_out
+    grads: List[Tensor] = [dX] * (12 * n_layers)
+    for li in reversed(range(n_layers)):
+        h1, qkv, att, lse, a, h2, u, g, ff = saved[9 * li:9 * li + 9]
+        Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
+        WqkvT, WoT, W1T, W2T = wt[4 * li:4 * li + 4]
+        pb, pm, grp = _drop_of(drop, li, S, a.shape[1])
+        # y = LN2(ff)
+        dff, dg2, dbe2, dffb, db2 = ops.layernorm_bwd(ff, g2, dX, eps2[li], want_bf16=True, want_colsum=True)
+        if pb > 0:  # ff = x1 + drop(delta): the branch gradient is the masked, scaled dff
+            dffb = ops.dropout(dff, pb, seed, 16 * li + 2, group=grp, out_dtype=bf)
+            db2 = ops.colsum(dffb)
+        du = dgrad_t(dffb, W2T, bf, _ACT_GRAD[act], u)
+        if pm > 0:
+            ops.dropout(du, pm, seed, 16 * li + 1, out=du)
+        dW2 = wgrad(dffb, g)
+        dx1 = dgrad_t(du, W1T, f32, ops.ACT_NONE, dff)  # dff + du W1: the residual add is the GEMM's epilogue
+        dW1, db1 = wgrad(du, h2, bias=True)
+        # x1 = LN1(a)
+        da, dg1, dbe1, dab, dbo = ops.layernorm_bwd(a, g1, dx1, eps1[li], want_bf16=True, want_colsum=True)
+        if pb > 0:
+            dab = ops.dropout(da, pb, seed, 16 * li, group=grp, out_dtype=bf)
+            dbo = ops.colsum(dab)
+        datt = dgrad_t(dab, WoT, bf)
+        dWo = wgrad(dab, att)
+        dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
+        dX = dgrad_t(dqkv, WqkvT, f32, ops.ACT_NONE, da)  # da + dqkv Wqkv
+        dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
+        if li > 0 and dhidden and dhidden[li - 1] is not None:
+            extra = dhidden[li - 1].detach()
+            dX = ops.dropout(extra if extra.is_contiguous() else extra.contiguous(), 0.0, 0, 0, residual=dX)
+        grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
+    if n_layers == 0:
+        dX = dx_out.clone()
+    return [dX] + grads
+
+
+def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, norm_first=True, full_mask=None):
     return [torch.empty_like(x0)] + [torch.empty_like(p) for p in params]
 
 
 from ._custom_op import define as _define  # noqa: E402
 
 _STACK_SCALARS = "int n_head, int B, int S, bool causal, int act, float[] eps1, float[] eps2, Tensor? key_mask, float[] drop, int seed"
-stack_fwd_op = _define("encoder_stack_fwd", f"(Tensor x0, Tensor[] params, {_STACK_SCALARS}) -> Tensor[]", _stack_fwd_impl, _stack_fwd_fake)
-stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}, Tensor?[] dhidden) -> Tensor[]",
+stack_fwd_op = _define("encoder_stack_fwd", f"(Tensor x0, Tensor[] params, {_STACK_SCALARS}, bool norm_first=True, Tensor? full_mask=None) -> Tensor[]", _stack_fwd_impl, _stack_fwd_fake)
+stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}, Tensor?[] dhidden, bool norm_first=True, Tensor? full_mask=None) -> Tensor[]",
                        _stack_bwd_impl, _stack_bwd_fake)
 
 
@@ -334,7 +413,8 @@ class EncoderStackFn(torch.autograd.Function):
         canon: List[Tensor] = []
         for li in range(cfg.n_layers):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
-        outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop, cfg.seed)
+        outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop, cfg.seed, cfg.norm_first, cfg.full_mask)
+        ns = _saved_per_layer(cfg.norm_first)
         ctx.save_for_backward(x, *outs[1:], *params)
         ctx.cfg, ctx.nparam = cfg, len(params)
         ctx.set_materialize_grads(False)
@@ -343,8 +423,8 @@ class EncoderStackFn(torch.autograd.Function):
             # attached to the graph in training like the reference's (models/flava/transformer.py:254-259); hidden_states[0] is the caller's own
             # input tensor and hidden_states[N] the result.  cfg.qkv: the packed projections of every layer, for callers that also hand out
             # attention probabilities in training (they recompute them from here, detached)
-            mids = list(outs[1 + 8 * cfg.n_layers:9 * cfg.n_layers])
-            cfg.qkv = [outs[1 + 8 * li + 1] for li in range(cfg.n_layers)]
+            mids = list(outs[1 + ns * cfg.n_layers:(ns + 1) * cfg.n_layers])
+            cfg.qkv = [outs[1 + ns * li + 1] for li in range(cfg.n_layers)]
             ctx.n_mid = len(mids)
             return (outs[0], *mids)
         ctx.n_mid = -1
@@ -365,7 +445,7 @@ class EncoderStackFn(torch.autograd.Function):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
         dhidden = list(dmid) if any(d is not None for d in dmid) else []
         outs = stack_bwd_op(dX, x0, list(saved), canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop,
-                            cfg.seed, dhidden)
+                            cfg.seed, dhidden, cfg.norm_first, cfg.full_mask)
         grads: List[Optional[Tensor]] = [None] * nparam
         for li in range(cfg.n_layers):
             grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical(list(outs[1 + 12 * li:13 + 12 * li]))
@@ -473,6 +553,20 @@ class L2NormalizeFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         return l2norm_bwd_op(x, dy.contiguous())
+
+
+def plain_layers(layers, cls) -> bool:
+    """True when every member of a layer stack is EXACTLY `cls` and carries no hooks: the stack may then read the layers' parameters
+    directly (one autograd node, grouped launches, in-place residual streams for the whole stack).  Anything else -- a layer wrapped by
+    FullyShardedDataParallel or checkpoint_wrapper (reference examples/flava/native/train.py:141-206 wraps exactly the encoder layers), a
+    layer with forward / backward hooks, a subclass with its own forward -- must be CALLED as a module, one layer at a time: FSDP gathers a
+    layer's parameters only around that layer's own forward() (outside it they are views of a freed buffer), and hooks fire on __call__."""
+    for m in layers:
+        if type(m) is not cls:
+            return False
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+            return False
+    return True
 
 
 def grad_requested(module, *inputs) -> bool:

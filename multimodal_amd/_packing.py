@@ -83,6 +83,15 @@ class _Ready:
             cur.wait_event(ev)
 
 
+def _cacheable(p: torch.Tensor) -> bool:
+    """A kernel-ready copy may be cached only for a tensor whose in-place updates bump a version counter we can see: an ordinary
+    nn.Parameter.  Under FullyShardedDataParallel a module's `weight` is (use_orig_params=False) a plain Tensor VIEW of the unit's gathered
+    flat parameter, recreated on every unshard, or (use_orig_params=True) a Parameter whose `.data` FSDP re-points at that buffer
+    (`_fsdp_flattened`): the all-gather refills the same addresses after every optimizer step without touching any version counter, so a
+    cached copy keyed on (id, data_ptr, _version) would go stale silently.  Those are converted per call (one small HIP launch each)."""
+    return isinstance(p, torch.nn.Parameter) and not getattr(p, "_fsdp_flattened", False)
+
+
 class PackedCache:
     def __init__(self) -> None:
         self._store: Dict[Tuple[int, torch.dtype], tuple] = {}
@@ -113,6 +122,8 @@ class PackedCache:
                 f"parameter lives on {t.device}: move the module to a HIP device (.to('cuda')); there is no CPU path")
         if t.dtype == dtype and t.is_contiguous():
             return t
+        if not _cacheable(p):
+            return ops.convert(t if t.is_contiguous() else t.contiguous(), dtype)
         key = (id(p), dtype)
         hit = self._store.get(key)
         if hit is not None and hit[0] == t.data_ptr() and hit[1] == p._version and hit[2] == t.device:
@@ -135,7 +146,7 @@ class PackedCache:
                     f"parameter lives on {t.device}: move the module to a HIP device (.to('cuda')); there is no CPU path")
         key = (tuple(id(p) for p in params), dtype)
         sig = tuple((t.data_ptr(), p._version) for t, p in zip(ts, params))
-        hit = self._cat.get(key)
+        hit = self._cat.get(key) if all(_cacheable(p) for p in params) else None
         if hit is not None and hit[0] == sig:
             if hit[2].event is not None:
                 hit[2].guard()
@@ -164,7 +175,7 @@ class PackedCache:
             return self.get(p, dtype)
         key = (("pad", id(p), multiple), dtype)
         sig = ((t.data_ptr(), p._version),)
-        hit = self._cat.get(key)
+        hit = self._cat.get(key) if _cacheable(p) else None
         if hit is not None and hit[0] == sig:
             if hit[2].event is not None:
                 hit[2].guard()

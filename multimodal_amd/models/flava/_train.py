@@ -152,7 +152,12 @@ def _from_canonical(g: List[Tensor]):
 
 
 def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool, want_probs: bool = False):
-    """Differentiable pass through a flava.TransformerEncoder.  Returns (x_L [B,S,d], hidden states or None, attention probabilities or None).
+    """Differentiable pass through a flava.TransformerEncoder (all its layers as ONE autograd node)."""
+    return run_layers(list(encoder.layer), encoder.training, x, key_mask, keep_hidden, want_probs)
+
+
+def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool, want_probs: bool = False):
+    """Differentiable pass through a list of flava TransformerEncoderLayers (a whole encoder, or ONE stand-alone / wrapped layer).  Returns (x_L [B,S,d], hidden states or None, attention probabilities or None).
     keep_hidden: ALL hidden states, attached to the graph (the input, the input of every further layer, the result) like the reference's
     training forward (models/flava/transformer.py:254-259).  want_probs: the per-layer attention probabilities [B,H,S,S] fp32, recomputed from
     each layer's saved projections by the inference kernel (mmamd_attention_probs_fwd) -- values as in eval mode, NOT differentiable (the
@@ -161,9 +166,10 @@ def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: boo
 
     B, S, d = x.shape
     params, eps1, eps2, act = [], [], [], None
-    for layer in encoder.layer:
-        if not layer.norm_first:
-            raise ops.MmamdError("training on the MI355X path implements pre-norm (norm_first=True) encoder layers")
+    norm_first = {bool(layer.norm_first) for layer in layers}
+    if len(norm_first) != 1:
+        raise ops.MmamdError("training: all layers of a stack must share norm_first")
+    for layer in layers:
         steps = layer.feedforward.plan()
         if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
             raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
@@ -179,9 +185,9 @@ def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: boo
         eps2.append(layer.feedforward_layernorm.eps)
     # training-time dropout (reference flava/transformer.py: attention_dropout / feedforward_dropout on the branches, the MLP's hidden dropout,
     # and SelfAttention(attn_dropout) on the attention probabilities -- the general attention kernels then carry the Philox mask)
-    drop, seed = stack_drop_spec(encoder.layer, attn_p=lambda l: l.attention.attn.attn_dropout, training=encoder.training)
-    cfg = StackConfig(len(encoder.layer), encoder.layer[0].attention.n_head, B, S, False, act, eps1, eps2, 16, _to_canonical,
-                      _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden, drop=drop, seed=seed)
+    drop, seed = stack_drop_spec(layers, attn_p=lambda l: l.attention.attn.attn_dropout, training=training)
+    cfg = StackConfig(len(layers), layers[0].attention.n_head, B, S, False, act, eps1, eps2, 16, _to_canonical,
+                      _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden, drop=drop, seed=seed, norm_first=norm_first.pop())
     cfg.keep_hidden = keep_hidden or want_probs
     xc = x if x.is_contiguous() else x.contiguous()
     res = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)

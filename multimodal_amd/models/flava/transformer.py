@@ -25,7 +25,7 @@ from ...modules.layers.attention import key_mask_from_attention_mask, MultiHeadA
 from ...modules.layers.mlp import MLP
 from ...modules.layers.normalizations import Fp32LayerNorm
 from ...modules.layers.transformer import TransformerOutput
-from ..._autograd import wants_grad
+from ..._autograd import plain_layers, wants_grad
 from ..clip._transformer import forbid_training_forward
 
 
@@ -119,7 +119,20 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None,
                 return_attn_weights: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
-        forbid_training_forward(self)
+        if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
+            # differentiable stand-alone layer (a one-layer EncoderStackFn node, models/flava/_train.py): what a layer wrapped by FSDP /
+            # checkpoint_wrapper (reference examples/flava/native/train.py:141-206) or a user's own loop over layers runs in training
+            if head_mask is not None:
+                raise ops.MmamdError("head_mask is an inference-time feature on the MI355X path (the attention backward kernels do not carry it): call .eval() / no_grad")
+            if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
+                raise ops.MmamdError("encoder layers on the MI355X path take fp32 [b, seq, c] hidden states in training")
+            from ...schedule import get_schedule
+            from ._train import run_layers
+
+            B, S, _ = hidden_states.shape
+            km = key_mask_from_attention_mask(attention_mask, B, S)
+            y, _, probs = run_layers([self], self.training, hidden_states, km, False, return_attn_weights and get_schedule().train_attentions)
+            return (y, probs[0] if probs is not None else None) if return_attn_weights else y
         shape = hidden_states.shape
         d = shape[-1]
         B = shape[0]
@@ -160,6 +173,27 @@ class TransformerEncoder(nn.Module):
         if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
             raise ops.MmamdError("TransformerEncoder on the MI355X path takes fp32 [b, seq, c] hidden states")
         B, S, d = hidden_states.shape
+        if not plain_layers(self.layer, TransformerEncoderLayer):
+            # the reference's own loop (:254-290), every layer CALLED as a module: wrapped (FSDP, checkpoint_wrapper) or hooked layers
+            all_hidden_states = [] if return_hidden_states else None
+            all_self_attentions = [] if return_attn_weights else None
+            x = hidden_states
+            for layer_module in self.layer:
+                if return_hidden_states:
+                    all_hidden_states.append(x)
+                out = layer_module(x, attention_mask=attention_mask, head_mask=head_mask, return_attn_weights=return_attn_weights)
+                if return_attn_weights:
+                    x, probs = out
+                    all_self_attentions.append(probs)
+                else:
+                    x = out
+            if return_hidden_states:
+                all_hidden_states.append(x)
+            if self.final_layer_norm is not None:
+                x = self.final_layer_norm(x)
+            if return_attn_weights and any(p is None for p in all_self_attentions):
+                all_self_attentions = None  # (schedule.train_attentions = False)
+            return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, attentions=all_self_attentions)
         if head_mask is not None and (wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad)):
             raise ops.MmamdError("head_mask is an inference-time feature on the MI355X path (the attention backward kernels do not carry it): call .eval() / no_grad")
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
@@ -197,6 +231,8 @@ def two_encoders_groupable(ea: "TransformerEncoder", eb: "TransformerEncoder") -
     blocks with the SAME activation (one grouped launch has one epilogue kind), no forward hooks on the layers."""
     if len(ea.layer) != len(eb.layer) or ea.final_layer_norm is not None or eb.final_layer_norm is not None:
         return False
+    if not plain_layers(ea.layer, TransformerEncoderLayer) or not plain_layers(eb.layer, TransformerEncoderLayer):
+        return False  # wrapped (FSDP / checkpoint) or hooked layers are called one by one
     acts = set()
     for enc in (ea, eb):
         for layer in enc.layer:

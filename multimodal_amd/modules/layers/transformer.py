@@ -13,7 +13,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import _torch_ops, ops
-from ..._autograd import wants_grad
+from ..._autograd import plain_layers, wants_grad
 from ..._packing import PackedCache
 from .mlp import MLP
 from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask
@@ -106,7 +106,10 @@ class TransformerEncoderLayer(nn.Module):
 
     @torch.jit.unused
     def _forward_host(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
-        _forbid_training(self)
+        if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
+            # differentiable stand-alone layer (a one-layer EncoderStackFn node): what a wrapped layer (FSDP, checkpoint_wrapper) or a
+            # user's own stack of layers runs in training
+            return _layers_forward_train([self], self.training, None, hidden_states, attention_mask, False).last_hidden_state
         B, S, d = hidden_states.shape
         y = self.run(_f32_rows(hidden_states, "TransformerEncoderLayer"), B, S, to_attn_mask(attention_mask, False, B, S, S))
         return y.view(B, S, d)
@@ -162,6 +165,8 @@ class TransformerEncoder(nn.Module):
     def _forward_host(self, hidden_states: Tensor, attention_mask: Optional[Tensor] = None, return_hidden_states: bool = False
                       ) -> TransformerOutput:
         B, S, d = hidden_states.shape
+        if not plain_layers(self.layer, TransformerEncoderLayer):
+            return self._forward_by_module(hidden_states, attention_mask, return_hidden_states)
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
             return self._forward_train(hidden_states, attention_mask, return_hidden_states)
         if torch.compiler.is_compiling():
@@ -181,18 +186,48 @@ class TransformerEncoder(nn.Module):
         return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states if return_hidden_states else None)
 
 
+def _encoder_forward_by_module(self, hidden_states: Tensor, attention_mask, return_hidden_states: bool) -> TransformerOutput:
+    """The reference's own loop (transformer.py:230-247): every layer CALLED as a module, so that wrappers (FSDP unshards a layer's
+    parameters around its forward; checkpoint_wrapper) and hooks see the call.  Each layer decides between its inference kernels and its
+    one-layer autograd node on its own; hidden states are the layers' outputs, attached to the graph in training."""
+    x = hidden_states
+    all_hidden_states = []
+    for layer_module in self.layer:
+        if return_hidden_states:
+            all_hidden_states.append(x)
+        x = layer_module(x, attention_mask=attention_mask)
+    if return_hidden_states:
+        all_hidden_states.append(x)
+    if self.final_layer_norm is not None:
+        x = self.final_layer_norm(x)
+    return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states if return_hidden_states else None)
+
+
+TransformerEncoder._forward_by_module = _encoder_forward_by_module
+
+
 def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_hidden_states: bool) -> TransformerOutput:
     """Differentiable TransformerEncoder.forward: the packed input_proj layout is the canonical one of EncoderStackFn."""
+    return _layers_forward_train(list(self.layer), self.training, self.final_layer_norm, hidden_states, attention_mask, return_hidden_states)
+
+
+def _layers_forward_train(layers, training: bool, final_layer_norm, hidden_states: Tensor, attention_mask,
+                          return_hidden_states: bool) -> TransformerOutput:
+    """Differentiable forward of a list of TransformerEncoderLayers (a whole TransformerEncoder, or ONE stand-alone layer) as one
+    EncoderStackFn node.  Pre-norm and post-norm (the reference's default, transformer.py:56) layers; attention_mask: None, or any mask that
+    the reference's boolean masks (to_attn_mask: [S, S], [B, S, S], [B, 1, S, S]; they go through the general attention kernels)."""
     from ..._autograd import EncoderStackFn, StackConfig, stack_drop_spec
     from .mlp import fused_activation_code  # noqa: F401
 
     B, S, d = hidden_states.shape
-    if attention_mask is not None:
-        raise ops.MmamdError("training on the MI355X path: TransformerEncoder attention masks are not implemented")
+    if hidden_states.dtype != torch.float32:
+        raise ops.MmamdError("TransformerEncoder on the MI355X path takes fp32 [bsz, seq_len, d_model] tensors")
+    mask = to_attn_mask(attention_mask, False, B, S, S)
+    norm_first = {bool(layer.norm_first) for layer in layers}
+    if len(norm_first) != 1:
+        raise ops.MmamdError("training: all layers of a stack must share norm_first")
     params, eps1, eps2, act = [], [], [], None
-    for layer in self.layer:
-        if not layer.norm_first:
-            raise ops.MmamdError("training on the MI355X path implements pre-norm layers")
+    for layer in layers:
         steps = layer.feedforward.plan()
         if len(steps) != 2 or steps[1][1] != ops.ACT_NONE or steps[0][1] not in (ops.ACT_GELU_ERF, ops.ACT_QUICKGELU):
             raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
@@ -206,9 +241,10 @@ def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_h
     ident = lambda t: t
     # training-time dropout / stochastic depth of the residual branches and the MLP's hidden dropout (reference :64-93); MultiHeadSelfAttention is
     # built without attention-probability dropout (:60-63)
-    drop, seed = stack_drop_spec(self.layer, training=self.training)
-    cfg = StackConfig(len(self.layer), self.layer[0].attention.num_heads, B, S, False, act, eps1, eps2, 12, ident, ident,
-                      keep_hidden=return_hidden_states, drop=drop, seed=seed)
+    drop, seed = stack_drop_spec(layers, training=training)
+    cfg = StackConfig(len(layers), layers[0].attention.num_heads, B, S, bool(mask.causal), act, eps1, eps2, 12, ident, ident,
+                      key_mask=mask.key_mask, keep_hidden=return_hidden_states, drop=drop, seed=seed, norm_first=norm_first.pop(),
+                      full_mask=mask.full)
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
     res = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)
     hidden = None
@@ -217,8 +253,8 @@ def _encoder_forward_train(self, hidden_states: Tensor, attention_mask, return_h
         hidden = [hidden_states] + [h.view(B, S, d) for h in res[1:]] + [x]
     else:
         x = res.view(B, S, d)
-    if self.final_layer_norm is not None:
-        x = self.final_layer_norm(x)
+    if final_layer_norm is not None:
+        x = final_layer_norm(x)
     return TransformerOutput(last_hidden_state=x, hidden_states=hidden)
 
 
@@ -332,7 +368,14 @@ class TransformerDecoderLayer(nn.Module):
     def _forward_host(self, hidden_states: Tensor, encoder_hidden_states: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                       cross_attention_mask: Optional[Tensor] = None, past_key_value: Optional[Tuple[Tensor, Tensor]] = None,
                       use_cache: bool = False) -> Tuple[Tensor, Optional[Tuple[Tensor, Tensor]]]:
-        _forbid_training(self)
+        if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
+            # differentiable stand-alone layer: a one-layer DecoderStackFn node (what a wrapped layer runs in training)
+            if past_key_value is not None or use_cache:
+                raise ops.MmamdError("key/value caching is an inference feature: call the layer under torch.no_grad() / in eval mode")
+            if cross_attention_mask is not None:
+                raise ops.MmamdError("training on the MI355X path: cross_attention_mask is not implemented")
+            out = _decoder_layers_forward_train([self], self.training, None, hidden_states, encoder_hidden_states, attention_mask, False)
+            return out.last_hidden_state, None
         B, S, d = hidden_states.shape
         enc, Sk = None, 0
         if encoder_hidden_states is not None:
@@ -411,6 +454,22 @@ class TransformerDecoder(nn.Module):
                       use_cache: bool = False, return_hidden_states: bool = False) -> TransformerOutput:
         B, S, d = hidden_states.shape
         caching = past_key_values is not None or use_cache
+        if not plain_layers(self.layer, TransformerDecoderLayer):
+            # the reference's own loop (:606-640), every layer CALLED as a module (wrapped / hooked layers)
+            x = hidden_states
+            all_hidden_states, current_key_values = [], []
+            for i, layer_module in enumerate(self.layer):
+                if return_hidden_states:
+                    all_hidden_states.append(x)
+                x, present = layer_module(x, encoder_hidden_states, attention_mask=attention_mask,
+                                          past_key_value=past_key_values[i] if past_key_values is not None else None, use_cache=use_cache)
+                if use_cache:
+                    current_key_values.append(present)
+            if return_hidden_states:
+                all_hidden_states.append(x)
+            if self.final_layer_norm is not None:
+                x = self.final_layer_norm(x)
+            return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, current_key_values=current_key_values)
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
             if caching:
                 raise ops.MmamdError("key/value caching is an inference feature: call the decoder under torch.no_grad() / in eval mode")
@@ -447,6 +506,13 @@ class TransformerDecoder(nn.Module):
 
 def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, attention_mask, return_hidden_states: bool) -> TransformerOutput:
     """Differentiable TransformerDecoder.forward (DecoderStackFn: self-attention with the mask, optional cross-attention, feed-forward)."""
+    return _decoder_layers_forward_train(list(self.layer), self.training, self.final_layer_norm, hidden_states, encoder_hidden_states,
+                                         attention_mask, return_hidden_states)
+
+
+def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, hidden_states: Tensor, encoder_hidden_states, attention_mask,
+                                  return_hidden_states: bool) -> TransformerOutput:
+    """Differentiable forward of a list of TransformerDecoderLayers (a whole TransformerDecoder, or ONE stand-alone / wrapped layer)."""
     from ..._autograd import DecoderStackConfig, DecoderStackFn, draw_seed
 
     B, S, d = hidden_states.shape
@@ -454,7 +520,7 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
     layers, params = [], []
     bounds = [0]  # params[bounds[i]:bounds[i + 1]] belong to layer i
     drop_rates = set()
-    for layer in self.layer:
+    for layer in dec_layers:
         if not layer.norm_first:
             raise ops.MmamdError("training on the MI355X path implements pre-norm decoder layers")
         # training-time dropout: the reference builds every dropout of a decoder layer from ONE value (:262-290) -- attention probabilities
@@ -489,9 +555,9 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
         Sk = encoder_hidden_states.shape[1]
         e = encoder_hidden_states if encoder_hidden_states.is_contiguous() else encoder_hidden_states.contiguous()
         enc2d = e.view(B * Sk, e.shape[-1])
-    if self.training and len(drop_rates) > 1:
+    if training and len(drop_rates) > 1:
         raise ops.MmamdError(f"training: all dropout sites of a decoder stack must share one rate, got {sorted(drop_rates)}")
-    drop_p = drop_rates.pop() if (drop_rates and self.training) else 0.0  # eval mode: every nn.Dropout is the identity
+    drop_p = drop_rates.pop() if (drop_rates and training) else 0.0  # eval mode: every nn.Dropout is the identity
     seed = draw_seed() if drop_p > 0 else 0
     xc = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
     all_hidden_states = []
@@ -508,8 +574,8 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
     else:
         cfg = DecoderStackConfig(B, S, Sk, layers, mask, drop_p=drop_p, seed=seed)
         x = DecoderStackFn.apply(xc.view(B * S, d), enc2d, cfg, *params).view(B, S, d)
-    if self.final_layer_norm is not None:
-        x = self.final_layer_norm(x)
+    if final_layer_norm is not None:
+        x = final_layer_norm(x)
     return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, current_key_values=[])
 
 
