@@ -206,6 +206,12 @@ int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int ldw, float
  * transposed copies: the kernel reads its MFMA operands from LDS with ds_read_b64_tr_b16. */
 int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
                               mmamd_stream_t stream);
+/* The same weight-gradient GEMM with the bias gradient db[M] = column sums of A (= dY) produced by the SAME pass over A (the torch autograd
+ * it replaces computes grad_bias = grad_output.sum(0) as its own reduction: torch/csrc/autograd/FunctionsManual.cpp, linear backward;
+ * reference caller: every nn.Linear of modules/layers/{attention,mlp,multi_head_attention}.py under loss.backward(),
+ * examples/flava/native/train.py:312-322).  ws: (splits + 1) * M * N + splits * M floats. */
+int mmamd_gemm_bf16_tn_splitk_colsum(const void* A, int lda, const void* W, int ldw, float* C, float* db, float* ws, int M, int N, int K,
+                                     int splits, mmamd_stream_t stream);
 
 /* Same, additionally returning the attention probabilities (normalised, [B,H,S,S], probs_dtype F32 or BF16) and honouring a
  * key-padding mask (uint8 [B,S], 0 = masked key, NULL = none).  Non-causal.  Replaces scaled_dot_product_attention of

@@ -49,6 +49,9 @@ def dgrad_t(dy: Tensor, wT: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act:
     return ops.gemm_bf16(dy, wT, None, act=act, residual=pre_act, out_dtype=out_dtype)
 
 
+_FUSED_BIAS_GRAD = True  # tools/train_bench.py --no-fused-bias flips it for the A/B
+
+
 def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
     """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens.  bias=True also returns
     db[N] = column sums of the bf16-rounded dY.  Token counts that are multiples of 128 (every full-size batch) go straight from the
@@ -56,6 +59,8 @@ def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
     if dy.shape[0] % 128 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
         dyb = dy if dy.dtype == bf else ops.convert(dy, bf)
         xb = x if x.dtype == bf else ops.convert(x, bf)
+        if bias and _FUSED_BIAS_GRAD:  # db from the wgrad GEMM's own pass over dY (no column-sum pass)
+            return ops.gemm_bf16_tn_splitk(dyb, xb, want_colsum=True)
         dW = ops.gemm_bf16_tn_splitk(dyb, xb)
         return (dW, ops.colsum(dyb)) if bias else dW
     if bias:

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "mmamd_attention_fwd_grouped": (_i, [_vp, _i, _f, _vp]),
     "mmamd_gemm_bf16_splitk": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_gemm_bf16_tn_splitk": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mmamd_gemm_bf16_tn_splitk_colsum": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_attention_probs_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_contrastive_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -81,6 +81,9 @@ struct GemmArgs {
   // BDIR kernels: W in MFMA-fragment order (mmamd_pack_w_frag): block (nb = n / 32, ks = k / 16) = 64 lanes x 16 B, lane (l31, half) holds
   // W[32 nb + l31][16 ks + 8 half .. + 7] -- the first operand of v_mfma_f32_32x32x16_bf16 as one coalesced 1 KiB buffer load, no LDS
   const bf16* Wp = nullptr;
+  // TN split-K kernel with CS (weight gradient + bias gradient in one pass): column sums of A (= dY) over this split's contraction rows,
+  // written by the column-tile-0 workgroups to cs_out[split * M + m] (NULL = none)
+  float* cs_out = nullptr;
 };
 
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway).  A plain
@@ -552,10 +555,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 // K-tile is then [64 t][256 cols], stored as 256-byte units of [4 t][32 cols] (two [4][16] blocks) in [t/4][cols/32] order — the
 // DMA lays it out through its per-lane source addresses — and every MFMA operand is two ds_read_b64_tr_b16 (4 + 4 contraction
 // indices of one column per lane; the two 16-lane groups of a half-wave read one contiguous 256-byte unit: conflict-free).
-template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0, bool CS = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m,
                                                                         unsigned long long* trace = nullptr) {
   static_assert(!TNM || (BM == 256 && BN == 256), "TN image below is laid out for 256-column operand tiles");
+  static_assert(!CS || (TNM && BM / WM / 32 == WN), "CS: wave (wm, wn) sums the A fragment mi = wn of its 128 columns");
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
@@ -700,6 +704,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
 #pragma unroll
     for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
 
+  // CS (bias gradient beside the weight gradient, r05): in TN mode an A fragment holds 8 contraction rows of ONE column of dY per lane, so
+  // db[m] = sum_t dY[t][m] is 4 v_dot2c_f32_bf16 (x . (1, 1)) per fragment and k-step.  The workgroups of column tile 0 do it, and wave
+  // (wm, wn) owns fragment mi = wn of its 128 columns: in the hand-ordered first segment of every K-tile it reads that fragment of the
+  // tile's four k-steps once more from LDS (the wave-uniform wn only moves the ADDRESS: no run-time register indexing, no coupling with the
+  // live ranges of the MFMA fragments) -- 8 transpose reads and 16 dot products per K-tile beside 32 MFMAs.  Deterministic: a fixed order per
+  // lane; the split partials are summed by splitk_reduce_kernel.
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cs;
+  [[maybe_unused]] float cs = 0.f;
+  [[maybe_unused]] bool do_cs = false;
+  [[maybe_unused]] bf16x8 csf[4];
+  if constexpr (CS) do_cs = tn == 0 && p.cs_out != nullptr;
+  auto cs_dot = [&](const bf16x8& f) __attribute__((always_inline)) {
+    const bf16x2_cs ones = {(bf16)1.0f, (bf16)1.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x2_cs v = {f[2 * j], f[2 * j + 1]};
+      cs = __builtin_amdgcn_fdot2_f32_bf16(v, ones, cs, false);
+    }
+  };
+
   auto load_frags = [&](auto bufc, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
     if constexpr ((ABL & 8) != 0) return;
     constexpr int BF = decltype(bufc)::value;
@@ -745,6 +769,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
     for (int i = 0; i < NM; ++i) {
       mma_one(xa1, wb1, i);
       if (NEXT && i < NDMA) issue_piece(BF ^ 1, kt + 1, i);  // wave-uniform scalar branch
+      if constexpr (CS && NM >= 8) {
+        if (do_cs) {  // workgroup-uniform: k-step i's copy of this wave's own A fragment is requested behind MFMA i, summed behind MFMA i + 4
+          if (i < 4) csf[i] = tr_frag(ra[BF][i] + wn * 256);
+          else if (i < 8) cs_dot(csf[i - 4]);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     // segment 2 (compiler-scheduled under the pattern below): k-steps 0..2 with the next step's reads interleaved
@@ -828,6 +858,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmA
   }
   stamp();
   mma(xa1, wb1);
+  if constexpr (CS) {
+    if (do_cs) {
+      // the two lane halves hold the sums over different contraction rows of the same column: add them, lanes 0-31 store the wave's 32 columns
+      cs += __shfl_xor(cs, 32);
+      const int col = m0 + wm * TM + wn * 32 + l31;
+      if (half == 0 && col < p.M) p.cs_out[(size_t)split * p.M + col] = cs;
+    }
+  }
 
   if constexpr ((ABL & 4) != 0) {
     float ssum = 0.f;
@@ -2147,12 +2185,19 @@ static int gemm_bf16_impl(const void* A, int lda, const void* W, int ldw, const 
 
 // column-wise sum of `splits` partial outputs (second stage of the split-K weight-gradient GEMM)
 namespace mmamd {
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, float* __restrict__ out) {
-  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, float* __restrict__ out,
+                                                            const float* __restrict__ part2, long long n2, float* __restrict__ out2) {
+  // elements [0, n): the weight-gradient partials (split stride n); [n, n + n2): the bias-gradient partials of the CS kernels (split stride n2)
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  long long stride = n;
+  if (i >= n) {
+    i -= n;
+    if (i >= n2) return;
+    part = part2; out = out2; stride = n2;
+  }
   f32x4 acc = load4(part + i);
   for (int s = 1; s < splits; ++s) {
-    const f32x4 v = load4(part + (size_t)s * n + i);
+    const f32x4 v = load4(part + (size_t)s * stride + i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] += v[j];
   }
@@ -2163,9 +2208,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // FLAT (default): 1-D grid of tiles * splits, split-major after the XCD-contiguous remap — an XCD then runs neighbouring tiles of ONE split,
 // which stream the same contraction rows at the same time and share operand panels in its L2 (the 2-D grid scattered a split's tiles over all
 // XCDs: PMC FETCH_SIZE 3x the operand bytes on the MLP-up gradient).  Measured (tools/wgrad_bench.py --sched): -3...-10 % on every shape.
-template <bool TNM, int SCH = 0, int GMV = 8, bool FLAT = true>
+template <bool TNM, int SCH = 0, int GMV = 8, bool FLAT = true, bool CSK = false>
 static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K, int splits,
-                            mmamd_stream_t stream) {
+                            mmamd_stream_t stream, float* db = nullptr) {
   const int KT = K / 64;
   int chunk = (KT + splits - 1) / splits;
   chunk += chunk & 1;  // even number of K-tiles per split (the K loop is unrolled by two); KT is even, so is the remainder
@@ -2175,8 +2220,10 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = 0; p.ldc = N; p.act = MMAMD_ACT_NONE;
   p.kt_chunk = chunk; p.c_split_stride = (long long)M * N; p.res_mode = 0;
   p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0; p.split_flat = FLAT ? 1 : 0;
+  float* db_part = CSK ? (nsplit == 1 ? db : ws + (size_t)nsplit * M * N) : nullptr;  // bias-gradient partials behind the weight-gradient ones
+  p.cs_out = db_part;
   constexpr int smem = 2 * 512 * 128;
-  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, GMV, 0, true, TNM, SCH>;
+  auto kern = gemm_bf16_nt_kernel_p<256, 256, 2, 4, true, MMAMD_ACT_NONE, GMV, 0, true, TNM, SCH, CSK>;
   static unsigned long long attr_mask = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int tiles_m = (M + 255) / 256;
@@ -2186,7 +2233,8 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   else hipLaunchKernelGGL(kern, dim3(tiles_m * p.tiles_n, nsplit), dim3(512), smem, st, p, tiles_m, nullptr);
   if (nsplit > 1) {
     const long long n = (long long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit, n, C);
+    const long long n2 = CSK ? (long long)M : 0;  // (n % 4 == 0 and M % 8 == 0: the two ranges never share a 4-element group)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((n + n2) / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit, n, C, db_part, n2, db);
   }
   return launch_status("gemm_bf16_splitk");
 }
@@ -2225,4 +2273,21 @@ extern "C" int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, 
   // (fragment-read placement variants 40-43 differ by less than the run-to-run spread of a 20-launch loop — the same kernel measured 295 and
   //  252 us depending on its position in the loop — and the training step time is unchanged by them: the MFMA-first order stays)
   return gemm_splitk_impl<true>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
+}
+
+// dW = dY^T X AND db = column sums of dY from ONE pass over dY (r05; VERDICT r04 next 2b: the colsum passes were 6 % of the training step's
+// kernel time and ran at the HBM ceiling -- only fusion removes them).  A = dY [K tokens, M], W = X [K tokens, N]; C [M, N] and db [M] fp32;
+// ws: (splits + 1) * M * N + splits * M floats.  Same kernel as mmamd_gemm_bf16_tn_splitk (bit-identical C); the workgroups of column tile 0
+// also sum their A fragments (gemm_bf16_nt_kernel_p<.., CS = true>), the split partials of both results are summed by one reduce launch.
+extern "C" int mmamd_gemm_bf16_tn_splitk_colsum(const void* A, int lda, const void* W, int ldw, float* C, float* db, float* ws, int M, int N,
+                                                int K, int splits, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(A && W && C && db && ws && M > 0 && N > 0 && K > 0 && splits >= 1, MMAMD_E_BADARG, "gemm_tn_splitk_colsum: bad argument");
+  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_colsum: contraction length K=%d must be a multiple of 128", K);
+  MMAMD_CHECK_ARG(M % 8 == 0 && N % 8 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_colsum: M=%d and N=%d must be multiples of 8", M, N);
+  MMAMD_CHECK_ARG(lda >= M && ldw >= N && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "gemm_tn_splitk_colsum: bad leading dimension");
+  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws) && aligned16(db), MMAMD_E_ALIGN,
+                  "gemm_tn_splitk_colsum: base pointers must be 16-byte aligned");
+  MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)lda * 2u < (1ull << 31) && (uint64_t)64 * (uint64_t)ldw * 2u < (1ull << 31), MMAMD_E_UNSUPPORTED,
+                  "gemm_tn_splitk_colsum: leading dimension too large for the 32-bit DMA offsets");
+  return gemm_splitk_impl<true, 0, 8, true, true>(A, lda, W, ldw, C, ws, M, N, K, splits, stream, db);
 }

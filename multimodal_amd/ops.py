@@ -277,8 +277,9 @@ def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 256)
     return out
 
 
-def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 256) -> torch.Tensor:
-    """fp32 [M,N] = y[T,M]^T @ x[T,N] (dW = dY^T X) from the row-major bf16 operands, T = tokens (T % 128 == 0)."""
+def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 256, want_colsum: bool = False):
+    """fp32 [M,N] = y[T,M]^T @ x[T,N] (dW = dY^T X) from the row-major bf16 operands, T = tokens (T % 128 == 0).  want_colsum=True: returns
+    (dW, db) with db fp32 [M] = the column sums of y (the bias gradient) from the SAME pass over y (mmamd_gemm_bf16_tn_splitk_colsum)."""
     _chk(y, "y", torch.bfloat16); _chk(x, "x", torch.bfloat16)
     T, M = y.shape
     T2, N = x.shape
@@ -287,6 +288,12 @@ def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 2
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     splits = max(1, min(T // 128, target_blocks // tiles))
     out = torch.empty((M, N), dtype=torch.float32, device=y.device)
+    if want_colsum:
+        db = torch.empty(M, dtype=torch.float32, device=y.device)
+        ws = torch.empty((splits + 1) * M * N + splits * M + 4, dtype=torch.float32, device=y.device)
+        check(_lib.lib().mmamd_gemm_bf16_tn_splitk_colsum(y.data_ptr(), M, x.data_ptr(), N, out.data_ptr(), db.data_ptr(), ws.data_ptr(), M, N, T,
+                                                          splits, _stream()), "mmamd_gemm_bf16_tn_splitk_colsum")
+        return out, db
     ws = torch.empty((splits + 1) * M * N if splits > 1 else 4, dtype=torch.float32, device=y.device)
     check(_lib.lib().mmamd_gemm_bf16_tn_splitk(y.data_ptr(), M, x.data_ptr(), N, out.data_ptr(), ws.data_ptr(), M, N, T, splits, _stream()),
           "mmamd_gemm_bf16_tn_splitk")

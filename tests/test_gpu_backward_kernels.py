@@ -539,6 +539,39 @@ def test_weight_gradient_gemm_from_row_major_operands():
         ops.gemm_bf16_tn_splitk(y[:64], x[:64])  # token count must be a multiple of 128
 
 
+def test_weight_gradient_gemm_with_fused_bias_gradient():
+    """mmamd_gemm_bf16_tn_splitk_colsum (r05): dW bit-identical to the plain TN split-K GEMM, and db = the column sums of dY summed in fp32
+    from the same bf16 values -- against float64 sums, and run-to-run bit-identical (fixed summation order: no atomics).  Shapes: every
+    split count, partial tiles in M (columns past the matrix are clamped duplicates that must not leak into db), M < 256, one split."""
+    from multimodal_amd import ops
+
+    set_rng_seed(34)
+    for (T, M, N) in ((256, 64, 64), (50432, 768, 3072), (6400, 2304, 768), (1280, 200, 520), (19712, 512, 2048), (128, 8, 8), (3840, 3072, 768),
+                      (128, 1544, 128)):
+        y = (torch.randn(T, M) * 0.1 + 0.01).to(torch.bfloat16).cuda()
+        x = torch.randn(T, N).to(torch.bfloat16).cuda()
+        dW0 = ops.gemm_bf16_tn_splitk(y, x)
+        dW, db = ops.gemm_bf16_tn_splitk(y, x, want_colsum=True)
+        assert torch.equal(dW, dW0), (T, M, N)
+        ref = y.double().sum(0)
+        scale = float(y.double().abs().sum(0).max())
+        assert float((db.double() - ref).abs().max()) <= 2e-6 * scale, (T, M, N, float((db.double() - ref).abs().max()), scale)
+        dW2, db2 = ops.gemm_bf16_tn_splitk(y, x, want_colsum=True)
+        assert torch.equal(db, db2) and torch.equal(dW, dW2), (T, M, N)
+    # the autograd helper takes it for full-size batches and agrees with the two-pass form
+    from multimodal_amd import _autograd
+
+    y = (torch.randn(1024, 384) * 0.1).to(torch.bfloat16).cuda()
+    x = torch.randn(1024, 256).to(torch.bfloat16).cuda()
+    dW, db = _autograd.wgrad(y, x, bias=True)
+    _autograd._FUSED_BIAS_GRAD = False
+    try:
+        dW_, db_ = _autograd.wgrad(y, x, bias=True)
+    finally:
+        _autograd._FUSED_BIAS_GRAD = True
+    assert torch.equal(dW, dW_) and float((db - db_).abs().max()) <= 1e-5 * float(db_.abs().max() + 1.0)
+
+
 def test_small_fp32_linear_with_relu_backward():
     """Classifier-head Linear(+ReLU) in exact fp32 (mmamd_rows_linear_f32 / mmamd_relu_bwd / strided fp32 GEMMs) vs float64 autograd."""
     from multimodal_amd._autograd import SmallLinearF32Fn

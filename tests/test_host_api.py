@@ -62,7 +62,8 @@ def test_no_cpu_fallback():
 
 def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
     """CLIP, FLAVA (encoders, pre-training heads, losses) and CoCa have a differentiable (training) forward on the HIP kernels; like
-    everything else it has no CPU path, and configurations the backward does not cover (post-norm layers, dropout) raise."""
+    everything else it has no CPU path -- post-norm layers (the reference's default; trainable since r05) included; configurations the
+    backward does not cover (post-norm DECODER layers) raise."""
     from multimodal_amd import ops
     from multimodal_amd.models.clip import CLIPViTEncoder
     from multimodal_amd.models.flava.transformer import TransformerEncoder as FlavaEncoder
@@ -74,12 +75,21 @@ def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
         vit(torch.zeros(1, 3, 32, 32))
     with pytest.raises(ops.MmamdError, match="no CPU"):
         FlavaEncoder(1, 128, 2, 256, activation=torch.nn.GELU, norm_first=True).train()(torch.zeros(1, 4, 128))
-    with pytest.raises(ops.MmamdError, match="pre-norm"):
+    with pytest.raises(ops.MmamdError, match="no CPU"):  # post-norm (norm_first=False, the reference's default)
         FlavaEncoder(1, 128, 2, 256, activation=torch.nn.GELU).train()(torch.zeros(1, 4, 128))
     with pytest.raises(ops.MmamdError, match="no CPU"):  # CoCa's layers train too
         LayersEncoder(1, 128, 2, 256, activation=torch.nn.GELU, norm_first=True).train()(torch.zeros(1, 4, 128))
-    with pytest.raises(ops.MmamdError, match="pre-norm"):
+    with pytest.raises(ops.MmamdError, match="no CPU"):
         LayersEncoder(1, 128, 2, 256, activation=torch.nn.GELU).train()(torch.zeros(1, 4, 128))
+    from multimodal_amd.modules.layers.transformer import TransformerDecoder
+
+    with pytest.raises(ops.MmamdError, match="pre-norm"):
+        TransformerDecoder(1, 128, 2, 256, activation=torch.nn.GELU, use_cross_attention=False).train()(torch.zeros(1, 4, 128))
+    # a stand-alone layer in training is a differentiable call now (it used to raise NotImplementedError): no CPU path either
+    from multimodal_amd.modules.layers.transformer import TransformerEncoderLayer
+
+    with pytest.raises(ops.MmamdError, match="no CPU"):
+        TransformerEncoderLayer(128, 2, 256, activation=torch.nn.GELU, norm_first=True).train()(torch.zeros(1, 4, 128))
     with pytest.raises(ops.MmamdError, match="no CPU"):  # the pre-training heads are differentiable too: still no CPU path
         FLAVAPretrainingLoss(hidden_size=128, text_vocab_size=64, image_vocab_size=64)(
             image_masked_sequence=torch.zeros(1, 5, 128, requires_grad=True), mim_labels=torch.zeros(1, 4, dtype=torch.long))
