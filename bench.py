@@ -67,7 +67,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-probe", action="store_true", help="do not bracket the dominant GEMM with events")
     ap.add_argument("--fp32-images", action="store_true", help="(default since r04) feed fp32 images: the stem converts them to bf16 inside the timed step")
     ap.add_argument("--bf16-images", action="store_true", help="feed an already-cast bf16 image batch (the r03 default): the cast is then outside the timed step")
-    ap.add_argument("--phases", type=int, default=0, choices=[0, 1, 2], help="override schedule.phases (0 = the library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" IS RCCL on ROCm; gloo only with --dry-run')
     ap.add_argument("--dry-run", action="store_true", help="CPU control-flow run of the multi-rank path (no towers, no measurement)")
     ap.add_argument("--graph", action="store_true",
@@ -317,10 +316,6 @@ def main() -> None:
     images_bf16 = images_d.to(torch.bfloat16)
     if args.bf16_images:
         images_d = images_bf16
-    if args.phases:
-        from multimodal_amd.schedule import set_schedule
-
-        set_schedule(phases=args.phases)
 
     def step():
         out = model(images_d, ids_d)
@@ -488,7 +483,7 @@ def main() -> None:
     from multimodal_amd.schedule import get_schedule
 
     sch = get_schedule()
-    schedule_desc = {"two_tower": sch.two_tower, "residual": sch.residual, "phases": sch.phases, "phase_lead": sch.phase_lead}
+    schedule_desc = {"two_tower": sch.two_tower, "side_stream": sch.side_stream}
 
     if rank == 0:
         line = {

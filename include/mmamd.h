@@ -54,29 +54,9 @@ const char* mmamd_last_error(void);
  * hipErrorNotReady, a device probe's hipErrorNoDevice): bindings call this immediately before an entry point. */
 int mmamd_clear_last_hip_error(void);
 
-/* Select a GEMM kernel variant at run time (0 = default).  Test/bench hook; variants are bit-compatible
- * in what they compute, they differ in tiling/pipelining only. */
-int mmamd_set_gemm_variant(int variant);
-int mmamd_get_gemm_variant(void);
-/* Start-up stagger of the persistent GEMM, in per cent of the estimated time of one tile (default 60; 0 = off): the workgroups that walk one tile
- * fewer than the others (the last round of tiles is partial) start up to that much later, spread evenly — it de-synchronises the
- * C-tile store bursts of the 256 CUs and is free as long as it stays below one tile time.  Results do not change.
- * 1000 + percent (experiment, single-problem persistent kernel only): EVERY workgroup is delayed, the 32 of an XCD spread over 0 .. percent of a tile
- * time — measured to cost as much makespan as the spread-out bursts save. */
-int mmamd_debug_set_gemm_stagger(int percent);
-/* Experiment knobs of the GEMM launchers (results never change; knob 0: tile-order group of the grouped persistent kernel -- 0 = by the stream's
- * CU budget, 4, 8;  knob 1: start-up stagger policy of the grouped kernel -- 0 = light workgroups only, 1 = every workgroup by its slack). */
-int mmamd_debug_set_gemm_knob(int knob, int value);
-/* W [N, K] bf16 row-major (leading dimension ldw) -> MFMA-fragment order for the direct-W GEMM kernels: ceil(N / 32) x (K / 16) blocks of 1 KiB,
- * block (nb, ks) = 64 lanes x 16 B, lane (l = lane & 31, h = lane >> 5) holds W[32 nb + l][16 ks + 8 h .. + 7] (rows >= N: zeros).  Wp: ceil(N / 32) * 32 * K
- * bf16.  A layout of the static operand of torch's nn.Linear inside TransformerEncoderLayer (models/clip/image_encoder.py:65-77). */
-int mmamd_pack_w_frag(const void* W, int ldw, int N, int K, void* Wp, mmamd_stream_t stream);
-/* Experiment: fragment-order copy of W used by the direct-W GEMM variants (84, 85) of the following mmamd_gemm_bf16 calls (NULL = none). */
-int mmamd_debug_set_gemm_wp(const void* Wp);
-/* Diagnostic: device buffer of 64*2*256 uint64 that GEMM variant 14 fills with s_memtime stamps (NULL = off). */
-int mmamd_debug_set_gemm_trace(void* buf);
-/* Diagnostic: attention ablation variant (timing experiments; non-zero values compute WRONG results). */
-int mmamd_debug_set_attn_variant(int v);
+/* Bench / experiment hooks (kernel-variant selectors, ablation switches, CU-mask streams, stream timers) are NOT part of this surface:
+ * include/mmamd_debug.h declares them (same library, same ABI version). */
+
 
 /* --- K2: row LayerNorm ----------------------------------------------------------------------
  * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta, statistics in fp32 (biased variance).
@@ -420,21 +400,6 @@ int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int 
 /* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(1024, rows) * n floats. */
 int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */
-/* Streams confined to a subset of the CUs (hipExtStreamCreateWithCUMask): the two towers of the dual encoder are independent until
- * the loss (reference models/clip/model.py:70-71 runs them one after the other); here each gets its own CU partition so that neither
- * tower's persistent kernels queue behind the other's.  mask: `words` 32-bit words, bit i = CU i in the runtime's CU numbering.
- * mmamd_stream_cus(stream): CUs a launch on the stream may occupy (256 for any stream not created here) -- what the persistent
- * GEMM / attention kernels size their grids with.  mmamd_debug_cu_census: blocks x {XCC_ID, HW_ID} of a spinning grid (placement probe). */
-int mmamd_stream_create_cu_mask(const uint32_t* mask, int words, mmamd_stream_t* out);
-int mmamd_stream_destroy(mmamd_stream_t stream);
-int mmamd_stream_cus(mmamd_stream_t stream);
-/* CU BUDGET of an ordinary stream (no mask): persistent kernels launched on it use `cus` workgroups (a multiple of 8; 0 or >= 256 clears it)
- * instead of one per CU of the chip.  Two streams with a budget of 128 each run their persistent GEMM / attention kernels side by side on
- * disjoint CUs, and a phase shift between the two lets one stream's HBM-bound kernels (LayerNorm, attention, residual epilogues) run while the
- * other's matrix-bound main loops leave the memory system idle: the phased half-batch schedule of the dual encoder (each half-batch of
- * reference models/clip/model.py:65-74 is independent of the other until the loss).  Host-side state, read when a launch is enqueued. */
-int mmamd_stream_set_cus(mmamd_stream_t stream, int cus);
-int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks, mmamd_stream_t stream);
 /* Training-time dropout / stochastic depth (reference: nn.Dropout at modules/layers/mlp.py:59-60, modules/layers/transformer.py:69-70,86-93;
  * torchvision StochasticDepth(mode="row") at transformer.py:64-67):  out[i] = (residual ? residual[i] : 0) + x[i] * keep(i) / (1 - p).
  * keep() is Philox4x32-10 keyed by `seed` with counter (index group, site): a pure function of (seed, site, i), so the backward calls the same
@@ -539,14 +504,6 @@ int mmamd_target_rank(const float* scores, int64_t ld, const int64_t* target, in
 int mmamd_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
                   mmamd_stream_t stream);
 
-/* --- timing helper for bench.py: HIP events on the SAME stream the kernels run on ------------
- * mmamd_timer_create returns an opaque handle (two hipEvents); start/stop record on `stream`;
- * elapsed_ms synchronises on the stop event (host-side call, not capturable). */
-void* mmamd_timer_create(void);
-void mmamd_timer_destroy(void* t);
-int mmamd_timer_start(void* t, mmamd_stream_t stream);
-int mmamd_timer_stop(void* t, mmamd_stream_t stream);
-int mmamd_timer_elapsed_ms(void* t, float* ms_host);
 
 #ifdef __cplusplus
 }

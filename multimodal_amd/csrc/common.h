@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/mmamd.h"
+#include "../../include/mmamd_debug.h"
 
 namespace mmamd {
 

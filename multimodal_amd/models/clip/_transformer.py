@@ -22,7 +22,6 @@ from torch import nn
 
 from ... import _torch_ops, ops
 from ..._packing import PackedCache
-from ...schedule import get_schedule
 
 _torch_ops.try_load()
 
@@ -147,22 +146,12 @@ def two_stacks_groupable(sa: TransformerStack, Ma: int, sb: TransformerStack, Mb
 
 def run_two_stacks(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, causal_a: bool, sb: TransformerStack, xb: torch.Tensor, Bb: int,
                    Sb: int, causal_b: bool, hn0_a: torch.Tensor = None):
-    """two_stacks_steps run to the end (one stream, no interleaving with anything else)."""
-    for _ in two_stacks_steps(sa, xa, Ba, Sa, causal_a, sb, xb, Bb, Sb, causal_b, hn0_a=hn0_a):
-        pass
-    return xa, xb
-
-
-def two_stacks_steps(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, causal_a: bool, sb: TransformerStack, xb: torch.Tensor, Bb: int,
-                     Sb: int, causal_b: bool, hn0_a: torch.Tensor = None):
-    """GENERATOR: yields after every kernel launch, so that a caller can interleave the launches of several independent batches on several
-    streams (the phased half-batch schedule, models/clip/model.py::CLIP._towers_phased); run_two_stacks simply exhausts it.
-
-    Both towers of a dual encoder, layer-locked on ONE stream: layer i of tower A and layer i of tower B are independent until the loss
+    """Both towers of a dual encoder, layer-locked on ONE stream: layer i of tower A and layer i of tower B are independent until the loss
     (reference models/clip/model.py:63-75 simply runs one encoder after the other), so each of the four projections of a layer is ONE
     grouped persistent GEMM over both towers' tiles (ops.gemm_bf16_grouped): the short tower's tiles fill the partial last round of the
-    long one's instead of competing with it from a second stream.  Same kernels' arithmetic, bit-identical results to TransformerStack.run
-    per tower.  Layers beyond the shorter stack's depth (CLIP L/14: 24 vision, 12 text) run alone.  xa / xb are updated in place."""
+    long one's instead of competing with it from a second stream; LayerNorm and attention are one grouped launch each too.  Same kernels'
+    arithmetic, bit-identical results to TransformerStack.run per tower.  Layers beyond the shorter stack's depth (CLIP L/14: 24 vision, 12
+    text) run alone.  xa / xb are updated in place (fp32 residual read-modify-write in the GEMM epilogues)."""
     for st in (sa, sb):
         if st.d_model // st.nhead != HEAD_DIM:
             raise ops.MmamdError(f"the MI355X attention kernel is built for head dim 64, got {st.d_model // st.nhead}")
@@ -180,58 +169,33 @@ def two_stacks_steps(sa: TransformerStack, xa: torch.Tensor, Ba: int, Sa: int, c
     if hn0_a is not None:  # norm1 of tower A's first layer came with its stem (fused ViT stem): only tower B's is left to do
         hna = hn0_a
     n = min(len(sa.layers), len(sb.layers))
-    delta_ln = get_schedule().residual == "delta_ln"
-    if delta_ln:
-        da, db = torch.empty((Ma, sa.d_model), dtype=bf, device=dev), torch.empty((Mb, sb.d_model), dtype=bf, device=dev)
 
-    def ln(norm_a, norm_b, delta_a=None, delta_b=None):  # both towers' LayerNorms (and, with deltas, the residual adds in front of them) in one launch
-        ops.add_layernorm_grouped([(xa, delta_a, pa(norm_a.weight, f32), pa(norm_a.bias, f32), norm_a.eps, hna),
-                                   (xb, delta_b, pb(norm_b.weight, f32), pb(norm_b.bias, f32), norm_b.eps, hnb)])
+    def ln(norm_a, norm_b):  # both towers' LayerNorms in one launch
+        ops.add_layernorm_grouped([(xa, None, pa(norm_a.weight, f32), pa(norm_a.bias, f32), norm_a.eps, hna),
+                                   (xb, None, pb(norm_b.weight, f32), pb(norm_b.bias, f32), norm_b.eps, hnb)])
 
     for li in range(n):
         la, lb = sa.layers[li], sb.layers[li]
         aa, ab = la.self_attn, lb.self_attn
         if li == 0 and hn0_a is not None:
             ops.add_layernorm_grouped([(xb, None, pb(lb.norm1.weight, f32), pb(lb.norm1.bias, f32), lb.norm1.eps, hnb)])
-            yield
-        elif li == 0 or not delta_ln:
+        else:
             ln(la.norm1, lb.norm1)
-            yield
         ops.gemm_bf16_grouped([(hna, pa(aa.in_proj_weight, bf), pa(aa.in_proj_bias, f32), None, qkva),
                                (hnb, pb(ab.in_proj_weight, bf), pb(ab.in_proj_bias, f32), None, qkvb)])
-        yield
         ops.attention_fwd_grouped([(qkva, Ba, Sa, sa.nhead, causal_a, atta), (qkvb, Bb, Sb, sb.nhead, causal_b, attb)])
-        yield
-        if delta_ln:
-            # the projections store bf16 deltas (cheap epilogue); x += delta and the next LayerNorm are ONE streaming launch for both towers
-            ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), None, da),
-                                   (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), None, db)])
-            yield
-            ln(la.norm2, lb.norm2, da, db)
-        else:
-            ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), xa, xa),
-                                   (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), xb, xb)], out_dtype=f32)
-            yield
-            ln(la.norm2, lb.norm2)
-        yield
+        ops.gemm_bf16_grouped([(atta, pa(aa.out_proj.weight, bf), pa(aa.out_proj.bias, f32), xa, xa),
+                               (attb, pb(ab.out_proj.weight, bf), pb(ab.out_proj.bias, f32), xb, xb)], out_dtype=f32)
+        ln(la.norm2, lb.norm2)
         ops.gemm_bf16_grouped([(hna, pa(la.linear1.weight, bf), pa(la.linear1.bias, f32), None, upa),
                                (hnb, pb(lb.linear1.weight, bf), pb(lb.linear1.bias, f32), None, upb)], act=ops.ACT_QUICKGELU)
-        yield
-        if delta_ln and li + 1 < n:
-            ops.gemm_bf16_grouped([(upa, pa(la.linear2.weight, bf), pa(la.linear2.bias, f32), None, da),
-                                   (upb, pb(lb.linear2.weight, bf), pb(lb.linear2.bias, f32), None, db)])
-            yield
-            ln(sa.layers[li + 1].norm1, sb.layers[li + 1].norm1, da, db)
-        else:  # (the last common layer: nothing normalises x behind it here)
-            ops.gemm_bf16_grouped([(upa, pa(la.linear2.weight, bf), pa(la.linear2.bias, f32), xa, xa),
-                                   (upb, pb(lb.linear2.weight, bf), pb(lb.linear2.bias, f32), xb, xb)], out_dtype=f32)
-        yield
+        ops.gemm_bf16_grouped([(upa, pa(la.linear2.weight, bf), pa(la.linear2.bias, f32), xa, xa),
+                               (upb, pb(lb.linear2.weight, bf), pb(lb.linear2.bias, f32), xb, xb)], out_dtype=f32)
     if len(sa.layers) > n:
         sa.run(xa, Ba, Sa, causal_a, first=n)
-        yield
     if len(sb.layers) > n:
         sb.run(xb, Bb, Sb, causal_b, first=n)
-        yield
+    return xa, xb
 
 
 def forbid_training_forward(module: nn.Module) -> None:

@@ -17,7 +17,7 @@ from . import _train
 from .image_encoder import CLIPViTEncoder
 from .text_encoder import CLIPTextEncoder
 from ...schedule import get_schedule, train_side_stream_now
-from ._transformer import run_two_stacks, two_stacks_groupable, two_stacks_steps
+from ._transformer import run_two_stacks, two_stacks_groupable
 
 
 _torch_ops.try_load()
@@ -165,8 +165,6 @@ class CLIP(PackedModeMixin, nn.Module):
                 embeddings_b.record_stream(main)
             return CLIPOutput(embeddings_a=embeddings_a, embeddings_b=embeddings_b)
         if self._grouped_towers(tower_a, features_a, features_b):
-            if self._phased(tower_a, features_a, features_b):
-                return self._towers_phased(features_a, features_b)
             embeddings_a, embeddings_b = self._towers_grouped(tower_a, features_a, features_b)
         else:
             embeddings_a, embeddings_b = self._towers_streams(tower_a, features_a, features_b)
@@ -198,80 +196,6 @@ class CLIP(PackedModeMixin, nn.Module):
         Bb, Sb = ids.shape
         run_two_stacks(va.encoder, ha, Ba, Sa, False, tb.encoder, hb, Bb, Sb, True, hn0_a=hn0)
         return va._head(ha, Ba, Sa), tb._head(hb, Bb, Sb, ids)
-
-    @torch.jit.unused
-    def _phased(self, tower_a, features_a, features_b) -> bool:
-        """schedule.phases = 2: the batch as two half-batches on two streams with a CU budget of half the chip each (_towers_phased), for the
-        image-tensor entry at batch sizes whose HALVES still make every projection pair one grouped persistent launch on 128 CUs."""
-        sch = get_schedule()
-        if sch.phases != 2 or tower_a is not self.encoder_a or get_schedule().residual != "epilogue":
-            return False
-        B = features_a.size(0)
-        if B < 2 or features_b.size(0) != B or self._side_stream(features_a) is None:
-            return False
-        va, tb = self.encoder_a, self.encoder_b
-        if va.projection.dtype != torch.float32 or tb.projection.weight.dtype != torch.float32 or va.projection.shape[1] != tb.projection.weight.shape[0]:
-            return False
-        g = va.image_size // va.patch_size
-        return two_stacks_groupable(va.encoder, (B // 2) * (g * g + 1), tb.encoder, (B // 2) * features_b.size(1), cus=ops.chip_cus() // 2)
-
-    @torch.jit.unused
-    def _towers_phased(self, features_a, features_b) -> CLIPOutput:
-        """PHASED HALF-BATCH SCHEDULE.  The samples of a batch are independent until the loss (reference models/clip/model.py:65-74), and the step
-        alternates between matrix-bound phases (GEMM main loops: HBM idle) and HBM-bound ones (LayerNorm, attention, the residual epilogues:
-        matrix pipes idle) that no single kernel overlaps.  Here the two halves of the batch run the SAME grouped layer-locked launch list
-        (_transformer.two_stacks_steps) on two streams whose persistent kernels take half the chip's CUs each (mmamd_stream_set_cus), the second
-        half a few launches behind the first: one half's HBM-bound kernels then run beside the other half's main loops, on disjoint CUs.  Same
-        kernels, same per-sample arithmetic: bit-identical to the one-stream grouped schedule (tests/test_gpu_phased.py).  Each half L2-normalises
-        its rows straight into the packed [B, 2E] output block."""
-        va, tb = self.encoder_a, self.encoder_b
-        sch = get_schedule()
-        B = features_a.size(0)
-        ids = features_b if (features_b.dtype == torch.int64 and features_b.is_contiguous()) else features_b.to(torch.int64).contiguous()
-        imgs = features_a if features_a.is_contiguous() else features_a.contiguous()
-        E = tb.projection.weight.shape[0]
-        packed = torch.empty((B, 2 * E), dtype=torch.float32, device=imgs.device)
-        main = torch.cuda.current_stream()
-        side = self._side_stream(imgs)
-        cuts = (0, (B + 1) // 2, B)
-
-        def half(r0, r1):  # generator: one `yield` per launch group, so the two halves' launches interleave on the host
-            ha, Ba, Sa, hn0 = va._stem(imgs[r0:r1], want_hn0=True)
-            yield
-            idh = ids[r0:r1]
-            hb = tb._stem(idh)
-            yield
-            yield from two_stacks_steps(va.encoder, ha, Ba, Sa, False, tb.encoder, hb, r1 - r0, idh.size(1), True, hn0_a=hn0)
-            ops.l2_normalize(va._head(ha, Ba, Sa), eps=1e-12, out=packed[r0:r1, :E])
-            ops.l2_normalize(tb._head(hb, r1 - r0, idh.size(1), idh), eps=1e-12, out=packed[r0:r1, E:])
-
-        budget = ops.chip_cus() // 2
-        gens = [half(cuts[0], cuts[1]), half(cuts[1], cuts[2])]
-        streams = [main, side]
-        side.wait_stream(main)  # inputs (and whatever produced them) are visible to the side stream
-        ops.stream_set_cus(main, budget)
-        ops.stream_set_cus(side, budget)
-        try:
-            lead = max(2, int(sch.phase_lead))  # launches of half 0 before half 1 starts (>= its stem: the packed-parameter copies are made there)
-            alive = [True, True]
-            for _ in range(lead):
-                if next(gens[0], self) is self:
-                    alive[0] = False
-                    break
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            while alive[0] or alive[1]:
-                for i in (1, 0):
-                    if alive[i]:
-                        with torch.cuda.stream(streams[i]):
-                            if next(gens[i], self) is self:
-                                alive[i] = False
-        finally:
-            ops.stream_set_cus(main, 0)
-            ops.stream_set_cus(side, 0)
-        main.wait_stream(side)
-        return CLIPOutput(embeddings_a=packed[:, :E], embeddings_b=packed[:, E:])
 
     @torch.jit.unused
     def _towers_streams(self, tower_a, features_a, features_b):

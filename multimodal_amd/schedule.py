@@ -5,18 +5,10 @@ Every choice is between paths that compute the same function; the defaults are t
 
     two_tower   "auto" | "grouped" | "streams"    CLIP pair: layer-locked grouped launches on one stream vs one stream per tower
                                                   (auto: grouped only where it measured faster, _transformer.two_stacks_groupable)
-    residual    "epilogue" | "delta_ln"           x += proj(...) inside the GEMM epilogue (fp32 read-modify-write per tile), or the GEMM
-                                                  stores a bf16 delta and ONE streaming kernel does x += delta; hn = LN(x) for both towers
-                                                  (delta_ln applies to the GROUPED two-tower schedule only: TransformerStack.run and the
-                                                  two-stream path always use the epilogue form)
     side_stream  True | False                     tower-agnostic path: second tower on a side stream (False = one stream)
     flava_batched_passes  True | False            FLAVA inference: the unmasked and the masked pass of a tower as ONE pass over a 2B batch
     train_side_stream  True | False               CLIP training step: the text tower's forward (and, through autograd, backward) on a side stream
                                                   (same kernels, bit-identical step; -1.3 ... -4 ms of 54 depending on the box)
-
-    phases      1 | 2                              CLIP pair, grouped schedule: the batch as ONE launch list on the whole chip, or as two half-batches
-                                                  on two streams with half the chip's CUs each, the second `phase_lead` launches behind the first, so
-                                                  that one half's HBM-bound kernels run beside the other's matrix-bound ones
 
     flava_grouped  True | False                   FLAVA inference with both towers wanted: the image and the text encoder layer-locked on one
                                                   stream with grouped LayerNorm / GEMM launches (models/flava/transformer.py::run_two_encoders)
@@ -30,7 +22,11 @@ Every choice is between paths that compute the same function; the defaults are t
                                                   callers that never read them (the pre-training losses do not): the fp32 [B, H, S, S] tensors are 4.7 GB of
                                                   writes per forward at B = 128 and a fifth of the step
 
-Environment (read once): MMAMD_TWO_TOWER, MMAMD_RESIDUAL (epilogue | delta_ln), MMAMD_SINGLE_STREAM=1, MMAMD_PHASES (1 | 2).
+Environment (read once): MMAMD_TWO_TOWER, MMAMD_SINGLE_STREAM=1.
+
+Retired in r05 (measured losers of r03 / r04; the measurements stay under profiles/, the code in the history before this round):
+`residual = "delta_ln"` (bf16 delta GEMMs + one fused residual-add + LayerNorm launch: profiles/r03_delta_ln_ab.txt), `phases = 2` (two
+half-batches on two streams with half the chip's CUs each: profiles/r04_phased_schedule_ab.txt) and the per-stream CU budget under it.
 """
 from __future__ import annotations
 
@@ -38,18 +34,14 @@ import os
 from dataclasses import dataclass, replace
 
 _TWO_TOWER = ("auto", "grouped", "streams")
-_RESIDUAL = ("epilogue", "delta_ln")
 
 
 @dataclass(frozen=True)
 class Schedule:
     two_tower: str = "auto"
-    residual: str = "epilogue"
     side_stream: bool = True
     flava_batched_passes: bool = True
     train_side_stream: bool = True
-    phases: int = 1
-    phase_lead: int = 4
     train_attentions: bool = True
     flava_grouped: bool = True
     flava_attentions: bool = True
@@ -57,17 +49,10 @@ class Schedule:
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:
             raise ValueError(f"two_tower must be one of {_TWO_TOWER}, got {self.two_tower!r}")
-        if self.residual not in _RESIDUAL:
-            raise ValueError(f"residual must be one of {_RESIDUAL}, got {self.residual!r}")
-        if self.phases not in (1, 2):
-            raise ValueError(f"phases must be 1 or 2, got {self.phases!r}")
-        if self.phase_lead < 0:
-            raise ValueError(f"phase_lead must be >= 0, got {self.phase_lead!r}")
 
 
 def _from_env() -> Schedule:
-    """The environment is advisory: an unknown value warns and falls back to the default instead of failing `import multimodal_amd`
-    (MMAMD_RESIDUAL=fp32 / bf16 were round-2 spellings: fp32 is today's "epilogue", the bf16 residual stream is gone)."""
+    """The environment is advisory: an unknown value warns and falls back to the default instead of failing `import multimodal_amd`."""
     import warnings
 
     def pick(var, allowed, default, legacy=()):
@@ -80,9 +65,7 @@ def _from_env() -> Schedule:
             return default
         return v
 
-    phases = pick("MMAMD_PHASES", ("1", "2"), "1")
-    return Schedule(two_tower=pick("MMAMD_TWO_TOWER", _TWO_TOWER, "auto"), residual=pick("MMAMD_RESIDUAL", _RESIDUAL, "epilogue", legacy=(("fp32", "epilogue"),)),
-                    side_stream=os.environ.get("MMAMD_SINGLE_STREAM") != "1", phases=int(phases))
+    return Schedule(two_tower=pick("MMAMD_TWO_TOWER", _TWO_TOWER, "auto"), side_stream=os.environ.get("MMAMD_SINGLE_STREAM") != "1")
 
 
 _current = _from_env()

@@ -77,10 +77,16 @@ def main():
     from torch.distributed.fsdp.wrap import transformer_auto_wrap_policy
 
     use_orig = os.environ.get("FSDP_PROBE_USE_ORIG_PARAMS", "0") == "1"
-    wrapped = FSDP(copy.deepcopy(plain), device_id=dev, limit_all_gathers=True, use_orig_params=use_orig,
+    to_wrap = copy.deepcopy(plain)
+    # torch >= 2.1 FSDP refuses 0-dim parameters ("FSDP doesn't support scalar parameters"); the contrastive loss's logit_scale is one in the
+    # reference too (modules/losses/flava.py:262, contrastive_loss_with_temperature.py:160): it stays an ordinary replicated parameter
+    scalars = [p for p in to_wrap.parameters() if p.dim() == 0]
+    res_scalars = len(scalars)
+    wrapped = FSDP(to_wrap, device_id=dev, limit_all_gathers=True, use_orig_params=use_orig, ignored_states=scalars,
                    auto_wrap_policy=functools.partial(transformer_auto_wrap_policy, transformer_layer_cls={
                        TransformerEncoderLayer, ImageTransformer, BERTTextEncoder, FLAVATransformerWithoutEmbeddings}))
-    res = {"rank": rank, "world": world, "backend": backend, "use_orig_params": use_orig, "sharding": str(wrapped.sharding_strategy)}
+    res = {"rank": rank, "world": world, "backend": backend, "use_orig_params": use_orig, "sharding": str(wrapped.sharding_strategy),
+           "ignored_scalar_params": res_scalars}
     inner = wrapped.module
     enc_layers = inner.model.image_encoder.encoder.layer
     res["layers_are_fsdp"] = all(isinstance(m, FSDP) for m in enc_layers) and isinstance(inner.model.image_encoder, FSDP) and isinstance(

@@ -19,14 +19,19 @@ def built_lib():
 
 
 def test_capi_exports_every_declared_symbol(built_lib):
-    """libmmamd.so loads and exports every prototype of include/mmamd.h; the ctypes table lists them all."""
+    """libmmamd.so loads and exports every prototype of include/mmamd.h (the drop-in surface) and include/mmamd_debug.h (bench / experiment
+    hooks, split off in r05); the ctypes table lists them all, and no debug hook hides in the product header."""
     import ctypes
 
     from multimodal_amd import _lib
 
     header = (ROOT / "include" / "mmamd.h").read_text()
-    declared = set(re.findall(r"\b(mmamd_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no prototypes parsed"
+    debug = (ROOT / "include" / "mmamd_debug.h").read_text()
+    product = set(re.findall(r"\b(mmamd_[a-z0-9_]+)\s*\(", header))
+    hooks = set(re.findall(r"\b(mmamd_[a-z0-9_]+)\s*\(", debug))
+    assert product and hooks and not (product & hooks)
+    assert not any(n.startswith("mmamd_debug_") or n.startswith("mmamd_timer_") or n in ("mmamd_set_gemm_variant", "mmamd_stream_set_cus") for n in product)
+    declared = product | hooks
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     handle = ctypes.CDLL(str(built_lib))
     for name in declared:

@@ -14,11 +14,9 @@ def test_defaults_and_validation():
     from multimodal_amd.schedule import Schedule, get_schedule, set_schedule
 
     s = Schedule()
-    assert (s.two_tower, s.residual, s.side_stream, s.flava_batched_passes, s.train_side_stream) == ("auto", "epilogue", True, True, True)
+    assert (s.two_tower, s.side_stream, s.flava_batched_passes, s.train_side_stream) == ("auto", True, True, True)
     with pytest.raises(ValueError):
         Schedule(two_tower="both")
-    with pytest.raises(ValueError):
-        Schedule(residual="bf16")
     with pytest.raises(Exception):
         s.two_tower = "streams"  # frozen
     prev = set_schedule(two_tower="streams", train_side_stream=False)
@@ -26,7 +24,7 @@ def test_defaults_and_validation():
         assert get_schedule().two_tower == "streams" and get_schedule().train_side_stream is False
         assert prev.two_tower in ("auto", "grouped", "streams")
         with pytest.raises(ValueError):
-            set_schedule(residual="nope")
+            set_schedule(two_tower="nope")
         assert get_schedule().two_tower == "streams"  # a rejected change leaves the record as it was
     finally:
         set_schedule(two_tower=prev.two_tower, train_side_stream=prev.train_side_stream)
@@ -34,29 +32,26 @@ def test_defaults_and_validation():
 
 
 def test_environment_is_read_once_at_import():
-    code = "from multimodal_amd.schedule import get_schedule as g; s = g(); print(s.two_tower, s.residual, s.side_stream)"
-    env = dict(os.environ, MMAMD_TWO_TOWER="grouped", MMAMD_RESIDUAL="delta_ln", MMAMD_SINGLE_STREAM="1", PYTHONPATH=str(ROOT))
+    code = "from multimodal_amd.schedule import get_schedule as g; s = g(); print(s.two_tower, s.side_stream)"
+    env = dict(os.environ, MMAMD_TWO_TOWER="grouped", MMAMD_SINGLE_STREAM="1", PYTHONPATH=str(ROOT))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split() == ["grouped", "delta_ln", "False"]
-    # the environment is advisory: an unknown value warns and falls back to the default, a round-2 spelling is mapped -- the import never fails
-    bad = subprocess.run([sys.executable, "-c", code], env=dict(env, MMAMD_TWO_TOWER="sideways", MMAMD_RESIDUAL="fp32"), capture_output=True, text=True, timeout=120)
+    assert out.stdout.split() == ["grouped", "False"]
+    # the environment is advisory: an unknown value warns and falls back to the default -- the import never fails; the knobs retired in
+    # r05 (MMAMD_RESIDUAL, MMAMD_PHASES) are simply not read any more
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(env, MMAMD_TWO_TOWER="sideways", MMAMD_RESIDUAL="delta_ln", MMAMD_PHASES="2"),
+                         capture_output=True, text=True, timeout=120)
     assert bad.returncode == 0, bad.stderr[-2000:]
-    assert bad.stdout.split() == ["auto", "epilogue", "False"] and "MMAMD_TWO_TOWER" in bad.stderr
-    ph = subprocess.run([sys.executable, "-c", "from multimodal_amd.schedule import get_schedule as g; print(g().phases, g().phase_lead)"],
-                        env=dict(env, MMAMD_PHASES="2"), capture_output=True, text=True, timeout=120)
-    assert ph.returncode == 0 and ph.stdout.split() == ["2", "4"], ph.stderr[-2000:]
+    assert bad.stdout.split() == ["auto", "False"] and "MMAMD_TWO_TOWER" in bad.stderr
 
 
-def test_phases_fields():
+def test_retired_schedule_fields_are_gone():
+    """r05 hygiene: the measured losers `residual = "delta_ln"`, `phases = 2` / `phase_lead` are no longer part of the record."""
     from multimodal_amd.schedule import Schedule
 
-    assert Schedule().phases == 1
-    assert Schedule(phases=2, phase_lead=6).phase_lead == 6
-    with pytest.raises(ValueError):
-        Schedule(phases=3)
-    with pytest.raises(ValueError):
-        Schedule(phase_lead=-1)
+    for kw in ({"phases": 2}, {"phase_lead": 4}, {"residual": "delta_ln"}):
+        with pytest.raises(TypeError):
+            Schedule(**kw)
 
 
 def test_round4_schedule_fields_and_mask_flags():
@@ -67,7 +62,7 @@ def test_round4_schedule_fields_and_mask_flags():
     from multimodal_amd.schedule import Schedule
 
     s = Schedule()
-    assert s.flava_attentions is True and s.flava_grouped is True and s.phases == 1 and s.train_attentions is True
+    assert s.flava_attentions is True and s.flava_grouped is True and s.train_attentions is True
     assert ops.AttnMask().causal_flags == 0 and ops.AttnMask(causal=True).causal_flags == 1
     km = torch.ones(2, 5, dtype=torch.uint8)
     assert ops.AttnMask(causal=True, key_mask=km, key_mask_last_row=True).causal_flags == 3

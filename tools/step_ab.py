@@ -3,8 +3,8 @@ alternating arms (guide rules 13 / 24).  Each arm is timed three ways: eager wit
 ENQUEUE a step (is the Python thread the limit?), and a HIP-graph replay of the same step (no host in the loop).
 
     python tools/step_ab.py --arms ring,r02attn [--rounds 3] [--steps 20]
-arms (joined with +): base, r02attn (register-staged attention kernel), delta_ln (bf16 delta GEMMs + fused add+LayerNorm), streams,
-ln_cached (LayerNorm input loads never non-temporal), stagger<percent>, phases2 (two half-batches on two streams with half the chip's CUs each),
+arms (joined with +): base, r02attn (register-staged attention kernel), streams,
+ln_cached (LayerNorm input loads never non-temporal), stagger<percent> (the delta_ln and phases2 arms of r03 / r04 were retired in r05),
 lead<n> (launches of half 0 before half 1 starts), slack<percent> (slack-aware start-up stagger of the grouped GEMM), gm<4|8> (its tile-order group)"""
 import argparse
 import json
@@ -49,22 +49,16 @@ def main():
         L.mmamd_debug_set_gemm_stagger(60)
         L.mmamd_debug_set_gemm_knob(0, 0)
         L.mmamd_debug_set_gemm_knob(1, 0)
-        set_schedule(residual="epilogue", two_tower="auto", phases=1, phase_lead=4)
+        set_schedule(two_tower="auto")
         for part in name.split("+"):
             if part in ("ring", "base"):
                 pass
             elif part == "r02attn":
                 L.mmamd_debug_set_attn_variant(1000)
-            elif part == "delta_ln":
-                set_schedule(residual="delta_ln")
             elif part == "streams":
                 set_schedule(two_tower="streams")
             elif part.startswith("stagger"):  # start-up stagger of the persistent GEMMs, per cent of a tile time (default 60)
                 L.mmamd_debug_set_gemm_stagger(int(part[7:]))
-            elif part == "phases2":
-                set_schedule(phases=2)
-            elif part.startswith("lead"):
-                set_schedule(phase_lead=int(part[4:]))
             elif part.startswith("slack"):
                 L.mmamd_debug_set_gemm_knob(1, int(part[5:]))
             elif part.startswith("gm"):
