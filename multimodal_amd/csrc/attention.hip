@@ -56,7 +56,8 @@ __device__ __forceinline__ int tr_off(int lane, int stride) {
 // 8 = phase timers (results right; `lse` receives 8 floats of s_memtime cycles per wave instead of the log-sum-exp)
 template <int NKT, bool CAUSAL, int ABL = 0, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                            int S, int H, int BH, float scale_log2e, float* __restrict__ lse) {
+                                                            int S, int H, int BH, float scale_log2e, float* __restrict__ lse,
+                                                            int lse_stride) {
   constexpr int SP = NKT * 32;   // padded key count
   constexpr int VS = SP + 4;     // V^T row stride (elements): (SP+4)/2 dwords = 2 (mod 4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
       const uint64_t tb = now();
       tacc[2] += tb - ta;
       // training: log2-domain log-sum-exp for the backward kernels (m is the running REFERENCE, not necessarily the max: m + log2(sum) is exact either way)
-      if (!TIMED && lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __builtin_amdgcn_logf(lsum);
+      if (!TIMED && lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * lse_stride + q] = m + __builtin_amdgcn_logf(lsum);
       if (q < S) {
         bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
 #pragma unroll
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(256) void attention_probs_kernel(const bf16* __rest
 }
 
 static int g_attn_probs_serial = 0;  // mmamd_debug_set_attn_variant(512): the serial key loops (A/B of the pipelined form; same results)
+static int g_attn_probs_twopass = 0;  // mmamd_debug_set_attn_variant(514): unmasked fp32 probabilities from the two-pass kernel too (515: back to flash + one pass)
 
 template <int NKT, typename TP, bool PIPE = true>
 static int launch_attn_probs(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int B, int S, int H, float scale,
@@ -1847,7 +1849,7 @@ static int g_attn_variant = 0;
 static int g_attn_bwd_variant = 0;  // mmamd_debug_set_attn_variant(4000 two kernels | 4001 single pass | 4002 fused two-role | 4003 default): backward form only
 
 template <int NKT, bool CAUSAL, int ABL = 0>
-static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st, float* lse = nullptr) {
+static int launch_attn(const void* qkv, void* out, int B, int S, int H, float scale, hipStream_t st, float* lse = nullptr, int lse_stride = 0) {
   constexpr int SP = NKT * 32;
   constexpr int smem = SP * kKStride * 2 + ((NKT <= 8 && (ABL & 1) == 0) ? SP * kKStride * 2 : 64 * (SP + 4) * 2);
   constexpr int NW = 4;  // 8 waves per workgroup needs <= 128 VGPRs to be resident twice per CU: the kernel uses ~170
@@ -1858,7 +1860,7 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
   const int slots = 2 * stream_cus(st);
   const int grid = BH < slots ? BH : slots;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,
-                     scale * 1.4426950408889634f, lse);
+                     scale * 1.4426950408889634f, lse, lse_stride > 0 ? lse_stride : S);
   return launch_status("attention_fwd");
 }
 
@@ -1873,12 +1875,19 @@ extern int g_attn_ring_abl;
 extern int g_attn_ring_depth_cap;
 int g_ln_nt_policy = 0;  // mmamd_debug_set_attn_variant(3100 + p): LayerNorm x loads 0 = by size (default), 1 = never non-temporal, 2 = always (A/B)
 int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse, const int* B, const int* S, const int* H, const int* causal,
-                     const float* scale, int nprob, hipStream_t st);
+                     const float* scale, int nprob, hipStream_t st, const int* lse_stride = nullptr);
+// attention_probs_lse.hip: normalised probabilities from q, k and the saved log-sum-exp, stored as whole 256-byte segments
+bool attn_probs_lse_supports(int S);
+int launch_attn_probs_lse(const void* qkv, float* probs, int B, int S, int H, float scale, hipStream_t st);
 }  // namespace mmamd
 
 extern "C" int mmamd_debug_set_attn_variant(int v) {
   if (v == 512 || v == 513) {  // attention_probs_fwd: 512 = serial key loops, 513 = back to the pipelined default
     g_attn_probs_serial = v == 512;
+    return 0;
+  }
+  if (v == 514 || v == 515) {  // attention_probs_fwd without a key mask: 514 = the two-pass kernel, 515 = back to flash forward + probabilities pass
+    g_attn_probs_twopass = v == 514;
     return 0;
   }
   if (v >= 2000 && v < 3000) {  // ring kernel ablations (timing only): 2000 + {1: no DMA, 2: no key loops, 4: no Q loads, 8: no O stores}
@@ -1901,7 +1910,8 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
   return 0;
 }
 
-static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream);
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream,
+                              int lse_stride = 0);
 
 
 extern "C" int mmamd_attention_fwd(const void* qkv, void* out, int B, int S, int H, int causal, float scale,
@@ -1915,7 +1925,9 @@ extern "C" int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, i
   return attention_fwd_impl(qkv, out, lse, B, S, H, causal, scale, stream);
 }
 
-static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream) {
+// lse_stride: floats between the log-sum-exp rows of consecutive (batch, head) items (0 = S: the dense [B, H, S] layout)
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream,
+                              int lse_stride) {
   MMAMD_CHECK_ARG(qkv && out && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention: bad argument");
   MMAMD_CHECK_ARG(S <= 288 || lse == nullptr, MMAMD_E_UNSUPPORTED, "attention: S=%d > 288 has no training forward (the streaming kernel does not save the log-sum-exp)", S);
   MMAMD_CHECK_ARG(aligned16(qkv) && aligned16(out), MMAMD_E_ALIGN, "attention: pointers must be 16-byte aligned");
@@ -1925,7 +1937,7 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
   const int nkt = (S + 31) / 32;
   // default for S <= 224: the LDS-DMA ring kernel (attention_ring.hip); mmamd_debug_set_attn_variant(1000) keeps the r02 register-staged kernel (A/B)
   if (g_attn_variant == 0 && attn_ring_supports(S))
-    return launch_attn_ring(&qkv, &out, &lse, &B, &S, &H, &causal, &scale, 1, st);
+    return launch_attn_ring(&qkv, &out, &lse, &B, &S, &H, &causal, &scale, 1, st, lse_stride > 0 ? &lse_stride : nullptr);
   if (g_attn_variant != 0 && g_attn_variant != 1000 && nkt == 7 && !causal) {  // ablations, vision shape only
     switch (g_attn_variant) {
       case 1: return launch_attn<7, false, 1>(qkv, out, B, S, H, scale, st);
@@ -1941,8 +1953,8 @@ static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int
   }
 #define ATTN_CASE(N)                                                              \
   case N:                                                                         \
-    return causal ? launch_attn<N, true>(qkv, out, B, S, H, scale, st, lse)       \
-                  : launch_attn<N, false>(qkv, out, B, S, H, scale, st, lse);
+    return causal ? launch_attn<N, true>(qkv, out, B, S, H, scale, st, lse, lse_stride)       \
+                  : launch_attn<N, false>(qkv, out, B, S, H, scale, st, lse, lse_stride);
   switch (nkt) {
     ATTN_CASE(1) ATTN_CASE(2) ATTN_CASE(3) ATTN_CASE(4) ATTN_CASE(5) ATTN_CASE(6) ATTN_CASE(7) ATTN_CASE(8) ATTN_CASE(9)
   }
@@ -1975,6 +1987,14 @@ extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mas
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (S > 288) return launch_attn_long(qkv, key_mask, out, probs, probs_dtype, B, S, H, 0, scale, st);
+  // No key-padding mask and fp32 (or no) probabilities: the flash forward, which parks each head's log-sum-exp in the first S floats of the head's
+  // own [S, S] block, then ONE pass that turns q.k into normalised probabilities and streams them out as whole cache lines
+  // (attention_probs_lse.hip).  mmamd_debug_set_attn_variant(514) keeps the two-pass kernel below (A/B).
+  if (key_mask == nullptr && g_attn_probs_twopass == 0 && g_attn_variant == 0 && (probs == nullptr || probs_dtype == MMAMD_F32) &&
+      attn_probs_lse_supports(S)) {
+    if (int rc = attention_fwd_impl(qkv, out, (float*)probs, B, S, H, 0, scale, stream, S * S)) return rc;
+    return probs != nullptr ? launch_attn_probs_lse(qkv, (float*)probs, B, S, H, scale, st) : 0;
+  }
   const int nkt = (S + 31) / 32;
 #define ATTNP_CASE(N)                                                                                              \
   case N:                                                                                                          \

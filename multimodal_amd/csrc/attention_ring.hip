@@ -58,7 +58,8 @@ struct AttnRingProb {
   int slot_bytes;   // one item: (2 * rows8 + 32 * nqt) * 128
   int entry_bytes;  // G * slot_bytes
   float scale_log2e;
-  int pad_;
+  int lse_stride;   // floats between the log-sum-exp rows of consecutive (batch, head) items: S, or S * S when the rows are parked in the
+                    // item's own block of a [B, H, S, S] probability tensor (mmamd_attention_probs_fwd)
 };
 struct AttnRingArgs {
   AttnRingProb p[2];
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
     const int nqt = args.p[pi].nqt, rows8 = args.p[pi].rows8, G = args.p[pi].G, nring = args.p[pi].nring;
     const int slot_bytes = args.p[pi].slot_bytes, entry_bytes = args.p[pi].entry_bytes;
     const float scale_log2e = args.p[pi].scale_log2e;
+    const int lse_stride = args.p[pi].lse_stride;
     const int D = H * 64;
     const int rsb = 3 * D * 2;  // bytes between consecutive tokens of qkv
     const int Nloc = (int)blockIdx.x < BH ? (BH - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;  // items of this workgroup
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
           const float inv = 1.0f / lsum;
           const int item = (int)blockIdx.x + n * (int)gridDim.x;
           const int b = item / H, h = item - b * H;
-          if (!TIMED && lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * S + q] = m + __builtin_amdgcn_logf(lsum);
+          if (!TIMED && lse != nullptr && half == 0 && q < S) lse[(size_t)item * lse_stride + q] = m + __builtin_amdgcn_logf(lsum);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -565,7 +567,8 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
 // host side ----------------------------------------------------------------------------------------------------------------
 int g_attn_ring_abl = 0;
 int g_attn_ring_depth_cap = 0;  // mmamd_debug_set_attn_variant(3000 + n): at most n ring entries (0 = as many as fit)
-static bool ring_prob_setup(AttnRingProb& p, const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, int& smem) {
+static bool ring_prob_setup(AttnRingProb& p, const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, int& smem,
+                            int lse_stride) {
   const int nqt = (S + 31) / 32;
   if (nqt > 7 || S < 1) return false;
   const int rows8 = (S + 7) & ~7;
@@ -584,7 +587,7 @@ static bool ring_prob_setup(AttnRingProb& p, const void* qkv, void* out, float* 
   if (nring < 2) return false;
   p.nring = nring;
   p.scale_log2e = scale * 1.4426950408889634f;
-  p.pad_ = 0;
+  p.lse_stride = lse_stride > 0 ? lse_stride : S;
   int need = nring * p.entry_bytes;
 #ifdef MMAMD_EXPERIMENTS
   if (g_attn_ring_abl == 400 || g_attn_ring_abl == 401) need += 4096;  // the V over-read of the last entry
@@ -611,13 +614,14 @@ static int launch_ring_t(const AttnRingArgs& a, int grid, int smem, hipStream_t 
 }
 
 int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse, const int* B, const int* S, const int* H, const int* causal,
-                     const float* scale, int nprob, hipStream_t st) {
+                     const float* scale, int nprob, hipStream_t st, const int* lse_stride) {
   AttnRingArgs a;
   a.nprob = 0;
   int smem = 0, maxbh = 0;
   for (int i = 0; i < nprob; ++i) {
     if (B[i] == 0) continue;
-    if (!ring_prob_setup(a.p[a.nprob], qkv[i], out[i], lse ? lse[i] : nullptr, B[i], S[i], H[i], causal[i], scale[i], smem)) {
+    if (!ring_prob_setup(a.p[a.nprob], qkv[i], out[i], lse ? lse[i] : nullptr, B[i], S[i], H[i], causal[i], scale[i], smem,
+                         lse_stride ? lse_stride[i] : 0)) {
       set_error("attention_ring: S=%d is not served by the ring kernel", S[i]);
       return MMAMD_E_UNSUPPORTED;
     }

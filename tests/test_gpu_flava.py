@@ -80,6 +80,48 @@ def test_attention_probs_kernel(B, S, H, masked, pdt):
         assert np.abs(host(fast) - host(out)).max() <= 2e-2 * max(1.0, np.abs(o).max())
 
 
+@pytest.mark.parametrize("B,S,H", [(3, 197, 5), (2, 205, 3), (4, 31, 2), (2, 2, 1), (3, 100, 4), (1, 288, 2), (2, 129, 3), (7, 67, 1), (2, 257, 2)])
+def test_attention_probs_flash_plus_one_pass_path(B, S, H):
+    """r05: without a key mask the probabilities come from the flash forward (log-sum-exp parked in each head's own block) and the one-pass
+    whole-line kernel (csrc/attention_probs_lse.hip).  Against float64, against the two-pass kernel (debug variant 514), and with guard
+    bands around a probability tensor placed at an odd float offset: the partial first / last segments of a band must not touch a neighbour."""
+    import math
+
+    from multimodal_amd import _lib, ops
+
+    set_rng_seed(B * 1000 + S)
+    D = H * 64
+    qkv_h = (torch.randn(B * S, 3 * D) * 1.5).to(torch.bfloat16)
+    qkv = qkv_h.cuda()
+    x = qkv_h.float().numpy().astype(np.float64).reshape(B, S, 3, H, 64)
+    q, k, v = (x[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(0, 1, 3, 2) / 8.0
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    n = B * H * S * S
+    L = _lib.lib()
+    for off in (0, 1, 37):  # float offset of the tensor inside its allocation: every phase of the 64-float segment grid
+        buf = torch.full((n + 256,), -7.0, dtype=torch.float32, device="cuda")
+        probs = buf[64 + off:64 + off + n].view(B, H, S, S)
+        out = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda")
+        ops.check(L.mmamd_attention_probs_fwd(qkv.data_ptr(), None, out.data_ptr(), probs.data_ptr(), ops.F32, B, S, H, 1.0 / math.sqrt(64.0),
+                                              ops._stream()), "mmamd_attention_probs_fwd")
+        torch.cuda.synchronize()
+        assert (buf[:64 + off] == -7.0).all() and (buf[64 + off + n:] == -7.0).all(), "write outside the probability tensor"
+        assert np.abs(host(probs) - p).max() <= 2e-6
+        assert np.abs(host(probs).sum(-1) - 1).max() <= 1e-5
+    L.mmamd_debug_set_attn_variant(514)
+    try:
+        out2, probs2 = ops.attention_probs_fwd(qkv, B, S, H, None)
+    finally:
+        L.mmamd_debug_set_attn_variant(515)
+    assert (probs2 - probs).abs().max().item() <= 2e-6
+    o = (p @ v).transpose(0, 2, 1, 3).reshape(B * S, D)
+    assert np.abs(host(out) - o).max() <= 2e-2 * max(1.0, np.abs(o).max())
+    assert np.abs(host(out2) - host(out)).max() <= 2e-2 * max(1.0, np.abs(o).max())
+    assert torch.equal(out, ops.attention_fwd(qkv, B, S, H, causal=False))  # the attention output IS the flash kernel's
+
+
 def test_attention_all_keys_masked_row_is_nan_like_reference():
     from multimodal_amd import ops
 
