@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--train", action="store_true", help="training step: forward + pre-training loss + backward + SGD")
     ap.add_argument("--grouped", action="store_true", help="schedule.flava_grouped: image and text towers layer-locked with grouped launches")
     ap.add_argument("--no-attentions", action="store_true", help="schedule.flava_attentions = False: the forwards do not produce the attention probabilities (opt-out)")
+    ap.add_argument("--probs-two-pass", action="store_true", help="A/B: unmasked attention probabilities from the two-pass kernel (debug variant 514) instead of flash + one pass")
     ap.add_argument("--codebook", action="store_true", help="MIM labels from the DALL-E codebook (112x112 images) inside the step instead of synthetic ones")
     a = ap.parse_args()
     from multimodal_amd.models.flava.model import flava_model
@@ -30,6 +31,10 @@ def main():
 
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
+    if a.probs_two_pass:
+        from multimodal_amd import _lib
+
+        _lib.lib().mmamd_debug_set_attn_variant(514)
     if a.no_attentions:
         from multimodal_amd.schedule import set_schedule
 
@@ -116,7 +121,7 @@ def main():
     print(json.dumps({"workload": ("TRAINING step: " if a.train else "") + "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + (" + bwd + SGD" if a.train else "") + (" + DALL-E codebook labels" if a.codebook else " (no codebook)"),
                       "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_sample": gf,
                       "tflops": round(B * gf / ms, 1), "mfma_frac": round(B * gf / ms / 2500.0, 4),
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "last": float(r.flatten()[0])}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "probs_path": "two_pass" if a.probs_two_pass else "flash+one_pass", "last": float(r.flatten()[0])}))
 
 
 if __name__ == "__main__":
