@@ -52,6 +52,17 @@ def dgrad_t(dy: Tensor, wT: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act:
 _FUSED_BIAS_GRAD = True  # tools/train_bench.py --no-fused-bias flips it for the A/B
 
 
+def _dh_dtype():
+    """dtype in which the two dgrad GEMMs of a pre-norm layer hand dh (the gradient of a LayerNorm OUTPUT) to the LayerNorm backward
+    (schedule.train_bf16_dh).  The residual-stream gradient (dX, dx_mid) stays fp32 either way; bf16 here is one more rounding of the kind du /
+    datt / dqkv already carry, for 77 MB less written by the GEMM epilogue and 77 MB less read by mmamd_layernorm_bwd per ViT-B/16 half layer
+    at B = 256."""
+    from .schedule import get_schedule
+
+    return bf if get_schedule().train_bf16_dh else f32
+
+
+
 def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
     """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens.  bias=True also returns
     db[N] = column sums of the bf16-rounded dY.  Token counts that are multiples of 128 (every full-size batch) go straight from the
@@ -297,7 +308,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         else:
             dW2, db2 = wgrad(dXb, g), dXsum
         # u = h2 W1^T + b1
-        dh2 = dgrad_t(du, W1T, f32)
+        dh2 = dgrad_t(du, W1T, _dh_dtype())
         dW1, db1 = wgrad(du, h2, bias=True)
         dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True)
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo)
@@ -308,7 +319,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         dWo = wgrad(dxmb, att)
         dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
         # qkv = h1 Wqkv^T + bqkv
-        dh1 = dgrad_t(dqkv, WqkvT, f32)
+        dh1 = dgrad_t(dqkv, WqkvT, _dh_dtype())
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
         dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
         if li > 0 and dhidden and dhidden[li - 1] is not None:

@@ -338,8 +338,13 @@ def test_full_size_flava_b2_vs_reference_fixture(golden):
     }
     print("flava full-size parity |d|:", {k: float(f"{v:.2e}") for k, v in rep.items()})
     assert len(img.hidden_states) == 13 and len(img.attentions) == 12 and img.attentions[0].shape == (2, 12, 197, 197)
-    assert max(rep["proj_image"], rep["proj_text"], rep["image_pooler"], rep["text_pooler"]) <= ROW_TOL
-    assert max(rep["image_cls"], rep["text_cls"]) <= HID_TOL and rep["text_attn_row"] <= PROB_TOL
+    # bound per tensor: the reference's OWN bf16-CPU error on it (tests/golden/flava_full_b2_bf16.npz, made by make_golden_flava_bf16.py from the
+    # reference run in bfloat16 on the same weights and batch) -- not a constant tuned to a first measurement
+    z16 = golden("flava_full_b2_bf16.npz")
+    print("reference's own bf16-CPU |d|:", {k: float(f"{float(z16['err_' + k]):.2e}") for k in rep if "err_" + k in z16})
+    for k in ("proj_image", "proj_text", "image_cls", "text_cls", "image_pooler", "text_pooler"):
+        assert rep[k] <= float(z16["err_" + k]), (k, rep[k], float(z16["err_" + k]))
+    assert rep["text_attn_row"] <= PROB_TOL
     assert abs(float(img.attentions[-1].double().sum()) - float(z["image_attn_last_sum"])) <= 1e-2  # 2*12*197 rows summing to 1
     assert abs(float(img.hidden_states[-1].double().mean()) - float(z["image_hidden_last_mean"])) <= 1e-3
 
