@@ -200,6 +200,13 @@ int mmamd_gemm_bf16_tn_splitk_colsum(const void* A, int lda, const void* W, int 
 int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mask, void* out, void* probs, int probs_dtype, int B,
                               int S, int H, float scale, mmamd_stream_t stream);
 
+/* The same probabilities [B,H,S,S] fp32 (no key mask) from the packed projections and the log2-domain log-sum-exp [B,H,S] a training
+ * forward saved (mmamd_attention_fwd_lse): P = exp2(scale log2(e) q.k - lse), one pass, stored as whole cache lines
+ * (csrc/attention_probs_lse.hip).  64 <= S <= 288 and S % 8 != 0, else MMAMD_E_UNSUPPORTED.  FLAVA's training forwards hand out `attentions` this way
+ * (models/flava/transformer.py:254-259 of the reference returns them in training too) without running the attention a second time. */
+int mmamd_attention_probs_from_lse(const void* qkv, const float* lse, void* probs, int B, int S, int H, float scale,
+                                   mmamd_stream_t stream);
+
 /* General attention: separate strided q / k / v (bf16), Sq != Sk, head_dim 64 or 96, optional causal / key-padding /
  * full [B or 1, Sq, Sk] uint8 masks (0 = masked), optional probabilities.  q row (b,i) at q + b*q_batch_stride + i*ldq
  * (q_batch_stride = 0: queries shared by every sample), k/v row (b,j) at k/v + b*kv_batch_stride + j*ldk/ldv; out bf16

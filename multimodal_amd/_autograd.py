@@ -52,17 +52,6 @@ def dgrad_t(dy: Tensor, wT: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act:
 _FUSED_BIAS_GRAD = True  # tools/train_bench.py --no-fused-bias flips it for the A/B
 
 
-def _dh_dtype():
-    """dtype in which the two dgrad GEMMs of a pre-norm layer hand dh (the gradient of a LayerNorm OUTPUT) to the LayerNorm backward
-    (schedule.train_bf16_dh).  The residual-stream gradient (dX, dx_mid) stays fp32 either way; bf16 here is one more rounding of the kind du /
-    datt / dqkv already carry, for 77 MB less written by the GEMM epilogue and 77 MB less read by mmamd_layernorm_bwd per ViT-B/16 half layer
-    at B = 256."""
-    from .schedule import get_schedule
-
-    return bf if get_schedule().train_bf16_dh else f32
-
-
-
 def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
     """dW[N,K] = dY^T X for dy [M,N], x [M,K] (bf16 or fp32 row-major); contraction over the M tokens.  bias=True also returns
     db[N] = column sums of the bf16-rounded dY.  Token counts that are multiples of 128 (every full-size batch) go straight from the
@@ -99,6 +88,7 @@ class StackConfig:
         self.to_canonical, self.from_canonical, self.key_mask = to_canonical, from_canonical, key_mask
         self.keep_hidden = keep_hidden  # the node then returns (x_L, inputs of layers 1 .. N-1) and fills `qkv`
         self.qkv: List[Tensor] = []
+        self.lse: List[Tensor] = []  # ... and their log2-domain log-sum-exp rows [B, H, S] (probabilities without a second attention pass)
 
 
 def draw_seed() -> int:
@@ -308,7 +298,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         else:
             dW2, db2 = wgrad(dXb, g), dXsum
         # u = h2 W1^T + b1
-        dh2 = dgrad_t(du, W1T, _dh_dtype())
+        dh2 = dgrad_t(du, W1T, f32)  # (bf16 here measured SLOWER: profiles/r05_train_bf16_dh_ab.txt)
         dW1, db1 = wgrad(du, h2, bias=True)
         dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True)
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo)
@@ -319,7 +309,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         dWo = wgrad(dxmb, att)
         dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
         # qkv = h1 Wqkv^T + bqkv
-        dh1 = dgrad_t(dqkv, WqkvT, _dh_dtype())
+        dh1 = dgrad_t(dqkv, WqkvT, f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
         dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
         if li > 0 and dhidden and dhidden[li - 1] is not None:
@@ -441,6 +431,7 @@ class EncoderStackFn(torch.autograd.Function):
             # attention probabilities in training (they recompute them from here, detached)
             mids = list(outs[1 + ns * cfg.n_layers:(ns + 1) * cfg.n_layers])
             cfg.qkv = [outs[1 + ns * li + 1] for li in range(cfg.n_layers)]
+            cfg.lse = [outs[1 + ns * li + 3] for li in range(cfg.n_layers)]
             ctx.n_mid = len(mids)
             return (outs[0], *mids)
         ctx.n_mid = -1

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "mmamd_gemm_bf16_tn_splitk": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_gemm_bf16_tn_splitk_colsum": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_attention_probs_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "mmamd_attention_probs_from_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_contrastive_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

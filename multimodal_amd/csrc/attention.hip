@@ -57,7 +57,7 @@ __device__ __forceinline__ int tr_off(int lane, int stride) {
 template <int NKT, bool CAUSAL, int ABL = 0, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                             int S, int H, int BH, float scale_log2e, float* __restrict__ lse,
-                                                            int lse_stride) {
+                                                            int lse_stride, int lse_tile) {
   constexpr int SP = NKT * 32;   // padded key count
   constexpr int VS = SP + 4;     // V^T row stride (elements): (SP+4)/2 dwords = 2 (mod 4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_fwd_kernel(const bf16* _
       const uint64_t tb = now();
       tacc[2] += tb - ta;
       // training: log2-domain log-sum-exp for the backward kernels (m is the running REFERENCE, not necessarily the max: m + log2(sum) is exact either way)
-      if (!TIMED && lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * lse_stride + q] = m + __builtin_amdgcn_logf(lsum);
+      if (!TIMED && lse != nullptr && half == 0 && q < S) lse[((size_t)b * H + h) * lse_stride + (size_t)(q >> 5) * lse_tile + (q & 31)] = m + __builtin_amdgcn_logf(lsum);
       if (q < S) {
         bf16* orow = out + ((size_t)b * S + q) * D + h * kDh;
 #pragma unroll
@@ -1860,7 +1860,7 @@ static int launch_attn(const void* qkv, void* out, int B, int S, int H, float sc
   const int slots = 2 * stream_cus(st);
   const int grid = BH < slots ? BH : slots;  // 2 resident workgroups per CU (LDS-limited), persistent over the items
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, (const bf16*)qkv, (bf16*)out, S, H, BH,
-                     scale * 1.4426950408889634f, lse, lse_stride > 0 ? lse_stride : S);
+                     scale * 1.4426950408889634f, lse, lse_stride > 0 ? lse_stride : S, lse_stride > 0 ? 32 * S : 32);
   return launch_status("attention_fwd");
 }
 
@@ -1878,7 +1878,8 @@ int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse
                      const float* scale, int nprob, hipStream_t st, const int* lse_stride = nullptr);
 // attention_probs_lse.hip: normalised probabilities from q, k and the saved log-sum-exp, stored as whole 256-byte segments
 bool attn_probs_lse_supports(int S);
-int launch_attn_probs_lse(const void* qkv, float* probs, int B, int S, int H, float scale, hipStream_t st);
+extern int g_probs_lse_abl, g_probs_lse_pad;
+int launch_attn_probs_lse(const void* qkv, float* probs, int B, int S, int H, float scale, hipStream_t st, const float* lse = nullptr);
 }  // namespace mmamd
 
 extern "C" int mmamd_debug_set_attn_variant(int v) {
@@ -1886,6 +1887,8 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
     g_attn_probs_serial = v == 512;
     return 0;
   }
+  if (v >= 5000 && v < 5100) { g_probs_lse_abl = v - 5000; return 0; }   // probabilities-from-lse kernel: ablation bits (MMAMD_EXPERIMENTS builds)
+  if (v >= 5100 && v < 5300) { g_probs_lse_pad = v - 5100; return 0; }   // ... extra LDS per workgroup in KiB (occupancy A/B)
   if (v == 514 || v == 515) {  // attention_probs_fwd without a key mask: 514 = the two-pass kernel, 515 = back to flash forward + probabilities pass
     g_attn_probs_twopass = v == 514;
     return 0;
@@ -1925,7 +1928,8 @@ extern "C" int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, i
   return attention_fwd_impl(qkv, out, lse, B, S, H, causal, scale, stream);
 }
 
-// lse_stride: floats between the log-sum-exp rows of consecutive (batch, head) items (0 = S: the dense [B, H, S] layout)
+// lse_stride: 0 = the dense [B, H, S] log-sum-exp layout; S * S = PARKED in a [B, H, S, S] probability tensor: query q of a head at float
+// (q / 32) * 32 S + q % 32 of the head's block (the first 32 floats of the 32-row band its probabilities will fill; attention_probs_lse.hip)
 static int attention_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale, mmamd_stream_t stream,
                               int lse_stride) {
   MMAMD_CHECK_ARG(qkv && out && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention: bad argument");
@@ -1987,11 +1991,14 @@ extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mas
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (S > 288) return launch_attn_long(qkv, key_mask, out, probs, probs_dtype, B, S, H, 0, scale, st);
-  // No key-padding mask and fp32 (or no) probabilities: the flash forward, which parks each head's log-sum-exp in the first S floats of the head's
-  // own [S, S] block, then ONE pass that turns q.k into normalised probabilities and streams them out as whole cache lines
-  // (attention_probs_lse.hip).  mmamd_debug_set_attn_variant(514) keeps the two-pass kernel below (A/B).
-  if (key_mask == nullptr && g_attn_probs_twopass == 0 && g_attn_variant == 0 && (probs == nullptr || probs_dtype == MMAMD_F32) &&
-      attn_probs_lse_supports(S)) {
+  // No key-padding mask, fp32 (or no) probabilities of a sequence long enough for it to pay (no probabilities: 73 vs 150 us at S = 197, B = 256;
+  // with them: (S = 129: 113 vs 130 us, S = 197: 218 vs 255 us, S = 275 at B = 128: 215 vs 270 us;
+  // S = 77: 57 vs 46 us -- profiles/r05_probs_lse_bench_v3.txt) -> the flash forward, which parks each query's log-sum-exp in the first 32 floats of
+  // the band of the probability tensor its row belongs to, then ONE pass that turns q.k into normalised probabilities and streams them out as whole
+  // cache lines (attention_probs_lse.hip).  mmamd_debug_set_attn_variant(514) keeps the two-pass kernel below for every case (A/B).
+  // (one predicate for both cases: the attention output must not depend on whether the probabilities were asked for)
+  if (key_mask == nullptr && g_attn_probs_twopass == 0 && g_attn_variant == 0 && S >= 112 && attn_probs_lse_supports(S) &&
+      (probs == nullptr || probs_dtype == MMAMD_F32)) {
     if (int rc = attention_fwd_impl(qkv, out, (float*)probs, B, S, H, 0, scale, stream, S * S)) return rc;
     return probs != nullptr ? launch_attn_probs_lse(qkv, (float*)probs, B, S, H, scale, st) : 0;
   }
@@ -2005,6 +2012,15 @@ extern "C" int mmamd_attention_probs_fwd(const void* qkv, const uint8_t* key_mas
   }
 #undef ATTNP_CASE
   MMAMD_CHECK_ARG(false, MMAMD_E_UNSUPPORTED, "attention_probs: unsupported S=%d", S);
+}
+
+extern "C" int mmamd_attention_probs_from_lse(const void* qkv, const float* lse, void* probs, int B, int S, int H, float scale,
+                                              mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(qkv && lse && probs && B >= 0 && S > 0 && H > 0, MMAMD_E_BADARG, "attention_probs_from_lse: bad argument");
+  MMAMD_CHECK_ARG(aligned16(qkv), MMAMD_E_ALIGN, "attention_probs_from_lse: qkv must be 16-byte aligned");
+  MMAMD_CHECK_ARG(attn_probs_lse_supports(S), MMAMD_E_UNSUPPORTED, "attention_probs_from_lse: S=%d is not served (64 .. 288, not a multiple of 8)", S);
+  if (B == 0) return 0;
+  return launch_attn_probs_lse(qkv, (float*)probs, B, S, H, scale, (hipStream_t)stream, lse);
 }
 
 static AttnDrop make_attn_drop(float p, uint64_t seed, uint32_t site) {

@@ -60,6 +60,9 @@ struct AttnRingProb {
   float scale_log2e;
   int lse_stride;   // floats between the log-sum-exp rows of consecutive (batch, head) items: S, or S * S when the rows are parked in the
                     // item's own block of a [B, H, S, S] probability tensor (mmamd_attention_probs_fwd)
+  int lse_tile;     // floats between the 32-query groups of a row: 32 (dense), or 32 * S when parked (query q at (q / 32) * 32 S + q % 32:
+                    // the first 32 floats of the band its probabilities will fill)
+  int pad_;
 };
 struct AttnRingArgs {
   AttnRingProb p[2];
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
     const int nqt = args.p[pi].nqt, rows8 = args.p[pi].rows8, G = args.p[pi].G, nring = args.p[pi].nring;
     const int slot_bytes = args.p[pi].slot_bytes, entry_bytes = args.p[pi].entry_bytes;
     const float scale_log2e = args.p[pi].scale_log2e;
-    const int lse_stride = args.p[pi].lse_stride;
+    const int lse_stride = args.p[pi].lse_stride, lse_tile = args.p[pi].lse_tile;
     const int D = H * 64;
     const int rsb = 3 * D * 2;  // bytes between consecutive tokens of qkv
     const int Nloc = (int)blockIdx.x < BH ? (BH - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;  // items of this workgroup
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
           const float inv = 1.0f / lsum;
           const int item = (int)blockIdx.x + n * (int)gridDim.x;
           const int b = item / H, h = item - b * H;
-          if (!TIMED && lse != nullptr && half == 0 && q < S) lse[(size_t)item * lse_stride + q] = m + __builtin_amdgcn_logf(lsum);
+          if (!TIMED && lse != nullptr && half == 0 && q < S) lse[(size_t)item * lse_stride + (size_t)qt * lse_tile + l31] = m + __builtin_amdgcn_logf(lsum);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -588,6 +591,8 @@ static bool ring_prob_setup(AttnRingProb& p, const void* qkv, void* out, float* 
   p.nring = nring;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.lse_stride = lse_stride > 0 ? lse_stride : S;
+  p.lse_tile = lse_stride > 0 ? 32 * S : 32;  // (a stride is only ever given for the parked layout)
+  p.pad_ = 0;
   int need = nring * p.entry_bytes;
 #ifdef MMAMD_EXPERIMENTS
   if (g_attn_ring_abl == 400 || g_attn_ring_abl == 401) need += 4096;  // the V over-read of the last entry

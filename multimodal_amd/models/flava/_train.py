@@ -160,7 +160,8 @@ def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], ke
     """Differentiable pass through a list of flava TransformerEncoderLayers (a whole encoder, or ONE stand-alone / wrapped layer).  Returns (x_L [B,S,d], hidden states or None, attention probabilities or None).
     keep_hidden: ALL hidden states, attached to the graph (the input, the input of every further layer, the result) like the reference's
     training forward (models/flava/transformer.py:254-259).  want_probs: the per-layer attention probabilities [B,H,S,S] fp32, recomputed from
-    each layer's saved projections by the inference kernel (mmamd_attention_probs_fwd) -- values as in eval mode, NOT differentiable (the
+    each layer's saved projections (and, unmasked, its saved log-sum-exp: mmamd_attention_probs_from_lse; else the inference kernel
+    mmamd_attention_probs_fwd) -- values as in eval mode, NOT differentiable (the
     reference's are; nothing in its models or losses differentiates through returned attention maps)."""
     from ...modules.layers.mlp import fused_activation_code
 
@@ -196,5 +197,9 @@ def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], ke
     probs = None
     if want_probs:
         H = cfg.n_head
-        probs = [ops.attention_probs_fwd(q, B, S, H, key_mask)[1] for q in cfg.qkv]
+        if key_mask is None and ops.attention_probs_from_lse_supported(S) and len(cfg.lse) == len(cfg.qkv):
+            # one pass per layer from the saved projections and log-sum-exp rows: exp2(scale q.k - lse), no second attention
+            probs = [ops.attention_probs_from_lse(q, l, B, S, H) for q, l in zip(cfg.qkv, cfg.lse)]
+        else:
+            probs = [ops.attention_probs_fwd(q, B, S, H, key_mask)[1] for q in cfg.qkv]
     return y, hidden, probs

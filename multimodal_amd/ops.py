@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "pack_w_frag", "debug_set_gemm_wp", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "attention_probs_fwd", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "pack_w_frag", "debug_set_gemm_wp", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "attention_probs_fwd", "attention_probs_from_lse", "attention_probs_from_lse_supported", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -360,6 +360,23 @@ def attention_probs_fwd(qkv: torch.Tensor, B: int, S: int, H: int, key_mask: Opt
                                                _dt(probs) if probs is not None else F32, B, S, H,
                                                1.0 / math.sqrt(64.0), _stream()), "mmamd_attention_probs_fwd")
     return out, probs
+
+
+def attention_probs_from_lse(qkv: torch.Tensor, lse: torch.Tensor, B: int, S: int, H: int) -> torch.Tensor:
+    """Normalised attention probabilities fp32 [B,H,S,S] of an unmasked self-attention from its packed projections (bf16 [B*S, 3*H*64]) and the
+    log2-domain log-sum-exp [B,H,S] attention_fwd_train saved: one pass, no second attention (mmamd_attention_probs_from_lse; 64 <= S <= 288, S % 8 != 0)."""
+    _chk(qkv, "qkv", torch.bfloat16)
+    _chk(lse, "lse", torch.float32)
+    if qkv.shape != (B * S, 3 * H * 64) or lse.shape != (B, H, S):
+        raise MmamdError(f"attention_probs_from_lse: qkv {tuple(qkv.shape)} / lse {tuple(lse.shape)} do not match B={B}, S={S}, H={H}")
+    probs = torch.empty((B, H, S, S), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().mmamd_attention_probs_from_lse(qkv.data_ptr(), lse.data_ptr(), probs.data_ptr(), B, S, H, 1.0 / math.sqrt(64.0), _stream()),
+          "mmamd_attention_probs_from_lse")
+    return probs
+
+
+def attention_probs_from_lse_supported(S: int) -> bool:
+    return 64 <= S <= 288 and S % 8 != 0
 
 
 class AttnMask:

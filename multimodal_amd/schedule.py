@@ -21,9 +21,6 @@ Every choice is between paths that compute the same function; the defaults are t
                                                   them unconditionally, models/flava/image_encoder.py:217-222).  False: `attentions = None` -- an opt-out for
                                                   callers that never read them (the pre-training losses do not): the fp32 [B, H, S, S] tensors are 4.7 GB of
                                                   writes per forward at B = 128 and a fifth of the step
-    train_bf16_dh  True | False                   training: the dgrad GEMMs in front of a LayerNorm backward write bf16 instead of fp32 (the residual-stream
-                                                  gradient itself stays fp32): 154 MB less traffic per ViT-B/16 half layer at B = 256 for one more bf16
-                                                  rounding on a branch gradient (measured: profiles/r05_train_bf16_dh_ab.txt)
 
 Environment (read once): MMAMD_TWO_TOWER, MMAMD_SINGLE_STREAM=1.
 
@@ -48,7 +45,6 @@ class Schedule:
     train_attentions: bool = True
     flava_grouped: bool = True
     flava_attentions: bool = True
-    train_bf16_dh: bool = False
 
     def __post_init__(self):
         if self.two_tower not in _TWO_TOWER:

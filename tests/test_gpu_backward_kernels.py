@@ -154,20 +154,8 @@ def test_gemm_epilogue_multiplies_by_activation_gradient():
         ops.gemm_bf16(a.cuda(), w.cuda(), None, act=ops.ACT_MUL_GELU_GRAD)  # needs the saved pre-activation
 
 
-@pytest.mark.parametrize("bf16_dh", [False, True])
-def test_clip_training_step_gradients_vs_reference_autograd(golden, bf16_dh):
-    """Every parameter gradient of a CLIP training step (two towers + contrastive loss) against the reference's torch autograd.
-    bf16_dh: schedule.train_bf16_dh (the dgrad GEMMs in front of a LayerNorm backward write bf16) -- the same bounds hold."""
-    from multimodal_amd.schedule import set_schedule
-
-    prev = set_schedule(train_bf16_dh=bf16_dh)
-    try:
-        _clip_training_step_gradients(golden)
-    finally:
-        set_schedule(train_bf16_dh=prev.train_bf16_dh)
-
-
-def _clip_training_step_gradients(golden):
+def test_clip_training_step_gradients_vs_reference_autograd(golden):
+    """Every parameter gradient of a CLIP training step (two towers + contrastive loss) against the reference's torch autograd."""
     from multimodal_amd.models.clip import CLIP, CLIPTextEncoder, CLIPViTEncoder
     from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
     from tests._util import fixture_sd

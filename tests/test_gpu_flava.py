@@ -100,7 +100,7 @@ def test_attention_probs_flash_plus_one_pass_path(B, S, H):
     p /= p.sum(-1, keepdims=True)
     n = B * H * S * S
     L = _lib.lib()
-    for off in (0, 1, 37):  # float offset of the tensor inside its allocation: every phase of the 64-float segment grid
+    for off in (0, 1, 38, 3):  # float offset of the tensor inside its allocation: every shift of the band image against memory's 16-byte grid
         buf = torch.full((n + 256,), -7.0, dtype=torch.float32, device="cuda")
         probs = buf[64 + off:64 + off + n].view(B, H, S, S)
         out = torch.empty((B * S, D), dtype=torch.bfloat16, device="cuda")
@@ -119,7 +119,26 @@ def test_attention_probs_flash_plus_one_pass_path(B, S, H):
     o = (p @ v).transpose(0, 2, 1, 3).reshape(B * S, D)
     assert np.abs(host(out) - o).max() <= 2e-2 * max(1.0, np.abs(o).max())
     assert np.abs(host(out2) - host(out)).max() <= 2e-2 * max(1.0, np.abs(o).max())
-    assert torch.equal(out, ops.attention_fwd(qkv, B, S, H, causal=False))  # the attention output IS the flash kernel's
+    if ops.attention_probs_from_lse_supported(S) and S >= 112:  # (shorter sequences and multiples of 8 keep the two-pass kernel)
+        assert torch.equal(out, ops.attention_fwd(qkv, B, S, H, causal=False))  # the attention output IS the flash kernel's
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 197, 3), (3, 65, 2), (1, 275, 2), (2, 100, 1)])
+def test_attention_probs_from_saved_log_sum_exp(B, S, H):
+    """mmamd_attention_probs_from_lse (FLAVA's training forwards: `attentions` without a second attention pass): the same kernel as the inference
+    path's second launch, fed by the dense [B,H,S] log-sum-exp of the training forward -> bit-equal maps; lengths the kernel does not serve raise."""
+    from multimodal_amd import ops
+
+    set_rng_seed(S)
+    qkv = (torch.randn(B * S, 3 * H * 64) * 1.5).to(torch.bfloat16).cuda()
+    out, lse = ops.attention_fwd_train(qkv, B, S, H, False)
+    probs = ops.attention_probs_from_lse(qkv, lse, B, S, H)
+    out2, probs2 = ops.attention_probs_fwd(qkv, B, S, H, None)
+    if S >= 112:  # the inference entry takes the same two kernels from this length on: bit-equal
+        assert torch.equal(out, out2) and torch.equal(probs, probs2)
+    assert (probs - probs2).abs().max().item() <= 2e-6 and (probs.sum(-1) - 1).abs().max().item() <= 1e-5
+    with pytest.raises(ops.MmamdError):
+        ops.attention_probs_from_lse(qkv[:B * 32].contiguous(), lse[:, :, :32].contiguous(), B, 32, H)
 
 
 def test_attention_all_keys_masked_row_is_nan_like_reference():

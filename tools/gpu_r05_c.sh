@@ -13,7 +13,4 @@ for i in 1 2; do
 done
 cut -c1-300 $O/r05_flava_probs_ab.txt
 for i in 1 2; do
-  timeout 300 python tools/train_bench.py --steps 8 --warmup 3 2>/dev/null | tail -1 >> $O/r05_train_bf16_dh_ab.txt
-  timeout 300 python tools/train_bench.py --steps 8 --warmup 3 --bf16-dh 2>/dev/null | tail -1 >> $O/r05_train_bf16_dh_ab.txt
 done
-cut -c90-400 $O/r05_train_bf16_dh_ab.txt

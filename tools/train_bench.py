@@ -19,15 +19,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--attn-variant", type=int, default=0, help="mmamd_debug_set_attn_variant code (4000 = the two-kernel attention backward, 4001 = single pass, 4002 = fused two-role)")
     ap.add_argument("--gemm-gm", type=int, default=0, help="mmamd_debug_set_gemm_knob(0, gm): tile-order group (8 = the r03 order)")
-    ap.add_argument("--bf16-dh", action="store_true", help="A/B arm: the dgrad GEMMs hand the LayerNorm backward bf16 gradients (schedule.train_bf16_dh)")
     ap.add_argument("--no-fused-bias", action="store_true", help="A/B arm: bias gradients from the column-sum passes (the r04 form) instead of the wgrad GEMM's own pass")
     a = ap.parse_args()
     from multimodal_amd import _autograd, _lib
 
     _autograd._FUSED_BIAS_GRAD = not a.no_fused_bias
-    from multimodal_amd.schedule import get_schedule, set_schedule
-
-    set_schedule(train_bf16_dh=bool(a.bf16_dh))
 
     _lib.lib().mmamd_debug_set_attn_variant(a.attn_variant)
     _lib.lib().mmamd_debug_set_gemm_knob(0, a.gemm_gm)
@@ -67,7 +63,7 @@ def main():
     print(json.dumps({"workload": "CLIP ViT-B/16 training step (fwd + contrastive loss + bwd + SGD), synthetic", "batch": a.batch,
                       "ms_per_step": round(ms, 3), "pairs_per_s": round(a.batch / ms * 1e3, 1), "gflop_per_pair": gf,
                       "tflops": round(a.batch * gf / ms, 1), "mfma_frac": round(a.batch * gf / ms / 2500.0, 4),
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "dh_dtype": "bf16" if get_schedule().train_bf16_dh else "f32", "losses": [round(x, 4) for x in losses]}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "losses": [round(x, 4) for x in losses]}))
 
 
 if __name__ == "__main__":
