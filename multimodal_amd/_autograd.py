@@ -582,7 +582,23 @@ def grad_requested(module, *inputs) -> bool:
         return False
     if any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs):
         return True
-    return any(p.requires_grad for p in module.parameters())
+    return params_require_grad(module)
+
+
+def params_require_grad(module) -> bool:
+    """A parameter of `module` (or of a sub-module) requires grad -- including parameters FullyShardedDataParallel has DE-REGISTERED: with
+    use_orig_params=False (FSDP's default, what the reference trainer uses) a wrapped unit's modules hold, inside the unit's forward, plain
+    Tensor VIEWS of the flat parameter as ordinary attributes (module.__dict__), and module.parameters() yields nothing.  Missing them sent
+    such modules down the inference path: no gradient for their weights (found by tests/test_gpu_fsdp_single_rank.py: FLAVA's cls_token /
+    embeddings were never updated)."""
+    for p in module.parameters():
+        if p.requires_grad:
+            return True
+    for m in module.modules():  # only reached when no REGISTERED parameter requires grad
+        for v in m.__dict__.values():
+            if isinstance(v, torch.Tensor) and v.requires_grad:
+                return True
+    return False
 
 
 _EVAL_GRAD_MSG = ("{name}: this eval-mode forward has no differentiable path on the MI355X kernels (the differentiable path of the module runs "

@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from ... import _torch_ops, ops
+from ..._autograd import params_require_grad
 from ..._packing import PackedCache
 
 _torch_ops.try_load()
@@ -202,7 +203,7 @@ def forbid_training_forward(module: nn.Module) -> None:
     """Standalone sub-modules (a single encoder layer, a bare tower called outside its model) have no differentiable forward: training
     runs through the stack-level autograd nodes (multimodal_amd/_autograd.py) that the models and encoders dispatch to.  Refuse, loudly,
     to return non-differentiable outputs to a training loop instead of silently detaching them."""
-    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+    if module.training and torch.is_grad_enabled() and params_require_grad(module):
         raise NotImplementedError(
             f"{type(module).__name__}: this module has no differentiable forward of its own on the MI355X path (training goes through the "
             "enclosing encoder / model); call .eval() and/or run under torch.no_grad() for inference")

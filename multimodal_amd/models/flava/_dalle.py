@@ -19,6 +19,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
+from ..._autograd import params_require_grad
 
 bf, f32 = torch.bfloat16, torch.float32
 
@@ -156,7 +157,7 @@ class DalleEncoder(nn.Module):
             raise ValueError(f"input has {x.shape[1]} channels but model built for {self.input_channels}")
         if not x.is_cuda:
             raise ops.MmamdError(f"images are on {x.device}: the MI355X path needs HIP device tensors (no CPU fallback)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+        if torch.is_grad_enabled() and params_require_grad(self) and self.training:
             raise ops.MmamdError("DalleEncoder on the MI355X path is inference-only (the codebook only supplies labels): call it under "
                                  "torch.no_grad() or in eval mode")
         groups = [m for n, m in self.blocks.named_children() if n.startswith("group_")]

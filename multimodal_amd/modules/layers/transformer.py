@@ -13,7 +13,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import _torch_ops, ops
-from ..._autograd import plain_layers, wants_grad
+from ..._autograd import params_require_grad, plain_layers, wants_grad
 from ..._packing import PackedCache
 from .mlp import MLP
 from .multi_head_attention import MultiHeadAttentionWithCache, MultiHeadSelfAttention, to_attn_mask
@@ -34,7 +34,7 @@ class TransformerOutput(NamedTuple):
 
 
 def _forbid_training(module: nn.Module) -> None:
-    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+    if module.training and torch.is_grad_enabled() and params_require_grad(module):
         raise NotImplementedError(f"{type(module).__name__}: a standalone layer has no differentiable forward on the MI355X path (training runs "
                                   "through TransformerEncoder / TransformerDecoder); call .eval() and/or run under torch.no_grad()")
 

@@ -134,7 +134,9 @@ def main():
     worst, worst_k = 0.0, ""
     for k, v in sd_p.items():
         if k in sd_w and v.dtype.is_floating_point:
-            d = float((sd_w[k].to(v.device).float() - v.float()).abs().max()) / (float(v.float().abs().max()) + 1e-9)
+            # relative to the tensor's size, with a floor: parameters that start at zero and whose gradient is mathematically zero (the attention
+            # key biases: softmax is invariant to a per-query shift) hold 1e-9-sized round-off on both sides, where a relative figure means nothing
+            d = float((sd_w[k].to(v.device).float() - v.float()).abs().max()) / max(float(v.float().abs().max()), 1e-3)
             if d > worst:
                 worst, worst_k = d, k
     res["params_worst_rel"] = worst
