@@ -107,6 +107,7 @@ def main():
             return 0.0 if a is b else float("inf")
         return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12) / tol
 
+    sd0 = {k: v.detach().clone() for k, v in plain.state_dict().items()}
     e0p, e0w = eval_out(plain), eval_out(wrapped)
     res["eval_before_dloss"] = abs(e0p[0] - e0w[0])
     res["eval_before_worst_rel_over_tol"] = max(close(a, b, 1e-3) for a, b in zip(e0w[1:], e0p[1:]))
@@ -131,16 +132,23 @@ def main():
     sd_w = wrapped.state_dict()
     sd_p = plain.state_dict()
     res["state_dict_keys_equal"] = sorted(sd_w.keys()) == sorted(sd_p.keys())
-    worst, worst_k = 0.0, ""
+    # The UPDATES the two steps made to every parameter (final - initial), wrapped vs unwrapped: relative to the tensor's largest update, with a
+    # floor at 1e-3 of the largest update of any tensor -- parameters whose gradient is mathematically zero (the attention key biases: softmax is
+    # invariant to a per-query shift) move by round-off on both sides, where a relative figure means nothing.  What differs between the two runs is
+    # the order of fp32 atomics (embedding gradients) and one autograd node per layer instead of one per stack: the same kernels on the same
+    # values, so the updates agree far inside the bf16-gradient tolerance of the gradient fixtures (6e-2).
+    upd_max = max(float((sd_p[k].float() - sd0[k].float()).abs().max()) for k in sd_p if sd_p[k].dtype.is_floating_point)
+    worst, worst_k, worst_abs = 0.0, "", 0.0
     for k, v in sd_p.items():
         if k in sd_w and v.dtype.is_floating_point:
-            # relative to the tensor's size, with a floor: parameters that start at zero and whose gradient is mathematically zero (the attention
-            # key biases: softmax is invariant to a per-query shift) hold 1e-9-sized round-off on both sides, where a relative figure means nothing
-            d = float((sd_w[k].to(v.device).float() - v.float()).abs().max()) / max(float(v.float().abs().max()), 1e-3)
+            up, uw = v.float() - sd0[k].float(), sd_w[k].to(v.device).float() - sd0[k].float()
+            d = float((uw - up).abs().max()) / max(float(up.abs().max()), 1e-3 * upd_max)
             if d > worst:
-                worst, worst_k = d, k
+                worst, worst_k, worst_abs = d, k, float((uw - up).abs().max())
     res["params_worst_rel"] = worst
     res["params_worst_key"] = worst_k
+    res["params_worst_abs"] = worst_abs
+    res["largest_update"] = upd_max
     print("FSDP_PROBE_RESULT " + json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()

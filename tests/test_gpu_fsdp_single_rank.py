@@ -61,7 +61,8 @@ def _check(r, sharded: bool):
     # after training: eval forwards of the wrapped model use the UPDATED parameters (no stale packed copies) and match the unwrapped model
     assert r["eval_changed_by_training"] > 1e-3, r
     assert r["eval_after_dloss"] <= 5e-3 and r["eval_after_worst_rel_over_tol"] <= 1.0, r
-    assert r["params_worst_rel"] <= 2e-3, r
+    # the two steps moved every parameter by the same amount (relative to the tensor's largest update; tests/_fsdp_probe.py)
+    assert r["params_worst_rel"] <= 3e-2, (r["params_worst_key"], r["params_worst_rel"], r["params_worst_abs"], r["largest_update"])
 
 
 def test_flava_pretraining_under_fsdp_one_rccl_rank():
