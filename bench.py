@@ -457,15 +457,23 @@ def main() -> None:
             try:
                 z = json.loads(pmc.read_text())["shapes"]
                 traffic = int(sum(v["hbm_bytes_per_launch"] for v in z.values()) / len(z))
-                # the stored PMC pass also has the clock the launches ran at (GRBM_GUI_ACTIVE / 8 XCDs / duration; 2.4 GHz nominal): the part clocks down under
-                # MFMA load, so the fraction of what THAT clock allows is reported beside `frac` (which stays against the nominal peak)
-                for key, name in (("outproj", "out_projection"), ("mlpdown", "mlp_down")):
-                    clk = z.get(key, {}).get("effective_clock_ghz")
-                    if clk and name in by_shape:
-                        by_shape[name]["pmc_effective_clock_ghz"] = round(clk, 3)
-                        by_shape[name]["frac_at_that_clock"] = round(by_shape[name]["achieved"] / (MFMA_BF16_PEAK_TFLOPS * clk / 2.4), 4)
             except Exception:
                 traffic = None
+        # MEASURED clocks (r05): amdsmi telemetry of 5-s loops of these very launches (socket power / gfxclk at 20 Hz; 1400 W cap) -- a stored figure from
+        # profiles/r05_power_clocks_summary.json, not this run.  `frac` stays against the nominal 2.4 GHz peak; `frac_at_measured_clock` is against what
+        # the clock the chip sustains under that kernel allows.  (Until r04 this field was derived from GRBM_GUI_ACTIVE, which misreads short kernels.)
+        tele = ROOT / "profiles" / "r05_power_clocks_summary.json"
+        if tele.exists():
+            try:
+                tk = json.loads(tele.read_text())["kernels"]
+                for name in by_shape:
+                    if name in tk:
+                        mhz = tk[name]["gfxclk_mhz"]
+                        by_shape[name]["telemetry"] = {"gfxclk_mhz": mhz, "socket_power_w": tk[name]["socket_power_w"], "power_cap_w": 1400,
+                                                       "source": "profiles/r05_power_clocks.json (stored; amdsmi at 20 Hz over 5-s loops of this launch)"}
+                        by_shape[name]["frac_at_measured_clock"] = round(by_shape[name]["achieved"] / (MFMA_BF16_PEAK_TFLOPS * mhz / 2400.0), 4)
+            except Exception:
+                pass
         roofline = {"bound": "mfma",
                     "kernel": "gemm_bf16_nt_kernel_ppg<true,0>: grouped out-projection / MLP-down of both towers (+bias, fp32 residual read-modify-write); "
                               "the kernel with the largest share of the step",
