@@ -1878,7 +1878,7 @@ int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse
                      const float* scale, int nprob, hipStream_t st, const int* lse_stride = nullptr);
 // attention_probs_lse.hip: normalised probabilities from q, k and the saved log-sum-exp, stored as whole 256-byte segments
 bool attn_probs_lse_supports(int S);
-extern int g_probs_lse_abl, g_probs_lse_pad;
+extern int g_probs_lse_abl, g_probs_lse_pad, g_probs_lse_waves;
 int launch_attn_probs_lse(const void* qkv, float* probs, int B, int S, int H, float scale, hipStream_t st, const float* lse = nullptr);
 }  // namespace mmamd
 
@@ -1888,7 +1888,8 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
     return 0;
   }
   if (v >= 5000 && v < 5100) { g_probs_lse_abl = v - 5000; return 0; }   // probabilities-from-lse kernel: ablation bits (MMAMD_EXPERIMENTS builds)
-  if (v >= 5100 && v < 5300) { g_probs_lse_pad = v - 5100; return 0; }   // ... extra LDS per workgroup in KiB (occupancy A/B)
+  if (v >= 5100 && v < 5300) { g_probs_lse_pad = v - 5100; return 0; }
+  if (v == 5300 || v == 5308 || v == 5316) { g_probs_lse_waves = v - 5300; return 0; }  // ... waves per workgroup (A/B)   // ... extra LDS per workgroup in KiB (occupancy A/B)
   if (v == 514 || v == 515) {  // attention_probs_fwd without a key mask: 514 = the two-pass kernel, 515 = back to flash forward + probabilities pass
     g_attn_probs_twopass = v == 514;
     return 0;

@@ -48,9 +48,12 @@ __device__ __forceinline__ int pl_f(int row) { return (((row >> 1) & 1) << 2) | 
 
 // ABL (timing experiments, results WRONG; built only with MMAMD_EXPERIMENTS=1, tools/probs_lse_ablate.py): 1 = no global stores, 2 = no compute phase (no Q reads,
 // MFMA, exp2, band writes), 4 = no LDS reads in the streaming phase (a constant is stored), 8 = no barrier
-template <int NKT, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void attention_probs_lse_kernel(const ProbsLseArgs a) {
-  constexpr int KPW = (NKT + 7) / 8;  // key tiles per wave (wave w: tiles w, w + 8)
+// NW: waves per workgroup.  The LDS image allows two workgroups per CU either way; 16 waves per workgroup = 32 waves per CU in the streaming phase
+// (stores in flight are what the store rate follows: tools/microbench/store_pattern.hip, profiles/r05_probs_lse_ablation_v3.txt) while waves >= NKT
+// sit out the compute phase.
+template <int NKT, int ABL = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 8 : 2) void attention_probs_lse_kernel(const ProbsLseArgs a) {
+  constexpr int KPW = (NKT + NW - 1) / NW;  // key tiles per wave (wave w: tiles w, w + NW)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = a.S, H = a.H, rows_q = a.rows_q;
   char* Qimg = smem;                                            // [rows_q][128 B], chunk c of row r at position c ^ pl_f(r)
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void attention_probs_lse_kernel(const Probs
   const int l31 = lane & 31, half = lane >> 5;
 
   // ---- everything the head needs from memory, once: Q rows -> LDS, this wave's K fragments -> registers, the log-sum-exp -> LDS
-  for (int r = tid >> 3; r < rows_q; r += 64) {
+  for (int r = tid >> 3; r < rows_q; r += NW * 8) {
     const int c = tid & 7;
     const int rs = r < S ? r : S - 1;  // (rows past S repeat row S - 1: finite, their band rows are never streamed)
     const bf16x8 qv = *reinterpret_cast<const bf16x8*>(base + (size_t)rs * row_stride + c * 8);
@@ -77,13 +80,13 @@ __global__ __launch_bounds__(512, 2) void attention_probs_lse_kernel(const Probs
   bf16x8 kf[KPW][4];  // K fragment t of key tile kt: row kt*32 + l31, elements 16 t + 8 half .. + 7 (keys past S repeat key S - 1: never stored)
 #pragma unroll
   for (int i = 0; i < KPW; ++i) {
-    const int key = (wave + 8 * i) * 32 + l31;
+    const int key = (wave + NW * i) * 32 + l31;
     const bf16* kp = base + (size_t)(key < S ? key : S - 1) * row_stride + D + 8 * half;
 #pragma unroll
     for (int t = 0; t < 4; ++t) kf[i][t] = *reinterpret_cast<const bf16x8*>(kp + 16 * t);
   }
   const float* lrow = a.lse + (size_t)bh * a.lse_stride;
-  for (int q = tid; q < NKT * 32; q += 512) Ls[q] = q < S ? lrow[(size_t)(q >> 5) * a.lse_tile + (q & 31)] : 0.f;
+  for (int q = tid; q < NKT * 32; q += NW * 64) Ls[q] = q < S ? lrow[(size_t)(q >> 5) * a.lse_tile + (q & 31)] : 0.f;
   // lane constants: Q fragment t of a 32-row tile = row l31, chunk 2t + half (swizzled)
   const int fq = pl_f(l31);
   int qo[4];
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void attention_probs_lse_kernel(const Probs
     }
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-      const int kt = wave + 8 * i;
+      const int kt = wave + NW * i;
       if ((ABL & 2) == 0 && kt < NKT) {
         f32x16 acc;
 #pragma unroll
@@ -149,12 +152,12 @@ __global__ __launch_bounds__(512, 2) void attention_probs_lse_kernel(const Probs
     const int nchunk = (ph + n + 3) >> 2;
     const int nseg = (nchunk + 63) >> 6;
 #pragma unroll 1
-    for (int s0 = wave; s0 < nseg; s0 += 32) {
+    for (int s0 = wave; s0 < nseg; s0 += 4 * NW) {
       f32x4 v[4];
       int g[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int c = (s0 + 8 * i) * 64 + lane;
+        const int c = (s0 + NW * i) * 64 + lane;
         g[i] = 4 * c - ph;  // first band float of the chunk
         const bool inside = g[i] + 3 >= 0 && g[i] < n;  // (chunks of segments >= nseg start past n)
         if constexpr ((ABL & 4) != 0) v[i] = f32x4{(float)c, 0.f, 0.f, 0.f};
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void attention_probs_lse_kernel(const Probs
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int c = (s0 + 8 * i) * 64 + lane;
+        const int c = (s0 + NW * i) * 64 + lane;
         float* dst = sbase + 4 * (size_t)(uint32_t)c;
         if constexpr ((ABL & 1) != 0) {
           if (v[i][0] == 1.2345e33f) *reinterpret_cast<f32x4*>(dst) = v[i];
@@ -192,13 +195,20 @@ bool attn_probs_lse_supports(int S) { return S >= 64 && S <= 288 && (S & 7) != 0
 int g_probs_lse_abl = 0;   // mmamd_debug_set_attn_variant(5000 + bits): ablations of the S = 193 .. 224 instantiation (MMAMD_EXPERIMENTS builds)
 int g_probs_lse_pad = 0;   // mmamd_debug_set_attn_variant(5100 + KiB): extra dynamic LDS per workgroup (occupancy A/B: 10 -> one workgroup per CU)
 
-template <int NKT, int ABL = 0>
+// waves per workgroup: 0 = by length (16 from 7 key tiles up: S = 197 127-142 vs 135-137 us, S = 275 120-136 vs 134-141 us; S = 129 75-81 vs 66-69 us
+// the other way: profiles/r05_probs_lse_waves_ab.txt); mmamd_debug_set_attn_variant(5308 / 5316) forces 8 / 16 (A/B)
+int g_probs_lse_waves = 0;
+
+template <int NKT, int ABL = 0, int NW = 8>
 static int launch_probs_lse_t(const ProbsLseArgs& a, int grid, int smem, hipStream_t st) {
+  if constexpr (NW == 8 && ABL == 0) {
+    if (g_probs_lse_waves == 16 || (g_probs_lse_waves == 0 && NKT >= 7)) return launch_probs_lse_t<NKT, 0, 16>(a, grid, smem, st);
+  }
   static unsigned long long attr_mask = 0;
-  auto kern = attention_probs_lse_kernel<NKT, ABL>;
+  auto kern = attention_probs_lse_kernel<NKT, ABL, NW>;
   if (g_probs_lse_pad > 0 && smem + g_probs_lse_pad * 1024 <= 160 * 1024) { smem += g_probs_lse_pad * 1024; attr_mask = 0; }
   if (int rc = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, a);
   return launch_status("attention_probs_lse");
 }
 
