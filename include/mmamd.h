@@ -404,6 +404,15 @@ int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, co
 int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
                         void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int d, float eps,
                         mmamd_stream_t stream);
+/* mmamd_layernorm_bwd with dgamma == dbeta == NULL leaves its per-workgroup partials in ws ([G][ns][d], G = min(768, ceil(rows/4)), ns = 2 or 3 with
+ * dx_colsum) and skips the reduction; mmamd_colsum_stage2_batched reduces any number of such jobs in one launch per 64 (out0 | out1 | out2 receive the
+ * column segments [0, seg) | [seg, 2 seg) | [2 seg, n) of sum_g part[g][0..n); out1 == NULL: one array of n).  Same arithmetic as the immediate form. */
+typedef struct {
+  const float* part;
+  float *out0, *out1, *out2;
+  int G, n, seg;
+} mmamd_colsum_job;
+int mmamd_colsum_stage2_batched(const mmamd_colsum_job* jobs, int njobs, mmamd_stream_t stream);
 /* out[n] = column sums of x[rows,n] (bias gradients).  ws: min(1024, rows) * n floats. */
 int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream);
 /* g = act(u) and du = dg * act'(u), bf16, n % 4 == 0 (MMAMD_ACT_QUICKGELU / MMAMD_ACT_GELU_ERF). */

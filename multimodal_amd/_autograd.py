@@ -50,6 +50,12 @@ def dgrad_t(dy: Tensor, wT: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act:
 
 
 _FUSED_BIAS_GRAD = True  # tools/train_bench.py --no-fused-bias flips it for the A/B
+_DEFER_LN_REDUCE = True  # tools/train_bench.py --no-deferred-ln-reduce: every LayerNorm backward reduces its own partials (the r04 form)
+
+
+def _pending():
+    """The list the LayerNorm backward calls of a stack park their reductions in (None: reduce at once)."""
+    return [] if _DEFER_LN_REDUCE else None
 
 
 def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
@@ -277,6 +283,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
     wt = saved[(ns + 1) * n_layers - 1:]  # bf16 transposes of (Wqkv, Wo, W1, W2) per layer, made by the forward's weight pack
     dX = dx_out
     grads: List[Tensor] = [dX] * (12 * n_layers)
+    pending = _pending()  # the LayerNorm backward calls park their dgamma / dbeta / column-sum partials: ONE reduction launch at the end of the stack
     dXb = None  # bf16 copy of dX: produced by the LayerNorm backward of the layer above
     dXsum = None  # ... and its column sums (= the bias gradient of this layer's second MLP Linear) from the same kernel
     for li in reversed(range(n_layers)):
@@ -300,7 +307,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         # u = h2 W1^T + b1
         dh2 = dgrad_t(du, W1T, f32)  # (bf16 here measured SLOWER: profiles/r05_train_bf16_dh_ab.txt)
         dW1, db1 = wgrad(du, h2, bias=True)
-        dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True)
+        dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True, defer=pending)
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo)
             dxmb = ops.dropout(dx_mid, pb, seed, 16 * li, group=grp, out_dtype=bf)
             dbo = ops.colsum(dxmb)
@@ -311,7 +318,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         # qkv = h1 Wqkv^T + bqkv
         dh1 = dgrad_t(dqkv, WqkvT, f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
-        dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True)
+        dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True, defer=pending)
         if li > 0 and dhidden and dhidden[li - 1] is not None:
             # this layer's input was also handed out as hidden_states[li] and something differentiated through it: dX += that gradient
             # (mmamd_dropout with p = 0 is the fp32 add kernel); the bf16 copy / column sums of dX made above are stale
@@ -319,6 +326,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
             dX = ops.dropout(extra if extra.is_contiguous() else extra.contiguous(), 0.0, 0, 0, residual=dX)
             dXb, dXsum = None, None
         grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
+    ops.colsum_flush(pending)
     if n_layers == 0:
         dX = dx_out.clone()  # (no alias of an input, see _stack_fwd_impl)
     return [dX] + grads
@@ -360,13 +368,14 @@ def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, ep
     wt = saved[10 * n_layers - 1:]
     dX = dx_out
     grads: List[Tensor] = [dX] * (12 * n_layers)
+    pending = _pending()  # parked LayerNorm-backward reductions: one launch at the end (ops.colsum_flush)
     for li in reversed(range(n_layers)):
         h1, qkv, att, lse, a, h2, u, g, ff = saved[9 * li:9 * li + 9]
         Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2 = params[12 * li:12 * li + 12]
         WqkvT, WoT, W1T, W2T = wt[4 * li:4 * li + 4]
         pb, pm, grp = _drop_of(drop, li, S, a.shape[1])
         # y = LN2(ff)
-        dff, dg2, dbe2, dffb, db2 = ops.layernorm_bwd(ff, g2, dX, eps2[li], want_bf16=True, want_colsum=True)
+        dff, dg2, dbe2, dffb, db2 = ops.layernorm_bwd(ff, g2, dX, eps2[li], want_bf16=True, want_colsum=True, defer=pending)
         if pb > 0:  # ff = x1 + drop(delta): the branch gradient is the masked, scaled dff
             dffb = ops.dropout(dff, pb, seed, 16 * li + 2, group=grp, out_dtype=bf)
             db2 = ops.colsum(dffb)
@@ -377,7 +386,7 @@ def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, ep
         dx1 = dgrad_t(du, W1T, f32, ops.ACT_NONE, dff)  # dff + du W1: the residual add is the GEMM's epilogue
         dW1, db1 = wgrad(du, h2, bias=True)
         # x1 = LN1(a)
-        da, dg1, dbe1, dab, dbo = ops.layernorm_bwd(a, g1, dx1, eps1[li], want_bf16=True, want_colsum=True)
+        da, dg1, dbe1, dab, dbo = ops.layernorm_bwd(a, g1, dx1, eps1[li], want_bf16=True, want_colsum=True, defer=pending)
         if pb > 0:
             dab = ops.dropout(da, pb, seed, 16 * li, group=grp, out_dtype=bf)
             dbo = ops.colsum(dab)
@@ -390,6 +399,7 @@ def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, ep
             extra = dhidden[li - 1].detach()
             dX = ops.dropout(extra if extra.is_contiguous() else extra.contiguous(), 0.0, 0, 0, residual=dX)
         grads[12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo, dW1, db1, dW2, db2, dg1, dbe1, dg2, dbe2]
+    ops.colsum_flush(pending)
     if n_layers == 0:
         dX = dx_out.clone()
     return [dX] + grads
@@ -923,6 +933,7 @@ class DecoderStackFn(torch.autograd.Function):
             offs.append(o)
             o += cfg.nparams(li)
         dXb = None
+        pending = _pending()  # parked LayerNorm-backward reductions: one launch at the end (ops.colsum_flush)
         for li in reversed(range(len(cfg.layers))):
             L, rec = cfg.layers[li], recs[li]
             pr = [c32(t) for t in params[offs[li]:offs[li] + cfg.nparams(li)]]
@@ -951,7 +962,7 @@ class DecoderStackFn(torch.autograd.Function):
             dW2, db2 = wgrad(dXb, g, bias=True)
             dh2 = dgrad(du, w1, f32)
             dW1, db1 = wgrad(du, h2, bias=True)
-            d_a2, dg2, dbe2, d_a2b = ops.layernorm_bwd(a2, g2, dh2, L["eps2"], add=dX, want_bf16=True)
+            d_a2, dg2, dbe2, d_a2b = ops.layernorm_bwd(a2, g2, dh2, L["eps2"], add=dX, want_bf16=True, defer=pending)
             gl = [None] * cfg.nparams(li)
             if L["has_cross"]:
                 if pd > 0:
@@ -966,7 +977,7 @@ class DecoderStackFn(torch.autograd.Function):
                 d_enc = de if d_enc is None else ops.gemm_bf16(dkvc, ops.transpose_to_bf16(wckv, pad_to=64), None, residual=d_enc,
                                                                out_dtype=f32, out=d_enc)
                 dWckv, dbckv = wgrad(dkvc, encb, bias=True)
-                d_a, dgc, dbec, d_ab = ops.layernorm_bwd(a, gc, dhc, L["epsc"], add=d_a2, want_bf16=True)
+                d_a, dgc, dbec, d_ab = ops.layernorm_bwd(a, gc, dhc, L["epsc"], add=d_a2, want_bf16=True, defer=pending)
                 gl[10:20] = [dWcq, dbcq, dWckv[:d], dbckv[:d], dWckv[d:], dbckv[d:], dWco, dbco, dgc, dbec]
                 gl[20:] = [dW1, db1, dW2, db2, dg2, dbe2]
             else:
@@ -984,7 +995,8 @@ class DecoderStackFn(torch.autograd.Function):
             dh1 = ops.gemm_bf16(dkv, ops.transpose_to_bf16(wqkv[d:], pad_to=64), None, residual=dh1, out_dtype=f32, out=dh1)
             dWq, dbq = wgrad(dq, h1, bias=True)
             dWkv, dbkv = wgrad(dkv, h1, bias=True)
-            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, L["eps1"], add=d_a, want_bf16=True)
+            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, L["eps1"], add=d_a, want_bf16=True, defer=pending)
             gl[:10] = [dWq, dbq, dWkv[:d], dbkv[:d], dWkv[d:], dbkv[d:], dWo, dbo, dg1, dbe1]
             grads[offs[li]:offs[li] + cfg.nparams(li)] = gl
+        ops.colsum_flush(pending)
         return (dX, d_enc, None, *grads)

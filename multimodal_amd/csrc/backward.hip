@@ -111,11 +111,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // column, 8 groups) was latency-bound — 22 us average over the 596 calls of a CLIP training step, 4 % of the step.
 // (out1 / out2 / seg: the result is split into segments of `seg` columns that go to up to three separate arrays — the LayerNorm backward's
 // dgamma | dbeta | column sums of dx; out1 == NULL: one array)
-__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out,
-                                                            float* __restrict__ out1 = nullptr, float* __restrict__ out2 = nullptr, int seg = 0) {
+__device__ __forceinline__ void colsum_stage2_body(const float* __restrict__ part, int G, int n, float* __restrict__ out, float* __restrict__ out1,
+                                                   float* __restrict__ out2, int seg, int block) {
   __shared__ f32x4 red[32][8];
   const int cq = threadIdx.x & 7, grp = threadIdx.x >> 3;
-  const int c = blockIdx.x * 32 + cq * 4;
+  const int c = block * 32 + cq * 4;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   if ((n & 3) == 0) {
     if (c < n) {
@@ -150,6 +150,23 @@ __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restr
           (which == 0 ? out : which == 1 ? out1 : out2)[cc] = red[0][cq][j];
         }
       }
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int G, int n, float* __restrict__ out,
+                                                            float* __restrict__ out1 = nullptr, float* __restrict__ out2 = nullptr, int seg = 0) {
+  colsum_stage2_body(part, G, n, out, out1, out2, seg, blockIdx.x);
+}
+
+// The same reduction for up to 64 independent (partials -> up to three result arrays) jobs in ONE launch (blockIdx.y = job): the LayerNorm backward calls of a
+// layer stack park their partials and the stack's backward reduces all of them at its end (r05: 53 launches of ~25 us on the training step's critical path,
+// each with 72 workgroups on 256 CUs, become two).  Same arithmetic per job as colsum_stage2_kernel -> bit-identical results.
+struct ColsumJobs {
+  mmamd_colsum_job j[64];
+};
+__global__ __launch_bounds__(256) void colsum_stage2_batched_kernel(const ColsumJobs jobs) {
+  const mmamd_colsum_job& jb = jobs.j[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= jb.n) return;  // (whole workgroup: no barrier is skipped by part of it)
+  colsum_stage2_body(jb.part, jb.G, jb.n, jb.out0, jb.out1, jb.out2, jb.seg, blockIdx.x);
 }
 
 // column sums of x [rows, n] (bias gradients): stage 1.  Workgroup g owns rows [g*rpb, (g+1)*rpb); a thread owns one 16-byte column
@@ -437,7 +454,7 @@ using namespace mmamd;
 extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
                                    void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int d, float eps,
                                    mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(x && gamma && dy && dx && dgamma && dbeta && ws && rows > 0 && d > 0, MMAMD_E_BADARG, "layernorm_bwd: bad argument");
+  MMAMD_CHECK_ARG(x && gamma && dy && dx && ws && rows > 0 && d > 0 && (dgamma != nullptr) == (dbeta != nullptr), MMAMD_E_BADARG, "layernorm_bwd: bad argument");
   MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "layernorm_bwd: d=%d must be a multiple of 4 and <= 2048", d);
   hipStream_t st = (hipStream_t)stream;
   const int G = rows < 4 * 768 ? (rows + 3) / 4 : 768;  // 3 workgroups per CU; ws: (G + 1) * 3 * d floats
@@ -450,8 +467,27 @@ extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const voi
   // part layout [G][ns][d] = G rows of width ns*d: dgamma | dbeta | (column sums of dx)
   // (the three results go straight to their arrays: the three 3 KB device-to-device copies this used to end with were 150 of the 182
   //  copies of a CLIP training step, 0.7 ms of serialised 5 us operations)
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((ns * d + 31) / 32), dim3(256), 0, st, ws, G, ns * d, dgamma, dbeta, dx_colsum, d);
+  // dgamma == dbeta == NULL: the caller reduces the partials later (mmamd_colsum_stage2_batched: job {ws, G, ns * d, dgamma, dbeta, dx_colsum, seg = d})
+  if (dgamma != nullptr) hipLaunchKernelGGL(colsum_stage2_kernel, dim3((ns * d + 31) / 32), dim3(256), 0, st, ws, G, ns * d, dgamma, dbeta, dx_colsum, d);
   return launch_status("layernorm_bwd");
+}
+
+extern "C" int mmamd_colsum_stage2_batched(const mmamd_colsum_job* jobs, int njobs, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(njobs >= 0 && (jobs != nullptr || njobs == 0), MMAMD_E_BADARG, "colsum_stage2_batched: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += 64) {
+    ColsumJobs a;
+    const int nj = njobs - j0 < 64 ? njobs - j0 : 64;
+    int nmax = 0;
+    for (int i = 0; i < nj; ++i) {
+      const mmamd_colsum_job& jb = jobs[j0 + i];
+      MMAMD_CHECK_ARG(jb.part && jb.out0 && jb.G > 0 && jb.n > 0 && (jb.out1 == nullptr || jb.seg > 0), MMAMD_E_BADARG, "colsum_stage2_batched: bad job %d", j0 + i);
+      a.j[i] = jb;
+      if (jb.n > nmax) nmax = jb.n;
+    }
+    hipLaunchKernelGGL(colsum_stage2_batched_kernel, dim3((nmax + 31) / 32, nj), dim3(256), 0, st, a);
+  }
+  return launch_status("colsum_stage2_batched");
 }
 
 extern "C" int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream) {

@@ -21,7 +21,7 @@ __all__ = [
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "pack_w_frag", "debug_set_gemm_wp", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "attention_probs_fwd", "attention_probs_from_lse", "attention_probs_from_lse_supported", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
-    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
+    "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum_flush", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
     "attention_x_bwd", "gemm_bf16_grouped", "image_resample", "group_mean_normalize", "scale_normalize", "target_rank",
 ]
@@ -980,11 +980,17 @@ def contrastive_bwd(a: torch.Tensor, b: torch.Tensor, a_all: torch.Tensor, b_all
     return ga, gb, g_all, gs
 
 
+class _ColsumJob(C.Structure):  # mmamd_colsum_job (include/mmamd.h)
+    _fields_ = [("part", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p), ("out2", C.c_void_p), ("G", C.c_int), ("n", C.c_int), ("seg", C.c_int)]
+
+
 def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float,
-                  add: Optional[torch.Tensor] = None, want_bf16: bool = False, want_colsum: bool = False):
+                  add: Optional[torch.Tensor] = None, want_bf16: bool = False, want_colsum: bool = False, defer: Optional[list] = None):
     """(dx fp32 [rows,d] (+ add), dgamma [d], dbeta [d]) for y = LayerNorm(x) * gamma + beta; dy fp32 or bf16.  With
     want_bf16=True a bf16 copy of dx (written by the same kernel) is appended to the result, with want_colsum=True the column
-    sums of dx ([d] fp32: the bias gradient of the Linear that wrote into this residual stream) after that."""
+    sums of dx ([d] fp32: the bias gradient of the Linear that wrote into this residual stream) after that.
+    defer (a list): the kernel leaves its per-workgroup partials and appends the reduction job to the list; dgamma / dbeta / the column sums are
+    valid only after colsum_flush(defer) -- one launch for all the LayerNorm backward calls of a stack instead of one small launch each."""
     _chk(x, "x", torch.float32); _chk(gamma, "gamma", torch.float32); _chk(dy, "dy")
     d = x.shape[-1]
     rows = x.numel() // d
@@ -999,14 +1005,31 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: f
     ws = torch.empty((G + 1) * 3 * d, dtype=torch.float32, device=dev)
     dxb = torch.empty((rows, d), dtype=torch.bfloat16, device=dev) if want_bf16 else None
     cs = torch.empty(d, dtype=torch.float32, device=dev) if want_colsum else None
+    later = defer is not None
     check(_lib.lib().mmamd_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _dt(dy), _ptr(add), dx.data_ptr(), _ptr(dxb),
-                                         dg.data_ptr(), db.data_ptr(), _ptr(cs), ws.data_ptr(), rows, d, float(eps), _stream()), "mmamd_layernorm_bwd")
+                                         None if later else dg.data_ptr(), None if later else db.data_ptr(), _ptr(cs), ws.data_ptr(), rows, d,
+                                         float(eps), _stream()), "mmamd_layernorm_bwd")
+    if later:
+        defer.append((ws, G, (3 if want_colsum else 2) * d, dg, db, cs, d))  # (the tuple keeps the tensors alive until the flush)
     out = (dx, dg, db)
     if want_bf16:
         out += (dxb,)
     if want_colsum:
         out += (cs,)
     return out
+
+
+def colsum_flush(jobs: list) -> None:
+    """Reduce the partials every layernorm_bwd(..., defer=jobs) call left behind: one launch per 64 jobs (mmamd_colsum_stage2_batched), on the current
+    stream -- the same stream the deferring calls ran on."""
+    if not jobs:  # (None: the caller reduces at once; []: nothing parked)
+        return
+    arr = (_ColsumJob * len(jobs))()
+    for i, (ws, G, n, o0, o1, o2, seg) in enumerate(jobs):
+        arr[i].part, arr[i].out0, arr[i].out1, arr[i].out2 = ws.data_ptr(), o0.data_ptr(), o1.data_ptr(), _ptr(o2)
+        arr[i].G, arr[i].n, arr[i].seg = G, n, seg
+    check(_lib.lib().mmamd_colsum_stage2_batched(C.cast(arr, C.c_void_p), len(jobs), _stream()), "mmamd_colsum_stage2_batched")
+    jobs.clear()
 
 
 def colsum(x: torch.Tensor) -> torch.Tensor:

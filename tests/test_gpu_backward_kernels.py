@@ -88,6 +88,28 @@ def test_layernorm_backward_and_colsum():
         assert np.abs(host(dxs) - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
+def test_layernorm_backward_deferred_reduction_is_bit_identical():
+    """r05: the LayerNorm backward calls of a stack park their dgamma / dbeta / column-sum partials and ONE launch reduces all of them
+    (mmamd_colsum_stage2_batched) -- the same arithmetic per job as the immediate form."""
+    from multimodal_amd import ops
+
+    set_rng_seed(11)
+    cases = []
+    for rows, d, cs, bf_dy in ((517, 768, True, False), (64, 512, False, True), (3100, 128, True, True), (9, 2048, True, False)):
+        dy = torch.randn(rows, d).cuda()
+        cases.append((torch.randn(rows, d).cuda(), torch.randn(d).cuda(), dy.to(torch.bfloat16) if bf_dy else dy, torch.randn(rows, d).cuda(), cs))
+    want = [ops.layernorm_bwd(x, g, dy, 1e-5, add=add, want_bf16=True, want_colsum=cs) for x, g, dy, add, cs in cases]
+    pending = []
+    got = [ops.layernorm_bwd(x, g, dy, 1e-5, add=add, want_bf16=True, want_colsum=cs, defer=pending) for x, g, dy, add, cs in cases]
+    assert len(pending) == len(cases)
+    ops.colsum_flush(pending)  # one launch for the four jobs
+    assert pending == []
+    for w, o in zip(want, got):
+        assert len(w) == len(o)
+        for a, b in zip(w, o):
+            assert torch.equal(a, b)
+
+
 def test_activation_transpose_normalize_scatter_kernels():
     from multimodal_amd import ops
 

@@ -19,11 +19,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--attn-variant", type=int, default=0, help="mmamd_debug_set_attn_variant code (4000 = the two-kernel attention backward, 4001 = single pass, 4002 = fused two-role)")
     ap.add_argument("--gemm-gm", type=int, default=0, help="mmamd_debug_set_gemm_knob(0, gm): tile-order group (8 = the r03 order)")
+    ap.add_argument("--no-deferred-ln-reduce", action="store_true", help="A/B arm: every LayerNorm backward reduces its own dgamma / dbeta / column-sum partials (53 small launches per step) instead of one batched launch per stack")
     ap.add_argument("--no-fused-bias", action="store_true", help="A/B arm: bias gradients from the column-sum passes (the r04 form) instead of the wgrad GEMM's own pass")
     a = ap.parse_args()
     from multimodal_amd import _autograd, _lib
 
     _autograd._FUSED_BIAS_GRAD = not a.no_fused_bias
+    _autograd._DEFER_LN_REDUCE = not a.no_deferred_ln_reduce
 
     _lib.lib().mmamd_debug_set_attn_variant(a.attn_variant)
     _lib.lib().mmamd_debug_set_gemm_knob(0, a.gemm_gm)
@@ -63,7 +65,7 @@ def main():
     print(json.dumps({"workload": "CLIP ViT-B/16 training step (fwd + contrastive loss + bwd + SGD), synthetic", "batch": a.batch,
                       "ms_per_step": round(ms, 3), "pairs_per_s": round(a.batch / ms * 1e3, 1), "gflop_per_pair": gf,
                       "tflops": round(a.batch * gf / ms, 1), "mfma_frac": round(a.batch * gf / ms / 2500.0, 4),
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "losses": [round(x, 4) for x in losses]}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "deferred_ln_reduce": _autograd._DEFER_LN_REDUCE, "losses": [round(x, 4) for x in losses]}))
 
 
 if __name__ == "__main__":
