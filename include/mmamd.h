@@ -145,6 +145,14 @@ int mmamd_attention_x_bwd(const void* q, int ldq, int64_t q_batch_stride, const 
                           int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo, const float* lse,
                           void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim,
                           float scale, mmamd_stream_t stream);
+/* mmamd_attention_x_bwd for a forward that ran with `head_mask` (mmamd_attention_x_fwd_head_mask below: same mask, same element strides; the mask is a
+ * constant, it multiplies P in dV = P'^T dO and dP in dS = P (dP m - D)): training with the reference's head_mask (modules/layers/attention.py:236-237). */
+int mmamd_attention_x_bwd_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                    int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                    int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo, const float* lse,
+                                    void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim,
+                                    float scale, const float* head_mask, int64_t hm_stride_b, int64_t hm_stride_h, int64_t hm_stride_q,
+                                    int64_t hm_stride_k, mmamd_stream_t stream);
 /* mmamd_attention_x_fwd with the reference's `head_mask` (modules/layers/attention.py:190,236-237: `attn = attn * head_mask` after softmax and
  * dropout; what is returned as the attention weights and what multiplies V): fp32, any tensor that broadcasts to [b, h, q, k], given by its element
  * strides over those four dimensions (0 = broadcast).  Inference only. */

@@ -84,9 +84,12 @@ class StackConfig:
     def __init__(self, n_layers: int, n_head: int, B: int, S: int, causal: bool, act: int, eps1: Sequence[float], eps2: Sequence[float],
                  params_per_layer: int, to_canonical: Callable, from_canonical: Callable, key_mask: Optional[Tensor] = None,
                  keep_hidden: bool = False, drop: Optional[Sequence[float]] = None, seed: int = 0, norm_first: bool = True,
-                 full_mask: Optional[Tensor] = None):
+                 full_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None):
         self.n_layers, self.n_head, self.B, self.S, self.causal, self.act = n_layers, n_head, B, S, causal, act
         self.full_mask = full_mask  # uint8 [B or 1, S, S] (0 = masked): arbitrary attention masks go through the general attention kernels
+        # the reference's head_mask (modules/layers/attention.py:236-237): fp32, broadcastable to [B, H, S, S], multiplied into the probabilities after
+        # softmax (and dropout) in every layer of the stack; a constant (no gradient); general attention kernels, forward and backward
+        self.head_mask = head_mask
         self.norm_first = bool(norm_first)  # False: the reference's DEFAULT post-norm layers (modules/layers/transformer.py:56,118-132)
         # training-time dropout (stack_drop_spec): [] = none, else [p_branch, p_mlp, p_attn] + one stochastic-depth rate per layer (-1 = none)
         self.drop, self.seed = [float(v) for v in (drop or [])], int(seed)
@@ -192,7 +195,7 @@ def _saved_per_layer(norm_first: bool) -> int:
 
 def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: int, causal: bool, act: int, eps1: List[float],
                     eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int, norm_first: bool = True,
-                    full_mask: Optional[Tensor] = None) -> List[Tensor]:
+                    full_mask: Optional[Tensor] = None, head_mask: Optional[Tensor] = None) -> List[Tensor]:
     """Forward of N layers.  params: the 12 canonical fp32 tensors per layer.  Returns [x_L] + per layer
     [h1, qkv, att, lse, x_mid, h2, u, g] (+ [ff] for post-norm layers) + the inputs of layers 1 .. N-1 (layer 0's input is x0 itself).
     Pre-norm (reference transformer.py:96-116):  x_mid = x + attn(LN1 x);  x' = x_mid + mlp(LN2 x_mid)
@@ -216,7 +219,7 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
             inputs.append(x)
         h1 = ops.layernorm(x, g1, be1, eps1[li], out_dtype=bf) if norm_first else ops.convert(x, bf)
         qkv = ops.gemm_bf16(h1, Wqkv, bqkv)
-        att, lse = _attn_fwd_any(qkv, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
+        att, lse = _attn_fwd_any(qkv, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3, head_mask)
         pb, pm, grp = _drop_of(drop, li, S, x.shape[1])
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo): the projection without the residual, then ONE pass: mask, scale, add
             x_mid = ops.dropout(ops.gemm_bf16(att, Wo, bo, out_dtype=f32), pb, seed, 16 * li, residual=x, group=grp)
@@ -245,7 +248,7 @@ def _stack_fwd_impl(x0: Tensor, params: List[Tensor], n_head: int, B: int, S: in
     return [x] + saved + inputs + wt
 
 
-def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, norm_first=True, full_mask=None):
+def _stack_fwd_fake(x0, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, norm_first=True, full_mask=None, head_mask=None):
     n_layers = len(params) // 12
     M, d = x0.shape
     saved, inputs = [], []
@@ -271,14 +274,15 @@ _ACT_GRAD = {ops.ACT_QUICKGELU: ops.ACT_MUL_QUICKGELU_GRAD, ops.ACT_GELU_ERF: op
 
 def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: List[Tensor], n_head: int, B: int, S: int, causal: bool,
                     act: int, eps1: List[float], eps2: List[float], key_mask: Optional[Tensor], drop: List[float], seed: int,
-                    dhidden: List[Optional[Tensor]], norm_first: bool = True, full_mask: Optional[Tensor] = None) -> List[Tensor]:
+                    dhidden: List[Optional[Tensor]], norm_first: bool = True, full_mask: Optional[Tensor] = None,
+                    head_mask: Optional[Tensor] = None) -> List[Tensor]:
     """Backward of _stack_fwd_impl: saved = its outputs [1:].  Returns [dX0] + the 12 canonical gradients per layer.  dhidden (empty, or one
     entry per layer 1 .. N-1): gradients that arrived through the intermediate hidden states the forward handed out (None = unused)."""
     H = n_head
     n_layers = len(params) // 12
     ns = _saved_per_layer(norm_first)
     if not norm_first:
-        return _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, full_mask)
+        return _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, full_mask, head_mask)
     inputs = [x0] + list(saved[ns * n_layers:(ns + 1) * n_layers - 1])
     wt = saved[(ns + 1) * n_layers - 1:]  # bf16 transposes of (Wqkv, Wo, W1, W2) per layer, made by the forward's weight pack
     dX = dx_out
@@ -314,7 +318,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         # x_mid = x + att Wo^T + bo
         datt = dgrad_t(dxmb, WoT, bf)
         dWo = wgrad(dxmb, att)
-        dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
+        dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3, head_mask)
         # qkv = h1 Wqkv^T + bqkv
         dh1 = dgrad_t(dqkv, WqkvT, f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
@@ -332,26 +336,26 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
     return [dX] + grads
 
 
-def _attn_fwd_any(qkv, B, S, H, causal, key_mask, full_mask, pa, seed, site):
+def _attn_fwd_any(qkv, B, S, H, causal, key_mask, full_mask, pa, seed, site, head_mask=None):
     """(att, lse) of the self-attention of a stack layer: the packed-qkv flash kernels, or the general kernels when the probabilities carry
     dropout (FLAVA's SelfAttention(dropout): the kernel generates the Philox mask) or the caller gave an arbitrary [Sq, Sk] mask."""
-    if pa > 0 or full_mask is not None:
+    if pa > 0 or full_mask is not None or head_mask is not None:
         dm = qkv.shape[1] // 3
         lse = torch.empty((B, H, S), dtype=f32, device=qkv.device)
         att, _ = ops.attention_x_fwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], B, S, S, H, dm // H,
                                      ops.AttnMask(causal=causal, key_mask=key_mask, full=full_mask), lse=lse,
-                                     drop=(pa, seed, site) if pa > 0 else None)
+                                     drop=(pa, seed, site) if pa > 0 else None, head_mask=head_mask)
         return att, lse
     return ops.attention_fwd_train(qkv, B, S, H, causal, key_mask)
 
 
-def _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, pa, seed, site):
+def _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, pa, seed, site, head_mask=None):
     """dqkv of _attn_fwd_any."""
-    if pa > 0 or full_mask is not None:
+    if pa > 0 or full_mask is not None or head_mask is not None:
         dm = att.shape[1]
         dq_, dkv_ = ops.attention_x_bwd(qkv[:, :dm], qkv[:, dm:2 * dm], qkv[:, 2 * dm:], att, datt, lse, B, S, S, H, dm // H,
                                         ops.AttnMask(causal=causal, key_mask=key_mask, full=full_mask),
-                                        drop=(pa, seed, site) if pa > 0 else None)
+                                        drop=(pa, seed, site) if pa > 0 else None, head_mask=head_mask)
         dqkv = torch.empty((B * S, 3 * dm), dtype=bf, device=att.device)  # [dq | dk | dv]: placement copies of the two kernel outputs
         dqkv[:, :dm].copy_(dq_)
         dqkv[:, dm:].copy_(dkv_)
@@ -359,7 +363,8 @@ def _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, pa,
     return ops.attention_bwd(qkv, att, datt, lse, B, S, H, causal, key_mask)
 
 
-def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, full_mask=None) -> List[Tensor]:
+def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, full_mask=None,
+                        head_mask=None) -> List[Tensor]:
     """Backward of the post-norm layers (reference transformer.py:118-132): y = LN2(ff), ff = x1 + mlp(x1), x1 = LN1(a), a = x + attn(x).
     The same kernels as the pre-norm backward in another order: each LayerNorm backward now sits at the END of its block, and the two
     residual sums are epilogues of the dgrad GEMMs (dx1 = dff + du W1, dx = da + dqkv Wqkv)."""
@@ -392,7 +397,7 @@ def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, ep
             dbo = ops.colsum(dab)
         datt = dgrad_t(dab, WoT, bf)
         dWo = wgrad(dab, att)
-        dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3)
+        dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3, head_mask)
         dX = dgrad_t(dqkv, WqkvT, f32, ops.ACT_NONE, da)  # da + dqkv Wqkv
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
         if li > 0 and dhidden and dhidden[li - 1] is not None:
@@ -405,15 +410,16 @@ def _stack_bwd_postnorm(dx_out, x0, saved, params, n_head, B, S, causal, act, ep
     return [dX] + grads
 
 
-def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, norm_first=True, full_mask=None):
+def _stack_bwd_fake(dx_out, x0, saved, params, n_head, B, S, causal, act, eps1, eps2, key_mask, drop, seed, dhidden, norm_first=True, full_mask=None,
+                    head_mask=None):
     return [torch.empty_like(x0)] + [torch.empty_like(p) for p in params]
 
 
 from ._custom_op import define as _define  # noqa: E402
 
 _STACK_SCALARS = "int n_head, int B, int S, bool causal, int act, float[] eps1, float[] eps2, Tensor? key_mask, float[] drop, int seed"
-stack_fwd_op = _define("encoder_stack_fwd", f"(Tensor x0, Tensor[] params, {_STACK_SCALARS}, bool norm_first=True, Tensor? full_mask=None) -> Tensor[]", _stack_fwd_impl, _stack_fwd_fake)
-stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}, Tensor?[] dhidden, bool norm_first=True, Tensor? full_mask=None) -> Tensor[]",
+stack_fwd_op = _define("encoder_stack_fwd", f"(Tensor x0, Tensor[] params, {_STACK_SCALARS}, bool norm_first=True, Tensor? full_mask=None, Tensor? head_mask=None) -> Tensor[]", _stack_fwd_impl, _stack_fwd_fake)
+stack_bwd_op = _define("encoder_stack_bwd", f"(Tensor dx_out, Tensor x0, Tensor[] saved, Tensor[] params, {_STACK_SCALARS}, Tensor?[] dhidden, bool norm_first=True, Tensor? full_mask=None, Tensor? head_mask=None) -> Tensor[]",
                        _stack_bwd_impl, _stack_bwd_fake)
 
 
@@ -429,7 +435,7 @@ class EncoderStackFn(torch.autograd.Function):
         canon: List[Tensor] = []
         for li in range(cfg.n_layers):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
-        outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop, cfg.seed, cfg.norm_first, cfg.full_mask)
+        outs = stack_fwd_op(x, canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop, cfg.seed, cfg.norm_first, cfg.full_mask, cfg.head_mask)
         ns = _saved_per_layer(cfg.norm_first)
         ctx.save_for_backward(x, *outs[1:], *params)
         ctx.cfg, ctx.nparam = cfg, len(params)
@@ -462,7 +468,7 @@ class EncoderStackFn(torch.autograd.Function):
             canon += list(cfg.to_canonical([c32(p) for p in params[cfg.ppl * li:cfg.ppl * (li + 1)]]))
         dhidden = list(dmid) if any(d is not None for d in dmid) else []
         outs = stack_bwd_op(dX, x0, list(saved), canon, cfg.n_head, cfg.B, cfg.S, cfg.causal, cfg.act, cfg.eps1, cfg.eps2, cfg.key_mask, cfg.drop,
-                            cfg.seed, dhidden, cfg.norm_first, cfg.full_mask)
+                            cfg.seed, dhidden, cfg.norm_first, cfg.full_mask, cfg.head_mask)
         grads: List[Optional[Tensor]] = [None] * nparam
         for li in range(cfg.n_layers):
             grads[cfg.ppl * li:cfg.ppl * (li + 1)] = cfg.from_canonical(list(outs[1 + 12 * li:13 + 12 * li]))

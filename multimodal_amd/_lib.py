@@ -96,6 +96,8 @@ PROTOTYPES = {
                                             _i, _i, _i, _f, _f, C.c_uint64, C.c_uint32, _vp]),
     "mmamd_attention_x_bwd": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
                                     _i, _i, _i, _f, _vp]),
+    "mmamd_attention_x_bwd_head_mask": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
+                                              _i, _i, _i, _f, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mmamd_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_coca_text_embed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mmamd_coca_text_mask": (_i, [_vp, _i, _i64, _vp, _i, _i, _vp]),

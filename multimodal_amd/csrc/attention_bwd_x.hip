@@ -23,9 +23,13 @@ struct AttnXB {
   float scale;
   AttnDrop drop;  // the forward's dropout on the probabilities (thresh = 0: none): O = P' V with P' = P keep / (1 - p), so
                   // dV = P'^T dO, dP = (dO V^T) keep / (1 - p), dS = P (dP - D) with D = sum dO O (unchanged form)
+  // the forward's head_mask (reference modules/layers/attention.py:236-237: attn = attn * head_mask AFTER softmax and dropout; a constant): it multiplies
+  // exactly where the dropout factor does -- P' = P m, dV = P'^T dO, dP = (dO V^T) m, D unchanged.  fp32, element strides of its [b, h, q, k] broadcast
+  const float* hmask = nullptr;
+  long long hm_sb = 0, hm_sh = 0, hm_sq = 0, hm_sk = 0;
 };
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool HM>
 __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p) {
   constexpr int KS = DH + 8;
   constexpr int CPR = DH / 8;
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
           const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2) : 0.f;
           float dpr = dp[r];
           if constexpr (DROP) dpr = rr.v[j] >= p.drop.thresh ? dpr * p.drop.scale : 0.f;
+          if constexpr (HM) dpr *= ok ? p.hmask[(long long)b * p.hm_sb + (long long)h * p.hm_sh + (long long)qc * p.hm_sq + (long long)key * p.hm_sk] : 0.f;
           e[j] = pr * (dpr - Dq);
         }
         bf16x2 p0, p1;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
   }
 }
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool HM>
 __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p) {
   constexpr int KS = DH + 8;
   constexpr int CPR = DH / 8;
@@ -272,6 +277,11 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p
                 pd = keep ? pr * p.drop.scale : 0.f;
                 dpr = keep ? dpr * p.drop.scale : 0.f;
               }
+              if constexpr (HM) {
+                const float m = ok ? p.hmask[(long long)b * p.hm_sb + (long long)h * p.hm_sh + (long long)q * p.hm_sq + (long long)key * p.hm_sk] : 0.f;
+                pd *= m;
+                dpr *= m;
+              }
               e[j] = pd;
               f[j] = pr * (dpr - Dqs[ql]);
             }
@@ -321,14 +331,14 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p
   }
 }
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool HM = false>
 static int launch_x_bwd(const AttnXB& p, int B, hipStream_t st) {
   const int SP = ((p.Sk + 31) / 32) * 32;
   const int smem1 = 2 * SP * (DH + 8) * 2 + DH * (SP + 4) * 2 + SP;
   constexpr int smem2 = 2 * 128 * (DH + 8) * 2 + 2 * DH * 132 * 2 + 2 * 128 * 4;
   if (smem1 > 160 * 1024) { set_error("attention_x_bwd: Sk=%d with head_dim=%d needs %d B of LDS (> 160 KiB)", p.Sk, DH, smem1); return MMAMD_E_UNSUPPORTED; }
-  auto k1 = attention_x_bwd_dq_kernel<DH, DROP>;
-  auto k2 = attention_x_bwd_dkv_kernel<DH, DROP>;
+  auto k1 = attention_x_bwd_dq_kernel<DH, DROP, HM>;
+  auto k2 = attention_x_bwd_dkv_kernel<DH, DROP, HM>;
   // per-device opt-in to > 64 KiB dynamic LDS; the dQ kernel's size varies with Sk, so it opts in to the 160 KiB maximum once
   static unsigned long long m1 = 0, m2 = 0;
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(k1), smem1 > 64 * 1024 ? 160 * 1024 : 0, m1)) return rc_attr;
@@ -346,7 +356,7 @@ static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
                                 int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
                                 int causal, const void* out, const void* dout, int ldo, const float* lse, void* dq, int lddq, void* dk, void* dv,
                                 int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed,
-                                uint32_t site, mmamd_stream_t stream);
+                                uint32_t site, mmamd_stream_t stream, const float* head_mask = nullptr, const int64_t* hm_strides = nullptr);
 
 extern "C" int mmamd_attention_x_bwd(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                      int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
@@ -368,11 +378,24 @@ extern "C" int mmamd_attention_x_bwd_dropout(const void* q, int ldq, int64_t q_b
                               dout, ldo, lse, dq, lddq, dk, dv, lddk, lddv, B, Sq, Sk, H, head_dim, scale, drop_p, seed, site, stream);
 }
 
+extern "C" int mmamd_attention_x_bwd_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                               int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                               int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo,
+                                               const float* lse, void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq,
+                                               int Sk, int H, int head_dim, float scale, const float* head_mask, int64_t hm_stride_b,
+                                               int64_t hm_stride_h, int64_t hm_stride_q, int64_t hm_stride_k, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(head_mask != nullptr && hm_stride_b >= 0 && hm_stride_h >= 0 && hm_stride_q >= 0 && hm_stride_k >= 0, MMAMD_E_BADARG,
+                  "attention_x_bwd: head_mask must be given with non-negative element strides");
+  const int64_t hms[4] = {hm_stride_b, hm_stride_h, hm_stride_q, hm_stride_k};
+  return attention_x_bwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              dout, ldo, lse, dq, lddq, dk, dv, lddk, lddv, B, Sq, Sk, H, head_dim, scale, 0.f, 0, 0, stream, head_mask, hms);
+}
+
 static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                 int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
                                 int causal, const void* out, const void* dout, int ldo, const float* lse, void* dq, int lddq, void* dk, void* dv,
                                 int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed,
-                                uint32_t site, mmamd_stream_t stream) {
+                                uint32_t site, mmamd_stream_t stream, const float* head_mask, const int64_t* hm_strides) {
   MMAMD_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && B >= 0 && Sq > 0 && Sk > 0 && H > 0, MMAMD_E_BADARG,
                   "attention_x_bwd: bad argument");
   MMAMD_CHECK_ARG(head_dim == 64 || head_dim == 96, MMAMD_E_UNSUPPORTED, "attention_x_bwd: head_dim=%d (64 and 96 are built)", head_dim);
@@ -398,6 +421,11 @@ static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
   p.drop.k0 = (uint32_t)seed; p.drop.k1 = (uint32_t)(seed >> 32); p.drop.site = site; p.drop.scale = 1.0f / (1.0f - drop_p);
   MMAMD_CHECK_ARG(lddk == lddv, MMAMD_E_BADARG, "attention_x_bwd: dk and dv must share their row pitch");
   hipStream_t st = (hipStream_t)stream;
+  if (head_mask != nullptr) {  // (with dropout as well: not built -- the forward refuses the combination too)
+    MMAMD_CHECK_ARG(p.drop.thresh == 0, MMAMD_E_UNSUPPORTED, "attention_x_bwd: head_mask together with dropout on the probabilities is not built");
+    p.hmask = head_mask; p.hm_sb = hm_strides[0]; p.hm_sh = hm_strides[1]; p.hm_sq = hm_strides[2]; p.hm_sk = hm_strides[3];
+    return head_dim == 64 ? launch_x_bwd<64, false, true>(p, B, st) : launch_x_bwd<96, false, true>(p, B, st);
+  }
   if (p.drop.thresh != 0) return head_dim == 64 ? launch_x_bwd<64, true>(p, B, st) : launch_x_bwd<96, true>(p, B, st);
   return head_dim == 64 ? launch_x_bwd<64, false>(p, B, st) : launch_x_bwd<96, false>(p, B, st);
 }

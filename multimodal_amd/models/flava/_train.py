@@ -151,18 +151,21 @@ def _from_canonical(g: List[Tensor]):
             dg2, dbe2]
 
 
-def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool, want_probs: bool = False):
+def run_encoder(encoder, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool, want_probs: bool = False, head_mask: Optional[Tensor] = None):
     """Differentiable pass through a flava.TransformerEncoder (all its layers as ONE autograd node)."""
-    return run_layers(list(encoder.layer), encoder.training, x, key_mask, keep_hidden, want_probs)
+    return run_layers(list(encoder.layer), encoder.training, x, key_mask, keep_hidden, want_probs, head_mask=head_mask)
 
 
-def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool, want_probs: bool = False):
+def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], keep_hidden: bool, want_probs: bool = False,
+               head_mask: Optional[Tensor] = None):
     """Differentiable pass through a list of flava TransformerEncoderLayers (a whole encoder, or ONE stand-alone / wrapped layer).  Returns (x_L [B,S,d], hidden states or None, attention probabilities or None).
     keep_hidden: ALL hidden states, attached to the graph (the input, the input of every further layer, the result) like the reference's
     training forward (models/flava/transformer.py:254-259).  want_probs: the per-layer attention probabilities [B,H,S,S] fp32, recomputed from
     each layer's saved projections (and, unmasked, its saved log-sum-exp: mmamd_attention_probs_from_lse; else the inference kernel
     mmamd_attention_probs_fwd) -- values as in eval mode, NOT differentiable (the
-    reference's are; nothing in its models or losses differentiates through returned attention maps)."""
+    reference's are; nothing in its models or losses differentiates through returned attention maps).
+    head_mask (reference layers/attention.py:236-237; the same mask for every layer, flava/transformer.py:268-275): multiplied into the probabilities
+    after softmax in the forward and the backward kernels (a constant: no gradient of its own); the returned maps carry it too."""
     from ...modules.layers.mlp import fused_activation_code
 
     B, S, d = x.shape
@@ -187,8 +190,13 @@ def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], ke
     # training-time dropout (reference flava/transformer.py: attention_dropout / feedforward_dropout on the branches, the MLP's hidden dropout,
     # and SelfAttention(attn_dropout) on the attention probabilities -- the general attention kernels then carry the Philox mask)
     drop, seed = stack_drop_spec(layers, attn_p=lambda l: l.attention.attn.attn_dropout, training=training)
+    hm = None
+    if head_mask is not None:
+        from ...modules.layers.attention import head_mask_f32
+
+        hm = head_mask_f32(head_mask)
     cfg = StackConfig(len(layers), layers[0].attention.n_head, B, S, False, act, eps1, eps2, 16, _to_canonical,
-                      _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden, drop=drop, seed=seed, norm_first=norm_first.pop())
+                      _from_canonical, key_mask=key_mask, keep_hidden=keep_hidden, drop=drop, seed=seed, norm_first=norm_first.pop(), head_mask=hm)
     cfg.keep_hidden = keep_hidden or want_probs
     xc = x if x.is_contiguous() else x.contiguous()
     res = EncoderStackFn.apply(xc.view(B * S, d), cfg, *params)
@@ -197,7 +205,11 @@ def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], ke
     probs = None
     if want_probs:
         H = cfg.n_head
-        if key_mask is None and ops.attention_probs_from_lse_supported(S) and len(cfg.lse) == len(cfg.qkv):
+        if hm is not None:  # the masked maps, as the inference path returns them: one general-attention pass per layer with the probabilities written
+            d3 = cfg.qkv[0].shape[1] // 3
+            probs = [ops.attention_x_fwd(q[:, :d3], q[:, d3:2 * d3], q[:, 2 * d3:], B, S, S, H, d3 // H, ops.AttnMask(key_mask=key_mask),
+                                         want_probs=True, head_mask=hm)[1] for q in cfg.qkv]
+        elif key_mask is None and ops.attention_probs_from_lse_supported(S) and len(cfg.lse) == len(cfg.qkv):
             # one pass per layer from the saved projections and log-sum-exp rows: exp2(scale q.k - lse), no second attention
             probs = [ops.attention_probs_from_lse(q, l, B, S, H) for q, l in zip(cfg.qkv, cfg.lse)]
         else:

@@ -122,8 +122,6 @@ class TransformerEncoderLayer(nn.Module):
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
             # differentiable stand-alone layer (a one-layer EncoderStackFn node, models/flava/_train.py): what a layer wrapped by FSDP /
             # checkpoint_wrapper (reference examples/flava/native/train.py:141-206) or a user's own loop over layers runs in training
-            if head_mask is not None:
-                raise ops.MmamdError("head_mask is an inference-time feature on the MI355X path (the attention backward kernels do not carry it): call .eval() / no_grad")
             if hidden_states.dim() != 3 or hidden_states.dtype != torch.float32:
                 raise ops.MmamdError("encoder layers on the MI355X path take fp32 [b, seq, c] hidden states in training")
             from ...schedule import get_schedule
@@ -131,7 +129,8 @@ class TransformerEncoderLayer(nn.Module):
 
             B, S, _ = hidden_states.shape
             km = key_mask_from_attention_mask(attention_mask, B, S)
-            y, _, probs = run_layers([self], self.training, hidden_states, km, False, return_attn_weights and get_schedule().train_attentions)
+            y, _, probs = run_layers([self], self.training, hidden_states, km, False, return_attn_weights and get_schedule().train_attentions,
+                                     head_mask=head_mask)
             return (y, probs[0] if probs is not None else None) if return_attn_weights else y
         shape = hidden_states.shape
         d = shape[-1]
@@ -194,8 +193,6 @@ class TransformerEncoder(nn.Module):
             if return_attn_weights and any(p is None for p in all_self_attentions):
                 all_self_attentions = None  # (schedule.train_attentions = False)
             return TransformerOutput(last_hidden_state=x, hidden_states=all_hidden_states, attentions=all_self_attentions)
-        if head_mask is not None and (wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad)):
-            raise ops.MmamdError("head_mask is an inference-time feature on the MI355X path (the attention backward kernels do not carry it): call .eval() / no_grad")
         if wants_grad(self) or (torch.is_grad_enabled() and hidden_states.requires_grad):
             # differentiable forward (models/flava/_train.py): every hidden state attached to the graph, attention probabilities as values
             # (schedule.train_attentions = False skips their recomputation: attentions = None, the r03 behaviour)
@@ -204,7 +201,7 @@ class TransformerEncoder(nn.Module):
 
             km = key_mask_from_attention_mask(attention_mask, B, S)
             want_probs = return_attn_weights and get_schedule().train_attentions
-            x, hidden, probs = run_encoder(self, hidden_states, km, return_hidden_states, want_probs)
+            x, hidden, probs = run_encoder(self, hidden_states, km, return_hidden_states, want_probs, head_mask=head_mask)
             if self.final_layer_norm is not None:
                 x = self.final_layer_norm(x)
             return TransformerOutput(last_hidden_state=x, hidden_states=hidden, attentions=probs)

@@ -496,9 +496,9 @@ def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse:
 
 def attention_x_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int,
                     Sq: int, Sk: int, H: int, head_dim: int, mask: Optional[AttnMask] = None, shared_q: bool = False,
-                    drop: Optional[Tuple[float, int, int]] = None):
-    """Backward of attention_x_fwd (drop: the forward's (p, seed, site)).  Returns (dq bf16 [B*Sq, D] — per sample even when the queries are shared —, dkv bf16 [B*Sk, 2D]
-    = [dK | dV])."""
+                    drop: Optional[Tuple[float, int, int]] = None, head_mask: Optional[torch.Tensor] = None):
+    """Backward of attention_x_fwd (drop: the forward's (p, seed, site); head_mask: the forward's fp32 head_mask).  Returns (dq bf16 [B*Sq, D] — per sample
+    even when the queries are shared —, dkv bf16 [B*Sk, 2D] = [dK | dV])."""
     _mat_view(q, "q"); _mat_view(k, "k"); _mat_view(v, "v"); _mat_view(out, "out"); _mat_view(dout, "dout")
     _chk(lse, "lse", torch.float32)
     D = H * head_dim
@@ -513,7 +513,13 @@ def attention_x_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
     args = (q.data_ptr(), q.stride(0), 0 if shared_q else Sq * q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
             Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, mask.causal_flags, out.data_ptr(), dout.data_ptr(), out.stride(0), lse.data_ptr(),
             dq.data_ptr(), D, dkv.data_ptr(), dkv.data_ptr() + 2 * D, 2 * D, 2 * D, B, Sq, Sk, H, head_dim, 1.0 / math.sqrt(float(head_dim)))
-    if drop is not None and drop[0] > 0:
+    if head_mask is not None:
+        if drop is not None and drop[0] > 0:
+            raise MmamdError("attention_x_bwd: head_mask with training-time dropout is not implemented")
+        _chk(head_mask, "head_mask", torch.float32)
+        hm = head_mask.expand(B, H, Sq, Sk)  # (a view: broadcast dimensions get stride 0)
+        check(_lib.lib().mmamd_attention_x_bwd_head_mask(*args, hm.data_ptr(), *[int(x) for x in hm.stride()], _stream()), "mmamd_attention_x_bwd_head_mask")
+    elif drop is not None and drop[0] > 0:
         check(_lib.lib().mmamd_attention_x_bwd_dropout(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF, _stream()),
               "mmamd_attention_x_bwd_dropout")
     else:

@@ -4,6 +4,8 @@ python -m tests.golden.make_golden_head_mask  ->  head_mask.npz
           [3,1,7,7] one, each with a key-padding attention_mask; output + returned probabilities
   enc.*   flava TransformerEncoder (2 pre-norm layers, 128 wide, 2 heads) with a per-head mask [1,2,1,1] (reference transformer.py:268-275: the same
           head_mask for every layer): last hidden state, hidden states, attentions
+  head_mask_grad.npz (r05): the same encoder in TRAIN mode (all dropout rates 0) with a real-valued [2,2,9,9] head_mask and the key-padding mask:
+          loss = sum(last_hidden_state * w) -> the gradient of the input and of every parameter (torch autograd of the reference)
 """
 from __future__ import annotations
 
@@ -62,6 +64,26 @@ def main():
         st.update({"enc.sd." + k: v for k, v in sd_np(enc).items()})
     np.savez_compressed(OUT / "head_mask.npz", **st)
     print("head_mask.npz", {k: v.shape for k, v in st.items() if ".sd." not in k})
+
+    # ---- gradients through a head-masked encoder (training mode)
+    seed(63)
+    enc = TransformerEncoder(n_layer=2, d_model=128, n_head=2, dim_feedforward=256, activation=nn.GELU, norm_first=True).train()
+    g = torch.Generator().manual_seed(23)
+    h = torch.randn(2, 9, 128, generator=g).requires_grad_(True)
+    am = (torch.rand(2, 1, 1, 9, generator=g) > 0.2).long()
+    am[..., 0] = 1
+    hm = torch.rand(2, 2, 9, 9, generator=g)
+    hm[0, 1] = 0.0  # one head of one sample pruned outright
+    w = torch.randn(2, 9, 128, generator=g)
+    o = enc(h, attention_mask=am, head_mask=hm, return_attn_weights=True, return_hidden_states=True)
+    loss = (o.last_hidden_state * w).sum()
+    loss.backward()
+    sg = {"x": tnp(h), "mask": tnp(am), "hm": tnp(hm), "w": tnp(w), "last": tnp(o.last_hidden_state), "loss": tnp(loss), "dx": tnp(h.grad),
+          "attn": np.stack([tnp(t) for t in o.attentions])}
+    sg.update({"sd." + k: v for k, v in sd_np(enc).items()})
+    sg.update({"g." + k: tnp(p.grad) for k, p in enc.named_parameters()})
+    np.savez_compressed(OUT / "head_mask_grad.npz", **sg)
+    print("head_mask_grad.npz", float(loss), {k: v.shape for k, v in sg.items() if k.startswith("g.")}.__len__(), "parameter gradients")
 
 
 if __name__ == "__main__":

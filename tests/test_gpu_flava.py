@@ -799,7 +799,7 @@ def test_head_mask_vs_reference_fixture(golden):
     """VERDICT r03 missing #6, last item: `head_mask` of the reference's scaled_dot_product_attention (modules/layers/attention.py:190,236-237) -- multiplied
     into the probabilities after the softmax; what is returned and what multiplies V.  Fixtures from the reference (tests/golden/make_golden_head_mask.py):
     MultiHeadAttention with a full [b, h, q, k] 0/1 mask, a per-head [1, h, 1, 1] mask and a real-valued [b, 1, q, k] one, each under a key-padding
-    attention_mask; FLAVA's TransformerEncoder with a per-head mask on every layer (hidden states and attentions).  Training with it raises."""
+    attention_mask; FLAVA's TransformerEncoder with a per-head mask on every layer (hidden states and attentions)."""
     from torch import nn
 
     from multimodal_amd.models.flava.transformer import TransformerEncoder
@@ -834,9 +834,7 @@ def test_head_mask_vs_reference_fixture(golden):
         assert np.abs(host(o.attentions[i]) - z["enc.attn"][i]).max() <= 5e-3, i
     layer_out = enc.layer[0](t("enc.x"), attention_mask=t("enc.mask"), head_mask=t("enc.hm"))
     assert np.abs(host(layer_out) - z["enc.hidden"][1]).max() <= HID_TOL
-    enc.train()
-    with torch.enable_grad(), pytest.raises(ops_error()):
-        enc(t("enc.x").requires_grad_(True), head_mask=t("enc.hm"))
+    # (training with head_mask: tests/test_gpu_layer_grad.py::test_head_mask_in_training_matches_the_reference_gradients)
 
 
 @torch.no_grad()

@@ -183,3 +183,51 @@ def test_hooked_layers_are_called_one_by_one_with_the_same_results(family):
         e1, e2 = call(enc, x), call(hooked, x)
     assert fired == list(range(len(hooked.layer)))
     assert float((e1.last_hidden_state - e2.last_hidden_state).abs().max()) <= 1e-5 * float(e1.last_hidden_state.abs().max())
+
+
+def test_head_mask_in_training_matches_the_reference_gradients(golden):
+    """r05: the reference's `head_mask` while TRAINING (modules/layers/attention.py:236-237: multiplied into the probabilities
+    after softmax and dropout; flava/transformer.py:268-275: the same mask for every layer).  The general attention kernels carry it in the forward
+    and in both backward kernels (P' = P m in dV, dP m in dS).  Fixture: tests/golden/make_golden_head_mask.py -> head_mask_grad.npz -- a 2-layer
+    pre-norm FLAVA encoder in train mode, real-valued [2, 2, 9, 9] mask with one head of one sample pruned, key-padding mask; the input gradient and
+    all 32 parameter gradients from the reference's torch autograd; also through stand-alone layers (one autograd node per layer)."""
+    from multimodal_amd.models.flava.transformer import TransformerEncoder
+
+    z = golden("head_mask_grad.npz")
+    t = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    for per_layer in (False, True):
+        enc = TransformerEncoder(n_layer=2, d_model=128, n_head=2, dim_feedforward=256, activation=torch.nn.GELU, norm_first=True)
+        enc.load_state_dict({k[len("sd."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}, strict=True)
+        enc = enc.cuda().train()
+        x = t("x").requires_grad_(True)
+        if per_layer:  # a user's own loop over the layers: every layer is its own autograd node
+            h = x
+            for layer in enc.layer:
+                h = layer(h, attention_mask=t("mask"), head_mask=t("hm"))
+            last, attn = h, None
+        else:
+            o = enc(x, attention_mask=t("mask"), head_mask=t("hm"), return_attn_weights=True, return_hidden_states=True)
+            last, attn = o.last_hidden_state, o.attentions
+        loss = (last * t("w")).sum()
+        loss.backward()
+        assert abs(float(loss) - float(z["loss"])) <= 2e-2 * max(1.0, abs(float(z["loss"])))
+        assert np.abs(host(last) - z["last"]).max() <= 3e-2
+        if attn is not None:  # the returned maps carry the mask (values, detached)
+            for i in range(2):
+                assert np.abs(host(attn[i]) - z["attn"][i]).max() <= 5e-3, i
+            assert float(host(attn[0])[0, 1].max()) == 0.0  # the pruned head of sample 0
+        ref_dx = z["dx"].astype(np.float64)
+        assert np.abs(host(x.grad) - ref_dx).max() <= 6e-2 * np.abs(ref_dx).max()
+        gscale = max(float(np.abs(z["g." + k]).max()) for k, _ in enc.named_parameters())
+        worst = ("", 0.0)
+        for k, p in enc.named_parameters():
+            ref = z["g." + k].astype(np.float64)
+            got = host(p.grad)
+            if np.abs(ref).max() < 1e-6 * gscale:  # key biases: mathematically zero (see _check)
+                assert k.endswith("key.bias") and np.abs(got).max() <= 1e-3 * gscale, (k, np.abs(got).max())
+                continue
+            rel = np.abs(got - ref).max() / np.abs(ref).max()
+            rms = np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-12)
+            assert rel <= 6e-2 and rms <= 3e-2, (per_layer, k, rel, rms)
+            worst = (k, rel) if rel > worst[1] else worst
+        print("head_mask training, per_layer =", per_layer, "worst max-rel", worst)
