@@ -54,6 +54,11 @@ int mmamd_stream_cus(mmamd_stream_t stream);
 int mmamd_stream_set_cus(mmamd_stream_t stream, int cus);
 int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks, mmamd_stream_t stream);
 
+/* --- launch counters: how many times the launcher named `what` (the string its errors carry: "attention_probs_lse", "attention_ring",
+ * "gemm_bf16_splitk", "layernorm_bwd", "colsum_stage2_batched", ...) has enqueued since the library was loaded.  The A/B tools assert on the difference
+ * around each arm that the knob they flipped took effect (no profiler needed). */
+unsigned long long mmamd_debug_launch_count(const char* what);
+
 /* --- timing helper for bench.py: HIP events on the SAME stream the kernels run on ------------
  * mmamd_timer_create returns an opaque handle (two hipEvents); start/stop record on `stream`;
  * elapsed_ms synchronises on the stop event (host-side call, not capturable). */

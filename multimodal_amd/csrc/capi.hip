@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -29,6 +30,27 @@ __global__ void cu_census_kernel(int* __restrict__ out, long long spin) {
     out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
   }
   while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+}
+
+// launch counters: one slot per launcher name (string literals: compared by pointer first, by content on a miss), relaxed atomics -- a launch costs one
+// pointer scan of <= 96 slots
+struct LaunchSlot {
+  std::atomic<const char*> name{nullptr};
+  std::atomic<unsigned long long> n{0};
+};
+static LaunchSlot g_launch_slots[96];
+void count_launch(const char* what) {
+  for (auto& s : g_launch_slots) {
+    const char* cur = s.name.load(std::memory_order_acquire);
+    if (cur == what || (cur != nullptr && strcmp(cur, what) == 0)) { s.n.fetch_add(1, std::memory_order_relaxed); return; }
+    if (cur == nullptr) {
+      const char* expected = nullptr;
+      if (s.name.compare_exchange_strong(expected, what, std::memory_order_acq_rel) || strcmp(expected, what) == 0) {
+        s.n.fetch_add(1, std::memory_order_relaxed);
+        return;
+      }
+    }
+  }
 }
 
 void set_error(const char* fmt, ...) {
@@ -122,4 +144,13 @@ extern "C" int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks,
   MMAMD_CHECK_ARG(out && blocks > 0, MMAMD_E_BADARG, "cu_census: bad argument");
   hipLaunchKernelGGL(mmamd::cu_census_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, out, spin_ticks);
   return mmamd::launch_status("cu_census");
+}
+
+extern "C" unsigned long long mmamd_debug_launch_count(const char* what) {
+  if (what == nullptr) return 0;
+  for (auto& s : mmamd::g_launch_slots) {
+    const char* cur = s.name.load(std::memory_order_acquire);
+    if (cur != nullptr && strcmp(cur, what) == 0) return s.n.load(std::memory_order_relaxed);
+  }
+  return 0;
 }

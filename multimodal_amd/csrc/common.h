@@ -34,7 +34,11 @@ void set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+// per-launcher launch counters (mmamd_debug_launch_count): how an A/B tool checks that its knob took effect without a profiler -- VERDICT r04 hygiene
+void count_launch(const char* what);
+
 inline int launch_status(const char* what) {
+  count_launch(what);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: %s", what, hipGetErrorString(e));

@@ -19,7 +19,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
 __all__ = [
     "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
-    "convert", "set_gemm_variant", "pack_w_frag", "debug_set_gemm_wp", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "attention_probs_fwd", "attention_probs_from_lse", "attention_probs_from_lse_supported", "key_mask", "bert_embed_ln", "flava_image_embed",
+    "convert", "set_gemm_variant", "pack_w_frag", "debug_set_gemm_wp", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "launch_count", "attention_probs_fwd", "attention_probs_from_lse", "attention_probs_from_lse_supported", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
     "AttnMask", "contrastive_bwd", "attention_fwd_train", "attention_bwd", "layernorm_bwd", "colsum_flush", "colsum", "act_fwd", "act_bwd", "activation", "gemm_bf16_dual",
     "transpose_to_bf16", "l2_normalize_bwd", "scatter_add_rows_", "f32_gemm_strided", "gemm_bf16_splitk", "gemm_bf16_tn_splitk", "cross_entropy_bwd", "bicubic_pos_embed", "offset_position_ids", "mask_labels_", "relu_bwd", "conv_gemm_bf16", "dalle_stem_im2col", "dalle_maxpool2", "dalle_argmax", "dalle_pack", "row_softmax_",
@@ -60,6 +60,12 @@ def _stream() -> int:
     # (include/mmamd.h: mmamd_clear_last_hip_error) that the entry point's launch check would otherwise report as its own
     _lib.lib().mmamd_clear_last_hip_error()
     return torch.cuda.current_stream().cuda_stream
+
+
+def launch_count(what: str) -> int:
+    """How many times the launcher named `what` has enqueued since the library was loaded (mmamd_debug_launch_count): the A/B tools assert on the
+    difference around an arm that the knob they flipped took effect."""
+    return int(_lib.lib().mmamd_debug_launch_count(what.encode()))
 
 
 def cu_partition_masks(cus_per_xcd_b: int, layout: str = "interleaved", xcds: int = 8, cus_per_xcd: int = 32):

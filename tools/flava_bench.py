@@ -118,10 +118,15 @@ def main():
         from tools.codebook_bench import encoder_gflop
 
         gf += encoder_gflop(vae)  # forward only: the codebook supplies labels
+    # the arm ran the probability kernels it is named after (launch counters of the library: no profiler needed)
+    from multimodal_amd import ops as _ops
+
+    launches = {k: _ops.launch_count(k) for k in ("attention_probs_lse", "attention_probs_fwd")}
+    assert a.train or (launches["attention_probs_lse"] > 0) == (not a.probs_two_pass and not a.no_attentions), launches
     print(json.dumps({"workload": ("TRAINING step: " if a.train else "") + "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + (" + bwd + SGD" if a.train else "") + (" + DALL-E codebook labels" if a.codebook else " (no codebook)"),
                       "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_sample": gf,
                       "tflops": round(B * gf / ms, 1), "mfma_frac": round(B * gf / ms / 2500.0, 4),
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "probs_path": "two_pass" if a.probs_two_pass else "flash+one_pass", "last": float(r.flatten()[0])}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "probs_path": "two_pass" if a.probs_two_pass else "flash+one_pass", "launches": launches, "last": float(r.flatten()[0])}))
 
 
 if __name__ == "__main__":

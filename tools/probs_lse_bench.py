@@ -40,7 +40,12 @@ def main():
         for rnd in range(2):  # alternate the arms (clock / power state drifts over a process)
             for name, code in (("two_pass", 514), ("flash+one_pass", 515)):
                 L.mmamd_debug_set_attn_variant(code)
+                before = {k: ops.launch_count(k) for k in ("attention_probs_fwd", "attention_probs_lse")}
                 res.setdefault(name, []).append(timed(lambda: ops.attention_probs_fwd(qkv, B, S, H, None, True, torch.float32, out=out)))
+                ran = {k: ops.launch_count(k) - v for k, v in before.items()}
+                new_path = S >= 112 and ops.attention_probs_from_lse_supported(S)
+                # the arm ran the kernel it is named after (and only that one): an A/B of a knob that did not take effect is not printed
+                assert (ran["attention_probs_lse"] > 0) == (code == 515 and new_path) and (ran["attention_probs_fwd"] > 0) == (code == 514 or not new_path), (name, ran)
                 res.setdefault(name + " (no probs)", []).append(timed(lambda: ops.attention_probs_fwd(qkv, B, S, H, None, False, out=out)))
         L.mmamd_debug_set_attn_variant(515)
         res["flash forward + lse alone"] = [timed(lambda: ops.attention_fwd_train(qkv, B, S, H, False))]

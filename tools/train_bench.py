@@ -62,10 +62,16 @@ def main():
     losses.append(float(loss))
     ms = t0.elapsed_time(t1) / a.steps
     gf = 3 * 41.09
+    from multimodal_amd import ops as _ops
+
+    launches = {k: _ops.launch_count(k) // (a.steps + a.warmup) for k in ("colsum_stage2_batched", "colsum", "gemm_bf16_splitk", "layernorm_bwd")}
+    # the arms ran what they are named after (launch counters of the library): batched reductions exist exactly in the deferred arm, stand-alone
+    # column-sum passes exactly in the unfused-bias arm
+    assert (launches["colsum_stage2_batched"] > 0) == _autograd._DEFER_LN_REDUCE and (launches["colsum"] > 40) == (not _autograd._FUSED_BIAS_GRAD), launches
     print(json.dumps({"workload": "CLIP ViT-B/16 training step (fwd + contrastive loss + bwd + SGD), synthetic", "batch": a.batch,
                       "ms_per_step": round(ms, 3), "pairs_per_s": round(a.batch / ms * 1e3, 1), "gflop_per_pair": gf,
                       "tflops": round(a.batch * gf / ms, 1), "mfma_frac": round(a.batch * gf / ms / 2500.0, 4),
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "deferred_ln_reduce": _autograd._DEFER_LN_REDUCE, "losses": [round(x, 4) for x in losses]}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "deferred_ln_reduce": _autograd._DEFER_LN_REDUCE, "launches_per_step": launches, "losses": [round(x, 4) for x in losses]}))
 
 
 if __name__ == "__main__":
