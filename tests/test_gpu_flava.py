@@ -424,7 +424,7 @@ def test_select_gather_cross_entropy_kernels():
         assert torch.equal(ops.gather_rows(src.cuda(), d, idx, d, torch.bfloat16).cpu(), src[bb, off + ll].to(torch.bfloat16))
     none, _ = ops.select_tokens(torch.full((4, 3), -1).cuda(), -1, 3, 0)
     assert none.numel() == 0
-    for (N, V, pad) in ((300, 30522, 6), (5, 2, 0), (64, 8192, 0)):
+    for (N, V, pad) in ((300, 30522, 6), (5, 2, 0), (64, 8192, 0), (24, 49408, 0), (7, 1028, 4)):  # (one-pass kernel: 16-byte chunks when V % 4 == 0)
         logits = torch.randn(N, V + pad) * 3
         lab = torch.randint(0, V, (N,))
         lab[torch.rand(N) < 0.3] = -1
