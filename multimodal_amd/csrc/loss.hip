@@ -237,6 +237,100 @@ __global__ __launch_bounds__(256) void ce_generic_bwd_kernel(const float* __rest
     return;
   }
   const float* x = logits + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int j = tid; j < V; j += 256) m = fmaxf(m, x[j]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int j = tid; j < V; j += 256) se += expf(x[j] - m);
+  se = wave_sum(se);
+  if (lane == 0) red[wave] = se;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  const float w = gout[0] / cnt[0];
+  for (int j = tid; j < (int)ldd; j += 256) {
+    float g = 0.f;
+    if (j < V) g = w * (expf(x[j] - m) * inv - (j == lab ? 1.f : 0.f));
+    out[j] = (TD)g;
+  }
+}
+
+}  // namespace mmamd
+
+using namespace mmamd;
+
+
+// ---------------------------------------------------------------------------------------------------------
+// FLAVA masked-prediction / ITM heads (modules/losses/flava.py:110-238)
+// ---------------------------------------------------------------------------------------------------------
+// Order-preserving compaction of the labelled positions: for labels [B, L] (and an optional per-sample keep flag) emit, for
+// every kept (b, l) in row-major order, the source row b*seq_S + tok_offset + l and its label.  This is what the reference
+// does with boolean indexing (`hidden_states[masked_tokens, :]`, `labels[masked_tokens]`, `sequence[pos_mask]`): one block,
+// ballot + popcount prefix per 1024-element chunk (B*L is at most a few 10^4).
+__global__ __launch_bounds__(1024) void select_tokens_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ row_keep,
+                                                             long long ignore, int B, int L, int seq_S, int tok_offset,
+                                                             int* __restrict__ idx_out, int64_t* __restrict__ label_out,
+                                                             int* __restrict__ count_out) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = B * L;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int start = 0; start < total; start += 1024) {
+    const int i = start + tid;
+    bool flag = false;
+    int b = 0, l = 0;
+    long long lab = 0;
+    if (i < total) {
+      b = i / L; l = i - b * L;
+      lab = labels[i];
+      flag = (row_keep == nullptr || row_keep[b] != 0) && lab != ignore;
+    }
+    const unsigned long long ballot = __ballot(flag);
+    const int lanepos = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(ballot);
+    __syncthreads();
+    int prefix = 0, chunk = 0;
+    for (int w = 0; w < 16; ++w) { const int c = wave_cnt[w]; if (w < wave) prefix += c; chunk += c; }
+    if (flag) {
+      const int pos = base + prefix + lanepos;
+      idx_out[pos] = b * seq_S + tok_offset + l;
+      if (label_out) label_out[pos] = lab;
+    }
+    __syncthreads();
+    if (tid == 0) base += chunk;
+    __syncthreads();
+  }
+  if (tid == 0) count_out[0] = base;
+}
+
+// dst[i, :] = src[idx[i], :] (fp32 rows `row_stride` floats apart) as fp32 or bf16 — wave per row
+template <typename TO>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, size_t row_stride, const int* __restrict__ idx,
+                                                          int n, int d, TO* __restrict__ dst, const int64_t* __restrict__ zero_rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* s = src + (size_t)idx[row] * row_stride;
+  const bool zero = zero_rows != nullptr && zero_rows[row] != 0;  // e.g. masked patches: their embedding gets no gradient
+  for (int c = lane; c < (d >> 2); c += 64) store4(dst + (size_t)row * d + 4 * c, zero ? f32x4{0.f, 0.f, 0.f, 0.f} : load4(s + 4 * c));
+}
+
+// nn.CrossEntropyLoss(ignore_index) rows: ws[row] = lse - logit[label] (0 for ignored rows), ws[N + row] = 1 / 0 kept flag
+__global__ __launch_bounds__(256) void ce_generic_rows_kernel(const float* __restrict__ logits, size_t ld, const int64_t* __restrict__ labels,
+                                                              int N, int V, long long ignore, float* __restrict__ ws) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long lab = labels[row];
+  if (lab == ignore || lab < 0 || lab >= V) {  // out-of-range labels are an error in torch; they are dropped here
+    if (tid == 0) { ws[row] = 0.f; ws[N + row] = 0.f; }
+    return;
+  }
+  const float* x = logits + (size_t)row * ld;
   // ONE pass over the row (r05; it was two: 1.9 GB of CoCa's [9728, 49408] caption logits read twice, 768 us): every thread keeps a running
   // (max, sum of exp relative to it) over its 16-byte chunks, the 256 pairs are merged at the end.  The result differs from the two-pass form
   // by the rounding of the rescales (~1e-7 relative).
@@ -256,7 +350,7 @@ __global__ __launch_bounds__(256) void ce_generic_bwd_kernel(const float* __rest
       m = mn;
     }
   }
-  // merge: threads that saw no element hold (-inf, 0) and drop out (exp(-inf - M) = 0; an all -inf row gives NaN like torch)
+  // merge: threads that saw no element hold (-inf, 0) and drop out (an all -inf row gives NaN like torch)
   const float wm = wave_max(m);
   se = wave_sum(m == -INFINITY ? 0.f : se * __expf(m - wm));
   __shared__ float redm[4];
