@@ -237,24 +237,51 @@ __global__ __launch_bounds__(256) void ce_generic_bwd_kernel(const float* __rest
     return;
   }
   const float* x = logits + (size_t)row * ld;
-  float m = -INFINITY;
-  for (int j = tid; j < V; j += 256) m = fmaxf(m, x[j]);
-  m = wave_max(m);
-  if (lane == 0) red[wave] = m;
+  // pass 1 (r05: ONE read for max and sum -- running (max, sum relative to it) per thread over 16-byte chunks, merged at the end; it was two reads),
+  // pass 2: the gradient, 4 columns per thread (8- / 16-byte stores; it was one 2- / 4-byte store per thread)
+  const bool vec = (V & 3) == 0 && (ld & 3) == 0 && (ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0;
+  float m = -INFINITY, se = 0.f;
+  if (vec) {
+    for (int j = tid * 4; j < V; j += 1024) {
+      const f32x4 v = load4(x + j);
+      const float mn = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+      se = se * __expf(m - mn) + ((__expf(v[0] - mn) + __expf(v[1] - mn)) + (__expf(v[2] - mn) + __expf(v[3] - mn)));
+      m = mn;
+    }
+  } else {
+    for (int j = tid; j < V; j += 256) {
+      const float v = x[j], mn = fmaxf(m, v);
+      se = se * __expf(m - mn) + __expf(v - mn);
+      m = mn;
+    }
+  }
+  const float wm = wave_max(m);
+  se = wave_sum(m == -INFINITY ? 0.f : se * __expf(m - wm));
+  __shared__ float redm[4];
+  if (lane == 0) { red[wave] = se; redm[wave] = wm; }
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float se = 0.f;
-  for (int j = tid; j < V; j += 256) se += expf(x[j] - m);
-  se = wave_sum(se);
-  if (lane == 0) red[wave] = se;
-  __syncthreads();
-  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  const float M = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  float tot = 0.f;
+  for (int w4 = 0; w4 < 4; ++w4) tot += redm[w4] == -INFINITY ? 0.f : red[w4] * __expf(redm[w4] - M);
+  const float inv = 1.0f / tot;
   const float w = gout[0] / cnt[0];
-  for (int j = tid; j < (int)ldd; j += 256) {
-    float g = 0.f;
-    if (j < V) g = w * (expf(x[j] - m) * inv - (j == lab ? 1.f : 0.f));
-    out[j] = (TD)g;
+  if (vec) {
+    for (int j = tid * 4; j < (int)ldd; j += 1024) {
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (j < V) {
+        const f32x4 v = load4(x + j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = w * (__expf(v[i] - M) * inv - (j + i == lab ? 1.f : 0.f));
+      }
+      store4(out + j, g);
+    }
+  } else {
+    for (int j = tid; j < (int)ldd; j += 256) {
+      float g = 0.f;
+      if (j < V) g = w * (__expf(x[j] - M) * inv - (j == lab ? 1.f : 0.f));
+      out[j] = (TD)g;
+    }
   }
 }
 

@@ -322,7 +322,8 @@ def test_cross_entropy_backward_kernel():
     from multimodal_amd import ops
 
     set_rng_seed(21)
-    for (N, V, pad, dt) in ((300, 30522, 64, torch.bfloat16), (5, 2, 1, torch.float32), (64, 200, 64, torch.bfloat16)):
+    for (N, V, pad, dt) in ((300, 30522, 64, torch.bfloat16), (5, 2, 1, torch.float32), (64, 200, 64, torch.bfloat16), (40, 49408, 64, torch.bfloat16),
+                            (33, 1024, 4, torch.float32)):  # (the last two take the vectorised one-read / 4-columns-per-thread form)
         logits = (torch.randn(N, V) * 3).requires_grad_(True)
         lab = torch.randint(0, V, (N,))
         lab[torch.rand(N) < 0.3] = -1
