@@ -70,6 +70,31 @@ class FlavaImageEmbedFn(torch.autograd.Function):
         return None, dconv, db, dcls.view(cls_shape) if hc else None, dpos.view(pos_shape), None, None, dmt
 
 
+class BicubicTableFn(torch.autograd.Function):
+    """ImageEmbeddings.interpolate_pos_encoding (models/flava/image_encoder.py:102-137) as a differentiable map of the position table: the
+    bicubic resampling of the patch grid (CLS row passed through) is LINEAR in the table, so its backward is the transpose of the same map.  The
+    map's matrix A [1 + h0 w0, 1 + n] is what the forward kernel makes of an identity table; d table = A^T d out in exact fp32
+    (mmamd_f32_gemm_strided).  r05: interpolate_pos_encoding raised in training."""
+
+    @staticmethod
+    def forward(ctx, table, h0: int, w0: int, scale_h: float, scale_w: float):
+        t = c32(table)
+        out = ops.bicubic_pos_embed(t.view(t.shape[-2], t.shape[-1]), h0, w0, scale_h, scale_w)
+        ctx.meta = (tuple(table.shape), h0, w0, scale_h, scale_w)
+        return out.view(1, out.shape[0], out.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, h0, w0, scale_h, scale_w = ctx.meta
+        n1, d = shape[-2], shape[-1]
+        eye = torch.eye(n1, dtype=f32, device=dout.device)
+        A = ops.bicubic_pos_embed(eye, h0, w0, scale_h, scale_w)  # [1 + h0 w0, n1]
+        g = dout.detach().contiguous().view(A.shape[0], d)
+        # dtable[j, k] = sum_i A[i, j] g[i, k]:  X(m = j, k = i) = A[i n1 + j],  Y(n = k, k = i) = g[i d + k]
+        dt = ops.f32_gemm_strided(A, 1, n1, g, 1, d, n1, d, A.shape[0])
+        return dt.view(shape), None, None, None, None
+
+
 class BertEmbedFn(torch.autograd.Function):
     """LayerNorm(word[ids] + position[pos] + token_type[type]) (modules/layers/text_embedding.py:74-104)."""
 

@@ -105,21 +105,28 @@ class ImageEmbeddings(nn.Module):
                 interpolate_pos_encoding: bool = False) -> Tensor:
         B = pixel_values.shape[0]
         if wants_grad(self, pixel_values):
-            if interpolate_pos_encoding:
-                raise ops.MmamdError("training on the MI355X path: interpolate_pos_encoding is not implemented")
             if image_patches_mask is not None and self.mask_token is None:
                 warnings.warn("image_patches_mask passed but use_image_masking in init was false. Ignoring.")
                 image_patches_mask = None
             pe_mod = self.patch_embeddings
-            if pixel_values.shape[2] != pe_mod.image_size[0] or pixel_values.shape[3] != pe_mod.image_size[1]:
-                raise ValueError(f"Input image size ({pixel_values.shape[2]}*{pixel_values.shape[3]}) doesn't match model "
-                                 f"({pe_mod.image_size[0]}*{pe_mod.image_size[1]}).")
-            from ._train import FlavaImageEmbedFn
+            H, W = pixel_values.shape[2], pixel_values.shape[3]
+            from ._train import BicubicTableFn, FlavaImageEmbedFn
 
             from ..._autograd import dropout_train
 
+            pos = self.position_embeddings
+            if interpolate_pos_encoding:  # (reference :170-173) another resolution: the table resampled bicubically, differentiably (r05)
+                p0, p1 = pe_mod.patch_size
+                if H != W or p0 != p1 or H % p0 != 0:
+                    raise ops.MmamdError("interpolate_pos_encoding on the MI355X path: square images whose side is a multiple of the patch size")
+                n = pos.shape[1] - 1
+                if (H // p0) * (W // p1) != n:
+                    h0, w0 = H // p0 + 0.1, W // p1 + 0.1  # reference :118-121
+                    pos = BicubicTableFn.apply(pos, int(h0), int(w0), h0 / math.sqrt(n), w0 / math.sqrt(n))
+            elif H != pe_mod.image_size[0] or W != pe_mod.image_size[1]:
+                raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({pe_mod.image_size[0]}*{pe_mod.image_size[1]}).")
             emb = FlavaImageEmbedFn.apply(pixel_values, pe_mod.projection.weight, pe_mod.projection.bias, self.cls_token,
-                                          self.position_embeddings, pe_mod.patch_size[0], image_patches_mask,
+                                          pos, pe_mod.patch_size[0], image_patches_mask,
                                           self.mask_token if image_patches_mask is not None else None)
             return dropout_train(emb, self.dropout.p)  # reference flava/image_encoder.py:165: dropout on the assembled embeddings
         if self.training and self.dropout.p > 0:

@@ -231,3 +231,31 @@ def test_head_mask_in_training_matches_the_reference_gradients(golden):
             assert rel <= 6e-2 and rms <= 3e-2, (per_layer, k, rel, rms)
             worst = (k, rel) if rel > worst[1] else worst
         print("head_mask training, per_layer =", per_layer, "worst max-rel", worst)
+
+
+def test_interpolate_pos_encoding_in_training_matches_the_reference_gradients(golden):
+    """r05: ImageEmbeddings(..., interpolate_pos_encoding=True) while TRAINING (reference models/flava/image_encoder.py:102-137,170-173) -- the bicubic
+    resampling of the position table is linear in the table, its backward the transpose of the same map (models/flava/_train.py::BicubicTableFn).
+    Fixture: tests/golden/make_golden_interp_grad.py -> interp_grad.npz (4 x 4 grid resampled to 6 x 6, patch mask, all five parameter gradients from the
+    reference's torch autograd through F.interpolate(mode="bicubic"))."""
+    from multimodal_amd.models.flava.image_encoder import ImageEmbeddings
+
+    z = golden("interp_grad.npz")
+    emb = ImageEmbeddings(image_size=64, patch_size=16, hidden_size=128, use_image_masking=True)
+    emb.load_state_dict({k[len("sd."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}, strict=True)
+    emb = emb.cuda().train()
+    t = lambda k: torch.from_numpy(z[k]).cuda()  # noqa: E731
+    out = emb(t("image"), image_patches_mask=t("patches_mask"), interpolate_pos_encoding=True)
+    assert out.shape == (3, 37, 128) and out.grad_fn is not None
+    assert np.abs(host(out) - z["out"]).max() <= 2e-2 * max(1.0, np.abs(z["out"]).max())  # patch GEMM in bf16
+    (out * t("w")).sum().backward()
+    for k, p in emb.named_parameters():
+        ref = z["g." + k].astype(np.float64)
+        got = host(p.grad)
+        assert got.shape == ref.shape, k
+        rel = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)
+        # position / cls gradients are exact-fp32 sums of w (no bf16 operand on their path: the resampling's transpose runs on the exact-fp32 MFMA);
+        # the projection's come from bf16-operand GEMMs, and the mask token's is (all patch rows) - (the conv-bias gradient), which carries that rounding
+        assert rel <= (6e-2 if "projection" in k else 1e-2 if k == "mask_token" else 1e-5), (k, rel)
+    with pytest.raises(ValueError):
+        emb(t("image"))  # without the flag the reference's size check stands, in training too
