@@ -859,8 +859,8 @@ class DecoderStackConfig:
 
 
 class DecoderStackFn(torch.autograd.Function):
-    """Pre-norm TransformerDecoder layers (modules/layers/transformer.py:398-433): self-attention with the given mask, optional
-    cross-attention to `enc` (fp32 [B*Sk, dkv], differentiable), feed-forward.  x0 fp32 [B*S, d]."""
+    """TransformerDecoder layers, pre-norm (modules/layers/transformer.py:398-433) or post-norm (:435-470; layer spec "post"): self-attention with the
+    given mask, optional cross-attention to `enc` (fp32 [B*Sk, dkv], differentiable), feed-forward.  x0 fp32 [B*S, d]."""
 
     @staticmethod
     def forward(ctx, x0, enc, cfg: DecoderStackConfig, *params):
@@ -875,10 +875,51 @@ class DecoderStackFn(torch.autograd.Function):
             H, d = L["n_head"], x.shape[1]
             hd = d // H
             qw, qb, kw, kb, vw, vb, ow, ob, g1, be1 = pr[:10]
+            pd, sd = cfg.drop_p, cfg.seed  # ONE rate on every dropout site of a decoder layer (reference transformer.py:262-290)
+            if L.get("post"):
+                # post-norm layer (the reference's DEFAULT, norm_first=False; transformer.py:435-470): every block is LN(x + drop(f(x))) -- the
+                # sub-blocks read the fp32 stream itself (rounded to bf16 for the MFMA) and the LayerNorms sit at the END of the blocks.  r05.
+                site = 16 * (cfg.layer0 + li)
+
+                def branch(delta_in, w_o, b_o, res, s_):  # res + drop(delta_in W_o^T + b_o)
+                    if pd > 0:
+                        return ops.dropout(ops.gemm_bf16(delta_in, ops.convert(w_o, bf), b_o, out_dtype=f32), pd, sd, s_, residual=res)
+                    return ops.gemm_bf16(delta_in, ops.convert(w_o, bf), b_o, residual=res, out_dtype=f32, out=torch.empty_like(res))
+
+                h1 = ops.convert(x, bf)
+                qkv = ops.gemm_bf16(h1, ops.convert(torch.cat([qw, kw, vw], 0), bf), torch.cat([qb, kb, vb], 0))
+                lse = torch.empty((B, H, S), dtype=f32, device=x.device)
+                att, _ = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, cfg.mask, lse=lse, drop=(pd, sd, site + 3))
+                a_raw = branch(att, ow, ob, x, site)
+                a = ops.layernorm(a_raw, g1, be1, L["eps1"], out_dtype=f32)
+                rec = [x, h1, qkv, att, lse, a_raw, a]
+                if L["has_cross"]:
+                    cqw, cqb, ckw, ckb, cvw, cvb, cow, cob, gc, bec = pr[10:20]
+                    hc = ops.convert(a, bf)
+                    qc = ops.gemm_bf16(hc, ops.convert(cqw, bf), cqb)
+                    kvc = ops.gemm_bf16(encb, ops.convert(torch.cat([ckw, cvw], 0), bf), torch.cat([ckb, cvb], 0))
+                    lsec = torch.empty((B, H, S), dtype=f32, device=x.device)
+                    attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, None, lse=lsec, drop=(pd, sd, site + 5))
+                    c_raw = branch(attc, cow, cob, a, site + 4)
+                    a2 = ops.layernorm(c_raw, gc, bec, L["epsc"], out_dtype=f32)
+                    rec += [hc, qc, kvc, attc, lsec, c_raw, a2]
+                    ff = pr[20:]
+                else:
+                    a2 = a
+                    ff = pr[10:]
+                w1, b1, w2, b2, g2, be2 = ff
+                h2 = ops.convert(a2, bf)
+                u, g = ops.gemm_bf16_dual(h2, ops.convert(w1, bf), b1, L["act"])
+                if pd > 0:
+                    ops.dropout(g, pd, sd, site + 1, out=g)
+                f_raw = branch(g, w2, b2, a2, site + 2)
+                x = ops.layernorm(f_raw, g2, be2, L["eps2"], out_dtype=f32)
+                rec += [h2, u, g, f_raw]
+                recs.append(rec)
+                continue
             h1 = ops.layernorm(x, g1, be1, L["eps1"], out_dtype=bf)
             qkv = ops.gemm_bf16(h1, ops.convert(torch.cat([qw, kw, vw], 0), bf), torch.cat([qb, kb, vb], 0))
             lse = torch.empty((B, H, S), dtype=f32, device=x.device)
-            pd, sd = cfg.drop_p, cfg.seed  # ONE rate on every dropout site of a decoder layer (reference transformer.py:262-290)
             att, _ = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, cfg.mask, lse=lse,
                                          drop=(pd, sd, 16 * (cfg.layer0 + li) + 3))
             if pd > 0:
@@ -947,6 +988,59 @@ class DecoderStackFn(torch.autograd.Function):
             qw, qb, kw, kb, vw, vb, ow, ob, g1, be1 = pr[:10]
             d = qw.shape[0]
             hd = d // H
+            if L.get("post"):
+                # backward of the post-norm layer: each LayerNorm backward comes FIRST in its block, and the residual sums are epilogues of the dgrad GEMMs
+                pd, sd, site = cfg.drop_p, cfg.seed, 16 * (cfg.layer0 + li)
+                gl = [None] * cfg.nparams(li)
+                h2, u, g, f_raw = rec[-4:]
+                w1, b1, w2, b2, g2, be2 = pr[20:] if L["has_cross"] else pr[10:]
+                d_f, dg2, dbe2, d_fb = ops.layernorm_bwd(f_raw, g2, dX, L["eps2"], want_bf16=True, defer=pending)
+                if pd > 0:
+                    d_fb = ops.dropout(d_f, pd, sd, site + 2, out_dtype=bf)
+                du = dgrad(d_fb, w2, bf, _ACT_GRAD[L["act"]], u)
+                if pd > 0:
+                    ops.dropout(du, pd, sd, site + 1, out=du)
+                dW2, db2 = wgrad(d_fb, g, bias=True)
+                d_a2 = dgrad(du, w1, f32, ops.ACT_NONE, d_f)  # d_f + du W1: a2 feeds the MLP and the residual
+                dW1, db1 = wgrad(du, h2, bias=True)
+                if L["has_cross"]:
+                    cqw, cqb, ckw, ckb, cvw, cvb, cow, cob, gc, bec = pr[10:20]
+                    hc, qc, kvc, attc, lsec, c_raw, _a2 = rec[7:14]
+                    d_c, dgc, dbec, d_cb = ops.layernorm_bwd(c_raw, gc, d_a2, L["epsc"], want_bf16=True, defer=pending)
+                    if pd > 0:
+                        d_cb = ops.dropout(d_c, pd, sd, site + 4, out_dtype=bf)
+                    dattc = dgrad(d_cb, cow, bf)
+                    dWco, dbco = wgrad(d_cb, attc, bias=True)
+                    dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, None, drop=(pd, sd, site + 5))
+                    d_a = dgrad(dqc, cqw, f32, ops.ACT_NONE, d_c)  # d_c + dqc Wq
+                    dWcq, dbcq = wgrad(dqc, hc, bias=True)
+                    wckv = torch.cat([ckw, cvw], 0)
+                    de = dgrad(dkvc, wckv, f32)
+                    d_enc = de if d_enc is None else ops.gemm_bf16(dkvc, ops.transpose_to_bf16(wckv, pad_to=64), None, residual=d_enc,
+                                                                   out_dtype=f32, out=d_enc)
+                    dWckv, dbckv = wgrad(dkvc, encb, bias=True)
+                    gl[10:20] = [dWcq, dbcq, dWckv[:d], dbckv[:d], dWckv[d:], dbckv[d:], dWco, dbco, dgc, dbec]
+                    gl[20:] = [dW1, db1, dW2, db2, dg2, dbe2]
+                else:
+                    d_a = d_a2
+                    gl[10:] = [dW1, db1, dW2, db2, dg2, dbe2]
+                x, h1, qkv, att, lse, a_raw, _a = rec[:7]
+                d_ar, dg1, dbe1, d_arb = ops.layernorm_bwd(a_raw, g1, d_a, L["eps1"], want_bf16=True, defer=pending)
+                if pd > 0:
+                    d_arb = ops.dropout(d_ar, pd, sd, site, out_dtype=bf)
+                datt = dgrad(d_arb, ow, bf)
+                dWo, dbo = wgrad(d_arb, att, bias=True)
+                dq, dkv = ops.attention_x_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, datt, lse, B, S, S, H, hd, cfg.mask,
+                                              drop=(pd, sd, site + 3))
+                wqkv = torch.cat([qw, kw, vw], 0)
+                dh1 = dgrad(dq, qw, f32, ops.ACT_NONE, d_ar)  # d_ar + dq Wq + [dk | dv] [Wk; Wv]: x feeds the attention and the residual
+                dh1 = ops.gemm_bf16(dkv, ops.transpose_to_bf16(wqkv[d:], pad_to=64), None, residual=dh1, out_dtype=f32, out=dh1)
+                dWq, dbq = wgrad(dq, h1, bias=True)
+                dWkv, dbkv = wgrad(dkv, h1, bias=True)
+                gl[:10] = [dWq, dbq, dWkv[:d], dbkv[:d], dWkv[d:], dbkv[d:], dWo, dbo, dg1, dbe1]
+                grads[offs[li]:offs[li] + cfg.nparams(li)] = gl
+                dX, dXb = dh1, None
+                continue
             x, h1, qkv, att, lse, a = rec[:6]
             if L["has_cross"]:
                 hc, qc, kvc, attc, lsec, a2 = rec[6:12]

@@ -104,10 +104,12 @@ class CLIPTextEncoder(PackedModeMixin, nn.Module):
         B, S = text.shape
         ids = text if (text.dtype == torch.int64 and text.is_contiguous()) else text.to(torch.int64).contiguous()
         if _train.wants_grad(self):
-            if return_hidden_state:
-                raise ops.MmamdError("return_hidden_state is not implemented for the differentiable (training) forward")
             x0 = _train.TextEmbedFn.apply(ids, self.token_embedding.weight, self.positional_embedding)
             h = _train.run_stack(self.encoder, x0, B, S, True)
+            if return_hidden_state:  # reference :125-127: ln_final over every token, [B, 77, width], attached to the graph (r05)
+                from ..._autograd import LayerNormFn
+
+                return LayerNormFn.apply(h, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps).view(B, S, self.width)
             eot_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=ids.device) + ids.argmax(dim=-1)  # index bookkeeping
             return _train.PooledHeadFn.apply(h, eot_rows, self.ln_final.weight, self.ln_final.bias, self.projection.weight,
                                              self.ln_final.eps, True)

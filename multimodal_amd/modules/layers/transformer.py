@@ -521,8 +521,6 @@ def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, 
     bounds = [0]  # params[bounds[i]:bounds[i + 1]] belong to layer i
     drop_rates = set()
     for layer in dec_layers:
-        if not layer.norm_first:
-            raise ops.MmamdError("training on the MI355X path implements pre-norm decoder layers")
         # training-time dropout: the reference builds every dropout of a decoder layer from ONE value (:262-290) -- attention probabilities
         # (MultiHeadAttentionWithCache.dropout), the three residual branches, the MLP's hidden dropout
         rates = {float(layer.attention_dropout.p), float(layer.feedforward_dropout.p), float(layer.feedforward.hidden_dropout_p()),
@@ -540,7 +538,7 @@ def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, 
         params += [at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight, at.v_proj.bias,
                    at.output_proj.weight, at.output_proj.bias, layer.attention_layernorm.weight, layer.attention_layernorm.bias]
         spec = {"n_head": at.num_heads, "eps1": layer.attention_layernorm.eps, "eps2": layer.feedforward_layernorm.eps, "act": steps[0][1],
-                "has_cross": has_cross}
+                "has_cross": has_cross, "post": not layer.norm_first}  # post-norm: the reference's default (transformer.py:289,435-470)
         if has_cross:
             ca = layer.cross_attention
             params += [ca.q_proj.weight, ca.q_proj.bias, ca.k_proj.weight, ca.k_proj.bias, ca.v_proj.weight, ca.v_proj.bias,

@@ -32,7 +32,7 @@ def _check(z, tag, mod, y, xg, y_tol=2e-2, sd_tag=None):
         if np.abs(ref).max() < 1e-6 * gscale:
             # mathematically zero (key biases: a shift of every score of a query is softmax-invariant): the reference holds fp32 round-off
             # there, this path the bf16 round-off of the dK rows it sums -- both ~0 on the scale of the module's gradients
-            assert k.endswith("key.bias") or "in_proj" in k or k.endswith("input_proj.bias"), (tag, k)
+            assert k.endswith("key.bias") or k.endswith("k_proj.bias") or "in_proj" in k or k.endswith("input_proj.bias"), (tag, k)
             assert np.abs(got).max() <= 1e-3 * gscale, (tag, k, np.abs(got).max(), gscale)
             continue
         rel = np.abs(got - ref).max() / np.abs(ref).max()
@@ -259,3 +259,62 @@ def test_interpolate_pos_encoding_in_training_matches_the_reference_gradients(go
         assert rel <= (6e-2 if "projection" in k else 1e-2 if k == "mask_token" else 1e-5), (k, rel)
     with pytest.raises(ValueError):
         emb(t("image"))  # without the flag the reference's size check stands, in training too
+
+
+def test_clip_text_encoder_hidden_states_in_training_match_the_reference_gradients(golden):
+    """r05: CLIPTextEncoder(..., return_hidden_state=True) while TRAINING (reference models/clip/text_encoder.py:125-127: ln_final over every token)
+    returns the hidden states attached to the graph.  Fixture: tests/golden/make_golden_text_hidden_grad.py -> text_hidden_grad.npz."""
+    from multimodal_amd.models.clip import CLIPTextEncoder
+
+    z = golden("text_hidden_grad.npz")
+    enc = CLIPTextEncoder(embedding_dim=64, context_length=77, vocab_size=1000, width=128, dim_feedforward=256, heads=2, layers=2)
+    enc.load_state_dict({k[len("sd."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}, strict=True)
+    enc = enc.cuda().train()
+    hidden = enc(torch.from_numpy(z["ids"]).cuda(), return_hidden_state=True)
+    assert hidden.shape == (4, 77, 128) and hidden.grad_fn is not None
+    assert np.abs(host(hidden) - z["hidden"]).max() <= 2e-2 * max(1.0, np.abs(z["hidden"]).max())  # (the bound _check puts on a stack's output)
+    (hidden * torch.from_numpy(z["w"]).cuda()).sum().backward()
+    gscale = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("g."))
+    for k, p in enc.named_parameters():
+        if "g." + k not in z.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k  # the projection is not on this path
+            continue
+        ref = z["g." + k].astype(np.float64)
+        got = host(p.grad)
+        if np.abs(ref).max() < 1e-6 * gscale:  # (in_proj key-bias third: mathematically zero)
+            assert np.abs(got).max() <= 1e-3 * gscale, k
+            continue
+        if k == "token_embedding.weight" or k.endswith("in_proj_bias"):
+            # rows of unused tokens / the key third of the packed bias are zero on both sides: compare on the tensor's own scale
+            assert np.abs(got - ref).max() <= 6e-2 * np.abs(ref).max(), k
+            continue
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        rms = np.sqrt(((got - ref) ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-12)
+        assert rel <= 6e-2 and rms <= 3e-2, (k, rel, rms)
+
+
+def test_post_norm_decoder_trains_like_the_reference(golden):
+    """r05: POST-NORM TransformerDecoder layers in training -- the reference's default, norm_first=False (modules/layers/transformer.py:289,435-470):
+    LayerNorms at the end of the self-attention / cross-attention / feed-forward blocks (DecoderStackFn, layer spec "post").  Fixture:
+    tests/golden/make_golden_decoder_post_grad.py -> decoder_post_grad.npz: two layers with cross-attention to 64-wide encoder states (gradient of the
+    input, of the encoder states and of every parameter), and one self-attention-only layer behind a final LayerNorm; also with every hidden state
+    returned (one autograd node per layer)."""
+    from multimodal_amd.modules.layers.transformer import TransformerDecoder
+
+    z = golden("decoder_post_grad.npz")
+    causal = torch.ones(9, 9, dtype=torch.bool).tril().cuda()
+    for tag, kw in (("dec", dict(n_layer=2, use_cross_attention=True, dim_kv=64)), ("self", dict(n_layer=1, use_cross_attention=False, final_layer_norm_eps=1e-5))):
+        for per_layer in (False, True):
+            dec = _load(TransformerDecoder(d_model=128, n_head=2, dim_feedforward=256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=False,
+                                           **kw), z, tag)
+            x = torch.from_numpy(z[f"{tag}.x"]).cuda().requires_grad_(True)
+            enc = torch.from_numpy(z[f"{tag}.enc"]).cuda().requires_grad_(True) if tag == "dec" else None
+            out = dec(x, enc, attention_mask=causal, return_hidden_states=per_layer)
+            y = out.last_hidden_state
+            (y * torch.from_numpy(z[f"{tag}.w"]).cuda()).sum().backward()
+            if per_layer:
+                assert len(out.hidden_states) == kw["n_layer"] + 1 and all(h.grad_fn is not None for h in out.hidden_states[1:])
+            _check(z, tag, dec, y, x)
+            if enc is not None:
+                ref = z["dec.denc"].astype(np.float64)
+                assert np.abs(host(enc.grad) - ref).max() <= 6e-2 * np.abs(ref).max()
