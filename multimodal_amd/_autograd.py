@@ -50,6 +50,7 @@ def dgrad_t(dy: Tensor, wT: Tensor, out_dtype, act: int = ops.ACT_NONE, pre_act:
 
 
 _FUSED_BIAS_GRAD = True  # tools/train_bench.py --no-fused-bias flips it for the A/B
+_BF16_DH = True  # the two dgrad GEMMs in front of a LayerNorm backward hand it bf16 (the residual-stream gradient stays fp32): -0.57 ms on the CLIP step (profiles/r05_train_bf16_dh_ab2.txt); tools/train_bench.py --f32-dh is the other arm
 _DEFER_LN_REDUCE = True  # tools/train_bench.py --no-deferred-ln-reduce: every LayerNorm backward reduces its own partials (the r04 form)
 
 
@@ -309,7 +310,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         else:
             dW2, db2 = wgrad(dXb, g), dXsum
         # u = h2 W1^T + b1
-        dh2 = dgrad_t(du, W1T, f32)  # (bf16 here measured SLOWER: profiles/r05_train_bf16_dh_ab.txt)
+        dh2 = dgrad_t(du, W1T, bf if _BF16_DH else f32)
         dW1, db1 = wgrad(du, h2, bias=True)
         dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True, defer=pending)
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo)
@@ -320,7 +321,7 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         dWo = wgrad(dxmb, att)
         dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3, head_mask)
         # qkv = h1 Wqkv^T + bqkv
-        dh1 = dgrad_t(dqkv, WqkvT, f32)
+        dh1 = dgrad_t(dqkv, WqkvT, bf if _BF16_DH else f32)
         dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
         dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True, defer=pending)
         if li > 0 and dhidden and dhidden[li - 1] is not None:

@@ -3,6 +3,8 @@
 // lets the NT MFMA GEMM compute weight gradients (dW = dY^T X: both operands are needed with the token index contiguous).
 // All HBM-bound: wave per row, float4 / bf16x4 accesses, fp32 accumulation; column reductions are two-stage (no atomics),
 // the embedding-table gradient uses fp32 atomics (rows collide by construction).
+#include <type_traits>
+
 #include "common.h"
 
 namespace mmamd {
@@ -12,7 +14,7 @@ namespace mmamd {
 // dx (+= add) in fp32;  per-block partial column sums of dy*xh (dgamma) and dy (dbeta) -> part[block][2][d]
 // ---------------------------------------------------------------------------------------------
 template <typename TD, int MAXV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, MAXV <= 4 ? 3 : 1) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const TD* __restrict__ dy, const float* __restrict__ add,
                                                             float* __restrict__ dx, bf16* __restrict__ dx_bf16, float* __restrict__ part,
                                                             int rows, int d, float eps, int with_cs) {
@@ -29,14 +31,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const TD* dr = dy + (size_t)row * d;
     // every load of the row is issued before the first reduction: one memory round trip per row instead of three dependent ones
     // (x -> statistics -> dy -> means -> add): the first form ran at 2.7 TB/s, latency-bound with 2 waves per SIMD
+    // (dy stays in its storage type until it is used: a bf16 dy then holds 2 registers per chunk instead of 4 while the row's loads are in flight --
+    //  the bf16 instantiation at d = 768 needed 183 registers, one step over the 168 that allow three waves per SIMD: 179 vs 128 us, r05)
+    typedef typename std::conditional<std::is_same<TD, float>::value, f32x4, bf16x4>::type raw4;
     f32x4 xv[MAXV], gv[MAXV], av[MAXV];
+    raw4 graw[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + 64 * i;
-      xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) graw[i][j] = (TD)0.f;
       if (c < d4) {
         xv[i] = load4(xr + 4 * c);
-        gv[i] = load4(dr + 4 * c);
+        graw[i] = *reinterpret_cast<const raw4*>(dr + 4 * c);
         if (add != nullptr) av[i] = load4(add + (size_t)row * d + 4 * c);
       }
     }
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float xh = (xv[i][j] - mean) * rstd;
-          const float dyj = gv[i][j];
+          const float dyj = (float)graw[i][j];
           xv[i][j] = xh;
           gv[i][j] = dyj * gm[j];
           sg += gv[i][j];
