@@ -408,11 +408,12 @@ int mmamd_contrastive_bwd(const float* a, const float* b, const float* a_all, co
  * LayerNorm backward: dx[rows,d] (fp32) = LN'(x; gamma)(dy) (+ add), dgamma[d], dbeta[d].  dy fp32 or bf16.  dx_bf16 (optional):
  * the same dx rounded to bf16 (operand of the following gradient GEMMs).  dx_colsum (optional, [d]): column sums of dx — the bias
  * gradient of the Linear whose output fed this LayerNorm's residual stream.
- * ws: (min(768, ceil(rows/4)) + 1) * 3 * d floats. */
+ * ws: (G + 1) * 3 * d floats, G = mmamd_layernorm_bwd_groups(rows, d) (the number of workgroups: <= 1024). */
+int mmamd_layernorm_bwd_groups(int rows, int d);
 int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
                         void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int d, float eps,
                         mmamd_stream_t stream);
-/* mmamd_layernorm_bwd with dgamma == dbeta == NULL leaves its per-workgroup partials in ws ([G][ns][d], G = min(768, ceil(rows/4)), ns = 2 or 3 with
+/* mmamd_layernorm_bwd with dgamma == dbeta == NULL leaves its per-workgroup partials in ws ([G][ns][d], G = mmamd_layernorm_bwd_groups(rows, d), ns = 2 or 3 with
  * dx_colsum) and skips the reduction; mmamd_colsum_stage2_batched reduces any number of such jobs in one launch per 64 (out0 | out1 | out2 receive the
  * column segments [0, seg) | [seg, 2 seg) | [2 seg, n) of sum_g part[g][0..n); out1 == NULL: one array of n).  Same arithmetic as the immediate form. */
 typedef struct {

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "mmamd_attention_probs_from_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_contrastive_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "mmamd_layernorm_bwd_groups": (_i, [_i, _i]),
     "mmamd_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "mmamd_colsum_stage2_batched": (_i, [_vp, _i, _vp]),
     "mmamd_colsum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

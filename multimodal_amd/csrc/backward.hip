@@ -14,7 +14,7 @@ namespace mmamd {
 // dx (+= add) in fp32;  per-block partial column sums of dy*xh (dgamma) and dy (dbeta) -> part[block][2][d]
 // ---------------------------------------------------------------------------------------------
 template <typename TD, int MAXV>
-__global__ __launch_bounds__(256, MAXV <= 4 ? 3 : 1) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, MAXV <= 3 ? 4 : MAXV <= 4 ? 3 : 1) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const TD* __restrict__ dy, const float* __restrict__ add,
                                                             float* __restrict__ dx, bf16* __restrict__ dx_bf16, float* __restrict__ part,
                                                             int rows, int d, float eps, int with_cs) {
@@ -459,17 +459,24 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 
 using namespace mmamd;
 
+// workgroups of the LayerNorm backward = what is resident at once (the kernel walks rows with a grid stride, so a second round would be a tail):
+// 4 per CU where the instantiation fits four waves per SIMD (d <= 768, but more than 512: 120 registers, 36 KB LDS), 3 per CU otherwise
+extern "C" int mmamd_layernorm_bwd_groups(int rows, int d) {
+  const int cap = (d > 512 && d <= 768) ? 1024 : 768;
+  return rows < 4 * cap ? (rows + 3) / 4 : cap;
+}
+
 extern "C" int mmamd_layernorm_bwd(const float* x, const float* gamma, const void* dy, int dy_dtype, const float* add, float* dx,
                                    void* dx_bf16, float* dgamma, float* dbeta, float* dx_colsum, float* ws, int rows, int d, float eps,
                                    mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(x && gamma && dy && dx && ws && rows > 0 && d > 0 && (dgamma != nullptr) == (dbeta != nullptr), MMAMD_E_BADARG, "layernorm_bwd: bad argument");
   MMAMD_CHECK_ARG(d % 4 == 0 && d <= 2048, MMAMD_E_UNSUPPORTED, "layernorm_bwd: d=%d must be a multiple of 4 and <= 2048", d);
   hipStream_t st = (hipStream_t)stream;
-  const int G = rows < 4 * 768 ? (rows + 3) / 4 : 768;  // 3 workgroups per CU; ws: (G + 1) * 3 * d floats
+  const int G = mmamd_layernorm_bwd_groups(rows, d);  // ws: (G + 1) * 3 * d floats
   const int d4 = d / 4, cs = dx_colsum != nullptr, ns = cs ? 3 : 2;
 #define LNB(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(G), dim3(256), 0, st, x, gamma, (const T*)dy, add, dx, (bf16*)dx_bf16, ws, rows, d, eps, cs)
-  if (dy_dtype == MMAMD_F32) { if (d4 <= 128) LNB(float, 2); else if (d4 <= 256) LNB(float, 4); else LNB(float, 8); }
-  else if (dy_dtype == MMAMD_BF16) { if (d4 <= 128) LNB(bf16, 2); else if (d4 <= 256) LNB(bf16, 4); else LNB(bf16, 8); }
+  if (dy_dtype == MMAMD_F32) { if (d4 <= 128) LNB(float, 2); else if (d4 <= 192) LNB(float, 3); else if (d4 <= 256) LNB(float, 4); else LNB(float, 8); }
+  else if (dy_dtype == MMAMD_BF16) { if (d4 <= 128) LNB(bf16, 2); else if (d4 <= 192) LNB(bf16, 3); else if (d4 <= 256) LNB(bf16, 4); else LNB(bf16, 8); }
   else MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "layernorm_bwd: bad dy dtype");
 #undef LNB
   // part layout [G][ns][d] = G rows of width ns*d: dgamma | dbeta | (column sums of dx)

@@ -1013,7 +1013,7 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: f
     dev = x.device
     dx = torch.empty((rows, d), dtype=torch.float32, device=dev)
     dg, db = torch.empty(d, dtype=torch.float32, device=dev), torch.empty(d, dtype=torch.float32, device=dev)
-    G = min(768, (rows + 3) // 4)
+    G = _lib.lib().mmamd_layernorm_bwd_groups(rows, d)
     ws = torch.empty((G + 1) * 3 * d, dtype=torch.float32, device=dev)
     dxb = torch.empty((rows, d), dtype=torch.bfloat16, device=dev) if want_bf16 else None
     cs = torch.empty(d, dtype=torch.float32, device=dev) if want_colsum else None
