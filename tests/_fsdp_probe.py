@@ -126,10 +126,11 @@ def main():
     res["dloss_steps"] = [abs(a - b) for a, b in zip(losses["plain"], losses["fsdp"])]
     e1p, e1w = eval_out(plain), eval_out(wrapped)
     res["eval_after_dloss"] = abs(e1p[0] - e1w[0])
-    # (3e-3 of the tensor's largest value: the two arrangements round at different places -- per-layer nodes against the stack-level node, fp32 atomics in
-    #  the embedding gradients, and since r05 a bf16 (2^-9) gradient handed to each LayerNorm backward -- and two lr = 0.05 steps carry that into the outputs;
-    #  measured 2.2e-3 on the two-rank FULL_SHARD case)
-    res["eval_after_worst_rel_over_tol"] = max(close(a, b, 3e-3) for a, b in zip(e1w[1:], e1p[1:]))
+    # (4e-3 = one bf16 ulp (2^-8) of the tensor's largest value: the two arrangements round at different places -- per-layer nodes against the stack-level
+    #  node, fp32 atomics in the embedding gradients, and since r05 a bf16 gradient handed to each LayerNorm backward -- and two lr = 0.05 steps carry that
+    #  into the outputs, where the bf16 forward turns any parameter difference into whole-ulp flips; measured 2.2e-3 on the two-rank FULL_SHARD case,
+    #  < 2e-3 on one rank)
+    res["eval_after_worst_rel_over_tol"] = max(close(a, b, 4e-3) for a, b in zip(e1w[1:], e1p[1:]))
     res["eval_changed_by_training"] = abs(e1p[0] - e0p[0])
     # final parameters: FSDP's full state dict (clean names; gathers the shards) against the unwrapped model's
     sd_w = wrapped.state_dict()
