@@ -67,8 +67,7 @@ def test_no_cpu_fallback():
 
 def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
     """CLIP, FLAVA (encoders, pre-training heads, losses) and CoCa have a differentiable (training) forward on the HIP kernels; like
-    everything else it has no CPU path -- post-norm layers (the reference's default; trainable since r05) included; configurations the
-    backward does not cover (post-norm DECODER layers) raise."""
+    everything else it has no CPU path -- post-norm encoder AND decoder layers (the reference's default; trainable since r05) included."""
     from multimodal_amd import ops
     from multimodal_amd.models.clip import CLIPViTEncoder
     from multimodal_amd.models.flava.transformer import TransformerEncoder as FlavaEncoder
@@ -88,7 +87,7 @@ def test_training_forward_needs_the_gpu_and_other_families_still_refuse():
         LayersEncoder(1, 128, 2, 256, activation=torch.nn.GELU).train()(torch.zeros(1, 4, 128))
     from multimodal_amd.modules.layers.transformer import TransformerDecoder
 
-    with pytest.raises(ops.MmamdError, match="pre-norm"):
+    with pytest.raises(ops.MmamdError, match="no CPU"):  # post-norm decoder layers
         TransformerDecoder(1, 128, 2, 256, activation=torch.nn.GELU, use_cross_attention=False).train()(torch.zeros(1, 4, 128))
     # a stand-alone layer in training is a differentiable call now (it used to raise NotImplementedError): no CPU path either
     from multimodal_amd.modules.layers.transformer import TransformerEncoderLayer
