@@ -200,6 +200,22 @@ int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, int ldw, fl
  * examples/flava/native/train.py:312-322).  ws: (splits + 1) * M * N + splits * M floats. */
 int mmamd_gemm_bf16_tn_splitk_colsum(const void* A, int lda, const void* W, int ldw, float* C, float* db, float* ws, int M, int N, int K,
                                      int splits, mmamd_stream_t stream);
+/* Up to 8 weight gradients in ONE launch (the four dW = dY^T X of a transformer layer) + one reduce launch: job i is dw[M,N] = dy[K,M]^T x[K,N]
+ * (row-major bf16 operands over the K tokens, K % 128 == 0, M and N multiples of 8), db[M] (optional) = the column sums of dy from the same pass.
+ * `splits`: K is cut into that many parts per problem (every (tile, split) pair is one workgroup: pick it so that the launch fills the CUs a whole
+ * number of times).  ws: mmamd_gemm_bf16_tn_splitk_group_ws(jobs, njobs, splits) floats.  Each result equals mmamd_gemm_bf16_tn_splitk(_colsum) of
+ * that problem with the same `splits`, bit for bit.  Replaces the per-Linear weight / bias gradients of torch autograd. */
+typedef struct {
+  const void* dy;
+  int lddy;
+  const void* x;
+  int ldx;
+  float* dw;
+  float* db;
+  int M, N, K;
+} mmamd_wgrad_job;
+long long mmamd_gemm_bf16_tn_splitk_group_ws(const mmamd_wgrad_job* jobs, int njobs, int splits);
+int mmamd_gemm_bf16_tn_splitk_group(const mmamd_wgrad_job* jobs, int njobs, int splits, float* ws, mmamd_stream_t stream);
 
 /* Same, additionally returning the attention probabilities (normalised, [B,H,S,S], probs_dtype F32 or BF16) and honouring a
  * key-padding mask (uint8 [B,S], 0 = masked key, NULL = none).  Non-causal.  Replaces scaled_dot_product_attention of

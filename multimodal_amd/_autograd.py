@@ -78,6 +78,20 @@ def wgrad(dy: Tensor, x: Tensor, bias: bool = False):
     return (dW, db) if bias else dW
 
 
+_GROUPED_WGRAD = True  # tools/train_bench.py --no-grouped-wgrad: one split-K launch (+ reduce) per Linear, the form before r05's grouped launch
+
+
+def wgrad_many(jobs):
+    """[(dy, x, bias)] -> [(dW, db or None)]: the weight / bias gradients of a layer's Linears.  Full-size batches (token counts that are multiples of 128)
+    go to ONE grouped split-K launch + one reduce launch (mmamd_gemm_bf16_tn_splitk_group: together the four problems of a layer fill the CUs at 5-7
+    splits each, where the small ones alone need 21-28 and every one its own reduce); everything else takes wgrad() one by one."""
+    ok = _GROUPED_WGRAD and _FUSED_BIAS_GRAD and 1 < len(jobs) <= 8 and all(
+        dy.shape[0] % 128 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.shape[0] == x.shape[0] for dy, x, _ in jobs)
+    if not ok:
+        return [wgrad(dy, x, bias=True) if b else (wgrad(dy, x), None) for dy, x, b in jobs]
+    return ops.gemm_bf16_tn_splitk_group([(dy if dy.dtype == bf else ops.convert(dy, bf), x if x.dtype == bf else ops.convert(x, bf), b) for dy, x, b in jobs])
+
+
 class StackConfig:
     """Static description of a layer stack for EncoderStackFn.  to_canonical(layer params) -> the 12 canonical tensors
     (Wqkv [3d,d], bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2); from_canonical(12 grads) -> grads in the layer's parameter order."""
@@ -305,24 +319,24 @@ def _stack_bwd_impl(dx_out: Tensor, x0: Tensor, saved: List[Tensor], params: Lis
         du = dgrad_t(dXb, W2T, bf, _ACT_GRAD[act], u)
         if pm > 0:
             ops.dropout(du, pm, seed, 16 * li + 1, out=du)  # g' = g * m / (1 - p): the mask commutes with the activation's derivative
-        if dXsum is None:
-            dW2, db2 = wgrad(dXb, g, bias=True)
-        else:
-            dW2, db2 = wgrad(dXb, g), dXsum
+        wjobs = [(dXb, g, dXsum is None)]  # the layer's four weight gradients go out together below (nothing on the way down needs them)
         # u = h2 W1^T + b1
         dh2 = dgrad_t(du, W1T, bf if _BF16_DH else f32)
-        dW1, db1 = wgrad(du, h2, bias=True)
+        wjobs.append((du, h2, True))
         dx_mid, dg2, dbe2, dxmb, dbo = ops.layernorm_bwd(x_mid, g2, dh2, eps2[li], add=dX, want_bf16=True, want_colsum=True, defer=pending)
         if pb > 0:  # x_mid = x + drop(att Wo^T + bo)
             dxmb = ops.dropout(dx_mid, pb, seed, 16 * li, group=grp, out_dtype=bf)
             dbo = ops.colsum(dxmb)
         # x_mid = x + att Wo^T + bo
         datt = dgrad_t(dxmb, WoT, bf)
-        dWo = wgrad(dxmb, att)
+        wjobs.append((dxmb, att, False))
         dqkv = _attn_bwd_any(qkv, att, datt, lse, B, S, H, causal, key_mask, full_mask, drop[2] if drop else 0.0, seed, 16 * li + 3, head_mask)
         # qkv = h1 Wqkv^T + bqkv
         dh1 = dgrad_t(dqkv, WqkvT, bf if _BF16_DH else f32)
-        dWqkv, dbqkv = wgrad(dqkv, h1, bias=True)
+        wjobs.append((dqkv, h1, True))
+        (dW2, db2), (dW1, db1), (dWo, _), (dWqkv, dbqkv) = wgrad_many(wjobs)
+        if dXsum is not None:
+            db2 = dXsum
         dX, dg1, dbe1, dXb, dXsum = ops.layernorm_bwd(x, g1, dh1, eps1[li], add=dx_mid, want_bf16=True, want_colsum=True, defer=pending)
         if li > 0 and dhidden and dhidden[li - 1] is not None:
             # this layer's input was also handed out as hidden_states[li] and something differentiated through it: dX += that gradient
@@ -848,8 +862,12 @@ class DecoderStackConfig:
     has_cross; params per layer in the order self q/k/v/o (w, b), attention LN (w, b), [cross q/k/v/o (w, b), cross LN (w, b)],
     ff0 (w, b), ff1 (w, b), feedforward LN (w, b)."""
 
-    def __init__(self, B: int, S: int, Sk: int, layers, mask: Optional[ops.AttnMask], drop_p: float = 0.0, seed: int = 0, layer0: int = 0):
+    def __init__(self, B: int, S: int, Sk: int, layers, mask: Optional[ops.AttnMask], drop_p: float = 0.0, seed: int = 0, layer0: int = 0,
+                 cross_mask: Optional[ops.AttnMask] = None):
         self.B, self.S, self.Sk, self.layers, self.mask = B, S, Sk, layers, mask or ops.AttnMask()
+        # mask of the cross-attention blocks ([S, Sk] per sample or shared): a stand-alone TransformerDecoderLayer takes one (reference transformer.py:
+        # 366-376); the reference's TransformerDecoder does not hand its own to its layers (:630-636), so a whole stack runs without
+        self.cross_mask = cross_mask
         self.layer0 = int(layer0)  # index of layers[0] in the module's stack (a stack run as one node per layer keeps its dropout sites)
         # training-time dropout: ONE rate on the six sites of a layer (self-attention probabilities and branch, cross-attention probabilities and
         # branch, the MLP's hidden dropout, the feed-forward branch), masks from Philox(seed, 16 * layer + site)
@@ -900,7 +918,7 @@ class DecoderStackFn(torch.autograd.Function):
                     qc = ops.gemm_bf16(hc, ops.convert(cqw, bf), cqb)
                     kvc = ops.gemm_bf16(encb, ops.convert(torch.cat([ckw, cvw], 0), bf), torch.cat([ckb, cvb], 0))
                     lsec = torch.empty((B, H, S), dtype=f32, device=x.device)
-                    attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, None, lse=lsec, drop=(pd, sd, site + 5))
+                    attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, cfg.cross_mask, lse=lsec, drop=(pd, sd, site + 5))
                     c_raw = branch(attc, cow, cob, a, site + 4)
                     a2 = ops.layernorm(c_raw, gc, bec, L["epsc"], out_dtype=f32)
                     rec += [hc, qc, kvc, attc, lsec, c_raw, a2]
@@ -934,7 +952,7 @@ class DecoderStackFn(torch.autograd.Function):
                 qc = ops.gemm_bf16(hc, ops.convert(cqw, bf), cqb)
                 kvc = ops.gemm_bf16(encb, ops.convert(torch.cat([ckw, cvw], 0), bf), torch.cat([ckb, cvb], 0))
                 lsec = torch.empty((B, H, S), dtype=f32, device=x.device)
-                attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, None, lse=lsec, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
+                attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, cfg.cross_mask, lse=lsec, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
                 if pd > 0:
                     a2 = ops.dropout(ops.gemm_bf16(attc, ops.convert(cow, bf), cob, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li) + 4, residual=a)
                 else:
@@ -1012,7 +1030,7 @@ class DecoderStackFn(torch.autograd.Function):
                         d_cb = ops.dropout(d_c, pd, sd, site + 4, out_dtype=bf)
                     dattc = dgrad(d_cb, cow, bf)
                     dWco, dbco = wgrad(d_cb, attc, bias=True)
-                    dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, None, drop=(pd, sd, site + 5))
+                    dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, cfg.cross_mask, drop=(pd, sd, site + 5))
                     d_a = dgrad(dqc, cqw, f32, ops.ACT_NONE, d_c)  # d_c + dqc Wq
                     dWcq, dbcq = wgrad(dqc, hc, bias=True)
                     wckv = torch.cat([ckw, cvw], 0)
@@ -1070,7 +1088,7 @@ class DecoderStackFn(torch.autograd.Function):
                     d_a2b = ops.dropout(d_a2, pd, sd, 16 * (cfg.layer0 + li) + 4, out_dtype=bf)
                 dattc = dgrad(d_a2b, cow, bf)
                 dWco, dbco = wgrad(d_a2b, attc, bias=True)
-                dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, None, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
+                dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, cfg.cross_mask, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
                 dhc = dgrad(dqc, cqw, f32)
                 dWcq, dbcq = wgrad(dqc, hc, bias=True)
                 wckv = torch.cat([ckw, cvw], 0)

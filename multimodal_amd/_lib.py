@@ -56,6 +56,8 @@ PROTOTYPES = {
     "mmamd_layernorm_bwd_groups": (_i, [_i, _i]),
     "mmamd_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "mmamd_colsum_stage2_batched": (_i, [_vp, _i, _vp]),
+    "mmamd_gemm_bf16_tn_splitk_group_ws": (C.c_longlong, [_vp, _i, _i]),
+    "mmamd_gemm_bf16_tn_splitk_group": (_i, [_vp, _i, _i, _vp, _vp]),
     "mmamd_colsum": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmamd_gemm_bf16_dual": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmamd_bicubic_pos_embed": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _f, _vp]),

@@ -558,336 +558,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(const GemmArg
 template <int BM, int BN, int WM, int WN, bool OUT_F32, int ACT, int GM, int ABL = 0, bool LDSEPI = true, bool TNM = false, int SCH = 0, bool CS = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_p(const GemmArgs p, const int tiles_m,
                                                                         unsigned long long* trace = nullptr) {
-  static_assert(!TNM || (BM == 256 && BN == 256), "TN image below is laid out for 256-column operand tiles");
-  static_assert(!CS || (TNM && BM / WM / 32 == WN), "CS: wave (wm, wn) sums the A fragment mi = wn of its 128 columns");
-  constexpr int NW = WM * WN;
-  constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int MI = TM / 32, NI = TN / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
-  constexpr int NF = NI + MI, NM = NI * MI, NDMA = A_INSTR + B_INSTR;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 4 == 0, "tile/wave geometry");
-  static_assert(NM >= NF && NM >= NDMA, "interleave below needs one MFMA per fragment read / DMA piece");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
   int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  // split-K, flat form: the XCD-contiguous id enumerates (split, tile) split-major, so the ~32 workgroups an XCD runs are ONE split's
-  // neighbouring tiles: they stream the same contraction rows at the same time and share the operand panels in that XCD's L2
-  int split = (int)blockIdx.y;
-  if (p.split_flat) {
-    const int ntile = tiles_m * p.tiles_n;
-    split = bid / ntile;
-    bid -= split * ntile;
-  }
-  int tm, tn;
-  {
-    const int per_group = GM * p.tiles_n;
-    const int grp = bid / per_group, within = bid - grp * per_group;
-    const int gm0 = grp * GM;
-    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
-    tn = within / rows;
-    tm = gm0 + (within - tn * rows);
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int nwg = gridDim.x, bid_launch = blockIdx.x, split_y = blockIdx.y;
+#include "gemm_p_body.inc"
+}
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave / WN, wn = wave - wm * WN;
 
-  const int sw = (4 * (wave & 3) + (lane >> 4)) & 15;
-  const int slot = (lane & 15) ^ sw;
-  const int row8 = 2 * (lane >> 4) + (slot >> 3);
-  const int chunk = slot & 7;
-  uint32_t a_off[A_INSTR], b_off[B_INSTR];
-  if constexpr (TNM) {
-    // piece pi (1 KiB = 4 units) holds contraction rows 4*(pi>>1)..+3, columns 128*(pi&1)..+127: lane -> unit lane>>4, block
-    // (lane>>3)&1, row (lane>>1)&3, 16-byte half of the block row lane&1.  Columns past the matrix are clamped (they only feed
-    // rows / columns of C that are never stored).
-    const int pu = lane >> 4, pcb = (lane >> 3) & 1, prow = (lane >> 1) & 3, phr = lane & 1;
+// Grouped weight gradients (r05): up to 8 TN split-K problems in ONE launch -- the four dW = dY^T X of a transformer layer.  Launched one by one, the
+// small ones need 21-28 splits to fill 256 CUs (28 K-tiles per workgroup between a 64 KiB prologue and a 256 KiB partial store; 66 MB of partials per
+// GEMM whatever its size) and each pays its own reduce launch; together they fill the chip at a few splits each.  Problem i owns the workgroups
+// [wg0[i], wg0[i] + nwg[i]) (wg0 8-aligned, so a workgroup's XCD is its local index mod 8 as in the plain launch); the padding workgroups exit.
+constexpr int kTnGroupMax = 8;
+struct GemmTnGroupArgs {
+  GemmArgs p[kTnGroupMax];
+  int wg0[kTnGroupMax], nwg[kTnGroupMax], tiles_m[kTnGroupMax];
+  int nprob;
+};
+template <bool CS>
+__global__ __launch_bounds__(512) void gemm_bf16_tn_group_kernel(const GemmTnGroupArgs g) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, ACT = MMAMD_ACT_NONE, GM = 8, ABL = 0, SCH = 0;
+  constexpr bool OUT_F32 = true, LDSEPI = true, TNM = true;
+  int pi = 0;
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      const int pi = wave + NW * j;
-      int c = m0 + (4 * (pi & 1) + pu) * 32 + pcb * 16 + phr * 8;
-      c = c + 8 <= p.M ? c : p.M - 8;
-      a_off[j] = ((uint32_t)(4 * (pi >> 1) + prow) * (uint32_t)p.lda + c) * 2u;
-    }
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
-      const int pi = wave + NW * j;
-      int c = n0 + (4 * (pi & 1) + pu) * 32 + pcb * 16 + phr * 8;
-      c = c + 8 <= p.N ? c : p.N - 8;
-      b_off[j] = ((uint32_t)(4 * (pi >> 1) + prow) * (uint32_t)p.ldw + c) * 2u;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      int r = m0 + 8 * (wave + NW * j) + row8;
-      r = r < p.M ? r : p.M - 1;
-      a_off[j] = ((uint32_t)r * (uint32_t)p.lda + chunk * 8) * 2u;
-    }
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
-      int r = n0 + 8 * (wave + NW * j) + row8;
-      r = r < p.N ? r : p.N - 1;
-      b_off[j] = ((uint32_t)r * (uint32_t)p.ldw + chunk * 8) * 2u;
-    }
-  }
-  // split-K: this block owns K-tiles [kt0, kt0 + KT) and writes its own partial output (no bias / residual / activation)
-  const int kt0 = p.kt_chunk > 0 ? split * p.kt_chunk : 0;
-  const size_t a_step = TNM ? (size_t)64 * p.lda * 2 : 128, w_step = TNM ? (size_t)64 * p.ldw * 2 : 128;  // bytes per K-tile
-  const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)kt0 * a_step;
-  const char* Wb = reinterpret_cast<const char*>(p.W) + (size_t)kt0 * w_step;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  // piece i of a stage (i < A_INSTR: activation rows, else weight rows): scalar base + K offset, per-lane 32-bit offset
-  auto issue_piece = [&](int buf, int kt, int i) __attribute__((always_inline)) {
-    const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
-    if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * a_step, a_off[i], dst);
-    else dma_piece_s(Wb + (size_t)kt * w_step, b_off[i - A_INSTR], dst);
-  };
-  auto issue_stage = [&](int buf, int kt) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) issue_piece(buf, kt, i);
-  };
-
-  const int l31 = lane & 31, half = lane >> 5;
-  const int hsw = l31 >> 1;
-  // per-lane LDS byte addresses of the fragment reads, fully precomputed per (buffer, k-step): the K loop is unrolled by
-  // two so the buffer is a compile-time constant and NO address VALU is left inside the loop (every VALU instruction
-  // beside the MFMA stream waits for an issue gap of the matrix pipe; the 8 v_add per K-tile cost ~25 % of the loop)
-  uint32_t ra[2][4], rb[2][4];
-#pragma unroll
-  for (int bf = 0; bf < 2; ++bf)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if constexpr (TNM) {
-        // k-step t = contraction rows 16t..16t+15: this lane's slots 0-3 are rows 16t + 4*half + {0..3} (unit row 4t + half),
-        // slots 4-7 the same + 8 (unit row + 2, i.e. + 4096 bytes); 32-column block b of the operand tile = unit column b
-        const uint32_t ro = (uint32_t)((4 * t + half) * 8) * 256 + ((lane >> 4) & 1) * 128 + ((lane & 15) >> 2) * 32 + (lane & 3) * 8;
-        ra[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + (wm * TM / 32) * 256 + ro;
-        rb[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + A_BYTES + (wn * TN / 32) * 256 + ro;
-      } else {
-        const uint32_t ro = hsw * 256 + (((((l31 & 1) << 3) | (2 * t + half)) ^ hsw) << 4);
-        ra[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + (wm * TM) * 128 + ro;
-        rb[bf][t] = (uint32_t)(uintptr_t)(lds_u32p)smem + bf * STAGE + A_BYTES + (wn * TN) * 128 + ro;
-      }
-    }
-  typedef __attribute__((address_space(3))) const bf16x8* lds_frag_p;
-  typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-  typedef __attribute__((address_space(3))) s16x4_t* lds_tr_p;
-  auto tr_frag = [&](uint32_t addr) -> bf16x8 {  // two transpose reads: contraction rows r..r+3 and r+8..r+11 of this lane's column
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr_p>((uintptr_t)addr));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_tr_p>((uintptr_t)(addr + 4096)));
-    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-  };
-
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-
-  bf16x8 xa0[MI], wb0[NI], xa1[MI], wb1[NI];  // two fragment sets, statically named (no runtime indexing)
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xa1[mi][j] = (bf16)0.f;  // first rotated MFMA group multiplies zeros
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wb1[ni][j] = (bf16)0.f;
-
-  // CS (bias gradient beside the weight gradient, r05): in TN mode an A fragment holds 8 contraction rows of ONE column of dY per lane, so
-  // db[m] = sum_t dY[t][m] is 4 v_dot2c_f32_bf16 (x . (1, 1)) per fragment and k-step.  The workgroups of column tile 0 do it, and wave
-  // (wm, wn) owns fragment mi = wn of its 128 columns: in the hand-ordered first segment of every K-tile it reads that fragment of the
-  // tile's four k-steps once more from LDS (the wave-uniform wn only moves the ADDRESS: no run-time register indexing, no coupling with the
-  // live ranges of the MFMA fragments) -- 8 transpose reads and 16 dot products per K-tile beside 32 MFMAs.  Deterministic: a fixed order per
-  // lane; the split partials are summed by splitk_reduce_kernel.
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_cs;
-  [[maybe_unused]] float cs = 0.f;
-  [[maybe_unused]] bool do_cs = false;
-  [[maybe_unused]] bf16x8 csf[4];
-  if constexpr (CS) do_cs = tn == 0 && p.cs_out != nullptr;
-  auto cs_dot = [&](const bf16x8& f) __attribute__((always_inline)) {
-    const bf16x2_cs ones = {(bf16)1.0f, (bf16)1.0f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16x2_cs v = {f[2 * j], f[2 * j + 1]};
-      cs = __builtin_amdgcn_fdot2_f32_bf16(v, ones, cs, false);
-    }
-  };
-
-  auto load_frags = [&](auto bufc, int t, bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
-    if constexpr ((ABL & 8) != 0) return;
-    constexpr int BF = decltype(bufc)::value;
-    if constexpr (TNM) {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wb[ni] = tr_frag(rb[BF][t] + ni * 256);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xa[mi] = tr_frag(ra[BF][t] + mi * 256);
-    } else {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wb[ni] = *reinterpret_cast<lds_frag_p>((uintptr_t)(rb[BF][t] + ni * 32 * 128));
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<lds_frag_p>((uintptr_t)(ra[BF][t] + mi * 32 * 128));
-    }
-  };
-  auto mma = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI]) {
-    if constexpr ((ABL & 2) != 0) {  // keep the fragment reads alive without the matrix work
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wb[ni]));
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(xa[mi]));
-      return;
-    }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ni], xa[mi], acc[ni][mi], 0, 0, 0);
-  };
-  // one K-tile between two barriers.  On entry: tile kt is visible in LDS, (xa1, wb1) hold the LAST k-step of
-  // tile kt-1 (or zeros).  On exit: (xa1, wb1) hold the last k-step of tile kt, everything else is consumed.
-  auto mma_one = [&](bf16x8 (&xa)[MI], bf16x8 (&wb)[NI], int i) {
-    acc[i / MI][i % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i / MI], xa[i % MI], acc[i / MI][i % MI], 0, 0, 0);
-  };
-  auto tile_body = [&](int kt, auto bufc, const bool has_next) __attribute__((always_inline)) {
-    constexpr int BF = decltype(bufc)::value;
-    const bool NEXT = has_next && (ABL & 1) == 0;
-    // segment 1 (hand-ordered; the asm DMA is invisible to sched_group_barrier): this tile's first fragments, then the
-    // previous tile's last k-step with one DMA piece of tile kt+1 behind every MFMA
-    load_frags(bufc, 0, xa0, wb0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      mma_one(xa1, wb1, i);
-      if (NEXT && i < NDMA) issue_piece(BF ^ 1, kt + 1, i);  // wave-uniform scalar branch
-      if constexpr (CS && NM >= 8) {
-        if (do_cs) {  // workgroup-uniform: k-step i's copy of this wave's own A fragment is requested behind MFMA i, summed behind MFMA i + 4
-          if (i < 4) csf[i] = tr_frag(ra[BF][i] + wn * 256);
-          else if (i < 8) cs_dot(csf[i - 4]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // segment 2 (compiler-scheduled under the pattern below): k-steps 0..2 with the next step's reads interleaved
-    load_frags(bufc, 1, xa1, wb1);
-    mma(xa0, wb0);
-    load_frags(bufc, 2, xa0, wb0);
-    mma(xa1, wb1);
-    load_frags(bufc, 3, xa1, wb1);
-    mma(xa0, wb0);
-    if constexpr (ABL != 0 || SCH == 2) return;  // ablations / experiment: leave the order to the compiler
-    if constexpr (SCH == 1) {  // experiment: all fragment reads of the next k-step in one burst, then the MFMAs
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x100, (TNM ? 2 : 1) * NF, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-      }
-      return;
-    }
-    if constexpr (SCH == 3) {  // experiment: reads first, in pairs, each pair followed by one MFMA
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x100, TNM ? 2 : 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
-      }
-      return;
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-#pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, TNM ? 2 : 1, 0);
-      }
-      if constexpr (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
-    }
-  };
-  int tix = 0;
-  unsigned long long* tr = nullptr;
-  if constexpr ((ABL & 64) != 0) {
-    if (trace != nullptr && blockIdx.x < 64 && (wave & 3) == 0) tr = trace + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256;
-  }
-  auto stamp = [&]() __attribute__((always_inline)) {
-    if constexpr ((ABL & 64) != 0) {
-      if (tr != nullptr && tix < 255) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        if (lane == 0) tr[1 + tix] = t;
-        ++tix;
-      }
-    }
-  };
-  stamp();
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  auto sync_tile = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the tile have landed
-    __syncthreads();                                   // ... everyone's; and the previous tile's reads are done
-  };
-
-  if constexpr ((ABL & 32) != 0) {
-    // experiment: break the lock-step of the first wave of blocks (all CUs otherwise hit their store bursts together)
-    if (blockIdx.x < 256) {
-      const int phase = (blockIdx.x >> 3) & 3;  // 4 phases inside every XCD
-      for (int i = 0; i < phase * 2; ++i) __builtin_amdgcn_s_sleep(127);  // 127*64 cycles ~ 3.4 us each -> ~T/4 per phase
-    }
-  }
-  // even (checked by the launcher): two tiles per trip, the buffer index is a compile-time constant
-  const int KT = p.kt_chunk > 0 ? ((p.K >> 6) - kt0 < p.kt_chunk ? (p.K >> 6) - kt0 : p.kt_chunk) : (p.K >> 6);
-  issue_stage(0, 0);
-#pragma unroll 1
-  for (int kt = 0; kt < KT; kt += 2) {
-    sync_tile();
-    stamp();
-    tile_body(kt, B0{}, true);
-    sync_tile();
-    stamp();
-    tile_body(kt + 1, B1{}, kt + 2 < KT);
-  }
-  stamp();
-  mma(xa1, wb1);
-  if constexpr (CS) {
-    if (do_cs) {
-      // the two lane halves hold the sums over different contraction rows of the same column: add them, lanes 0-31 store the wave's 32 columns
-      cs += __shfl_xor(cs, 32);
-      const int col = m0 + wm * TM + wn * 32 + l31;
-      if (half == 0 && col < p.M) p.cs_out[(size_t)split * p.M + col] = cs;
-    }
-  }
-
-  if constexpr ((ABL & 4) != 0) {
-    float ssum = 0.f;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ssum += acc[ni][mi][r];
-    if (ssum == 1.2345678e33f) reinterpret_cast<float*>(p.C)[0] = ssum;
-    return;
-  }
-  GemmArgs pe = p;
-  if (p.kt_chunk > 0) pe.C = reinterpret_cast<float*>(p.C) + (size_t)split * (size_t)p.c_split_stride;
-  if constexpr (LDSEPI) gemm_epilogue_lds<MI, NI, TM, TN, OUT_F32, ACT, ABL>(acc, pe, m0, n0, wm, wn, lane, wave, smem);
-  else gemm_epilogue<MI, NI, TM, TN, OUT_F32, ACT>(acc, pe, m0, n0, wm, wn, lane);
-  if constexpr ((ABL & 64) != 0) {
-    stamp();                                           // stores issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores retired
-    stamp();
-    if (tr != nullptr && lane == 0) tr[0] = (unsigned long long)tix;
-  }
+  for (int i = 1; i < kTnGroupMax; ++i)
+    if (i < g.nprob && (int)blockIdx.x >= g.wg0[i]) pi = i;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  int bid = (int)blockIdx.x - g.wg0[pi];
+  const int nwg = g.nwg[pi];
+  if (bid >= nwg) return;
+  const GemmArgs& p = g.p[pi];
+  const int tiles_m = g.tiles_m[pi], bid_launch = blockIdx.x, split_y = 0;
+  unsigned long long* const trace = nullptr;
+#include "gemm_p_body.inc"
 }
 
 
@@ -2237,6 +1939,122 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((n + n2) / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit, n, C, db_part, n2, db);
   }
   return launch_status("gemm_bf16_splitk");
+}
+
+// ---- grouped weight gradients: one GEMM launch + one reduce launch for up to 8 problems (gemm_bf16_tn_group_kernel above) ----
+namespace mmamd {
+struct SplitkReduceJob {
+  const float* part;
+  float* out;
+  const float* part2;
+  float* out2;
+  long long n, n2;
+  int splits;
+};
+struct SplitkReduceJobs {
+  SplitkReduceJob j[kTnGroupMax];
+};
+// splitk_reduce_kernel per job (blockIdx.y): the same sums in the same order
+__global__ __launch_bounds__(256) void splitk_reduce_batched_kernel(const SplitkReduceJobs jobs) {
+  const SplitkReduceJob& jb = jobs.j[blockIdx.y];
+  const float* part = jb.part;
+  float* out = jb.out;
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  long long stride = jb.n;
+  if (i >= jb.n) {
+    i -= jb.n;
+    if (i >= jb.n2) return;
+    part = jb.part2; out = jb.out2; stride = jb.n2;
+  }
+  if (jb.splits <= 1) return;  // the GEMM wrote this problem's result itself
+  f32x4 acc = load4(part + i);
+  for (int s = 1; s < jb.splits; ++s) {
+    const f32x4 v = load4(part + (size_t)s * stride + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += v[j];
+  }
+  store4(out + i, acc);
+}
+}  // namespace mmamd
+
+static int tn_group_nsplit(int K, int splits, int* chunk_out) {
+  const int KT = K / 64;
+  int chunk = (KT + splits - 1) / splits;
+  chunk += chunk & 1;  // even number of K-tiles per split, as in gemm_splitk_impl
+  *chunk_out = chunk;
+  return (KT + chunk - 1) / chunk;
+}
+
+extern "C" long long mmamd_gemm_bf16_tn_splitk_group_ws(const mmamd_wgrad_job* jobs, int njobs, int splits) {
+  if (!jobs || njobs < 1 || splits < 1) return -1;
+  long long total = 4;
+  for (int i = 0; i < njobs; ++i) {
+    if (jobs[i].K <= 0 || jobs[i].K % 128 != 0) return -1;
+    int chunk;
+    const int ns = tn_group_nsplit(jobs[i].K, splits, &chunk);
+    if (ns > 1) total += (long long)ns * jobs[i].M * jobs[i].N + (jobs[i].db ? (long long)ns * jobs[i].M : 0);
+  }
+  return total;
+}
+
+extern "C" int mmamd_gemm_bf16_tn_splitk_group(const mmamd_wgrad_job* jobs, int njobs, int splits, float* ws, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(jobs && ws && njobs >= 1 && njobs <= kTnGroupMax && splits >= 1, MMAMD_E_BADARG, "gemm_tn_splitk_group: bad argument (1..%d jobs)", kTnGroupMax);
+  GemmTnGroupArgs g;
+  SplitkReduceJobs rj;
+  bool any_cs = false, any_split = false;
+  int wg = 0;
+  unsigned max_blocks = 1;
+  float* wsp = ws;
+  for (int i = 0; i < njobs; ++i) {
+    const mmamd_wgrad_job& jb = jobs[i];
+    MMAMD_CHECK_ARG(jb.dy && jb.x && jb.dw && jb.M > 0 && jb.N > 0 && jb.K > 0, MMAMD_E_BADARG, "gemm_tn_splitk_group: bad job %d", i);
+    MMAMD_CHECK_ARG(jb.K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_group: contraction length K=%d must be a multiple of 128", jb.K);
+    MMAMD_CHECK_ARG(jb.M % 8 == 0 && jb.N % 8 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_group: M=%d and N=%d must be multiples of 8", jb.M, jb.N);
+    MMAMD_CHECK_ARG(jb.lddy >= jb.M && jb.ldx >= jb.N && jb.lddy % 8 == 0 && jb.ldx % 8 == 0, MMAMD_E_BADARG, "gemm_tn_splitk_group: bad leading dimension");
+    MMAMD_CHECK_ARG(aligned16(jb.dy) && aligned16(jb.x) && aligned16(jb.dw) && aligned16(ws), MMAMD_E_ALIGN, "gemm_tn_splitk_group: base pointers must be 16-byte aligned");
+    MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)jb.lddy * 2u < (1ull << 32) && (uint64_t)64 * (uint64_t)jb.ldx * 2u < (1ull << 32), MMAMD_E_UNSUPPORTED,
+                    "gemm_tn_splitk_group: leading dimension too large for the 32-bit DMA offsets");
+    int chunk;
+    const int nsplit = tn_group_nsplit(jb.K, splits, &chunk);
+    GemmArgs& p = g.p[i];
+    p = GemmArgs{};
+    float* part = nsplit == 1 ? jb.dw : wsp;
+    if (nsplit > 1) wsp += (size_t)nsplit * jb.M * jb.N;
+    float* db_part = jb.db ? (nsplit == 1 ? jb.db : wsp) : nullptr;
+    if (jb.db && nsplit > 1) wsp += (size_t)nsplit * jb.M;
+    p.A = (const bf16*)jb.dy; p.W = (const bf16*)jb.x; p.bias = nullptr; p.R = nullptr; p.C = part;
+    p.M = jb.M; p.N = jb.N; p.K = jb.K; p.lda = jb.lddy; p.ldw = jb.ldx; p.ldr = 0; p.ldc = jb.N; p.act = MMAMD_ACT_NONE;
+    p.kt_chunk = chunk; p.c_split_stride = (long long)jb.M * jb.N; p.res_mode = 0;
+    p.C2 = nullptr; p.ldc2 = 0; p.act2 = 0; p.split_flat = 1;
+    p.cs_out = db_part;
+    p.tiles_n = (jb.N + 255) / 256;
+    g.tiles_m[i] = (jb.M + 255) / 256;
+    g.nwg[i] = g.tiles_m[i] * p.tiles_n * nsplit;
+    g.wg0[i] = wg;
+    wg += (g.nwg[i] + 7) & ~7;
+    any_cs |= jb.db != nullptr;
+    any_split |= nsplit > 1;
+    const long long n = (long long)jb.M * jb.N, n2 = jb.db ? (long long)jb.M : 0;
+    rj.j[i] = SplitkReduceJob{part, jb.dw, db_part, jb.db, n, n2, nsplit};
+    const unsigned nb = (unsigned)(((n + n2) / 4 + 255) / 256);
+    if (nsplit > 1 && nb > max_blocks) max_blocks = nb;
+  }
+  for (int i = njobs; i < kTnGroupMax; ++i) { g.p[i] = GemmArgs{}; g.wg0[i] = wg; g.nwg[i] = 0; g.tiles_m[i] = 0; rj.j[i] = SplitkReduceJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0}; }
+  g.nprob = njobs;
+  constexpr int smem = 2 * 512 * 128;
+  hipStream_t st = (hipStream_t)stream;
+  static unsigned long long attr_cs = 0, attr_plain = 0;  // per-device one-time opt-in to > 64 KiB dynamic LDS
+  if (any_cs) {
+    auto kern = gemm_bf16_tn_group_kernel<true>;
+    if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_cs)) return rc_attr;
+    hipLaunchKernelGGL(kern, dim3(wg), dim3(512), smem, st, g);
+  } else {
+    auto kern = gemm_bf16_tn_group_kernel<false>;
+    if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_plain)) return rc_attr;
+    hipLaunchKernelGGL(kern, dim3(wg), dim3(512), smem, st, g);
+  }
+  if (any_split) hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3(max_blocks, njobs), dim3(256), 0, st, rj);
+  return launch_status("gemm_bf16_tn_splitk_group");
 }
 
 extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K,

@@ -372,9 +372,8 @@ class TransformerDecoderLayer(nn.Module):
             # differentiable stand-alone layer: a one-layer DecoderStackFn node (what a wrapped layer runs in training)
             if past_key_value is not None or use_cache:
                 raise ops.MmamdError("key/value caching is an inference feature: call the layer under torch.no_grad() / in eval mode")
-            if cross_attention_mask is not None:
-                raise ops.MmamdError("training on the MI355X path: cross_attention_mask is not implemented")
-            out = _decoder_layers_forward_train([self], self.training, None, hidden_states, encoder_hidden_states, attention_mask, False)
+            out = _decoder_layers_forward_train([self], self.training, None, hidden_states, encoder_hidden_states, attention_mask, False,
+                                                cross_attention_mask=cross_attention_mask)
             return out.last_hidden_state, None
         B, S, d = hidden_states.shape
         enc, Sk = None, 0
@@ -511,7 +510,7 @@ def _decoder_forward_train(self, hidden_states: Tensor, encoder_hidden_states, a
 
 
 def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, hidden_states: Tensor, encoder_hidden_states, attention_mask,
-                                  return_hidden_states: bool) -> TransformerOutput:
+                                  return_hidden_states: bool, cross_attention_mask: Optional[Tensor] = None) -> TransformerOutput:
     """Differentiable forward of a list of TransformerDecoderLayers (a whole TransformerDecoder, or ONE stand-alone / wrapped layer)."""
     from ..._autograd import DecoderStackConfig, DecoderStackFn, draw_seed
 
@@ -553,6 +552,7 @@ def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, 
         Sk = encoder_hidden_states.shape[1]
         e = encoder_hidden_states if encoder_hidden_states.is_contiguous() else encoder_hidden_states.contiguous()
         enc2d = e.view(B * Sk, e.shape[-1])
+    cross_mask = to_attn_mask(cross_attention_mask, False, B, S, Sk) if (cross_attention_mask is not None and enc2d is not None) else None
     if training and len(drop_rates) > 1:
         raise ops.MmamdError(f"training: all dropout sites of a decoder stack must share one rate, got {sorted(drop_rates)}")
     drop_p = drop_rates.pop() if (drop_rates and training) else 0.0  # eval mode: every nn.Dropout is the identity
@@ -565,12 +565,12 @@ def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, 
         x = xc.view(B * S, d)
         for li in range(len(layers)):
             all_hidden_states.append(x.view(B, S, d))
-            cfg = DecoderStackConfig(B, S, Sk, [layers[li]], mask, drop_p=drop_p, seed=seed, layer0=li)
+            cfg = DecoderStackConfig(B, S, Sk, [layers[li]], mask, drop_p=drop_p, seed=seed, layer0=li, cross_mask=cross_mask)
             x = DecoderStackFn.apply(x, enc2d, cfg, *params[bounds[li]:bounds[li + 1]])
         x = x.view(B, S, d)
         all_hidden_states.append(x)
     else:
-        cfg = DecoderStackConfig(B, S, Sk, layers, mask, drop_p=drop_p, seed=seed)
+        cfg = DecoderStackConfig(B, S, Sk, layers, mask, drop_p=drop_p, seed=seed, cross_mask=cross_mask)
         x = DecoderStackFn.apply(xc.view(B * S, d), enc2d, cfg, *params).view(B, S, d)
     if final_layer_norm is not None:
         x = final_layer_norm(x)

@@ -283,7 +283,7 @@ def gemm_bf16_splitk(a: torch.Tensor, w: torch.Tensor, target_blocks: int = 256)
     return out
 
 
-def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 256, want_colsum: bool = False):
+def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 256, want_colsum: bool = False, splits: Optional[int] = None):
     """fp32 [M,N] = y[T,M]^T @ x[T,N] (dW = dY^T X) from the row-major bf16 operands, T = tokens (T % 128 == 0).  want_colsum=True: returns
     (dW, db) with db fp32 [M] = the column sums of y (the bias gradient) from the SAME pass over y (mmamd_gemm_bf16_tn_splitk_colsum)."""
     _chk(y, "y", torch.bfloat16); _chk(x, "x", torch.bfloat16)
@@ -292,7 +292,8 @@ def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 2
     if T != T2:
         raise MmamdError(f"gemm_tn_splitk: token counts differ ({T} vs {T2})")
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    splits = max(1, min(T // 128, target_blocks // tiles))
+    if splits is None:
+        splits = max(1, min(T // 128, target_blocks // tiles))
     out = torch.empty((M, N), dtype=torch.float32, device=y.device)
     if want_colsum:
         db = torch.empty(M, dtype=torch.float32, device=y.device)
@@ -304,6 +305,57 @@ def gemm_bf16_tn_splitk(y: torch.Tensor, x: torch.Tensor, target_blocks: int = 2
     check(_lib.lib().mmamd_gemm_bf16_tn_splitk(y.data_ptr(), M, x.data_ptr(), N, out.data_ptr(), ws.data_ptr(), M, N, T, splits, _stream()),
           "mmamd_gemm_bf16_tn_splitk")
     return out
+
+
+class _WgradJob(C.Structure):  # mmamd_wgrad_job (include/mmamd.h)
+    _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("dw", C.c_void_p), ("db", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int)]
+
+
+def wgrad_group_splits(tiles: int, kt: int, target_blocks: int = 256) -> int:
+    """Splits per problem for a grouped weight-gradient launch of `tiles` 256 x 256 output tiles in all: the launch's tiles * splits workgroups should fill
+    `target_blocks` CUs a whole number of times (the workgroups of a launch are dispatched as CUs free up), with at least 32 K-tiles (of 64 tokens) left
+    per workgroup and no more splits than that takes (every split writes and re-reads a partial result)."""
+    best, best_score = 1, -1.0
+    for s in range(1, max(1, kt // 32) + 1):
+        wg = tiles * s
+        score = wg / (target_blocks * ((wg + target_blocks - 1) // target_blocks)) - 0.01 * s
+        if score > best_score:
+            best, best_score = s, score
+    return best
+
+
+def gemm_bf16_tn_splitk_group(jobs, target_blocks: int = 256, splits: Optional[int] = None):
+    """The weight (and bias) gradients of up to 8 Linears in ONE launch + one reduce launch (mmamd_gemm_bf16_tn_splitk_group): jobs = [(y bf16 [T, M],
+    x bf16 [T, N], want_colsum)], T % 128 == 0 -> [(dW fp32 [M, N], db fp32 [M] or None)].  Each result is what gemm_bf16_tn_splitk(y, x) returns at the
+    same number of splits."""
+    if not 1 <= len(jobs) <= 8:
+        raise MmamdError("gemm_bf16_tn_splitk_group: 1 to 8 jobs per launch")
+    arr = (_WgradJob * len(jobs))()
+    outs, tiles, kt = [], 0, None
+    dev = jobs[0][0].device
+    for i, (y, x, want_cs) in enumerate(jobs):
+        _chk(y, "y", torch.bfloat16); _chk(x, "x", torch.bfloat16)
+        T, M = y.shape
+        T2, N = x.shape
+        if T != T2 or y.stride(1) != 1 or x.stride(1) != 1:
+            raise MmamdError(f"gemm_bf16_tn_splitk_group: job {i}: token counts differ ({T} vs {T2}) or columns are not contiguous")
+        dw = torch.empty((M, N), dtype=torch.float32, device=dev)
+        db = torch.empty(M, dtype=torch.float32, device=dev) if want_cs else None
+        arr[i].dy, arr[i].lddy, arr[i].x, arr[i].ldx = y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0)
+        arr[i].dw, arr[i].db, arr[i].M, arr[i].N, arr[i].K = dw.data_ptr(), _ptr(db), M, N, T
+        outs.append((dw, db))
+        tiles += ((M + 255) // 256) * ((N + 255) // 256)
+        kt = T // 64 if kt is None else min(kt, T // 64)
+    if splits is None:
+        splits = wgrad_group_splits(tiles, kt, target_blocks)
+    L = _lib.lib()
+    n = L.mmamd_gemm_bf16_tn_splitk_group_ws(C.cast(arr, C.c_void_p), len(jobs), splits)
+    if n < 0:
+        raise MmamdError("gemm_bf16_tn_splitk_group: token counts must be multiples of 128")
+    ws = torch.empty(n, dtype=torch.float32, device=dev)
+    check(L.mmamd_gemm_bf16_tn_splitk_group(C.cast(arr, C.c_void_p), len(jobs), splits, ws.data_ptr(), _stream()), "mmamd_gemm_bf16_tn_splitk_group")
+    return outs
 
 
 def attention_fwd(qkv: torch.Tensor, B: int, S: int, H: int, causal: bool,

@@ -672,3 +672,38 @@ def test_fused_attention_backward_equals_the_two_kernel_form(B, S, H, causal, ma
     again = ops.attention_bwd(qkv, out, dout, lse, B, S, H, causal, km).float()
     assert torch.equal(again, got)  # fixed summation order everywhere (mailbox schedule, no atomics): run-to-run bit-identical
     assert torch.isfinite(got.float()).all()
+
+
+def test_grouped_weight_gradients_equal_the_single_launches_bit_for_bit():
+    """r05: the four weight gradients of a layer in ONE split-K launch + one reduce launch (mmamd_gemm_bf16_tn_splitk_group): every problem's dW and db equal
+    what mmamd_gemm_bf16_tn_splitk(_colsum) returns for it at the same number of splits, bit for bit (same kernel body, same partial order), on the shapes
+    of a ViT-B/16 layer, a text layer and ragged ones (M, N not multiples of 256; a problem without a bias gradient; a single split)."""
+    from multimodal_amd import ops
+
+    set_rng_seed(23)
+    cases = [
+        (6400, [(768, 3072, True), (3072, 768, True), (768, 768, False), (2304, 768, True)], None),
+        (2560, [(1536, 512, True), (512, 512, False), (2048, 512, True), (512, 2048, True)], None),
+        (1280, [(200, 328, True), (72, 264, False), (520, 8, True)], 3),
+        (256, [(256, 256, True), (264, 64, False)], 1),
+        (1024, [(64, 64, False)] * 8, 4),
+    ]
+    for T, probs, splits in cases:
+        jobs = [((torch.randn(T, M) * 0.1).to(torch.bfloat16).cuda(), torch.randn(T, N).to(torch.bfloat16).cuda(), cs) for M, N, cs in probs]
+        tiles = sum(((M + 255) // 256) * ((N + 255) // 256) for M, N, _ in probs)
+        s_used = splits if splits is not None else ops.wgrad_group_splits(tiles, T // 64)
+        before = ops.launch_count("gemm_bf16_tn_splitk_group")
+        outs = ops.gemm_bf16_tn_splitk_group(jobs, splits=splits)
+        assert ops.launch_count("gemm_bf16_tn_splitk_group") == before + 1
+        again = ops.gemm_bf16_tn_splitk_group(jobs, splits=splits)  # deterministic run to run
+        for (y, x, cs), (dw, db), (dw2, db2) in zip(jobs, outs, again):
+            assert torch.equal(dw, dw2) and (db is None or torch.equal(db, db2))
+            if cs:
+                ref_dw, ref_db = ops.gemm_bf16_tn_splitk(y, x, want_colsum=True, splits=s_used)
+                assert torch.equal(db, ref_db), (T, tuple(y.shape), tuple(x.shape))
+            else:
+                ref_dw = ops.gemm_bf16_tn_splitk(y, x, splits=s_used)
+                assert db is None
+            assert torch.equal(dw, ref_dw), (T, tuple(y.shape), tuple(x.shape), s_used)
+            want = y.double().T @ x.double()
+            assert (dw.double() - want).abs().max().item() <= 2e-5 * T ** 0.5 * max(1.0, float(want.abs().max()))

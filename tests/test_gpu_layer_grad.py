@@ -318,3 +318,29 @@ def test_post_norm_decoder_trains_like_the_reference(golden):
             if enc is not None:
                 ref = z["dec.denc"].astype(np.float64)
                 assert np.abs(host(enc.grad) - ref).max() <= 6e-2 * np.abs(ref).max()
+
+
+def test_stand_alone_decoder_layer_with_cross_attention_mask_trains_like_the_reference(golden):
+    """r05: a stand-alone TransformerDecoderLayer hands `cross_attention_mask` to its cross-attention block (reference modules/layers/transformer.py:366-376),
+    in training as well (DecoderStackConfig.cross_mask: the forward and backward cross-attention kernels take the same [S, Sk] mask).  Fixture:
+    tests/golden/make_golden_decoder_xmask_grad.py -> decoder_xmask_grad.npz, pre- and post-norm, a per-sample boolean [2, 1, 9, 5] mask."""
+    from multimodal_amd.modules.layers.transformer import TransformerDecoderLayer
+
+    z = golden("decoder_xmask_grad.npz")
+    causal = torch.ones(9, 9, dtype=torch.bool).tril().cuda()
+    xmask = torch.from_numpy(z["xmask"]).cuda()
+    for tag, nf in (("pre", True), ("post", False)):
+        layer = _load(TransformerDecoderLayer(d_model=128, n_head=2, dim_feedforward=256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=nf,
+                                              use_cross_attention=True, dim_kv=64), z, tag)
+        x = torch.from_numpy(z[f"{tag}.x"]).cuda().requires_grad_(True)
+        enc = torch.from_numpy(z[f"{tag}.enc"]).cuda().requires_grad_(True)
+        y, _ = layer(x, enc, attention_mask=causal, cross_attention_mask=xmask)
+        (y * torch.from_numpy(z[f"{tag}.w"]).cuda()).sum().backward()
+        _check(z, tag, layer, y, x)
+        ref = z[f"{tag}.denc"].astype(np.float64)
+        assert np.abs(host(enc.grad) - ref).max() <= 6e-2 * np.abs(ref).max()
+        # the differentiable forward equals the inference forward with the same mask
+        layer.eval()
+        with torch.no_grad():
+            y_inf, _ = layer(x.detach(), enc.detach(), attention_mask=causal, cross_attention_mask=xmask)
+        assert (y_inf - y.detach()).abs().max().item() <= 2e-2 * max(1.0, float(y.detach().abs().max()))
