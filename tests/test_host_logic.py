@@ -1,0 +1,49 @@
+"""Host-side arithmetic of the training path that needs no GPU: the split chooser of the grouped weight-gradient launch, the workspace size the C-ABI
+reports for it, and the workgroup count of the LayerNorm backward (the sizes the Python layer and a C caller must agree on)."""
+import ctypes as C
+
+import pytest
+
+
+def test_wgrad_group_split_chooser_fills_whole_rounds():
+    from multimodal_amd import ops
+
+    # a ViT-B/16 layer at B = 256: 27 + 9 + 36 + 36 tiles over 788 K-tiles -> 7 splits = 756 workgroups = 2.95 rounds of 256
+    assert ops.wgrad_group_splits(108, 50432 // 64) == 7
+    # the text layer (12 + 4 + 16 + 16 tiles, 308 K-tiles): 5 splits = 240 workgroups, one round
+    assert ops.wgrad_group_splits(48, 19712 // 64) == 5
+    # ViT-L/14 (192 tiles): 4 splits = exactly three rounds
+    assert ops.wgrad_group_splits(192, 32896 // 64) == 4
+    # never fewer than 32 K-tiles per workgroup, never less than one split
+    assert ops.wgrad_group_splits(4, 64) <= 2 and ops.wgrad_group_splits(1000, 2) == 1
+    for tiles in (1, 7, 100, 255, 256, 257, 1000):
+        for kt in (2, 40, 400, 4000):
+            s = ops.wgrad_group_splits(tiles, kt)
+            assert 1 <= s <= max(1, kt // 32)
+
+
+def test_grouped_wgrad_workspace_size_and_argument_checks():
+    from multimodal_amd import _lib, ops
+
+    L = _lib.lib()
+    jobs = (ops._WgradJob * 3)()
+    for j, (M, N, K, db) in zip(jobs, ((768, 3072, 50432, 1), (768, 768, 50432, 0), (512, 2048, 256, 1))):
+        j.M, j.N, j.K, j.db = M, N, K, db  # (db: any non-NULL value means "wanted" for the size query)
+    # K = 50432 at 7 splits: 788 K-tiles -> chunks of 114 (even) -> 7 parts; K = 256 at 7 splits: 4 K-tiles -> chunks of 2 -> 2 parts
+    want = 4 + 7 * 768 * 3072 + 7 * 768 + 7 * 768 * 768 + 2 * 512 * 2048 + 2 * 512
+    assert L.mmamd_gemm_bf16_tn_splitk_group_ws(C.cast(jobs, C.c_void_p), 3, 7) == want
+    # one split: every problem writes its own result, no partials
+    assert L.mmamd_gemm_bf16_tn_splitk_group_ws(C.cast(jobs, C.c_void_p), 3, 1) == 4
+    jobs[2].K = 200  # not a multiple of 128
+    assert L.mmamd_gemm_bf16_tn_splitk_group_ws(C.cast(jobs, C.c_void_p), 3, 7) == -1
+    assert L.mmamd_gemm_bf16_tn_splitk_group_ws(None, 0, 7) == -1
+    # argument errors of the launch itself are reported before anything touches a device
+    assert L.mmamd_gemm_bf16_tn_splitk_group(None, 0, 1, None, None) != 0
+    assert L.mmamd_gemm_bf16_tn_splitk_group(C.cast(jobs, C.c_void_p), 9, 1, None, None) != 0
+
+
+@pytest.mark.parametrize("rows,d,want", [(50432, 768, 1024), (50432, 1024, 768), (19712, 512, 768), (1000, 768, 250), (3, 2048, 1), (4096, 640, 1024), (5000, 512, 768)])
+def test_layernorm_backward_workgroup_count(rows, d, want):
+    from multimodal_amd import _lib
+
+    assert _lib.lib().mmamd_layernorm_bwd_groups(rows, d) == want
