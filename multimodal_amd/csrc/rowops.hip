@@ -737,19 +737,27 @@ __global__ __launch_bounds__(256) void rows_linear_f32_kernel(const float* __res
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < d; k0 += 8) {
-    const int k = k0 + 4 * half;
-    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
-    if (vec && k + 3 < d) {
-      xv = load4(lp + k);
-      yv = load4(rp + k);
-    } else {
+  // four k-steps (32 columns) per trip, all eight loads issued before the first MFMA: the loop was one dependent load -> MFMA chain per 8 columns
+  // (41 us for a 256 x 768 x 768 pooler: latency, not arithmetic; r05).  Same products in the same order: bit-identical results.
+  for (int k0 = 0; k0 < d; k0 += 32) {
+    f32x4 xv[4], yv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (k + u < d) { xv[u] = lp[k + u]; yv[u] = rp[k + u]; }
+    for (int s = 0; s < 4; ++s) {
+      const int k = k0 + 8 * s + 4 * half;
+      xv[s] = f32x4{0.f, 0.f, 0.f, 0.f}; yv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (vec && k + 3 < d) {
+        xv[s] = load4(lp + k);
+        yv[s] = load4(rp + k);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k + u < d) { xv[s][u] = lp[k + u]; yv[s][u] = rp[k + u]; }
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[u], yv[u], acc, 0, 0, 0);
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s][u], yv[s][u], acc, 0, 0, 0);
   }
   const int j = j0 + (lane & 31);
   if (j < E) {

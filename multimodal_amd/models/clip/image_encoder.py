@@ -186,11 +186,21 @@ class CLIPViTEncoder(PackedModeMixin, nn.Module):
     @torch.jit.unused
     def _forward_train(self, x: Tensor) -> Tensor:
         """Differentiable forward (train mode, grad enabled): the autograd nodes of models/clip/_train.py."""
+        x0, B, S = self._train_stem(x)
+        return self._train_head(_train.run_stack(self.encoder, x0, B, S, False), B, S)
+
+    @torch.jit.unused
+    def _train_stem(self, x: Tensor):
+        """Differentiable patch embedding + CLS + positions + ln_pre -> (fp32 residual stream [B*S, w], B, S)."""
         B = x.size(0)
         g = self.image_size // self.patch_size
         S = g * g + 1
         x0 = _train.VisionEmbedFn.apply(x, self.conv.weight, self.cls_token_embedding, self.positional_embedding, self.ln_pre.weight,
                                         self.ln_pre.bias, self.patch_size, self.ln_pre.eps)
-        h = _train.run_stack(self.encoder, x0, B, S, False)
-        cls_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=x.device)
+        return x0, B, S
+
+    @torch.jit.unused
+    def _train_head(self, h: Tensor, B: int, S: int) -> Tensor:
+        """Differentiable ln_post over the CLS rows + projection."""
+        cls_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=h.device)
         return _train.PooledHeadFn.apply(h, cls_rows, self.ln_post.weight, self.ln_post.bias, self.projection, self.ln_post.eps, False)

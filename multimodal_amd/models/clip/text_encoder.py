@@ -104,18 +104,27 @@ class CLIPTextEncoder(PackedModeMixin, nn.Module):
         B, S = text.shape
         ids = text if (text.dtype == torch.int64 and text.is_contiguous()) else text.to(torch.int64).contiguous()
         if _train.wants_grad(self):
-            x0 = _train.TextEmbedFn.apply(ids, self.token_embedding.weight, self.positional_embedding)
-            h = _train.run_stack(self.encoder, x0, B, S, True)
-            if return_hidden_state:  # reference :125-127: ln_final over every token, [B, 77, width], attached to the graph (r05)
-                from ..._autograd import LayerNormFn
-
-                return LayerNormFn.apply(h, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps).view(B, S, self.width)
-            eot_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=ids.device) + ids.argmax(dim=-1)  # index bookkeeping
-            return _train.PooledHeadFn.apply(h, eot_rows, self.ln_final.weight, self.ln_final.bias, self.projection.weight,
-                                             self.ln_final.eps, True)
+            h = _train.run_stack(self.encoder, self._train_stem(ids), B, S, True)
+            return self._train_head(h, B, S, ids, return_hidden_state)
         h = self._stem(ids)
         h = self.encoder.run(h, B, S, causal=True)
         return self._head(h, B, S, ids, return_hidden_state)
+
+    @torch.jit.unused
+    def _train_stem(self, ids: Tensor) -> Tensor:
+        """Differentiable token + positional embedding -> fp32 residual stream [B*S, w] (ids: contiguous int64 [B, S])."""
+        return _train.TextEmbedFn.apply(ids, self.token_embedding.weight, self.positional_embedding)
+
+    @torch.jit.unused
+    def _train_head(self, h: Tensor, B: int, S: int, ids: Tensor, return_hidden_state: bool = False) -> Tensor:
+        """Differentiable ln_final (+ projection of the end-of-text rows)."""
+        if return_hidden_state:  # reference :125-127: ln_final over every token, [B, 77, width], attached to the graph (r05)
+            from ..._autograd import LayerNormFn
+
+            return LayerNormFn.apply(h, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps).view(B, S, self.width)
+        eot_rows = torch.arange(0, B * S, S, dtype=torch.int64, device=ids.device) + ids.argmax(dim=-1)  # index bookkeeping
+        return _train.PooledHeadFn.apply(h, eot_rows, self.ln_final.weight, self.ln_final.bias, self.projection.weight,
+                                         self.ln_final.eps, True)
 
     @torch.jit.unused
     def _stem(self, ids: Tensor) -> Tensor:

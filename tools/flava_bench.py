@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--grouped", action="store_true", help="schedule.flava_grouped: image and text towers layer-locked with grouped launches")
     ap.add_argument("--no-attentions", action="store_true", help="schedule.flava_attentions = False: the forwards do not produce the attention probabilities (opt-out)")
     ap.add_argument("--probs-two-pass", action="store_true", help="A/B: unmasked attention probabilities from the two-pass kernel (debug variant 514) instead of flash + one pass")
+    ap.add_argument("--copy-trace", action="store_true", help="after the timing: one more step under the torch profiler -> which host call sites issue copies / fills / cats / casts")
     ap.add_argument("--codebook", action="store_true", help="MIM labels from the DALL-E codebook (112x112 images) inside the step instead of synthetic ones")
     a = ap.parse_args()
     from multimodal_amd.models.flava.model import flava_model
@@ -118,6 +119,22 @@ def main():
         from tools.codebook_bench import encoder_gflop
 
         gf += encoder_gflop(vae)  # forward only: the codebook supplies labels
+    if a.copy_trace:
+        from collections import Counter
+
+        from torch.profiler import ProfilerActivity, profile
+
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        c = Counter()
+        for ev in prof.events():
+            if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::zeros", "aten::zero_", "aten::fill_", "aten::cat", "aten::to", "aten::_to_copy",
+                           "aten::index", "aten::index_select", "aten::masked_fill_", "aten::where", "aten::add", "aten::mul", "aten::sum", "aten::mean", "aten::stack"):
+                frames = [f for f in (ev.stack or []) if "multimodal_amd" in f or "tools/" in f]
+                c[(ev.name, str(ev.input_shapes)[:70], (frames[0] if frames else "?")[-100:])] += 1
+        for (name, shp, fr), n in c.most_common(60):
+            print(f"{n:4d} {name:18s} {shp:70s} {fr}", file=sys.stderr)
     # the arm ran the probability kernels it is named after (launch counters of the library: no profiler needed)
     from multimodal_amd import ops as _ops
 
