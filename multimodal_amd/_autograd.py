@@ -490,151 +490,6 @@ class EncoderStackFn(torch.autograd.Function):
         return (outs[0], None, *grads)
 
 
-_PAIR_NODE = True  # tools/train_bench.py --no-pair-node: the two towers as two autograd nodes (the second on a side stream), the form before r05's pair node
-
-
-def pair_stack_ok(cfg_a: StackConfig, cfg_b: StackConfig) -> bool:
-    """The two stacks can run as ONE PairStackFn node: plain pre-norm stacks of equal depth -- no dropout, masks (causal excepted), head masks or
-    hidden states handed out -- in eager mode (the node is not a dispatcher op)."""
-    if not _PAIR_NODE or torch.compiler.is_compiling():
-        return False
-    for c in (cfg_a, cfg_b):
-        if not c.norm_first or c.drop or c.key_mask is not None or c.full_mask is not None or c.head_mask is not None or c.keep_hidden:
-            return False
-    return cfg_a.n_layers == cfg_b.n_layers and cfg_a.n_layers > 0
-
-
-def _pair_fwd_impl(xs: List[Tensor], ps: List[List[Tensor]], cfgs: List[StackConfig]) -> List[List[Tensor]]:
-    """_stack_fwd_impl of two towers, layer-locked on one stream: the qkv, out-projection (+ residual) and MLP-down (+ residual) GEMMs of a layer are ONE
-    grouped persistent launch over both towers' tiles (mmamd_gemm_bf16_grouped: bit-identical to the separate launches) -- the second tower's tiles
-    fill the partial last round of the first's, as in the inference schedule (models/clip/_transformer.run_two_stacks).  LayerNorm, attention and the
-    dual-output MLP-up GEMM stay one launch per tower.  Returns, per tower, what _stack_fwd_impl returns."""
-    n_layers = cfgs[0].n_layers
-    wb, wt = [], []
-    for t in (0, 1):
-        b, tr = ops.pack_weights([ps[t][12 * li + k] for li in range(n_layers) for k in (0, 2, 4, 6)])
-        wb.append(b); wt.append(tr)
-    x = list(xs)
-    saved: List[List[Tensor]] = [[], []]
-    inputs: List[List[Tensor]] = [[], []]
-    for li in range(n_layers):
-        P = [ps[t][12 * li:12 * li + 12] for t in (0, 1)]  # Wqkv, bqkv, Wo, bo, W1, b1, W2, b2, g1, be1, g2, be2
-        W = [wb[t][4 * li:4 * li + 4] for t in (0, 1)]
-        if li > 0:
-            for t in (0, 1):
-                inputs[t].append(x[t])
-        h1 = [ops.layernorm(x[t], P[t][8], P[t][9], cfgs[t].eps1[li], out_dtype=bf) for t in (0, 1)]
-        qkv = ops.gemm_bf16_grouped([(h1[t], W[t][0], P[t][1], None, None) for t in (0, 1)], out_dtype=bf)
-        al = [_attn_fwd_any(qkv[t], cfgs[t].B, cfgs[t].S, cfgs[t].n_head, cfgs[t].causal, None, None, 0.0, 0, 0) for t in (0, 1)]
-        x_mid = ops.gemm_bf16_grouped([(al[t][0], W[t][1], P[t][3], x[t], torch.empty_like(x[t])) for t in (0, 1)], out_dtype=f32)
-        h2 = [ops.layernorm(x_mid[t], P[t][10], P[t][11], cfgs[t].eps2[li], out_dtype=bf) for t in (0, 1)]
-        ug = [ops.gemm_bf16_dual(h2[t], W[t][2], P[t][5], cfgs[t].act) for t in (0, 1)]
-        x_out = ops.gemm_bf16_grouped([(ug[t][1], W[t][3], P[t][7], x_mid[t], torch.empty_like(x[t])) for t in (0, 1)], out_dtype=f32)
-        for t in (0, 1):
-            saved[t] += [h1[t], qkv[t], al[t][0], al[t][1], x_mid[t], h2[t], ug[t][0], ug[t][1]]
-        x = x_out
-    return [[x[t]] + saved[t] + inputs[t] + list(wt[t]) for t in (0, 1)]
-
-
-def _pair_bwd_impl(dxs: List[Tensor], x0s: List[Tensor], saveds: List[List[Tensor]], ps: List[List[Tensor]], cfgs: List[StackConfig]) -> List[List[Tensor]]:
-    """_stack_bwd_impl (pre-norm, no dropout) of two towers, layer-locked: of a layer's four dgrad GEMMs the three without an activation epilogue
-    (dh2 = du W1, datt = dx_mid Wo, dh1 = dqkv Wqkv) are ONE grouped persistent launch over both towers; each tower's four weight gradients are one
-    grouped split-K launch (wgrad_many); the activation-gradient dgrad, attention backward and LayerNorm backward stay one launch per tower.
-    Per tower the same kernels on the same operands as _stack_bwd_impl.  Returns, per tower, [dX0] + the 12 canonical gradients per layer."""
-    n_layers = cfgs[0].n_layers
-    inputs = [[x0s[t]] + list(saveds[t][8 * n_layers:9 * n_layers - 1]) for t in (0, 1)]
-    wts = [saveds[t][9 * n_layers - 1:] for t in (0, 1)]
-    dX = list(dxs)
-    grads: List[List[Tensor]] = [[dX[t]] * (12 * n_layers) for t in (0, 1)]
-    pending = _pending()
-    dXb: List[Optional[Tensor]] = [None, None]
-    dXsum: List[Optional[Tensor]] = [None, None]
-    dh_dt = bf if _BF16_DH else f32
-    R = (0, 1)
-    for li in reversed(range(n_layers)):
-        h1, qkv, att, lse, x_mid, h2, u, g = ([saveds[t][8 * li + k] for t in R] for k in range(8))
-        x = [inputs[t][li] for t in R]
-        P = [ps[t][12 * li:12 * li + 12] for t in R]
-        WT = [wts[t][4 * li:4 * li + 4] for t in R]  # transposes of Wqkv, Wo, W1, W2
-        for t in R:
-            if dXb[t] is None:
-                dXb[t] = ops.convert(dX[t], bf)
-        du = [dgrad_t(dXb[t], WT[t][3], bf, _ACT_GRAD[cfgs[t].act], u[t]) for t in R]
-        wj = [[(dXb[t], g[t], dXsum[t] is None)] for t in R]
-        dh2 = ops.gemm_bf16_grouped([(du[t], WT[t][2], None, None, None) for t in R], out_dtype=dh_dt)
-        lnb = [ops.layernorm_bwd(x_mid[t], P[t][10], dh2[t], cfgs[t].eps2[li], add=dX[t], want_bf16=True, want_colsum=True, defer=pending) for t in R]
-        dx_mid, dxmb, dbo = [r[0] for r in lnb], [r[3] for r in lnb], [r[4] for r in lnb]
-        datt = ops.gemm_bf16_grouped([(dxmb[t], WT[t][1], None, None, None) for t in R], out_dtype=bf)
-        dqkv = [_attn_bwd_any(qkv[t], att[t], datt[t], lse[t], cfgs[t].B, cfgs[t].S, cfgs[t].n_head, cfgs[t].causal, None, None, 0.0, 0, 0) for t in R]
-        dh1 = ops.gemm_bf16_grouped([(dqkv[t], WT[t][0], None, None, None) for t in R], out_dtype=dh_dt)
-        for t in R:
-            wj[t] += [(du[t], h2[t], True), (dxmb[t], att[t], False), (dqkv[t], h1[t], True)]
-            (dW2, db2), (dW1, db1), (dWo, _), (dWqkv, dbqkv) = wgrad_many(wj[t])
-            if dXsum[t] is not None:
-                db2 = dXsum[t]
-            dXn, dg1, dbe1, dXb[t], dXsum[t] = ops.layernorm_bwd(x[t], P[t][8], dh1[t], cfgs[t].eps1[li], add=dx_mid[t], want_bf16=True, want_colsum=True,
-                                                                defer=pending)
-            dX[t] = dXn
-            grads[t][12 * li:12 * li + 12] = [dWqkv, dbqkv, dWo, dbo[t], dW1, db1, dW2, db2, dg1, dbe1, lnb[t][1], lnb[t][2]]
-    ops.colsum_flush(pending)
-    return [[dX[t]] + grads[t] for t in R]
-
-
-def _pair_canon(cfgs, params, na: int) -> List[List[Tensor]]:
-    """The two towers' parameters in canonical order (12 per layer), as EncoderStackFn hands them to the stack ops."""
-    out: List[List[Tensor]] = []
-    for cfg, prm in zip(cfgs, (params[:na], params[na:])):
-        canon: List[Tensor] = []
-        for li in range(cfg.n_layers):
-            canon += list(cfg.to_canonical([c32(p) for p in prm[cfg.ppl * li:cfg.ppl * (li + 1)]]))
-        out.append(canon)
-    return out
-
-
-class PairStackFn(torch.autograd.Function):
-    """The pre-norm layer stacks of the TWO towers of a dual encoder as ONE autograd node (r05): (xa0, xb0) -> (xa_L, xb_L), layer-locked, with the
-    projections of both towers in grouped launches, forward and backward (_pair_fwd_impl / _pair_bwd_impl).  As two nodes the second tower ran on a
-    side stream and cost 8.0 of the 10.0 ms it takes alone (CLIP ViT-B/16, B = 256: 39.1 ms image tower alone, 47.1 ms both); the towers are
-    independent until the loss (reference models/clip/model.py:63-75), so the order of their kernels is free.  Same values per tower as
-    EncoderStackFn (the grouped GEMMs are bit-identical to separate launches)."""
-
-    @staticmethod
-    def forward(ctx, xa0: Tensor, xb0: Tensor, cfg_a: StackConfig, cfg_b: StackConfig, *params: Tensor):
-        cfgs = [cfg_a, cfg_b]
-        na = cfg_a.ppl * cfg_a.n_layers
-        xs = []
-        for x0 in (xa0, xb0):
-            x = x0.detach()
-            xs.append(x if x.is_contiguous() else x.contiguous())
-        ps = _pair_canon(cfgs, params, na)
-        outs = _pair_fwd_impl(xs, ps, cfgs)
-        ctx.save_for_backward(xs[0], *outs[0][1:], xs[1], *outs[1][1:], *params)
-        ctx.cfgs, ctx.nsaved, ctx.na, ctx.nparam = cfgs, (len(outs[0]) - 1, len(outs[1]) - 1), na, len(params)
-        ctx.set_materialize_grads(False)
-        return outs[0][0], outs[1][0]
-
-    @staticmethod
-    def backward(ctx, dxa, dxb):
-        cfgs, (sa, sb), na, nparam = ctx.cfgs, ctx.nsaved, ctx.na, ctx.nparam
-        tensors = ctx.saved_tensors
-        x0s = [tensors[0], tensors[1 + sa]]
-        saveds = [list(tensors[1:1 + sa]), list(tensors[2 + sa:2 + sa + sb])]
-        params = tensors[2 + sa + sb:]
-        assert len(params) == nparam
-        dxs = []
-        for d, x0 in zip((dxa, dxb), x0s):
-            if d is None:  # this tower's output was not used by anything differentiated
-                d = torch.zeros_like(x0)
-            d = d.detach()
-            dxs.append(d if d.is_contiguous() else d.contiguous())
-        outs = _pair_bwd_impl(dxs, x0s, saveds, _pair_canon(cfgs, params, na), cfgs)
-        grads: List[Optional[Tensor]] = []
-        for t in (0, 1):
-            for li in range(cfgs[t].n_layers):
-                grads += list(cfgs[t].from_canonical(list(outs[t][1 + 12 * li:13 + 12 * li])))
-        return (outs[0][0], outs[1][0], None, None, *grads)
-
-
 class LayerNormFn(torch.autograd.Function):
     """y = LayerNorm(x) over the last dimension of a contiguous fp32 tensor (affine)."""
 

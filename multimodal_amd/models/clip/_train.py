@@ -49,34 +49,6 @@ def _stack_cfg(stack, B: int, S: int, causal: bool):
                        [l.norm2.eps for l in stack.layers], 12, ident, ident), params
 
 
-def pair_stacks_ok(stack_a, Ba: int, Sa: int, stack_b, Bb: int, Sb: int) -> bool:
-    """Both TransformerStacks can go through ONE PairStackFn node (same depth, widths / MLP widths on the GEMMs' 64-column grid)."""
-    from ..._autograd import pair_stack_ok
-
-    if len(stack_a.layers) != len(stack_b.layers) or len(stack_a.layers) == 0:
-        return False
-    from ..._autograd import plain_layers
-
-    for st in (stack_a, stack_b):
-        l0 = st.layers[0]
-        if not plain_layers(st.layers, type(l0)) or not hasattr(l0, "linear1"):
-            return False  # wrapped / hooked layers are called one by one
-        if l0.linear1.weight.shape[1] % 64 != 0 or l0.linear1.weight.shape[0] % 64 != 0:
-            return False
-    ca, _ = _stack_cfg(stack_a, Ba, Sa, False)
-    cb, _ = _stack_cfg(stack_b, Bb, Sb, True)
-    return pair_stack_ok(ca, cb)
-
-
-def run_pair_stacks(stack_a, xa0: Tensor, Ba: int, Sa: int, causal_a: bool, stack_b, xb0: Tensor, Bb: int, Sb: int, causal_b: bool) -> Tuple[Tensor, Tensor]:
-    """Both towers' layer stacks as one autograd node with grouped launches (PairStackFn)."""
-    from ..._autograd import PairStackFn
-
-    ca, pa = _stack_cfg(stack_a, Ba, Sa, causal_a)
-    cb, pb = _stack_cfg(stack_b, Bb, Sb, causal_b)
-    return PairStackFn.apply(xa0, xb0, ca, cb, *pa, *pb)
-
-
 def _vision_embed_fwd(images: Tensor, conv_w: Tensor, cls: Tensor, pos: Tensor, ln_w: Tensor, ln_b: Tensor, patch: int, eps: float) -> List[Tensor]:
     """-> [x0 fp32 [B*(G2+1), w], cols (bf16 im2col rows), asm (the residual stream before ln_pre)]"""
     B = images.shape[0]

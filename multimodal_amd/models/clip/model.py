@@ -151,17 +151,6 @@ class CLIP(PackedModeMixin, nn.Module):
             # differentiable path (train mode, grad enabled): autograd nodes with HIP forward and backward
             # (not under a process group: DistributedDataParallel stashes its AccumulateGrad hooks on the stream it was constructed on, so a tower
             #  whose backward runs on a side stream pays extra syncs there and cannot be captured in a HIP graph -- ADVICE r03)
-            if self._pair_trainable(tower_a, features_a, features_b):
-                # both towers' layer stacks as ONE autograd node, layer-locked, the projections of both towers in grouped launches (forward and
-                # backward): the text tower then costs what its tiles add to the ViT's launches instead of 8 of the 10 ms it takes alone (r05)
-                va, tb = self.encoder_a, self.encoder_b
-                ids = features_b if (features_b.dtype == torch.int64 and features_b.is_contiguous()) else features_b.to(torch.int64).contiguous()
-                xa0, Ba, Sa = va._train_stem(features_a)
-                xb0 = tb._train_stem(ids)
-                Bb, Sb = ids.shape
-                ha, hb = _train.run_pair_stacks(va.encoder, xa0, Ba, Sa, False, tb.encoder, xb0, Bb, Sb, True)
-                return CLIPOutput(embeddings_a=_train.L2NormalizeFn.apply(va._train_head(ha, Ba, Sa)),
-                                  embeddings_b=_train.L2NormalizeFn.apply(tb._train_head(hb, Bb, Sb, ids)))
             side = self._side_stream(features_a) if train_side_stream_now() else None
             if side is None:
                 embeddings_a = _train.L2NormalizeFn.apply(tower_a(features_a))
@@ -258,27 +247,6 @@ class CLIP(PackedModeMixin, nn.Module):
             return True
         # only when every projection pair of a layer becomes ONE persistent launch (else: the two-stream schedule overlaps better)
         return two_stacks_groupable(va.encoder, Ba * (g * g + 1), tb.encoder, features_b.size(0) * features_b.size(1))
-
-    @torch.jit.unused
-    def _pair_trainable(self, tower_a, features_a, features_b) -> bool:
-        """Training forward of the CLIP pair of this package through ONE pair node (_autograd.PairStackFn): both encoders are called as themselves
-        (no hooks, no wrappers, the image given as pixels), both train (a frozen tower takes its inference path), and their stacks are plain pre-norm
-        stacks of equal depth.  Anything else keeps one node per tower."""
-        va, tb = self.encoder_a, self.encoder_b
-        if type(va) is not CLIPViTEncoder or type(tb) is not CLIPTextEncoder or tower_a is not va:
-            return False
-        if not (isinstance(features_a, torch.Tensor) and isinstance(features_b, torch.Tensor) and features_a.is_cuda and features_b.is_cuda):
-            return False
-        if va._forward_hooks or va._forward_pre_hooks or tb._forward_hooks or tb._forward_pre_hooks or va.encoder._forward_hooks or tb.encoder._forward_hooks:
-            return False
-        if features_a.requires_grad or features_b.dim() != 2 or features_b.size(1) != tb.context_length:
-            return False  # (the encoders' own forwards raise the reference's errors)
-        if not (features_a.dim() == 4 and features_a.size(1) == 3 and features_a.size(2) == va.image_size and features_a.size(3) == va.image_size):
-            return False
-        if not (_train.wants_grad(va) and _train.wants_grad(tb)):
-            return False
-        g = va.image_size // va.patch_size
-        return _train.pair_stacks_ok(va.encoder, features_a.size(0), g * g + 1, tb.encoder, features_b.size(0), features_b.size(1))
 
     @torch.jit.unused
     def _side_stream(self, ref):

@@ -107,10 +107,7 @@ def test_training_step_with_the_text_tower_on_a_side_stream_equals_one_stream():
     ids = torch.randint(1, 500, (8, 16), generator=g)
     ids[:, -1] = 511
     ids = ids.cuda()
-    from multimodal_amd import _autograd
-
     prev = set_schedule(train_side_stream=False)
-    pair_prev, _autograd._PAIR_NODE = _autograd._PAIR_NODE, False  # (the pair node keeps both towers on one stream: this test is about the two-node form)
     try:
         for it in range(3):
             results = []
@@ -131,55 +128,5 @@ def test_training_step_with_the_text_tower_on_a_side_stream_equals_one_stream():
                 else:
                     assert torch.equal(a, b), (it, n)
     finally:
-        _autograd._PAIR_NODE = pair_prev
         set_schedule(train_side_stream=prev.train_side_stream)
 
-
-def test_pair_node_equals_one_node_per_tower_bit_for_bit():
-    """r05: both towers' layer stacks as ONE autograd node with grouped launches over both towers (_autograd.PairStackFn: the qkv / out-projection /
-    MLP-down GEMMs forward, three of the four dgrad GEMMs backward) against one EncoderStackFn node per tower: per tower the same kernels on the same
-    operands, and a grouped launch computes every tile exactly as its own launch would -- loss and every parameter gradient are bit-identical.  At the
-    widths of ViT-B/16 + its text tower with B = 256 (token counts that are multiples of 128 and enough tiles per projection: the grouped split-K weight
-    gradients and the grouped persistent launches are what runs), two layers per tower; and at a small size where every grouped call falls back to separate launches."""
-    from multimodal_amd import _autograd, ops
-    from multimodal_amd.models.clip import CLIPTextEncoder, CLIPViTEncoder
-    from multimodal_amd.models.clip.model import CLIP
-    from multimodal_amd.modules.losses.contrastive_loss_with_temperature import ContrastiveLossWithTemperature
-
-    for B, vit_kw, txt_kw in ((256, dict(embedding_dim=512, heads=12, layers=2, patch_size=16, image_size=224, width=768), dict(embedding_dim=512, layers=2)),
-                              (8, dict(embedding_dim=128, heads=2, layers=2, patch_size=16, image_size=64, width=128),
-                               dict(embedding_dim=128, context_length=16, vocab_size=512, width=128, heads=2, layers=2))):
-        torch.manual_seed(5)
-        model = CLIP(CLIPViTEncoder(**vit_kw), CLIPTextEncoder(**txt_kw)).cuda().train()
-        loss_fn = ContrastiveLossWithTemperature().cuda()
-        g = torch.Generator().manual_seed(6)
-        S = model.encoder_b.context_length
-        images = torch.randn(B, 3, vit_kw["image_size"], vit_kw["image_size"], generator=g).cuda()
-        ids = torch.randint(1, 500, (B, S), generator=g)
-        ids[:, -1] = model.encoder_b.token_embedding.weight.shape[0] - 1
-        ids = ids.cuda()
-        results = []
-        prev = _autograd._PAIR_NODE
-        try:
-            for pair in (False, True):
-                _autograd._PAIR_NODE = pair
-                for p in list(model.parameters()) + list(loss_fn.parameters()):
-                    p.grad = None
-                before = ops.launch_count("gemm_bf16_grouped")
-                out = model(images, ids)
-                loss = loss_fn(out.embeddings_a, out.embeddings_b)
-                loss.backward()
-                torch.cuda.synchronize()
-                grouped = ops.launch_count("gemm_bf16_grouped") - before
-                # the arm ran what it is named after: grouped two-tower launches exist exactly in the pair arm at the full widths
-                assert (grouped >= 12) == (pair and B == 256), (pair, B, grouped)
-                results.append((loss.detach().clone(), [(n, p.grad.clone()) for n, p in list(model.named_parameters()) + list(loss_fn.named_parameters())]))
-        finally:
-            _autograd._PAIR_NODE = prev
-        (l0, g0), (l1, g1) = results
-        assert torch.equal(l0, l1), (B, float(l0), float(l1))
-        for (n, a), (_, b) in zip(g0, g1):
-            if n.endswith("token_embedding.weight"):  # fp32 atomics
-                torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
-            else:
-                assert torch.equal(a, b), (B, n, float((a - b).abs().max()))

@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--gemm-gm", type=int, default=0, help="mmamd_debug_set_gemm_knob(0, gm): tile-order group (8 = the r03 order)")
     ap.add_argument("--no-deferred-ln-reduce", action="store_true", help="A/B arm: every LayerNorm backward reduces its own dgamma / dbeta / column-sum partials (53 small launches per step) instead of one batched launch per stack")
     ap.add_argument("--no-fused-bias", action="store_true", help="A/B arm: bias gradients from the column-sum passes (the r04 form) instead of the wgrad GEMM's own pass")
-    ap.add_argument("--no-pair-node", action="store_true", help="A/B arm: one autograd node per tower, the text tower on a side stream, instead of ONE pair node with grouped launches over both towers")
     ap.add_argument("--no-grouped-wgrad", action="store_true", help="A/B arm: one split-K launch + reduce per Linear's weight gradient instead of one grouped launch per layer")
     ap.add_argument("--tower", choices=("both", "image", "text"), default="both", help="image / text: the training step of ONE tower alone (loss = mean of its embedding's squares): what each tower costs by itself")
     ap.add_argument("--f32-dh", action="store_true", help="A/B arm: the dgrad GEMMs in front of a LayerNorm backward write fp32 (the form before r05's LayerNorm-backward register fix) instead of bf16")
@@ -30,7 +29,6 @@ def main():
 
     _autograd._BF16_DH = not a.f32_dh
     _autograd._GROUPED_WGRAD = not a.no_grouped_wgrad
-    _autograd._PAIR_NODE = not a.no_pair_node
 
     _autograd._FUSED_BIAS_GRAD = not a.no_fused_bias
     _autograd._DEFER_LN_REDUCE = not a.no_deferred_ln_reduce
@@ -76,16 +74,15 @@ def main():
     gf = 3 * 41.09
     from multimodal_amd import ops as _ops
 
-    launches = {k: _ops.launch_count(k) // (a.steps + a.warmup) for k in ("colsum_stage2_batched", "colsum", "gemm_bf16_splitk", "gemm_bf16_tn_splitk_group", "layernorm_bwd", "gemm_bf16_grouped")}
+    launches = {k: _ops.launch_count(k) // (a.steps + a.warmup) for k in ("colsum_stage2_batched", "colsum", "gemm_bf16_splitk", "gemm_bf16_tn_splitk_group", "layernorm_bwd")}
     # the arms ran what they are named after (launch counters of the library): batched reductions exist exactly in the deferred arm, stand-alone
     # column-sum passes exactly in the unfused-bias arm
     assert (launches["colsum_stage2_batched"] > 0) == _autograd._DEFER_LN_REDUCE and (launches["colsum"] > 40) == (not _autograd._FUSED_BIAS_GRAD), launches
-    assert (launches["gemm_bf16_grouped"] >= 60) == (_autograd._PAIR_NODE and a.tower == "both"), launches  # 12 layers x (3 forward + 3 backward) grouped launches
     assert (launches["gemm_bf16_tn_splitk_group"] >= 12) == (_autograd._GROUPED_WGRAD and _autograd._FUSED_BIAS_GRAD), launches
     print(json.dumps({"workload": "CLIP ViT-B/16 training step (fwd + contrastive loss + bwd + SGD), synthetic" + ("" if a.tower == "both" else f" -- {a.tower.upper()} TOWER ALONE (tflops / mfma_frac do not apply)"), "batch": a.batch,
                       "ms_per_step": round(ms, 3), "pairs_per_s": round(a.batch / ms * 1e3, 1), "gflop_per_pair": gf,
                       "tflops": round(a.batch * gf / ms, 1), "mfma_frac": round(a.batch * gf / ms / 2500.0, 4),
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "deferred_ln_reduce": _autograd._DEFER_LN_REDUCE, "dh_dtype": "bf16" if _autograd._BF16_DH else "f32", "grouped_wgrad": _autograd._GROUPED_WGRAD, "pair_node": _autograd._PAIR_NODE and a.tower == "both", "launches_per_step": launches, "losses": [round(x, 4) for x in losses]}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fused_bias_grad": _autograd._FUSED_BIAS_GRAD, "deferred_ln_reduce": _autograd._DEFER_LN_REDUCE, "dh_dtype": "bf16" if _autograd._BF16_DH else "f32", "grouped_wgrad": _autograd._GROUPED_WGRAD, "launches_per_step": launches, "losses": [round(x, 4) for x in losses]}))
 
 
 if __name__ == "__main__":
