@@ -17,6 +17,8 @@ timeout 300 python tools/flava_bench.py 2>/dev/null | tail -1
 timeout 300 python tools/flava_bench.py --no-attentions 2>/dev/null | tail -1
 timeout 300 python tools/coca_bench.py 2>/dev/null | tail -1
 timeout 400 python tools/train_bench.py 2>/dev/null | tail -1
+timeout 400 python tools/train_bench.py --tower image 2>/dev/null | tail -1
+timeout 400 python tools/train_bench.py --tower text 2>/dev/null | tail -1
 timeout 400 python tools/flava_bench.py --train 2>/dev/null | tail -1
 timeout 400 python tools/coca_bench.py --train 2>/dev/null | tail -1
 } > $O/other_models.jsonl
