@@ -39,7 +39,7 @@ def _hipcc() -> str:
 def _digest(src: Path) -> str:
     h = hashlib.sha256()
     h.update(" ".join(CXXFLAGS).encode())
-    for f in [src, *sorted(CSRC.glob("*.h")), *sorted(INCLUDE.glob("*.h")), *sorted(CSRC.glob("experiments/*.inc"))]:
+    for f in [src, *sorted(CSRC.glob("*.h")), *sorted(INCLUDE.glob("*.h")), *sorted(CSRC.glob("*.inc")), *sorted(CSRC.glob("experiments/*.inc"))]:
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()
