@@ -35,6 +35,8 @@ int mmamd_debug_set_gemm_wp(const void* Wp);
 int mmamd_debug_set_gemm_trace(void* buf);
 /* Diagnostic: attention ablation variant (timing experiments; non-zero values compute WRONG results). */
 int mmamd_debug_set_attn_variant(int v);
+/* A/B: 0 = mmamd_colsum never takes its few-rows / very-wide form (every shape goes through the row-per-workgroup form, as before r05); 1 = default. */
+int mmamd_debug_set_colsum_wide(int on);
 
 /* --- CU-mask streams, per-stream CU budget (r02 / r04 experiments: profiles/r02_cu_partition_sweep.txt, r04_cu_budget_sweep.txt,
  * r04_phased_schedule_ab.txt), placement probe --------------------------------------------------------------------------------------- */

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "mmamd_pack_w_frag": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmamd_debug_set_gemm_wp": (_i, [_vp]),
     "mmamd_debug_set_attn_variant": (_i, [_i]),
+    "mmamd_debug_set_colsum_wide": (_i, [_i]),
     "mmamd_debug_launch_count": (C.c_ulonglong, [C.c_char_p]),
     "mmamd_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mmamd_add_layernorm_grouped": (_i, [_vp, _i, _vp]),

@@ -505,13 +505,56 @@ extern "C" int mmamd_colsum_stage2_batched(const mmamd_colsum_job* jobs, int njo
   return launch_status("colsum_stage2_batched");
 }
 
+namespace mmamd {
+// FEW rows of a VERY wide matrix (the positional-embedding gradient: column sums of d_asm viewed as [B, S * w] = [256, 151 296]): one row per workgroup
+// (colsum_stage1_kernel) writes as many partial bytes as it reads -- 155 MB in, 155 MB of partials out, 155 MB back in: 100 + 23 us.  Here a thread owns
+// one 16-byte chunk of columns and walks a row group with four loads in flight; the partials are [row groups <= 8][n].  r05.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, int rows, int n, float* __restrict__ part, int rpg) {
+  constexpr int VEC = 16 / sizeof(T);
+  typedef typename std::conditional<sizeof(T) == 2, bf16x8, f32x4>::type vec_t;
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch * VEC >= n) return;
+  const int r0 = blockIdx.y * rpg, r1 = r0 + rpg < rows ? r0 + rpg : rows;
+  const T* p = x + (size_t)ch * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    const vec_t v0 = *reinterpret_cast<const vec_t*>(p + (size_t)r * n), v1 = *reinterpret_cast<const vec_t*>(p + (size_t)(r + 1) * n);
+    const vec_t v2 = *reinterpret_cast<const vec_t*>(p + (size_t)(r + 2) * n), v3 = *reinterpret_cast<const vec_t*>(p + (size_t)(r + 3) * n);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { acc[j] += (float)v0[j]; acc[j] += (float)v1[j]; acc[j] += (float)v2[j]; acc[j] += (float)v3[j]; }
+  }
+  for (; r < r1; ++r) {
+    const vec_t v = *reinterpret_cast<const vec_t*>(p + (size_t)r * n);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += (float)v[j];
+  }
+  float* o = part + (size_t)blockIdx.y * n + (size_t)ch * VEC;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) o[j] = acc[j];
+}
+}  // namespace mmamd
+
+static int g_colsum_wide = 1;
+extern "C" int mmamd_debug_set_colsum_wide(int on) { g_colsum_wide = on != 0; return 0; }
+
 extern "C" int mmamd_colsum(const void* x, int dtype, int rows, int n, float* out, float* ws, mmamd_stream_t stream) {
   MMAMD_CHECK_ARG(x && out && ws && rows > 0 && n > 0, MMAMD_E_BADARG, "colsum: bad argument");
   MMAMD_CHECK_ARG(dtype == MMAMD_F32 || dtype == MMAMD_BF16, MMAMD_E_BADARG, "colsum: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   const int vec = dtype == MMAMD_F32 ? 4 : 8;
   int G;  // ws: min(1024, rows) * n floats
-  if (n % vec == 0 && aligned16(x)) {
+  if (g_colsum_wide && n % vec == 0 && aligned16(x) && rows <= 2048 && (long long)n >= 64LL * rows && n >= 16384) {
+    const int rg = rows >= 64 ? 8 : 1;  // row groups: 8 x (n / vec / 256) workgroups keep every CU loading
+    const int rpg = (rows + rg - 1) / rg;
+    G = (rows + rpg - 1) / rpg;
+    const dim3 grid((n / vec + 255) / 256, G);
+    if (dtype == MMAMD_F32) hipLaunchKernelGGL((colsum_wide_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, n, ws, rpg);
+    else hipLaunchKernelGGL((colsum_wide_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, rows, n, ws, rpg);
+  } else if (n % vec == 0 && aligned16(x)) {
     const int rpb = (rows + 1023) / 1024;
     G = (rows + rpb - 1) / rpb;
     if (dtype == MMAMD_F32) hipLaunchKernelGGL((colsum_stage1_kernel<float>), dim3(G), dim3(256), 0, st, (const float*)x, rows, n, ws, rpb);

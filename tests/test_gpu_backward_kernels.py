@@ -707,3 +707,17 @@ def test_grouped_weight_gradients_equal_the_single_launches_bit_for_bit():
             assert torch.equal(dw, ref_dw), (T, tuple(y.shape), tuple(x.shape), s_used)
             want = y.double().T @ x.double()
             assert (dw.double() - want).abs().max().item() <= 2e-5 * T ** 0.5 * max(1.0, float(want.abs().max()))
+
+
+def test_column_sums_of_few_very_wide_rows():
+    """r05: mmamd_colsum's form for few rows of a very wide matrix (the positional-embedding gradient sums d_asm viewed as [B, S * w]): a thread per
+    16-byte column chunk, eight row groups -- against float64 sums; shapes on both sides of its dispatch predicate, fp32 and bf16, a ragged row count."""
+    from multimodal_amd import ops
+
+    set_rng_seed(29)
+    for rows, n, dt in ((256, 32768, torch.float32), (64, 16392, torch.bfloat16), (7, 20000, torch.float32), (203, 151296 // 8, torch.float32),
+                        (300, 16384, torch.bfloat16), (256, 16376, torch.float32)):
+        x = torch.randn(rows, n).to(dt)
+        got = host(ops.colsum(x.cuda()))
+        want = x.double().sum(0).numpy()
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (rows, n, dt)
