@@ -185,10 +185,14 @@ __global__ __launch_bounds__(256) void f32_gemm_strided_kernel(const float* __re
                                                                const float* __restrict__ Y, long long syn, long long syk,
                                                                const float* __restrict__ log_alpha, const float* __restrict__ R,
                                                                int ldr, float* __restrict__ C, int ldc, int M, int N, int K) {
+  // One 32 x 32 tile of C per workgroup, its contraction split over the four waves (r05): these are the 0.07-0.2 GFLOP gradients of the projections and
+  // of the loss, ten of them at the head of a CLIP training step's backward with nothing to overlap -- a wave per tile walking all of K was a chain of
+  // K / 32 dependent memory round trips (58 us for K = 256 .. 768).  Wave w takes k in [w Kq, (w + 1) Kq); the four partial tiles meet in LDS and are added
+  // in wave order (deterministic).
+  __shared__ float red[3][16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m0 = blockIdx.y * 32;
-  const int n0 = (blockIdx.x * 4 + wv) * 32;
-  if (n0 >= N) return;
+  const int n0 = blockIdx.x * 32;
   const int half = lane >> 5;
   int rm = m0 + (lane & 31); rm = rm < M ? rm : M - 1;
   int rn = n0 + (lane & 31); rn = rn < N ? rn : N - 1;
@@ -197,22 +201,30 @@ __global__ __launch_bounds__(256) void f32_gemm_strided_kernel(const float* __re
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // 32 contraction steps per trip, all 32 loads of the trip issued before the first MFMA (r05: the loop was one dependent round trip to memory per
-  // 8 steps -- 89 us for the 0.07-0.2 GFLOP gradients of the projections and the loss, ten of them on the critical path of a CLIP training step).
-  // Same products in the same order: bit-identical results.
-  for (int k0 = 0; k0 < K; k0 += 32) {
+  const int Kq = (((K + 3) / 4) + 7) & ~7;  // per-wave share, a multiple of the 8 contraction steps one load group covers
+  const int kb = wv * Kq, ke = kb + Kq < K ? kb + Kq : K;
+  // 32 contraction steps per trip, all 32 loads of the trip issued before the first MFMA
+  for (int k0 = kb; k0 < ke; k0 += 32) {
     float xs[16], ys[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int k = k0 + 8 * i + 4 * half + u;
-        xs[4 * i + u] = k < K ? xp[(size_t)k * sxk] : 0.f;
-        ys[4 * i + u] = k < K ? yp[(size_t)k * syk] : 0.f;
+        xs[4 * i + u] = k < ke ? xp[(size_t)k * sxk] : 0.f;
+        ys[4 * i + u] = k < ke ? yp[(size_t)k * syk] : 0.f;
       }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[i], ys[i], acc, 0, 0, 0);
   }
+  if (wv > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wv != 0) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
   const float alpha = log_alpha ? expf(*log_alpha) : 1.f;
   const int n = n0 + (lane & 31);
   if (n < N) {
@@ -479,7 +491,7 @@ extern "C" int mmamd_cross_entropy(const float* logits, int64_t ld, const int64_
 
 static int launch_f32_gemm(const float* X, long long sxm, long long sxk, const float* Y, long long syn, long long syk,
                            const float* log_alpha, const float* R, int ldr, float* C, int ldc, int M, int N, int K, hipStream_t st) {
-  hipLaunchKernelGGL(f32_gemm_strided_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, st, X, sxm, sxk, Y, syn, syk, log_alpha,
+  hipLaunchKernelGGL(f32_gemm_strided_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, st, X, sxm, sxk, Y, syn, syk, log_alpha,
                      R, ldr, C, ldc, M, N, K);
   return launch_status("contrastive_bwd gemm");
 }

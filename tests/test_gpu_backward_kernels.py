@@ -721,3 +721,21 @@ def test_column_sums_of_few_very_wide_rows():
         got = host(ops.colsum(x.cuda()))
         want = x.double().sum(0).numpy()
         assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), (rows, n, dt)
+
+
+def test_f32_strided_gemm_with_the_contraction_split_over_the_waves():
+    """r05: mmamd_f32_gemm_strided computes one 32 x 32 tile per workgroup, the contraction split over its four waves (partials added in wave order):
+    against float64 at the shapes of the projection / loss gradients of a CLIP step, ragged shapes, short contractions (waves without any work) and both
+    stride orders; deterministic run to run."""
+    from multimodal_amd import ops
+
+    set_rng_seed(31)
+    for M, N, K in ((768, 512, 256), (256, 768, 512), (256, 512, 256), (40, 70, 5), (33, 31, 9), (64, 64, 1000), (1, 1, 1), (100, 3, 37)):
+        X, Y = torch.randn(M, K), torch.randn(N, K)
+        want = (X.double() @ Y.double().t()).numpy()
+        C = ops.f32_gemm_strided(X.cuda(), K, 1, Y.cuda(), K, 1, M, N, K)
+        assert np.abs(host(C) - want).max() <= 2e-6 * max(1.0, K ** 0.5) * max(1.0, np.abs(want).max()), (M, N, K)
+        assert torch.equal(C, ops.f32_gemm_strided(X.cuda(), K, 1, Y.cuda(), K, 1, M, N, K))
+        Xt, Yt = X.t().contiguous(), Y.t().contiguous()  # the same product from [K, M] / [K, N] buffers (element strides 1 and M / N)
+        Ct = ops.f32_gemm_strided(Xt.cuda(), 1, M, Yt.cuda(), 1, N, M, N, K)
+        assert torch.equal(Ct, C), (M, N, K)
