@@ -47,3 +47,28 @@ def test_layernorm_backward_workgroup_count(rows, d, want):
     from multimodal_amd import _lib
 
     assert _lib.lib().mmamd_layernorm_bwd_groups(rows, d) == want
+
+
+def test_step_timeline_tool_on_a_synthetic_trace(tmp_path, capsys):
+    """tools/step_timeline.py (busy / idle / co-running time per queue from a rocprofv3 kernel trace) on a hand-made trace: two queues, one 10 us gap."""
+    import sys
+
+    from tools import step_timeline
+
+    rows = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp"']
+    ev = [(1, "gemm", 0, 100_000), (2, "ln", 50_000, 80_000), (1, "attn", 110_000, 200_000), (2, "ln", 120_000, 150_000)]  # ns
+    for i, (q, name, s, e) in enumerate(ev):
+        rows.append(f'"KERNEL_DISPATCH","Agent 2",{q},0,1,{i},1,"{name}",{i},{1_000_000 + s},{1_000_000 + e}')
+    f = tmp_path / "t_kernel_trace.csv"
+    f.write_text("\n".join(rows) + "\n")
+    argv = sys.argv
+    try:
+        sys.argv = ["step_timeline.py", str(f), "--last-ms", "1"]
+        step_timeline.main()
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    assert "4 kernels" in out and "q1: 0.2 ms" in out and "q2: 0.1 ms" in out
+    # 200 us window: idle 10 us (5 %), one kernel 130 us, two kernels 60 us
+    assert "0.0 ms (5.0 %) / 0.1 ms (65.0 %) / 0.1 ms (30.0 %)" in out
+    assert "1 idle gaps" in out and "after gemm" in out and "before attn" in out
