@@ -1423,33 +1423,12 @@ __global__ __launch_bounds__(512) void attention_bwd_sp_kernel(const bf16* __res
   for (int item = blockIdx.x; item < BH; item += gridDim.x) {
     const int b = item / H, h = item - b * H;
     const bf16* base = qkv + (size_t)b * S * row_stride + h * kDh;
-    for (int r = tid >> 3; r < SP; r += NT >> 3) {
-      const int c = tid & 7;
-      bf16x8 qv, kv, dv, ov;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { qv[j] = (bf16)0.f; kv[j] = (bf16)0.f; dv[j] = (bf16)0.f; ov[j] = (bf16)0.f; }
-      if (r < S) {
-        const bf16* row = base + (size_t)r * row_stride + c * 8;
-        qv = *reinterpret_cast<const bf16x8*>(row);
-        kv = *reinterpret_cast<const bf16x8*>(row + D);
-        dv = *reinterpret_cast<const bf16x8*>(dO + ((size_t)b * S + r) * D + h * kDh + c * 8);
-        ov = *reinterpret_cast<const bf16x8*>(O + ((size_t)b * S + r) * D + h * kDh + c * 8);
-      }
-      *reinterpret_cast<bf16x8*>(Qs + r * kKStride + c * 8) = qv;
-      *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv;
-      *reinterpret_cast<bf16x8*>(dOs + r * kKStride + c * 8) = dv;
-      float part = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) part += (float)dv[j] * (float)ov[j];
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      if (c == 0) {
-        Dqs[r] = r < S ? part : 0.f;
-        L2s[r] = r < S ? lse[((size_t)b * H + h) * S + r] : INFINITY;
-        Mk[r] = (r < S && (key_mask == nullptr || key_mask[(size_t)b * S + r] != 0)) ? 1 : 0;
-      }
-    }
+    // Staging with EVERY global load of the item in flight before the first one is consumed (r05): the row loop used to be a rolled loop of
+    // ceil(SP / 64) trips, each a round trip for its four rows' chunks and then a second, dependent one for the log-sum-exp (and a third for the key
+    // mask) -- seven or more serial round trips to memory per (batch, head) item, ~10 of its 25 us at S = 197; the K / V fragments of this wave's key
+    // tile came after that.  Now: this wave's K / V fragments, then all row chunks, log-sum-exp values and mask bytes, then the LDS image.  The loads
+    // are UNCONDITIONAL on clamped addresses (rows / keys past S read row S - 1 and are zeroed afterwards): a load inside a divergent branch makes the
+    // compiler drain the whole queue (s_waitcnt vmcnt(0)) where the branch joins.
     const int tile = wave;
     const bool live = tile < T;
     // this wave's key tile: K and V fragments (lane = key), V straight from global
@@ -1457,13 +1436,63 @@ __global__ __launch_bounds__(512) void attention_bwd_sp_kernel(const bf16* __res
     {
       const int key = tile * 32 + l31;
       const bool in = live && key < S;
+      const bf16* krow = base + (size_t)(key < S ? key : S - 1) * row_stride + 8 * half;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        kf[t] = *reinterpret_cast<const bf16x8*>(krow + D + 16 * t);
+        vf[t] = *reinterpret_cast<const bf16x8*>(krow + 2 * D + 16 * t);
+      }
+      constexpr int NI = (SP + (NT >> 3) - 1) / (NT >> 3);
+      const int c = tid & 7;
+      bf16x8 qv[NI], kv[NI], dv[NI], ov[NI];
+      float lv[NI];
+      uint8_t mv[NI];
+      const uint8_t* mbase = key_mask != nullptr ? key_mask + (size_t)b * S : reinterpret_cast<const uint8_t*>(lse);  // (no mask: any readable byte)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = (tid >> 3) + i * (NT >> 3);
+        const int rr = r < S ? r : S - 1;
+        const bf16* row = base + (size_t)rr * row_stride + c * 8;
+        qv[i] = *reinterpret_cast<const bf16x8*>(row);
+        kv[i] = *reinterpret_cast<const bf16x8*>(row + D);
+        dv[i] = *reinterpret_cast<const bf16x8*>(dO + ((size_t)b * S + rr) * D + h * kDh + c * 8);
+        ov[i] = *reinterpret_cast<const bf16x8*>(O + ((size_t)b * S + rr) * D + h * kDh + c * 8);
+        lv[i] = lse[((size_t)b * H + h) * S + rr];
+        mv[i] = mbase[rr];
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[t][j] = (bf16)0.f; vf[t][j] = (bf16)0.f; }
-        if (in) {
-          kf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * row_stride + D + 16 * t + 8 * half);
-          vf[t] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * row_stride + 2 * D + 16 * t + 8 * half);
+        for (int j = 0; j < 8; ++j) {
+          kf[t][j] = in ? kf[t][j] : (bf16)0.f;
+          vf[t][j] = in ? vf[t][j] : (bf16)0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = (tid >> 3) + i * (NT >> 3);
+        const bool rin = r < S;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          qv[i][j] = rin ? qv[i][j] : (bf16)0.f;
+          kv[i][j] = rin ? kv[i][j] : (bf16)0.f;
+          dv[i][j] = rin ? dv[i][j] : (bf16)0.f;
+        }
+        if (r < SP) {
+          *reinterpret_cast<bf16x8*>(Qs + r * kKStride + c * 8) = qv[i];
+          *reinterpret_cast<bf16x8*>(Ks + r * kKStride + c * 8) = kv[i];
+          *reinterpret_cast<bf16x8*>(dOs + r * kKStride + c * 8) = dv[i];
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)dv[i][j] * (float)ov[i][j];
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        if (c == 0 && r < SP) {
+          Dqs[r] = rin ? part : 0.f;
+          L2s[r] = rin ? lv[i] : INFINITY;
+          Mk[r] = (rin && (key_mask == nullptr || mv[i] != 0)) ? 1 : 0;
         }
       }
     }
