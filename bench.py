@@ -74,6 +74,9 @@ def parse_args(argv=None):
                          "between the kernels, so host jitter cannot skew N lock-stepped ranks; falls back to eager launches (and says so) when "
                          "the capture fails")
     ap.add_argument("--no-affinity", action="store_true", help="do not pin each rank to the CPUs next to its GPU")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST MODE, not a measurement: every rank of an N > 1 job runs on device 0 and the process group is gloo (RCCL refuses two "
+                         "ranks on one device) -- the driver's N = 8 control flow with the real towers on a one-GPU box (tests/test_gpu_loss_w8.py)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with ONE rank: the N > 1 code path (communicator, packed all-gather, rank-offset "
                          "labels, fences, max-over-ranks) on a single-GPU box")
@@ -250,6 +253,10 @@ def main() -> None:
         return dry_main(args, rank, world)
     if args.backend != "nccl":
         raise SystemExit("the measured path runs over RCCL (--backend nccl); gloo is for --dry-run")
+    if args.share_gpu:
+        local_rank = 0  # every rank on the one device of the box; gloo carries the collectives
+        args.no_probe = True
+        args.cpu_sample = 0
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to fd 1 from here on (RCCL prints its library path
     # through C stdio, flushed at exit, i.e. AFTER the record) goes to stderr; the record is written to the saved descriptor
@@ -273,7 +280,7 @@ def main() -> None:
             bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
         except Exception:  # noqa: BLE001
             bdf = None
-        affinity = pin_rank_to_local_cpus(local_rank, world, bdf)
+        affinity = pin_rank_to_local_cpus(int(os.environ.get("LOCAL_RANK", "0")), world, bdf)
 
     import torch.distributed as dist
 
@@ -285,14 +292,17 @@ def main() -> None:
             os.environ["MASTER_PORT"] = str(free_port())
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm; intra-node transport = xGMI
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm; intra-node transport = xGMI
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
 
     from multimodal_amd import build
 
-    if local_rank == 0:
+    if rank == 0 or (local_rank == 0 and not args.share_gpu):
         build.build()
     if use_dist:
         dist.barrier()
@@ -383,6 +393,21 @@ def main() -> None:
             e1.record()
             torch.cuda.synchronize(dev)
             allgather_ms = e0.elapsed_time(e1) / 20
+    share_check = None
+    if args.share_gpu and use_dist:
+        # the 8c protocol (3) inside the bench's own control flow: mean over ranks of the per-rank losses == the one-process loss on the gathered batch
+        from multimodal_amd.utils.distributed import gather_packed_features
+
+        with torch.no_grad():
+            out = model(images_d, ids_d)
+            buf, r_, w_ = gather_packed_features(out.embeddings_a, out.embeddings_b)
+            assert (r_, w_) == (rank, world) and buf.shape[0] == world * B
+            E_ = buf.shape[1] // 2
+            out3, la_, _ = ops.contrastive_fwd(buf[:, :E_], buf[:, E_:], buf[:, :E_], buf[:, E_:], 2 * E_, loss_fn.logit_scale.detach().reshape(1), 0)
+            mine = loss_fn(out.embeddings_a, out.embeddings_b).reshape(1).float()
+            dist.all_reduce(mine)
+            share_check = {"loss_mean_over_ranks": float(mine) / world, "loss_one_process_on_gathered": float(out3[0]),
+                           "logits_block": list(la_.shape)}
     loss_val = float(loss)
     if not math.isfinite(loss_val):
         raise SystemExit(f"non-finite loss {loss_val}")
@@ -519,8 +544,13 @@ def main() -> None:
             line["graph_note"] = graph_note
         if affinity is not None:
             line["cpu_affinity_rank0"] = affinity
+        if share_check is not None:
+            line.update(share_check)
+            line["share_gpu_test"] = True
+            line["ranks_seen"] = ranks_seen
+            line["note"] = "TEST MODE (--share-gpu): all ranks on device 0 over gloo; value is not a measurement"
         if ranks_seen is not None:
-            line["rccl_ranks_seen"] = ranks_seen
+            line["rccl_ranks_seen"] = None if args.share_gpu else ranks_seen
             line["allgather_ms"] = [round(float(x[2]), 4) for x in per_rank_all]
         os.write(record_fd, (json.dumps(line) + "\n").encode())
     os.close(record_fd)

@@ -265,14 +265,18 @@ __global__ __launch_bounds__(256) void ce_generic_bwd_kernel(const float* __rest
     for (int j = tid * 4; j < V; j += 1024) {
       const f32x4 v = load4(x + j);
       const float mn = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-      se = se * __expf(m - mn) + ((__expf(v[0] - mn) + __expf(v[1] - mn)) + (__expf(v[2] - mn) + __expf(v[3] - mn)));
-      m = mn;
+      if (mn != -INFINITY) {  // (a thread whose elements so far are all -inf keeps (-inf, 0): m - mn would be NaN)
+        se = se * __expf(m - mn) + ((__expf(v[0] - mn) + __expf(v[1] - mn)) + (__expf(v[2] - mn) + __expf(v[3] - mn)));
+        m = mn;
+      }
     }
   } else {
     for (int j = tid; j < V; j += 256) {
       const float v = x[j], mn = fmaxf(m, v);
-      se = se * __expf(m - mn) + __expf(v - mn);
-      m = mn;
+      if (mn != -INFINITY) {  // masked (-inf) logits before the thread's first finite one: keep (-inf, 0), do not form -inf - -inf
+        se = se * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+      }
     }
   }
   const float wm = wave_max(m);
@@ -386,14 +390,18 @@ __global__ __launch_bounds__(256) void ce_generic_rows_kernel(const float* __res
       const f32x4 v = load4(x + j);
       const float cm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
       const float mn = fmaxf(m, cm);
-      se = se * __expf(m - mn) + ((__expf(v[0] - mn) + __expf(v[1] - mn)) + (__expf(v[2] - mn) + __expf(v[3] - mn)));  // (first chunk: 0 * exp(-inf) = 0)
-      m = mn;
+      if (mn != -INFINITY) {  // (first finite chunk: 0 * exp(-inf) = 0; all -inf so far: keep (-inf, 0) -- m - mn would be NaN)
+        se = se * __expf(m - mn) + ((__expf(v[0] - mn) + __expf(v[1] - mn)) + (__expf(v[2] - mn) + __expf(v[3] - mn)));
+        m = mn;
+      }
     }
   } else {
     for (int j = tid; j < V; j += 256) {
       const float v = x[j], mn = fmaxf(m, v);
-      se = se * __expf(m - mn) + __expf(v - mn);
-      m = mn;
+      if (mn != -INFINITY) {  // masked (-inf) logits before the thread's first finite one: keep (-inf, 0), do not form -inf - -inf
+        se = se * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+      }
     }
   }
   // merge: threads that saw no element hold (-inf, 0) and drop out (an all -inf row gives NaN like torch)

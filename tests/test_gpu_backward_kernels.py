@@ -337,6 +337,34 @@ def test_cross_entropy_backward_kernel():
         assert np.abs(host(g[:, :V]) - ref).max() <= tol + 1e-7
 
 
+def test_cross_entropy_with_masked_minus_inf_logits():
+    """Rows whose FIRST columns are -inf (a masked vocabulary prefix): torch returns a finite loss and gradient; the one-pass running
+    (max, sum) must not form -inf - -inf (the scalar path, V % 4 != 0 such as FLAVA's 30522, and the vectorised path)."""
+    from multimodal_amd import ops
+
+    set_rng_seed(22)
+    for (N, V, pad, dt) in ((7, 30522, 64, torch.float32), (9, 49408, 64, torch.float32), (5, 1000, 4, torch.bfloat16), (4, 301, 1, torch.float32)):
+        logits = torch.randn(N, V) * 3
+        logits[:, :300] = -float("inf")          # every thread's first element / first 16-byte chunk is -inf
+        logits[1, 300:V - 2] = -float("inf")     # only the tail of a row is finite
+        lab = torch.randint(300, V, (N,))
+        lab[1] = V - 1
+        if V > 302:
+            logits[2, ::2] = -float("inf")
+            lab[2] = 301
+        logits.requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(logits.double(), lab)
+        assert torch.isfinite(loss)
+        (loss * 1.3).backward()
+        got = ops.cross_entropy(logits.detach().cuda(), lab.cuda(), -1)
+        assert abs(float(got) - float(loss)) <= 2e-6 * max(1.0, abs(float(loss))), (V, float(got), float(loss))
+        g = ops.cross_entropy_bwd(logits.detach().cuda(), lab.cuda(), -1, torch.tensor([1.3], device="cuda"), out_dtype=dt, pad_cols_to=pad)
+        ref = logits.grad.double().numpy()
+        assert np.isfinite(host(g)).all()
+        tol = 1e-6 if dt == torch.float32 else 2 ** -8 * np.abs(ref).max()
+        assert np.abs(host(g[:, :V]) - ref).max() <= tol + 1e-7
+
+
 def test_flava_full_pretraining_step_gradients_vs_reference_autograd(golden):
     """The whole FLAVA pre-training objective (ITM + MMM text/image heads + global contrastive; patch mask, padded text, ITM row
     filter) in train mode: every parameter gradient of the model AND of the loss heads against the reference's torch autograd."""
