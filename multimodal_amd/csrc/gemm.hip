@@ -28,6 +28,17 @@
 
 namespace mmamd {
 
+// cache-policy bits of the fp32 epilogue's buffer loads / stores (gfx94x: 1 = sc0, 2 = nt, 16 = sc1); build-time A/B only
+#ifndef MMAMD_EPI_LD_AUX
+#define MMAMD_EPI_LD_AUX 0
+#endif
+#ifndef MMAMD_EPI_WIN
+#define MMAMD_EPI_WIN 1
+#endif
+#ifndef MMAMD_EPI_ST_AUX
+#define MMAMD_EPI_ST_AUX 16  // sc1: written through, not kept in the XCD's L2 (r06 A/B: the step -0.8 % against plain stores)
+#endif
+
 typedef uint32_t __attribute__((address_space(3))) * lds_u32p;
 typedef const uint32_t __attribute__((address_space(1))) * glb_u32p;
 typedef __attribute__((ext_vector_type(4))) int int32x4;
@@ -988,7 +999,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
         if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + r_row(m) * p.ldr + n);
       }
     };
-    if constexpr (OUT_F32) {
+    // the pipelined buffer-descriptor epilogue (gemm_epi_f32.inc, r06) serves the plain fp32 output of the 8-wave form; the patch-embedding
+    // mode (rows remapped per image) and the 4-wave form keep the predicated loop below
+    constexpr bool PIPE = OUT_F32 && A_MODE == 0 && MI * NI == 8;
+#define MMAMD_EPI_PART 1
+#include "gemm_epi_f32.inc"
+    if constexpr (OUT_F32 && !PIPE) {
       if (p.R != nullptr) {
 #pragma unroll
         for (int d = 0; d < RD; ++d) res_load(d, rq[d]);
@@ -1005,10 +1021,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     }
     constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
     char* strip = smem + STAGE + wave * (32 * ROWB);
-    __syncthreads();  // every wave has finished reading the last K-tile out of ring buffer 1
-    if constexpr (OUT_F32) {
+    if constexpr (!PIPE) __syncthreads();  // every wave has finished reading the last K-tile out of ring buffer 1 (PIPE: inside the include)
+    if constexpr (PIPE) {
+#define MMAMD_EPI_PART 2
+#include "gemm_epi_f32.inc"
+    } else if constexpr (OUT_F32) {
       const bool has_res = p.R != nullptr;
-      float fs1[4], fs2[4];  // LN fold (producer): row partials of the 4 rows this lane touches per pass, over the wave's TN columns
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1211,7 +1229,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Wb = reinterpret_cast<const char*>(p.W);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)smem;
-  uint32_t a_off[A_INSTR], b_off[B_INSTR], a_nxt[A_INSTR], b_nxt[B_INSTR];
+  uint32_t a_off[A_INSTR], b_off[B_INSTR];
   auto issue_piece = [&](int buf, int kt, int i) __attribute__((always_inline)) {
     const uint32_t dst = lds0 + buf * STAGE + (i < A_INSTR ? (wave + NW * i) * 1024 : A_BYTES + (wave + NW * (i - A_INSTR)) * 1024);
     if (i < A_INSTR) dma_piece_s(Ab + (size_t)kt * 128, a_off[i], dst);
@@ -1335,7 +1353,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
     const char *Abn = Ab, *Wbn = Wb;
     if (more) {
       tile_of(nvb, nsel, ntm, ntn);
-      tile_offsets(g.prob[nsel], ntm, ntn, a_nxt, b_nxt);
       Abn = reinterpret_cast<const char*>(g.prob[nsel].A);
       Wbn = reinterpret_cast<const char*>(g.prob[nsel].W);
     }
@@ -1360,10 +1377,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
       tile_body(B0{}, kt + 1, true);
       const bool last = kt + 2 >= KT;
       if (last && more) {  // this tile's loads are all issued: switch the DMA source to the next tile's first K-tile
-#pragma unroll
-        for (int j = 0; j < A_INSTR; ++j) a_off[j] = a_nxt[j];
-#pragma unroll
-        for (int j = 0; j < B_INSTR; ++j) b_off[j] = b_nxt[j];
+        // (the offsets are computed HERE, not a tile ahead, and again at the head of the next tile: ~40 VALU instructions per tile buy 8 registers
+        // in the K loop and 16 in the epilogue, whose residual-load window they bound)
+        tile_offsets(g.prob[nsel], ntm, ntn, a_off, b_off);
         Ab = Abn;  // ... which may belong to the other problem
         Wb = Wbn;
       }
@@ -1377,25 +1393,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
     // Measured (tools/gemm_variant_bench.py --variants 60,61,62,63, r02): depth 1 = 2 (out-proj 100.7 / 100.5 us), depth 3 and 4
     // LOSE (115 / 133 us: 21 spilled registers and more loads queued per CU) -- the residual's latency is not what the fp32
     // epilogue waits for; the default stays 1.
-    constexpr int RD = 1;
     const int nw0 = n0 + wn * TN;
     const int rrow = lane >> 3, rc = (lane & 7) * 4;  // fp32 read-back: 8 rows x 128 B per wave-instruction
-    f32x4 rq[RD][4];
-    auto res_load = [&](int pass, f32x4 (&dst)[4]) __attribute__((always_inline)) {  // pass = mi * NI + ni
-      const int mi = pass / NI, ni = pass - mi * NI;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
-        dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
-      }
-    };
-    if constexpr (OUT_F32) {
-      if (p.R != nullptr) {
-#pragma unroll
-        for (int d = 0; d < RD; ++d) res_load(d, rq[d]);
-      }
-    }
+#define MMAMD_EPI_PART 1
+#include "gemm_epi_f32.inc"
     if (p.bias != nullptr) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
@@ -1420,41 +1421,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
     }
     constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
     char* strip = smem + STAGE + wave * (32 * ROWB);
-    __syncthreads();  // every wave has finished reading the last K-tile out of ring buffer 1
+    // (below) __syncthreads(): every wave has finished reading the last K-tile out of ring buffer 1 -- issued inside each branch of the
+    // wave- and workgroup-uniform residual test, so that the first residual load and its consumer stay in ONE straight-line region (a value
+    // that crosses the join of a uniform branch was spilled to scratch by the register allocator: read off the ISA)
+    if constexpr (!OUT_F32) __syncthreads();
     if constexpr (OUT_F32) {
-      const bool has_res = p.R != nullptr;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int pass = mi * NI + ni;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            f32x4 t;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = ACT == MMAMD_ACT_GELU_ERF ? gelu_erf(acc[ni][mi][4 * g4 + j]) : acc[ni][mi][4 * g4 + j];
-            *reinterpret_cast<f32x4*>(strip + l31 * ROWB + (8 * g4 + 4 * half) * 4) = t;
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          f32x4 vv[4];
-#pragma unroll
-          for (int it = 0; it < 4; ++it) vv[it] = *reinterpret_cast<const f32x4*>(strip + (it * 8 + rrow) * ROWB + rc * 4);
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
-            const bool ok = m < p.M && n + 3 < p.N;
-            f32x4 v = vv[it];
-            if (ok) {
-              if (has_res) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += rq[pass % RD][it][j];
-              }
-              store16<STP>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, __builtin_bit_cast(uint4, v));
-            }
-          }
-          if (has_res && pass + RD < MI * NI) res_load(pass + RD, rq[pass % RD]);  // refill the slot this pass just consumed
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+#define MMAMD_EPI_PART 2
+#include "gemm_epi_f32.inc"
     } else {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -1506,6 +1479,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
       p = g.prob[sel];
     }
     KT = p.K >> 6;
+    tile_offsets(p, tm, tn, a_off, b_off);  // (the values the last K-tile already computed: recomputed so that they are dead across the epilogue)
   }
 }
 
