@@ -867,12 +867,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   using B1 = std::integral_constant<int, 1>;
   // BDIR, `first` = first K-tile of an output tile: the epilogue's stores are in flight too (they do not retire in order with loads): vmcnt(0).
   // Otherwise the DMA pieces of this K-tile and slot 3 must have landed; the reloads of slots 0 .. 2 (3 NI loads, the youngest) may stay in flight.
+  // `drain` (r06, see the grouped kernel's sync_first): the number of unconditional buffer loads / stores the previous tile's epilogue issued
+  // AFTER the DMA of this tile's first K-tile -- the first barrier of a tile waits for that DMA only, not for the epilogue's stores
+  int drain = 0;
   auto sync_tile = [&](const bool first = true) __attribute__((always_inline)) {
     if constexpr (BDIR) {
       if (first) bdir_wait_plain(std::integral_constant<int, 0>{});
       bdir_wait(std::integral_constant<int, 3>{}, std::integral_constant<int, 3 * NI>{});
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (first && drain == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (first && drain == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      else if (first && drain == 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
   };
@@ -1025,7 +1031,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
     if constexpr (PIPE) {
 #define MMAMD_EPI_PART 2
 #include "gemm_epi_f32.inc"
+      drain = has_res ? 63 : 32;
     } else if constexpr (OUT_F32) {
+      drain = 0;
       const bool has_res = p.R != nullptr;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -1059,7 +1067,46 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
           if (has_res && pass + RD < MI * NI) res_load(pass + RD, rq[pass % RD]);  // refill the slot this pass just consumed
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+    } else if (A_MODE == 0 && CH == 1 && MI * 4 == 16 && p.R == nullptr && p.C2 == nullptr) {
+      // bf16 output, no residual, no second output: buffer-descriptor stores (the grouped kernel's form), not drained by the next tile's first barrier
+      const int mw = m0 + wm * TM;
+      const long long rows_left = (long long)p.M - mw;
+      const long long cb = rows_left > 0 ? rows_left * p.ldc * 2 : 0;
+      const __amdgpu_buffer_rsrc_t c16_srd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.C) + ((size_t)mw * p.ldc + nw0) * 2, 0,
+                                                                               cb > 0x7fffffffLL ? 0x7fffffff : (int)cb, 0x00020000);
+      const uint32_t c16_lane = ((uint32_t)((lane >> 3) * p.ldc + (lane & 7) * 8) * 2u) | ((nw0 + (lane & 7) * 8 + 7 < p.N) ? 0u : 0x80000000u);
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_s;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const int ni = nn;
+            bf16x4 pa, pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float va = acc[ni][mi][4 * g + j], vb = acc[ni][mi][4 * (g + 1) + j];
+              if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb = gelu_erf(vb); }
+              pa[j] = (bf16)va; pb[j] = (bf16)vb;
+            }
+            uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+            auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+            *reinterpret_cast<uint4*>(strip + l31 * ROWB + (nn * 32 + 8 * (g + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
+          const uint4 v = *reinterpret_cast<const uint4*>(strip + (it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, v), c16_srd, c16_lane + (uint32_t)((it * 8 + mi * 32) * p.ldc) * 2u, 0,
+                                                 STP == 2 ? 2 : (STP == 1 ? 16 : 0));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      drain = 16;
     } else {
+      drain = 0;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1313,6 +1360,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
+  // First barrier of an output tile (r06).  What must have landed is the tile's first K-tile, DMA'd behind the LAST K-tile of the previous
+  // tile -- i.e. BEFORE the previous epilogue's loads and stores.  vmcnt retires in issue order, so waiting until at most `drain` operations
+  // are outstanding, with drain = the number of vector-memory instructions the epilogue issued (every one of them an unconditional buffer
+  // instruction: the count is exact), covers the DMA without draining the epilogue's stores: the r01-r05 vmcnt(0) here paid the write
+  // acknowledgement of the tile's last stores at the head of every tile.  0 = wait for everything (first tile; epilogues with predicated ops).
+  int drain = 0;
+  auto sync_first = [&]() __attribute__((always_inline)) {
+    if (drain == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (drain == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (drain == 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
 
   int KT = p.K >> 6;  // even (launcher), per problem
   tile_offsets(p, tm, tn, a_off, b_off);
@@ -1373,7 +1433,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
 
 #pragma unroll 1
     for (int kt = 0; kt < KT; kt += 2) {
-      sync_tile();
+      if (kt == 0) sync_first();
+      else sync_tile();
       tile_body(B0{}, kt + 1, true);
       const bool last = kt + 2 >= KT;
       if (last && more) {  // this tile's loads are all issued: switch the DMA source to the next tile's first K-tile
@@ -1428,7 +1489,49 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
     if constexpr (OUT_F32) {
 #define MMAMD_EPI_PART 2
 #include "gemm_epi_f32.inc"
+      drain = has_res ? 63 : 32;  // 32 buffer stores (+ 32 buffer loads: more than the 6-bit counter holds)
+    } else if (p.R == nullptr) {
+      // bf16 output, no residual (qkv, MLP-up): the same strips, stored through a buffer descriptor (rows past M dropped by the range check,
+      // columns past N by bit 31 of the lane's offset) -- 16 unconditional stores per wave, which the next tile's first barrier does not drain
+      static_assert(CH == 1, "one 64-column chunk per wave tile");
+      const int mw = m0 + wm * TM;
+      const long long rows_left = (long long)p.M - mw;
+      const long long cb = rows_left > 0 ? rows_left * p.ldc * 2 : 0;
+      const __amdgpu_buffer_rsrc_t c16_srd = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.C) + ((size_t)mw * p.ldc + nw0) * 2, 0,
+                                                                               cb > 0x7fffffffLL ? 0x7fffffff : (int)cb, 0x00020000);
+      const uint32_t c16_lane = ((uint32_t)((lane >> 3) * p.ldc + (lane & 7) * 8) * 2u) | ((nw0 + (lane & 7) * 8 + 7 < p.N) ? 0u : 0x80000000u);
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_s;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; g4 += 2) {
+            const int ni = nn;
+            bf16x4 pa, pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float va = acc[ni][mi][4 * g4 + j], vb2 = acc[ni][mi][4 * (g4 + 1) + j];
+              if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb2 = gelu_erf(vb2); }
+              pa[j] = (bf16)va; pb[j] = (bf16)vb2;
+            }
+            uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+            auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+            *reinterpret_cast<uint4*>(strip + l31 * ROWB + (nn * 32 + 8 * (g4 + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
+          const uint4 v = *reinterpret_cast<const uint4*>(strip + (it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, v), c16_srd, c16_lane + (uint32_t)((it * 8 + mi * 32) * p.ldc) * 2u, 0,
+                                                 STP == 2 ? 2 : (STP == 1 ? 16 : 0));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      drain = MI * 4;
     } else {
+      drain = 0;  // (predicated residual loads and stores: not countable)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
