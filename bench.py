@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (the metric is quoted at 256)")
     ap.add_argument("--cpu-sample", type=int, default=32, help="batch of the CPU-baseline sample; 0 = skip")
+    ap.add_argument("--cpu-full", type=int, default=1, help="1: also ONE timed CPU pass over the whole batch (about 17 s at B = 256) next to the sample's figure")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--no-probe", action="store_true", help="do not bracket the dominant GEMM with events")
     ap.add_argument("--fp32-images", action="store_true", help="(default since r04) feed fp32 images: the stem converts them to bf16 inside the timed step")
@@ -196,7 +197,7 @@ def dry_main(args, rank, world) -> None:
         dist.destroy_process_group()
 
 
-def cpu_baseline_leg(sd_host, images, ids, n):
+def cpu_baseline_leg(sd_host, images, ids, n, full=False):
     """The reference's CPU path, timed on this host (see the module docstring): 1 warm-up + 3 timed passes of n pairs."""
     import torch
 
@@ -221,6 +222,13 @@ def cpu_baseline_leg(sd_host, images, ids, n):
         out = m.forward_loss(im_s, id_s)
         times.append(time.perf_counter() - tc)
     med = sorted(times)[1]
+    full_batch = None
+    if full and images.shape[0] > n:  # ONE pass over the whole batch at the same thread count (carry both figures)
+        tc = time.perf_counter()
+        out_full = m.forward_loss(images, ids)
+        tf = time.perf_counter() - tc
+        full_batch = {"value": round(images.shape[0] / tf, 3), "unit": "pairs/s", "pairs": int(images.shape[0]), "seconds": round(tf, 2), "passes": 1,
+                      "threads": best_t, "loss": round(float(out_full[4]), 5)}
     ref_itself = None
     p = ROOT / "profiles" / "r02_reference_cpu.json"
     if p.exists():
@@ -236,7 +244,7 @@ def cpu_baseline_leg(sd_host, images, ids, n):
             "sample": f"first {n} pairs of the same synthetic ViT-B/16 batch, fp32, torch {torch.__version__} CPU kernels through "
                       f"nn.TransformerEncoder (oracle/torch_cpu_clip.py), one warm-up pass per thread count then 3 timed passes at "
                       f"{best_t} threads, median {med:.2f} s",
-            "loss_on_sample": round(float(out[4]), 5), "reference_itself": ref_itself}
+            "loss_on_sample": round(float(out[4]), 5), "full_batch": full_batch, "reference_itself": ref_itself}
 
 
 def main() -> None:
@@ -512,7 +520,7 @@ def main() -> None:
                     "share_of_step": round(24 * (ms / len(samples)) / (dt_local / args.steps * 1e3), 4),
                     "algorithmic_flops_per_launch": fl / len(samples), "by_shape": by_shape, "other_kernels": other_kernels}
 
-    cpu_baseline = cpu_baseline_leg(sd_host, images, ids, args.cpu_sample) if sd_host is not None else None
+    cpu_baseline = cpu_baseline_leg(sd_host, images, ids, args.cpu_sample, full=bool(args.cpu_full)) if sd_host is not None else None
     from multimodal_amd.schedule import get_schedule
 
     sch = get_schedule()

@@ -333,91 +333,38 @@ def _record(o: TransformerOutput, stream) -> None:
 
 
 def flava_model(
-    # Image encoder specific parameters
-    image_hidden_size: int = 768,
-    image_num_attention_heads: int = 12,
-    image_num_hidden_layers: int = 12,
-    image_dropout: float = 0.0,
-    image_intermediate_size: int = 3072,
-    image_intermediate_activation: Callable[..., nn.Module] = nn.GELU,
-    image_layer_norm_eps: float = 1e-12,
-    use_image_masking: bool = True,
-    image_size: int = 224,
-    patch_size: int = 16,
-    num_channels: int = 3,
-    # Text encoder specific parameters
-    text_hidden_size: int = 768,
-    text_num_attention_heads: int = 12,
-    text_num_hidden_layers: int = 12,
-    text_dropout: float = 0.0,
-    text_intermediate_size: int = 3072,
-    text_intermediate_activation: Callable[..., nn.Module] = nn.GELU,
-    text_layer_norm_eps: float = 1e-12,
-    vocab_size: int = 30522,
-    pad_token_id: int = 0,
-    type_vocab_size: int = 2,
-    max_position_embeddings: int = 512,
-    # Multimodal encoder specific parameters
-    multimodal_hidden_size: int = 768,
-    multimodal_num_attention_heads: int = 12,
-    multimodal_num_hidden_layers: int = 6,
-    multimodal_dropout: float = 0.0,
-    multimodal_intermediate_size: int = 3072,
-    multimodal_intermediate_activation: Callable[..., nn.Module] = nn.GELU,
-    multimodal_layer_norm_eps: float = 1e-12,
-    # projection
-    text_and_image_proj_size: int = 768,
-    pretrained: bool = False,
-    **kwargs: Any,
+    image_hidden_size: int = 768, image_num_attention_heads: int = 12, image_num_hidden_layers: int = 12, image_dropout: float = 0.0,
+    image_intermediate_size: int = 3072, image_intermediate_activation: Callable[..., nn.Module] = nn.GELU, image_layer_norm_eps: float = 1e-12,
+    use_image_masking: bool = True, image_size: int = 224, patch_size: int = 16, num_channels: int = 3,
+    text_hidden_size: int = 768, text_num_attention_heads: int = 12, text_num_hidden_layers: int = 12, text_dropout: float = 0.0,
+    text_intermediate_size: int = 3072, text_intermediate_activation: Callable[..., nn.Module] = nn.GELU, text_layer_norm_eps: float = 1e-12,
+    vocab_size: int = 30522, pad_token_id: int = 0, type_vocab_size: int = 2, max_position_embeddings: int = 512,
+    multimodal_hidden_size: int = 768, multimodal_num_attention_heads: int = 12, multimodal_num_hidden_layers: int = 6,
+    multimodal_dropout: float = 0.0, multimodal_intermediate_size: int = 3072,
+    multimodal_intermediate_activation: Callable[..., nn.Module] = nn.GELU, multimodal_layer_norm_eps: float = 1e-12,
+    text_and_image_proj_size: int = 768, pretrained: bool = False, **kwargs: Any,
 ) -> FLAVAModel:
-    image_encoder = flava_image_encoder(
-        hidden_size=image_hidden_size,
-        num_attention_heads=image_num_attention_heads,
-        num_hidden_layers=image_num_hidden_layers,
-        use_image_masking=use_image_masking,
-        dropout=image_dropout,
-        intermediate_size=image_intermediate_size,
-        intermediate_activation=image_intermediate_activation,
-        layer_norm_eps=image_layer_norm_eps,
-        image_size=image_size,
-        patch_size=patch_size,
-        num_channels=num_channels,
-    )
-    text_encoder = flava_text_encoder(
-        hidden_size=text_hidden_size,
-        num_attention_heads=text_num_attention_heads,
-        num_hidden_layers=text_num_hidden_layers,
-        dropout=text_dropout,
-        intermediate_size=text_intermediate_size,
-        intermediate_activation=text_intermediate_activation,
-        layer_norm_eps=text_layer_norm_eps,
-        vocab_size=vocab_size,
-        pad_token_id=pad_token_id,
-        type_vocab_size=type_vocab_size,
-        max_position_embeddings=max_position_embeddings,
-    )
-    mm_encoder = flava_multimodal_encoder(
-        hidden_size=multimodal_hidden_size,
-        num_attention_heads=multimodal_num_attention_heads,
-        num_hidden_layers=multimodal_num_hidden_layers,
-        dropout=multimodal_dropout,
-        intermediate_size=multimodal_intermediate_size,
-        intermediate_activation=multimodal_intermediate_activation,
-        layer_norm_eps=multimodal_layer_norm_eps,
-    )
-    image_to_mm_projection = nn.Linear(image_hidden_size, multimodal_hidden_size)
-    text_to_mm_projection = nn.Linear(text_hidden_size, multimodal_hidden_size)
-    image_projection = nn.Linear(image_hidden_size, text_and_image_proj_size)
-    text_projection = nn.Linear(text_hidden_size, text_and_image_proj_size)
-    flava = FLAVAModel(
-        image_encoder=image_encoder,
-        text_encoder=text_encoder,
-        mm_encoder=mm_encoder,
-        image_to_mm_projection=image_to_mm_projection,
-        text_to_mm_projection=text_to_mm_projection,
-        text_projection=text_projection,
-        image_projection=image_projection,
-    )
+    """Factory with the reference's keyword names, defaults and positional order (models/flava/model.py:428-500; the names ARE the contract: callers and
+    the example configs pass them by keyword).  The three encoder factories share one set of tower keywords (`hidden_size`, `num_attention_heads`,
+    `num_hidden_layers`, `dropout`, `intermediate_size`, `intermediate_activation`, `layer_norm_eps`), prefixed per tower here; the rest belong to
+    one tower each.  Construction order = the reference's (image, text, multimodal encoder, then the image->mm, text->mm, image, text
+    projections): the seeded initial values are checksum-equal tensor for tensor (tests/test_host_api_flava.py)."""
+    given = dict(locals())
+    shared = ("hidden_size", "num_attention_heads", "num_hidden_layers", "dropout", "intermediate_size", "intermediate_activation", "layer_norm_eps")
+
+    def tower(prefix: str, own: tuple = ()) -> dict:
+        return {**{k: given[f"{prefix}_{k}"] for k in shared}, **{k: given[k] for k in own}}
+
+    towers = {
+        "image_encoder": flava_image_encoder(**tower("image", ("use_image_masking", "image_size", "patch_size", "num_channels"))),
+        "text_encoder": flava_text_encoder(**tower("text", ("vocab_size", "pad_token_id", "type_vocab_size", "max_position_embeddings"))),
+        "mm_encoder": flava_multimodal_encoder(**tower("multimodal")),
+    }
+    # (attribute name, fan-in, fan-out) in the reference's construction order: nn.Linear draws from the global RNG
+    heads = {name: nn.Linear(fan_in, fan_out) for name, fan_in, fan_out in (
+        ("image_to_mm_projection", image_hidden_size, multimodal_hidden_size), ("text_to_mm_projection", text_hidden_size, multimodal_hidden_size),
+        ("image_projection", image_hidden_size, text_and_image_proj_size), ("text_projection", text_hidden_size, text_and_image_proj_size))}
+    flava = FLAVAModel(**towers, **heads)
     if pretrained:
         load_module_from_url(flava, FLAVA_MODEL_MAPPING[CKPT_KEY])
     return flava

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--no-attentions", action="store_true", help="schedule.flava_attentions = False: the forwards do not produce the attention probabilities (opt-out)")
     ap.add_argument("--probs-two-pass", action="store_true", help="A/B: unmasked attention probabilities from the two-pass kernel (debug variant 514) instead of flash + one pass")
     ap.add_argument("--copy-trace", action="store_true", help="after the timing: one more step under the torch profiler -> which host call sites issue copies / fills / cats / casts")
+    ap.add_argument("--fsdp", action="store_true", help="with --train: model + loss heads wrapped by FullyShardedDataParallel exactly as the reference trainer does "
+                    "(examples/flava/native/train.py:183-206: transformer_auto_wrap_policy over the encoder layers and the three encoders), one RCCL rank (NO_SHARD)")
+    ap.add_argument("--fsdp-orig-params", action="store_true", help="use_orig_params=True for --fsdp")
     ap.add_argument("--codebook", action="store_true", help="MIM labels from the DALL-E codebook (112x112 images) inside the step instead of synthetic ones")
     a = ap.parse_args()
     from multimodal_amd.models.flava.model import flava_model
@@ -47,7 +50,49 @@ def main():
     model = flava_model().to(dev)
     loss = FLAVAPretrainingLoss().to(dev)
     model, loss = (model.train(), loss.train()) if a.train else (model.eval(), loss.eval())
-    opt = torch.optim.SGD(list(model.parameters()) + list(loss.parameters()), lr=1e-4) if a.train else None
+    wrapped, fsdp_units = None, 0
+    if a.fsdp:
+        assert a.train, "--fsdp prices the wrapped TRAINING step"
+        import functools
+        import os
+        import socket
+
+        import torch.distributed as dist
+        from torch import nn
+        from torch.distributed.fsdp import FullyShardedDataParallel as FSDP
+        from torch.distributed.fsdp.wrap import transformer_auto_wrap_policy
+
+        from multimodal_amd.models.flava.image_encoder import ImageTransformer
+        from multimodal_amd.models.flava.transformer import FLAVATransformerWithoutEmbeddings, TransformerEncoderLayer
+        from multimodal_amd.modules.encoders.bert_text_encoder import BERTTextEncoder
+
+        class PreTrain(nn.Module):  # the reference's FLAVAPreTrainModule shape: model + loss heads in ONE module, which the trainer wraps
+            def __init__(self, model, loss):
+                super().__init__()
+                self.model, self.loss = model, loss
+
+            def forward(self, image, text, pmask, text_masked, itm, mim, mlm):
+                o = self.model(image, text, image_patches_mask=pmask, text_masked=text_masked)
+                lo = self.loss(image_sequence=o.image.last_hidden_state, text_sequence=o.text.last_hidden_state,
+                               image_masked_sequence=o.image_masked.last_hidden_state, text_masked_sequence=o.text_masked.last_hidden_state,
+                               multimodal_masked_sequence=o.multimodal_masked.last_hidden_state, itm_labels=itm, mim_labels=mim, mlm_labels=mlm,
+                               projected_image_embeddings=o.projected_image_embeddings, projected_text_embeddings=o.projected_text_embeddings)
+                return lo.losses.itm_loss + lo.losses.mmm_text_loss + lo.losses.mmm_image_loss + lo.losses.global_contrastive_loss
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        both = PreTrain(model, loss)
+        scalars = [p for p in both.parameters() if p.dim() == 0]  # FSDP refuses 0-dim parameters (logit_scale): replicated, as in the probe
+        wrapped = FSDP(both, device_id=dev, limit_all_gathers=True, use_orig_params=a.fsdp_orig_params, ignored_states=scalars,
+                       auto_wrap_policy=functools.partial(transformer_auto_wrap_policy, transformer_layer_cls={
+                           TransformerEncoderLayer, ImageTransformer, BERTTextEncoder, FLAVATransformerWithoutEmbeddings}))
+        fsdp_units = sum(1 for m in wrapped.modules() if isinstance(m, FSDP))
+        wrapped.train()
+    opt = (torch.optim.SGD(wrapped.parameters() if wrapped is not None else list(model.parameters()) + list(loss.parameters()), lr=1e-4)) if a.train else None
     B = a.batch
     g = torch.Generator().manual_seed(1)
     image = torch.randn(B, 3, 224, 224, generator=g).to(dev)
@@ -81,6 +126,11 @@ def main():
 
     def train_step():
         opt.zero_grad(set_to_none=True)
+        if wrapped is not None:
+            total = wrapped(image, text, pmask, text_masked, itm, labels(), mlm)
+            total.backward()
+            opt.step()
+            return total.detach()
         o = model(image, text, image_patches_mask=pmask, text_masked=text_masked)
         lo = loss(image_sequence=o.image.last_hidden_state, text_sequence=o.text.last_hidden_state,
                   image_masked_sequence=o.image_masked.last_hidden_state, text_masked_sequence=o.text_masked.last_hidden_state,
@@ -143,7 +193,13 @@ def main():
     print(json.dumps({"workload": ("TRAINING step: " if a.train else "") + "flava_model() fwd" + ("" if a.no_loss else " + FLAVAPretrainingLoss") + (" + bwd + SGD" if a.train else "") + (" + DALL-E codebook labels" if a.codebook else " (no codebook)"),
                       "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 1), "gflop_per_sample": gf,
                       "tflops": round(B * gf / ms, 1), "mfma_frac": round(B * gf / ms / 2500.0, 4),
-                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "probs_path": "two_pass" if a.probs_two_pass else "flash+one_pass", "launches": launches, "last": float(r.flatten()[0])}))
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "fsdp": ({"units": fsdp_units, "use_orig_params": a.fsdp_orig_params, "sharding": str(wrapped.sharding_strategy), "ranks": 1} if wrapped is not None else None),
+                      "probs_path": "two_pass" if a.probs_two_pass else "flash+one_pass", "launches": launches, "last": float(r.flatten()[0])}))
+
+    if a.fsdp:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
