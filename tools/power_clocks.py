@@ -48,7 +48,8 @@ class Telemetry:
                    "throttle_status", "indep_throttle_status", "temperature_hotspot", "temperature_mem", "accumulation_counter",
                    "prochot_residency_acc", "ppt_residency_acc", "socket_thm_residency_acc", "vr_thm_residency_acc", "hbm_thm_residency_acc",
                    "gfxclk_lock_status", "firmware_timestamp", "system_clock_counter", "gfx_below_host_limit_acc", "gfx_below_host_limit_ppt_acc",
-                   "gfx_below_host_limit_thm_acc", "gfx_below_host_limit_total_acc", "gfx_low_utilization_acc")
+                   "gfx_below_host_limit_thm_acc", "gfx_below_host_limit_total_acc", "gfx_low_utilization_acc", "energy_accumulator", "gfx_activity_acc",
+                   "mem_activity_acc", "temperature_vrsoc")
 
     def __init__(self, hz: float):
         self.dt = 1.0 / hz
@@ -120,7 +121,7 @@ class Telemetry:
             m = self._call("amdsmi_get_gpu_metrics_info")
             if isinstance(m, dict):
                 s["metrics"] = {k: m[k] for k in self.METRIC_KEYS if k in m}
-        if self.smi is not None and self._tick % 8 == 1:  # the slow calls (violation status ~50 ms) on every 8th tick only
+        if self.smi is not None and self._tick % 4 == 1:  # the slow calls (violation status ~50 ms) on every 4th tick only
             p = self._call("amdsmi_get_power_info")
             if p is not None:
                 s["power_info"] = p
@@ -229,11 +230,42 @@ def summarise(samples, label, skip_s=1.0):
         out["accumulation_counter_delta"] = acc1 - acc0
     ts = {str(s.get("metrics", {}).get("throttle_status")) for s in ss} | {"indep:" + str(s.get("metrics", {}).get("indep_throttle_status")) for s in ss}
     out["throttle_status_values_seen"] = sorted(ts)[:8]
-    v0, v1 = ss[0].get("violation"), ss[-1].get("violation")
+    vs = [s["violation"] for s in ss if isinstance(s.get("violation"), dict)]
+    v0, v1 = (vs[0], vs[-1]) if len(vs) >= 2 else (None, vs[-1] if vs else None)
     if isinstance(v1, dict):
         out["violation_last"] = {k: v for k, v in v1.items() if isinstance(v, (int, float, str, bool))}
         if isinstance(v0, dict):
             out["violation_acc_delta"] = {k: _num(v1[k]) - _num(v0[k]) for k in v1 if k.startswith("acc_") and _num(v1.get(k)) is not None and _num(v0.get(k)) is not None}
+            # r06 -- WHY the shader clock sits below the host limit, per XCD of partition 0 (firmware residency counters, same time base as acc_counter):
+            # _pwr = the socket power limit (PPT), _thm = a thermal limit, _total = any reason; total - pwr - thm = a limiter the counters do not name
+            # (electrical: peak-current / voltage-droop management of the matrix pipes).  acc_low_utilization = clock lowered because the XCD idles.
+            dc = (_num(v1.get("acc_counter")) or 0) - (_num(v0.get("acc_counter")) or 0)
+
+            def xcd_delta(key):
+                a, b = v0.get(key), v1.get(key)
+                if isinstance(a, list) and isinstance(b, list) and a and isinstance(a[0], list):
+                    d = [(_num(y), _num(x)) for x, y in zip(a[0], b[0])]
+                    d = [y - x for y, x in d if x is not None and y is not None]
+                    return d
+                return None
+
+            if dc > 0:
+                rep = {"acc_counter_delta": dc}
+                for key in ("acc_gfx_clk_below_host_limit_pwr", "acc_gfx_clk_below_host_limit_thm", "acc_gfx_clk_below_host_limit_total", "acc_low_utilization"):
+                    d = xcd_delta(key)
+                    if d:
+                        rep[key + "_share_mean_over_xcds"] = round(sum(d) / len(d) / dc, 4)
+                        rep[key + "_share_per_xcd"] = [round(x / dc, 3) for x in d]
+                t_, p_, h_ = (rep.get("acc_gfx_clk_below_host_limit_%s_share_mean_over_xcds" % k) for k in ("total", "pwr", "thm"))
+                if t_ is not None and p_ is not None and h_ is not None:
+                    rep["below_host_limit_unnamed_reason_share"] = round(t_ - p_ - h_, 4)
+                out["clock_limit_reasons"] = rep
+    # energy_accumulator (firmware's accumulated socket energy; 15.259 uJ per count on this family): mean power over the workload without sampling noise
+    es = [(s["t"], _num(s.get("metrics", {}).get("energy_accumulator"))) for s in ss]
+    es = [(t, e) for t, e in es if e is not None]
+    if len(es) >= 2 and es[-1][0] > es[0][0]:
+        out["energy_accumulator_delta"] = es[-1][1] - es[0][1]
+        out["mean_power_W(energy_accumulator x 15.259 uJ / wall time)"] = round((es[-1][1] - es[0][1]) * 15.259e-6 / (es[-1][0] - es[0][0]), 1)
     return out
 
 
@@ -255,12 +287,13 @@ def external(args):
            "errors": tel.errors, "workloads": {}}
     for label, o in outs.items():
         t = summarise(tel.samples, label, 1.0)
-        if t:
-            t.pop("violation_last", None)
         rec["workloads"][label] = {"run": o, "telemetry": t}
         pw = (t or {}).get("socket_power_W(metrics.current_socket_power)")
         ck = (t or {}).get("gfxclk_MHz(metrics.current_gfxclks mean over XCDs)")
-        print(f"{label:28s} {o['stdout'].strip()[-200:]}\n{'':28s} power {pw} gfxclk {ck} ppt {(t or {}).get('ppt_residency_acc_delta')} / {(t or {}).get('accumulation_counter_delta')}")
+        cr = (t or {}).get("clock_limit_reasons") or {}
+        print(f"{label:28s} {o['stdout'].strip()[-200:]}\n{'':28s} power {pw} (energy counter: {(t or {}).get('mean_power_W(energy_accumulator x 15.259 uJ / wall time)')} W) gfxclk {ck} ppt {(t or {}).get('ppt_residency_acc_delta')} / {(t or {}).get('accumulation_counter_delta')}"
+              f"\n{'':28s} clock below host limit: any reason {cr.get('acc_gfx_clk_below_host_limit_total_share_mean_over_xcds')}, power {cr.get('acc_gfx_clk_below_host_limit_pwr_share_mean_over_xcds')}, "
+              f"thermal {cr.get('acc_gfx_clk_below_host_limit_thm_share_mean_over_xcds')}, unnamed {cr.get('below_host_limit_unnamed_reason_share')}, low utilisation {cr.get('acc_low_utilization_share_mean_over_xcds')}")
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(rec, indent=1))
 
@@ -407,7 +440,11 @@ def main():
         t = w["telemetry"] or {}
         pw = next((t[k] for k in t if k.startswith("socket_power_W") or k.startswith("power_W")), None)
         ck = next((t[k] for k in t if k.startswith("gfxclk_MHz") or k.startswith("sclk_MHz")), None)
-        print(f"{label[:64]:64s} {json.dumps(w['timing'])}  power {pw}  gfxclk {ck}  ppt_delta {t.get('ppt_residency_acc_delta')} / acc {t.get('accumulation_counter_delta')}")
+        cr = t.get("clock_limit_reasons") or {}
+        print(f"{label[:64]:64s} {json.dumps(w['timing'])}  power {pw}  gfxclk {ck}  ppt_delta {t.get('ppt_residency_acc_delta')} / acc {t.get('accumulation_counter_delta')}  "
+              f"energy-counter W {t.get('mean_power_W(energy_accumulator x 15.259 uJ / wall time)')}  below-limit any/pwr/thm/unnamed/lowutil "
+              f"{cr.get('acc_gfx_clk_below_host_limit_total_share_mean_over_xcds')}/{cr.get('acc_gfx_clk_below_host_limit_pwr_share_mean_over_xcds')}/"
+              f"{cr.get('acc_gfx_clk_below_host_limit_thm_share_mean_over_xcds')}/{cr.get('below_host_limit_unnamed_reason_share')}/{cr.get('acc_low_utilization_share_mean_over_xcds')}")
 
 
 if __name__ == "__main__":
