@@ -103,19 +103,37 @@ __device__ __forceinline__ float quick_gelu(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));
 }
 
-// nn.GELU() = 0.5 v (1 + erf(v / sqrt 2)).  libm's erff is ~60 instructions with branches (it doubled the epilogue's register
-// use); this is the Abramowitz-Stegun 7.1.26 rational form on the hardware rcp / exp2: |erf error| <= 1.5e-7, i.e. the result
-// differs from the exact GELU by < 1e-7 |v| -- far below the bf16 rounding of the value that is stored.  Branch-free.
-__device__ __forceinline__ float gelu_erf(float v) {
-  const float x = fabsf(v) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float h = 0.5f * v * (poly * t) * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);  // 0.5 v (1 - erf|x|)
-  return v >= 0.f ? v - h : h;
+// Two values at a time (r06): the epilogues run these on 128 accumulator values per lane while the matrix pipe idles -- 27 % of a tile's time for the
+// erf form (FLAVA / CoCa MLP-up), 12 % for QuickGELU (CLIP).  On float2 the multiplies / adds / fmas compile to v_pk_mul / v_pk_add / v_pk_fma_f32
+// (one issue slot for two values; IEEE-exact like their scalar forms); only rcp / exp2 and the |v| operand stay per value.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 quick_gelu2(f32x2 v) {  // bit-identical to quick_gelu() per element (same operations in the same order)
+  const f32x2 z = v * (-1.702f * 1.4426950408889634f);
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + 1.0f;
+  return v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
+// erf-GELU as 0.5 v + |v| (0.5 - tau(|v|)) [= max(v, 0) - |v| tau], tau = 0.5 (1 - erf(|v| / sqrt 2)) by the Abramowitz-Stegun 7.1.26 rational form (0.5 folded into the
+// polynomial, 1 / sqrt 2 into the rcp's argument): no compare / select, 9 issue slots per value where the r01-r05 form (x = |v| / sqrt 2, h = 0.5 v (1 - erf x),
+// v >= 0 ? v - h : h) took ~16.  Both are < 1e-7 |v| from the exact GELU; the result is rounded to bf16.
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+  const f32x2 ax = __builtin_elementwise_abs(v);
+  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f}, f32x2{1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 poly = __builtin_elementwise_fma(f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, t, f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+  const f32x2 z = (v * (-0.5f * 1.4426950408889634f)) * v;  // -x^2 log2(e), x = v / sqrt 2
+  const f32x2 q = (poly * t) * f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};  // tau = 0.5 (1 - erf|x|)
+  // max(v, 0) - |v| tau = 0.5 v + |v| (0.5 - tau)   (max as an fp32 instruction canonicalises its operand first: two issue slots per value)
+  return __builtin_elementwise_fma(ax, f32x2{0.5f, 0.5f} - q, v * 0.5f);
+}
+
+// nn.GELU() = 0.5 v (1 + erf(v / sqrt 2)), one value: the SAME operation sequence as gelu_erf2 (every GEMM kernel of the library must round the
+// activation identically -- a batch of 8 takes the plain tiled kernel, a batch of 128 the persistent one, and their rows are compared bit for bit).
+// libm's erff is ~60 instructions with branches; this is the Abramowitz-Stegun 7.1.26 rational form on the hardware rcp / exp2: |erf error| <= 1.5e-7,
+// far below the bf16 rounding of the value that is stored.  Branch-free.
+__device__ __forceinline__ float gelu_erf(float v) { return gelu_erf2(f32x2{v, v})[0]; }
 
 // d/du [u sigmoid(1.702 u)] and d/du [u Phi(u)]: the factor the MLP's backward multiplies the incoming gradient with
 __device__ __forceinline__ float act_grad(float u, int mode) {
@@ -361,7 +379,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float va = acc[ni][mi][4 * g + j], vb = acc[ni][mi][4 * (g + 1) + j];
-            if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb = gelu_erf(vb); }
+            if constexpr (ACT == MMAMD_ACT_GELU_ERF) { const f32x2 ge = gelu_erf2(f32x2{va, vb}); va = ge[0]; vb = ge[1]; }
             pa[j] = (bf16)va; pb[j] = (bf16)vb;
           }
           uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
@@ -1017,13 +1035,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
       }
     }
     add_bias<MI, NI, TM, TN>(acc, p, n0, wn, lane, BLDS ? smem + 2 * STAGE : nullptr);
-    if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+    if constexpr (ACT == MMAMD_ACT_QUICKGELU || (ACT == MMAMD_ACT_GELU_ERF && !OUT_F32)) {  // (activation + fp32 output: inside the fp32 passes; no model path)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[ni][mi][r] = quick_gelu(acc[ni][mi][r]);
+          for (int r = 0; r < 16; r += 2) {  // adjacent accumulator registers: the pairs need no moves
+            const f32x2 in = {acc[ni][mi][r], acc[ni][mi][r + 1]};
+            const f32x2 qg = ACT == MMAMD_ACT_QUICKGELU ? quick_gelu2(in) : gelu_erf2(in);
+            acc[ni][mi][r] = qg[0]; acc[ni][mi][r + 1] = qg[1];
+          }
     }
     constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
     char* strip = smem + STAGE + wave * (32 * ROWB);
@@ -1087,7 +1109,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float va = acc[ni][mi][4 * g + j], vb = acc[ni][mi][4 * (g + 1) + j];
-              if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb = gelu_erf(vb); }
               pa[j] = (bf16)va; pb[j] = (bf16)vb;
             }
             uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
@@ -1120,8 +1141,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 float va = acc[ni][mi][4 * g + j], vb = acc[ni][mi][4 * (g + 1) + j];
-                if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb = gelu_erf(vb); }
-                pa[j] = (bf16)va; pb[j] = (bf16)vb;
+                  pa[j] = (bf16)va; pb[j] = (bf16)vb;
               }
               uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
               auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
@@ -1472,13 +1492,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
             for (int j = 0; j < 4; ++j) acc[ni][mi][4 * g4 + j] += bv[j];
         }
     }
-    if constexpr (ACT == MMAMD_ACT_QUICKGELU) {
+    if constexpr (ACT == MMAMD_ACT_QUICKGELU || (ACT == MMAMD_ACT_GELU_ERF && !OUT_F32)) {  // (activation + fp32 output: inside the fp32 passes; no model path)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[ni][mi][r] = quick_gelu(acc[ni][mi][r]);
+          for (int r = 0; r < 16; r += 2) {  // adjacent accumulator registers: the pairs need no moves
+            const f32x2 in = {acc[ni][mi][r], acc[ni][mi][r + 1]};
+            const f32x2 qg = ACT == MMAMD_ACT_QUICKGELU ? quick_gelu2(in) : gelu_erf2(in);
+            acc[ni][mi][r] = qg[0]; acc[ni][mi][r + 1] = qg[1];
+          }
     }
     constexpr int ROWB = 144;  // 128-byte strip rows + 16 B pad (conflict-free b128 both ways)
     char* strip = smem + STAGE + wave * (32 * ROWB);
@@ -1512,7 +1536,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float va = acc[ni][mi][4 * g4 + j], vb2 = acc[ni][mi][4 * (g4 + 1) + j];
-              if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb2 = gelu_erf(vb2); }
               pa[j] = (bf16)va; pb[j] = (bf16)vb2;
             }
             uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
@@ -1545,8 +1568,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 float va = acc[ni][mi][4 * g4 + j], vb2 = acc[ni][mi][4 * (g4 + 1) + j];
-                if constexpr (ACT == MMAMD_ACT_GELU_ERF) { va = gelu_erf(va); vb2 = gelu_erf(vb2); }
-                pa[j] = (bf16)va; pb[j] = (bf16)vb2;
+                  pa[j] = (bf16)va; pb[j] = (bf16)vb2;
               }
               uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
               auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
