@@ -32,25 +32,33 @@ __global__ void cu_census_kernel(int* __restrict__ out, long long spin) {
   while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
 }
 
-// launch counters: one slot per launcher name (string literals: compared by pointer first, by content on a miss), relaxed atomics -- a launch costs one
-// pointer scan of <= 96 slots
+// launch counters: one slot per launcher name.  The names are string literals, so the hot path is a POINTER scan (no strcmp: ADVICE r05); only a
+// name whose pointer is not in the table yet -- the first launch through a call site, or the same literal from another translation unit -- takes the
+// slow pass, which matches by content or claims a free slot.  A full table is counted (g_launch_overflow) and reported by
+// mmamd_debug_launch_count("__overflow__") instead of being dropped silently.
 struct LaunchSlot {
   std::atomic<const char*> name{nullptr};
   std::atomic<unsigned long long> n{0};
 };
-static LaunchSlot g_launch_slots[96];
+static LaunchSlot g_launch_slots[128];
+static std::atomic<unsigned long long> g_launch_overflow{0};
+unsigned long long launch_overflow() { return g_launch_overflow.load(std::memory_order_relaxed); }
 void count_launch(const char* what) {
   for (auto& s : g_launch_slots) {
     const char* cur = s.name.load(std::memory_order_acquire);
-    if (cur == what || (cur != nullptr && strcmp(cur, what) == 0)) { s.n.fetch_add(1, std::memory_order_relaxed); return; }
+    if (cur == what) { s.n.fetch_add(1, std::memory_order_relaxed); return; }
+    if (cur == nullptr) break;  // slots fill front to back: nothing behind the first free one
+  }
+  for (auto& s : g_launch_slots) {  // slow pass
+    const char* cur = s.name.load(std::memory_order_acquire);
     if (cur == nullptr) {
       const char* expected = nullptr;
-      if (s.name.compare_exchange_strong(expected, what, std::memory_order_acq_rel) || strcmp(expected, what) == 0) {
-        s.n.fetch_add(1, std::memory_order_relaxed);
-        return;
-      }
+      if (s.name.compare_exchange_strong(expected, what, std::memory_order_acq_rel)) { s.n.fetch_add(1, std::memory_order_relaxed); return; }
+      cur = expected;  // somebody else claimed it first
     }
+    if (cur == what || strcmp(cur, what) == 0) { s.n.fetch_add(1, std::memory_order_relaxed); return; }
   }
+  g_launch_overflow.fetch_add(1, std::memory_order_relaxed);
 }
 
 void set_error(const char* fmt, ...) {
@@ -148,6 +156,7 @@ extern "C" int mmamd_debug_cu_census(int* out, int blocks, long long spin_ticks,
 
 extern "C" unsigned long long mmamd_debug_launch_count(const char* what) {
   if (what == nullptr) return 0;
+  if (strcmp(what, "__overflow__") == 0) return mmamd::launch_overflow();  // launches that found the name table full (0 unless it must grow)
   for (auto& s : mmamd::g_launch_slots) {
     const char* cur = s.name.load(std::memory_order_acquire);
     if (cur != nullptr && strcmp(cur, what) == 0) return s.n.load(std::memory_order_relaxed);

@@ -2040,6 +2040,21 @@ static int gemm_splitk_impl(const void* A, int lda, const void* W, int ldw, floa
   return launch_status("gemm_bf16_splitk");
 }
 
+// One validation for every TN split-K launcher (single, + column sums, grouped: ADVICE r05 -- they had drifted apart, 2^31 here and 2^32 there).
+// dW[M, N] = A[K, M]^T . W[K, N] with A = dY and W = X row-major over the contraction: 64 contraction rows of either operand must stay inside the
+// DMA's signed 32-bit byte offsets; M * N % 4 == 0 (from M % 8) is what lets the reduce kernel run in 4-element groups without the weight-gradient
+// and the bias-gradient ranges sharing one.
+static int tn_splitk_check(const char* who, const void* A, int lda, const void* W, int ldw, const void* C, const void* ws, int M, int N, int K) {
+  MMAMD_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0, MMAMD_E_BADARG, "%s: bad argument", who);
+  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "%s: contraction length K=%d must be a multiple of 128", who, K);
+  MMAMD_CHECK_ARG(M % 8 == 0 && N % 8 == 0, MMAMD_E_UNSUPPORTED, "%s: M=%d and N=%d must be multiples of 8", who, M, N);
+  MMAMD_CHECK_ARG(lda >= M && ldw >= N && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "%s: bad leading dimension", who);
+  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws), MMAMD_E_ALIGN, "%s: base pointers must be 16-byte aligned", who);
+  MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)lda * 2u < (1ull << 31) && (uint64_t)64 * (uint64_t)ldw * 2u < (1ull << 31), MMAMD_E_UNSUPPORTED,
+                  "%s: leading dimension too large for the 32-bit DMA offsets", who);
+  return 0;
+}
+
 // ---- grouped weight gradients: one GEMM launch + one reduce launch for up to 8 problems (gemm_bf16_tn_group_kernel above) ----
 namespace mmamd {
 struct SplitkReduceJob {
@@ -2106,13 +2121,7 @@ extern "C" int mmamd_gemm_bf16_tn_splitk_group(const mmamd_wgrad_job* jobs, int 
   float* wsp = ws;
   for (int i = 0; i < njobs; ++i) {
     const mmamd_wgrad_job& jb = jobs[i];
-    MMAMD_CHECK_ARG(jb.dy && jb.x && jb.dw && jb.M > 0 && jb.N > 0 && jb.K > 0, MMAMD_E_BADARG, "gemm_tn_splitk_group: bad job %d", i);
-    MMAMD_CHECK_ARG(jb.K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_group: contraction length K=%d must be a multiple of 128", jb.K);
-    MMAMD_CHECK_ARG(jb.M % 8 == 0 && jb.N % 8 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_group: M=%d and N=%d must be multiples of 8", jb.M, jb.N);
-    MMAMD_CHECK_ARG(jb.lddy >= jb.M && jb.ldx >= jb.N && jb.lddy % 8 == 0 && jb.ldx % 8 == 0, MMAMD_E_BADARG, "gemm_tn_splitk_group: bad leading dimension");
-    MMAMD_CHECK_ARG(aligned16(jb.dy) && aligned16(jb.x) && aligned16(jb.dw) && aligned16(ws), MMAMD_E_ALIGN, "gemm_tn_splitk_group: base pointers must be 16-byte aligned");
-    MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)jb.lddy * 2u < (1ull << 32) && (uint64_t)64 * (uint64_t)jb.ldx * 2u < (1ull << 32), MMAMD_E_UNSUPPORTED,
-                    "gemm_tn_splitk_group: leading dimension too large for the 32-bit DMA offsets");
+    if (int rc = tn_splitk_check("gemm_tn_splitk_group", jb.dy, jb.lddy, jb.x, jb.ldx, jb.dw, ws, jb.M, jb.N, jb.K)) return rc;
     int chunk;
     const int nsplit = tn_group_nsplit(jb.K, splits, &chunk);
     GemmArgs& p = g.p[i];
@@ -2170,13 +2179,8 @@ extern "C" int mmamd_gemm_bf16_splitk(const void* A, int lda, const void* W, int
 
 extern "C" int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, int ldw, float* C, float* ws, int M, int N, int K,
                                          int splits, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(A && W && C && ws && M > 0 && N > 0 && K > 0 && splits >= 1, MMAMD_E_BADARG, "gemm_tn_splitk: bad argument");
-  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk: contraction length K=%d must be a multiple of 128", K);
-  MMAMD_CHECK_ARG(M % 8 == 0 && N % 8 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk: M=%d and N=%d must be multiples of 8", M, N);
-  MMAMD_CHECK_ARG(lda >= M && ldw >= N && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "gemm_tn_splitk: bad leading dimension");
-  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws), MMAMD_E_ALIGN, "gemm_tn_splitk: base pointers must be 16-byte aligned");
-  MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)lda * 2u < (1ull << 31) && (uint64_t)64 * (uint64_t)ldw * 2u < (1ull << 31), MMAMD_E_UNSUPPORTED,
-                  "gemm_tn_splitk: leading dimension too large for the 32-bit DMA offsets");
+  MMAMD_CHECK_ARG(ws && splits >= 1, MMAMD_E_BADARG, "gemm_tn_splitk: bad argument");
+  if (int rc = tn_splitk_check("gemm_tn_splitk", A, lda, W, ldw, C, ws, M, N, K)) return rc;
 #ifdef MMAMD_EXPERIMENTS  // fragment-read placement experiments of the TN main loop (mmamd_set_gemm_variant(40 .. 43))
   if (g_gemm_variant == 40) return gemm_splitk_impl<true, 0, 8, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);  // 2-D grid (split = blockIdx.y)
   if (g_gemm_variant == 41) return gemm_splitk_impl<true, 1, 8, false>(A, lda, W, ldw, C, ws, M, N, K, splits, stream);
@@ -2198,13 +2202,7 @@ extern "C" int mmamd_gemm_bf16_tn_splitk(const void* A, int lda, const void* W, 
 // also sum their A fragments (gemm_bf16_nt_kernel_p<.., CS = true>), the split partials of both results are summed by one reduce launch.
 extern "C" int mmamd_gemm_bf16_tn_splitk_colsum(const void* A, int lda, const void* W, int ldw, float* C, float* db, float* ws, int M, int N,
                                                 int K, int splits, mmamd_stream_t stream) {
-  MMAMD_CHECK_ARG(A && W && C && db && ws && M > 0 && N > 0 && K > 0 && splits >= 1, MMAMD_E_BADARG, "gemm_tn_splitk_colsum: bad argument");
-  MMAMD_CHECK_ARG(K % 128 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_colsum: contraction length K=%d must be a multiple of 128", K);
-  MMAMD_CHECK_ARG(M % 8 == 0 && N % 8 == 0, MMAMD_E_UNSUPPORTED, "gemm_tn_splitk_colsum: M=%d and N=%d must be multiples of 8", M, N);
-  MMAMD_CHECK_ARG(lda >= M && ldw >= N && lda % 8 == 0 && ldw % 8 == 0, MMAMD_E_BADARG, "gemm_tn_splitk_colsum: bad leading dimension");
-  MMAMD_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(ws) && aligned16(db), MMAMD_E_ALIGN,
-                  "gemm_tn_splitk_colsum: base pointers must be 16-byte aligned");
-  MMAMD_CHECK_ARG((uint64_t)64 * (uint64_t)lda * 2u < (1ull << 31) && (uint64_t)64 * (uint64_t)ldw * 2u < (1ull << 31), MMAMD_E_UNSUPPORTED,
-                  "gemm_tn_splitk_colsum: leading dimension too large for the 32-bit DMA offsets");
+  MMAMD_CHECK_ARG(db && ws && splits >= 1 && aligned16(db), MMAMD_E_BADARG, "gemm_tn_splitk_colsum: bad argument");
+  if (int rc = tn_splitk_check("gemm_tn_splitk_colsum", A, lda, W, ldw, C, ws, M, N, K)) return rc;
   return gemm_splitk_impl<true, 0, 8, true, true>(A, lda, W, ldw, C, ws, M, N, K, splits, stream, db);
 }

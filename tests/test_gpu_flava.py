@@ -362,7 +362,8 @@ def test_full_size_flava_b2_vs_reference_fixture(golden):
     z16 = golden("flava_full_b2_bf16.npz")
     print("reference's own bf16-CPU |d|:", {k: float(f"{float(z16['err_' + k]):.2e}") for k in rep if "err_" + k in z16})
     for k in ("proj_image", "proj_text", "image_cls", "text_cls", "image_pooler", "text_pooler"):
-        assert rep[k] <= float(z16["err_" + k]), (k, rep[k], float(z16["err_" + k]))
+        # (0.8 x the reference's own bf16 error: the regression bound of tests/test_gpu_headline_parity.py)
+        assert rep[k] <= 0.8 * float(z16["err_" + k]), (k, rep[k], float(z16["err_" + k]))
     assert rep["text_attn_row"] <= PROB_TOL
     assert abs(float(img.attentions[-1].double().sum()) - float(z["image_attn_last_sum"])) <= 1e-2  # 2*12*197 rows summing to 1
     assert abs(float(img.hidden_states[-1].double().mean()) - float(z["image_hidden_last_mean"])) <= 1e-3
