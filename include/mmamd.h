@@ -155,7 +155,7 @@ int mmamd_attention_x_bwd_head_mask(const void* q, int ldq, int64_t q_batch_stri
                                     int64_t hm_stride_k, mmamd_stream_t stream);
 /* mmamd_attention_x_fwd with the reference's `head_mask` (modules/layers/attention.py:190,236-237: `attn = attn * head_mask` after softmax and
  * dropout; what is returned as the attention weights and what multiplies V): fp32, any tensor that broadcasts to [b, h, q, k], given by its element
- * strides over those four dimensions (0 = broadcast).  Inference only. */
+ * strides over those four dimensions (0 = broadcast). */
 int mmamd_attention_x_fwd_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                     int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
                                     int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
@@ -179,6 +179,22 @@ int mmamd_attention_x_bwd_dropout(const void* q, int ldq, int64_t q_batch_stride
                           void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk, int H, int head_dim,
                           float scale, float drop_p, uint64_t seed,
                                   uint32_t site, mmamd_stream_t stream);
+
+/* Both at once -- training-time dropout on the probabilities AND the reference's head_mask (modules/layers/attention.py:232-237 applies F.dropout and
+ * then `attn = attn * head_mask`): P' = P keep / (1 - p) m.  Same conventions as the two pairs above. */
+int mmamd_attention_x_fwd_dropout_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                            int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                            int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
+                                            float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed,
+                                            uint32_t site, const float* head_mask, int64_t hm_stride_b, int64_t hm_stride_h,
+                                            int64_t hm_stride_q, int64_t hm_stride_k, mmamd_stream_t stream);
+int mmamd_attention_x_bwd_dropout_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                            int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                            int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo,
+                                            const float* lse, void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq, int Sk,
+                                            int H, int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site,
+                                            const float* head_mask, int64_t hm_stride_b, int64_t hm_stride_h, int64_t hm_stride_q,
+                                            int64_t hm_stride_k, mmamd_stream_t stream);
 
 /* mmamd_attention_fwd that also saves the log2-domain log-sum-exp [B,H,S] (fp32) of the scaled scores for mmamd_attention_bwd. */
 int mmamd_attention_fwd_lse(const void* qkv, void* out, float* lse, int B, int S, int H, int causal, float scale,

@@ -99,6 +99,10 @@ PROTOTYPES = {
                                             C.c_uint64, C.c_uint32, _vp]),
     "mmamd_attention_x_bwd_dropout": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
                                             _i, _i, _i, _f, _f, C.c_uint64, C.c_uint32, _vp]),
+    "mmamd_attention_x_fwd_dropout_head_mask": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f,
+                                                      C.c_uint64, C.c_uint32, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "mmamd_attention_x_bwd_dropout_head_mask": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i,
+                                                      _i, _i, _i, _i, _f, _f, C.c_uint64, C.c_uint32, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mmamd_attention_x_bwd": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
                                     _i, _i, _i, _f, _vp]),
     "mmamd_attention_x_bwd_head_mask": (_i, [_vp, _i, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
@@ -167,6 +171,8 @@ def lib() -> C.CDLL:
         try:
             fn = getattr(handle, name)
         except AttributeError as e:
+            if os.environ.get("MMAMD_LIB_ALLOW_MISSING") == "1":  # A/B tools against an OLDER build (MMAMD_LIB=...): entries it lacks stay unbound
+                continue
             raise MmamdError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args

@@ -2099,6 +2099,20 @@ extern "C" int mmamd_attention_x_fwd_dropout(const void* q, int ldq, int64_t q_b
                               ldo, probs, probs_dtype, lse, B, Sq, Sk, H, head_dim, scale, drop_p, seed, site, stream);
 }
 
+extern "C" int mmamd_attention_x_fwd_dropout_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                                       int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                                       int64_t full_mask_batch_stride, int causal, void* out, int ldo, void* probs, int probs_dtype,
+                                                       float* lse, int B, int Sq, int Sk, int H, int head_dim, float scale, float drop_p,
+                                                       uint64_t seed, uint32_t site, const float* head_mask, int64_t hm_stride_b,
+                                                       int64_t hm_stride_h, int64_t hm_stride_q, int64_t hm_stride_k, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, MMAMD_E_BADARG, "attention_x: dropout p = %g must be in [0, 1)", (double)drop_p);
+  MMAMD_CHECK_ARG(head_mask != nullptr && hm_stride_b >= 0 && hm_stride_h >= 0 && hm_stride_q >= 0 && hm_stride_k >= 0, MMAMD_E_BADARG,
+                  "attention_x: head_mask must be given with non-negative element strides");
+  const int64_t hms[4] = {hm_stride_b, hm_stride_h, hm_stride_q, hm_stride_k};
+  return attention_x_fwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              ldo, probs, probs_dtype, lse, B, Sq, Sk, H, head_dim, scale, drop_p, seed, site, stream, head_mask, hms);
+}
+
 static int attention_x_fwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                 int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
                                 int causal, void* out, int ldo, void* probs, int probs_dtype, float* lse, int B, int Sq, int Sk, int H,

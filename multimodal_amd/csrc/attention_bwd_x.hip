@@ -391,6 +391,21 @@ extern "C" int mmamd_attention_x_bwd_head_mask(const void* q, int ldq, int64_t q
                               dout, ldo, lse, dq, lddq, dk, dv, lddk, lddv, B, Sq, Sk, H, head_dim, scale, 0.f, 0, 0, stream, head_mask, hms);
 }
 
+extern "C" int mmamd_attention_x_bwd_dropout_head_mask(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
+                                                       int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask,
+                                                       int64_t full_mask_batch_stride, int causal, const void* out, const void* dout, int ldo,
+                                                       const float* lse, void* dq, int lddq, void* dk, void* dv, int lddk, int lddv, int B, int Sq,
+                                                       int Sk, int H, int head_dim, float scale, float drop_p, uint64_t seed, uint32_t site,
+                                                       const float* head_mask, int64_t hm_stride_b, int64_t hm_stride_h, int64_t hm_stride_q,
+                                                       int64_t hm_stride_k, mmamd_stream_t stream) {
+  MMAMD_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, MMAMD_E_BADARG, "attention_x_bwd: dropout p = %g must be in [0, 1)", (double)drop_p);
+  MMAMD_CHECK_ARG(head_mask != nullptr && hm_stride_b >= 0 && hm_stride_h >= 0 && hm_stride_q >= 0 && hm_stride_k >= 0, MMAMD_E_BADARG,
+                  "attention_x_bwd: head_mask must be given with non-negative element strides");
+  const int64_t hms[4] = {hm_stride_b, hm_stride_h, hm_stride_q, hm_stride_k};
+  return attention_x_bwd_impl(q, ldq, q_batch_stride, k, v, ldk, ldv, kv_batch_stride, key_mask, full_mask, full_mask_batch_stride, causal, out,
+                              dout, ldo, lse, dq, lddq, dk, dv, lddk, lddv, B, Sq, Sk, H, head_dim, scale, drop_p, seed, site, stream, head_mask, hms);
+}
+
 static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, const void* k, const void* v, int ldk, int ldv,
                                 int64_t kv_batch_stride, const uint8_t* key_mask, const uint8_t* full_mask, int64_t full_mask_batch_stride,
                                 int causal, const void* out, const void* dout, int ldo, const float* lse, void* dq, int lddq, void* dk, void* dv,
@@ -421,9 +436,9 @@ static int attention_x_bwd_impl(const void* q, int ldq, int64_t q_batch_stride, 
   p.drop.k0 = (uint32_t)seed; p.drop.k1 = (uint32_t)(seed >> 32); p.drop.site = site; p.drop.scale = 1.0f / (1.0f - drop_p);
   MMAMD_CHECK_ARG(lddk == lddv, MMAMD_E_BADARG, "attention_x_bwd: dk and dv must share their row pitch");
   hipStream_t st = (hipStream_t)stream;
-  if (head_mask != nullptr) {  // (with dropout as well: not built -- the forward refuses the combination too)
-    MMAMD_CHECK_ARG(p.drop.thresh == 0, MMAMD_E_UNSUPPORTED, "attention_x_bwd: head_mask together with dropout on the probabilities is not built");
+  if (head_mask != nullptr) {
     p.hmask = head_mask; p.hm_sb = hm_strides[0]; p.hm_sh = hm_strides[1]; p.hm_sq = hm_strides[2]; p.hm_sk = hm_strides[3];
+    if (p.drop.thresh != 0) return head_dim == 64 ? launch_x_bwd<64, true, true>(p, B, st) : launch_x_bwd<96, true, true>(p, B, st);  // r06: both
     return head_dim == 64 ? launch_x_bwd<64, false, true>(p, B, st) : launch_x_bwd<96, false, true>(p, B, st);
   }
   if (p.drop.thresh != 0) return head_dim == 64 ? launch_x_bwd<64, true>(p, B, st) : launch_x_bwd<96, true>(p, B, st);

@@ -310,9 +310,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[ni][mi][r];
-          acc[ni][mi][r] = quick_gelu(v);
+        for (int r = 0; r < 16; r += 2) {  // (pairs: v_pk_mul / v_pk_add issue, bit-identical to quick_gelu() per value)
+          const f32x2 qg = quick_gelu2(f32x2{acc[ni][mi][r], acc[ni][mi][r + 1]});
+          acc[ni][mi][r] = qg[0]; acc[ni][mi][r + 1] = qg[1];
         }
   }
   // erf-GELU is applied where the values are packed for the strip (32x32 at a time): as one pass over all 256

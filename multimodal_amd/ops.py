@@ -474,7 +474,7 @@ def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, S
     every sample), k / v: bf16 [B*Sk, >=H*hd]; all may be column-slice views of wider matrices (stride(0) is the row
     pitch).  Returns (bf16 [B*Sq, H*hd], probabilities fp32 [B,H,Sq,Sk] or None).  drop = (p, seed, site): training-time dropout on the
     probabilities (mmamd_attention_x_fwd_dropout; the returned probabilities are then the dropped ones).  head_mask: fp32, broadcastable to
-    [B, H, Sq, Sk], multiplied into the probabilities after the softmax (the reference's head_mask; inference only)."""
+    [B, H, Sq, Sk], multiplied into the probabilities after the softmax and the dropout (the reference's head_mask)."""
     _mat_view(q, "q"); _mat_view(k, "k"); _mat_view(v, "v")
     D = H * head_dim
     if q.shape[1] != D or k.shape[1] != D or v.shape[1] != D:
@@ -499,14 +499,17 @@ def attention_x_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, S
             Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, mask.causal_flags, out.data_ptr(), out.stride(0), _ptr(probs), F32, _ptr(lse), B, Sq, Sk, H,
             head_dim, 1.0 / math.sqrt(float(head_dim)))
     if head_mask is not None:
-        if drop is not None and drop[0] > 0:
-            raise MmamdError("attention_x: head_mask with training-time dropout is not implemented")
         _chk(head_mask, "head_mask", torch.float32)
         try:
             hm = head_mask.expand(B, H, Sq, Sk)  # (a view: broadcast dimensions get stride 0)
         except RuntimeError as e:
             raise MmamdError(f"attention_x: head_mask of shape {tuple(head_mask.shape)} does not broadcast to {(B, H, Sq, Sk)}") from e
-        check(_lib.lib().mmamd_attention_x_fwd_head_mask(*args, hm.data_ptr(), *[int(x) for x in hm.stride()], _stream()), "mmamd_attention_x_fwd_head_mask")
+        if drop is not None and drop[0] > 0:  # the reference applies both (modules/layers/attention.py:232-237)
+            check(_lib.lib().mmamd_attention_x_fwd_dropout_head_mask(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF,
+                                                                     hm.data_ptr(), *[int(x) for x in hm.stride()], _stream()),
+                  "mmamd_attention_x_fwd_dropout_head_mask")
+        else:
+            check(_lib.lib().mmamd_attention_x_fwd_head_mask(*args, hm.data_ptr(), *[int(x) for x in hm.stride()], _stream()), "mmamd_attention_x_fwd_head_mask")
         return out, probs
     if drop is not None and drop[0] > 0:
         check(_lib.lib().mmamd_attention_x_fwd_dropout(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF, _stream()),
@@ -572,11 +575,14 @@ def attention_x_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torc
             Sk * k.stride(0), _ptr(km), _ptr(fm), fm_bs, mask.causal_flags, out.data_ptr(), dout.data_ptr(), out.stride(0), lse.data_ptr(),
             dq.data_ptr(), D, dkv.data_ptr(), dkv.data_ptr() + 2 * D, 2 * D, 2 * D, B, Sq, Sk, H, head_dim, 1.0 / math.sqrt(float(head_dim)))
     if head_mask is not None:
-        if drop is not None and drop[0] > 0:
-            raise MmamdError("attention_x_bwd: head_mask with training-time dropout is not implemented")
         _chk(head_mask, "head_mask", torch.float32)
         hm = head_mask.expand(B, H, Sq, Sk)  # (a view: broadcast dimensions get stride 0)
-        check(_lib.lib().mmamd_attention_x_bwd_head_mask(*args, hm.data_ptr(), *[int(x) for x in hm.stride()], _stream()), "mmamd_attention_x_bwd_head_mask")
+        if drop is not None and drop[0] > 0:
+            check(_lib.lib().mmamd_attention_x_bwd_dropout_head_mask(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF,
+                                                                     hm.data_ptr(), *[int(x) for x in hm.stride()], _stream()),
+                  "mmamd_attention_x_bwd_dropout_head_mask")
+        else:
+            check(_lib.lib().mmamd_attention_x_bwd_head_mask(*args, hm.data_ptr(), *[int(x) for x in hm.stride()], _stream()), "mmamd_attention_x_bwd_head_mask")
     elif drop is not None and drop[0] > 0:
         check(_lib.lib().mmamd_attention_x_bwd_dropout(*args, float(drop[0]), int(drop[1]) & 0xFFFFFFFFFFFFFFFF, int(drop[2]) & 0xFFFFFFFF, _stream()),
               "mmamd_attention_x_bwd_dropout")

@@ -235,9 +235,12 @@ def test_flava_training_forward_returns_attentions_and_hidden_states():
         set_schedule(train_attentions=prev.train_attentions)
 
 
-def test_attention_probability_dropout_kernels_vs_oracle():
+@pytest.mark.parametrize("hm_kind", ["none", "per_head", "full"])
+def test_attention_probability_dropout_kernels_vs_oracle(hm_kind):
     """mmamd_attention_x_fwd_dropout / _bwd_dropout: the returned (dropped) probabilities equal softmax * Philox mask / (1 - p) element for
-    element, O = P' V, and dQ / dK / dV equal torch autograd of the same expression with the same mask."""
+    element, O = P' V, and dQ / dK / dV equal torch autograd of the same expression with the same mask.  With a head_mask as well
+    (mmamd_attention_x_fwd/_bwd_dropout_head_mask, r06): P' = P keep / (1 - p) m, the order of the reference (modules/layers/attention.py:232-237:
+    F.dropout, then `attn = attn * head_mask`) -- a per-head [1, H, 1, 1] mask and a full [B, H, S, S] one."""
     from multimodal_amd import ops
 
     B, H, S, hd, p, seed, site = 2, 2, 40, 64, 0.2, 4242, 19
@@ -245,9 +248,11 @@ def test_attention_probability_dropout_kernels_vs_oracle():
     q, k, v = (torch.randn(B * S, H * hd).to(torch.bfloat16) for _ in range(3))
     km = torch.ones(B, S, dtype=torch.uint8)
     km[1, 33:] = 0
+    hmask = {"none": None, "per_head": torch.tensor([0.5, 1.5]).view(1, H, 1, 1), "full": torch.rand(B, H, S, S) * 2}[hm_kind]
+    hm_dev = hmask.cuda() if hmask is not None else None
     lse = torch.empty((B, H, S), dtype=torch.float32, device="cuda")
     out, probs = ops.attention_x_fwd(q.cuda(), k.cuda(), v.cuda(), B, S, S, H, hd, ops.AttnMask(key_mask=km.cuda()), want_probs=True, lse=lse,
-                                     drop=(p, seed, site))
+                                     drop=(p, seed, site), head_mask=hm_dev)
     keep = torch.from_numpy(dropout_layers.attention_mask_bhqk(B, H, S, S, p, seed, site))
     scale = float(np.float32(1) / (np.float32(1) - np.float32(p)))
 
@@ -256,6 +261,8 @@ def test_attention_probability_dropout_kernels_vs_oracle():
         s = (qh @ kh.transpose(-1, -2)) / 8.0
         s = s.masked_fill(km[:, None, None, :] == 0, float("-inf"))
         pr = torch.softmax(s, -1) * keep * scale
+        if hmask is not None:
+            pr = pr * hmask
         return pr, (pr @ vh).transpose(1, 2).reshape(B * S, H * hd)
 
     qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
@@ -266,7 +273,7 @@ def test_attention_probability_dropout_kernels_vs_oracle():
     do = torch.randn(B * S, H * hd).to(torch.bfloat16)
     o.backward(do.float())
     dq, dkv = ops.attention_x_bwd(q.cuda(), k.cuda(), v.cuda(), out, do.cuda(), lse, B, S, S, H, hd, ops.AttnMask(key_mask=km.cuda()),
-                                  drop=(p, seed, site))
+                                  drop=(p, seed, site), head_mask=hm_dev)
     D = H * hd
     for got, want, name in ((dq, qf.grad, "dq"), (dkv[:, :D], kf.grad, "dk"), (dkv[:, D:], vf.grad, "dv")):
         err = float((got.float().cpu() - want).abs().max())
@@ -309,6 +316,46 @@ def test_flava_encoder_with_dropout_on_every_site():
         for got, want, name in ((gq, layers[li]["Wqkv"].grad, "Wqkv"), (layer.attention.output.weight.grad.cpu(), layers[li]["Wo"].grad, "Wo"),
                                 (layer.feedforward.model[0].weight.grad.cpu(), layers[li]["W1"].grad, "W1")):
             assert float((got - want).abs().max()) < 6e-2 * float(want.abs().max()) + 1e-6, (li, name)
+
+
+def test_flava_encoder_head_mask_with_dropout_trains():
+    """head_mask TOGETHER with attention dropout in training (raised until r06; the reference applies F.dropout and then `attn * head_mask`,
+    modules/layers/attention.py:232-237).  Module level: (a) an all-ones head_mask is the identity -- the step equals the one without a mask under the
+    same seed, output and every gradient bit for bit (x 1.0 is exact; the kernels regenerate the same Philox masks); (b) zeroing head 0 of every layer
+    equals zeroing the corresponding 64 input columns of each layer's output projection."""
+    from multimodal_amd.models.flava.transformer import TransformerEncoder
+
+    p, d, H, B, S = 0.2, 128, 2, 3, 40
+    torch.manual_seed(7)
+    enc = TransformerEncoder(2, d, H, 256, dropout=p, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True).cuda().train()
+    x, gout = torch.randn(B, S, d).cuda(), torch.randn(B, S, d).cuda()
+
+    def step(head_mask):
+        enc.zero_grad(set_to_none=True)
+        torch.manual_seed(99)  # the stack draws its Philox seed from torch's generator
+        xg = x.clone().requires_grad_(True)
+        out = enc(xg, head_mask=head_mask, return_hidden_states=True).last_hidden_state
+        out.backward(gout)
+        return out.detach().clone(), xg.grad.clone(), {n: q.grad.clone() for n, q in enc.named_parameters()}
+
+    o0, gx0, gp0 = step(None)
+    o1, gx1, gp1 = step(torch.ones(1, H, 1, 1, device="cuda"))
+    assert torch.equal(o0, o1) and torch.equal(gx0, gx1)
+    assert all(torch.equal(gp0[n], gp1[n]) for n in gp0)
+    hm = torch.ones(1, H, 1, 1, device="cuda")
+    hm[0, 0] = 0.0
+    o2, gx2, _ = step(hm)
+    saved = [layer.attention.output.weight.detach().clone() for layer in enc.layer]
+    with torch.no_grad():
+        for layer in enc.layer:
+            layer.attention.output.weight[:, :64] = 0.0  # head 0's slice of the merged heads
+    o3, gx3, _ = step(None)
+    with torch.no_grad():
+        for layer, w in zip(enc.layer, saved):
+            layer.attention.output.weight.copy_(w)
+    assert float((o2 - o3).abs().max()) <= 2e-2 * float(o3.abs().max())
+    assert float((gx2 - gx3).abs().max()) <= 5e-2 * float(gx3.abs().max())
+    assert float((o2 - o0).abs().max()) > 1e-2 * float(o0.abs().max())  # (the mask did something)
 
 
 def test_decoder_stack_trains_with_dropout():

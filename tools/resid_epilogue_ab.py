@@ -99,6 +99,7 @@ def main():
             env.pop("MMAMD_AB_STAGGER", None)
             if lib:
                 env["MMAMD_LIB"] = lib
+                env["MMAMD_LIB_ALLOW_MISSING"] = "1"
             if stg:
                 env["MMAMD_AB_STAGGER"] = stg
             p = subprocess.run([sys.executable, __file__, "--child", "--batch", str(a.batch)], env=env, capture_output=True, text=True, timeout=900)
