@@ -593,6 +593,19 @@ class L2NormalizeFn(torch.autograd.Function):
         return l2norm_bwd_op(x, dy.contiguous())
 
 
+def bias_or_zeros(linear) -> "torch.Tensor":
+    """A Linear's bias, or -- for the reference's `add_bias=False` attention projections (modules/layers/multi_head_attention.py:107-113,
+    modules/layers/attention.py:100-113) -- a cached fp32 zero vector that requires no grad: the training kernels add it (exactly nothing) and the
+    gradient the backward returns for it is dropped by autograd.  A plain attribute, not a buffer: state_dict stays the reference's."""
+    if linear.bias is not None:
+        return linear.bias
+    z = getattr(linear, "_mmamd_zero_bias", None)
+    if z is None or z.device != linear.weight.device or z.shape[0] != linear.out_features:
+        z = torch.zeros(linear.out_features, dtype=torch.float32, device=linear.weight.device)
+        object.__setattr__(linear, "_mmamd_zero_bias", z)
+    return z
+
+
 def plain_layers(layers, cls) -> bool:
     """True when every member of a layer stack is EXACTLY `cls` and carries no hooks: the stack may then read the layers' parameters
     directly (one autograd node, grouped launches, in-place residual streams for the whole stack).  Anything else -- a layer wrapped by

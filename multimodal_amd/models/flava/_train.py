@@ -13,7 +13,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import ops
-from ..._autograd import EncoderStackFn, StackConfig, c32, dgrad, stack_drop_spec, wgrad
+from ..._autograd import EncoderStackFn, StackConfig, bias_or_zeros, c32, dgrad, stack_drop_spec, wgrad
 
 bf, f32 = torch.bfloat16, torch.float32
 
@@ -206,7 +206,7 @@ def run_layers(layers, training: bool, x: Tensor, key_mask: Optional[Tensor], ke
         if act != steps[0][1]:
             raise ops.MmamdError("training: all layers of a stack must use the same activation")
         at = layer.attention
-        params += [at.query.weight, at.query.bias, at.key.weight, at.key.bias, at.value.weight, at.value.bias, at.output.weight,
+        params += [at.query.weight, bias_or_zeros(at.query), at.key.weight, bias_or_zeros(at.key), at.value.weight, bias_or_zeros(at.value), at.output.weight,
                    at.output.bias, steps[0][0].weight, steps[0][0].bias, steps[1][0].weight, steps[1][0].bias,
                    layer.attention_layernorm.weight, layer.attention_layernorm.bias, layer.feedforward_layernorm.weight,
                    layer.feedforward_layernorm.bias]

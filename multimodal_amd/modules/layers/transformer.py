@@ -513,6 +513,7 @@ def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, 
                                   return_hidden_states: bool, cross_attention_mask: Optional[Tensor] = None) -> TransformerOutput:
     """Differentiable forward of a list of TransformerDecoderLayers (a whole TransformerDecoder, or ONE stand-alone / wrapped layer)."""
     from ..._autograd import DecoderStackConfig, DecoderStackFn, draw_seed
+    from ..._autograd import bias_or_zeros as _bias_or_zeros
 
     B, S, d = hidden_states.shape
     mask = to_attn_mask(attention_mask, False, B, S, S)
@@ -532,15 +533,14 @@ def _decoder_layers_forward_train(dec_layers, training: bool, final_layer_norm, 
             raise ops.MmamdError("training: the feed-forward block must be Linear -> GELU/QuickGELU -> Linear")
         has_cross = bool(layer.use_cross_attention and encoder_hidden_states is not None)
         at = layer.attention
-        if at.q_proj.bias is None:
-            raise ops.MmamdError("training on the MI355X path: attention projections without bias are not implemented")
-        params += [at.q_proj.weight, at.q_proj.bias, at.k_proj.weight, at.k_proj.bias, at.v_proj.weight, at.v_proj.bias,
+        bz = _bias_or_zeros  # (add_bias=False projections: a zero vector without grad stands in for the missing bias)
+        params += [at.q_proj.weight, bz(at.q_proj), at.k_proj.weight, bz(at.k_proj), at.v_proj.weight, bz(at.v_proj),
                    at.output_proj.weight, at.output_proj.bias, layer.attention_layernorm.weight, layer.attention_layernorm.bias]
         spec = {"n_head": at.num_heads, "eps1": layer.attention_layernorm.eps, "eps2": layer.feedforward_layernorm.eps, "act": steps[0][1],
                 "has_cross": has_cross, "post": not layer.norm_first}  # post-norm: the reference's default (transformer.py:289,435-470)
         if has_cross:
             ca = layer.cross_attention
-            params += [ca.q_proj.weight, ca.q_proj.bias, ca.k_proj.weight, ca.k_proj.bias, ca.v_proj.weight, ca.v_proj.bias,
+            params += [ca.q_proj.weight, bz(ca.q_proj), ca.k_proj.weight, bz(ca.k_proj), ca.v_proj.weight, bz(ca.v_proj),
                        ca.output_proj.weight, ca.output_proj.bias, layer.cross_attention_layernorm.weight, layer.cross_attention_layernorm.bias]
             spec["epsc"] = layer.cross_attention_layernorm.eps
         params += [steps[0][0].weight, steps[0][0].bias, steps[1][0].weight, steps[1][0].bias, layer.feedforward_layernorm.weight,

@@ -344,3 +344,36 @@ def test_stand_alone_decoder_layer_with_cross_attention_mask_trains_like_the_ref
         with torch.no_grad():
             y_inf, _ = layer(x.detach(), enc.detach(), attention_mask=causal, cross_attention_mask=xmask)
         assert (y_inf - y.detach()).abs().max().item() <= 2e-2 * max(1.0, float(y.detach().abs().max()))
+
+
+def test_bias_free_attention_projections_train_like_the_reference(golden):
+    """`add_bias=False` attention projections in training (raised until r06; reference modules/layers/multi_head_attention.py:107-113 and
+    modules/layers/attention.py:100-113): a TransformerDecoderLayer whose self- and cross-attention are MultiHeadAttentionWithCache(add_bias=False)
+    (post-norm, causal mask, 64-wide memory) and a FLAVA TransformerEncoderLayer with a bias-free MultiHeadAttention -- output, input gradients and every
+    parameter gradient against the reference's autograd (tests/golden/make_golden_nobias_grad.py -> nobias_grad.npz)."""
+    from multimodal_amd.models.flava.transformer import TransformerEncoderLayer as FlavaLayer
+    from multimodal_amd.modules.layers.attention import MultiHeadAttention, SelfAttention
+    from multimodal_amd.modules.layers.multi_head_attention import MultiHeadAttentionWithCache
+    from multimodal_amd.modules.layers.transformer import TransformerDecoderLayer
+
+    z = golden("nobias_grad.npz")
+    dec = TransformerDecoderLayer(d_model=128, n_head=2, dim_feedforward=256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=False,
+                                  use_cross_attention=True, dim_kv=64)
+    dec.attention = MultiHeadAttentionWithCache(dim_q=128, dim_kv=128, num_heads=2, add_bias=False)
+    dec.cross_attention = MultiHeadAttentionWithCache(dim_q=128, dim_kv=64, num_heads=2, add_bias=False)
+    dec = _load(dec, z, "dec")
+    assert dec.attention.q_proj.bias is None and "attention.q_proj.bias" not in dec.state_dict()
+    x = torch.from_numpy(z["dec.x"]).cuda().requires_grad_(True)
+    enc = torch.from_numpy(z["dec.enc"]).cuda().requires_grad_(True)
+    y, _ = dec(x, enc, attention_mask=torch.ones(9, 9, dtype=torch.bool).tril().cuda())
+    (y * torch.from_numpy(z["dec.w"]).cuda()).sum().backward()
+    _check(z, "dec", dec, y, x)
+    ref = z["dec.denc"].astype(np.float64)
+    assert np.abs(host(enc.grad) - ref).max() <= 6e-2 * np.abs(ref).max()
+
+    fl = FlavaLayer(d_model=128, n_head=2, dim_feedforward=256, activation=torch.nn.GELU, layer_norm_eps=1e-5, norm_first=True)
+    fl.attention = MultiHeadAttention(dim_q=128, dim_kv=128, n_head=2, attn_module=SelfAttention(0.0), add_bias=False)
+    fl = _load(fl, z, "flava")
+    assert fl.attention.query.bias is None
+    y, x = _step(fl, z, "flava", lambda m, t: m(t))
+    _check(z, "flava", fl, y, x)
