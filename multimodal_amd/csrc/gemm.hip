@@ -135,24 +135,46 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
 // far below the bf16 rounding of the value that is stored.  Branch-free.
 __device__ __forceinline__ float gelu_erf(float v) { return gelu_erf2(f32x2{v, v})[0]; }
 
-// d/du [u sigmoid(1.702 u)] and d/du [u Phi(u)]: the factor the MLP's backward multiplies the incoming gradient with
-__device__ __forceinline__ float act_grad(float u, int mode) {
-  if (mode == 1) {
-    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * u));
-    return sg * (1.0f + 1.702f * u * (1.0f - sg));
-  }
-  const float x = fabsf(u) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);  // exp(-u^2/2)
-  const float tail = 0.5f * (poly * t) * ex;                               // 0.5 (1 - erf|x|)
-  const float cdf = u >= 0.f ? 1.0f - tail : tail;
-  return cdf + u * 0.3989422804014327f * ex;
+// d/du [u sigmoid(1.702 u)] and d/du [u Phi(u)]: the factor the MLP's backward multiplies the incoming gradient with -- two values at a time (r06: packed
+// multiplies / adds / fmas like the forward activations above; the per-value form below is the same operation sequence)
+__device__ __forceinline__ f32x2 act_grad2_quick(f32x2 u) {
+  const f32x2 z = u * (-1.702f * 1.4426950408889634f);
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + 1.0f;
+  const f32x2 sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2 w = (u * 1.702f) * (f32x2{1.0f, 1.0f} - sg);
+  return __builtin_elementwise_fma(sg, w, sg);  // sg (1 + 1.702 u (1 - sg))
 }
+__device__ __forceinline__ f32x2 act_grad2_erf(f32x2 u) {
+  const f32x2 ax = __builtin_elementwise_abs(u);
+  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f}, f32x2{1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 poly = __builtin_elementwise_fma(f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, t, f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+  const f32x2 z = (u * (-0.5f * 1.4426950408889634f)) * u;
+  const f32x2 ex = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};  // exp(-u^2 / 2)
+  const f32x2 h = f32x2{0.5f, 0.5f} - (poly * t) * ex;                           // 0.5 - tail = 0.5 erf(|u| / sqrt 2)
+  const f32x2 cdf = f32x2{0.5f, 0.5f} + f32x2{__builtin_copysignf(h[0], u[0]), __builtin_copysignf(h[1], u[1])};  // Phi(u), no compare / select
+  return __builtin_elementwise_fma(u * 0.3989422804014327f, ex, cdf);            // Phi(u) + u phi(u)
+}
+__device__ __forceinline__ float act_grad(float u, int mode) { return mode == 1 ? act_grad2_quick(f32x2{u, u})[0] : act_grad2_erf(f32x2{u, u})[0]; }
 __device__ __forceinline__ float combine_res(float v, float r, int mode) { return mode == 0 ? v + r : v * act_grad(r, mode); }
+// 8 bf16 results x their 8 bf16 residual values (mode 0: +; 1 / 2: x QuickGELU' / GELU' of the saved pre-activation), the mode switch hoisted (wave-uniform)
+__device__ __forceinline__ bf16x8 combine_res8(bf16x8 a8, bf16x8 r8, int mode) {
+  if (mode == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a8[j] = (bf16)((float)a8[j] + (float)r8[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 r = {(float)r8[j], (float)r8[j + 1]};
+      const f32x2 o = f32x2{(float)a8[j], (float)a8[j + 1]} * (mode == 1 ? act_grad2_quick(r) : act_grad2_erf(r));
+      a8[j] = (bf16)o[0]; a8[j + 1] = (bf16)o[1];
+    }
+  }
+  return a8;
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == MMAMD_ACT_QUICKGELU) return quick_gelu(v);
@@ -164,8 +186,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 __device__ __forceinline__ void store_act_copy(const GemmArgs& p, uint4 v, int m, int n) {
   if (p.C2 == nullptr) return;  // wave-uniform
   bf16x8 a8 = __builtin_bit_cast(bf16x8, v);
+  if (p.act2 != MMAMD_ACT_NONE) {  // (wave-uniform; pairs: packed issue, the same values as apply_act per element)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) a8[j] = (bf16)apply_act((float)a8[j], p.act2);
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 in = {(float)a8[j], (float)a8[j + 1]};
+      const f32x2 o = p.act2 == MMAMD_ACT_QUICKGELU ? quick_gelu2(in) : gelu_erf2(in);
+      a8[j] = (bf16)o[0]; a8[j + 1] = (bf16)o[1];
+    }
+  }
   *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C2) + (size_t)m * p.ldc2 + n) = __builtin_bit_cast(uint4, a8);
 }
 
@@ -398,8 +426,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
           if (p.R != nullptr) {
             const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
             bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a8[j] = (bf16)combine_res((float)a8[j], (float)r8[j], p.res_mode);
+            a8 = combine_res8(a8, r8, p.res_mode);
             v = __builtin_bit_cast(uint4, a8);
           }
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = v;
@@ -1158,8 +1185,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
               if (p.R != nullptr) {
                 const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
                 bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] = (bf16)combine_res((float)a8[j], (float)r8[j], p.res_mode);
+                a8 = combine_res8(a8, r8, p.res_mode);
                 v = __builtin_bit_cast(uint4, a8);
               }
               store16<STP>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v);
