@@ -493,9 +493,9 @@ def main() -> None:
             except Exception:
                 traffic = None
         # MEASURED clocks (r05): amdsmi telemetry of 5-s loops of these very launches (socket power / gfxclk at 20 Hz; 1400 W cap) -- a stored figure from
-        # profiles/r05_power_clocks_summary.json, not this run.  `frac` stays against the nominal 2.4 GHz peak; `frac_at_measured_clock` is against what
+        # profiles/r06_power_clocks_summary.json, not this run.  `frac` stays against the nominal 2.4 GHz peak; `frac_at_measured_clock` is against what
         # the clock the chip sustains under that kernel allows.  (Until r04 this field was derived from GRBM_GUI_ACTIVE, which misreads short kernels.)
-        tele = ROOT / "profiles" / "r05_power_clocks_summary.json"
+        tele = ROOT / "profiles" / "r06_power_clocks_summary.json"
         if tele.exists():
             try:
                 tk = json.loads(tele.read_text())["kernels"]
@@ -503,7 +503,7 @@ def main() -> None:
                     if name in tk:
                         mhz = tk[name]["gfxclk_mhz"]
                         by_shape[name]["telemetry"] = {"gfxclk_mhz": mhz, "socket_power_w": tk[name]["socket_power_w"], "power_cap_w": 1400,
-                                                       "source": "profiles/r05_power_clocks.json (stored; amdsmi at 20 Hz over 5-s loops of this launch)"}
+                                                       "source": "profiles/r06_power_clocks.json (stored; amdsmi at 20 Hz over 5-s loops of this launch)"}
                         by_shape[name]["frac_at_measured_clock"] = round(by_shape[name]["achieved"] / (MFMA_BF16_PEAK_TFLOPS * mhz / 2400.0), 4)
             except Exception:
                 pass

@@ -2,7 +2,7 @@
 # PMC of the fp32-residual grouped GEMM gemm_bf16_nt_kernel_ppg<true,0,8> (37.5 % of the r03 step; never looked at with counters before r04), both shapes it
 # runs in the step: out-projection (ViT [50432 x 768 x 768] + text [19712 x 512 x 512]) and MLP-down (ViT [50432 x 768 x 3072] + text [19712 x 512 x 2048]),
 # + bias + fp32 residual read-modify-write.  FETCH_SIZE and WRITE_SIZE need separate passes (TCC: 4 slots, they cost 3 + 2).
-# Writes gpurun_out/r04_pmc_residual_kernel.json (+ .txt)
+# Writes gpurun_out/pmc_residual_kernel.json
 export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 rm -rf /tmp/pmc_res
 for shape in "outproj 768 768 512 512" "mlpdown 768 3072 512 2048"; do
@@ -45,11 +45,11 @@ for name, probs in shapes.items():
                  "active_inst_frac": m.get("SQ_ACTIVE_INST_ANY", 0) / m["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in m else None,
                  "lds_bank_conflict_frac": m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_LDS_IDX_ACTIVE"] if m.get("SQ_LDS_IDX_ACTIVE") else None,
                  "raw": m}
-out = {"kernel": "gemm_bf16_nt_kernel_ppg<true,0,8>: grouped out-projection / MLP-down of both towers, + bias + fp32 residual read-modify-write (r04)",
+out = {"kernel": "gemm_bf16_nt_kernel_ppg<true,0>: grouped out-projection / MLP-down of both towers, + bias + fp32 residual read-modify-write (pipelined buffer-descriptor epilogue, r06)",
        "source": "tools/gpu_pmc_residual.sh (rocprofv3 --pmc, one counter group per run, mean over 8 dispatches; isolated launches on random operands)",
        "correction": "gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE as reported",
        "shapes": res}
-json.dump(out, open("gpurun_out/r04_pmc_residual_kernel.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/pmc_residual_kernel.json", "w"), indent=1)
 for k, v in res.items():
     print(k, json.dumps({a: b for a, b in v.items() if a != "raw"}))
 PY
