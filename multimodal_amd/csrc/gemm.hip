@@ -89,6 +89,7 @@ struct GemmArgs {
   int i2c_ltpc = 0;  // log2(K-tiles per channel) = log2(p*p / 64)
   int i2c_rpk = 0;   // image rows per K-tile = 64 / p
   int gm = 0;        // persistent kernel: tile-order group at run time (0 = the kernel's template value); pick_gm()
+  int cn = 0;        // persistent kernel: column tiles per column CHUNK (0 = all of them): chunks are the OUTERMOST level of the tile order; pick_cn()
   // BDIR kernels: W in MFMA-fragment order (mmamd_pack_w_frag): block (nb = n / 32, ks = k / 16) = 64 lanes x 16 B, lane (l31, half) holds
   // W[32 nb + l31][16 ks + 8 half .. + 7] -- the first operand of v_mfma_f32_32x32x16_bf16 as one coalesced 1 KiB buffer load, no LDS
   const bf16* Wp = nullptr;
@@ -231,6 +232,25 @@ static int g_gemm_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // (step 13.39 ms with the r03 value 8, 13.30 with row-major order for N <= 1024 only, 13.25 with 2 everywhere): with few row panels per group
 // the column tiles of a panel run at the same time, in lock-step, and every K-slice of the panel is fetched into the XCD's L2 once -- MLP-down
 // (3 column tiles, a 1.5 MiB panel per 256 rows that no cache level keeps between rounds) 311 -> 301 us, the vision out-projection alone 93.6 -> 86.5 us.
+// Column chunking of the tile order (r06).  The W operand of a wide GEMM does not fit an XCD's 4 MiB L2 (MLP-up: 3072 x 768 bf16 = 4.7 MB), so with all
+// column tiles in one group every `gm` row panels re-stream the whole of W through the L2 (MLP-up: 463 MB of W fetches against 104 MB of algorithmic
+// reads -- the 1.84 x over-fetch of profiles/r04_pmc_mlp_up_kernel.json).  With the column tiles cut into chunks whose W slice (cn x 256 x K bf16) fits
+// beside the A panels in flight, and the chunk as the OUTERMOST level of the tile list, an XCD's contiguous slice of the list lies inside one chunk (or
+// two, one after the other): its W slice stays resident for the whole launch and the A panels are read once per chunk.  Bytes are energy, and the step is
+// energy-limited.  Tile arithmetic does not depend on the order: bit-identical.
+static int pick_cn(int tiles_n, int K) {
+  if (g_gemm_knob[4] != 0) return g_gemm_knob[4] < 0 ? tiles_n : g_gemm_knob[4];  // mmamd_debug_set_gemm_knob(4, cn): A/B (-1 = no chunking)
+  const long long w_bytes = (long long)tiles_n * 256 * K * 2;
+  // W fits: one chunk.  Few column tiles (MLP-down: 3 tiles of a 1.5 MB W slice each, K = 3072): no chunking either -- there the concurrent column tiles
+  // of a row panel walk K in lock-step and SHARE the A panel's K-slices; cutting them apart re-reads the 310 MB A operand once per chunk (measured
+  // r06: the step +0.33 ms with one-tile chunks on that launch)
+  if (w_bytes <= 3ll << 20 || tiles_n <= 6) return tiles_n;
+  const long long per_tile = 256ll * K * 2;
+  int cn = (int)((5ll << 19) / per_tile);                // chunks of <= 2.5 MiB of W
+  if (cn < 1) cn = 1;
+  const int nchunk = (tiles_n + cn - 1) / cn;
+  return (tiles_n + nchunk - 1) / nchunk;                // equal-width chunks (the last one may be one tile narrower)
+}
 static int pick_gm(int tiles_n, int cus) {
   if (g_gemm_knob[0] != 0) return g_gemm_knob[0];
   (void)cus;
@@ -684,15 +704,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   const int l31 = lane & 31, half = lane >> 5;
 
   const int GMr = p.gm > 0 ? p.gm : GM;  // (row-major, gm = 1, for few column tiles: see pick_gm)
+  const int CNr = p.cn > 0 && p.cn < p.tiles_n ? p.cn : p.tiles_n;  // column tiles per chunk (pick_cn); chunk = outermost level of the order
   auto tile_of = [&](int vb, int& tm, int& tn) __attribute__((always_inline)) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, loc = vb >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int per_group = GMr * p.tiles_n;
-    const int grp = id / per_group, within = id - grp * per_group;
+    const int full = tiles_m * CNr;                       // tiles of a full-width chunk
+    int ck = id / full;
+    const int nck = (p.tiles_n + CNr - 1) / CNr;
+    ck = ck < nck ? ck : nck - 1;
+    const int cw = (p.tiles_n - ck * CNr) < CNr ? (p.tiles_n - ck * CNr) : CNr;  // this chunk's width
+    const int idl = id - ck * full;
+    const int per_group = GMr * cw;
+    const int grp = idl / per_group, within = idl - grp * per_group;
     const int gm0 = grp * GMr;
     const int rows = (tiles_m - gm0) < GMr ? (tiles_m - gm0) : GMr;
-    tn = within / rows;
-    tm = gm0 + (within - tn * rows);
+    const int tnl = within / rows;
+    tn = ck * CNr + tnl;
+    tm = gm0 + (within - tnl * rows);
   };
 
   // DMA source offsets of this lane (see kernel above for the swizzle): depend on the tile, not on K
@@ -1236,6 +1264,7 @@ struct GemmGroupArgs {
   // into the XCD's L2 once -- what a GEMM with FEW column tiles and a LONG K wants (MLP-down: 3 column tiles, a 1.5 MiB panel per 256 rows
   // that no cache level keeps between rounds; r04: HBM bytes per launch 1254 -> ... MB, profiles/r04_pmc_residual_kernel.json)
   int gm[2];
+  int cn[2];  // column tiles per chunk, per problem (pick_cn): the chunk is the outermost level of each problem's tile order
 };
 
 template <bool OUT_F32, int ACT>
@@ -1286,14 +1315,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
       sel = l >= xc0 ? 1 : 0;
       id = sel ? xb1 + (l - xc0) : xb0 + l;
     }
-    const int tiles_m = g.prob[sel].tiles_m;
+    const int tiles_m = g.prob[sel].tiles_m, tiles_n = g.prob[sel].tiles_n;
     const int GM = g.gm[sel];
-    const int per_group = GM * g.prob[sel].tiles_n;
-    const int grp = id / per_group, within = id - grp * per_group;
+    const int CN = g.cn[sel];  // (1 <= CN <= tiles_n: launcher)
+    const int full = tiles_m * CN;
+    int ck = id / full;
+    const int nck = (tiles_n + CN - 1) / CN;
+    ck = ck < nck ? ck : nck - 1;
+    const int cw = (tiles_n - ck * CN) < CN ? (tiles_n - ck * CN) : CN;
+    const int idl = id - ck * full;
+    const int per_group = GM * cw;
+    const int grp = idl / per_group, within = idl - grp * per_group;
     const int gm0 = grp * GM;
     const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
-    tn = within / rows;
-    tm = gm0 + (within - tn * rows);
+    const int tnl = within / rows;
+    tn = ck * CN + tnl;
+    tm = gm0 + (within - tnl * rows);
   };
 
   // DMA source offsets of this lane (see kernel above for the swizzle): depend on the tile, not on K
@@ -1709,6 +1746,7 @@ static int launch_tiled_pp(GemmArgs& p, hipStream_t st) {
   const int cus = stream_cus(st);                   // 256, or the CU partition of a masked stream (multiple of 8: whole XCD slices)
   const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
   p.gm = pick_gm(p.tiles_n, cus);
+  p.cn = pick_cn(p.tiles_n, p.K);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), smem, st, p, tiles_m, ntiles);
   return launch_status("gemm_bf16_pp");
 }
@@ -1721,7 +1759,7 @@ static int launch_grouped(GemmGroupArgs& g, hipStream_t st) {
   if (int rc_attr = opt_in_lds(reinterpret_cast<const void*>(kern), smem, attr_mask)) return rc_attr;
   const int ntiles = g.tile_start[g.nprob];
   const int cus = stream_cus(st);
-  for (int i = 0; i < 2; ++i) g.gm[i] = pick_gm(g.prob[i].tiles_n, cus);
+  for (int i = 0; i < 2; ++i) { g.gm[i] = pick_gm(g.prob[i].tiles_n, cus); g.cn[i] = pick_cn(g.prob[i].tiles_n, g.prob[i].K); }
   const int grid = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, g);
   return launch_status("gemm_bf16_grouped");

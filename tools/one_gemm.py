@@ -18,6 +18,11 @@ w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
 bias = torch.randn(N, generator=g).to(dev)
 out = torch.zeros((M, N), dtype=torch.float32 if res else torch.bfloat16, device=dev)
 ops.set_gemm_variant(variant)
+import os  # noqa: E402
+if os.environ.get("MMAMD_GEMM_CN"):  # column tiles per chunk of the tile order (-1 = no chunking): PMC A/B of tools/gpu_pmc_cn.sh
+    from multimodal_amd import _lib
+
+    _lib.lib().mmamd_debug_set_gemm_knob(4, int(os.environ["MMAMD_GEMM_CN"]))
 if len(sys.argv) > 10:
     M2, N2, K2 = (int(x) for x in sys.argv[8:11])
     a2 = torch.randn(M2, K2, generator=g).to(dev).to(torch.bfloat16)

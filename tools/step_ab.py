@@ -5,7 +5,7 @@ ENQUEUE a step (is the Python thread the limit?), and a HIP-graph replay of the 
     python tools/step_ab.py --arms ring,r02attn [--rounds 3] [--steps 20]
 arms (joined with +): base, r02attn (register-staged attention kernel), streams,
 ln_cached (LayerNorm input loads never non-temporal), stagger<percent> (the delta_ln and phases2 arms of r03 / r04 were retired in r05),
-lead<n> (launches of half 0 before half 1 starts), slack<percent> (slack-aware start-up stagger of the grouped GEMM), gm<4|8> (its tile-order group)"""
+lead<n> (launches of half 0 before half 1 starts), slack<percent> (slack-aware start-up stagger of the grouped GEMM), gm<4|8> (its tile-order group), cn<k> (column tiles per chunk of the tile order; cn-1 = none)"""
 import argparse
 import json
 import sys
@@ -49,6 +49,7 @@ def main():
         L.mmamd_debug_set_gemm_stagger(60)
         L.mmamd_debug_set_gemm_knob(0, 0)
         L.mmamd_debug_set_gemm_knob(1, 0)
+        L.mmamd_debug_set_gemm_knob(4, 0)
         set_schedule(two_tower="auto")
         for part in name.split("+"):
             if part in ("ring", "base"):
@@ -63,6 +64,8 @@ def main():
                 L.mmamd_debug_set_gemm_knob(1, int(part[5:]))
             elif part.startswith("gm"):
                 L.mmamd_debug_set_gemm_knob(0, int(part[2:]))
+            elif part.startswith("cn"):  # column tiles per chunk of the persistent GEMMs' tile order (r06; cn-1 = no chunking, default = by W size)
+                L.mmamd_debug_set_gemm_knob(4, int(part[2:]))
             elif part == "ln_cached":  # LayerNorm input loads never non-temporal (the r02 behaviour)
                 L.mmamd_debug_set_attn_variant(3101)
             else:
