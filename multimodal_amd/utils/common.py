@@ -11,23 +11,26 @@ from torch import nn
 
 
 class ModelOutput(OrderedDict):
+    """Base of the dataclass outputs that must also read like a mapping (contract of the reference's utils/common.py:122-139): iteration and `keys()` give
+    the dataclass field names in declaration order, `values()` / `items()` / `out[name]` read the ATTRIBUTES -- the dict storage itself stays empty."""
+
+    def _field_names(self):
+        return [f.name for f in fields(self)]  # type: ignore[arg-type]
+
     def keys(self) -> Any:
-        for field in fields(self):  # type: ignore
-            yield field.name
+        return iter(self._field_names())
+
+    def __iter__(self) -> Any:
+        return self.keys()
 
     def __getitem__(self, key: Any) -> Any:
         return getattr(self, key)
 
-    def __iter__(self) -> Any:
-        yield from self.keys()
-
     def values(self) -> Any:
-        for field in fields(self):  # type: ignore
-            yield getattr(self, field.name)
+        return (getattr(self, name) for name in self._field_names())
 
     def items(self) -> Any:
-        for field in fields(self):  # type: ignore
-            yield field.name, getattr(self, field.name)
+        return ((name, getattr(self, name)) for name in self._field_names())
 
 
 def load_module_from_url(model: nn.Module, url: str, strict: bool = True, progress: bool = True) -> None:
