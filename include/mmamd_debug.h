@@ -23,8 +23,13 @@ int mmamd_get_gemm_variant(void);
  * time — measured to cost as much makespan as the spread-out bursts save. */
 int mmamd_debug_set_gemm_stagger(int percent);
 /* Experiment knobs of the GEMM launchers (results never change; knob 0: tile-order group of the grouped persistent kernel -- 0 = by the stream's
- * CU budget, 4, 8;  knob 1: start-up stagger policy of the grouped kernel -- 0 = light workgroups only, 1 = every workgroup by its slack). */
+ * CU budget, 4, 8;  knob 1: start-up stagger policy of the grouped kernel -- 0 = light workgroups only, 1 = every workgroup by its slack;  knob 4 (r06): column tiles
+ * per chunk of the persistent kernels' tile order -- 0 = by the size of W, -1 = no chunking, k = k tiles). */
 int mmamd_debug_set_gemm_knob(int knob, int value);
+/* Host-side enumeration of the persistent GEMM kernels' tile order for a tiles_m x tiles_n grid of 256 x 256 tiles (gm / cn <= 0: the launchers' own choice for
+ * contraction length K): out[2 id] = row tile, out[2 id + 1] = column tile for id = 0 .. tiles_m * tiles_n - 1; returns the column-chunk width used (or a
+ * negative error).  No device work: the CPU test enumerates it and asserts every tile is visited exactly once. */
+int mmamd_debug_tile_order(int tiles_m, int tiles_n, int K, int gm, int cn, int* out);
 /* W [N, K] bf16 row-major (leading dimension ldw) -> MFMA-fragment order for the direct-W GEMM kernels: ceil(N / 32) x (K / 16) blocks of 1 KiB,
  * block (nb, ks) = 64 lanes x 16 B, lane (l = lane & 31, h = lane >> 5) holds W[32 nb + l][16 ks + 8 h .. + 7] (rows >= N: zeros).  Wp: ceil(N / 32) * 32 * K
  * bf16.  A layout of the static operand of torch's nn.Linear inside TransformerEncoderLayer (models/clip/image_encoder.py:65-77). */

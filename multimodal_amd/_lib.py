@@ -32,6 +32,7 @@ PROTOTYPES = {
     "mmamd_debug_set_gemm_stagger": (_i, [_i]),
     "mmamd_debug_set_gemm_trace": (_i, [_vp]),
     "mmamd_debug_set_gemm_knob": (_i, [_i, _i]),
+    "mmamd_debug_tile_order": (_i, [_i, _i, _i, _i, _i, _vp]),
     "mmamd_pack_w_frag": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmamd_debug_set_gemm_wp": (_i, [_vp]),
     "mmamd_debug_set_attn_variant": (_i, [_i]),

@@ -232,6 +232,25 @@ static int g_gemm_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // (step 13.39 ms with the r03 value 8, 13.30 with row-major order for N <= 1024 only, 13.25 with 2 everywhere): with few row panels per group
 // the column tiles of a panel run at the same time, in lock-step, and every K-slice of the panel is fetched into the XCD's L2 once -- MLP-down
 // (3 column tiles, a 1.5 MiB panel per 256 rows that no cache level keeps between rounds) 311 -> 301 us, the vision out-projection alone 93.6 -> 86.5 us.
+// Tile order of the persistent kernels, one function for the device code and for the host-side check (mmamd_debug_tile_order; tests/test_host_logic.py
+// enumerates it over many grids and asserts a bijection): linear id -> (row tile tm, column tile tn) with the column CHUNK (cn column tiles, the last chunk
+// possibly narrower) as the outermost level, then groups of gm row tiles, then the chunk's column tiles, row tile innermost.
+__host__ __device__ __forceinline__ void tile_order_map(int id, int tiles_m, int tiles_n, int gm, int cn, int& tm, int& tn) {
+  const int full = tiles_m * cn;  // tiles of a full-width chunk
+  const int nck = (tiles_n + cn - 1) / cn;
+  int ck = id / full;
+  ck = ck < nck ? ck : nck - 1;
+  const int cw = (tiles_n - ck * cn) < cn ? (tiles_n - ck * cn) : cn;  // this chunk's width
+  const int idl = id - ck * full;
+  const int per_group = gm * cw;
+  const int grp = idl / per_group, within = idl - grp * per_group;
+  const int gm0 = grp * gm;
+  const int rows = (tiles_m - gm0) < gm ? (tiles_m - gm0) : gm;
+  const int tnl = within / rows;
+  tn = ck * cn + tnl;
+  tm = gm0 + (within - tnl * rows);
+}
+
 // Column chunking of the tile order (r06).  The W operand of a wide GEMM does not fit an XCD's 4 MiB L2 (MLP-up: 3072 x 768 bf16 = 4.7 MB), so with all
 // column tiles in one group every `gm` row panels re-stream the whole of W through the L2 (MLP-up: 463 MB of W fetches against 104 MB of algorithmic
 // reads -- the 1.84 x over-fetch of profiles/r04_pmc_mlp_up_kernel.json).  With the column tiles cut into chunks whose W slice (cn x 256 x K bf16) fits
@@ -708,19 +727,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
   auto tile_of = [&](int vb, int& tm, int& tn) __attribute__((always_inline)) {
     const int q = ntiles >> 3, r = ntiles & 7, xcd = vb & 7, loc = vb >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int full = tiles_m * CNr;                       // tiles of a full-width chunk
-    int ck = id / full;
-    const int nck = (p.tiles_n + CNr - 1) / CNr;
-    ck = ck < nck ? ck : nck - 1;
-    const int cw = (p.tiles_n - ck * CNr) < CNr ? (p.tiles_n - ck * CNr) : CNr;  // this chunk's width
-    const int idl = id - ck * full;
-    const int per_group = GMr * cw;
-    const int grp = idl / per_group, within = idl - grp * per_group;
-    const int gm0 = grp * GMr;
-    const int rows = (tiles_m - gm0) < GMr ? (tiles_m - gm0) : GMr;
-    const int tnl = within / rows;
-    tn = ck * CNr + tnl;
-    tm = gm0 + (within - tnl * rows);
+    tile_order_map(id, tiles_m, p.tiles_n, GMr, CNr, tm, tn);
   };
 
   // DMA source offsets of this lane (see kernel above for the swizzle): depend on the tile, not on K
@@ -1315,22 +1322,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_nt_kernel_ppg(const GemmGroupAr
       sel = l >= xc0 ? 1 : 0;
       id = sel ? xb1 + (l - xc0) : xb0 + l;
     }
-    const int tiles_m = g.prob[sel].tiles_m, tiles_n = g.prob[sel].tiles_n;
-    const int GM = g.gm[sel];
-    const int CN = g.cn[sel];  // (1 <= CN <= tiles_n: launcher)
-    const int full = tiles_m * CN;
-    int ck = id / full;
-    const int nck = (tiles_n + CN - 1) / CN;
-    ck = ck < nck ? ck : nck - 1;
-    const int cw = (tiles_n - ck * CN) < CN ? (tiles_n - ck * CN) : CN;
-    const int idl = id - ck * full;
-    const int per_group = GM * cw;
-    const int grp = idl / per_group, within = idl - grp * per_group;
-    const int gm0 = grp * GM;
-    const int rows = (tiles_m - gm0) < GM ? (tiles_m - gm0) : GM;
-    const int tnl = within / rows;
-    tn = ck * CN + tnl;
-    tm = gm0 + (within - tnl * rows);
+    tile_order_map(id, g.prob[sel].tiles_m, g.prob[sel].tiles_n, g.gm[sel], g.cn[sel], tm, tn);  // (1 <= cn <= tiles_n: launcher)
   };
 
   // DMA source offsets of this lane (see kernel above for the swizzle): depend on the tile, not on K
@@ -1862,6 +1854,16 @@ extern "C" int mmamd_debug_set_gemm_stagger(int percent) {
   return 0;
 }
 
+// host-side enumeration of the persistent kernels' tile order for a tiles_m x tiles_n grid (gm / cn <= 0: the launchers' own choice for contraction length K):
+// out[2 * id] = tm, out[2 * id + 1] = tn for id = 0 .. tiles_m * tiles_n - 1.  No device work.
+extern "C" int mmamd_debug_tile_order(int tiles_m, int tiles_n, int K, int gm, int cn, int* out) {
+  MMAMD_CHECK_ARG(tiles_m > 0 && tiles_n > 0 && K > 0 && out != nullptr, MMAMD_E_BADARG, "debug_tile_order: bad argument");
+  if (gm <= 0) gm = pick_gm(tiles_n, 256);
+  if (cn <= 0) cn = pick_cn(tiles_n, K);
+  cn = cn < tiles_n ? cn : tiles_n;
+  for (int id = 0; id < tiles_m * tiles_n; ++id) tile_order_map(id, tiles_m, tiles_n, gm, cn, out[2 * id], out[2 * id + 1]);
+  return cn;
+}
 extern "C" int mmamd_debug_set_gemm_knob(int knob, int value) {
   MMAMD_CHECK_ARG(knob >= 0 && knob < 8, MMAMD_E_BADARG, "debug_set_gemm_knob: knob %d out of range", knob);
   g_gemm_knob[knob] = value;

@@ -72,3 +72,33 @@ def test_step_timeline_tool_on_a_synthetic_trace(tmp_path, capsys):
     # 200 us window: idle 10 us (5 %), one kernel 130 us, two kernels 60 us
     assert "0.0 ms (5.0 %) / 0.1 ms (65.0 %) / 0.1 ms (30.0 %)" in out
     assert "1 idle gaps" in out and "after gemm" in out and "before attn" in out
+
+
+def test_persistent_gemm_tile_order_visits_every_tile_once():
+    """The tile order of the persistent GEMM kernels (column chunk outermost, then groups of gm row tiles, then the chunk's column tiles: csrc/gemm.hip
+    tile_order_map, the SAME function the kernels call) enumerated on the host through mmamd_debug_tile_order: a bijection onto the tile grid for the
+    launchers' own (gm, cn) choices and for forced ones -- including ragged last chunks, last row groups, single-row / single-column grids and the 193-column
+    vocabulary GEMM of CoCa.  No GPU."""
+    import ctypes as C
+
+    import numpy as np
+
+    from multimodal_amd import _lib
+
+    L = _lib.lib()
+    cases = [(197, 12, 768, 0, 0), (197, 9, 768, 0, 0), (197, 3, 3072, 0, 0), (77, 8, 512, 0, 0), (257, 16, 1024, 0, 0), (38, 193, 768, 0, 0),
+             (5, 7, 4096, 0, 0), (1, 1, 64, 0, 0), (1, 13, 2048, 0, 0), (13, 1, 2048, 0, 0)]
+    cases += [(tm, tn, 768, gm, cn) for tm in (1, 2, 7, 31) for tn in (1, 2, 5, 12) for gm in (1, 2, 3, 8) for cn in (1, 2, 5, 6, 12, 20)]
+    for tiles_m, tiles_n, K, gm, cn in cases:
+        out = np.full((tiles_m * tiles_n, 2), -1, dtype=np.int32)
+        used = L.mmamd_debug_tile_order(tiles_m, tiles_n, K, gm, cn, out.ctypes.data_as(C.c_void_p))
+        assert 1 <= used <= tiles_n, (tiles_m, tiles_n, K, gm, cn, used)
+        assert out[:, 0].min() >= 0 and out[:, 0].max() == tiles_m - 1 and out[:, 1].min() >= 0 and out[:, 1].max() == tiles_n - 1
+        flat = out[:, 0].astype(np.int64) * tiles_n + out[:, 1]
+        assert len(np.unique(flat)) == tiles_m * tiles_n, (tiles_m, tiles_n, K, gm, cn)
+        # chunks are contiguous in the order: the column-chunk index never decreases along the list
+        ck = out[:, 1] // used
+        assert (np.diff(ck) >= 0).all(), (tiles_m, tiles_n, K, gm, cn)
+    # the launchers' choices: wide GEMMs with a W above 3 MB are chunked (MLP-up 12 -> 6 + 6, qkv 9 -> 5 + 4), few-column / small-W ones are not
+    pick = lambda tn, K: L.mmamd_debug_tile_order(4, tn, K, 0, 0, np.zeros((4 * tn, 2), dtype=np.int32).ctypes.data_as(C.c_void_p))  # noqa: E731
+    assert pick(12, 768) == 6 and pick(9, 768) == 5 and pick(3, 3072) == 3 and pick(8, 512) == 8 and pick(3, 768) == 3
