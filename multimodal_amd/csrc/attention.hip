@@ -1092,17 +1092,32 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const bf16* _
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(drow + 16 * t), vf[t], dp, 0, 0, 0);
       }
       uint32_t pk[8], dk[8];
+      // (r06) the queries' log-sum-exp / D values as 16-byte LDS reads one group ahead, exp2 unconditional, the key test a select afterwards: the
+      // per-element `ok ? exp2(.. - L2s[q]) : 0` compiled to an exec-masked branch with a 4-byte LDS read and lgkmcnt(0) inside, per element
+      f32x4 Lq = *reinterpret_cast<const f32x4*>(L2s + qt * 32 + 4 * half), Dq = *reinterpret_cast<const f32x4*>(Dqs + qt * 32 + 4 * half);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        const f32x4 Lc = Lq, Dc = Dq;
+        if (g < 3) {
+          Lq = *reinterpret_cast<const f32x4*>(L2s + qt * 32 + 8 * (g + 1) + 4 * half);
+          Dq = *reinterpret_cast<const f32x4*>(Dqs + qt * 32 + 8 * (g + 1) + 4 * half);
+        }
         float e[4], f[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const int q = qt * 32 + 8 * g + 4 * half + j;
           const bool ok = key_live && (!CAUSAL || key <= q);
-          const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;  // L2 = +inf for padded queries -> 0
+          float pr, dd;  // (L2 = +inf for padded queries -> 0)
+          if constexpr (CAUSAL) {  // (per-element branch form: faster where half a tile is masked, see the single-pass kernel)
+            pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;
+            dd = Dqs[q];
+          } else {
+            pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -Lc[j])) : 0.f;
+            dd = Dc[j];
+          }
           e[j] = pr;
-          f[j] = pr * (dp[r] - Dqs[q]);
+          f[j] = pr * (dp[r] - dd);
         }
         bf16x2 p0, p1, d0, d1;
         p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
@@ -1316,17 +1331,30 @@ __global__ __launch_bounds__(NWH * 64) void attention_bwd_fused_kernel(const bf1
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(drow + 16 * t), vf[t], dp, 0, 0, 0);
           }
           uint32_t pk[8], dk[8];
+          f32x4 Lq = *reinterpret_cast<const f32x4*>(L2s + qt * 32 + 4 * half), Dq = *reinterpret_cast<const f32x4*>(Dqs + qt * 32 + 4 * half);  // (r06: see the dK / dV kernel above)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
+            const f32x4 Lc = Lq, Dc = Dq;
+            if (g < 3) {
+              Lq = *reinterpret_cast<const f32x4*>(L2s + qt * 32 + 8 * (g + 1) + 4 * half);
+              Dq = *reinterpret_cast<const f32x4*>(Dqs + qt * 32 + 8 * (g + 1) + 4 * half);
+            }
             float e[4], f[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int r = 4 * g + j;
               const int q = qt * 32 + 8 * g + 4 * half + j;
               const bool ok = key_live && (!CAUSAL || key <= q);
-              const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;
+              float pr, dd;
+              if constexpr (CAUSAL) {  // (the diagonal tiles mask half their elements: the per-element branch form measured faster -- S = 77: 55.4 vs 63 us)
+                pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;
+                dd = Dqs[q];
+              } else {
+                pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -Lc[j])) : 0.f;
+                dd = Dc[j];
+              }
               e[j] = pr;
-              f[j] = pr * (dp[r] - Dqs[q]);
+              f[j] = pr * (dp[r] - dd);
             }
             bf16x2 p0, p1, d0, d1;
             p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
@@ -1529,17 +1557,34 @@ __global__ __launch_bounds__(512) void attention_bwd_sp_kernel(const bf16* __res
           }
           uint32_t pk[8], dk[8];
           bf16* mrow = mbuf + (size_t)qt * 32 * TS + l31 * TS + 4 * half;
+          // the 16 queries' log-sum-exp and D values: eight 16-byte LDS reads up front (r06).  The per-element form `ok ? exp2(st c2 - L2s[q]) : 0` compiled
+          // to an exec-masked branch per element with a 4-byte LDS read and `s_waitcnt lgkmcnt(0)` INSIDE it -- 32 exposed LDS round trips per pair and wave
+          // (read off the ISA).  exp2 runs unconditionally (rows past S hold +inf -> 0; masked keys are selected away afterwards): straight-line code.
+          // (two groups' worth in flight: all eight at once needs 32 registers the kernel does not have -- 32 B of scratch when tried)
+          f32x4 Lq = *reinterpret_cast<const f32x4*>(L2s + qt * 32 + 4 * half), Dq = *reinterpret_cast<const f32x4*>(Dqs + qt * 32 + 4 * half);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
+            const f32x4 Lc = Lq, Dc = Dq;
+            if (g < 3) {
+              Lq = *reinterpret_cast<const f32x4*>(L2s + qt * 32 + 8 * (g + 1) + 4 * half);
+              Dq = *reinterpret_cast<const f32x4*>(Dqs + qt * 32 + 8 * (g + 1) + 4 * half);
+            }
             float e[4], f[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int r = 4 * g + j;
               const int q = qt * 32 + 8 * g + 4 * half + j;
               const bool ok = key_live && (!CAUSAL || key <= q);
-              const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;
+              float pr, dd;
+              if constexpr (CAUSAL) {  // (the diagonal tiles mask half their elements: the per-element branch form measured faster -- S = 77: 55.4 vs 63 us)
+                pr = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - L2s[q]) : 0.f;
+                dd = Dqs[q];
+              } else {
+                pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -Lc[j])) : 0.f;
+                dd = Dc[j];
+              }
               e[j] = pr;
-              f[j] = pr * (dp[r] - Dqs[q]);
+              f[j] = pr * (dp[r] - dd);
             }
             bf16x2 p0, p1, d0, d1;
             p0[0] = (bf16)e[0]; p0[1] = (bf16)e[1]; p1[0] = (bf16)e[2]; p1[1] = (bf16)e[3];
