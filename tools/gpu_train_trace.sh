@@ -1,0 +1,23 @@
+#!/bin/bash
+# kernel timeline of ONE CLIP training step (the last profiled one): name, grid, duration, gap to the previous kernel -> gpurun_out/<tag>_train_timeline.txt
+export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
+cd /tmp && rm -rf /tmp/prof_tt && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tt -o p -- python $GRAFT_REPO_ROOT/tools/train_bench.py --steps 3 --warmup 2 > $O/train_trace.log 2>&1
+f=$(find /tmp/prof_tt -name "*kernel_trace.csv" | head -1)
+python3 - "$f" > $O/${1:-r06}_train_timeline.txt <<'PY'
+import csv,sys,re
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+n=len(rows)//5
+last=rows[-n:]
+t0=int(last[0]['Start_Timestamp']); prev=t0
+def short(s):
+    s=re.sub(r'^void ','',s); s=s.replace('mmamd::','')
+    return s[:86]
+print(f"{n} kernels per step; step span {(int(last[-1]['End_Timestamp'])-t0)/1e6:.2f} ms")
+for r in last:
+    s,e=int(r['Start_Timestamp']),int(r['End_Timestamp'])
+    g=r.get('Grid_Size_X') or r.get('Grid_Size') or ''
+    print(f"{(s-t0)/1e3:9.1f} us  dur {(e-s)/1e3:7.1f}  gap {(s-prev)/1e3:6.1f}  grid {g:>8s}  {short(r['Kernel_Name'])}")
+    prev=e
+PY
+head -3 $O/${1:-r06}_train_timeline.txt
