@@ -109,6 +109,28 @@ typedef struct {
 } mmamd_gemm_problem;
 int mmamd_gemm_bf16_grouped(const mmamd_gemm_problem* probs, int nprob, int out_dtype, int act, mmamd_stream_t stream);
 
+/* Out-projection + residual + the LayerNorm behind it, up to two problems (the two towers) in ONE persistent launch whose workgroups own whole
+ * rows (64 x N tiles):  X (fp32, in place) = A W^T + bias + X;  Y (bf16) = LayerNorm(X; gamma, beta, eps).  X is bit-identical to
+ * mmamd_gemm_bf16(..., residual = X, C = X, out fp32); Y is the LayerNorm of mmamd_layernorm up to the summation order of the two row
+ * statistics.  N must be 512 or 768 (mmamd_gemm_bf16_residual_ln_supported); callers fall back to the two separate launches otherwise.
+ * Replaces `x = x + self_attn.out_proj(...)` followed by `norm2(x)` of nn.TransformerEncoderLayer(norm_first=True) (the layers of
+ * models/clip/image_encoder.py:108 and models/clip/text_encoder.py:121). */
+typedef struct {
+  const void* A;      /* bf16 [M, K] */
+  const void* W;      /* bf16 [K / 32][N][32]: W [N, K] repacked by mmamd_pack_w_ksteps (once per weight) */
+  const float* bias;  /* fp32 [N] */
+  float* X;           /* fp32 [M, N]: residual in, updated stream out */
+  const float* gamma; /* fp32 [N] */
+  const float* beta;  /* fp32 [N] */
+  void* Y;            /* bf16 [M, N] */
+  int M, N, K;
+  float eps;
+} mmamd_gemm_ln_problem;
+int mmamd_gemm_bf16_residual_ln_grouped(const mmamd_gemm_ln_problem* probs, int nprob, mmamd_stream_t stream);
+int mmamd_gemm_bf16_residual_ln_supported(int M, int N, int K); /* 1 / 0 */
+/* W [N, K] bf16 row-major -> [K / 32][N][32] (same size), the operand layout of mmamd_gemm_bf16_residual_ln_grouped; K % 32 == 0 */
+int mmamd_pack_w_ksteps(const void* W, int N, int K, void* out, mmamd_stream_t stream);
+
 /* Training forward of an MLP's first linear (linear1 of the encoder layers, modules/layers/mlp.py:60-79 under autograd): ONE pass
  * writes the pre-activation U = A W^T + bias (bf16 [M, ldu], kept for the backward) and G = act(U) (bf16 [M, ldg], the input of the
  * second linear), act = MMAMD_ACT_QUICKGELU or MMAMD_ACT_GELU_ERF applied to the bf16-rounded U (exactly what mmamd_act_fwd on U

@@ -44,6 +44,9 @@ PROTOTYPES = {
     "mmamd_vit_cls_lnpre_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "mmamd_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmamd_gemm_bf16_grouped": (_i, [_vp, _i, _i, _i, _vp]),
+    "mmamd_gemm_bf16_residual_ln_grouped": (_i, [_vp, _i, _vp]),
+    "mmamd_gemm_bf16_residual_ln_supported": (_i, [_i, _i, _i]),
+    "mmamd_pack_w_ksteps": (_i, [_vp, _i, _i, _vp, _vp]),
     "mmamd_pack_weights": (_i, [_vp, _i, _vp]),
     "mmamd_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "mmamd_attention_fwd_lse": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

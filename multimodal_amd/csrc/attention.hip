@@ -1947,6 +1947,7 @@ namespace mmamd {
 bool attn_ring_supports(int S);
 extern int g_attn_ring_abl;
 extern int g_attn_ring_depth_cap;
+int g_ln_rev = 0;        // mmamd_debug_set_attn_variant(3110 + r): grouped LayerNorm walks its rows 1 = last to first (A/B)
 int g_ln_nt_policy = 0;  // mmamd_debug_set_attn_variant(3100 + p): LayerNorm x loads 0 = by size (default), 1 = never non-temporal, 2 = always (A/B)
 int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse, const int* B, const int* S, const int* H, const int* causal,
                      const float* scale, int nprob, hipStream_t st, const int* lse_stride = nullptr);
@@ -1974,6 +1975,10 @@ extern "C" int mmamd_debug_set_attn_variant(int v) {
   }
   if (v >= 3100 && v < 3103) {
     g_ln_nt_policy = v - 3100;
+    return 0;
+  }
+  if (v >= 3110 && v < 3112) {
+    g_ln_rev = v - 3110;
     return 0;
   }
   if (v >= 4000 && v < 4004) {  // attention BACKWARD form (the forward keeps its default)

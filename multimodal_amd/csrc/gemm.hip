@@ -226,6 +226,7 @@ static int g_gemm_variant = 0;
 static int g_gemm_stagger = 60;
 // experiment knobs (mmamd_debug_set_gemm_knob): [0] tile-order group of the grouped kernel (0 = by CU budget, 4, 8); [1] slack-aware stagger, per cent; [2] walk order of the grouped kernel's two problems
 static int g_gemm_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+void set_rowln_ablation(int code);  // gemm_rowln.hip
 
 // tile-order group (GemmGroupArgs::gm / GemmArgs::gm): the workgroups an XCD runs concurrently walk gm row panels x all column tiles.  Measured
 // on MI355X (r04, profiles/r04_tile_order_ab.txt): gm = 2 is the best or within 0.5 % of it on all four projection pairs of the headline step
@@ -1867,6 +1868,7 @@ extern "C" int mmamd_debug_tile_order(int tiles_m, int tiles_n, int K, int gm, i
 extern "C" int mmamd_debug_set_gemm_knob(int knob, int value) {
   MMAMD_CHECK_ARG(knob >= 0 && knob < 8, MMAMD_E_BADARG, "debug_set_gemm_knob: knob %d out of range", knob);
   g_gemm_knob[knob] = value;
+  if (knob == 5) set_rowln_ablation(value);  // gemm_rowln.hip: timing ablations of the out-projection + LayerNorm kernel
   return 0;
 }
 

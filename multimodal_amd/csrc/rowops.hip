@@ -8,6 +8,7 @@
 #include "common.h"
 
 namespace mmamd {
+extern int g_ln_rev;        // attention.hip (mmamd_debug_set_attn_variant(3110 + r))
 extern int g_ln_nt_policy;  // attention.hip (mmamd_debug_set_attn_variant(3100 + p)): 0 = by size, 1 = never, 2 = always
 // LayerNorm reads its fp32 input NON-TEMPORALLY when the tensor is larger than what the 256 MiB MALL keeps next to the bf16 output: the input rows then
 // stream through without evicting the output rows the next GEMM is about to read.  Measured per step, same-box alternating A/B
@@ -118,6 +119,7 @@ struct LnGroupArgs {
   LnProb p[2];
   int nprob;
   int blocks0;  // blocks (4 rows each) of problem 0
+  int rev;      // the blocks walk the rows from the last to the first
 };
 
 template <int MAXV, bool HAS_DELTA, int NT = 0>
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void add_layernorm_grouped_kernel(const LnGrou
 template <int MAXV, int RPW>
 __global__ __launch_bounds__(256) void layernorm_grouped_rows_kernel(const LnGroupArgs a) {
   const int lane = threadIdx.x & 63;
-  int blk = blockIdx.x, pi = 0;
+  int blk = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, pi = 0;
   const int b0 = (a.p[0].rows + 4 * RPW - 1) / (4 * RPW);
   if (blk >= b0) { blk -= b0; pi = 1; }
   const float* __restrict__ x = a.p[pi].x;
@@ -943,6 +945,7 @@ extern "C" int mmamd_add_layernorm_grouped(const mmamd_ln_problem* probs, int np
   LnGroupArgs a;
   a.nprob = 0;
   a.blocks0 = 0;
+  a.rev = g_ln_rev;
   int total = 0, dmax = 0;
   for (int i = 0; i < nprob; ++i) {
     const mmamd_ln_problem& q = probs[i];

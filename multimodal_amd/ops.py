@@ -17,7 +17,7 @@ from ._lib import (ACT_GELU_ERF, ACT_MUL_GELU_GRAD, ACT_MUL_QUICKGELU_GRAD, ACT_
                    check)
 
 __all__ = [
-    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
+    "ACT_NONE", "ACT_QUICKGELU", "ACT_GELU_ERF", "ACT_MUL_QUICKGELU_GRAD", "ACT_MUL_GELU_GRAD", "layernorm", "gemm_bf16", "attention_fwd", "attention_fwd_grouped", "add_layernorm_grouped", "gemm_residual_ln_grouped", "gemm_residual_ln_supported", "pack_w_ksteps", "patch_embed_fused", "vit_cls_lnpre_ln", "patchify",
     "vit_assemble_ln", "embed_tokens", "pool_ln_proj", "l2_normalize", "clamp_scalar_", "contrastive_fwd",
     "convert", "set_gemm_variant", "pack_w_frag", "debug_set_gemm_wp", "cu_partition_masks", "create_cu_mask_stream", "stream_cus", "stream_set_cus", "chip_cus", "cu_census", "dropout", "token_mean", "StreamTimer", "launch_count", "attention_probs_fwd", "attention_probs_from_lse", "attention_probs_from_lse_supported", "key_mask", "bert_embed_ln", "flava_image_embed",
     "rows_linear_f32", "select_tokens", "gather_rows", "cross_entropy", "attention_x_fwd", "coca_text_embed", "coca_text_mask",
@@ -205,6 +205,48 @@ def add_layernorm_grouped(problems) -> None:
         q = arr[i]
         q.x, q.delta, q.gamma, q.beta, q.y, q.rows, q.d, q.eps = x.data_ptr(), _ptr(delta), _ptr(gamma), _ptr(beta), _ptr(y), rows, d, float(eps)
     check(_lib.lib().mmamd_add_layernorm_grouped(C.cast(arr, C.c_void_p), n, _stream()), "mmamd_add_layernorm_grouped")
+
+
+class _GemmLnProblem(C.Structure):  # mmamd_gemm_ln_problem (include/mmamd.h)
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("X", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("Y", C.c_void_p), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("eps", C.c_float)]
+
+
+def gemm_residual_ln_supported(M: int, N: int, K: int) -> bool:
+    """Whether gemm_residual_ln_grouped takes a problem of this shape (mmamd_gemm_bf16_residual_ln_supported)."""
+    return bool(_lib.lib().mmamd_gemm_bf16_residual_ln_supported(int(M), int(N), int(K)))
+
+
+def pack_w_ksteps(w: torch.Tensor) -> torch.Tensor:
+    """W [N, K] bf16 -> the K-step-major copy [K / 32, N, 32] gemm_residual_ln_grouped reads (mmamd_pack_w_ksteps); once per weight."""
+    _chk(w, "w", torch.bfloat16)
+    N, K = w.shape
+    out = torch.empty((K // 32, N, 32), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().mmamd_pack_w_ksteps(w.data_ptr(), N, K, out.data_ptr(), _stream()), "mmamd_pack_w_ksteps")
+    return out
+
+
+def gemm_residual_ln_grouped(problems) -> None:
+    """Out-projection + residual + the LayerNorm behind it in one launch, for up to two problems:
+    problems = [(a bf16 [M, K], w bf16 [K / 32, N, 32] = pack_w_ksteps(W [N, K]), bias fp32 [N], x fp32 [M, N] (updated in place: x += a w^T + bias), gamma, beta fp32 [N], eps,
+    y bf16 [M, N] (= LayerNorm(x))), ...]  (mmamd_gemm_bf16_residual_ln_grouped)."""
+    n = len(problems)
+    if not 1 <= n <= 2:
+        raise MmamdError(f"gemm_residual_ln_grouped: 1 or 2 problems, got {n}")
+    arr = (_GemmLnProblem * n)()
+    for i, (a, w, bias, x, gamma, beta, eps, y) in enumerate(problems):
+        _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16); _chk(bias, "bias", torch.float32); _chk(x, "x", torch.float32)
+        _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32); _chk(y, "y", torch.bfloat16)
+        M, K = a.shape
+        if w.dim() != 3 or w.shape[2] != 32:
+            raise MmamdError(f"gemm_residual_ln_grouped: w must be the pack_w_ksteps layout [K / 32, N, 32], got {tuple(w.shape)}")
+        N, K2 = w.shape[1], w.shape[0] * 32
+        if K != K2 or tuple(x.shape) != (M, N) or tuple(y.shape) != (M, N) or bias.numel() != N or gamma.numel() != N or beta.numel() != N:
+            raise MmamdError(f"gemm_residual_ln_grouped: shapes a {tuple(a.shape)} w {tuple(w.shape)} x {tuple(x.shape)} y {tuple(y.shape)} do not agree")
+        q = arr[i]
+        q.A, q.W, q.bias, q.X, q.gamma, q.beta, q.Y = a.data_ptr(), w.data_ptr(), bias.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr()
+        q.M, q.N, q.K, q.eps = M, N, K, float(eps)
+    check(_lib.lib().mmamd_gemm_bf16_residual_ln_grouped(C.cast(arr, C.c_void_p), n, _stream()), "mmamd_gemm_bf16_residual_ln_grouped")
 
 
 class _GemmProblem(C.Structure):  # mmamd_gemm_problem (include/mmamd.h)

@@ -46,6 +46,7 @@ def main():
     def set_arm(name):
         L.mmamd_debug_set_attn_variant(0)
         L.mmamd_debug_set_attn_variant(3100)
+        L.mmamd_debug_set_attn_variant(3110)
         L.mmamd_debug_set_gemm_stagger(60)
         L.mmamd_debug_set_gemm_knob(0, 0)
         L.mmamd_debug_set_gemm_knob(1, 0)
@@ -66,6 +67,8 @@ def main():
                 L.mmamd_debug_set_gemm_knob(0, int(part[2:]))
             elif part.startswith("cn"):  # column tiles per chunk of the persistent GEMMs' tile order (r06; cn-1 = no chunking, default = by W size)
                 L.mmamd_debug_set_gemm_knob(4, int(part[2:]))
+            elif part == "ln_rev":  # grouped LayerNorm walks its rows from the last to the first (the rows the GEMM before it wrote last are read first)
+                L.mmamd_debug_set_attn_variant(3111)
             elif part == "ln_cached":  # LayerNorm input loads never non-temporal (the r02 behaviour)
                 L.mmamd_debug_set_attn_variant(3101)
             else:
