@@ -400,6 +400,24 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
   if constexpr (OUT_F32) {
     if (has_res) res_load(0, rr);  // in flight across the barrier and the first transpose
   }
+  // bf16 output with a bf16 epilogue operand R (+= R, or x act'(R): the MLP's backward): the 32-row slab's four 16-byte loads per lane are issued
+  // one slab ahead, UNCONDITIONALLY on clamped addresses (r06: loaded inside the lane's bounds branch and used at once they were sixteen exposed
+  // round trips per tile, `s_waitcnt vmcnt(0)` behind each -- see the persistent kernel's descriptor form)
+  [[maybe_unused]] uint4 rb[2][4];
+  [[maybe_unused]] auto rb_load = [&](int mi, int w) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      int m = m0 + wm * TM + mi * 32 + it * 8 + (lane >> 3), n = nw0 + (lane & 7) * 8;
+      m = m < p.M ? m : p.M - 1;
+      n = n + 7 < p.N ? n : 0;
+      rb[w][it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+    }
+  };
+  constexpr bool RB = !OUT_F32 && TN == 64;
+  const bool has_rb = RB && p.R != nullptr;
+  if constexpr (RB) {
+    if (has_rb) rb_load(0, 0);
+  }
   __syncthreads();  // every wave is done reading the operand stages: LDS can be reused
   char* strip = smem + wave * (32 * ROWB);
 #pragma unroll
@@ -457,13 +475,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
           *reinterpret_cast<uint4*>(strip + l31 * ROWB + (ni * 32 + 8 * (g + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (RB) {
+        if (has_rb && mi + 1 < MI) rb_load(mi + 1, (mi + 1) & 1);
+      }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {  // 8 rows x 128 B per wave-instruction
         const int row = it * 8 + (lane >> 3), c = lane & 7;
         uint4 v = *reinterpret_cast<const uint4*>(strip + row * ROWB + c * 16);
         const int m = mrow0 + row, n = nw0 + c * 8;
+        if constexpr (RB) {
+          if (has_rb) v = __builtin_bit_cast(uint4, combine_res8(__builtin_bit_cast(bf16x8, v), __builtin_bit_cast(bf16x8, rb[mi & 1][it]), p.res_mode));
+        }
         if (m < p.M && n + 7 < p.N && ((ABL & 16) == 0 || v.x == 0x12345678u)) {
-          if (p.R != nullptr) {
+          if (!RB && p.R != nullptr) {
             const uint4 rr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
             bf16x8 a8 = __builtin_bit_cast(bf16x8, v), r8 = __builtin_bit_cast(bf16x8, rr);
             a8 = combine_res8(a8, r8, p.res_mode);
@@ -1189,6 +1213,98 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       drain = 16;
+    } else if (A_MODE == 0 && CH == 1 && MI * 4 == 16 && (p.R != nullptr) != (p.C2 != nullptr)) {
+      // bf16 output with EITHER a bf16 operand R of the epilogue (C += R, or C *= act'(R): the MLP's backward, R = the saved pre-activation) OR a
+      // second output (C2 = act(C): the training forward's MLP-up).  r06: the generic loop below loads R inside the lane's (row < M, column < N)
+      // branch and uses it at once -- read off the ISA, `s_waitcnt vmcnt(0)` behind each of the 16 loads of a tile: sixteen exposed round trips to
+      // HBM per tile on the largest launch of the training step (the dgrad of MLP-down x act', 2364 tiles).  Here R and both outputs go through
+      // buffer descriptors (rows past M / columns past N: the hardware range check), R runs two 32-row passes ahead of its use and nothing is predicated.
+      const int mw = m0 + wm * TM;
+      const long long rows_left = (long long)p.M - mw;
+      auto span16 = [&](long long ld) -> int {
+        const long long b = rows_left > 0 ? rows_left * ld * 2 : 0;
+        return b > 0x7fffffffLL ? 0x7fffffff : (int)b;
+      };
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_s;
+      const uint32_t oob = (nw0 + (lane & 7) * 8 + 7 < p.N) ? 0u : 0x80000000u;
+      const __amdgpu_buffer_rsrc_t c16_srd =
+          __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.C) + ((size_t)mw * p.ldc + nw0) * 2, 0, span16(p.ldc), 0x00020000);
+      const uint32_t c16_lane = ((uint32_t)((lane >> 3) * p.ldc + (lane & 7) * 8) * 2u) | oob;
+      auto transpose = [&](int mi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            bf16x4 pa, pb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              pa[j] = (bf16)acc[nn][mi][4 * g + j]; pb[j] = (bf16)acc[nn][mi][4 * (g + 1) + j];
+            }
+            uint2 ua = __builtin_bit_cast(uint2, pa), ub = __builtin_bit_cast(uint2, pb);
+            auto s0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+            *reinterpret_cast<uint4*>(strip + l31 * ROWB + (nn * 32 + 8 * (g + half)) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      if (p.R != nullptr) {
+        const __amdgpu_buffer_rsrc_t r16_srd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.R)) + ((size_t)mw * p.ldr + nw0) * 2, 0, span16(p.ldr), 0x00020000);
+        const uint32_t r16_lane = ((uint32_t)((lane >> 3) * p.ldr + (lane & 7) * 8) * 2u) | oob;
+        u32x4_s rwin[2][4];
+        auto rload = [&](int mi, int w) __attribute__((always_inline)) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) rwin[w][it] = __builtin_amdgcn_raw_buffer_load_b128(r16_srd, r16_lane + (uint32_t)((it * 8 + mi * 32) * p.ldr) * 2u, 0, 0);
+        };
+        rload(0, 0);
+        rload(1, 1);
+        const int mode = p.res_mode;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          transpose(mi);
+          u32x4_s v[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const u32x4_s*>(strip + (it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            v[it] = __builtin_bit_cast(u32x4_s, combine_res8(__builtin_bit_cast(bf16x8, v[it]), __builtin_bit_cast(bf16x8, rwin[mi & 1][it]), mode));
+          __builtin_amdgcn_sched_barrier(0);
+          if (mi + 2 < MI) rload(mi + 2, mi & 1);
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            __builtin_amdgcn_raw_buffer_store_b128(v[it], c16_srd, c16_lane + (uint32_t)((it * 8 + mi * 32) * p.ldc) * 2u, 0, STP == 2 ? 2 : (STP == 1 ? 16 : 0));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        drain = 32;  // 16 loads + 16 stores, all unconditional
+      } else {
+        const __amdgpu_buffer_rsrc_t c2_srd =
+            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.C2) + ((size_t)mw * p.ldc2 + nw0) * 2, 0, span16(p.ldc2), 0x00020000);
+        const uint32_t c2_lane = ((uint32_t)((lane >> 3) * p.ldc2 + (lane & 7) * 8) * 2u) | oob;
+        const int act2 = p.act2;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          transpose(mi);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const u32x4_s v = *reinterpret_cast<const u32x4_s*>(strip + (it * 8 + (lane >> 3)) * ROWB + (lane & 7) * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, c16_srd, c16_lane + (uint32_t)((it * 8 + mi * 32) * p.ldc) * 2u, 0, STP == 2 ? 2 : (STP == 1 ? 16 : 0));
+            bf16x8 a8 = __builtin_bit_cast(bf16x8, v);
+            if (act2 != MMAMD_ACT_NONE) {  // (wave-uniform; the same values as store_act_copy)
+#pragma unroll
+              for (int j = 0; j < 8; j += 2) {
+                const f32x2 in = {(float)a8[j], (float)a8[j + 1]};
+                const f32x2 o = act2 == MMAMD_ACT_QUICKGELU ? quick_gelu2(in) : gelu_erf2(in);
+                a8[j] = (bf16)o[0]; a8[j + 1] = (bf16)o[1];
+              }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_s, a8), c2_srd, c2_lane + (uint32_t)((it * 8 + mi * 32) * p.ldc2) * 2u, 0, 0);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        drain = 32;  // 32 unconditional stores
+      }
     } else {
       drain = 0;
 #pragma unroll
