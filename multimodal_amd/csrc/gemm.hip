@@ -392,9 +392,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[NI][MI], const G
   auto res_load = [&](int mi, f32x4 (&dst)[8]) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int m = m0 + wm * TM + mi * 32 + it * 4 + (lane >> 4), n = nw0 + (lane & 15) * 4;
-      dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
+      // unconditional, on a clamped address (a lane past the edge reads a value it never uses): the predicated form merged the loaded registers with a
+      // zero initialisation at the branch join, i.e. `s_waitcnt vmcnt(0)` right behind the loads -- the slab-ahead prefetch below did not exist (r06)
+      int m = m0 + wm * TM + mi * 32 + it * 4 + (lane >> 4), n = nw0 + (lane & 15) * 4;
+      m = m < p.M ? m : p.M - 1;
+      n = n + 3 < p.N ? n : 0;
+      dst[it] = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
     }
   };
   if constexpr (OUT_F32) {
