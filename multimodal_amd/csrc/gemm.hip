@@ -318,6 +318,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
     for (int ni = 0; ni < NI; ++ni) {
       const int nb = n0 + wn * TN + ni * 32 + 4 * half;
       f32x4 v[4];
+      // the four residual vectors of this 32 x 32 block: unconditional loads on clamped addresses, all issued before the first is used (r06: loaded
+      // inside the lane's bounds branch and used at once, each of them was an exposed round trip -- `s_waitcnt vmcnt(0)` behind every load)
+      f32x4 rv4[4];
+      if (has_res) {
+        const int mc = mok ? m : p.M - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nc = (nb + 8 * g + 3 < p.N) ? nb + 8 * g : 0;
+          if constexpr (OUT_F32) rv4[g] = load4(reinterpret_cast<const float*>(p.R) + (size_t)mc * p.ldr + nc);
+          else rv4[g] = load4(reinterpret_cast<const bf16*>(p.R) + (size_t)mc * p.ldr + nc);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = nb + 8 * g;
@@ -325,10 +337,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmA
         f32x4 t;
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = acc[ni][mi][4 * g + j];
-        if (has_res && ok) {
-          f32x4 rv;
-          if constexpr (OUT_F32) rv = load4(reinterpret_cast<const float*>(p.R) + (size_t)m * p.ldr + n);
-          else rv = load4(reinterpret_cast<const bf16*>(p.R) + (size_t)m * p.ldr + n);
+        if (has_res) {
+          const f32x4 rv = rv4[g];
 #pragma unroll
           for (int j = 0; j < 4; ++j) t[j] = OUT_F32 ? t[j] + rv[j] : combine_res(t[j], rv[j], p.res_mode);
         }
