@@ -250,7 +250,11 @@ __global__ __launch_bounds__(kRingWaves * 64, 2) void attention_ring_kernel(cons
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);
       }
       const int di = wave / nqt, qt = wave - di * nqt;  // this wave's item of the round and its query tile (fixed per problem)
-      const bool wactive = wave < G * nqt;
+      bool wactive = wave < G * nqt;
+      // timing experiments (results WRONG): 32768 = the seventh query tile of a 7-tile item (5 valid rows at S = 197) is not computed; 65536 = the second
+      // tiles of SIMD 0 / 1 (waves 4, 5) are not computed -- which SIMD sets the round time (r06, profiles/r06_attn_tail_ablation.txt)
+      if constexpr ((ABL & 32768) != 0) wactive = wactive && !(nqt == 7 && qt == 6);
+      if constexpr ((ABL & 65536) != 0) wactive = wactive && !(nqt == 7 && (qt == 4 || qt == 5));
       const int q = qt * 32 + l31;
       const int kt_end = causal ? qt + 1 : nqt;
       ring_barrier();
@@ -662,6 +666,9 @@ int launch_attn_ring(const void* const* qkv, void* const* out, float* const* lse
     case 105: return launch_ring_t<9 + 32 + 64, 1>(a, grid, smem, st);
     case 233: return launch_ring_t<9 + 32 + 64 + 128, 1>(a, grid, smem, st);
     case 201: return launch_ring_t<9 + 64 + 128, 1>(a, grid, smem, st);
+    case 320: return launch_ring_t<32768, 2>(a, grid, smem, st);
+    case 321: return launch_ring_t<65536, 2>(a, grid, smem, st);
+    case 322: return launch_ring_t<32768 + 65536, 2>(a, grid, smem, st);
     case 410: return launch_ring_t<4096, 2>(a, grid, smem, st);
     case 412: return launch_ring_t<16384, 2>(a, grid, smem, st);
     case 413: return launch_ring_t<4096 + 16384, 2>(a, grid, smem, st);
