@@ -161,7 +161,8 @@ def test_gemm_epilogue_multiplies_by_activation_gradient():
     from multimodal_amd import ops
 
     set_rng_seed(9)
-    for (M, N, K) in ((300, 256, 128), (50432, 3072, 768), (5000, 768, 256)):
+    # (20011 x 776: a ragged last row tile AND a ragged last column tile on the persistent kernel -- the buffer-descriptor range checks of its R / C accesses)
+    for (M, N, K) in ((300, 256, 128), (50432, 3072, 768), (5000, 768, 256), (20011, 776, 128)):
         a = torch.randn(M, K).to(torch.bfloat16)
         w = (torch.randn(N, K) * 0.05).to(torch.bfloat16)
         u = (torch.randn(M, N) * 2).to(torch.bfloat16)
@@ -558,7 +559,7 @@ def test_gemm_dual_output_matches_gemm_then_activation():
     from multimodal_amd import ops
 
     set_rng_seed(21)
-    for (M, N, K) in ((300, 256, 128), (50432, 768, 128), (19712, 2048, 512), (50432, 3072, 768)):
+    for (M, N, K) in ((300, 256, 128), (50432, 768, 128), (19712, 2048, 512), (50432, 3072, 768), (20011, 776, 128)):
         a = torch.randn(M, K).to(torch.bfloat16).cuda()
         w = (torch.randn(N, K) * 0.05).to(torch.bfloat16).cuda()
         b = torch.randn(N).cuda()
