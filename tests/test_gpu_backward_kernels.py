@@ -161,8 +161,8 @@ def test_gemm_epilogue_multiplies_by_activation_gradient():
     from multimodal_amd import ops
 
     set_rng_seed(9)
-    # (20011 x 776: a ragged last row tile AND a ragged last column tile on the persistent kernel -- the buffer-descriptor range checks of its R / C accesses)
-    for (M, N, K) in ((300, 256, 128), (50432, 3072, 768), (5000, 768, 256), (20011, 776, 128)):
+    # (30011 x 776: a ragged last row tile AND a ragged last column tile on the persistent kernel -- the buffer-descriptor range checks of its R / C accesses)
+    for (M, N, K) in ((300, 256, 128), (50432, 3072, 768), (5000, 768, 256), (30011, 776, 128)):
         a = torch.randn(M, K).to(torch.bfloat16)
         w = (torch.randn(N, K) * 0.05).to(torch.bfloat16)
         u = (torch.randn(M, N) * 2).to(torch.bfloat16)
@@ -171,7 +171,10 @@ def test_gemm_epilogue_multiplies_by_activation_gradient():
             ud = u.double().requires_grad_(True)
             fn(ud).sum().backward()
             ref = (base * ud.grad).numpy()
+            before = ops.launch_count("gemm_bf16_pp")
             got = host(ops.gemm_bf16(a.cuda(), w.cuda(), None, act=code, residual=u.cuda()))
+            if M >= 30000:  # the large shapes take the persistent kernel (its descriptor epilogue)
+                assert ops.launch_count("gemm_bf16_pp") == before + 1, (M, N, K)
             assert np.abs(got - ref).max() <= 2 ** -6 * max(1.0, np.abs(ref).max()), (M, N, K, code)
     with pytest.raises(ops.MmamdError):
         ops.gemm_bf16(a.cuda(), w.cuda(), None, act=ops.ACT_MUL_GELU_GRAD)  # needs the saved pre-activation
@@ -559,7 +562,7 @@ def test_gemm_dual_output_matches_gemm_then_activation():
     from multimodal_amd import ops
 
     set_rng_seed(21)
-    for (M, N, K) in ((300, 256, 128), (50432, 768, 128), (19712, 2048, 512), (50432, 3072, 768), (20011, 776, 128)):
+    for (M, N, K) in ((300, 256, 128), (50432, 768, 128), (19712, 2048, 512), (50432, 3072, 768), (30011, 776, 128)):
         a = torch.randn(M, K).to(torch.bfloat16).cuda()
         w = (torch.randn(N, K) * 0.05).to(torch.bfloat16).cuda()
         b = torch.randn(N).cuda()
