@@ -1118,9 +1118,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel_pp(const Gemm
       const int mi = pass / NI, ni = pass - mi * NI;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
-        dst[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < p.M && n + 3 < p.N) dst[it] = load4(reinterpret_cast<const float*>(p.R) + r_row(m) * p.ldr + n);
+        // (unconditional, clamped: a predicated load is waited for at the branch join -- see gemm_epi_f32.inc; lanes past the edge never use the value)
+        int m = m0 + wm * TM + mi * 32 + it * 8 + rrow, n = nw0 + ni * 32 + rc;
+        m = m < p.M ? m : p.M - 1;
+        n = n + 3 < p.N ? n : 0;
+        dst[it] = load4(reinterpret_cast<const float*>(p.R) + r_row(m) * p.ldr + n);
       }
     };
     // the pipelined buffer-descriptor epilogue (gemm_epi_f32.inc, r06) serves the plain fp32 output of the 8-wave form; the patch-embedding
