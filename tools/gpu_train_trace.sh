@@ -14,10 +14,17 @@ def short(s):
     s=re.sub(r'^void ','',s); s=s.replace('mmamd::','')
     return s[:86]
 print(f"{n} kernels per step; step span {(int(last[-1]['End_Timestamp'])-t0)/1e6:.2f} ms")
+# per-queue occupancy over the window: busy time (union of its kernels) and the idle gaps between consecutive kernels of the SAME queue
+qs={}
+for r in last: qs.setdefault(r.get('Queue_Id','?'),[]).append((int(r['Start_Timestamp']),int(r['End_Timestamp'])))
+for q,iv in qs.items():
+    iv.sort(); busy=sum(e-s for s,e in iv); gaps=[iv[i+1][0]-iv[i][1] for i in range(len(iv)-1)]
+    big=sorted([g for g in gaps if g>0],reverse=True)[:5]
+    print(f"queue {q}: {len(iv)} kernels, busy {busy/1e6:.2f} ms, span {(iv[-1][1]-iv[0][0])/1e6:.2f} ms, idle inside {sum(g for g in gaps if g>0)/1e6:.2f} ms, largest gaps us {[round(g/1e3,1) for g in big]}")
 for r in last:
     s,e=int(r['Start_Timestamp']),int(r['End_Timestamp'])
     g=r.get('Grid_Size_X') or r.get('Grid_Size') or ''
-    print(f"{(s-t0)/1e3:9.1f} us  dur {(e-s)/1e3:7.1f}  gap {(s-prev)/1e3:6.1f}  grid {g:>8s}  {short(r['Kernel_Name'])}")
+    print(f"{(s-t0)/1e3:9.1f} us  dur {(e-s)/1e3:7.1f}  gap {(s-prev)/1e3:6.1f}  q {r.get('Queue_Id','?'):>2s}  grid {g:>8s}  {short(r['Kernel_Name'])}")
     prev=e
 PY
-head -3 $O/${1:-r06}_train_timeline.txt
+head -5 $O/${1:-r06}_train_timeline.txt
