@@ -94,7 +94,7 @@ __device__ __forceinline__ float rl_sum8(float v) {
   return v;
 }
 
-// ABL (timing experiments, results WRONG; mmamd_debug_set_gemm_knob(5, code)): 1 = no X / Y stores, 2 = no residual loads, 4 = no operand DMA, 8 = no fragment reads / MFMA
+// ABL (timing experiments, results WRONG; mmamd_debug_set_gemm_knob(5, code)): 1 = no X / Y stores, 2 = no residual loads, 4 = no operand DMA, 8 = no fragment reads / MFMA, 16 = K walk rotated per workgroup
 template <int ABL>
 __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -135,13 +135,20 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs g) {
   auto issue = [&]() -> int {  // DMA this wave's pieces of the cursor's stage; returns their number (0: nothing left)
     if (ij >= nmine) return 0;
     const uint32_t dst = lds0 + (uint32_t)(islot * kRlSlot);
-    const char* ws = i_w + (size_t)ik * i_wstep;
+    // ABL & 16 (experiment): every workgroup starts its K walk at a different step (the 32 CUs of an XCD otherwise sweep the SAME W slices through the
+    // same L2 channels at the same time); the accumulation order rotates with it, so X is no longer bit-identical to mmamd_gemm_bf16's
+    int ike = ik;
+    if constexpr ((ABL & 16) != 0) {
+      ike = ik + (int)(((blockIdx.x >> 3) * (unsigned)i_ks) >> 5);
+      ike = ike >= i_ks ? ike - i_ks : ike;
+    }
+    const char* ws = i_w + (size_t)ike * i_wstep;
     int n = i_pw;
 #pragma unroll
     for (int i = 0; i < kRlMaxN / 128; ++i)
       if (i < i_pw && (ABL & 4) == 0) rl_dma(ws + i * 1024, voff_w, dst + 4096u + (uint32_t)((wave * i_pw + i) * 1024));
     if (wave < 4) {
-      if constexpr ((ABL & 4) == 0) rl_dma(i_a + ik * 64, i_voff_a, dst + (uint32_t)(wave * 1024));
+      if constexpr ((ABL & 4) == 0) rl_dma(i_a + ike * 64, i_voff_a, dst + (uint32_t)(wave * 1024));
       ++n;
     }
     islot = islot + 1 == kRlSlots ? 0 : islot + 1;
@@ -387,7 +394,7 @@ extern "C" int mmamd_gemm_bf16_residual_ln_grouped(const mmamd_gemm_ln_problem* 
   const int cus = stream_cus(st);
   const int grid = a.tiles_total < cus ? a.tiles_total : cus;
   constexpr int smem = kRlSlots * kRlSlot;
-  static unsigned long long mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static unsigned long long mask[12] = {0};
 #define RL_LAUNCH(ABL, SLOT)                                                                           \
   do {                                                                                                  \
     if (int e = opt_in_lds((const void*)gemm_rowln_kernel<ABL>, smem, mask[SLOT])) return e;            \
@@ -402,6 +409,9 @@ extern "C" int mmamd_gemm_bf16_residual_ln_grouped(const mmamd_gemm_ln_problem* 
     case 8: RL_LAUNCH(8, 5); break;
     case 11: RL_LAUNCH(11, 6); break;
     case 7: RL_LAUNCH(7, 7); break;
+    case 16: RL_LAUNCH(16, 8); break;
+    case 27: RL_LAUNCH(27, 9); break;
+    case 19: RL_LAUNCH(19, 10); break;
     default: MMAMD_CHECK_ARG(false, MMAMD_E_BADARG, "gemm_bf16_residual_ln_grouped: unknown ablation %d", g_rowln_abl);
   }
 #undef RL_LAUNCH
