@@ -688,18 +688,35 @@ __global__ __launch_bounds__(256) void attention_x_kernel(const AttnX p) {
   const bf16* vb = p.v + (size_t)b * p.kv_bs + h * DH;
   const bf16* qb = p.q + (size_t)b * p.q_bs + h * DH;
 
-  for (int i = tid; i < SP * CPR; i += 256) {
-    const int r = i / CPR, c = i - r * CPR;
-    bf16x8 kv, vv;
+  // K / V staging: every 16-byte load of the item is issued before the first is stored to LDS, unconditionally on a clamped row (r06: the loop
+  // loaded inside `if (r < Sk)` and stored at once -- one exposed global round trip per trip, 8 to 14 of them in a row before any compute)
+  {
+    constexpr int NIT = (SP * CPR + 255) / 256;
+    bf16x8 kr[NIT], vr[NIT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
-    if (r < Sk) {
-      kv = *reinterpret_cast<const bf16x8*>(kb + (size_t)r * p.ldk + c * 8);
-      vv = *reinterpret_cast<const bf16x8*>(vb + (size_t)r * p.ldv + c * 8);
+    for (int it = 0; it < NIT; ++it) {
+      int i = tid + it * 256;
+      i = i < SP * CPR ? i : SP * CPR - 1;
+      const int r = i / CPR, c = i - r * CPR;
+      const int rc = r < Sk ? r : Sk - 1;
+      kr[it] = *reinterpret_cast<const bf16x8*>(kb + (size_t)rc * p.ldk + c * 8);
+      vr[it] = *reinterpret_cast<const bf16x8*>(vb + (size_t)rc * p.ldv + c * 8);
     }
-    *reinterpret_cast<bf16x8*>(Ks + r * KS + c * 8) = kv;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VS + r] = vv[j];
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * 256;
+      if (i < SP * CPR) {
+        const int r = i / CPR, c = i - r * CPR;
+        bf16x8 kv = kr[it], vv = vr[it];
+        if (r >= Sk) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+        }
+        *reinterpret_cast<bf16x8*>(Ks + r * KS + c * 8) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VS + r] = vv[j];
+      }
+    }
   }
   for (int k = tid; k < SP; k += 256)
     Mk[k] = (k < Sk && (p.key_mask == nullptr || p.key_mask[(size_t)b * Sk + k] != 0)) ? 0.f : -INFINITY;
@@ -728,7 +745,20 @@ __global__ __launch_bounds__(256) void attention_x_kernel(const AttnX p) {
       // full [Sq, Sk] mask: the 4 consecutive keys of a register group as ONE (unaligned) 32-bit load -- the byte-per-score form was 16 dependent global
       // loads per lane and tile in both passes (CoCa's padding-aware causal mask: 122 us average for the S = 77 decoder self-attention, r04)
       uint32_t fmw[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
-      if (fm != nullptr) {
+      if (fm != nullptr && Sk >= 4) {
+        // branch-free (r06): the word is loaded from a clamped key index and shifted, so that the four loads of a tile are straight-line code, issued
+        // together and waited for once -- inside the per-lane `key0 + 3 < Sk` branch each of them was waited for where it was issued
+        const uint8_t* row = fm + (size_t)qc * Sk;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int key0 = kt * 32 + 8 * g + 4 * half;
+          const int kc = key0 + 3 < Sk ? key0 : Sk - 4;
+          uint32_t w;
+          __builtin_memcpy(&w, row + kc, 4);
+          const int sh = key0 - kc;                      // 0 inside the row; 1..3 at its ragged end; >= 4 past it
+          fmw[g] = sh < 4 ? w >> (8 * sh) : 0u;          // keys >= Sk read as masked (Mk is -inf there anyway)
+        }
+      } else if (fm != nullptr) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int key0 = kt * 32 + 8 * g + 4 * half;
