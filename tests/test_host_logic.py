@@ -102,3 +102,19 @@ def test_persistent_gemm_tile_order_visits_every_tile_once():
     # the launchers' choices: wide GEMMs with a W above 3 MB are chunked (MLP-up 12 -> 6 + 6, qkv 9 -> 5 + 4), few-column / small-W ones are not
     pick = lambda tn, K: L.mmamd_debug_tile_order(4, tn, K, 0, 0, np.zeros((4 * tn, 2), dtype=np.int32).ctypes.data_as(C.c_void_p))  # noqa: E731
     assert pick(12, 768) == 6 and pick(9, 768) == 5 and pick(3, 3072) == 3 and pick(8, 512) == 8 and pick(3, 768) == 3
+
+
+def test_whole_row_gemm_layernorm_shape_gate_and_argument_checks():
+    """mmamd_gemm_bf16_residual_ln_supported / _grouped: the shape gate the schedules would consult, and the argument errors, without a GPU."""
+    from multimodal_amd import _lib
+
+    L = _lib.lib()
+    ok = L.mmamd_gemm_bf16_residual_ln_supported
+    assert ok(50432, 768, 768) == 1 and ok(19712, 512, 512) == 1 and ok(1, 768, 64 * 3) == 1
+    assert ok(128, 1024, 1024) == 0      # N: 512 or 768 only (a stage of W must fit a 48 KiB ring slot)
+    assert ok(128, 768, 48) == 0         # K: a multiple of 32, at least three stages
+    assert ok(0, 768, 768) == 0
+    assert ok(800000, 768, 768) == 0     # M N 4 bytes must stay below 2^31 (buffer-descriptor range)
+    assert L.mmamd_gemm_bf16_residual_ln_grouped(None, 1, None) == _lib.E_BADARG if hasattr(_lib, "E_BADARG") else L.mmamd_gemm_bf16_residual_ln_grouped(None, 1, None) < 0
+    assert L.mmamd_pack_w_ksteps(None, 768, 768, None, None) < 0
+    assert b"pack_w_ksteps" in L.mmamd_last_error()
