@@ -146,9 +146,12 @@ class FLAVAModel(PackedModeMixin, nn.Module):
         # over a 2B batch (the GEMMs see M = 2 B S rows: persistent 256 x 256 kernels at full rounds instead of 1.5 rounds / 128 x 128 tiles),
         # and the outputs are split back into the two TransformerOutputs as views.  Bit-identical to two passes (every kernel's per-row
         # arithmetic is independent of the row's position in the batch: tests/test_gpu_bench_size_parity.py; a patch mask of zeros blends
-        # nothing: csrc/rowops.hip::flava_image_embed_kernel).  Encoders with forward hooks, and training, keep the two calls.
-        batched = not training and get_schedule().flava_batched_passes
-        if (batched and get_schedule().flava_grouped and want_image and want_text and want_text_masked and image_patches_mask is not None
+        # nothing: csrc/rowops.hip::flava_image_embed_kernel).  Encoders with forward hooks keep the two calls.  Training takes the one pass too
+        # (schedule.flava_batched_train, r06): torch.cat / the slices are differentiable, every parameter then receives ONE gradient per step instead
+        # of two that autograd adds (399 small add launches per step), and the GEMMs run at M = 2 B S -- 80.2 -> 74.7 ms per step, gradients against
+        # the reference's autograd unchanged (tests/test_gpu_backward_kernels.py, both arrangements).
+        batched = get_schedule().flava_batched_passes and (not training or get_schedule().flava_batched_train)
+        if (batched and not training and get_schedule().flava_grouped and want_image and want_text and want_text_masked and image_patches_mask is not None
                 and self._groupable(image, text, text_masked, image_patches_mask)):
             return self._forward_grouped(image, text, image_patches_mask, text_masked, required_embedding, skip_unmasked_mm_encoder)
         ctx = torch.cuda.stream(side) if side is not None else _Null()

@@ -7,6 +7,7 @@ Every choice is between paths that compute the same function; the defaults are t
                                                   (auto: grouped only where it measured faster, _transformer.two_stacks_groupable)
     side_stream  True | False                     tower-agnostic path: second tower on a side stream (False = one stream)
     flava_batched_passes  True | False            FLAVA inference: the unmasked and the masked pass of a tower as ONE pass over a 2B batch
+    flava_batched_train   True | False            the same in TRAINING (each parameter then receives ONE gradient per step instead of two that autograd adds)
     train_side_stream  True | False               CLIP training step: the text tower's forward (and, through autograd, backward) on a side stream
                                                   (same kernels, bit-identical step; -1.3 ... -4 ms of 54 depending on the box)
 
@@ -41,6 +42,7 @@ class Schedule:
     two_tower: str = "auto"
     side_stream: bool = True
     flava_batched_passes: bool = True
+    flava_batched_train: bool = True
     train_side_stream: bool = True
     train_attentions: bool = True
     flava_grouped: bool = True

@@ -369,9 +369,23 @@ def test_cross_entropy_with_masked_minus_inf_logits():
         assert np.abs(host(g[:, :V]) - ref).max() <= tol + 1e-7
 
 
-def test_flava_full_pretraining_step_gradients_vs_reference_autograd(golden):
+@pytest.mark.parametrize("batched_train", [True, False])
+def test_flava_full_pretraining_step_gradients_vs_reference_autograd(golden, batched_train):
     """The whole FLAVA pre-training objective (ITM + MMM text/image heads + global contrastive; patch mask, padded text, ITM row
-    filter) in train mode: every parameter gradient of the model AND of the loss heads against the reference's torch autograd."""
+    filter) in train mode: every parameter gradient of the model AND of the loss heads against the reference's torch autograd -- with the
+    unmasked and the masked pass of each tower as ONE 2B pass (schedule.flava_batched_train, the default: every parameter receives one
+    gradient) and as the reference's two passes (autograd adds the two)."""
+    from multimodal_amd.schedule import get_schedule, set_schedule
+
+    prev = get_schedule().flava_batched_train
+    set_schedule(flava_batched_train=batched_train)
+    try:
+        _flava_pretraining_grads_vs_reference(golden)
+    finally:
+        set_schedule(flava_batched_train=prev)
+
+
+def _flava_pretraining_grads_vs_reference(golden):
     from multimodal_amd.models.flava.model import flava_model
     from multimodal_amd.modules.losses.flava import FLAVAPretrainingLoss
     from tests._util import fixture_sd

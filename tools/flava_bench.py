@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-loss", action="store_true")
     ap.add_argument("--train", action="store_true", help="training step: forward + pre-training loss + backward + SGD")
+    ap.add_argument("--two-pass-train", action="store_true", help="A/B arm: schedule.flava_batched_train = False -- the unmasked and the masked pass of a tower as the reference's two calls in training (default: one 2B pass)")
     ap.add_argument("--grouped", action="store_true", help="schedule.flava_grouped: image and text towers layer-locked with grouped launches")
     ap.add_argument("--no-attentions", action="store_true", help="schedule.flava_attentions = False: the forwards do not produce the attention probabilities (opt-out)")
     ap.add_argument("--probs-two-pass", action="store_true", help="A/B: unmasked attention probabilities from the two-pass kernel (debug variant 514) instead of flash + one pass")
@@ -47,6 +48,10 @@ def main():
         from multimodal_amd.schedule import set_schedule
 
         set_schedule(flava_grouped=True)
+    if a.two_pass_train:
+        from multimodal_amd.schedule import set_schedule
+
+        set_schedule(flava_batched_train=False)
     model = flava_model().to(dev)
     loss = FLAVAPretrainingLoss().to(dev)
     model, loss = (model.train(), loss.train()) if a.train else (model.eval(), loss.eval())
