@@ -900,12 +900,29 @@ class DecoderStackFn(torch.autograd.Function):
         x = x0.detach()
         x = x if x.is_contiguous() else x.contiguous()
         encb = ops.convert(enc.detach().contiguous(), bf) if enc is not None else None
+        # the bf16 operand copies of every Linear of the stack in one launch per 64 matrices (r06: one convert launch per weight and call before --
+        # 147 per CoCa step); the fused in-projections [Wq; Wk; Wv] / [Wk; Wv] are concatenated in fp32 first
+        mats, slot, off = [], [], 0
+        for li, L in enumerate(cfg.layers):
+            pr = [c32(t) for t in params[off:off + cfg.nparams(li)]]
+            off += cfg.nparams(li)
+            ent = {"qkv": len(mats), "o": len(mats) + 1}
+            mats += [torch.cat([pr[0], pr[2], pr[4]], 0), pr[6]]
+            if L["has_cross"]:
+                ent.update(cq=len(mats), ckv=len(mats) + 1, co=len(mats) + 2)
+                mats += [pr[10], torch.cat([pr[12], pr[14]], 0), pr[16]]
+            ff = pr[20:] if L["has_cross"] else pr[10:]
+            ent.update(w1=len(mats), w2=len(mats) + 1)
+            mats += [ff[0], ff[2]]
+            slot.append(ent)
+        wbf, _ = ops.pack_weights(mats, want_nt=True, want_tr=False)
         recs, off = [], 0
         for li, L in enumerate(cfg.layers):
             pr = [c32(t) for t in params[off:off + cfg.nparams(li)]]
             off += cfg.nparams(li)
             H, d = L["n_head"], x.shape[1]
             hd = d // H
+            Wb = {k: wbf[i] for k, i in slot[li].items()}
             qw, qb, kw, kb, vw, vb, ow, ob, g1, be1 = pr[:10]
             pd, sd = cfg.drop_p, cfg.seed  # ONE rate on every dropout site of a decoder layer (reference transformer.py:262-290)
             if L.get("post"):
@@ -915,24 +932,24 @@ class DecoderStackFn(torch.autograd.Function):
 
                 def branch(delta_in, w_o, b_o, res, s_):  # res + drop(delta_in W_o^T + b_o)
                     if pd > 0:
-                        return ops.dropout(ops.gemm_bf16(delta_in, ops.convert(w_o, bf), b_o, out_dtype=f32), pd, sd, s_, residual=res)
-                    return ops.gemm_bf16(delta_in, ops.convert(w_o, bf), b_o, residual=res, out_dtype=f32, out=torch.empty_like(res))
+                        return ops.dropout(ops.gemm_bf16(delta_in, w_o, b_o, out_dtype=f32), pd, sd, s_, residual=res)
+                    return ops.gemm_bf16(delta_in, w_o, b_o, residual=res, out_dtype=f32, out=torch.empty_like(res))
 
                 h1 = ops.convert(x, bf)
-                qkv = ops.gemm_bf16(h1, ops.convert(torch.cat([qw, kw, vw], 0), bf), torch.cat([qb, kb, vb], 0))
+                qkv = ops.gemm_bf16(h1, Wb["qkv"], torch.cat([qb, kb, vb], 0))
                 lse = torch.empty((B, H, S), dtype=f32, device=x.device)
                 att, _ = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, cfg.mask, lse=lse, drop=(pd, sd, site + 3))
-                a_raw = branch(att, ow, ob, x, site)
+                a_raw = branch(att, Wb["o"], ob, x, site)
                 a = ops.layernorm(a_raw, g1, be1, L["eps1"], out_dtype=f32)
                 rec = [x, h1, qkv, att, lse, a_raw, a]
                 if L["has_cross"]:
                     cqw, cqb, ckw, ckb, cvw, cvb, cow, cob, gc, bec = pr[10:20]
                     hc = ops.convert(a, bf)
-                    qc = ops.gemm_bf16(hc, ops.convert(cqw, bf), cqb)
-                    kvc = ops.gemm_bf16(encb, ops.convert(torch.cat([ckw, cvw], 0), bf), torch.cat([ckb, cvb], 0))
+                    qc = ops.gemm_bf16(hc, Wb["cq"], cqb)
+                    kvc = ops.gemm_bf16(encb, Wb["ckv"], torch.cat([ckb, cvb], 0))
                     lsec = torch.empty((B, H, S), dtype=f32, device=x.device)
                     attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, cfg.cross_mask, lse=lsec, drop=(pd, sd, site + 5))
-                    c_raw = branch(attc, cow, cob, a, site + 4)
+                    c_raw = branch(attc, Wb["co"], cob, a, site + 4)
                     a2 = ops.layernorm(c_raw, gc, bec, L["epsc"], out_dtype=f32)
                     rec += [hc, qc, kvc, attc, lsec, c_raw, a2]
                     ff = pr[20:]
@@ -941,35 +958,35 @@ class DecoderStackFn(torch.autograd.Function):
                     ff = pr[10:]
                 w1, b1, w2, b2, g2, be2 = ff
                 h2 = ops.convert(a2, bf)
-                u, g = ops.gemm_bf16_dual(h2, ops.convert(w1, bf), b1, L["act"])
+                u, g = ops.gemm_bf16_dual(h2, Wb["w1"], b1, L["act"])
                 if pd > 0:
                     ops.dropout(g, pd, sd, site + 1, out=g)
-                f_raw = branch(g, w2, b2, a2, site + 2)
+                f_raw = branch(g, Wb["w2"], b2, a2, site + 2)
                 x = ops.layernorm(f_raw, g2, be2, L["eps2"], out_dtype=f32)
                 rec += [h2, u, g, f_raw]
                 recs.append(rec)
                 continue
             h1 = ops.layernorm(x, g1, be1, L["eps1"], out_dtype=bf)
-            qkv = ops.gemm_bf16(h1, ops.convert(torch.cat([qw, kw, vw], 0), bf), torch.cat([qb, kb, vb], 0))
+            qkv = ops.gemm_bf16(h1, Wb["qkv"], torch.cat([qb, kb, vb], 0))
             lse = torch.empty((B, H, S), dtype=f32, device=x.device)
             att, _ = ops.attention_x_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, S, S, H, hd, cfg.mask, lse=lse,
                                          drop=(pd, sd, 16 * (cfg.layer0 + li) + 3))
             if pd > 0:
-                a = ops.dropout(ops.gemm_bf16(att, ops.convert(ow, bf), ob, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li), residual=x)
+                a = ops.dropout(ops.gemm_bf16(att, Wb["o"], ob, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li), residual=x)
             else:
-                a = ops.gemm_bf16(att, ops.convert(ow, bf), ob, residual=x, out_dtype=f32, out=torch.empty_like(x))
+                a = ops.gemm_bf16(att, Wb["o"], ob, residual=x, out_dtype=f32, out=torch.empty_like(x))
             rec = [x, h1, qkv, att, lse, a]
             if L["has_cross"]:
                 cqw, cqb, ckw, ckb, cvw, cvb, cow, cob, gc, bec = pr[10:20]
                 hc = ops.layernorm(a, gc, bec, L["epsc"], out_dtype=bf)
-                qc = ops.gemm_bf16(hc, ops.convert(cqw, bf), cqb)
-                kvc = ops.gemm_bf16(encb, ops.convert(torch.cat([ckw, cvw], 0), bf), torch.cat([ckb, cvb], 0))
+                qc = ops.gemm_bf16(hc, Wb["cq"], cqb)
+                kvc = ops.gemm_bf16(encb, Wb["ckv"], torch.cat([ckb, cvb], 0))
                 lsec = torch.empty((B, H, S), dtype=f32, device=x.device)
                 attc, _ = ops.attention_x_fwd(qc, kvc[:, :d], kvc[:, d:], B, S, Sk, H, hd, cfg.cross_mask, lse=lsec, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
                 if pd > 0:
-                    a2 = ops.dropout(ops.gemm_bf16(attc, ops.convert(cow, bf), cob, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li) + 4, residual=a)
+                    a2 = ops.dropout(ops.gemm_bf16(attc, Wb["co"], cob, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li) + 4, residual=a)
                 else:
-                    a2 = ops.gemm_bf16(attc, ops.convert(cow, bf), cob, residual=a, out_dtype=f32, out=torch.empty_like(x))
+                    a2 = ops.gemm_bf16(attc, Wb["co"], cob, residual=a, out_dtype=f32, out=torch.empty_like(x))
                 rec += [hc, qc, kvc, attc, lsec, a2]
                 ff = pr[20:]
             else:
@@ -977,12 +994,12 @@ class DecoderStackFn(torch.autograd.Function):
                 ff = pr[10:]
             w1, b1, w2, b2, g2, be2 = ff
             h2 = ops.layernorm(a2, g2, be2, L["eps2"], out_dtype=bf)
-            u, g = ops.gemm_bf16_dual(h2, ops.convert(w1, bf), b1, L["act"])
+            u, g = ops.gemm_bf16_dual(h2, Wb["w1"], b1, L["act"])
             if pd > 0:
                 ops.dropout(g, pd, sd, 16 * (cfg.layer0 + li) + 1, out=g)
-                x_out = ops.dropout(ops.gemm_bf16(g, ops.convert(w2, bf), b2, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li) + 2, residual=a2)
+                x_out = ops.dropout(ops.gemm_bf16(g, Wb["w2"], b2, out_dtype=f32), pd, sd, 16 * (cfg.layer0 + li) + 2, residual=a2)
             else:
-                x_out = ops.gemm_bf16(g, ops.convert(w2, bf), b2, residual=a2, out_dtype=f32, out=torch.empty_like(x))
+                x_out = ops.gemm_bf16(g, Wb["w2"], b2, residual=a2, out_dtype=f32, out=torch.empty_like(x))
             rec += [h2, u, g]
             recs.append(rec)
             x = x_out
@@ -1013,10 +1030,27 @@ class DecoderStackFn(torch.autograd.Function):
             o += cfg.nparams(li)
         dXb = None
         pending = _pending()  # parked LayerNorm-backward reductions: one launch at the end (ops.colsum_flush)
+        # the bf16 TRANSPOSES the dgrad GEMMs read (dX = dY . W as an NT GEMM against W^T), every Linear of the stack in one launch per 64 matrices
+        # (r06: one transpose launch per dgrad before -- 171 per CoCa step, 4.4 ms)
+        mats, tslot = [], []
+        for li, L in enumerate(cfg.layers):
+            pr = [c32(t) for t in params[offs[li]:offs[li] + cfg.nparams(li)]]
+            ent = {"q": len(mats), "kv": len(mats) + 1, "o": len(mats) + 2}
+            mats += [pr[0], torch.cat([pr[2], pr[4]], 0), pr[6]]
+            if L["has_cross"]:
+                ent.update(cq=len(mats), ckv=len(mats) + 1, co=len(mats) + 2)
+                mats += [pr[10], torch.cat([pr[12], pr[14]], 0), pr[16]]
+            ff = pr[20:] if L["has_cross"] else pr[10:]
+            ent.update(w1=len(mats), w2=len(mats) + 1)
+            mats += [ff[0], ff[2]]
+            tslot.append(ent)
+        _, wtr = ops.pack_weights(mats, want_nt=False, want_tr=True)
         for li in reversed(range(len(cfg.layers))):
             L, rec = cfg.layers[li], recs[li]
             pr = [c32(t) for t in params[offs[li]:offs[li] + cfg.nparams(li)]]
             H = L["n_head"]
+            WT = {k: wtr[i] for k, i in tslot[li].items()}
+            J = {}  # the layer's weight-gradient jobs (dY, X), run as ONE grouped split-K launch + one reduce at the end of the layer (r06; eight launch pairs before)
             qw, qb, kw, kb, vw, vb, ow, ob, g1, be1 = pr[:10]
             d = qw.shape[0]
             hd = d // H
@@ -1029,47 +1063,48 @@ class DecoderStackFn(torch.autograd.Function):
                 d_f, dg2, dbe2, d_fb = ops.layernorm_bwd(f_raw, g2, dX, L["eps2"], want_bf16=True, defer=pending)
                 if pd > 0:
                     d_fb = ops.dropout(d_f, pd, sd, site + 2, out_dtype=bf)
-                du = dgrad(d_fb, w2, bf, _ACT_GRAD[L["act"]], u)
+                du = dgrad_t(d_fb, WT["w2"], bf, _ACT_GRAD[L["act"]], u)
                 if pd > 0:
                     ops.dropout(du, pd, sd, site + 1, out=du)
-                dW2, db2 = wgrad(d_fb, g, bias=True)
-                d_a2 = dgrad(du, w1, f32, ops.ACT_NONE, d_f)  # d_f + du W1: a2 feeds the MLP and the residual
-                dW1, db1 = wgrad(du, h2, bias=True)
+                J["w2"] = (d_fb, g)
+                d_a2 = dgrad_t(du, WT["w1"], f32, ops.ACT_NONE, d_f)  # d_f + du W1: a2 feeds the MLP and the residual
+                J["w1"] = (du, h2)
                 if L["has_cross"]:
                     cqw, cqb, ckw, ckb, cvw, cvb, cow, cob, gc, bec = pr[10:20]
                     hc, qc, kvc, attc, lsec, c_raw, _a2 = rec[7:14]
                     d_c, dgc, dbec, d_cb = ops.layernorm_bwd(c_raw, gc, d_a2, L["epsc"], want_bf16=True, defer=pending)
                     if pd > 0:
                         d_cb = ops.dropout(d_c, pd, sd, site + 4, out_dtype=bf)
-                    dattc = dgrad(d_cb, cow, bf)
-                    dWco, dbco = wgrad(d_cb, attc, bias=True)
+                    dattc = dgrad_t(d_cb, WT["co"], bf)
+                    J["co"] = (d_cb, attc)
                     dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, cfg.cross_mask, drop=(pd, sd, site + 5))
-                    d_a = dgrad(dqc, cqw, f32, ops.ACT_NONE, d_c)  # d_c + dqc Wq
-                    dWcq, dbcq = wgrad(dqc, hc, bias=True)
-                    wckv = torch.cat([ckw, cvw], 0)
-                    de = dgrad(dkvc, wckv, f32)
-                    d_enc = de if d_enc is None else ops.gemm_bf16(dkvc, ops.transpose_to_bf16(wckv, pad_to=64), None, residual=d_enc,
-                                                                   out_dtype=f32, out=d_enc)
-                    dWckv, dbckv = wgrad(dkvc, encb, bias=True)
-                    gl[10:20] = [dWcq, dbcq, dWckv[:d], dbckv[:d], dWckv[d:], dbckv[d:], dWco, dbco, dgc, dbec]
-                    gl[20:] = [dW1, db1, dW2, db2, dg2, dbe2]
+                    d_a = dgrad_t(dqc, WT["cq"], f32, ops.ACT_NONE, d_c)  # d_c + dqc Wq
+                    J["cq"] = (dqc, hc)
+                    d_enc = dgrad_t(dkvc, WT["ckv"], f32) if d_enc is None else ops.gemm_bf16(dkvc, WT["ckv"], None, residual=d_enc, out_dtype=f32, out=d_enc)
+                    J["ckv"] = (dkvc, encb)
                 else:
                     d_a = d_a2
-                    gl[10:] = [dW1, db1, dW2, db2, dg2, dbe2]
                 x, h1, qkv, att, lse, a_raw, _a = rec[:7]
                 d_ar, dg1, dbe1, d_arb = ops.layernorm_bwd(a_raw, g1, d_a, L["eps1"], want_bf16=True, defer=pending)
                 if pd > 0:
                     d_arb = ops.dropout(d_ar, pd, sd, site, out_dtype=bf)
-                datt = dgrad(d_arb, ow, bf)
-                dWo, dbo = wgrad(d_arb, att, bias=True)
+                datt = dgrad_t(d_arb, WT["o"], bf)
+                J["o"] = (d_arb, att)
                 dq, dkv = ops.attention_x_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, datt, lse, B, S, S, H, hd, cfg.mask,
                                               drop=(pd, sd, site + 3))
-                wqkv = torch.cat([qw, kw, vw], 0)
-                dh1 = dgrad(dq, qw, f32, ops.ACT_NONE, d_ar)  # d_ar + dq Wq + [dk | dv] [Wk; Wv]: x feeds the attention and the residual
-                dh1 = ops.gemm_bf16(dkv, ops.transpose_to_bf16(wqkv[d:], pad_to=64), None, residual=dh1, out_dtype=f32, out=dh1)
-                dWq, dbq = wgrad(dq, h1, bias=True)
-                dWkv, dbkv = wgrad(dkv, h1, bias=True)
+                dh1 = dgrad_t(dq, WT["q"], f32, ops.ACT_NONE, d_ar)  # d_ar + dq Wq + [dk | dv] [Wk; Wv]: x feeds the attention and the residual
+                dh1 = ops.gemm_bf16(dkv, WT["kv"], None, residual=dh1, out_dtype=f32, out=dh1)
+                J["q"] = (dq, h1)
+                J["kv"] = (dkv, h1)
+                G = dict(zip(J.keys(), wgrad_many([(dy_, x_, True) for dy_, x_ in J.values()])))
+                (dWq, dbq), (dWkv, dbkv), (dWo, dbo), (dW1, db1), (dW2, db2) = G["q"], G["kv"], G["o"], G["w1"], G["w2"]
                 gl[:10] = [dWq, dbq, dWkv[:d], dbkv[:d], dWkv[d:], dbkv[d:], dWo, dbo, dg1, dbe1]
+                if L["has_cross"]:
+                    (dWcq, dbcq), (dWckv, dbckv), (dWco, dbco) = G["cq"], G["ckv"], G["co"]
+                    gl[10:20] = [dWcq, dbcq, dWckv[:d], dbckv[:d], dWckv[d:], dbckv[d:], dWco, dbco, dgc, dbec]
+                    gl[20:] = [dW1, db1, dW2, db2, dg2, dbe2]
+                else:
+                    gl[10:] = [dW1, db1, dW2, db2, dg2, dbe2]
                 grads[offs[li]:offs[li] + cfg.nparams(li)] = gl
                 dX, dXb = dh1, None
                 continue
@@ -1088,47 +1123,48 @@ class DecoderStackFn(torch.autograd.Function):
                 dXb = ops.dropout(dX, pd, sd, 16 * (cfg.layer0 + li) + 2, out_dtype=bf)
             elif dXb is None:
                 dXb = ops.convert(dX, bf)
-            du = dgrad(dXb, w2, bf, _ACT_GRAD[L["act"]], u)
+            du = dgrad_t(dXb, WT["w2"], bf, _ACT_GRAD[L["act"]], u)
             if pd > 0:
                 ops.dropout(du, pd, sd, 16 * (cfg.layer0 + li) + 1, out=du)
-            dW2, db2 = wgrad(dXb, g, bias=True)
-            dh2 = dgrad(du, w1, f32)
-            dW1, db1 = wgrad(du, h2, bias=True)
+            J["w2"] = (dXb, g)
+            dh2 = dgrad_t(du, WT["w1"], f32)
+            J["w1"] = (du, h2)
             d_a2, dg2, dbe2, d_a2b = ops.layernorm_bwd(a2, g2, dh2, L["eps2"], add=dX, want_bf16=True, defer=pending)
             gl = [None] * cfg.nparams(li)
             if L["has_cross"]:
                 if pd > 0:
                     d_a2b = ops.dropout(d_a2, pd, sd, 16 * (cfg.layer0 + li) + 4, out_dtype=bf)
-                dattc = dgrad(d_a2b, cow, bf)
-                dWco, dbco = wgrad(d_a2b, attc, bias=True)
+                dattc = dgrad_t(d_a2b, WT["co"], bf)
+                J["co"] = (d_a2b, attc)
                 dqc, dkvc = ops.attention_x_bwd(qc, kvc[:, :d], kvc[:, d:], attc, dattc, lsec, B, S, Sk, H, hd, cfg.cross_mask, drop=(pd, sd, 16 * (cfg.layer0 + li) + 5))
-                dhc = dgrad(dqc, cqw, f32)
-                dWcq, dbcq = wgrad(dqc, hc, bias=True)
-                wckv = torch.cat([ckw, cvw], 0)
-                de = dgrad(dkvc, wckv, f32)
-                d_enc = de if d_enc is None else ops.gemm_bf16(dkvc, ops.transpose_to_bf16(wckv, pad_to=64), None, residual=d_enc,
-                                                               out_dtype=f32, out=d_enc)
-                dWckv, dbckv = wgrad(dkvc, encb, bias=True)
+                dhc = dgrad_t(dqc, WT["cq"], f32)
+                J["cq"] = (dqc, hc)
+                d_enc = dgrad_t(dkvc, WT["ckv"], f32) if d_enc is None else ops.gemm_bf16(dkvc, WT["ckv"], None, residual=d_enc, out_dtype=f32, out=d_enc)
+                J["ckv"] = (dkvc, encb)
                 d_a, dgc, dbec, d_ab = ops.layernorm_bwd(a, gc, dhc, L["epsc"], add=d_a2, want_bf16=True, defer=pending)
+            else:
+                d_a, d_ab = d_a2, d_a2b
+            if pd > 0:
+                d_ab = ops.dropout(d_a, pd, sd, 16 * (cfg.layer0 + li), out_dtype=bf)
+            datt = dgrad_t(d_ab, WT["o"], bf)
+            J["o"] = (d_ab, att)
+            dq, dkv = ops.attention_x_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, datt, lse, B, S, S, H, hd, cfg.mask,
+                                          drop=(pd, sd, 16 * (cfg.layer0 + li) + 3))
+            # dh1 = dq Wq + [dk | dv] [Wk; Wv]: two GEMMs, the second accumulates onto the first
+            dh1 = dgrad_t(dq, WT["q"], f32)
+            dh1 = ops.gemm_bf16(dkv, WT["kv"], None, residual=dh1, out_dtype=f32, out=dh1)
+            J["q"] = (dq, h1)
+            J["kv"] = (dkv, h1)
+            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, L["eps1"], add=d_a, want_bf16=True, defer=pending)
+            G = dict(zip(J.keys(), wgrad_many([(dy_, x_, True) for dy_, x_ in J.values()])))
+            (dWq, dbq), (dWkv, dbkv), (dWo, dbo), (dW1, db1), (dW2, db2) = G["q"], G["kv"], G["o"], G["w1"], G["w2"]
+            gl[:10] = [dWq, dbq, dWkv[:d], dbkv[:d], dWkv[d:], dbkv[d:], dWo, dbo, dg1, dbe1]
+            if L["has_cross"]:
+                (dWcq, dbcq), (dWckv, dbckv), (dWco, dbco) = G["cq"], G["ckv"], G["co"]
                 gl[10:20] = [dWcq, dbcq, dWckv[:d], dbckv[:d], dWckv[d:], dbckv[d:], dWco, dbco, dgc, dbec]
                 gl[20:] = [dW1, db1, dW2, db2, dg2, dbe2]
             else:
-                d_a, d_ab = d_a2, d_a2b
                 gl[10:] = [dW1, db1, dW2, db2, dg2, dbe2]
-            if pd > 0:
-                d_ab = ops.dropout(d_a, pd, sd, 16 * (cfg.layer0 + li), out_dtype=bf)
-            datt = dgrad(d_ab, ow, bf)
-            dWo, dbo = wgrad(d_ab, att, bias=True)
-            dq, dkv = ops.attention_x_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], att, datt, lse, B, S, S, H, hd, cfg.mask,
-                                          drop=(pd, sd, 16 * (cfg.layer0 + li) + 3))
-            wqkv = torch.cat([qw, kw, vw], 0)
-            # dh1 = dq Wq + [dk | dv] [Wk; Wv]: two GEMMs, the second accumulates onto the first
-            dh1 = dgrad(dq, qw, f32)
-            dh1 = ops.gemm_bf16(dkv, ops.transpose_to_bf16(wqkv[d:], pad_to=64), None, residual=dh1, out_dtype=f32, out=dh1)
-            dWq, dbq = wgrad(dq, h1, bias=True)
-            dWkv, dbkv = wgrad(dkv, h1, bias=True)
-            dX, dg1, dbe1, dXb = ops.layernorm_bwd(x, g1, dh1, L["eps1"], add=d_a, want_bf16=True, defer=pending)
-            gl[:10] = [dWq, dbq, dWkv[:d], dbkv[:d], dWkv[d:], dbkv[d:], dWo, dbo, dg1, dbe1]
             grads[offs[li]:offs[li] + cfg.nparams(li)] = gl
         ops.colsum_flush(pending)
         return (dX, d_enc, None, *grads)
