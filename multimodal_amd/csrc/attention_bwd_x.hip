@@ -47,19 +47,35 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dq_kernel(const AttnXB p)
   const bf16* kb = p.k + (size_t)b * p.kv_bs + h * DH;
   const bf16* vb = p.v + (size_t)b * p.kv_bs + h * DH;
   const bf16* qb = p.q + (size_t)b * p.q_bs + h * DH;
-  for (int i = tid; i < SP * CPR; i += 256) {
-    const int r = i / CPR, c = i - r * CPR;
-    bf16x8 kv, vv;
+  // K / V staging, four trips at a time: the eight 16-byte loads of a group are issued together, unconditionally on clamped rows, then stored (r06: a
+  // load inside `if (r < Sk)` followed by its stores was one exposed global round trip per trip -- eight in a row at Sk = 256 before any compute)
+  for (int i0 = tid; i0 < SP * CPR; i0 += 4 * 256) {
+    bf16x8 kr[4], vr[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
-    if (r < Sk) {
-      kv = *reinterpret_cast<const bf16x8*>(kb + (size_t)r * p.ldk + c * 8);
-      vv = *reinterpret_cast<const bf16x8*>(vb + (size_t)r * p.ldv + c * 8);
+    for (int u = 0; u < 4; ++u) {
+      int i = i0 + u * 256;
+      i = i < SP * CPR ? i : SP * CPR - 1;
+      const int r = i / CPR, c = i - r * CPR;
+      const int rc = r < Sk ? r : Sk - 1;
+      kr[u] = *reinterpret_cast<const bf16x8*>(kb + (size_t)rc * p.ldk + c * 8);
+      vr[u] = *reinterpret_cast<const bf16x8*>(vb + (size_t)rc * p.ldv + c * 8);
     }
-    *reinterpret_cast<bf16x8*>(Ks + r * KS + c * 8) = kv;
-    *reinterpret_cast<bf16x8*>(Vs + r * KS + c * 8) = vv;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VS + r] = kv[j];
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      if (i < SP * CPR) {
+        const int r = i / CPR, c = i - r * CPR;
+        bf16x8 kv = kr[u], vv = vr[u];
+        if (r >= Sk) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { kv[j] = (bf16)0.f; vv[j] = (bf16)0.f; }
+        }
+        *reinterpret_cast<bf16x8*>(Ks + r * KS + c * 8) = kv;
+        *reinterpret_cast<bf16x8*>(Vs + r * KS + c * 8) = vv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VS + r] = kv[j];
+      }
+    }
   }
   for (int k = tid; k < SP; k += 256) Mk[k] = (k < Sk && (p.key_mask == nullptr || p.key_mask[(size_t)b * Sk + k] != 0)) ? 1 : 0;
   __syncthreads();
@@ -194,6 +210,52 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p
   const float c2 = p.scale * 1.4426950408889634f;
   const int nkt = (Sk + 31) >> 5, nchunk = (Sq + QC - 1) / QC;
   const uint8_t* fm = p.full_mask ? p.full_mask + (size_t)b * p.fm_bs : nullptr;
+  // Q / dO (row-major and transposed images), D = rowsum(dO * O) and the log-sum-exp of one chunk of <= 128 queries -> LDS.  Two trips at a time: the six
+  // 16-byte loads of a pair are issued together, unconditionally on clamped rows, before the first store (r06: the predicated form paid one exposed global
+  // round trip per trip, and the cross-attention's second round of key tiles staged the same chunk again)
+  auto stage_chunk = [&](int qbase) __attribute__((always_inline)) {
+    __syncthreads();  // the previous chunk (or round) is consumed
+    for (int i = tid; i < QC; i += 256) { L2s[i] = INFINITY; Dqs[i] = 0.f; }
+    __syncthreads();
+    constexpr int NTRIP = QC * CPR / 256;
+    static_assert(QC * CPR % 256 == 0 && NTRIP % 2 == 0, "chunk staging: whole pairs of trips");
+#pragma unroll
+    for (int t0 = 0; t0 < NTRIP; t0 += 2) {
+      bf16x8 qr[2], dr[2], orr[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = tid + (t0 + u) * 256;
+        const int r = i / CPR, c = i - r * CPR;
+        const int q = qbase + r < Sq ? qbase + r : Sq - 1;
+        qr[u] = *reinterpret_cast<const bf16x8*>(qb + (size_t)q * p.ldq + c * 8);
+        dr[u] = *reinterpret_cast<const bf16x8*>(p.dO + ((size_t)b * Sq + q) * p.ldo + h * DH + c * 8);
+        orr[u] = *reinterpret_cast<const bf16x8*>(p.O + ((size_t)b * Sq + q) * p.ldo + h * DH + c * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = tid + (t0 + u) * 256;
+        const int r = i / CPR, c = i - r * CPR;
+        const int q = qbase + r;
+        bf16x8 qv = qr[u], dv = dr[u], ov = orr[u];
+        if (q >= Sq) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { qv[j] = (bf16)0.f; dv[j] = (bf16)0.f; ov[j] = (bf16)0.f; }
+        }
+        *reinterpret_cast<bf16x8*>(Qs + r * KS + c * 8) = qv;
+        *reinterpret_cast<bf16x8*>(dOs + r * KS + c * 8) = dv;
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          Qt[(c * 8 + j) * QVS + r] = qv[j];
+          dOt[(c * 8 + j) * QVS + r] = dv[j];
+          part += (float)dv[j] * (float)ov[j];
+        }
+        if (q < Sq) atomicAdd(&Dqs[r], part);  // the CPR chunks of a row are not one aligned lane group when CPR = 12: LDS atomics
+        if (c == 0 && q < Sq) L2s[r] = p.lse[((size_t)b * p.H + h) * Sq + q];
+      }
+    }
+    __syncthreads();
+  };
   for (int r0 = 0; r0 < nkt; r0 += 4) {
     const int kt = r0 + wave;
     const bool active = kt < nkt;
@@ -214,33 +276,7 @@ __global__ __launch_bounds__(256) void attention_x_bwd_dkv_kernel(const AttnXB p
 #pragma unroll 1
     for (int ch = 0; ch < nchunk; ++ch) {
       const int qbase = ch * QC;
-      __syncthreads();  // the previous chunk (or round) is consumed
-      for (int i = tid; i < QC; i += 256) { L2s[i] = INFINITY; Dqs[i] = 0.f; }
-      __syncthreads();
-      for (int i = tid; i < QC * CPR; i += 256) {
-        const int r = i / CPR, c = i - r * CPR;
-        const int q = qbase + r;
-        bf16x8 qv, dv, ov;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { qv[j] = (bf16)0.f; dv[j] = (bf16)0.f; ov[j] = (bf16)0.f; }
-        if (q < Sq) {
-          qv = *reinterpret_cast<const bf16x8*>(qb + (size_t)q * p.ldq + c * 8);
-          dv = *reinterpret_cast<const bf16x8*>(p.dO + ((size_t)b * Sq + q) * p.ldo + h * DH + c * 8);
-          ov = *reinterpret_cast<const bf16x8*>(p.O + ((size_t)b * Sq + q) * p.ldo + h * DH + c * 8);
-        }
-        *reinterpret_cast<bf16x8*>(Qs + r * KS + c * 8) = qv;
-        *reinterpret_cast<bf16x8*>(dOs + r * KS + c * 8) = dv;
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          Qt[(c * 8 + j) * QVS + r] = qv[j];
-          dOt[(c * 8 + j) * QVS + r] = dv[j];
-          part += (float)dv[j] * (float)ov[j];
-        }
-        if (q < Sq) atomicAdd(&Dqs[r], part);  // the CPR chunks of a row are not one aligned lane group when CPR = 12: LDS atomics
-        if (c == 0 && q < Sq) L2s[r] = p.lse[((size_t)b * p.H + h) * Sq + q];
-      }
-      __syncthreads();
+      if (nchunk > 1 || r0 == 0) stage_chunk(qbase);  // one chunk (Sq <= 128): staged once, every round of key tiles reads the same images
       if (active) {
         const int nq_here = (Sq - qbase) < QC ? (Sq - qbase) : QC;
         const int nqt = (nq_here + 31) >> 5;
